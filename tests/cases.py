@@ -1,0 +1,82 @@
+"""Seed-generated parity cases shared by the golden generator (tests/golden/make_golden.py) and the tests.
+
+A case spec is a small dict; ``build_case(spec)`` regenerates its inputs (beta slices per sample + loci) from
+the seed, so fixtures store only the spec, an input checksum and the expected borders.
+"""
+import numpy as np
+
+from wgbs_tools_amd import synth
+
+SEED = 20260926
+
+
+def _loci_for(spec):
+    kind = spec.get('loci', 'hg19like')
+    n, a = spec['n'], spec['a']
+    if kind == 'hg19like':
+        # one long synthetic chromosome; take [a, a+n)
+        total = a + n
+        loci = synth.synth_loci(spec.get('loci_seed', SEED), [total])
+        return loci[a:a + n].copy()
+    if kind == 'dense':
+        # CpG-island-like: gaps 2..9 bp -> hundreds of CpGs inside max_bp
+        idx = np.arange(a, a + n, dtype=np.int64)
+        gap = 2 + (synth.hash_at(spec.get('loci_seed', SEED), 77, idx) & np.uint64(7)).astype(np.int64)
+        return (10000 + np.cumsum(gap)).astype(np.uint32)
+    if kind == 'equal_runs':
+        # repeated positions (distance 0) -- legal for the reference: dists[i+j]-dists[i] == 0 <= max_bp
+        idx = np.arange(a, a + n, dtype=np.int64)
+        gap = (synth.hash_at(spec.get('loci_seed', SEED), 78, idx) & np.uint64(3)).astype(np.int64) * 60
+        return (10000 + np.cumsum(gap)).astype(np.uint32)
+    raise ValueError(kind)
+
+
+def build_case(spec):
+    """-> (slices: list of uint8 [n,2] per sample, loci uint32[n])"""
+    n, a = spec['n'], spec['a']
+    seed = spec.get('seed', SEED)
+    slices = [synth.synth_betas(seed, s, a, a + n) for s in spec['samples']]
+    for (s_idx, x0, x1) in spec.get('zero_ranges', []):       # zero-coverage stretches in one sample
+        slices[s_idx][x0:x1, :] = 0
+    for s_idx in spec.get('zero_samples', []):                # an all-zero sample
+        slices[s_idx][:, :] = 0
+    for (s_idx, x0, x1) in spec.get('saturate_ranges', []):   # 255/255 sites
+        slices[s_idx][x0:x1, :] = 255
+    loci = _loci_for(spec)
+    return slices, loci
+
+
+def case_checksum(slices, loci):
+    return synth.checksum(loci, *slices)
+
+
+# name -> spec.  pcount/max_cpg/max_bp are the segmentor's own flags (main.cpp:44-48,69-84).
+CHUNK_CASES = {
+    'tiny':           dict(n=400, a=1000, samples=[0, 1, 2], pcount=15.0, max_cpg=50, max_bp=700),
+    'n1':             dict(n=1, a=5, samples=[0, 1], pcount=15.0, max_cpg=1000, max_bp=2000),
+    'n2':             dict(n=2, a=5, samples=[0], pcount=15.0, max_cpg=1000, max_bp=2000),
+    'n65':            dict(n=65, a=50, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=2000),
+    'max_cpg2':       dict(n=500, a=300, samples=[0, 1], pcount=15.0, max_cpg=2, max_bp=2000),
+    'max_cpg_binds':  dict(n=3000, a=7000, samples=[0, 1, 2, 3], pcount=15.0, max_cpg=10, max_bp=2000),
+    'pcount0':        dict(n=3000, a=20000, samples=[0, 1, 2, 3], pcount=0.0, max_cpg=1000, max_bp=2000),
+    'pcount_half':    dict(n=3000, a=20000, samples=[0, 1, 2, 3], pcount=0.5, max_cpg=1000, max_bp=2000),
+    'pcount15':       dict(n=3000, a=20000, samples=[0, 1, 2, 3], pcount=15.0, max_cpg=1000, max_bp=2000),
+    'zero_stretch':   dict(n=4000, a=40000, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=2000,
+                           zero_ranges=[(0, 500, 900), (1, 0, 130), (2, 3900, 4000), (0, 2000, 2001)]),
+    'zero_sample':    dict(n=3000, a=50000, samples=[0, 1, 2, 3], pcount=15.0, max_cpg=1000, max_bp=2000,
+                           zero_samples=[2]),
+    'all_zero':       dict(n=700, a=50000, samples=[0, 1], pcount=15.0, max_cpg=1000, max_bp=2000,
+                           zero_samples=[0, 1]),
+    'saturated':      dict(n=2500, a=60000, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=2000,
+                           saturate_ranges=[(0, 100, 1400), (1, 0, 2500)]),
+    'single_sample':  dict(n=5000, a=90000, samples=[5], pcount=15.0, max_cpg=1000, max_bp=2000),
+    'dense_w_gt_64':  dict(n=3000, a=0, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=2000, loci='dense'),
+    'dense_small_bp': dict(n=3000, a=0, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=300, loci='dense'),
+    'equal_loci':     dict(n=1500, a=0, samples=[0, 1], pcount=15.0, max_cpg=1000, max_bp=2000, loci='equal_runs'),
+    'deep':           dict(n=6000, a=120000, samples=[0, 1, 2, 3], pcount=15.0, max_cpg=5000, max_bp=100000000),
+    'n33_samples':    dict(n=2000, a=130000, samples=list(range(33)), pcount=15.0, max_cpg=1000, max_bp=2000),
+    'default_chunk':  dict(n=60000, a=200000, samples=list(range(8)), pcount=15.0, max_cpg=1000, max_bp=2000),
+}
+
+# chr21-shaped multi-chunk case (BASELINE.json configs[1]): 400,000 CpGs x 8 samples in default 60,000-site chunks
+CHR21 = dict(n=400000, a=0, samples=list(range(8)), pcount=15.0, max_cpg=1000, max_bp=2000, chunk=60000)

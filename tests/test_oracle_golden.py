@@ -1,0 +1,68 @@
+"""Pin the oracle: our C restatement (oracle/segment_oracle.c) must reproduce, bit for bit, the border lists the
+reference's own `segmentor` printed on the same seeded inputs (tests/golden/chunk_cases.json, captured by
+tests/golden/make_golden.py from oracle/_ref/segmentor).  When the reference binary is present (build container
+and, as a prebuilt file, the GPU box) it is also re-run live."""
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle
+
+SMALL = [k for k in cases.CHUNK_CASES]
+
+
+@pytest.mark.parametrize('name', SMALL)
+def test_restatement_matches_reference_golden(name, golden_chunks):
+    g = golden_chunks[name]
+    spec = g['spec']
+    slices, loci = cases.build_case(spec)
+    assert cases.case_checksum(slices, loci) == g['input_crc32'], 'synthetic input generator drifted'
+    b = oracle.segment_chunk(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp'])
+    assert b.tolist() == g['borders']
+    # format contract of print_borders (segmentor.cpp:30-34): ascending, starts at 0, ends at n
+    assert b[0] == 0 and b[-1] == spec['n'] and (np.diff(b) > 0).all()
+
+
+def test_chr21_multichunk_matches_reference_golden(golden_chunks):
+    g = golden_chunks['chr21']
+    spec = g['spec']
+    slices, loci = cases.build_case(spec)
+    assert cases.case_checksum(slices, loci) == g['input_crc32']
+    starts = np.array(g['starts'], dtype=np.int64)
+    lens = np.minimum(spec['chunk'], spec['n'] - starts).astype(np.int32)
+    res = oracle.segment_chunks(slices, loci, starts, lens, spec['pcount'], spec['max_cpg'], spec['max_bp'], threads=8)
+    for got, want in zip(res, g['borders']):
+        assert got.tolist() == want
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason='oracle/_ref/segmentor not built here')
+@pytest.mark.parametrize('name', ['tiny', 'pcount0', 'zero_stretch', 'dense_w_gt_64'])
+def test_live_reference_binary_agrees(name, golden_chunks):
+    g = golden_chunks[name]
+    spec = g['spec']
+    slices, loci = cases.build_case(spec)
+    b = oracle.ref_segment_arrays(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp'])
+    assert b.tolist() == g['borders']
+
+
+def test_meth_gt_cov_is_an_error():
+    """segmentor.cpp:181-188: a site with #meth > #cov aborts the run."""
+    spec = cases.CHUNK_CASES['tiny']
+    slices, loci = cases.build_case(spec)
+    slices[1][37, 0] = slices[1][37, 1] + 1
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.segment_chunk(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp'])
+    assert e.value.code == oracle.ORACLE_E_METH_GT_COV and e.value.sample == 1 and e.value.site == 37
+
+
+def test_debug_outputs_consistent():
+    spec = cases.CHUNK_CASES['tiny']
+    slices, loci = cases.build_case(spec)
+    b, M, T, band = oracle.segment_chunk(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp'], debug=True)
+    n = spec['n']
+    assert M[0] == 0 and (M[1:] <= 0).all() and (T[1:] >= 0).all() and (T[1:] < np.arange(1, n + 1)).all()
+    # recompute M from the band: M[i+1] = max_k M[k] + band[k, i-k]
+    for i in (0, 1, 17, n - 1):
+        ks = np.arange(max(0, i + 1 - spec['max_cpg']), i + 1)
+        v = M[ks] + band[ks, i - ks]
+        assert M[i + 1] == v.max() and T[i + 1] == ks[np.argmax(v)]
