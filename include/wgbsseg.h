@@ -1,0 +1,154 @@
+/*
+ * wgbsseg.h — C ABI of the MI355X-native `wgbstools segment` hot path (libwgbsseg.so, built by hipcc for gfx950).
+ *
+ * What it replaces.  The reference has no FFI on this path: its boundary is a PROCESS boundary.
+ * src/python/segment.py:41-59 (`segment_process`) runs, per chunk of CpG sites,
+ *     tabix rev.CpG.bed.gz chr:start-(end-1) | cut -f2 | segmentor b1.beta ... -s start-1 -n end-start
+ *                                                         -max_cpg M -ps P -max_bp B
+ * and parses the integers `segmentor` prints (src/segment_betas/main.cpp:89-112 ->
+ * segmentor::dp_wrapper segmentor.cpp:193-214 -> read_beta_file :164-190, load_dists :36-48, dp :60-159,
+ * traceback :50-58, print_borders :30-34).  One call of wgbsseg_segment_chunks() stands for a whole
+ * Pool.starmap(segment_process, chunks) (segment.py:144-146): same inputs (beta bytes, loci, -s/-n per chunk,
+ * -max_cpg/-ps/-max_bp), same outputs (per chunk the ascending border list including 0 and n, relative to the
+ * chunk start), bit-exact.  INTEGRATION.md shows the ctypes stub a maintainer would put in segment.py.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  The caller owns every host buffer for the
+ * duration of a call; the library never keeps a host pointer after returning.  Device buffers passed with the
+ * *_device setters are borrowed (the caller keeps them alive until they are replaced or the context is
+ * destroyed).  All calls on one context must come from one thread at a time; different contexts (one per GPU)
+ * are independent.  Every entry point returns WGBSSEG_OK or a negative code and, when `err` is non-NULL,
+ * a NUL-terminated message.  There is NO CPU fallback: without a gfx950 device wgbsseg_create() fails.
+ */
+#ifndef WGBSSEG_H
+#define WGBSSEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WGBSSEG_VERSION 100            /* 0.1.0 */
+
+#define WGBSSEG_OK              0
+#define WGBSSEG_E_ARG          -1      /* bad argument (message says which) */
+#define WGBSSEG_E_METH_GT_COV  -2      /* a requested site has #meth > #cov: segmentor.cpp:181-188 "invalid data" */
+#define WGBSSEG_E_NOMEM        -3
+#define WGBSSEG_E_HIP          -4      /* HIP runtime error / no usable device */
+#define WGBSSEG_E_LOCI_ORDER   -5      /* loci not ascending inside a chunk (chunks never cross chromosomes: segment.py:84-86) */
+#define WGBSSEG_E_CAPACITY     -6      /* borders_out too small */
+#define WGBSSEG_E_STATE        -7      /* betas / loci not set */
+
+typedef struct wgbsseg_ctx wgbsseg_ctx;
+
+/* struct Params of segmentor.h:16-23, minus start/nr_sites (those are per chunk). */
+typedef struct wgbsseg_params {
+    float    pseudo_count;   /* -ps      (segment.py passes --pcount, default 15: segment.py:269)            */
+    uint32_t max_cpg;        /* -max_cpg (segment.py passes min(--max_cpg, --max_bp/2): segment.py:65)       */
+    uint32_t max_bp;         /* -max_bp  (must be >= 1: with 0 the reference reads uninitialised memory, segmentor.cpp:38,114) */
+} wgbsseg_params;
+
+/* HIP-event timings of the last wgbsseg_segment_chunks() call, milliseconds, and its work counters. */
+typedef struct wgbsseg_timings {
+    double scan_ms;          /* prefix-scan + validation pass over the beta bytes (HBM-bound kernel)   */
+    double window_ms;        /* window extents from loci + CSR offsets                                 */
+    double cost_ms;          /* block log-likelihood evaluation, summed over stages                    */
+    double dp_ms;            /* changepoint recurrence, summed over stages                             */
+    double trace_ms;         /* traceback + compaction                                                 */
+    double total_ms;         /* first kernel start -> borders on the host (device time line)           */
+    int64_t sites;           /* sum of chunk lengths                                                   */
+    int64_t pairs;           /* sum over sites of window length W_i = candidate blocks scored          */
+    int64_t evals;           /* pairs * n_samples = per-(block, sample) likelihood evaluations         */
+    int64_t scan_bytes;      /* algorithmic bytes of the scan pass: 2 * n_samples * sites              */
+    int32_t max_window;      /* largest W_i                                                            */
+    int32_t n_stages;
+    int32_t scan_launches;   /* kernel launches behind scan_ms (1 per call)                            */
+    int32_t reserved;
+} wgbsseg_timings;
+
+int wgbsseg_version(void);
+
+/* Number of visible gfx950 devices (0 if none / no HIP runtime). */
+int wgbsseg_device_count(void);
+
+/* Create a context bound to HIP device `device` (its own streams and scratch memory). */
+int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen);
+void wgbsseg_destroy(wgbsseg_ctx* ctx);
+
+/*
+ * Beta data: n_samples arrays of n_sites x 2 uint8 (#meth, #cov) — the `.beta` file format
+ * (docs/beta_format.md:3-8; what read_beta_file segmentor.cpp:164-177 reads).  Sample order = argv order of the
+ * reference (it fixes the order of the double accumulation, segmentor.cpp:120-136).
+ * _host: copies every sample into one device allocation [n_samples][pitch] (pitch = 2*n_sites rounded up to 256 B).
+ * _device: borrows a device buffer with that layout; `base` and `pitch_bytes` must be multiples of 16.
+ */
+int wgbsseg_set_betas_host(wgbsseg_ctx* ctx, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites,
+                           char* err, size_t errlen);
+int wgbsseg_set_betas_device(wgbsseg_ctx* ctx, const void* base, int64_t n_samples, int64_t pitch_bytes,
+                             int64_t n_sites, char* err, size_t errlen);
+
+/* loci[i] = bp position of CpG i+1 (column 2 of CpG.bed.gz; what `tabix | cut -f2` feeds load_dists, segmentor.cpp:36-48). */
+int wgbsseg_set_loci_host(wgbsseg_ctx* ctx, const uint32_t* loci, int64_t n_sites, char* err, size_t errlen);
+int wgbsseg_set_loci_device(wgbsseg_ctx* ctx, const void* loci, int64_t n_sites, char* err, size_t errlen);
+
+/*
+ * Segment n_chunks chunks of the resident data.  Chunk c covers 0-based sites
+ * [chunk_start0[c], chunk_start0[c] + chunk_len[c])  (== segmentor's -s / -n).
+ * Output (CSR): chunk c's borders — ascending, relative to its start, first 0, last chunk_len[c], exactly the
+ * integers the reference prints (segmentor.cpp:30-34) — are borders_out[borders_off[c] .. borders_off[c+1]).
+ * borders_off has n_chunks+1 entries; borders_cap >= sum(chunk_len) + n_chunks always suffices.
+ * Errors the reference also raises: #meth > #cov inside a requested chunk (message names sample and site).
+ * Rejected up front: max_bp == 0, max_cpg < 1, 255*max_cpg >= 2^24 (float-exact block sums), chunk out of range.
+ */
+int wgbsseg_segment_chunks(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const int32_t* chunk_len,
+                           int64_t n_chunks, const wgbsseg_params* params,
+                           int32_t* borders_out, int64_t borders_cap, int64_t* borders_off,
+                           char* err, size_t errlen);
+
+/*
+ * One-shot form (host buffers in, host borders out): creates a context on `device`, uploads, segments, destroys.
+ * betas = [n_samples][sample_pitch_bytes] host bytes, each row holding n_sites_total x 2 uint8.
+ */
+int wgbsseg_segment_chunks_host(const uint8_t* betas, int64_t n_samples, int64_t sample_pitch_bytes,
+                                int64_t n_sites_total, const uint32_t* loci,
+                                const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
+                                const wgbsseg_params* params, int device,
+                                int32_t* borders_out, int64_t borders_cap, int64_t* borders_off,
+                                char* err, size_t errlen);
+
+/*
+ * Materialised per-sample prefix sums of one site range (the quantity the scan pass and the LDS tiles of the
+ * scoring kernel are built from; also what a block-sum reduction such as beta_to_blocks.py:101-105 needs):
+ * out[s][t][0] = sum_{u<t} meth_s[start0+u], out[s][t][1] = sum_{u<t} cov_s[start0+u], t = 0..len  (uint32).
+ * out is a HOST buffer of n_samples*(len+1)*2 uint32.
+ */
+int wgbsseg_prefix_sums(wgbsseg_ctx* ctx, int64_t start0, int64_t len, uint32_t* out, char* err, size_t errlen);
+
+/* The scan/validation pass alone over the given chunks (bandwidth benchmark): runs it `repeat` times and
+ * returns the mean HIP-event time per launch in *ms_per_launch and the algorithmic bytes per launch. */
+int wgbsseg_scan_only(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
+                      int repeat, double* ms_per_launch, int64_t* bytes_per_launch, char* err, size_t errlen);
+
+int wgbsseg_get_timings(const wgbsseg_ctx* ctx, wgbsseg_timings* out);
+
+/*
+ * Test hooks (used by tests/ to compare device intermediates with the oracle; not part of the drop-in surface).
+ * wgbsseg_debug_fetch copies an intermediate of the LAST wgbsseg_segment_chunks() call to a host buffer:
+ *   "window"  uint16[sites]   W_i            "cum"   uint32[sites]  exclusive prefix of W inside each chunk
+ *   "back"    uint16[sites]   i+1-argmax     "cost"  double[pairs]  scored blocks, CSR by (chunk, site), only if
+ *                                                     the call ran as a single stage
+ * Returns the number of bytes written, or a negative code.
+ * wgbsseg_debug_sample_terms evaluates the per-(block,sample) term on the device for arrays of (nmeth, ntotal).
+ * wgbsseg_debug_log2 evaluates the device log2f / log2(1-p) restatements for `count` consecutive float bit
+ * patterns starting at `first_bits` (out_f: uint32 bits of log2f(p); out_d: uint64 bits of log2(1.0-(double)p)).
+ */
+int64_t wgbsseg_debug_fetch(wgbsseg_ctx* ctx, const char* what, void* out, int64_t cap_bytes);
+int wgbsseg_debug_sample_terms(wgbsseg_ctx* ctx, const float* nmeth, const float* ntotal, int64_t count,
+                               float pseudo_count, float* out);
+int wgbsseg_debug_log2(wgbsseg_ctx* ctx, uint32_t first_bits, int64_t count, uint32_t* out_f, uint64_t* out_d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WGBSSEG_H */

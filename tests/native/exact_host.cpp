@@ -1,0 +1,38 @@
+// tests/native/exact_host.cpp — test shim: the HOST build of wgbs_tools_amd/csrc/exact_log2.h, exported so that
+// tests can compare it with the live libm (oracle/libm_probe.c) and with the oracle's per-sample term.
+// Build: g++ -O2 -ffp-contract=off -shared -fPIC (see __graft_entry__.build / tests/conftest.py).
+#include "../../wgbs_tools_amd/csrc/exact_log2.h"
+#include <thread>
+#include <vector>
+
+static const wg_log_tables g_tab = WG_LOG_TABLES_INIT;
+
+template <class F> static void par_for(uint64_t count, int threads, F f)
+{
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([=]() { f(count * t / threads, count * (t + 1) / threads); });
+    for (auto& x : th) x.join();
+}
+
+extern "C" {
+void exact_log2f_fill(uint32_t first, uint64_t count, uint32_t* out, int threads)
+{
+    par_for(count, threads, [=](uint64_t a, uint64_t b) {
+        for (uint64_t q = a; q < b; q++) out[q] = wg_f2u(wg_log2f(wg_u2f(first + (uint32_t)q), g_tab.f_tab));
+    });
+}
+void exact_log2_1mp_fill(uint32_t first, uint64_t count, uint64_t* out, int threads)
+{
+    par_for(count, threads, [=](uint64_t a, uint64_t b) {
+        for (uint64_t q = a; q < b; q++)
+            out[q] = wg_d2u(wg_log2(1.0 - (double)wg_u2f(first + (uint32_t)q), g_tab.d_tab, g_tab.d_tab2));
+    });
+}
+void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, float pc, float* out)
+{
+    float pc2 = pc + pc;
+    for (int64_t q = 0; q < count; q++) out[q] = wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_tab);
+}
+}

@@ -1,0 +1,243 @@
+"""Host-side driver parity on the CPU: chunk grid, junction stitching, min_cpg filter, stderr text and BED bytes of
+wgbs_tools_amd/segment.py against golden vectors captured from the reference's own Python driver
+(tests/golden/driver_cases.json, made by tests/golden/make_golden_driver.py with the reference binary as the chunk
+engine).  The chunk engine injected here is the ORACLE (test infrastructure) — the product's engine is the HIP
+library, exercised by the -m gpu tests with the same golden vectors."""
+import argparse
+import contextlib
+import hashlib
+import io
+import json
+import os
+import os.path as op
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from wgbs_tools_amd import genome as G
+from wgbs_tools_amd import segment as S
+from wgbs_tools_amd import synth
+
+ROOT = op.dirname(op.dirname(op.abspath(__file__)))
+
+
+class OracleEngine:
+    """Test-only chunk engine with HipEngine's interface, backed by oracle/segment_oracle.c."""
+
+    def __init__(self, betas, loci):
+        self.betas = betas
+        self.loci = loci
+        self.calls = []
+
+    def segment_many(self, sites_list, params):
+        out = [None] * len(sites_list)
+        idx, st0, ln = [], [], []
+        for i, (start, end) in enumerate(sites_list):
+            assert end - start > 0
+            self.calls.append((int(start), int(end)))
+            if end - start == 1:
+                out[i] = np.array([start, end])
+            else:
+                idx.append(i); st0.append(start - 1); ln.append(end - start)
+        if idx:
+            res = oracle.segment_chunks(self.betas, self.loci, st0, ln, params['pcount'], params['max_cpg'],
+                                        params['max_bp'], threads=os.cpu_count() or 1)
+            for i, r in zip(idx, res):
+                out[i] = r.astype(np.int64) + sites_list[i][0]
+        return out
+
+
+@pytest.fixture(scope='module')
+def driver_golden():
+    with open(op.join(ROOT, 'tests', 'golden', 'driver_cases.json')) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope='module')
+def synth_world(driver_golden, tmp_path_factory):
+    meta = driver_golden['meta']
+    names = [c for c, _ in meta['chrom_sizes']]
+    sizes = [s for _, s in meta['chrom_sizes']]
+    loci = synth.synth_loci(meta['seed'], sizes)
+    total = int(sum(sizes))
+    betas = [synth.synth_betas(meta['seed'], s, 0, total) for s in range(meta['n_betas'])]
+    d = tmp_path_factory.mktemp('world')
+    refdir = synth.write_genome(str(d / 'references' / 'synth'), names, sizes, loci)
+    paths = []
+    for i, b in enumerate(betas):
+        p = str(d / ('s%d.beta' % i))
+        synth.write_beta(p, b)
+        paths.append(p)
+    return dict(refdir=refdir, paths=paths, betas=betas, loci=loci, names=names, sizes=sizes, dir=str(d))
+
+
+def make_args(world, out_path, **kw):
+    d = dict(sites=None, region=None, array_id=None, bed_file=None, genome=world['refdir'], betas=world['paths'],
+             beta_file=None, chunk_size=60000, pcount=15, min_cpg=1, max_cpg=1000, max_bp=2000, out_path=out_path,
+             threads=1, device=0)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+CASES = ['wg_c20000', 'wg_c60000_min3', 'sites_3chunks', 'sites_single', 'wg_pcount0', 'small_chunks', 'tiny_chunks',
+         'wide_bp', 'bed_regions']
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_driver_matches_reference_driver(name, driver_golden, synth_world, tmp_path):
+    g = driver_golden['cases'][name]
+    kw = dict(g['args'])
+    out_path = str(tmp_path / 'out.bed')
+    if g['bed_rows'] is not None:
+        bed = str(tmp_path / 'regions.bed')
+        with open(bed, 'w') as f:
+            f.write('#chr\tstart\tend\tstartCpG\tendCpG\n')
+            for s, e in g['bed_rows']:
+                f.write('chrN\t0\t1\t%d\t%d\n' % (s, e))
+        kw['bed_file'] = bed
+    args = make_args(synth_world, out_path, **kw)
+    eng = OracleEngine(synth_world['betas'], synth_world['loci'])
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        sbc = S.SegmentByChunks(args, synth_world['paths'], engine=eng)
+        tags, starts, ends = sbc.break_to_chunks()
+        sbc.run()
+    # chunk grid (segment.py:124-135)
+    assert tags == g['chunks']['tags'] and starts == g['chunks']['starts'] and ends == g['chunks']['ends']
+    # the patches asked for are the reference's (as a set: we batch per round and cache repeats)
+    nch = len(starts)
+    assert set(eng.calls[nch:]) == set(tuple(c) for c in g['patch_calls'])
+    # stderr text (chunk-size warning + summary) verbatim; the golden capture also called break_to_chunks twice
+    assert err.getvalue() == g['stderr']
+    # output table
+    rows = [l.rstrip('\n').split('\t') for l in open(out_path)]
+    assert all(len(r) == 5 for r in rows)
+    table = np.array([[int(r[3]), int(r[4])] for r in rows], dtype=np.int64).reshape(-1, 2)
+    assert table.shape[0] == g['n_blocks']
+    assert hashlib.sha1(table.tobytes()).hexdigest() == g['table_sha1']
+    if g['start_cpg'] is not None:
+        assert table[:, 0].tolist() == g['start_cpg'] and table[:, 1].tolist() == g['end_cpg']
+    # BED columns 1-3 follow add_loci.cpp:51-54
+    loci = synth_world['loci'].astype(np.int64)
+    cum = np.cumsum(synth_world['sizes'])
+    for r, (s, e) in list(zip(rows, table))[:: max(1, len(rows) // 500)]:
+        assert r[0] == synth_world['names'][int(np.searchsorted(cum, s))]
+        assert int(r[1]) == loci[s - 1] and int(r[2]) == loci[e - 2] + 1 and int(r[1]) < int(r[2]) and s < e
+
+
+def test_stitch_helpers_match_reference(driver_golden):
+    for rec in driver_golden['funcs']:
+        b1, b2 = np.array(rec['b1']), np.array(rec['b2'])
+        assert S.find_dups(b1, b2).astype(int).tolist() == rec['find_dups']
+        assert int(S.is_2_overlap(b1, b2)) == rec['overlap']
+        if rec['overlap']:
+            assert S.merge2(b1, b2).tolist() == rec['merge2']
+    for p, m, want in driver_golden['increase_patch']:
+        assert S.increase_patch(p, m) == want
+
+
+def test_stitch_failure_raises_like_reference():
+    # b2 does not continue b1 (segment.py:202-205)
+    with pytest.raises(G.IllegalArgumentError, match='not supposed to be merged'):
+        S.stitch_2_dfs(np.array([1, 5, 9]), np.array([10, 12]), {})
+
+    class NeverOverlaps:
+        def segment_many(self, sites, params):
+            return [np.array([s[0], s[1]]) + 1000000 for s in sites]
+    with pytest.raises(G.IllegalArgumentError, match='Try increasing chunk size'):
+        S.stitch_2_dfs(np.array([1, 5, 9]), np.array([9, 12, 20]), {'engine': NeverOverlaps()})
+
+
+def test_genome_validation_and_args(synth_world, tmp_path):
+    bad = str(tmp_path / 'short.beta')
+    synth.write_beta(bad, synth_world['betas'][0][:-5])
+    args = make_args(synth_world, None, betas=[bad])
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err), pytest.raises(G.IllegalArgumentError, match='does not match the input beta file'):
+        S.SegmentByChunks(args, [bad], engine=object())
+    assert 'incomatible with current genome reference' in err.getvalue()          # utils_wgbs.py:299-302 (sic)
+    # max_cpg = min(max_cpg, max_bp // 2) must exceed 1 (segment.py:65-66)
+    with pytest.raises(AssertionError):
+        S.SegmentByChunks(make_args(synth_world, None, max_bp=3), synth_world['paths'], engine=object())
+    a = S.parse_args(['--betas', 'a.beta', 'b.beta', '-r', 'chr1:1-100'])
+    assert (a.chunk_size, a.pcount, a.min_cpg, a.max_cpg, a.max_bp) == (60000, 15, 1, 1000, 2000)
+    with pytest.raises(SystemExit):
+        S.parse_args(['--betas', 'a.beta', '-r', 'chr1', '-s', '1-5'])                 # mutually exclusive
+    with pytest.raises(G.IllegalArgumentError):
+        S.parse_betas_input(argparse.Namespace(betas=['nonexistent.beta'], beta_file=None))
+    lst = str(tmp_path / 'list.txt')
+    with open(lst, 'w') as f:
+        f.write('# comment\n' + synth_world['paths'][0] + '\n\n' + synth_world['paths'][1] + '\n')
+    assert S.parse_betas_input(argparse.Namespace(betas=None, beta_file=lst)) == synth_world['paths'][:2]
+
+
+def test_region_and_sites_parsing(synth_world):
+    gen = G.GenomeRefPaths(synth_world['refdir'])
+    loci = synth_world['loci']
+    n1 = synth_world['sizes'][0]
+    assert gen.get_nr_sites() == sum(synth_world['sizes']) and (gen.loci() == loci).all()
+    assert gen.index2chrom(1) == 'chr1' and gen.index2chrom(n1) == 'chr1' and gen.index2chrom(n1 + 1) == 'chr2'
+    gr = G.GenomicRegion(sites='100-200', genome=gen)
+    assert gr.sites == (100, 200) and gr.chrom == 'chr1' and gr.bp_tuple == (int(loci[99]), int(loci[198]) + 1)
+    assert G.GenomicRegion(sites='77', genome=gen).sites == (77, 78)
+    with pytest.raises(G.IllegalArgumentError):
+        G.GenomicRegion(sites=f'{n1 - 3}-{n1 + 5}', genome=gen)                   # crosses chromosomes
+    with pytest.raises(G.IllegalArgumentError):
+        G.GenomicRegion(sites='0-5', genome=gen)
+    # -r: CpGs with from <= locus <= to; a CpG exactly on `to` is excluded (genomic_region.py:144-148)
+    a, b = int(loci[500]), int(loci[520])
+    assert G.GenomicRegion(region=f'chr1:{a}-{b}', genome=gen).sites == (501, 521)
+    assert G.GenomicRegion(region=f'chr1:{a}-{b + 1}', genome=gen).sites == (501, 522)
+    assert G.GenomicRegion(region=f'chr1:{a + 1}-{b + 1}', genome=gen).sites == (502, 522)
+    off = n1
+    a2, b2 = int(loci[off + 10]), int(loci[off + 30])
+    assert G.GenomicRegion(region=f'chr2:{a2:,}-{b2 + 5:,}', genome=gen).sites == (off + 11, off + 32)
+    with pytest.raises(G.IllegalArgumentError, match='No CpGs in range'):
+        G.GenomicRegion(region=f'chr1:{int(loci[10]) + 1}-{int(loci[11]) - 1}', genome=gen)
+    with pytest.raises(G.IllegalArgumentError, match='Unknown chromosome'):
+        G.GenomicRegion(region='chr9:5-10', genome=gen)
+    whole = G.GenomicRegion(region='chr3', genome=gen)
+    s3 = synth_world['sizes'][0] + synth_world['sizes'][1]
+    assert whole.sites == (s3 + 1, s3 + synth_world['sizes'][2] + 1)
+
+
+def test_bed_writer_reproduces_reference_fixture(tmp_path):
+    """Byte-identity with the reference's own golden BED (tests/data/segment/chr19_100k_500k.blocks.bed) given a
+    loci table consistent with it: pins the add_loci formula and the text format."""
+    fx = op.join(ROOT, 'tests', 'golden', 'ref_fixtures', 'chr19_100k_500k.blocks.bed')
+    raw = open(fx).read()
+    rows = [l.split('\t') for l in raw.strip('\n').split('\n')]
+    s = np.array([int(r[3]) for r in rows]); e = np.array([int(r[4]) for r in rows])
+    st = np.array([int(r[1]) for r in rows]); en = np.array([int(r[2]) for r in rows])
+    first = int(s.min()); last = int(e.max())
+    loci = np.zeros(last, dtype=np.int64)
+    known = np.zeros(last, dtype=bool)
+    for a, b, x, y in zip(s, e, st, en):
+        for idx, val in ((a - 1, x), (b - 2, y - 1)):
+            assert not known[idx] or loci[idx] == val
+            loci[idx] = val; known[idx] = True
+    k = np.flatnonzero(known)
+    loci[first - 1:] = np.interp(np.arange(first - 1, last), k, loci[k]).astype(np.int64)
+    loci[k] = loci[k]
+    loci[:first - 1] = np.arange(first - 1) + 1
+
+    class Gen:
+        def get_chrom_cpg_sizes(self):
+            return ['chrA', 'chr19'], np.array([first - 1, last - first + 1 + 10])
+
+        def loci(self):
+            return np.concatenate([loci, np.zeros(10, dtype=np.int64)]).astype(np.uint32)
+    out = str(tmp_path / 'x.bed')
+    G.write_bed(Gen(), s, e, out)
+    assert open(out).read() == raw
+
+
+def test_cli_dispatch_and_native_required(synth_world, capsys):
+    """`wgbstools segment` must fail loudly, not fall back, when no GPU/HIP library can serve it."""
+    from wgbs_tools_amd import wgbs_tools, _lib
+    assert wgbs_tools.main(['wgbstools', 'view']) == 1
+    if _lib.device_count() == 0 if op.isfile(_lib.LIB_PATH) else True:
+        with pytest.raises((_lib.SegmentorError, _lib.NativeLibraryError)):
+            wgbs_tools.main(['wgbstools', 'segment', '--betas'] + synth_world['paths'] +
+                            ['--genome', synth_world['refdir'], '-s', '1-500', '-o', os.devnull])

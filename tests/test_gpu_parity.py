@@ -1,0 +1,277 @@
+"""GPU parity tests: the HIP path (through the C ABI, libwgbsseg.so) against the oracle, the committed golden
+vectors and numpy, stage by stage so that a failure names the kernel at fault.  Bit-exact everywhere
+(integer / byte / index work, and IEEE arithmetic restated exactly — no tolerance)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle
+from wgbs_tools_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _first_diff(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return 'shape %s vs %s' % (a.shape, b.shape)
+    d = np.flatnonzero(a != b)
+    if d.size == 0:
+        return None
+    i = int(d[0])
+    return '%d mismatches, first at %d: got %r want %r' % (d.size, i, a.flat[i], b.flat[i])
+
+
+@pytest.fixture(scope='module')
+def seg():
+    s = _lib.Segmenter(0)
+    yield s
+    s.close()
+
+
+def _load_case(seg, spec):
+    slices, loci = cases.build_case(spec)
+    seg.set_betas(slices)
+    seg.set_loci(loci)
+    return slices, loci
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 1. arithmetic: the device restatement of the platform libm, and the per-(block, sample) term
+# ---------------------------------------------------------------------------------------------------------
+def test_01_device_log2_matches_host_libm_exhaustively(seg):
+    """log2f(p) for every float in (0,1] and log2(1-(double)p) for every float in (0,1): device == live libm."""
+    O = oracle.lib()
+    threads = os.cpu_count() or 1
+    first, last = 0x00800000, 0x3f800000
+    B = 1 << 25
+    bad_f = bad_d = 0
+    msg = ''
+    q = first
+    while q <= last:
+        cnt = min(B, last - q + 1)
+        f, d = seg.debug_log2(q, cnt)
+        fb = C.c_uint32(0)
+        nf = O.probe_log2f_compare(q, cnt, f.ctypes.data, threads, C.byref(fb))
+        if nf and not msg:
+            msg = 'log2f first bad bits 0x%08x' % fb.value
+        cnt_d = cnt if q + cnt - 1 < last else cnt - 1
+        nd = O.probe_log2_1mp_compare(q, cnt_d, d.ctypes.data, threads, C.byref(fb)) if cnt_d else 0
+        if nd and not msg:
+            msg = 'log2(1-p) first bad bits 0x%08x' % fb.value
+        bad_f += nf
+        bad_d += nd
+        q += cnt
+    assert bad_f == 0 and bad_d == 0, 'log2f mismatches %d, log2(1-p) mismatches %d; %s' % (bad_f, bad_d, msg)
+
+
+@pytest.mark.parametrize('pcount', [15.0, 0.0, 0.5, 1.0])
+def test_02_device_sample_term_matches_oracle(seg, pcount):
+    rng = np.random.default_rng(1234)
+    t = np.concatenate([np.arange(0, 3000), rng.integers(0, 255 * 1000, 400000)]).astype(np.float32)
+    m = np.floor(rng.random(t.size) * (t + 1)).astype(np.float32)
+    m = np.minimum(m, t)
+    m[:3000:3] = 0
+    m[1:3000:3] = t[1:3000:3]
+    got = seg.debug_sample_terms(m, t, pcount)
+    want = oracle.sample_terms(m, t, pcount)
+    assert _first_diff(got.view(np.uint32), want.view(np.uint32)) is None, _first_diff(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 2. scan pass
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('start0,length', [(0, 1), (0, 64), (3, 700), (8, 512), (13, 5000), (1001, 60000), (0, 4097)])
+def test_03_prefix_sums_equal_numpy_cumsum(seg, start0, length):
+    n = 70000
+    slices = [synth.synth_betas(cases.SEED, s, 0, n) for s in range(5)]
+    seg.set_betas(slices)
+    got = seg.prefix_sums(start0, length)
+    for s, sl in enumerate(slices):
+        want = np.zeros((length + 1, 2), dtype=np.uint32)
+        want[1:] = np.cumsum(sl[start0:start0 + length].astype(np.uint32), axis=0)
+        assert _first_diff(got[s], want) is None, 'sample %d: %s' % (s, _first_diff(got[s], want))
+
+
+def test_04_meth_gt_cov_is_reported(seg):
+    spec = cases.CHUNK_CASES['tiny']
+    slices, loci = cases.build_case(spec)
+    slices[1][37, 0] = slices[1][37, 1] + 1
+    seg.set_betas(slices)
+    seg.set_loci(loci)
+    with pytest.raises(_lib.SegmentorError) as e:
+        seg.segment_chunks([0], [spec['n']], spec['pcount'], spec['max_cpg'], spec['max_bp'])
+    assert e.value.code == _lib.E_METH_GT_COV and 'sample 1' in e.value.msg and 'site 37' in e.value.msg
+    # a bad site OUTSIDE the requested chunks is not an error (the reference only reads the chunk's bytes)
+    b = seg.segment_chunks([40], [spec['n'] - 40], spec['pcount'], spec['max_cpg'], spec['max_bp'])[0]
+    assert b[0] == 0 and b[-1] == spec['n'] - 40
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 3. window extents, scored blocks, recurrence — against the oracle's intermediates
+# ---------------------------------------------------------------------------------------------------------
+def _numpy_windows(loci, max_cpg, max_bp):
+    l = loci.astype(np.int64)
+    i = np.arange(l.size)
+    lo = np.searchsorted(l, l - max_bp, 'left')
+    lo = np.maximum(lo, i + 1 - max_cpg)
+    return (i - lo + 1).astype(np.int64)
+
+
+@pytest.mark.parametrize('name', ['tiny', 'max_cpg_binds', 'dense_w_gt_64', 'equal_loci', 'zero_stretch', 'deep'])
+def test_05_intermediates_match_oracle(name, golden_chunks):
+    os.environ['WGBSSEG_FORCE_STAGES'] = '1'
+    try:
+        sg = _lib.Segmenter(0)
+    finally:
+        del os.environ['WGBSSEG_FORCE_STAGES']
+    try:
+        spec = golden_chunks[name]['spec']
+        slices, loci = _load_case(sg, spec)
+        n, max_cpg = spec['n'], spec['max_cpg']
+        got = sg.segment_chunks([0], [n], spec['pcount'], max_cpg, spec['max_bp'])[0]
+        W = _numpy_windows(loci, max_cpg, spec['max_bp'])
+        gW = sg.debug_fetch('window', np.uint16, n).astype(np.int64)
+        assert _first_diff(gW, W) is None, 'window: ' + _first_diff(gW, W)
+        cum = np.concatenate([[0], np.cumsum(W)[:-1]])
+        gcum = sg.debug_fetch('cum', np.uint32, n).astype(np.int64)
+        assert _first_diff(gcum, cum) is None, 'cum: ' + _first_diff(gcum, cum)
+        b, M, T, band = oracle.segment_chunk(slices, loci, spec['pcount'], max_cpg, spec['max_bp'], debug=True)
+        # oracle band[k, i-k] -> CSR rows by end site i, candidates k = i-W+1..i
+        gcost = sg.debug_fetch('cost', np.float64, int(W.sum()))
+        want = np.empty(int(W.sum()), dtype=np.float64)
+        for i in range(n):
+            ks = np.arange(i - W[i] + 1, i + 1)
+            want[cum[i]:cum[i] + W[i]] = band[ks, i - ks]
+        d = _first_diff(gcost.view(np.uint64), want.view(np.uint64))
+        if d is not None:
+            j = int(np.flatnonzero(gcost.view(np.uint64) != want.view(np.uint64))[0])
+            i = int(np.searchsorted(cum, j, 'right') - 1)
+            raise AssertionError('cost: %s (end site %d, k %d): got %r want %r' % (d, i, i - W[i] + 1 + j - cum[i], gcost[j], want[j]))
+        gback = sg.debug_fetch('back', np.uint16, n).astype(np.int64)
+        wback = np.arange(1, n + 1) - T[1:]
+        assert _first_diff(gback, wback) is None, 'back-pointers: ' + _first_diff(gback, wback)
+        assert got.tolist() == b.tolist()
+    finally:
+        sg.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 4. borders against the golden vectors captured from the reference binary
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', list(cases.CHUNK_CASES))
+def test_06_borders_match_reference_golden(seg, name, golden_chunks):
+    g = golden_chunks[name]
+    spec = g['spec']
+    slices, loci = _load_case(seg, spec)
+    assert cases.case_checksum(slices, loci) == g['input_crc32']
+    got = seg.segment_chunks([0], [spec['n']], spec['pcount'], spec['max_cpg'], spec['max_bp'])[0]
+    assert got.tolist() == g['borders'], _first_diff(got, np.array(g['borders']))
+
+
+@pytest.mark.parametrize('stages', [2, 3, 7, 64])
+def test_07_staging_does_not_change_borders(stages, golden_chunks):
+    os.environ['WGBSSEG_FORCE_STAGES'] = str(stages)
+    try:
+        sg = _lib.Segmenter(0)
+    finally:
+        del os.environ['WGBSSEG_FORCE_STAGES']
+    try:
+        for name in ['default_chunk', 'dense_w_gt_64', 'deep']:
+            g = golden_chunks[name]
+            spec = g['spec']
+            _load_case(sg, spec)
+            got = sg.segment_chunks([0], [spec['n']], spec['pcount'], spec['max_cpg'], spec['max_bp'])[0]
+            assert got.tolist() == g['borders'], '%s with %d stages: %s' % (name, stages, _first_diff(got, np.array(g['borders'])))
+            assert sg.timings()['n_stages'] >= min(stages, 2)
+    finally:
+        sg.close()
+
+
+def test_08_chr21_shaped_multichunk_matches_reference_golden(seg, golden_chunks):
+    """BASELINE.json configs[1]: 400,000 CpGs x 8 betas, default chunk grid, bit-exact vs the CPU reference."""
+    g = golden_chunks['chr21']
+    spec = g['spec']
+    slices, loci = _load_case(seg, spec)
+    assert cases.case_checksum(slices, loci) == g['input_crc32']
+    starts = np.array(g['starts'], dtype=np.int64)
+    lens = np.minimum(spec['chunk'], spec['n'] - starts).astype(np.int32)
+    res = seg.segment_chunks(starts, lens, spec['pcount'], spec['max_cpg'], spec['max_bp'])
+    for c, (got, want) in enumerate(zip(res, g['borders'])):
+        assert got.tolist() == want, 'chunk %d: %s' % (c, _first_diff(got, np.array(want)))
+    t = seg.timings()
+    assert t['sites'] == spec['n'] and t['evals'] == t['pairs'] * 8
+
+
+def test_09_many_small_and_ragged_chunks_match_oracle(seg):
+    """The shape of the stitching batch (segment.py:199-232): hundreds of ~100-site patches, plus ragged sizes,
+    overlapping ranges, 1-site chunks and chunks ending at the last site."""
+    n = 50000
+    slices = [synth.synth_betas(cases.SEED, s, 0, n) for s in range(6)]
+    loci = synth.synth_loci(cases.SEED, [n])
+    seg.set_betas(slices)
+    seg.set_loci(loci)
+    rng = np.random.default_rng(7)
+    starts = list(range(50, n - 200, 97))
+    lens = [100] * len(starts)
+    for _ in range(200):
+        ln = int(rng.integers(1, 700))
+        st = int(rng.integers(0, n - ln + 1))
+        starts.append(st)
+        lens.append(ln)
+    starts += [n - 1, n - 64, n - 65, 0, 0]
+    lens += [1, 64, 65, 1, 2]
+    got = seg.segment_chunks(starts, lens, 15.0, 1000, 2000)
+    want = oracle.segment_chunks(slices, loci, starts, lens, 15.0, 1000, 2000, threads=os.cpu_count() or 1)
+    for c, (a, b) in enumerate(zip(got, want)):
+        assert a.tolist() == b.tolist(), 'chunk %d [%d,+%d): %s' % (c, starts[c], lens[c], _first_diff(a, b))
+
+
+def test_10_one_shot_host_entry_point(golden_chunks):
+    g = golden_chunks['tiny']
+    spec = g['spec']
+    slices, loci = cases.build_case(spec)
+    res = _lib.segment_chunks_host(slices, loci, [0, 100], [spec['n'], 50], spec['pcount'], spec['max_cpg'], spec['max_bp'])
+    assert res[0].tolist() == g['borders']
+    want = oracle.segment_chunk([s[100:150] for s in slices], loci[100:150], spec['pcount'], spec['max_cpg'], spec['max_bp'])
+    assert res[1].tolist() == want.tolist()
+
+
+def test_11_argument_errors(seg):
+    spec = cases.CHUNK_CASES['tiny']
+    _load_case(seg, spec)
+    for kw, code in [(dict(max_bp=0), _lib.E_ARG), (dict(max_cpg=0), _lib.E_ARG), (dict(max_cpg=70000), _lib.E_ARG)]:
+        p = dict(pcount=15.0, max_cpg=50, max_bp=700)
+        p.update(kw)
+        with pytest.raises(_lib.SegmentorError) as e:
+            seg.segment_chunks([0], [spec['n']], p['pcount'], p['max_cpg'], p['max_bp'])
+        assert e.value.code == code
+    with pytest.raises(_lib.SegmentorError):
+        seg.segment_chunks([spec['n'] - 10], [11], 15.0, 50, 700)           # runs past the file
+    with pytest.raises(_lib.SegmentorError):
+        seg.segment_chunks([0], [0], 15.0, 50, 700)                          # empty chunk (segment.py:44 asserts)
+    # loci going backwards inside a chunk (a chunk crossing chromosomes)
+    slices, loci = cases.build_case(spec)
+    loci2 = loci.copy()
+    loci2[200:] -= loci2[200] - 5
+    seg.set_loci(loci2)
+    with pytest.raises(_lib.SegmentorError) as e:
+        seg.segment_chunks([0], [spec['n']], 15.0, 50, 700)
+    assert e.value.code == _lib.E_LOCI_ORDER
+
+
+def test_12_device_generator_equals_numpy_generator():
+    import torch
+    S = _lib.load_synth()
+    n, N = 100000, 3
+    pitch = ((2 * n + 255) // 256) * 256 + 256
+    buf = torch.zeros((N, pitch), dtype=torch.uint8, device='cuda:0')
+    rc = S.wgbssynth_fill_betas(C.c_void_p(buf.data_ptr()), pitch, n, 0, N, cases.SEED, None)
+    assert rc == 0
+    host = buf.cpu().numpy()
+    for s in range(N):
+        want = synth.synth_betas(cases.SEED, s, 0, n).reshape(-1)
+        assert _first_diff(host[s, :2 * n], want) is None, 'sample %d: %s' % (s, _first_diff(host[s, :2 * n], want))

@@ -1,0 +1,254 @@
+"""ctypes binding of libwgbsseg.so (include/wgbsseg.h).  Thin by design: numpy arrays in, numpy arrays out.
+
+There is no Python/CPU implementation behind this module: if the HIP library is missing or no gfx950 device is
+visible, every entry point raises (``NativeLibraryError`` / ``SegmentorError``) -- loudly, never a fallback.
+"""
+import ctypes as C
+import os.path as op
+
+import numpy as np
+
+HERE = op.dirname(op.abspath(__file__))
+LIB_PATH = op.join(HERE, 'csrc', 'libwgbsseg.so')
+SYNTH_LIB_PATH = op.join(HERE, 'csrc', 'libwgbssynth.so')
+
+OK, E_ARG, E_METH_GT_COV, E_NOMEM, E_HIP, E_LOCI_ORDER, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
+
+# every symbol include/wgbsseg.h declares (tests check the built library exports exactly these)
+EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg_destroy',
+           'wgbsseg_set_betas_host', 'wgbsseg_set_betas_device', 'wgbsseg_set_loci_host', 'wgbsseg_set_loci_device',
+           'wgbsseg_segment_chunks', 'wgbsseg_segment_chunks_host', 'wgbsseg_prefix_sums', 'wgbsseg_scan_only',
+           'wgbsseg_get_timings', 'wgbsseg_debug_fetch', 'wgbsseg_debug_sample_terms', 'wgbsseg_debug_log2']
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class SegmentorError(RuntimeError):
+    """A failed native call; `.code` is the WGBSSEG_E_* value, the message is the library's."""
+
+    def __init__(self, code, msg):
+        super().__init__('[wgbsseg %d] %s' % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+class Params(C.Structure):
+    _fields_ = [('pseudo_count', C.c_float), ('max_cpg', C.c_uint32), ('max_bp', C.c_uint32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [('scan_ms', C.c_double), ('window_ms', C.c_double), ('cost_ms', C.c_double), ('dp_ms', C.c_double),
+                ('trace_ms', C.c_double), ('total_ms', C.c_double), ('sites', C.c_int64), ('pairs', C.c_int64),
+                ('evals', C.c_int64), ('scan_bytes', C.c_int64), ('max_window', C.c_int32), ('n_stages', C.c_int32),
+                ('scan_launches', C.c_int32), ('reserved', C.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != 'reserved'}
+
+
+_lib = None
+_synth = None
+ERRLEN = 512
+
+
+def load():
+    """dlopen libwgbsseg.so and declare the prototypes.  Raises NativeLibraryError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not op.isfile(LIB_PATH):
+        raise NativeLibraryError('%s is missing: build it with `python -m wgbs_tools_amd.build` (needs hipcc). '
+                                 'There is no CPU fallback.' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.wgbsseg_version.restype = i32
+    L.wgbsseg_device_count.restype = i32
+    L.wgbsseg_create.restype = i32
+    L.wgbsseg_create.argtypes = [i32, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.wgbsseg_destroy.restype = None
+    L.wgbsseg_destroy.argtypes = [vp]
+    L.wgbsseg_set_betas_host.restype = i32
+    L.wgbsseg_set_betas_host.argtypes = [vp, C.POINTER(vp), i64, i64, C.c_char_p, C.c_size_t]
+    L.wgbsseg_set_betas_device.restype = i32
+    L.wgbsseg_set_betas_device.argtypes = [vp, vp, i64, i64, i64, C.c_char_p, C.c_size_t]
+    L.wgbsseg_set_loci_host.restype = i32
+    L.wgbsseg_set_loci_host.argtypes = [vp, vp, i64, C.c_char_p, C.c_size_t]
+    L.wgbsseg_set_loci_device.restype = i32
+    L.wgbsseg_set_loci_device.argtypes = [vp, vp, i64, C.c_char_p, C.c_size_t]
+    L.wgbsseg_segment_chunks.restype = i32
+    L.wgbsseg_segment_chunks.argtypes = [vp, vp, vp, i64, C.POINTER(Params), vp, i64, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_segment_chunks_host.restype = i32
+    L.wgbsseg_segment_chunks_host.argtypes = [vp, i64, i64, i64, vp, vp, vp, i64, C.POINTER(Params), i32, vp, i64, vp,
+                                              C.c_char_p, C.c_size_t]
+    L.wgbsseg_prefix_sums.restype = i32
+    L.wgbsseg_prefix_sums.argtypes = [vp, i64, i64, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_scan_only.restype = i32
+    L.wgbsseg_scan_only.argtypes = [vp, vp, vp, i64, i32, C.POINTER(C.c_double), C.POINTER(i64), C.c_char_p, C.c_size_t]
+    L.wgbsseg_get_timings.restype = i32
+    L.wgbsseg_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.wgbsseg_debug_fetch.restype = i64
+    L.wgbsseg_debug_fetch.argtypes = [vp, C.c_char_p, vp, i64]
+    L.wgbsseg_debug_sample_terms.restype = i32
+    L.wgbsseg_debug_sample_terms.argtypes = [vp, vp, vp, i64, C.c_float, vp]
+    L.wgbsseg_debug_log2.restype = i32
+    L.wgbsseg_debug_log2.argtypes = [vp, C.c_uint32, i64, vp, vp]
+    _lib = L
+    return L
+
+
+def load_synth():
+    global _synth
+    if _synth is None:
+        if not op.isfile(SYNTH_LIB_PATH):
+            raise NativeLibraryError('%s is missing: build it with `python -m wgbs_tools_amd.build`' % SYNTH_LIB_PATH)
+        S = C.CDLL(SYNTH_LIB_PATH)
+        S.wgbssynth_fill_betas.restype = C.c_int
+        S.wgbssynth_fill_betas.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
+        _synth = S
+    return _synth
+
+
+def device_count():
+    return int(load().wgbsseg_device_count())
+
+
+def _check(rc, buf):
+    if rc != OK:
+        raise SegmentorError(rc, buf.value.decode(errors='replace'))
+
+
+class Segmenter:
+    """One GPU context: resident betas + loci, batched chunk segmentation (wgbsseg_segment_chunks)."""
+
+    def __init__(self, device=0):
+        self._L = load()
+        self._h = C.c_void_p()
+        self._err = C.create_string_buffer(ERRLEN)
+        self._keep = []
+        _check(self._L.wgbsseg_create(int(device), C.byref(self._h), self._err, ERRLEN), self._err)
+        self.n_sites = 0
+        self.n_samples = 0
+
+    def close(self):
+        if self._h:
+            self._L.wgbsseg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- inputs -------------------------------------------------------------------------------------------
+    def set_betas(self, samples):
+        """samples: list of uint8 arrays shaped [n_sites, 2] (np.memmap of a .beta file works), CLI order."""
+        arrs = [np.ascontiguousarray(s, dtype=np.uint8).reshape(-1) for s in samples]
+        n2 = arrs[0].size
+        assert all(a.size == n2 for a in arrs) and n2 % 2 == 0
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        _check(self._L.wgbsseg_set_betas_host(self._h, ptrs, len(arrs), n2 // 2, self._err, ERRLEN), self._err)
+        self.n_sites, self.n_samples = n2 // 2, len(arrs)
+
+    def set_betas_device(self, data_ptr, n_samples, pitch_bytes, n_sites, keepalive=None):
+        """Borrow a device buffer [n_samples][pitch_bytes] (e.g. a torch uint8 tensor's data_ptr())."""
+        _check(self._L.wgbsseg_set_betas_device(self._h, C.c_void_p(int(data_ptr)), int(n_samples), int(pitch_bytes),
+                                                int(n_sites), self._err, ERRLEN), self._err)
+        self._keep = [keepalive]
+        self.n_sites, self.n_samples = int(n_sites), int(n_samples)
+
+    def set_loci(self, loci):
+        loci = np.ascontiguousarray(loci, dtype=np.uint32)
+        _check(self._L.wgbsseg_set_loci_host(self._h, loci.ctypes.data, loci.size, self._err, ERRLEN), self._err)
+
+    # ---- hot path -----------------------------------------------------------------------------------------
+    def segment_chunks(self, start0, lens, pcount, max_cpg, max_bp):
+        """-> list of int32 arrays: borders of each chunk relative to its start (first 0, last len)."""
+        flat, off = self.segment_chunks_csr(start0, lens, pcount, max_cpg, max_bp)
+        return [flat[off[c]:off[c + 1]] for c in range(len(off) - 1)]
+
+    def segment_chunks_csr(self, start0, lens, pcount, max_cpg, max_bp):
+        start0 = np.ascontiguousarray(start0, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        n = start0.size
+        assert lens.size == n and n >= 1
+        cap = int(lens.astype(np.int64).sum()) + n
+        out = np.empty(cap, dtype=np.int32)
+        off = np.empty(n + 1, dtype=np.int64)
+        p = Params(float(pcount), int(max_cpg), int(max_bp))
+        _check(self._L.wgbsseg_segment_chunks(self._h, start0.ctypes.data, lens.ctypes.data, n, C.byref(p),
+                                              out.ctypes.data, cap, off.ctypes.data, self._err, ERRLEN), self._err)
+        return out[:off[n]], off
+
+    def prefix_sums(self, start0, length):
+        out = np.empty((self.n_samples, length + 1, 2), dtype=np.uint32)
+        _check(self._L.wgbsseg_prefix_sums(self._h, int(start0), int(length), out.ctypes.data, self._err, ERRLEN), self._err)
+        return out
+
+    def scan_only(self, start0, lens, repeat=10):
+        start0 = np.ascontiguousarray(start0, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        ms, nbytes = C.c_double(0), C.c_int64(0)
+        _check(self._L.wgbsseg_scan_only(self._h, start0.ctypes.data, lens.ctypes.data, start0.size, int(repeat),
+                                         C.byref(ms), C.byref(nbytes), self._err, ERRLEN), self._err)
+        return ms.value, nbytes.value
+
+    def timings(self):
+        t = Timings()
+        self._L.wgbsseg_get_timings(self._h, C.byref(t))
+        return t.as_dict()
+
+    # ---- test hooks ---------------------------------------------------------------------------------------
+    def debug_fetch(self, what, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        got = self._L.wgbsseg_debug_fetch(self._h, what.encode(), out.ctypes.data, out.nbytes)
+        if got < 0:
+            raise SegmentorError(int(got), 'debug_fetch(%s) failed' % what)
+        return out[:got // out.itemsize]
+
+    def debug_sample_terms(self, nmeth, ntotal, pcount):
+        nmeth = np.ascontiguousarray(nmeth, dtype=np.float32)
+        ntotal = np.ascontiguousarray(ntotal, dtype=np.float32)
+        out = np.empty_like(nmeth)
+        rc = self._L.wgbsseg_debug_sample_terms(self._h, nmeth.ctypes.data, ntotal.ctypes.data, nmeth.size,
+                                                C.c_float(pcount), out.ctypes.data)
+        if rc != OK:
+            raise SegmentorError(rc, 'debug_sample_terms failed')
+        return out
+
+    def debug_log2(self, first_bits, count, want_f=True, want_d=True):
+        f = np.empty(count, dtype=np.uint32) if want_f else None
+        d = np.empty(count, dtype=np.uint64) if want_d else None
+        rc = self._L.wgbsseg_debug_log2(self._h, int(first_bits), int(count), f.ctypes.data if want_f else None,
+                                        d.ctypes.data if want_d else None)
+        if rc != OK:
+            raise SegmentorError(rc, 'debug_log2 failed')
+        return f, d
+
+
+def segment_chunks_host(samples, loci, start0, lens, pcount, max_cpg, max_bp, device=0):
+    """One-shot form over wgbsseg_segment_chunks_host (host buffers in, borders out)."""
+    L = load()
+    arr = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.uint8).reshape(-1) for s in samples]))
+    n_samples, pitch = arr.shape
+    loci = np.ascontiguousarray(loci, dtype=np.uint32)
+    start0 = np.ascontiguousarray(start0, dtype=np.int64)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    n = start0.size
+    cap = int(lens.astype(np.int64).sum()) + n
+    out = np.empty(cap, dtype=np.int32)
+    off = np.empty(n + 1, dtype=np.int64)
+    err = C.create_string_buffer(ERRLEN)
+    p = Params(float(pcount), int(max_cpg), int(max_bp))
+    _check(L.wgbsseg_segment_chunks_host(arr.ctypes.data, n_samples, pitch, pitch // 2, loci.ctypes.data,
+                                         start0.ctypes.data, lens.ctypes.data, n, C.byref(p), int(device),
+                                         out.ctypes.data, cap, off.ctypes.data, err, ERRLEN), err)
+    return [out[off[c]:off[c + 1]].copy() for c in range(n)]

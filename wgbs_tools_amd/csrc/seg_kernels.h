@@ -1,0 +1,659 @@
+// seg_kernels.h — gfx950 kernels of the `wgbstools segment` hot path.
+//
+// Pipeline for one batch of chunks (a chunk = what one reference `segmentor` process handles, segmentor.cpp:193-214):
+//   k_scan    per-sample prefix scan of (#meth,#cov) with 64-site carries + the #meth<=#cov validation of
+//             read_beta_file (segmentor.cpp:179-188).  HBM-bound: reads every beta byte once, writes 1/16 of that.
+//   k_window  window extent W_i of every site from the loci (the bp/CpG limits of segmentor.cpp:111-117) and the
+//             CSR row offsets of the scored-block matrix.
+//   k_cost    block log-likelihoods (segmentor.cpp:119-137) for every (start k, end i) inside the window, scored
+//             from LDS-staged prefix tiles; samples are visited in file order inside each lane (the double
+//             accumulation order is part of the bit-exactness contract).  fp64-VALU bound.
+//   k_dp      the changepoint recurrence (segmentor.cpp:142-154): one wavefront owns one chunk, 64 candidate
+//             start sites per step live in registers, arg-max by DPP reduction, first maximum wins.
+//   k_trace   traceback (segmentor.cpp:50-58) out of an LDS-resident window of back-pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "exact_log2.h"
+#include "wave_prims.h"
+
+#define WG_CARRY_G      64          // a carry (exclusive prefix) is stored every 64 sites of a chunk
+#define WG_BLOCK        256
+#define WG_RMAX         16          // candidate blocks per thread held in registers by k_cost
+#define WG_PAIR_CAP     (WG_BLOCK * WG_RMAX)
+#define WG_TRACE_WIN    65536       // back-pointers staged in LDS by k_trace (128 KiB)
+
+struct ChunkDesc {
+    int64_t start0;      // first site (0-based, absolute)
+    int64_t site_off;    // offset of this chunk in the job-site arrays (W16, cum32, back16)
+    int64_t carry_off;   // offset (in uint2) of this chunk's carries: [n_samples][nG]
+    int32_t len;
+    int32_t nG;          // len / 64 + 1
+};
+
+struct JobView {
+    const uint8_t* betas;     // [n_samples][pitch] bytes, row s = n_total x (meth, cov)
+    int64_t pitch;
+    int64_t n_total;
+    const uint32_t* loci;     // [n_total]
+    const ChunkDesc* chunks;
+    uint2* carry;
+    uint16_t* W16;            // [job sites] window length of step i (candidates k = i-W+1 .. i)
+    uint32_t* cum32;          // [job sites] exclusive prefix of W inside the chunk
+    uint16_t* back16;         // [job sites] i + 1 - argmax_k for M[i+1]
+    int64_t* chunk_pairs;     // [n_chunks] sum of W over the chunk
+    int32_t n_samples;
+    int32_t n_chunks;
+};
+
+struct JobStatus {            // zeroed (first_bad = ~0) before every call
+    unsigned long long first_bad;   // min over bad sites of (sample << 40 | absolute site)
+    unsigned long long total_pairs;
+    unsigned int max_window;
+    unsigned int loci_disorder;     // 1 + chunk index of a chunk whose loci are not ascending
+    unsigned int overflow;          // a chunk's pair count does not fit 32 bits
+    unsigned int pad;
+};
+
+struct StageView {            // tables produced by k_stage_plan, row `stage` of each
+    const int64_t* cbase;     // [n_stages][n_chunks] element offset of the chunk's rows in the stage's cost buffer
+    const uint32_t* cum0;     // [n_stages][n_chunks] cum32 at the chunk's first site of the stage
+    const int64_t* tbase;     // [n_stages][n_chunks+1] exclusive prefix of k_cost tiles
+    int32_t stage;
+    int32_t S;                // sites of each chunk per stage (multiple of 64)
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// k_scan: one wavefront streams one (chunk, sample) row: 64 lanes x 16 B = 512 sites per iteration.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 wg_load16_guarded(const uint8_t* row, int64_t abs_site, int64_t n_total)
+{
+    // 16-byte aligned load of 8 sites starting at abs_site (multiple of 8); bytes past the row end read as 0
+    if (abs_site + 8 <= n_total) return *reinterpret_cast<const uint4*>(row + 2 * abs_site);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (int j = 0; j < 8; j++) {
+        int64_t a = abs_site + j;
+        if (a < n_total) {
+            uint32_t m = row[2 * a], c = row[2 * a + 1];
+            w[j >> 1] |= (m | (c << 8)) << (16 * (j & 1));
+        }
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t rowid = (int64_t)blockIdx.x * (WG_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t nrows = (int64_t)J.n_chunks * J.n_samples;
+    if (rowid >= nrows) return;                       // whole wave leaves together
+    const int c = (int)(rowid / J.n_samples);
+    const int s = (int)(rowid - (int64_t)c * J.n_samples);
+    const ChunkDesc cd = J.chunks[c];
+    const uint8_t* row = J.betas + (int64_t)s * J.pitch;
+    uint2* carry = J.carry + cd.carry_off + (int64_t)s * cd.nG;
+
+    const int64_t a_abs = cd.start0 & ~7LL;           // first 16-byte aligned site of the stream
+    const int head = (int)(cd.start0 - a_abs);        // sites of the first vector that precede the chunk
+    const int64_t span = (int64_t)head + cd.len;      // sites from a_abs to the chunk end
+    uint32_t run_m = 0, run_t = 0;
+    bool bad = false;
+    int64_t bad_abs = 0;
+
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    if ((int64_t)lane * 8 < span) cur = wg_load16_guarded(row, a_abs + (int64_t)lane * 8, J.n_total);
+    for (int64_t base = 0; base < span; base += 512) {
+        const int64_t off = base + (int64_t)lane * 8;  // site offset of this lane's vector from a_abs
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (off + 512 < span) nxt = wg_load16_guarded(row, a_abs + off + 512, J.n_total);   // prefetch
+
+        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+        const int64_t rel0 = off - head;               // chunk-relative index of the vector's first site
+        // position of a 64-site boundary inside this vector (8 = none)
+        const int jstar = (int)((uint64_t)(-rel0) & 63);
+        uint32_t tm = 0, tt = 0, pm = 0, pt = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t h = w[j >> 1] >> (16 * (j & 1));
+            uint32_t m = h & 0xffu, cv = (h >> 8) & 0xffu;
+            const int64_t rel = rel0 + j;
+            const bool in = rel >= 0 && rel < cd.len;
+            if (!in) { m = 0; cv = 0; }
+            if (m > cv && !bad) { bad = true; bad_abs = cd.start0 + rel; }
+            if (j < jstar) { pm += m; pt += cv; }
+            tm += m; tt += cv;
+        }
+        // wave-wide exclusive prefix of the lane totals (two 32-bit DPP scans)
+        const uint32_t im = wg_wave_incl_scan_dpp_u32(tm);
+        const uint32_t it = wg_wave_incl_scan_dpp_u32(tt);
+        if (jstar < 8) {
+            const int64_t relb = rel0 + jstar;
+            if (relb >= 0 && relb <= cd.len)
+                carry[relb >> 6] = make_uint2(run_m + (im - tm) + pm, run_t + (it - tt) + pt);
+        }
+        run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
+        run_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
+        cur = nxt;
+    }
+    if (bad) atomicMin(&st->first_bad, ((unsigned long long)s << 40) | (unsigned long long)bad_abs);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_window: one workgroup per chunk.  W_i = number of admissible block starts for a block ending at site i:
+//   k admissible  <=>  i-k < max_cpg  and  loci[i]-loci[k] <= max_bp      (segmentor.cpp:111-117, loci ascending)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, uint32_t max_cpg, uint32_t max_bp)
+{
+    __shared__ uint32_t wsum[WG_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = blockIdx.x;
+    const ChunkDesc cd = J.chunks[c];
+    const uint32_t* loc = J.loci + cd.start0;
+    uint64_t run = 0;
+    uint32_t wmax = 0;
+    bool disorder = false;
+    for (int base = 0; base < cd.len; base += WG_BLOCK) {
+        const int i = base + tid;
+        uint32_t w = 0;
+        if (i < cd.len) {
+            const int64_t li = loc[i];
+            if (i > 0 && (int64_t)loc[i - 1] > li) disorder = true;
+            const int64_t target = li - (int64_t)max_bp;
+            int lo = i + 1 - (int)max_cpg;
+            if (lo < 0) lo = 0;
+            int hi = i;                                  // loc[i] >= target always
+            while (lo < hi) {                            // first k in [lo, i] with loc[k] >= target
+                const int mid = (lo + hi) >> 1;
+                if ((int64_t)loc[mid] >= target) hi = mid; else lo = mid + 1;
+            }
+            w = (uint32_t)(i - lo + 1);
+            J.W16[cd.site_off + i] = (uint16_t)w;
+            if (w > wmax) wmax = w;
+        }
+        const uint32_t incl = wg_wave_incl_scan_dpp_u32(w);
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t woff = 0, btot = 0;
+#pragma unroll
+        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) woff += wsum[q]; btot += wsum[q]; }
+        __syncthreads();
+        if (i < cd.len) J.cum32[cd.site_off + i] = (uint32_t)(run + woff + (incl - w));
+        run += btot;
+    }
+    wmax = wg_wave_max_u32(wmax);
+    const bool any_dis = __any(disorder);
+    if (lane == 0) {
+        atomicMax(&st->max_window, wmax);
+        if (any_dis) atomicMax(&st->loci_disorder, (unsigned int)(c + 1));
+    }
+    if (tid == 0) {
+        J.chunk_pairs[c] = (int64_t)run;
+        atomicAdd(&st->total_pairs, (unsigned long long)run);
+        if (run >> 32) atomicMax(&st->overflow, 1u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_stage_plan: one workgroup per stage; per chunk the number of scored blocks in the stage and of k_cost tiles,
+// and their exclusive prefixes over chunks.
+// ------------------------------------------------------------------------------------------------------------
+struct PlanArgs { int32_t S, TI, KT, n_stages; };
+
+__global__ __launch_bounds__(WG_BLOCK) void k_stage_plan(JobView J, PlanArgs P, int64_t* cbase, uint32_t* cum0,
+                                                         int64_t* tbase, int64_t* stage_pairs, int64_t* stage_tiles)
+{
+    __shared__ uint64_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int stg = blockIdx.x;
+    const int nC = J.n_chunks;
+    uint64_t runA = 0, runB = 0;
+    for (int base = 0; base < nC; base += WG_BLOCK) {
+        const int c = base + tid;
+        uint64_t sz = 0, nt = 0;
+        uint32_t c0 = 0;
+        if (c < nC) {
+            const ChunkDesc cd = J.chunks[c];
+            const int64_t s0 = (int64_t)stg * P.S;
+            if (s0 < cd.len) {
+                const int64_t s1 = (s0 + P.S < cd.len) ? s0 + P.S : cd.len;
+                c0 = J.cum32[cd.site_off + s0];
+                const uint64_t cend = (s1 < cd.len) ? (uint64_t)J.cum32[cd.site_off + s1] : (uint64_t)J.chunk_pairs[c];
+                sz = cend - c0;
+                nt = (uint64_t)((s1 - s0 + P.TI - 1) / P.TI) * (uint64_t)P.KT;
+            }
+        }
+        const uint64_t ia = wg_wave_incl_scan_u64(sz, lane), ib = wg_wave_incl_scan_u64(nt, lane);
+        if (lane == 63) { wa[wv] = ia; wb[wv] = ib; }
+        __syncthreads();
+        uint64_t oa = 0, ob = 0, ta = 0, tb2 = 0;
+#pragma unroll
+        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) { oa += wa[q]; ob += wb[q]; } ta += wa[q]; tb2 += wb[q]; }
+        __syncthreads();
+        if (c < nC) {
+            cbase[(int64_t)stg * nC + c] = (int64_t)(runA + oa + ia - sz);
+            cum0[(int64_t)stg * nC + c] = c0;
+            tbase[(int64_t)stg * (nC + 1) + c] = (int64_t)(runB + ob + ib - nt);
+        }
+        runA += ta; runB += tb2;
+    }
+    if (tid == 0) {
+        tbase[(int64_t)stg * (nC + 1) + nC] = (int64_t)runB;
+        stage_pairs[stg] = (int64_t)runA;
+        stage_tiles[stg] = (int64_t)runB;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_cost
+// ------------------------------------------------------------------------------------------------------------
+struct CostArgs {
+    float pc, pc2;
+    int32_t KT;        // k-tiles per i-tile (1: the whole window of the tile in one LDS array)
+    int32_t TK;        // sites per k-tile (KT > 1)
+    int32_t KS;        // uint2 entries per sample row of the K array
+    int32_t IS;        // entries per sample row of the I array (KT > 1), else 0
+    int32_t NS;        // samples per LDS group
+    int32_t pad;
+};
+
+// Stage `cnt` exclusive prefixes P[A+x], x = 0..cnt-1, of sample row `row` into dst (one wavefront).
+// A is chunk-relative and a multiple of 64, so the 64-site carry of k_scan seeds the scan.
+__device__ __forceinline__ void wg_stage_prefix_row(uint2* __restrict__ dst, const uint8_t* __restrict__ row,
+                                                    const uint2* __restrict__ carry, const ChunkDesc& cd,
+                                                    int64_t n_total, int A, int cnt, int lane)
+{
+    const uint2 c0 = carry[A >> 6];
+    uint32_t run_m = c0.x, run_t = c0.y;
+    const int64_t abs0 = cd.start0 + A;
+    const int64_t al = abs0 & ~3LL;                    // 8-byte aligned
+    const int hs = (int)(abs0 - al);
+    for (int p0 = 0; p0 < cnt + hs; p0 += 256) {
+        const int sidx = p0 + lane * 4;                // site offset from `al`
+        const int64_t a = al + sidx;
+        uint32_t w0 = 0, w1 = 0;
+        if (sidx < cnt + hs) {
+            if (a + 4 <= n_total) {
+                const uint2 v = *reinterpret_cast<const uint2*>(row + 2 * a);
+                w0 = v.x; w1 = v.y;
+            } else {
+                for (int j = 0; j < 4; j++) if (a + j < n_total) {
+                    const uint32_t h = (uint32_t)row[2 * (a + j)] | ((uint32_t)row[2 * (a + j) + 1] << 8);
+                    if (j < 2) w0 |= h << (16 * j); else w1 |= h << (16 * (j - 2));
+                }
+            }
+        }
+        uint32_t m[4], t[4];
+        uint32_t tot = 0;                              // packed lane total: meth | cov << 16 (<= 1020 each)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t h = ((j < 2) ? w0 : w1) >> (16 * (j & 1));
+            const int x = sidx + j - hs;               // entry index == site index relative to A
+            const bool in = x >= 0 && (A + x) < cd.len;
+            m[j] = in ? (h & 0xffu) : 0u;
+            t[j] = in ? ((h >> 8) & 0xffu) : 0u;
+            tot += m[j] | (t[j] << 16);
+        }
+        const uint32_t incl = wg_wave_incl_scan_dpp_u32(tot);   // <= 64*1020 = 65280 per half: no carry between halves
+        const uint32_t excl = incl - tot;
+        uint32_t em = run_m + (excl & 0xffffu), et = run_t + (excl >> 16);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = sidx + j - hs;
+            if (x >= 0 && x < cnt) dst[x] = make_uint2(em, et);
+            em += m[j]; et += t[j];
+        }
+        const uint32_t wt = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        run_m += wt & 0xffffu; run_t += wt >> 16;
+    }
+}
+
+template <int TI>
+__global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, CostArgs A, double* __restrict__ cost,
+                                                   int64_t n_tiles_padded)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wg_log_tables* tb = reinterpret_cast<wg_log_tables*>(smem);
+    uint2* Kt = reinterpret_cast<uint2*>(smem + sizeof(wg_log_tables));
+    uint2* It = Kt + (size_t)A.NS * A.KS;
+    int64_t* radj = reinterpret_cast<int64_t*>(It + (size_t)A.NS * A.IS);      // [TI]
+    int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
+    int32_t* kst = offs + (TI + 1);                                              // [TI]
+    int32_t* misc = kst + TI;                                                    // [2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nC = J.n_chunks;
+    const int64_t* tbase = SV.tbase + (int64_t)SV.stage * (nC + 1);
+    const int64_t n_tiles = tbase[nC];
+    // XCD-aware remap: consecutive tiles (which share halo sites) land on the same XCD's L2
+    const int64_t per = n_tiles_padded >> 3;
+    const int64_t t = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t >= n_tiles) return;
+
+    int clo = 0, chi = nC;                               // last chunk with tbase[c] <= t
+    while (chi - clo > 1) { const int mid = (clo + chi) >> 1; if (tbase[mid] <= t) clo = mid; else chi = mid; }
+    const int c = clo;
+    const ChunkDesc cd = J.chunks[c];
+    const int local = (int)(t - tbase[c]);
+    const int it = local / A.KT, kt = local - it * A.KT;
+    const int s0 = SV.stage * SV.S;
+    const int s1 = (s0 + SV.S < cd.len) ? s0 + SV.S : cd.len;
+    const int ia = s0 + it * TI;
+    const int ib = (ia + TI < s1) ? ia + TI : s1;
+    const int ni = ib - ia;
+    // k-tile [kt_lo, kt_hi); the last tile ends at ia+TI.  KT == 1: no restriction.
+    const int kt_hi = (A.KT > 1) ? ia + TI - (A.KT - 1 - kt) * A.TK : ia + TI;
+    const int kt_lo = (A.KT > 1) ? kt_hi - A.TK : -(1 << 30);
+    const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
+
+    {   // tables -> LDS
+        const wg_log_tables init = WG_LOG_TABLES_INIT;   // materialised from constant data
+        const double* src = reinterpret_cast<const double*>(&init);
+        double* d = reinterpret_cast<double*>(tb);
+        for (int x = tid; x < (int)(sizeof(wg_log_tables) / 8); x += WG_BLOCK) d[x] = src[x];
+    }
+    if (wv == 0) {
+        const int i = ia + lane;
+        const bool valid = lane < ni;
+        int cnt = 0, ks = 0;
+        if (valid) {
+            const int w = J.W16[cd.site_off + i];
+            const int lo = i - w + 1;
+            ks = lo > kt_lo ? lo : kt_lo;
+            const int ke = (i < kt_hi - 1) ? i : kt_hi - 1;
+            cnt = ke - ks + 1;
+            if (cnt < 0) cnt = 0;
+            if (lane < TI) {
+                radj[lane] = (int64_t)(J.cum32[cd.site_off + i] - cum0) - lo;
+                kst[lane] = ks;
+            }
+        }
+        const uint32_t incl = wg_wave_incl_scan_dpp_u32((uint32_t)cnt);
+        if (lane < TI) offs[lane + 1] = (int32_t)incl;
+        if (lane == 0) offs[0] = 0;
+        const uint32_t kmin = wg_wave_min_u32(cnt > 0 ? (uint32_t)ks : 0x7fffffffu);
+        if (lane == 0) misc[0] = (int32_t)kmin;
+    }
+    __syncthreads();
+    const int Q = offs[TI < ni ? TI : ni];
+    if (Q == 0) return;
+    const int kA = misc[0] & ~63;                        // 64-aligned start of the K array
+    int iA, ioff;                                        // I entries: index (i+1) - iA = il + ioff
+    const uint2* Ibase;
+    int Istride;
+    if (A.KT > 1) { iA = ia & ~63; Ibase = It; Istride = A.IS; }
+    else          { iA = kA;       Ibase = Kt; Istride = A.KS; }
+    ioff = ia + 1 - iA;
+    const int Kcnt = ((A.KT > 1) ? kt_hi : ib + 1) - kA;  // entries needed in the K array
+    const int Icnt = ib + 1 - iA;
+
+    // my candidate blocks: q = tid + 256 r  ->  (il, k)
+    const int R = (Q + WG_BLOCK - 1) / WG_BLOCK;
+    uint32_t pr[WG_RMAX];
+    double acc[WG_RMAX];
+#pragma unroll
+    for (int r = 0; r < WG_RMAX; r++) {
+        pr[r] = 0xffffffffu;
+        acc[r] = 0.0;
+        if (r < R) {
+            const int q = tid + WG_BLOCK * r;
+            if (q < Q) {
+                int lo = 0, hi = ni;                       // largest il with offs[il] <= q
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
+                const int k = kst[lo] + (q - offs[lo]);
+                pr[r] = (uint32_t)lo | ((uint32_t)(k - kA) << 8);
+            }
+        }
+    }
+
+    const float pc = A.pc, pc2 = A.pc2;
+    for (int g0 = 0; g0 < J.n_samples; g0 += A.NS) {
+        const int ns = (J.n_samples - g0 < A.NS) ? J.n_samples - g0 : A.NS;
+        __syncthreads();
+        for (int rr = wv; rr < ns; rr += WG_BLOCK / 64) {
+            const int s = g0 + rr;
+            const uint8_t* row = J.betas + (int64_t)s * J.pitch;
+            const uint2* carry = J.carry + cd.carry_off + (int64_t)s * cd.nG;
+            wg_stage_prefix_row(Kt + (size_t)rr * A.KS, row, carry, cd, J.n_total, kA, Kcnt, lane);
+            if (A.KT > 1) wg_stage_prefix_row(It + (size_t)rr * A.IS, row, carry, cd, J.n_total, iA, Icnt, lane);
+        }
+        __syncthreads();
+        for (int sl = 0; sl < ns; sl++) {
+            const uint2* Krow = Kt + (size_t)sl * A.KS;
+            const uint2* Irow = Ibase + (size_t)sl * Istride + ioff;
+#pragma unroll
+            for (int r = 0; r < WG_RMAX; r++) {
+                if (r < R) {
+                    if (pr[r] != 0xffffffffu) {
+                        const uint2 pi = Irow[pr[r] & 0xffu];
+                        const uint2 pk = Krow[pr[r] >> 8];
+                        const float nm = (float)(pi.x - pk.x);
+                        const float nt = (float)(pi.y - pk.y);
+                        acc[r] += (double)wg_sample_term(nm, nt, pc, pc2, tb);   // segmentor.cpp:135
+                    }
+                }
+            }
+        }
+    }
+
+    double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
+#pragma unroll
+    for (int r = 0; r < WG_RMAX; r++) {
+        if (r < R && pr[r] != 0xffffffffu) {
+            const int il = (int)(pr[r] & 0xffu);
+            const int k = (int)(pr[r] >> 8) + kA;
+            cb[radj[il] + k] = (acc[r] != 0.0) ? acc[r] : 0.0;                    // segmentor.cpp:106,137
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_dp: one wavefront per chunk.
+// ------------------------------------------------------------------------------------------------------------
+struct DpArgs { int32_t ringN; int32_t pad; };
+
+__global__ __launch_bounds__(64) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
+                                           double* __restrict__ state)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_dp[];
+    double* ring = reinterpret_cast<double*>(smem_dp);       // M[k] at slot k & (ringN-1), last >= max(64,max_cpg) values
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x;
+    const int nC = J.n_chunks;
+    const ChunkDesc cd = J.chunks[c];
+    const int s0 = SV.stage * SV.S;
+    if (s0 >= cd.len) return;
+    const int s1 = (s0 + SV.S < cd.len) ? s0 + SV.S : cd.len;
+    const int rmask = A.ringN - 1;
+    double* gs = state + (int64_t)c * A.ringN;
+    if (s0 == 0) { for (int x = lane; x < A.ringN; x += 64) ring[x] = 0.0; }       // M[0] = 0 (segmentor.cpp:97)
+    else         { for (int x = lane; x < A.ringN; x += 64) ring[x] = gs[x]; }
+    __syncthreads();
+    double mreg;                                         // M[k] of the latest k <= i with k == lane (mod 64)
+    { const int k = s0 - ((s0 - lane) & 63); mreg = (k >= 0) ? ring[k & rmask] : 0.0; }
+
+    const double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
+    const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
+    const uint16_t* Wp = J.W16 + cd.site_off;
+    const uint32_t* Cp = J.cum32 + cd.site_off;
+    const double NEG_INF = -__builtin_inf();
+
+    for (int base = s0; base < s1; base += 64) {
+        const int il = base + lane;
+        const bool inb = il < s1;
+        const uint32_t w_l = inb ? (uint32_t)Wp[il] : 1u;
+        const uint32_t rel_l = inb ? Cp[il] - cum0 : 0u;
+        uint32_t tbk = 0;
+        const int nst = (s1 - base < 64) ? s1 - base : 64;
+        for (int g = 0; g < nst; g += 8) {
+            double cv[8];
+            uint32_t ws[8], rs[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {                 // issue the loads of 8 steps up front
+                const int stp = g + u;
+                cv[u] = 0.0; ws[u] = 1; rs[u] = 0;
+                if (stp < nst) {
+                    ws[u] = (uint32_t)__builtin_amdgcn_readlane((int)w_l, stp);
+                    rs[u] = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, stp);
+                    const int i = base + stp;
+                    const int lo = i - (int)ws[u] + 1;
+                    const uint32_t j = (uint32_t)(lane - lo) & 63u;
+                    if (ws[u] <= 64u && j < ws[u]) cv[u] = cb[(int64_t)rs[u] + j];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int stp = g + u;
+                if (stp < nst) {
+                    const int i = base + stp;
+                    const uint32_t w = ws[u];
+                    const int lo = i - (int)w + 1;
+                    double vmax;
+                    int kbest;
+                    if (w <= 64u) {
+                        const uint32_t j = (uint32_t)(lane - lo) & 63u;
+                        const double v = (j < w) ? mreg + cv[u] : NEG_INF;
+                        vmax = wg_wave_max_f64(v);
+                        const unsigned long long eq = __ballot(v == vmax);
+                        const int rot = lo & 63;
+                        const unsigned long long rm = rot ? ((eq >> rot) | (eq << (64 - rot))) : eq;
+                        kbest = lo + __builtin_ctzll(rm);          // first maximum in ascending k (segmentor.cpp:148)
+                    } else {
+                        double best = NEG_INF;
+                        uint32_t bk = 0xffffffffu;
+                        for (uint32_t jj = (uint32_t)lane; jj < w; jj += 64) {
+                            const int k = lo + (int)jj;
+                            const double v = ring[k & rmask] + cb[(int64_t)rs[u] + jj];
+                            if (v > best) { best = v; bk = (uint32_t)k; }
+                        }
+                        vmax = wg_wave_max_f64(best);
+                        kbest = (int)wg_wave_min_u32(best == vmax ? bk : 0xffffffffu);
+                    }
+                    if (lane == ((i + 1) & 63)) mreg = vmax;
+                    if (lane == 0) ring[(i + 1) & rmask] = vmax;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == stp) tbk = (uint32_t)(i + 1 - kbest);
+                }
+            }
+        }
+        if (inb) J.back16[cd.site_off + il] = (uint16_t)tbk;
+    }
+    __syncthreads();
+    if (s1 < cd.len) for (int x = lane; x < A.ringN; x += 64) gs[x] = ring[x];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_trace / k_border_offsets / k_gather_borders
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_BLOCK) void k_trace(JobView J, int32_t* __restrict__ tmp, int32_t* __restrict__ nb)
+{
+    __shared__ uint16_t win[WG_TRACE_WIN];
+    __shared__ int sh_cur, sh_cnt;
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x;
+    const ChunkDesc cd = J.chunks[c];
+    int32_t* out = tmp + cd.site_off + c;                 // len+1 slots
+    const uint16_t* bk = J.back16 + cd.site_off;
+    if (tid == 0) { sh_cur = cd.len; sh_cnt = 1; out[0] = cd.len; }
+    __syncthreads();
+    int hi = cd.len;
+    while (hi > 0) {
+        const int wlo = (hi > WG_TRACE_WIN) ? hi - WG_TRACE_WIN : 0;
+        for (int x = tid; x < hi - wlo; x += WG_BLOCK) win[x] = bk[wlo + x];
+        __syncthreads();
+        if (tid == 0) {
+            int i = sh_cur, cnt = sh_cnt;
+            while (i > wlo) { i -= (int)win[i - 1 - wlo]; out[cnt++] = i; }   // i = T[i] (segmentor.cpp:55)
+            sh_cur = i; sh_cnt = cnt;
+        }
+        __syncthreads();
+        hi = sh_cur;
+        __syncthreads();
+    }
+    if (tid == 0) nb[c] = sh_cnt;
+}
+
+__global__ __launch_bounds__(WG_BLOCK) void k_border_offsets(const int32_t* __restrict__ nb, int n_chunks, int64_t* __restrict__ boff)
+{
+    __shared__ uint64_t ws[WG_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint64_t run = 0;
+    for (int base = 0; base < n_chunks; base += WG_BLOCK) {
+        const int c = base + tid;
+        const uint64_t v = (c < n_chunks) ? (uint64_t)nb[c] : 0;
+        const uint64_t incl = wg_wave_incl_scan_u64(v, lane);
+        if (lane == 63) ws[wv] = incl;
+        __syncthreads();
+        uint64_t o = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) o += ws[q]; tot += ws[q]; }
+        __syncthreads();
+        if (c < n_chunks) boff[c] = (int64_t)(run + o + incl - v);
+        run += tot;
+    }
+    if (tid == 0) boff[n_chunks] = (int64_t)run;
+}
+
+__global__ __launch_bounds__(WG_BLOCK) void k_gather_borders(JobView J, const int32_t* __restrict__ tmp, const int32_t* __restrict__ nb,
+                                                             const int64_t* __restrict__ boff, int32_t* __restrict__ out)
+{
+    const int c = blockIdx.x;
+    const ChunkDesc cd = J.chunks[c];
+    const int32_t* src = tmp + cd.site_off + c;
+    const int n = nb[c];
+    int32_t* dst = out + boff[c];
+    for (int x = threadIdx.x; x < n; x += WG_BLOCK) dst[x] = src[n - 1 - x];     // ascending (segmentor.cpp:30-34)
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// test hooks
+// ------------------------------------------------------------------------------------------------------------
+__global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, float pc, float* out)
+{
+    __shared__ wg_log_tables tb;
+    {
+        const wg_log_tables init = WG_LOG_TABLES_INIT;
+        const double* src = reinterpret_cast<const double*>(&init);
+        double* d = reinterpret_cast<double*>(&tb);
+        for (int x = threadIdx.x; x < (int)(sizeof(wg_log_tables) / 8); x += blockDim.x) d[x] = src[x];
+    }
+    __syncthreads();
+    const float pc2 = pc + pc;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x)
+        out[q] = wg_sample_term(nm[q], nt[q], pc, pc2, &tb);
+}
+
+__global__ void k_debug_log2(uint32_t first, int64_t count, uint32_t* out_f, uint64_t* out_d)
+{
+    __shared__ wg_log_tables tb;
+    {
+        const wg_log_tables init = WG_LOG_TABLES_INIT;
+        const double* src = reinterpret_cast<const double*>(&init);
+        double* d = reinterpret_cast<double*>(&tb);
+        for (int x = threadIdx.x; x < (int)(sizeof(wg_log_tables) / 8); x += blockDim.x) d[x] = src[x];
+    }
+    __syncthreads();
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x) {
+        const float p = wg_u2f(first + (uint32_t)q);
+        if (out_f) out_f[q] = wg_f2u(wg_log2f(p, tb.f_tab));
+        if (out_d) out_d[q] = wg_d2u(wg_log2(1.0 - (double)p, tb.d_tab, tb.d_tab2));
+    }
+}
+
+// Materialise P[t], t = 0..len, for one range of one sample from the carries (test / block-sum helper):
+// one wavefront per (sample, 64-site group).
+__global__ __launch_bounds__(64) void k_prefix_materialise(JobView J, int nG, uint32_t* __restrict__ out, int len)
+{
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x, s = blockIdx.y;
+    const ChunkDesc cd = J.chunks[0];
+    const uint8_t* row = J.betas + (int64_t)s * J.pitch;
+    const uint2 c0 = J.carry[cd.carry_off + (int64_t)s * cd.nG + g];
+    const int x = g * 64 + lane;
+    uint32_t m = 0, t = 0;
+    if (x < len) { m = row[2 * (cd.start0 + x)]; t = row[2 * (cd.start0 + x) + 1]; }
+    const uint32_t im = wg_wave_incl_scan_dpp_u32(m), it = wg_wave_incl_scan_dpp_u32(t);
+    uint32_t* o = out + ((int64_t)s * (len + 1)) * 2;
+    if (x < len) { o[2 * (x + 1)] = c0.x + im; o[2 * (x + 1) + 1] = c0.y + it; }
+    if (g == 0 && lane == 0) { o[0] = 0; o[1] = 0; }
+    (void)nG;
+}

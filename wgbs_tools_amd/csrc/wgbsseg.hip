@@ -1,0 +1,578 @@
+// wgbsseg.hip — host side of libwgbsseg.so: the C ABI of include/wgbsseg.h over the gfx950 kernels of
+// seg_kernels.h.  One context = one GPU (own streams, grow-only scratch in HBM).  No CPU compute path exists
+// here: without a HIP device every entry point fails.
+//
+// Build (see wgbs_tools_amd/build.py):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared wgbsseg.hip -o libwgbsseg.so
+// -ffp-contract=off is REQUIRED: the likelihood term must round exactly like the reference's x86-64 build
+// (no fused multiply-add anywhere; SURVEY.md 7 hard part 2).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wgbsseg.h"
+#include "seg_kernels.h"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+void set_err(char* err, size_t errlen, const char* fmt, ...)
+{
+    if (!err || !errlen) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err, errlen, fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            set_err(err, errlen, "HIP error %d (%s) at %s:%d: %s", (int)e__, hipGetErrorString(e__), \
+                    __FILE__, __LINE__, #expr);                                                    \
+            return WGBSSEG_E_HIP;                                                                  \
+        }                                                                                          \
+    } while (0)
+
+inline int ceil_pow2(int v) { int r = 1; while (r < v) r <<= 1; return r; }
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct wgbsseg_ctx {
+    int device = 0;
+    hipStream_t sA = nullptr, sB = nullptr;
+    // inputs
+    DevBuf betas_own, loci_own;
+    const uint8_t* betas = nullptr;
+    int64_t pitch = 0, n_total = 0;
+    int32_t n_samples = 0;
+    const uint32_t* loci = nullptr;
+    int64_t n_loci = 0;
+    // scratch
+    DevBuf chunks, carry, W16, cum32, back16, chunk_pairs, status;
+    DevBuf plan_cbase, plan_cum0, plan_tbase, plan_pairs, plan_tiles;
+    DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders, dbg_a, dbg_b, dbg_c;
+    // events
+    hipEvent_t ev[8] = {};
+    std::vector<hipEvent_t> ev_cost0, ev_cost1, ev_dp0, ev_dp1;
+    // last-call info
+    wgbsseg_timings tim = {};
+    int64_t last_sites = 0, last_pairs = 0;
+    int32_t last_stages = 0;
+    bool last_valid = false;
+    long long cost_budget_bytes = 0;
+    int force_stages = 0;
+    int force_ns = 0;
+};
+
+extern "C" {
+
+int wgbsseg_version(void) { return WGBSSEG_VERSION; }
+
+int wgbsseg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
+{
+    if (!out) { set_err(err, errlen, "out is NULL"); return WGBSSEG_E_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_err(err, errlen, "no HIP device available (%s); libwgbsseg has no CPU fallback", hipGetErrorString(e));
+        return WGBSSEG_E_HIP;
+    }
+    if (device < 0 || device >= n) { set_err(err, errlen, "device %d out of range (0..%d)", device, n - 1); return WGBSSEG_E_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (!strstr(prop.gcnArchName, "gfx950")) {
+        set_err(err, errlen, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+        return WGBSSEG_E_HIP;
+    }
+    wgbsseg_ctx* c = new (std::nothrow) wgbsseg_ctx();
+    if (!c) { set_err(err, errlen, "out of host memory"); return WGBSSEG_E_NOMEM; }
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->sA, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->sB, hipStreamNonBlocking));
+    for (auto& v : c->ev) HIP_TRY(hipEventCreate(&v));
+    const char* b = getenv("WGBSSEG_COST_BUDGET_MB");
+    c->cost_budget_bytes = (b && atoll(b) > 0 ? atoll(b) : 6144LL) << 20;
+    const char* fs = getenv("WGBSSEG_FORCE_STAGES");
+    c->force_stages = fs ? atoi(fs) : 0;
+    const char* fn = getenv("WGBSSEG_NS");
+    c->force_ns = fn ? atoi(fn) : 0;
+    *out = c;
+    return WGBSSEG_OK;
+}
+
+void wgbsseg_destroy(wgbsseg_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs,
+                     &c->status, &c->plan_cbase, &c->plan_cum0, &c->plan_tbase, &c->plan_pairs, &c->plan_tiles,
+                     &c->cost[0], &c->cost[1], &c->dpstate, &c->tmp_borders, &c->nb, &c->boff, &c->out_borders,
+                     &c->dbg_a, &c->dbg_b, &c->dbg_c};
+    for (auto* b : all) b->release();
+    for (auto& v : c->ev) if (v) (void)hipEventDestroy(v);
+    for (auto* vec : {&c->ev_cost0, &c->ev_cost1, &c->ev_dp0, &c->ev_dp1}) for (auto v : *vec) (void)hipEventDestroy(v);
+    if (c->sA) (void)hipStreamDestroy(c->sA);
+    if (c->sB) (void)hipStreamDestroy(c->sB);
+    delete c;
+}
+
+int wgbsseg_set_betas_host(wgbsseg_ctx* c, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites,
+                           char* err, size_t errlen)
+{
+    if (!c || !samples || n_samples < 1 || n_sites < 1) { set_err(err, errlen, "bad arguments to set_betas_host"); return WGBSSEG_E_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    const int64_t pitch = round_up(2 * n_sites, 256) + 256;      // slack: vector loads may run past the last site
+    HIP_TRY(c->betas_own.ensure((size_t)pitch * (size_t)n_samples));
+    for (int64_t s = 0; s < n_samples; s++) {
+        if (!samples[s]) { set_err(err, errlen, "samples[%lld] is NULL", (long long)s); return WGBSSEG_E_ARG; }
+        HIP_TRY(hipMemcpyAsync(c->betas_own.as<uint8_t>() + s * pitch, samples[s], (size_t)(2 * n_sites), hipMemcpyHostToDevice, c->sA));
+    }
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    c->betas = c->betas_own.as<uint8_t>();
+    c->pitch = pitch; c->n_total = n_sites; c->n_samples = (int32_t)n_samples;
+    c->last_valid = false;
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_set_betas_device(wgbsseg_ctx* c, const void* base, int64_t n_samples, int64_t pitch_bytes, int64_t n_sites,
+                             char* err, size_t errlen)
+{
+    if (!c || !base || n_samples < 1 || n_sites < 1 || pitch_bytes < 2 * n_sites) { set_err(err, errlen, "bad arguments to set_betas_device"); return WGBSSEG_E_ARG; }
+    if (((uintptr_t)base & 15) || (pitch_bytes & 15)) { set_err(err, errlen, "device betas base and pitch must be multiples of 16 bytes"); return WGBSSEG_E_ARG; }
+    c->betas = reinterpret_cast<const uint8_t*>(base);
+    c->pitch = pitch_bytes; c->n_total = n_sites; c->n_samples = (int32_t)n_samples;
+    c->last_valid = false;
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_set_loci_host(wgbsseg_ctx* c, const uint32_t* loci, int64_t n_sites, char* err, size_t errlen)
+{
+    if (!c || !loci || n_sites < 1) { set_err(err, errlen, "bad arguments to set_loci_host"); return WGBSSEG_E_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->loci_own.ensure((size_t)n_sites * 4));
+    HIP_TRY(hipMemcpyAsync(c->loci_own.p, loci, (size_t)n_sites * 4, hipMemcpyHostToDevice, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    c->loci = c->loci_own.as<uint32_t>();
+    c->n_loci = n_sites;
+    c->last_valid = false;
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_set_loci_device(wgbsseg_ctx* c, const void* loci, int64_t n_sites, char* err, size_t errlen)
+{
+    if (!c || !loci || n_sites < 1) { set_err(err, errlen, "bad arguments to set_loci_device"); return WGBSSEG_E_ARG; }
+    c->loci = reinterpret_cast<const uint32_t*>(loci);
+    c->n_loci = n_sites;
+    c->last_valid = false;
+    return WGBSSEG_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Host copy of the chunk table + job-wide offsets; uploads it and builds the JobView.
+struct Job {
+    std::vector<ChunkDesc> h;
+    int64_t sites = 0, carry_entries = 0;
+    int32_t max_len = 0;
+    JobStatus st0;          // source of an async H2D copy: must outlive the call's stream work
+    JobView v = {};
+};
+
+int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t n_chunks, Job& job, bool need_loci,
+              char* err, size_t errlen)
+{
+    if (!c) { set_err(err, errlen, "ctx is NULL"); return WGBSSEG_E_ARG; }
+    if (!c->betas) { set_err(err, errlen, "betas not set"); return WGBSSEG_E_STATE; }
+    if (need_loci && (!c->loci || c->n_loci != c->n_total)) { set_err(err, errlen, "loci not set or length differs from the betas (%lld vs %lld)", (long long)c->n_loci, (long long)c->n_total); return WGBSSEG_E_STATE; }
+    if (!start0 || !len || n_chunks < 1 || n_chunks > 0x7fffffff) { set_err(err, errlen, "bad chunk list"); return WGBSSEG_E_ARG; }
+    job.h.resize((size_t)n_chunks);
+    int64_t so = 0, co = 0;
+    for (int64_t i = 0; i < n_chunks; i++) {
+        if (len[i] < 1 || start0[i] < 0 || start0[i] + len[i] > c->n_total) {
+            set_err(err, errlen, "chunk %lld = [%lld, +%d) is empty or outside the %lld sites of the beta files",
+                    (long long)i, (long long)start0[i], (int)len[i], (long long)c->n_total);
+            return WGBSSEG_E_ARG;
+        }
+        ChunkDesc& d = job.h[(size_t)i];
+        d.start0 = start0[i]; d.len = len[i]; d.site_off = so; d.carry_off = co; d.nG = len[i] / WG_CARRY_G + 1;
+        so += len[i];
+        co += (int64_t)d.nG * c->n_samples;
+        job.max_len = std::max(job.max_len, len[i]);
+    }
+    job.sites = so; job.carry_entries = co;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->chunks.ensure(sizeof(ChunkDesc) * (size_t)n_chunks));
+    HIP_TRY(c->carry.ensure(sizeof(uint2) * (size_t)co));
+    HIP_TRY(c->status.ensure(sizeof(JobStatus)));
+    HIP_TRY(hipMemcpyAsync(c->chunks.p, job.h.data(), sizeof(ChunkDesc) * (size_t)n_chunks, hipMemcpyHostToDevice, c->sA));
+    memset(&job.st0, 0, sizeof(job.st0));
+    job.st0.first_bad = ~0ULL;
+    HIP_TRY(hipMemcpyAsync(c->status.p, &job.st0, sizeof(job.st0), hipMemcpyHostToDevice, c->sA));
+    JobView& v = job.v;
+    v.betas = c->betas; v.pitch = c->pitch; v.n_total = c->n_total; v.loci = c->loci;
+    v.chunks = c->chunks.as<ChunkDesc>(); v.carry = c->carry.as<uint2>();
+    v.n_samples = c->n_samples; v.n_chunks = (int32_t)n_chunks;
+    return WGBSSEG_OK;
+}
+
+int launch_scan(wgbsseg_ctx* c, const Job& job, char* err, size_t errlen)
+{
+    const int64_t rows = (int64_t)job.v.n_chunks * job.v.n_samples;
+    const int64_t blocks = (rows + (WG_BLOCK / 64) - 1) / (WG_BLOCK / 64);
+    if (blocks > 0x7fffffff) { set_err(err, errlen, "too many (chunk, sample) rows"); return WGBSSEG_E_ARG; }
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, c->sA, job.v, c->status.as<JobStatus>());
+    HIP_TRY(hipGetLastError());
+    return WGBSSEG_OK;
+}
+
+int report_bad_site(const wgbsseg_ctx* c, const JobStatus& st, char* err, size_t errlen)
+{
+    const long long s = (long long)(st.first_bad >> 40), site = (long long)(st.first_bad & ((1ULL << 40) - 1));
+    uint8_t mc[2] = {0, 0};
+    (void)hipMemcpy(mc, c->betas + s * c->pitch + 2 * site, 2, hipMemcpyDeviceToHost);
+    set_err(err, errlen, "invalid data: sample %lld (0-based, argument order), site %lld (0-based): meth %d > cov %d",
+            s, site, (int)mc[0], (int)mc[1]);
+    return WGBSSEG_E_METH_GT_COV;
+}
+
+template <int TI>
+hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a, double* cost, int64_t tiles, size_t lds, hipStream_t s)
+{
+    const int64_t padded = round_up(tiles, 8);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cost<TI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_cost<TI>, dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, cost, padded);
+    return hipGetLastError();
+}
+
+void grow_events(std::vector<hipEvent_t>& v, size_t n)
+{
+    while (v.size() < n) { hipEvent_t e; (void)hipEventCreate(&e); v.push_back(e); }
+}
+
+}  // namespace
+
+extern "C" {
+
+int wgbsseg_segment_chunks(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
+                           const wgbsseg_params* P, int32_t* borders_out, int64_t borders_cap, int64_t* borders_off,
+                           char* err, size_t errlen)
+{
+    if (!P || !borders_out || !borders_off) { set_err(err, errlen, "NULL params/borders pointer"); return WGBSSEG_E_ARG; }
+    if (P->max_bp == 0) { set_err(err, errlen, "max_bp must be >= 1 (the reference reads uninitialised loci when it is 0: segmentor.cpp:38,114)"); return WGBSSEG_E_ARG; }
+    if (P->max_cpg < 1) { set_err(err, errlen, "max_cpg must be >= 1"); return WGBSSEG_E_ARG; }
+    if (255ull * P->max_cpg >= (1ull << 24) || P->max_cpg > 16384) {
+        set_err(err, errlen, "max_cpg %u unsupported: block sums must stay exact in float (255*max_cpg < 2^24) and the DP ring must fit LDS (max_cpg <= 16384)", P->max_cpg);
+        return WGBSSEG_E_ARG;
+    }
+    if (!(P->pseudo_count >= 0.0f)) { set_err(err, errlen, "pseudo_count must be >= 0"); return WGBSSEG_E_ARG; }
+    Job job;
+    int rc = build_job(c, chunk_start0, chunk_len, n_chunks, job, true, err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
+    c->last_valid = false;
+    const int nC = (int)n_chunks;
+    const int64_t J = job.sites;
+    JobView& v = job.v;
+
+    HIP_TRY(c->W16.ensure((size_t)J * 2));
+    HIP_TRY(c->cum32.ensure((size_t)J * 4));
+    HIP_TRY(c->back16.ensure((size_t)J * 2));
+    HIP_TRY(c->chunk_pairs.ensure((size_t)nC * 8));
+    v.W16 = c->W16.as<uint16_t>(); v.cum32 = c->cum32.as<uint32_t>(); v.back16 = c->back16.as<uint16_t>();
+    v.chunk_pairs = c->chunk_pairs.as<int64_t>();
+
+    // ---- scan + validate, window extents -------------------------------------------------------------------
+    HIP_TRY(hipEventRecord(c->ev[0], c->sA));
+    rc = launch_scan(c, job, err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev[1], c->sA));
+    hipLaunchKernelGGL(k_window, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, c->status.as<JobStatus>(), P->max_cpg, P->max_bp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[2], c->sA));
+    JobStatus st;
+    HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    if (st.first_bad != ~0ULL) return report_bad_site(c, st, err, errlen);
+    if (st.loci_disorder) { set_err(err, errlen, "loci are not ascending inside chunk %u (a chunk must not cross chromosomes)", st.loci_disorder - 1); return WGBSSEG_E_LOCI_ORDER; }
+    if (st.overflow) { set_err(err, errlen, "a chunk scores more than 2^32 blocks; use a smaller chunk_size"); return WGBSSEG_E_ARG; }
+    const int Wmax = (int)st.max_window;
+    const int64_t total_pairs = (int64_t)st.total_pairs;
+
+    // ---- tiling of the scoring kernel ----------------------------------------------------------------------
+    int TI, KT = 1, TK = 0;
+    if (Wmax <= 64) TI = 64; else if (Wmax <= 128) TI = 32; else if (Wmax <= 256) TI = 16;
+    else { TI = 16; TK = 256; KT = (Wmax - 1 + TI + TK - 1) / TK; }
+    CostArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.pc = P->pseudo_count; ca.pc2 = P->pseudo_count + P->pseudo_count;
+    ca.KT = KT; ca.TK = TK;
+    ca.KS = (KT > 1) ? TK + 64 : TI + Wmax + 64;
+    ca.IS = (KT > 1) ? TI + 64 : 0;
+    int NS = c->force_ns > 0 ? c->force_ns : 16;
+    NS = std::min(NS, (int)c->n_samples);
+    const size_t lds_fixed = sizeof(wg_log_tables) + (size_t)TI * 8 + (size_t)(TI + 1) * 4 + (size_t)TI * 4 + 16;
+    while (NS > 1 && lds_fixed + (size_t)NS * (ca.KS + ca.IS) * 8 > 60 * 1024) NS--;
+    ca.NS = NS;
+    const size_t lds_cost = round_up((int64_t)(lds_fixed + (size_t)NS * (ca.KS + ca.IS) * 8), 16);
+
+    // ---- stages: bound the scored-block buffer and overlap scoring (stream A) with the recurrence (stream B) --
+    int n_stages = 1;
+    {
+        const long long bytes = total_pairs * 8;
+        n_stages = (int)std::max<long long>(1, (bytes + c->cost_budget_bytes - 1) / c->cost_budget_bytes);
+        if (job.max_len >= 8192) n_stages = std::max(n_stages, 4);
+        if (c->force_stages > 0) n_stages = c->force_stages;
+        n_stages = std::min<int>(n_stages, std::max(1, (job.max_len + 63) / 64));
+    }
+    const int S = (int)round_up((job.max_len + n_stages - 1) / n_stages, 64);
+    n_stages = (job.max_len + S - 1) / S;
+    HIP_TRY(c->plan_cbase.ensure((size_t)n_stages * nC * 8));
+    HIP_TRY(c->plan_cum0.ensure((size_t)n_stages * nC * 4));
+    HIP_TRY(c->plan_tbase.ensure((size_t)n_stages * (nC + 1) * 8));
+    HIP_TRY(c->plan_pairs.ensure((size_t)n_stages * 8));
+    HIP_TRY(c->plan_tiles.ensure((size_t)n_stages * 8));
+    PlanArgs pa = {S, TI, KT, n_stages};
+    hipLaunchKernelGGL(k_stage_plan, dim3((unsigned)n_stages), dim3(WG_BLOCK), 0, c->sA, v, pa, c->plan_cbase.as<int64_t>(),
+                       c->plan_cum0.as<uint32_t>(), c->plan_tbase.as<int64_t>(), c->plan_pairs.as<int64_t>(), c->plan_tiles.as<int64_t>());
+    HIP_TRY(hipGetLastError());
+    std::vector<int64_t> stage_pairs((size_t)n_stages), stage_tiles((size_t)n_stages);
+    HIP_TRY(hipMemcpyAsync(stage_pairs.data(), c->plan_pairs.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipMemcpyAsync(stage_tiles.data(), c->plan_tiles.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipEventRecord(c->ev[3], c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    int64_t max_stage_pairs = 1;
+    for (auto x : stage_pairs) max_stage_pairs = std::max(max_stage_pairs, x);
+    const int nbuf = n_stages > 1 ? 2 : 1;
+    for (int b = 0; b < nbuf; b++) HIP_TRY(c->cost[b].ensure((size_t)max_stage_pairs * 8));
+    const int ringN = ceil_pow2(std::max<int>(64, (int)P->max_cpg));
+    if (n_stages > 1) HIP_TRY(c->dpstate.ensure((size_t)nC * ringN * 8));
+    HIP_TRY(c->tmp_borders.ensure((size_t)(J + nC) * 4));
+    HIP_TRY(c->nb.ensure((size_t)nC * 4));
+    HIP_TRY(c->boff.ensure((size_t)(nC + 1) * 8));
+    HIP_TRY(c->out_borders.ensure((size_t)(J + nC) * 4));
+    grow_events(c->ev_cost0, n_stages); grow_events(c->ev_cost1, n_stages);
+    grow_events(c->ev_dp0, n_stages); grow_events(c->ev_dp1, n_stages);
+    static bool dp_attr = false;
+    if (!dp_attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dp_attr = true; }
+
+    StageView sv;
+    sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbase = c->plan_tbase.as<int64_t>();
+    sv.S = S;
+    DpArgs da = {ringN, 0};
+    for (int stg = 0; stg < n_stages; stg++) {
+        sv.stage = stg;
+        double* cbuf = c->cost[stg % nbuf].as<double>();
+        if (stg >= nbuf) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev_dp1[stg - nbuf], 0));   // buffer free again
+        HIP_TRY(hipEventRecord(c->ev_cost0[stg], c->sA));
+        if (stage_tiles[stg] > 0) {
+            hipError_t e;
+            if (TI == 64) e = launch_cost<64>(v, sv, ca, cbuf, stage_tiles[stg], lds_cost, c->sA);
+            else if (TI == 32) e = launch_cost<32>(v, sv, ca, cbuf, stage_tiles[stg], lds_cost, c->sA);
+            else e = launch_cost<16>(v, sv, ca, cbuf, stage_tiles[stg], lds_cost, c->sA);
+            HIP_TRY(e);
+        }
+        HIP_TRY(hipEventRecord(c->ev_cost1[stg], c->sA));
+        HIP_TRY(hipStreamWaitEvent(c->sB, c->ev_cost1[stg], 0));
+        HIP_TRY(hipEventRecord(c->ev_dp0[stg], c->sB));
+        hipLaunchKernelGGL(k_dp, dim3((unsigned)nC), dim3(64), (size_t)ringN * 8, c->sB, v, sv, cbuf, da, c->dpstate.as<double>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_dp1[stg], c->sB));
+    }
+    // ---- traceback, compaction, copy out ---------------------------------------------------------------------
+    HIP_TRY(hipEventRecord(c->ev[4], c->sB));
+    hipLaunchKernelGGL(k_trace, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sB, v, c->tmp_borders.as<int32_t>(), c->nb.as<int32_t>());
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_border_offsets, dim3(1), dim3(WG_BLOCK), 0, c->sB, c->nb.as<int32_t>(), nC, c->boff.as<int64_t>());
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_gather_borders, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sB, v, c->tmp_borders.as<int32_t>(), c->nb.as<int32_t>(),
+                       c->boff.as<int64_t>(), c->out_borders.as<int32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[5], c->sB));
+    HIP_TRY(hipMemcpyAsync(borders_off, c->boff.p, (size_t)(nC + 1) * 8, hipMemcpyDeviceToHost, c->sB));
+    HIP_TRY(hipStreamSynchronize(c->sB));
+    const int64_t total_b = borders_off[nC];
+    if (total_b > borders_cap) { set_err(err, errlen, "borders_out too small: need %lld ints, have %lld", (long long)total_b, (long long)borders_cap); return WGBSSEG_E_CAPACITY; }
+    HIP_TRY(hipMemcpyAsync(borders_out, c->out_borders.p, (size_t)total_b * 4, hipMemcpyDeviceToHost, c->sB));
+    HIP_TRY(hipEventRecord(c->ev[6], c->sB));
+    HIP_TRY(hipStreamSynchronize(c->sB));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+
+    // ---- timings ---------------------------------------------------------------------------------------------
+    wgbsseg_timings& T = c->tim;
+    memset(&T, 0, sizeof(T));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); T.scan_ms = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); T.window_ms = ms;
+    for (int stg = 0; stg < n_stages; stg++) {
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_cost0[stg], c->ev_cost1[stg])); T.cost_ms += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_dp0[stg], c->ev_dp1[stg])); T.dp_ms += ms;
+    }
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5])); T.trace_ms = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[6])); T.total_ms = ms;
+    T.sites = J; T.pairs = total_pairs; T.evals = total_pairs * c->n_samples;
+    T.scan_bytes = 2 * J * c->n_samples; T.max_window = Wmax; T.n_stages = n_stages; T.scan_launches = 1;
+    c->last_sites = J; c->last_pairs = total_pairs; c->last_stages = n_stages; c->last_valid = true;
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_segment_chunks_host(const uint8_t* betas, int64_t n_samples, int64_t sample_pitch_bytes, int64_t n_sites_total,
+                                const uint32_t* loci, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
+                                const wgbsseg_params* params, int device, int32_t* borders_out, int64_t borders_cap,
+                                int64_t* borders_off, char* err, size_t errlen)
+{
+    if (!betas || n_samples < 1 || sample_pitch_bytes < 2 * n_sites_total) { set_err(err, errlen, "bad beta buffer"); return WGBSSEG_E_ARG; }
+    wgbsseg_ctx* c = nullptr;
+    int rc = wgbsseg_create(device, &c, err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
+    std::vector<const uint8_t*> ptrs((size_t)n_samples);
+    for (int64_t s = 0; s < n_samples; s++) ptrs[(size_t)s] = betas + s * sample_pitch_bytes;
+    rc = wgbsseg_set_betas_host(c, ptrs.data(), n_samples, n_sites_total, err, errlen);
+    if (rc == WGBSSEG_OK) rc = wgbsseg_set_loci_host(c, loci, n_sites_total, err, errlen);
+    if (rc == WGBSSEG_OK) rc = wgbsseg_segment_chunks(c, chunk_start0, chunk_len, n_chunks, params, borders_out, borders_cap, borders_off, err, errlen);
+    wgbsseg_destroy(c);
+    return rc;
+}
+
+int wgbsseg_scan_only(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks, int repeat,
+                      double* ms_per_launch, int64_t* bytes_per_launch, char* err, size_t errlen)
+{
+    Job job;
+    int rc = build_job(c, chunk_start0, chunk_len, n_chunks, job, false, err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
+    if (repeat < 1) repeat = 1;
+    rc = launch_scan(c, job, err, errlen);                     // warm-up
+    if (rc != WGBSSEG_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev[0], c->sA));
+    for (int r = 0; r < repeat; r++) { rc = launch_scan(c, job, err, errlen); if (rc != WGBSSEG_OK) return rc; }
+    HIP_TRY(hipEventRecord(c->ev[1], c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    if (ms_per_launch) *ms_per_launch = (double)ms / repeat;
+    if (bytes_per_launch) *bytes_per_launch = 2 * job.sites * c->n_samples;
+    JobStatus st;
+    HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    if (st.first_bad != ~0ULL) return report_bad_site(c, st, err, errlen);
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_prefix_sums(wgbsseg_ctx* c, int64_t start0, int64_t len, uint32_t* out, char* err, size_t errlen)
+{
+    if (!out || len < 1 || len > 0x7fffffff) { set_err(err, errlen, "bad arguments to prefix_sums"); return WGBSSEG_E_ARG; }
+    const int32_t l32 = (int32_t)len;
+    Job job;
+    int rc = build_job(c, &start0, &l32, 1, job, false, err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
+    rc = launch_scan(c, job, err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
+    const size_t bytes = (size_t)c->n_samples * (size_t)(len + 1) * 8;
+    HIP_TRY(c->dbg_a.ensure(bytes));
+    const int nG = (int)((len + 63) / 64);
+    hipLaunchKernelGGL(k_prefix_materialise, dim3((unsigned)nG, (unsigned)c->n_samples), dim3(64), 0, c->sA, job.v, nG, c->dbg_a.as<uint32_t>(), l32);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->dbg_a.p, bytes, hipMemcpyDeviceToHost, c->sA));
+    JobStatus st;
+    HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    if (st.first_bad != ~0ULL) return report_bad_site(c, st, err, errlen);
+    c->last_valid = false;
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_get_timings(const wgbsseg_ctx* c, wgbsseg_timings* out)
+{
+    if (!c || !out) return WGBSSEG_E_ARG;
+    *out = c->tim;
+    return WGBSSEG_OK;
+}
+
+int64_t wgbsseg_debug_fetch(wgbsseg_ctx* c, const char* what, void* out, int64_t cap_bytes)
+{
+    if (!c || !what || !out || !c->last_valid) return WGBSSEG_E_STATE;
+    const void* src = nullptr;
+    int64_t bytes = 0;
+    if (!strcmp(what, "window")) { src = c->W16.p; bytes = c->last_sites * 2; }
+    else if (!strcmp(what, "cum")) { src = c->cum32.p; bytes = c->last_sites * 4; }
+    else if (!strcmp(what, "back")) { src = c->back16.p; bytes = c->last_sites * 2; }
+    else if (!strcmp(what, "cost")) { if (c->last_stages != 1) return WGBSSEG_E_STATE; src = c->cost[0].p; bytes = c->last_pairs * 8; }
+    else return WGBSSEG_E_ARG;
+    if (bytes > cap_bytes) return WGBSSEG_E_CAPACITY;
+    if (hipSetDevice(c->device) != hipSuccess) return WGBSSEG_E_HIP;
+    if (hipMemcpy(out, src, (size_t)bytes, hipMemcpyDeviceToHost) != hipSuccess) return WGBSSEG_E_HIP;
+    return bytes;
+}
+
+int wgbsseg_debug_sample_terms(wgbsseg_ctx* c, const float* nmeth, const float* ntotal, int64_t count, float pseudo_count, float* out)
+{
+    char* err = nullptr; size_t errlen = 0;
+    if (!c || !nmeth || !ntotal || !out || count < 1) return WGBSSEG_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->dbg_a.ensure((size_t)count * 4)); HIP_TRY(c->dbg_b.ensure((size_t)count * 4)); HIP_TRY(c->dbg_c.ensure((size_t)count * 4));
+    HIP_TRY(hipMemcpyAsync(c->dbg_a.p, nmeth, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
+    HIP_TRY(hipMemcpyAsync(c->dbg_b.p, ntotal, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
+    const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_debug_terms, dim3(blocks), dim3(256), 0, c->sA, c->dbg_a.as<float>(), c->dbg_b.as<float>(), count, pseudo_count, c->dbg_c.as<float>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->dbg_c.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_debug_log2(wgbsseg_ctx* c, uint32_t first_bits, int64_t count, uint32_t* out_f, uint64_t* out_d)
+{
+    char* err = nullptr; size_t errlen = 0;
+    if (!c || count < 1 || (!out_f && !out_d)) return WGBSSEG_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    if (out_f) HIP_TRY(c->dbg_a.ensure((size_t)count * 4));
+    if (out_d) HIP_TRY(c->dbg_b.ensure((size_t)count * 8));
+    const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_debug_log2, dim3(blocks), dim3(256), 0, c->sA, first_bits, count, out_f ? c->dbg_a.as<uint32_t>() : nullptr,
+                       out_d ? c->dbg_b.as<uint64_t>() : nullptr);
+    HIP_TRY(hipGetLastError());
+    if (out_f) HIP_TRY(hipMemcpyAsync(out_f, c->dbg_a.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->sA));
+    if (out_d) HIP_TRY(hipMemcpyAsync(out_d, c->dbg_b.p, (size_t)count * 8, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    return WGBSSEG_OK;
+}
+
+}  // extern "C"

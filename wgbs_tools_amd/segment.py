@@ -1,0 +1,456 @@
+#!/usr/bin/python3 -u
+"""`wgbstools segment` on MI355X: the driver side of the hot path.
+
+Mirrors the interface of the reference's src/python/segment.py (same flags, defaults, stderr text, exceptions,
+block-BED output) so that it is a drop-in for that command, but replaces its process fan-out
+(`Pool.starmap(segment_process)` launching one `tabix | cut | segmentor` pipeline per chunk, segment.py:41-59,
+144-146) by ONE batched call through the C ABI into the HIP kernels (wgbs_tools_amd/_lib.py ->
+csrc/libwgbsseg.so).  Chunk grid (segment.py:124-135) and junction stitching (segment.py:199-252) are kept
+exactly, because the running double sums of the DP make the chunk grid part of the bit-exact answer.
+
+There is no CPU fallback: without the HIP library and a gfx950 device `segment` fails.
+"""
+import argparse
+import multiprocessing
+import os
+import sys
+
+import numpy as np
+
+from .genome import (GenomeRefPaths, GenomicRegion, IllegalArgumentError, beta_sanity_check, eprint, write_bed)
+
+DEF_CHUNK = 60000
+
+
+# ------------------------------------------------------------------------------------------------------------
+# chunk engine: (start, end) 1-based half-open CpG ranges -> absolute border arrays
+# ------------------------------------------------------------------------------------------------------------
+class HipEngine:
+    """Resident betas + loci on one GPU; `segment_many` is the batched form of segment_process (segment.py:41-59)."""
+
+    def __init__(self, betas, genome, device=0, site_range=None):
+        from . import _lib                     # raises NativeLibraryError if libwgbsseg.so is not built
+        self._seg = _lib.Segmenter(device)
+        nr = genome.get_nr_sites()
+        lo, hi = (0, nr) if site_range is None else (max(0, site_range[0]), min(nr, site_range[1]))
+        self.base = lo                                           # 0-based site index of the first resident site
+        maps = [np.memmap(b, dtype=np.uint8, mode='r') for b in betas]
+        self._seg.set_betas([m[2 * lo:2 * hi] for m in maps])
+        self._seg.set_loci(genome.loci()[lo:hi])
+
+    def segment_many(self, sites_list, params):
+        """sites_list: [(start, end), ...] 1-based half-open; returns [np.int64 array of absolute borders, ...]."""
+        out = [None] * len(sites_list)
+        idx, st0, ln = [], [], []
+        for i, (start, end) in enumerate(sites_list):
+            assert end - start > 0, f'trying to segment an empty interval {(start, end)}'
+            if end - start == 1:                                 # segment.py:45-46
+                out[i] = np.array([start, end])
+            else:
+                idx.append(i)
+                st0.append(start - 1 - self.base)
+                ln.append(end - start)
+        if idx:
+            try:
+                res = self._seg.segment_chunks(st0, ln, params['pcount'], params['max_cpg'], params['max_bp'])
+            except Exception as e:
+                eprint(f'Failed in sites {sites_list[idx[0]]} .. {sites_list[idx[-1]]}')   # segment.py:57-59
+                raise e
+            for i, r in zip(idx, res):
+                out[i] = r.astype(np.int64) + sites_list[i][0]
+        return out
+
+    def timings(self):
+        return self._seg.timings()
+
+    def close(self):
+        self._seg.close()
+
+
+def segment_process(params):
+    """segment.py:41-59 for a single chunk (kept for interface parity; the driver itself batches)."""
+    return params['engine'].segment_many([params['sites']], params)[0]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# stitching (segment.py:199-252), restated with numpy set operations instead of pandas
+# ------------------------------------------------------------------------------------------------------------
+def find_dups(b1, b2):
+    """segment.py:239-240: mask over concatenate([b1, b2]) of the values that occur more than once."""
+    cat = np.concatenate([b1, b2])
+    _, inv, cnt = np.unique(cat, return_inverse=True, return_counts=True)
+    return cnt[inv] > 1
+
+
+def is_2_overlap(b1, b2):
+    return np.sum(find_dups(b1, b2))
+
+
+def merge2(b1, b2):
+    """segment.py:243-246"""
+    nr_from_df1 = np.argmax(find_dups(b1, b2))
+    skip_from_df2 = np.searchsorted(b2, b1[nr_from_df1])
+    return np.concatenate([b1[:nr_from_df1 + 1], b2[skip_from_df2 + 1:]]).copy()
+
+
+def increase_patch(pre_size, maxval):
+    """segment.py:249-252"""
+    if pre_size == maxval:
+        return maxval + 1
+    return int(min(pre_size * 2, maxval))
+
+
+STITCH_FAIL_MSG = '[wt segment] Patch stitching Failed! ' \
+                  '             Try increasing chunk size (--chunk_size flag)'
+
+
+class _Stitch:
+    """State machine of one stitch_2_dfs call (segment.py:199-232): `want()` names the patch it needs next,
+    `feed(patch)` consumes it; lets many junctions share one GPU batch per attempt."""
+
+    def __init__(self, b1, b2):
+        if b1[-1] != b2[0]:
+            msg = '[wt segment] Patch stitching Failed! ' \
+                  '             patches are not supposed to be merged'
+            raise IllegalArgumentError(msg)
+        self.b1, self.b2 = b1, b2
+        self.n1 = b1[-1] - b1[0]
+        self.n2 = b2[-1] - b2[0]
+        self.p1 = min(50, self.n1)
+        self.p2 = min(50, self.n2)
+        self.result = None
+
+    def want(self):
+        if self.result is not None:
+            return None
+        if not (self.p1 <= self.n1 and self.p2 <= self.n2):
+            raise IllegalArgumentError(STITCH_FAIL_MSG)
+        return (int(self.b1[-1] - self.p1), int(self.b1[-1] + self.p2))
+
+    def feed(self, patch):
+        o1 = is_2_overlap(self.b1, patch)
+        o2 = is_2_overlap(patch, self.b2)
+        if o1 and o2:
+            self.result = merge2(merge2(self.b1, patch), self.b2)
+        else:
+            if not o1:
+                self.p1 = increase_patch(self.p1, self.n1)
+            if not o2:
+                self.p2 = increase_patch(self.p2, self.n2)
+
+
+def stitch_2_dfs(b1, b2, params):
+    """segment.py:199-232 (one junction; patches come from params['engine'])."""
+    st = _Stitch(b1, b2)
+    while st.result is None:
+        sites = st.want()
+        st.feed(params['engine'].segment_many([sites], params)[0])
+    return st.result
+
+
+def stitch_round(pairs, params, cache):
+    """All junctions of one pairwise-reduce round (segment.py:159-161) together: every attempt's patches go to
+    the GPU as one batch.  The patch DP is a pure function of (start, end), so results are cached."""
+    states = [_Stitch(b1, b2) for b1, b2 in pairs]
+    while True:
+        need = {}
+        for st in states:
+            w = st.want()
+            if w is not None and w not in cache:
+                need[w] = None
+        if need:
+            keys = list(need)
+            for k, r in zip(keys, params['engine'].segment_many(keys, params)):
+                cache[k] = r
+        pending = False
+        for st in states:
+            w = st.want()
+            if w is not None:
+                st.feed(cache[w])
+                pending = pending or st.result is None
+        if not pending:
+            return [st.result for st in states]
+
+
+class SegmentByChunks:
+    def __init__(self, args, betas, engine=None):
+        self.betas = betas
+        max_cpg = min(args.max_cpg, args.max_bp // 2)            # segment.py:65
+        assert max_cpg > 1
+        self.genome = GenomeRefPaths(args.genome)
+        self.param_dict = {'betas': betas,
+                           'pcount': args.pcount,
+                           'max_cpg': max_cpg,
+                           'max_bp': args.max_bp,
+                           'genome': self.genome,
+                           'engine': engine}
+        self.args = args
+        self.validate_genome()
+
+    def validate_genome(self):                                   # segment.py:78-82
+        for beta in self.betas:
+            if not beta_sanity_check(beta, self.genome):
+                msg = f'[wt segment] ERROR: current genome reference ({self.genome.genome}) does not match the input beta file ({beta}).'
+                raise IllegalArgumentError(msg)
+
+    def regions(self):
+        """The (startCpG, endCpG) rows break_to_chunks iterates over (segment.py:95-122)."""
+        if self.args.bed_file:
+            df = load_blocks_file(self.args.bed_file)
+            is_nice, msg = is_block_file_nice(df)
+            if not is_nice:
+                msg = '[wt segment] ERROR: invalid bed file.\n' \
+                      f'                    {msg}\n' \
+                      f'                    Try: sort -k1,1 -k2,2n {self.args.bed_file} | ' \
+                      'bedtools merge -i - | wgbstools convert --drop_empty -p -L -'
+                eprint(msg)
+                raise IllegalArgumentError('Invalid bed file')
+            if df.shape[0] > 2 * 1e4:
+                msg = '[wt segment] WARNING: bed file contains many regions.\n' \
+                      '                      Segmentation will take a long time.\n' \
+                      '                      Consider running w/o -L flag and intersect the results\n'
+                eprint(msg)
+            return [(int(s), int(e)) for s, e in df]
+        gr = GenomicRegion(self.args, genome=self.genome)
+        if gr.is_whole():
+            _, sizes = self.genome.get_chrom_cpg_sizes()
+            ends = np.cumsum(sizes) + 1
+            starts = ends - sizes
+            return [(int(s), int(e)) for s, e in zip(starts, ends)]
+        return [tuple(int(x) for x in gr.sites)]
+
+    def break_to_chunks(self):
+        """ Break range of sites to chunks of size 'step',
+            while keeping chromosomes separated  (segment.py:84-135)"""
+        step = self.args.chunk_size
+        if step < self.args.max_cpg:
+            msg = '[wt segment] WARNING: chunk_size is small compared to max_cpg and/or max_bp.\n' \
+                  '                      It may cause wt segment to fail. It\'s best setting\n' \
+                  '                      chunk_size > min{max_cpg, max_bp/2}'
+            eprint(msg)
+        tags, starts, ends = [], [], []
+        for start, end in self.regions():
+            bords = list(range(start, end, step)) + [end]
+            tags += [f'{start}-{end}'] * (len(bords) - 1)
+            starts += bords[:-1]
+            ends += bords[1:]
+        return tags, starts, ends
+
+    def run(self):
+        tags, starts, ends = self.break_to_chunks()
+        own_engine = self.param_dict['engine'] is None
+        if own_engine:
+            lo = min(starts) - 1 if starts else 0
+            hi = max(ends) - 1 if ends else 0
+            self.param_dict['engine'] = HipEngine(self.betas, self.genome, device=getattr(self.args, 'device', 0),
+                                                  site_range=(lo, hi))
+        try:
+            arr = self.param_dict['engine'].segment_many(list(zip(starts, ends)), self.param_dict)
+            # merge chunks from the same "tag" group (segment.py:148-154); all groups advance round by round together
+            groups = {}
+            for i, t in enumerate(tags):
+                groups.setdefault(t, []).append(arr[i])
+            merged = self.merge_groups(groups)
+        finally:
+            if own_engine:
+                self.param_dict['engine'].close()
+                self.param_dict['engine'] = None
+        s = np.concatenate([m[:-1] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
+        e = np.concatenate([m[1:] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
+        self.dump_result(s, e)
+
+    def merge_groups(self, groups):
+        """merge_df_list (segment.py:157-165) for every tag at once: the pairing order inside a tag is the
+        reference's ((0,1),(2,3),.. then again on the merged list); rounds of different tags share GPU batches."""
+        lists = {t: list(v) for t, v in groups.items()}
+        cache = {}
+        while any(len(v) > 1 for v in lists.values()):
+            pairs, owner = [], []
+            for t, dflist in lists.items():
+                if len(dflist) > 1:
+                    for i in range(1, len(dflist), 2):
+                        pairs.append((dflist[i - 1], dflist[i]))
+                        owner.append(t)
+            res = stitch_round(pairs, self.param_dict, cache)
+            new = {t: [] for t in lists}
+            for t, r in zip(owner, res):
+                new[t].append(r)
+            for t, dflist in lists.items():
+                if len(dflist) > 1:
+                    last = [dflist[-1]] if len(dflist) % 2 else []
+                    lists[t] = new[t] + last
+        return {t: v[0] for t, v in lists.items()}
+
+    def merge_df_list(self, dflist, pool=None):
+        """segment.py:157-165 for one tag."""
+        return self.merge_groups({'x': dflist})['x']
+
+    def dump_result(self, start_cpg, end_cpg):
+        """segment.py:167-190"""
+        if start_cpg.size == 0:
+            eprint('Empty blocks array')
+            return
+        nr_blocks = start_cpg.size
+        order = np.argsort(start_cpg, kind='stable')
+        s, e = start_cpg[order], end_cpg[order]
+        keep = (e - s) > self.args.min_cpg - 1
+        s, e = s[keep], e[keep]
+        nr_blocks_filt = s.size
+        nr_dropped = nr_blocks - nr_blocks_filt
+        eprint(f'[wt segment] found {nr_blocks_filt:,} blocks\n'
+               f'             (dropped {nr_dropped:,} short blocks)')
+        write_bed(self.genome, s, e, self.args.out_path)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# -L blocks file (beta_to_blocks.py:50-91 load_blocks_file, segment.py:25-38 is_block_file_nice)
+# ------------------------------------------------------------------------------------------------------------
+def load_blocks_file(blocks_path):
+    """(startCpG, endCpG) int rows of a 5-column blocks BED (header line and '#' comments tolerated, rows with
+    missing CpG columns dropped: segment.py:96 `.dropna()`)."""
+    import gzip
+    if not os.path.isfile(blocks_path):
+        raise IllegalArgumentError(f'No such file: {blocks_path}')
+    opener = gzip.open if blocks_path.endswith('.gz') else open
+    rows = []
+    first = True
+    with opener(blocks_path, 'rt') as f:
+        for line in f:
+            if not line.strip() or line.startswith('#'):
+                continue
+            tok = line.rstrip('\n').split('\t')
+            if first:
+                first = False
+                if len(tok) < 5:
+                    msg = f'Invalid blocks file: {blocks_path}. less than 5 columns.\n'
+                    msg += f'Run wgbstools convert -L {blocks_path} -o OUTPUT_REGION_FILE to add the CpG columns'
+                    raise IllegalArgumentError(msg)
+                if not tok[1].isdigit():
+                    continue                                     # header row
+            if len(tok) < 5 or tok[3] in ('', 'NA') or tok[4] in ('', 'NA'):
+                continue
+            s, e = int(tok[3]), int(tok[4])
+            if e - s < 0:
+                raise IllegalArgumentError(f'Invalid CpG columns in blocks file {blocks_path}')
+            rows.append((s, e))
+    return np.array(rows, dtype=np.int64).reshape(-1, 2)
+
+
+def is_block_file_nice(df):
+    """segment.py:25-38"""
+    if df.shape[0] != np.unique(df, axis=0).shape[0]:
+        return False, 'Some blocks are duplicated'
+    sdf = df[np.argsort(df[:, 0], kind='stable')]
+    if not (sdf[1:, 0] - sdf[:-1, 1] >= 0).all():
+        return False, 'Some blocks overlap'
+    return True, ''
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Main (segment.py:261-313)
+# ------------------------------------------------------------------------------------------------------------
+def add_GR_args(parser, required=False, bed_file=False):
+    """utils_wgbs.py:233-247"""
+    region_or_sites = parser.add_mutually_exclusive_group(required=required)
+    region_or_sites.add_argument('-s', '--sites', help='a CpG index range, of the form: "450000-450050"')
+    region_or_sites.add_argument('-r', '--region', help='genomic region of the form "chr1:10,000-10,500"')
+    region_or_sites.add_argument('--array_id', help='Illumina array id, e.g. cg00001755')
+    if bed_file:
+        region_or_sites.add_argument('-L', '--bed_file', help='Bed file. Columns <chr, start, end>. '
+                                     'For some features columns 4-5 should be <startCpG, endCpG> (run wgbstools convert -L BED_PATH)')
+    parser.add_argument('--genome', help='Genome reference name. Default is "default".', default='default')
+    return region_or_sites
+
+
+def add_multi_thread_args(parser):
+    """utils_wgbs.py:250-260 (kept for command-line compatibility; the GPU path does not fork workers)."""
+    try:
+        cpu_env = 'SLURM_JOB_CPUS_PER_NODE'
+        if cpu_env in os.environ.keys():
+            def_cpus = int(os.environ[cpu_env])
+        else:
+            def_cpus = multiprocessing.cpu_count()
+    except Exception:
+        def_cpus = 8
+    parser.add_argument('-@', '--threads', type=int, default=def_cpus,
+                        help='Number of threads to use (default: all available CPUs)')
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description=main.__doc__)
+    add_GR_args(parser, bed_file=True)
+    betas_or_file = parser.add_mutually_exclusive_group(required=True)
+    betas_or_file.add_argument('--betas', nargs='+')
+    betas_or_file.add_argument('--beta_file', '-F')
+    parser.add_argument('-c', '--chunk_size', type=int, default=DEF_CHUNK,
+                        help=f'Chunk size. Default {DEF_CHUNK} sites')
+    parser.add_argument('-p', '--pcount', type=float, default=15,
+                        help='Pseudo counts of C\'s and T\'s in each block. Default 15')
+    parser.add_argument('--min_cpg', type=int, default=1,
+                        help='Minimal block size (in #sites) to output. Shorter blocks will simply be '
+                             'ommited from output (equivalent to set min_cpg to 1 and then filter output by '
+                             'length). Default is 1')
+    parser.add_argument('--max_cpg', type=int, default=1000,
+                        help='Maximal allowed block size (in #sites). Default is 1000')
+    parser.add_argument('--max_bp', type=int, default=2000,
+                        help='Maximal allowed block size (in bp). Default is 2000')
+    parser.add_argument('-o', '--out_path', default=sys.stdout,
+                        help='output path [stdout]')
+    add_multi_thread_args(parser)
+    parser.add_argument('--device', type=int, default=0, help='HIP device index [0]')
+    return parser.parse_args(argv)
+
+
+def validate_single_file(fpath, suff=None):
+    """utils_wgbs.py:383-406"""
+    if fpath is None:
+        raise IllegalArgumentError("Input file is None")
+    if not os.path.isfile(fpath):
+        raise IllegalArgumentError(f'No such file: {fpath}')
+    if suff is not None and not fpath.endswith(suff):
+        raise IllegalArgumentError(f'file {fpath} must end with {suff}')
+    return fpath
+
+
+def validate_file_list(files, min_len=1):
+    """utils_wgbs.py:355-380"""
+    if len(files) < min_len:
+        raise IllegalArgumentError(f'Input error: at least {min_len} input files must be given')
+    first = files[0]
+    if len(first) == 1:
+        raise IllegalArgumentError(f'Input is not a list of files: {files}')
+    suff = os.path.splitext(first)[1]
+    for fpath in files:
+        validate_single_file(fpath, suff)
+    if suff != '.beta':
+        # the reference's segmentor silently ignores argv tokens that do not end in ".beta" (main.cpp:101-107)
+        raise IllegalArgumentError(f'segment reads uint8 .beta files; got {first}')
+
+
+def parse_betas_input(args):
+    """segment.py:285-301"""
+    if args.betas:
+        betas = args.betas
+    elif args.beta_file:
+        validate_single_file(args.beta_file)
+        with open(args.beta_file, 'r') as f:
+            betas = [b.strip() for b in f.readlines() if b.strip() and not b.startswith('#')]
+        if not betas:
+            raise IllegalArgumentError(f'no beta files found in file {args.beta_file}')
+    validate_file_list(betas)
+    return betas
+
+
+def main(argv=None):
+    """
+    Segment the genome, or a subset region, to homogenously methylated blocks.
+    Input: one or more beta files to segment
+    Output: blocks file (BED format + startCpG, endCpG columns)
+    """
+    args = parse_args(argv)
+    betas = parse_betas_input(args)
+    SegmentByChunks(args, betas).run()
+
+
+if __name__ == '__main__':
+    main()

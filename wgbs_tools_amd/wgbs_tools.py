@@ -1,0 +1,51 @@
+#!/usr/bin/python3 -u
+"""`wgbstools <command>` dispatcher (reference: src/python/wgbs_tools.py:50-79).  This build carries ONE command,
+`segment` — the MI355X-native hot path; every other reference subcommand is out of scope and says so."""
+import sys
+
+from .genome import IllegalArgumentError, eprint
+
+VERSION = '0.1.0-mi355x'
+COMMANDS = ['segment']
+# reference command list (wgbs_tools.py:11-48), for the "not in this build" message
+REFERENCE_ONLY = ['view', 'merge', 'cview', 'index', 'convert', 'beta_cov', 'beta_to_table', 'beta_to_blocks',
+                  'beta2bed', 'beta2bw', 'bam2pat', 'mbias', 'init_genome', 'set_default_ref', 'vis', 'pat_fig',
+                  'find_markers', 'homog', 'test_bimodal', 'compare_betas', 'dmb', 'mix_pat', 'bed2beta',
+                  'pat2beta', 'split_by_allele', 'split_by_meth', 'frag_len', 'add_cpg_counts', 'beta_to_450k']
+
+
+def print_help():
+    msg = '\nUsage: wgbstools <command> [<args>]'
+    msg += '\nrun wgbstools <command> -h for more information'
+    msg += '\nOptional commands:\n'
+    for key in COMMANDS:
+        msg += '\t' + key + '\n'
+    print(msg)
+    return 1
+
+
+def main(argv=None):
+    argv = list(sys.argv if argv is None else argv)
+    if len(argv) < 2 or argv[1] in ('-h', '--help'):
+        return print_help()
+    if argv[1] in ('--version', '-v'):
+        print('wgbstools (MI355X segment) version', VERSION)
+        return 0
+    cmd = argv[1]
+    if cmd in REFERENCE_ONLY:
+        eprint(f'wgbstools {cmd}: not part of this build (it carries only the MI355X-native `segment`)')
+        return 1
+    if cmd not in COMMANDS:
+        eprint('Invalid command:', f'\033[01;31m{cmd}\033[00m')
+        return print_help()
+    try:
+        from . import segment
+        segment.main(argv[2:])
+        return 0
+    except IllegalArgumentError as e:          # wgbs_tools.py:77-79
+        eprint(f'Invalid input argument\n{e}')
+        return 1
+
+
+if __name__ == '__main__':
+    sys.exit(main())
