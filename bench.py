@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py — CpG-sites/sec segmented on synthetic hg19-shaped betas (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W] [--samples 32] [--sites 28217448]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one whole `segment` job over the resident beta bytes: scan/validate pass, window extents, block
+scoring, changepoint DP, traceback, junction patches and stitching (wgbsseg_segment_regions), borders back on the
+host.  Inputs are synthetic (seeded; wgbs_tools_amd/synth.py) and already in HBM when the timed region starts.
+N > 1: the chunk grid is cut into N contiguous pieces (one per rank, balanced by sites); no collective on the data
+path, ranks only meet at the timing barrier.  Total work is fixed as N grows => "scaling": "strong".
+
+The JSON line carries `roofline` for the HBM-bound scan kernel (k_scan; algorithmic bytes = 2 * samples * sites per
+launch) measured with HIP events on the kernel's own stream inside the timed steps, the fp64-VALU
+bound scoring kernel's rate as `scoring`, and `cpu_baseline`: the reference's own `segmentor` (oracle/_ref, built
+from the reference sources) timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import os.path as op
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = op.dirname(op.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 20260926
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+FP64_VALU_PEAK = 78.6e12         # flop/s, vector fp64 (FMA counted as 2)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--samples', type=int, default=32, help='number of beta files (BASELINE.json configs[2]: 32)')
+    ap.add_argument('--sites', type=int, default=28217448, help='CpG sites of the synthetic genome (hg19: 28,217,448)')
+    ap.add_argument('--chunk', type=int, default=60000)
+    ap.add_argument('--max-cpg', type=int, default=1000)
+    ap.add_argument('--max-bp', type=int, default=2000)
+    ap.add_argument('--pcount', type=float, default=15.0)
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target wall time of the CPU baseline sample (0: skip)')
+    return ap.parse_args()
+
+
+def shard_pieces(names, sizes, chunk, world):
+    """Cut the chunk grid into `world` contiguous runs of chunks balanced by site count.  Returns per rank a list
+    of (start, end) 1-based half-open pieces; every piece starts on its chromosome's chunk grid."""
+    chunks = []                                   # (chrom idx, start, end)
+    pos = 1
+    for ci, sz in enumerate(sizes):
+        for s in range(pos, pos + sz, chunk):
+            chunks.append((ci, s, min(s + chunk, pos + sz)))
+        pos += sz
+    total = sum(e - s for _, s, e in chunks)
+    out, acc, r = [[] for _ in range(world)], 0, 0
+    for ci, s, e in chunks:
+        while r < world - 1 and acc >= total * (r + 1) / world:
+            r += 1
+        p = out[r]
+        if p and p[-1][2] == s and p[-1][0] == ci:
+            p[-1] = (ci, p[-1][1], e)
+        else:
+            p.append((ci, s, e))
+        acc += e - s
+    return [[(s, e) for _, s, e in p] for p in out], len(chunks)
+
+
+def cpu_baseline(args, buf, sizes, loci, seg, params):
+    """The reference `segmentor` (oracle/_ref, built from the reference's own sources) on this host's cores over a
+    bounded sample of the same workload: rounds of `cores` default-size chunks taken evenly from the genome's chunk
+    grid, one single-threaded process per core — the reference's own parallel shape (segment.py:144-146, a Pool of
+    chunk processes).  Falls back to the oracle's C port (threads) when the reference binary is absent.  Also
+    checks the GPU's borders for exactly those chunks against what the CPU produced."""
+    import threading
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    n = args.chunk
+    kind = 'reference' if oracle.have_ref() else 'port'
+    grid, pos = [], 0
+    for sz in sizes:                                       # full-size chunks only (0-based starts)
+        grid += [s for s in range(pos, pos + sz - n + 1, n)]
+        pos += sz
+    if not grid:
+        grid, n = [0], min(n, sizes[0])
+    pick = [grid[i] for i in np.linspace(0, len(grid) - 1, min(len(grid), cores * 8)).astype(int)]
+    pick = sorted(set(pick))
+    done, wall, borders = 0, 0.0, {}
+    td = tempfile.mkdtemp(dir='/dev/shm' if op.isdir('/dev/shm') else None)
+    try:
+        t_end = time.time() + args.cpu_seconds
+        while done < len(pick) and (done == 0 or time.time() < t_end):
+            todo = pick[done:done + cores]
+            host = {st: buf[:, 2 * st:2 * (st + n)].cpu().numpy() for st in todo}
+            if kind == 'reference':
+                jobs = []
+                for st in todo:
+                    d = op.join(td, 'c%d' % st)
+                    os.mkdir(d)
+                    paths = []
+                    for s in range(host[st].shape[0]):
+                        pth = op.join(d, 's%04d.beta' % s)
+                        host[st][s].tofile(pth)
+                        paths.append(pth)
+                    cmd = [oracle.REF_BIN] + paths + ['-s', '0', '-n', str(n), '-max_cpg', str(params['max_cpg']),
+                                                     '-ps', repr(float(args.pcount)), '-max_bp', str(args.max_bp)]
+                    stdin = ('\n'.join(map(str, loci[st:st + n].tolist())) + '\n').encode()
+                    jobs.append((st, cmd, stdin))
+                outs = {}
+
+                def run(st, cmd, stdin):
+                    outs[st] = subprocess.run(cmd, input=stdin, stdout=subprocess.PIPE, check=True).stdout
+                th = [threading.Thread(target=run, args=j) for j in jobs]
+                t0 = time.time()
+                [t.start() for t in th]
+                [t.join() for t in th]
+                wall += time.time() - t0
+                for st in todo:
+                    borders[st] = np.array(outs[st].split(), dtype=np.int64)
+            else:
+                t0 = time.time()
+
+                def runp(st):                              # ctypes drops the GIL: one chunk per thread
+                    sl = [host[st][s].reshape(-1, 2) for s in range(host[st].shape[0])]
+                    borders[st] = oracle.segment_chunk(sl, loci[st:st + n], args.pcount, params['max_cpg'], args.max_bp).astype(np.int64)
+                thr = [threading.Thread(target=runp, args=(st,)) for st in todo]
+                [t.start() for t in thr]
+                [t.join() for t in thr]
+                wall += time.time() - t0
+            done += len(todo)
+    finally:
+        import shutil
+        shutil.rmtree(td, ignore_errors=True)
+    sts = sorted(borders)
+    got = seg.segment_chunks(sts, [n] * len(sts), args.pcount, params['max_cpg'], args.max_bp)
+    same = all(np.array_equal(g.astype(np.int64), borders[st]) for g, st in zip(got, sts))
+    used = min(cores, len(sts))
+    return {'value': len(sts) * n / wall, 'unit': 'CpG-sites/s', 'cores': used, 'kind': kind,
+            'sample': '%d chunks of %d CpGs x %d betas spread over the genome, %d concurrent single-threaded %s, %.1f s wall '
+                      '(host has %d logical CPUs)' % (len(sts), n, args.samples, used,
+                                                      'reference segmentor processes' if kind == 'reference' else 'oracle-port threads',
+                                                      wall, cores),
+            'gpu_borders_identical_on_sample': bool(same)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from wgbs_tools_amd import _lib, synth
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    names, sizes = synth.genome_shape(args.sites, 25 if args.sites >= 2500000 else max(1, min(25, args.sites // 100000)))
+    sizes = [int(s) for s in sizes]
+    loci = synth.synth_loci(SEED, sizes)
+    max_cpg = min(args.max_cpg, args.max_bp // 2)            # segment.py:65
+    params = dict(max_cpg=max_cpg)
+
+    # synthetic betas straight into HBM
+    pitch = ((2 * args.sites + 255) // 256) * 256 + 256
+    buf = torch.empty((args.samples, pitch), dtype=torch.uint8, device=dev)
+    S = _lib.load_synth()
+    rc = S.wgbssynth_fill_betas(C.c_void_p(buf.data_ptr()), pitch, args.sites, 0, args.samples, SEED, None)
+    assert rc == 0, 'synthetic fill failed (hip error %d)' % rc
+    torch.cuda.synchronize()
+
+    seg = _lib.Segmenter(local)
+    seg.set_betas_device(buf.data_ptr(), args.samples, pitch, args.sites, keepalive=buf)
+    seg.set_loci(loci)
+
+    pieces, n_chunks_total = shard_pieces(names, sizes, args.chunk, world)
+    mine = pieces[rank]
+    st = np.array([p[0] for p in mine], dtype=np.int64)
+    en = np.array([p[1] for p in mine], dtype=np.int64)
+    my_sites = int((en - st).sum())
+
+    def step():
+        return seg.segment_regions(st, en, args.chunk, args.pcount, max_cpg, args.max_bp)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    acc = None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, stats = step()
+        t = seg.timings()
+        if acc is None:
+            acc = dict(t)
+        else:
+            for k in t:
+                acc[k] = max(acc[k], t[k]) if k in ('max_window', 'n_stages') else acc[k] + t[k]
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    n_blocks = int(sum(len(r) - 1 for r in res))
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = args.sites / (dt / args.steps)
+        scan_gbs = acc['scan_bytes'] / (acc['scan_ms'] * 1e-3) / 1e9
+        evals_s = acc['evals'] / (acc['cost_ms'] * 1e-3)
+        out = {
+            'metric': 'CpG-sites/sec segmented',
+            'value': value, 'unit': 'CpG-sites/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'u8 counts -> u32 prefix sums -> f32/f64 log-likelihood (bit-exact with the reference)',
+            'data': 'synthetic (seeded hg19-shaped genome and betas, generated on the device)',
+            'config': {'workload': 'hg19-shaped %d CpGs x %d betas, whole-genome segment, chunk_size %d, max_cpg %d, max_bp %d, pcount %g'
+                                   % (args.sites, args.samples, args.chunk, args.max_cpg, args.max_bp, args.pcount),
+                       'baseline_config': 'BASELINE.json configs[2]' if (args.sites, args.samples) == (28217448, 32) else 'custom',
+                       'chunks': n_chunks_total, 'chromosomes': len(sizes), 'sharding': 'contiguous chunk ranges per rank, no collective',
+                       'rank0_sites': my_sites, 'rank0_stats': stats, 'rank0_blocks': n_blocks},
+            'roofline': {'kernel': 'k_scan (per-sample prefix scan + meth<=cov validation)', 'bound': 'hbm',
+                         'achieved': scan_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': scan_gbs / HBM_PEAK_GBS,
+                         'traffic': None,
+                         'algorithmic_bytes_per_launch': acc['scan_bytes'] / max(1, acc['scan_launches']),
+                         'avg_launch_ms': acc['scan_ms'] / max(1, acc['scan_launches']), 'launches': acc['scan_launches'],
+                         'note': 'rank 0, HIP events on the kernel stream inside the timed steps; traffic: see profiles/'},
+            'scoring': {'kernel': 'k_cost (block log-likelihoods, fp64 VALU bound)', 'evals_per_s': evals_s,
+                        'evals_per_step': acc['evals'] / args.steps, 'pairs_per_step': acc['pairs'] / args.steps,
+                        'max_window': acc['max_window'], 'stages': acc['n_stages']},
+            'device_ms_per_step': {k: acc[k] / args.steps for k in ('scan_ms', 'window_ms', 'cost_ms', 'dp_ms', 'trace_ms', 'total_ms')},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            try:
+                out['cpu_baseline'] = cpu_baseline(args, buf, sizes, loci, seg, params)
+                out['cpu_baseline']['gpu_over_cpu'] = value / out['cpu_baseline']['value']
+            except Exception as e:                       # the baseline must never break the bench line
+                out['cpu_baseline'] = {'value': None, 'unit': 'CpG-sites/s', 'cores': os.cpu_count(), 'kind': 'reference',
+                                       'sample': 'failed: %r' % (e,)}
+        print(json.dumps(out), flush=True)
+    seg.close()
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

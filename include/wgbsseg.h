@@ -107,6 +107,23 @@ int wgbsseg_segment_chunks(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const 
                            char* err, size_t errlen);
 
 /*
+ * Region-level form of the whole driver loop of segment.py:137-165 (SegmentByChunks.run + merge_df_list +
+ * stitch_2_dfs), native: regions (1-based half-open CpG ranges [region_start, region_end), e.g. one per chromosome)
+ * are cut into chunks `range(start, end, chunk_size) + [end]` (segment.py:124-135), every chunk and every
+ * junction's first-attempt patch [b-p1, b+p2), p = min(50, operand span) (segment.py:209-216) go to the GPU as one
+ * batch, then the junctions are stitched in the reference's pairwise order with its overlap / merge2 /
+ * patch-doubling rules (segment.py:219-252); failed attempts are re-batched.  Output (CSR over regions): the
+ * merged ABSOLUTE 1-based border list of each region (first region_start, last region_end); consecutive pairs
+ * are the blocks (startCpG, endCpG) the reference writes (segment.py:154).  borders_cap >= sum(region lengths) +
+ * n_regions always suffices.  stats (optional, 4 x int64): chunks, patch DPs run, GPU batches, junctions.
+ * wgbsseg_get_timings() afterwards returns the sums over all batches of the call.
+ */
+int wgbsseg_segment_regions(wgbsseg_ctx* ctx, const int64_t* region_start, const int64_t* region_end, int64_t n_regions,
+                            int64_t chunk_size, const wgbsseg_params* params,
+                            int64_t* borders_out, int64_t borders_cap, int64_t* borders_off, int64_t* stats,
+                            char* err, size_t errlen);
+
+/*
  * One-shot form (host buffers in, host borders out): creates a context on `device`, uploads, segments, destroys.
  * betas = [n_samples][sample_pitch_bytes] host bytes, each row holding n_sites_total x 2 uint8.
  */

@@ -241,3 +241,78 @@ def test_cli_dispatch_and_native_required(synth_world, capsys):
         with pytest.raises((_lib.SegmentorError, _lib.NativeLibraryError)):
             wgbs_tools.main(['wgbstools', 'segment', '--betas'] + synth_world['paths'] +
                             ['--genome', synth_world['refdir'], '-s', '1-500', '-o', os.devnull])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the NATIVE chunk grid + stitching (wgbs_tools_amd/csrc/stitch.h, what wgbsseg_segment_regions runs around the GPU
+# batches), driven here by the oracle through a callback
+# ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def stitch_lib():
+    import ctypes as C
+    import subprocess
+    src = op.join(ROOT, 'tests', 'native', 'stitch_host.cpp')
+    lib = op.join(ROOT, 'tests', 'native', 'libstitch_host.so')
+    hdr = op.join(ROOT, 'wgbs_tools_amd', 'csrc', 'stitch.h')
+    if not op.isfile(lib) or op.getmtime(lib) < max(op.getmtime(src), op.getmtime(hdr)):
+        subprocess.check_call(['g++', '-O2', '-std=c++17', '-shared', '-fPIC', src, '-o', lib])
+    return C.CDLL(lib)
+
+
+def native_segment_regions(stitch_lib, engine, params, regions, chunk_size):
+    import ctypes as C
+    CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64), C.c_int64,
+                     C.POINTER(C.c_int64))
+
+    def cb(starts, ends, n, out, cap, off):
+        sites = [(starts[i], ends[i]) for i in range(n)]
+        res = engine.segment_many(sites, params)
+        pos = 0
+        for i, r in enumerate(res):
+            off[i] = pos
+            for v in r.tolist():
+                out[pos] = v
+                pos += 1
+        off[n] = pos
+        return 0
+    rs = np.array([r[0] for r in regions], dtype=np.int64)
+    re_ = np.array([r[1] for r in regions], dtype=np.int64)
+    cap = int((re_ - rs).sum()) + len(regions)
+    out = np.empty(cap, dtype=np.int64)
+    off = np.empty(len(regions) + 1, dtype=np.int64)
+    stats = np.zeros(4, dtype=np.int64)
+    err = C.create_string_buffer(512)
+    rc = stitch_lib.stitch_segment_regions(rs.ctypes.data_as(C.POINTER(C.c_int64)), re_.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           len(regions), C.c_int64(chunk_size), CB(cb), out.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           C.c_int64(cap), off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           stats.ctypes.data_as(C.POINTER(C.c_int64)), err, 512)
+    assert rc == 0, err.value
+    return [out[off[r]:off[r + 1]].copy() for r in range(len(regions))], stats
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_native_stitching_matches_reference_driver(name, driver_golden, synth_world, stitch_lib):
+    g = driver_golden['cases'][name]
+    kw = dict(chunk_size=60000, pcount=15, min_cpg=1, max_cpg=1000, max_bp=2000)
+    kw.update({k: v for k, v in g['args'].items() if k in kw})
+    params = dict(pcount=kw['pcount'], max_cpg=min(kw['max_cpg'], kw['max_bp'] // 2), max_bp=kw['max_bp'])
+    regions, seen = [], set()
+    for t in g['chunks']['tags']:                       # regions in the driver's order
+        if t not in seen:
+            seen.add(t)
+            a, b = t.split('-')
+            regions.append((int(a), int(b)))
+    eng = OracleEngine(synth_world['betas'], synth_world['loci'])
+    res, stats = native_segment_regions(stitch_lib, eng, params, regions, kw['chunk_size'])
+    nch = len(g['chunks']['starts'])
+    assert stats[0] == nch
+    assert eng.calls[:nch] == list(zip(g['chunks']['starts'], g['chunks']['ends']))       # chunk grid
+    assert set(eng.calls[nch:]) == set(tuple(c) for c in g['patch_calls'])               # same patches, no extras
+    s = np.concatenate([r[:-1] for r in res]); e = np.concatenate([r[1:] for r in res])
+    order = np.argsort(s, kind='stable'); s, e = s[order], e[order]
+    keep = (e - s) > kw['min_cpg'] - 1
+    table = np.stack([s[keep], e[keep]], axis=1).astype(np.int64)
+    assert table.shape[0] == g['n_blocks']
+    assert hashlib.sha1(np.ascontiguousarray(table).tobytes()).hexdigest() == g['table_sha1']
+    for r, (a, b) in zip(res, regions):
+        assert r[0] == a and r[-1] == b and (np.diff(r) > 0).all()

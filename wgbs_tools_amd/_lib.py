@@ -17,7 +17,7 @@ OK, E_ARG, E_METH_GT_COV, E_NOMEM, E_HIP, E_LOCI_ORDER, E_CAPACITY, E_STATE = 0,
 # every symbol include/wgbsseg.h declares (tests check the built library exports exactly these)
 EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg_destroy',
            'wgbsseg_set_betas_host', 'wgbsseg_set_betas_device', 'wgbsseg_set_loci_host', 'wgbsseg_set_loci_device',
-           'wgbsseg_segment_chunks', 'wgbsseg_segment_chunks_host', 'wgbsseg_prefix_sums', 'wgbsseg_scan_only',
+           'wgbsseg_segment_chunks', 'wgbsseg_segment_regions', 'wgbsseg_segment_chunks_host', 'wgbsseg_prefix_sums', 'wgbsseg_scan_only',
            'wgbsseg_get_timings', 'wgbsseg_debug_fetch', 'wgbsseg_debug_sample_terms', 'wgbsseg_debug_log2']
 
 
@@ -79,6 +79,8 @@ def load():
     L.wgbsseg_set_loci_device.argtypes = [vp, vp, i64, C.c_char_p, C.c_size_t]
     L.wgbsseg_segment_chunks.restype = i32
     L.wgbsseg_segment_chunks.argtypes = [vp, vp, vp, i64, C.POINTER(Params), vp, i64, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_segment_regions.restype = i32
+    L.wgbsseg_segment_regions.argtypes = [vp, vp, vp, i64, i64, C.POINTER(Params), vp, i64, vp, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_segment_chunks_host.restype = i32
     L.wgbsseg_segment_chunks_host.argtypes = [vp, i64, i64, i64, vp, vp, vp, i64, C.POINTER(Params), i32, vp, i64, vp,
                                               C.c_char_p, C.c_size_t]
@@ -187,6 +189,23 @@ class Segmenter:
         _check(self._L.wgbsseg_segment_chunks(self._h, start0.ctypes.data, lens.ctypes.data, n, C.byref(p),
                                               out.ctypes.data, cap, off.ctypes.data, self._err, ERRLEN), self._err)
         return out[:off[n]], off
+
+    def segment_regions(self, starts, ends, chunk_size, pcount, max_cpg, max_bp):
+        """starts/ends: 1-based half-open CpG ranges RELATIVE TO THE RESIDENT DATA (site 1 = first resident site).
+        -> (list of int64 arrays: merged absolute border list of each region, stats dict)."""
+        starts = np.ascontiguousarray(starts, dtype=np.int64)
+        ends = np.ascontiguousarray(ends, dtype=np.int64)
+        n = starts.size
+        cap = int((ends - starts).sum()) + n
+        out = np.empty(cap, dtype=np.int64)
+        off = np.empty(n + 1, dtype=np.int64)
+        stats = np.zeros(4, dtype=np.int64)
+        p = Params(float(pcount), int(max_cpg), int(max_bp))
+        _check(self._L.wgbsseg_segment_regions(self._h, starts.ctypes.data, ends.ctypes.data, n, int(chunk_size), C.byref(p),
+                                               out.ctypes.data, cap, off.ctypes.data, stats.ctypes.data, self._err, ERRLEN),
+               self._err)
+        res = [out[off[r]:off[r + 1]] for r in range(n)]
+        return res, dict(chunks=int(stats[0]), patch_dps=int(stats[1]), batches=int(stats[2]), junctions=int(stats[3]))
 
     def prefix_sums(self, start0, length):
         out = np.empty((self.n_samples, length + 1, 2), dtype=np.uint32)

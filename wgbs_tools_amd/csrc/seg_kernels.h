@@ -562,7 +562,12 @@ __global__ __launch_bounds__(WG_BLOCK) void k_trace(JobView J, int32_t* __restri
         __syncthreads();
         if (tid == 0) {
             int i = sh_cur, cnt = sh_cnt;
-            while (i > wlo) { i -= (int)win[i - 1 - wlo]; out[cnt++] = i; }   // i = T[i] (segmentor.cpp:55)
+            while (i > wlo) {                                  // i = T[i] (segmentor.cpp:55)
+                int stepb = (int)win[i - 1 - wlo];
+                if (stepb < 1 || stepb > i) stepb = i;         // never loops on a corrupt back-pointer (would show up as a parity failure)
+                i -= stepb;
+                out[cnt++] = i;
+            }
             sh_cur = i; sh_cnt = cnt;
         }
         __syncthreads();

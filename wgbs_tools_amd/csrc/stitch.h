@@ -1,0 +1,248 @@
+// stitch.h — host-side chunk grid and junction stitching of `wgbstools segment`, native.
+//
+// Restates, on sorted int64 border lists, the reference driver's
+//   break_to_chunks   segment.py:124-135   bords = range(start, end, step) + [end]
+//   merge_df_list     segment.py:157-165   pairwise tree: (0,1),(2,3).. then again on the merged list
+//   stitch_2_dfs      segment.py:199-232   patch = DP over [b1[-1]-p1, b1[-1]+p2), p = min(50, span), doubling on failure
+//   is_2_overlap / find_dups / merge2 / increase_patch   segment.py:235-252
+// A merged list is kept as a rope of runs into stable storage (chunk results, patch results), because a stitch only
+// edits the neighbourhood of its junction; the rope is flattened once at the end.  The patch DP is a pure function
+// of (start, end), so every junction's first-attempt patch is known before any DP has run and goes to the GPU in
+// the same batch as the chunks; only failed attempts (doubling) need a follow-up batch.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace wgstitch {
+
+struct Run { const int64_t* p; int64_t n; };            // n >= 1, values strictly ascending, also across runs
+
+struct Rope {
+    std::vector<Run> runs;
+    int64_t front() const { return runs.front().p[0]; }
+    int64_t back() const { return runs.back().p[runs.back().n - 1]; }
+    int64_t span() const { return back() - front(); }
+    // is value x present?  (binary search over runs, then inside the run)
+    bool contains(int64_t x, size_t* run_idx = nullptr, int64_t* pos = nullptr) const
+    {
+        size_t lo = 0, hi = runs.size();                 // last run with first value <= x
+        while (hi - lo > 1) { size_t mid = (lo + hi) / 2; if (runs[mid].p[0] <= x) lo = mid; else hi = mid; }
+        const Run& r = runs[lo];
+        if (r.p[0] > x) return false;
+        const int64_t* e = std::lower_bound(r.p, r.p + r.n, x);
+        if (e == r.p + r.n || *e != x) return false;
+        if (run_idx) *run_idx = lo;
+        if (pos) *pos = e - r.p;
+        return true;
+    }
+    // keep everything up to and including value x (x must be present)
+    void truncate_after(int64_t x)
+    {
+        size_t ri = 0; int64_t pos = 0;
+        contains(x, &ri, &pos);
+        runs.resize(ri + 1);
+        runs[ri].n = pos + 1;
+    }
+    // append the elements of `o` that are > x (x must be present in o)
+    void append_after(const Rope& o, int64_t x)
+    {
+        size_t ri = 0; int64_t pos = 0;
+        o.contains(x, &ri, &pos);
+        if (pos + 1 < o.runs[ri].n) runs.push_back(Run{o.runs[ri].p + pos + 1, o.runs[ri].n - pos - 1});
+        for (size_t q = ri + 1; q < o.runs.size(); q++) runs.push_back(o.runs[q]);
+    }
+    int64_t size() const { int64_t s = 0; for (auto& r : runs) s += r.n; return s; }
+    void flatten(int64_t* out) const { for (auto& r : runs) { std::copy(r.p, r.p + r.n, out); out += r.n; } }
+};
+
+inline int64_t increase_patch(int64_t pre, int64_t maxval)    // segment.py:249-252
+{
+    if (pre == maxval) return maxval + 1;
+    return std::min(pre * 2, maxval);
+}
+
+// One stitch_2_dfs in progress.
+struct Stitch {
+    Rope b1, b2;
+    int64_t n1, n2, p1, p2;
+    bool done = false;
+    Rope result;
+    bool init(Rope&& a, Rope&& b, std::string& err)
+    {
+        b1 = std::move(a); b2 = std::move(b);
+        if (b1.back() != b2.front()) {                          // segment.py:202-205
+            err = "[wt segment] Patch stitching Failed!              patches are not supposed to be merged";
+            return false;
+        }
+        n1 = b1.span(); n2 = b2.span();
+        p1 = std::min<int64_t>(50, n1); p2 = std::min<int64_t>(50, n2);
+        return true;
+    }
+    // the patch this junction needs next; false + err when the reference would give up (segment.py:229-232)
+    bool want(std::pair<int64_t, int64_t>& sites, std::string& err) const
+    {
+        if (!(p1 <= n1 && p2 <= n2)) {
+            err = "[wt segment] Patch stitching Failed!              Try increasing chunk size (--chunk_size flag)";
+            return false;
+        }
+        sites = {b1.back() - p1, b1.back() + p2};
+        return true;
+    }
+    void feed(const int64_t* patch, int64_t np)
+    {
+        // is_2_overlap(b1, patch) / (patch, b2): a common value exists (segment.py:235-240)
+        int64_t x1 = 0, x2 = 0;
+        bool o1 = false, o2 = false;
+        for (int64_t q = 0; q < np && !o1; q++) if (b1.contains(patch[q])) { o1 = true; x1 = patch[q]; }   // smallest common value
+        for (int64_t q = 0; q < np && !o2; q++) if (b2.contains(patch[q])) { o2 = true; x2 = patch[q]; }
+        if (o1 && o2) {
+            // merge2(merge2(b1, patch), b2) (segment.py:221,243-246):
+            //   m = b1[.. x1] + patch[> x1];   the first element of m that occurs in b2 is the junction value itself
+            //   when x1 is the junction (then nothing of the patch survives), else the smallest patch value > x1 in b2.
+            result = std::move(b1);
+            result.truncate_after(x1);
+            const int64_t junction = b2.front();
+            if (x1 == junction) {
+                result.append_after(b2, junction);
+            } else {
+                const int64_t* a = std::upper_bound(patch, patch + np, x1);
+                const int64_t* b = std::lower_bound(patch, patch + np, x2);     // x2 >= junction > x1
+                if (b + 1 > a) result.runs.push_back(Run{a, (b + 1) - a});
+                result.append_after(b2, x2);
+            }
+            done = true;
+        } else {
+            if (!o1) p1 = increase_patch(p1, n1);
+            if (!o2) p2 = increase_patch(p2, n2);
+        }
+    }
+};
+
+// First-attempt patch of every junction of a region cut into chunks of lengths `lens` starting at 1-based `start`:
+// the pairwise tree fixes the operand spans and with them p1, p2.
+inline void upfront_patches(int64_t start, const std::vector<int64_t>& lens, std::vector<std::pair<int64_t, int64_t>>& out)
+{
+    struct Seg { int64_t a, b; };                              // site range [a, b)
+    std::vector<Seg> segs;
+    int64_t pos = start;
+    for (auto l : lens) { segs.push_back({pos, pos + l}); pos += l; }
+    while (segs.size() > 1) {
+        std::vector<Seg> nxt;
+        for (size_t i = 1; i < segs.size(); i += 2) {
+            const Seg &L = segs[i - 1], &R = segs[i];
+            const int64_t p1 = std::min<int64_t>(50, L.b - L.a), p2 = std::min<int64_t>(50, R.b - R.a);
+            out.push_back({L.b - p1, L.b + p2});
+            nxt.push_back({L.a, R.b});
+        }
+        if (segs.size() % 2) nxt.push_back(segs.back());
+        segs.swap(nxt);
+    }
+}
+
+typedef std::pair<int64_t, int64_t> Sites;                     // 1-based [start, end)
+// Runs one batch of chunk DPs: res[i] = absolute border list of todo[i] (first = start, last = end).  0 on success.
+typedef std::function<int(const std::vector<Sites>&, std::vector<std::vector<int64_t>>&, std::string&)> BatchFn;
+enum { E_ARG = -1, E_CAPACITY = -6 };
+
+// The whole driver loop of segment.py:137-165 over `n_regions` regions; see include/wgbsseg.h wgbsseg_segment_regions.
+inline int segment_regions(const int64_t* region_start, const int64_t* region_end, int64_t n_regions, int64_t chunk_size,
+                           const BatchFn& run_batch, int64_t* borders_out, int64_t borders_cap, int64_t* borders_off,
+                           int64_t* stats, std::string& err)
+{
+    if (!region_start || !region_end || n_regions < 1 || chunk_size < 1 || !borders_out || !borders_off) { err = "bad arguments to segment_regions"; return E_ARG; }
+    // ---- chunk grid (segment.py:124-135) and first-attempt patches ---------------------------------------------
+    std::vector<Sites> items;                                  // chunks first, then patches
+    std::vector<int64_t> region_first_chunk((size_t)n_regions + 1);
+    std::vector<Sites> patches;
+    for (int64_t r = 0; r < n_regions; r++) {
+        const int64_t a = region_start[r], b = region_end[r];
+        if (a < 1 || b <= a) { err = "region " + std::to_string(r) + " is empty or starts before site 1"; return E_ARG; }
+        region_first_chunk[(size_t)r] = (int64_t)items.size();
+        std::vector<int64_t> lens;
+        for (int64_t s = a; s < b; s += chunk_size) { const int64_t e = std::min(s + chunk_size, b); items.push_back({s, e}); lens.push_back(e - s); }
+        upfront_patches(a, lens, patches);
+    }
+    region_first_chunk[(size_t)n_regions] = (int64_t)items.size();
+    const int64_t n_chunks = (int64_t)items.size();
+    std::map<Sites, std::vector<int64_t>> cache;               // patch results; node addresses are stable
+    for (auto& p : patches) if (!cache.count(p)) { cache[p]; items.push_back(p); }
+    int64_t n_batches = 0, n_patch_dp = 0;
+
+    std::vector<std::vector<int64_t>> first;
+    int rc = run_batch(items, first, err);
+    if (rc != 0) return rc;
+    n_batches++;
+    for (size_t i = (size_t)n_chunks; i < items.size(); i++) { cache[items[i]] = std::move(first[i]); n_patch_dp++; }
+
+    // ---- pairwise-tree stitching (segment.py:157-165), all regions advancing round by round ------------------------
+    std::vector<std::vector<Rope>> lists((size_t)n_regions);
+    for (int64_t r = 0; r < n_regions; r++)
+        for (int64_t q = region_first_chunk[(size_t)r]; q < region_first_chunk[(size_t)r + 1]; q++) {
+            Rope rp;
+            rp.runs.push_back(Run{first[(size_t)q].data(), (int64_t)first[(size_t)q].size()});
+            lists[(size_t)r].push_back(std::move(rp));
+        }
+    for (;;) {
+        bool any = false;
+        for (auto& l : lists) any = any || l.size() > 1;
+        if (!any) break;
+        std::vector<Stitch> st;
+        std::vector<int64_t> owner;
+        std::vector<Rope> leftover((size_t)n_regions);
+        std::vector<char> has_left((size_t)n_regions, 0);
+        for (int64_t r = 0; r < n_regions; r++) {
+            auto& l = lists[(size_t)r];
+            if (l.size() <= 1) continue;
+            for (size_t i = 1; i < l.size(); i += 2) {
+                st.emplace_back();
+                if (!st.back().init(std::move(l[i - 1]), std::move(l[i]), err)) return E_ARG;
+                owner.push_back(r);
+            }
+            if (l.size() % 2) { leftover[(size_t)r] = std::move(l.back()); has_left[(size_t)r] = 1; }
+            l.clear();
+        }
+        for (;;) {
+            std::vector<Sites> need;
+            bool pending = false;
+            for (auto& s : st) {
+                if (s.done) continue;
+                Sites w;
+                if (!s.want(w, err)) return E_ARG;
+                if (!cache.count(w)) { cache[w]; need.push_back(w); }
+            }
+            if (!need.empty()) {
+                std::vector<std::vector<int64_t>> res;
+                rc = run_batch(need, res, err);
+                if (rc != 0) return rc;
+                n_batches++;
+                for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = std::move(res[i]); n_patch_dp++; }
+            }
+            for (auto& s : st) {
+                if (s.done) continue;
+                Sites w;
+                s.want(w, err);
+                const std::vector<int64_t>& pv = cache[w];
+                s.feed(pv.data(), (int64_t)pv.size());
+                pending = pending || !s.done;
+            }
+            if (!pending) break;
+        }
+        for (size_t i = 0; i < st.size(); i++) lists[(size_t)owner[i]].push_back(std::move(st[i].result));
+        for (int64_t r = 0; r < n_regions; r++) if (has_left[(size_t)r]) lists[(size_t)r].push_back(std::move(leftover[(size_t)r]));
+    }
+    // ---- flatten --------------------------------------------------------------------------------------------------
+    int64_t total = 0;
+    for (int64_t r = 0; r < n_regions; r++) { borders_off[r] = total; total += lists[(size_t)r][0].size(); }
+    borders_off[n_regions] = total;
+    if (total > borders_cap) { err = "borders_out too small: need " + std::to_string(total); return E_CAPACITY; }
+    for (int64_t r = 0; r < n_regions; r++) lists[(size_t)r][0].flatten(borders_out + borders_off[r]);
+    if (stats) { stats[0] = n_chunks; stats[1] = n_patch_dp; stats[2] = n_batches; stats[3] = (int64_t)patches.size(); }
+    return 0;
+}
+
+}  // namespace wgstitch

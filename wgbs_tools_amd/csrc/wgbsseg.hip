@@ -17,6 +17,7 @@
 
 #include "../../include/wgbsseg.h"
 #include "seg_kernels.h"
+#include "stitch.h"
 
 namespace {
 
@@ -86,6 +87,7 @@ struct wgbsseg_ctx {
     long long cost_budget_bytes = 0;
     int force_stages = 0;
     int force_ns = 0;
+    bool accumulate = false;   // add to `tim` instead of resetting it (region-level calls span several batches)
 };
 
 extern "C" {
@@ -438,18 +440,19 @@ int wgbsseg_segment_chunks(wgbsseg_ctx* c, const int64_t* chunk_start0, const in
 
     // ---- timings ---------------------------------------------------------------------------------------------
     wgbsseg_timings& T = c->tim;
-    memset(&T, 0, sizeof(T));
+    if (!c->accumulate) memset(&T, 0, sizeof(T));
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); T.scan_ms = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); T.window_ms = ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); T.scan_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); T.window_ms += ms;
     for (int stg = 0; stg < n_stages; stg++) {
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_cost0[stg], c->ev_cost1[stg])); T.cost_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_dp0[stg], c->ev_dp1[stg])); T.dp_ms += ms;
     }
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5])); T.trace_ms = ms;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[6])); T.total_ms = ms;
-    T.sites = J; T.pairs = total_pairs; T.evals = total_pairs * c->n_samples;
-    T.scan_bytes = 2 * J * c->n_samples; T.max_window = Wmax; T.n_stages = n_stages; T.scan_launches = 1;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5])); T.trace_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[6])); T.total_ms += ms;
+    T.sites += J; T.pairs += total_pairs; T.evals += total_pairs * c->n_samples;
+    T.scan_bytes += 2 * J * c->n_samples; T.max_window = std::max<int32_t>(T.max_window, Wmax);
+    T.n_stages = std::max<int32_t>(T.n_stages, n_stages); T.scan_launches += 1;
     c->last_sites = J; c->last_pairs = total_pairs; c->last_stages = n_stages; c->last_valid = true;
     return WGBSSEG_OK;
 }
@@ -470,6 +473,46 @@ int wgbsseg_segment_chunks_host(const uint8_t* betas, int64_t n_samples, int64_t
     if (rc == WGBSSEG_OK) rc = wgbsseg_segment_chunks(c, chunk_start0, chunk_len, n_chunks, params, borders_out, borders_cap, borders_off, err, errlen);
     wgbsseg_destroy(c);
     return rc;
+}
+
+int wgbsseg_segment_regions(wgbsseg_ctx* c, const int64_t* region_start, const int64_t* region_end, int64_t n_regions,
+                            int64_t chunk_size, const wgbsseg_params* P, int64_t* borders_out, int64_t borders_cap,
+                            int64_t* borders_off, int64_t* stats, char* err, size_t errlen)
+{
+    if (!c || !P) { set_err(err, errlen, "bad arguments to segment_regions"); return WGBSSEG_E_ARG; }
+    const bool acc_before = c->accumulate;
+    int64_t n_batches = 0;
+    // one GPU batch of 1-based site ranges -> absolute int64 border lists
+    wgstitch::BatchFn run_batch = [&](const std::vector<wgstitch::Sites>& todo, std::vector<std::vector<int64_t>>& res, std::string& msg) -> int {
+        std::vector<int64_t> st0(todo.size());
+        std::vector<int32_t> ln(todo.size());
+        int64_t cap = 0;
+        for (size_t i = 0; i < todo.size(); i++) {
+            st0[i] = todo[i].first - 1;
+            if (todo[i].second - todo[i].first > 0x7fffffff) { msg = "chunk too long"; return WGBSSEG_E_ARG; }
+            ln[i] = (int32_t)(todo[i].second - todo[i].first);
+            cap += ln[i] + 1;
+        }
+        std::vector<int32_t> flat((size_t)cap);
+        std::vector<int64_t> off(todo.size() + 1);
+        char ebuf[512] = {0};
+        c->accumulate = n_batches > 0;
+        const int rc = wgbsseg_segment_chunks(c, st0.data(), ln.data(), (int64_t)todo.size(), P, flat.data(), cap, off.data(), ebuf, sizeof(ebuf));
+        c->accumulate = acc_before;
+        if (rc != WGBSSEG_OK) { msg = ebuf; return rc; }
+        n_batches++;
+        res.resize(todo.size());
+        for (size_t i = 0; i < todo.size(); i++) {
+            res[i].resize((size_t)(off[i + 1] - off[i]));
+            for (int64_t q = off[i]; q < off[i + 1]; q++) res[i][(size_t)(q - off[i])] = (int64_t)flat[(size_t)q] + todo[i].first;
+        }
+        return WGBSSEG_OK;
+    };
+    std::string msg;
+    const int rc = wgstitch::segment_regions(region_start, region_end, n_regions, chunk_size, run_batch, borders_out, borders_cap,
+                                             borders_off, stats, msg);
+    if (rc != 0) { set_err(err, errlen, "%s", msg.c_str()); return rc == wgstitch::E_CAPACITY ? WGBSSEG_E_CAPACITY : (rc < -1 ? rc : WGBSSEG_E_ARG); }
+    return WGBSSEG_OK;
 }
 
 int wgbsseg_scan_only(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks, int repeat,

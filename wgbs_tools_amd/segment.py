@@ -60,6 +60,19 @@ class HipEngine:
                 out[i] = r.astype(np.int64) + sites_list[i][0]
         return out
 
+    def segment_regions(self, regions, chunk_size, params):
+        """The whole of SegmentByChunks.run's chunk fan-out + merge_df_list, native (wgbsseg_segment_regions):
+        regions = [(startCpG, endCpG), ...] 1-based half-open; returns the merged absolute border list of each."""
+        st = np.array([r[0] for r in regions], dtype=np.int64) - self.base
+        en = np.array([r[1] for r in regions], dtype=np.int64) - self.base
+        try:
+            res, self.last_stats = self._seg.segment_regions(st, en, chunk_size, params['pcount'], params['max_cpg'],
+                                                             params['max_bp'])
+        except Exception as e:
+            eprint(f'Failed in sites {regions[0]} .. {regions[-1]}')
+            raise e
+        return [r + self.base for r in res]
+
     def timings(self):
         return self._seg.timings()
 
@@ -245,12 +258,19 @@ class SegmentByChunks:
             self.param_dict['engine'] = HipEngine(self.betas, self.genome, device=getattr(self.args, 'device', 0),
                                                   site_range=(lo, hi))
         try:
-            arr = self.param_dict['engine'].segment_many(list(zip(starts, ends)), self.param_dict)
-            # merge chunks from the same "tag" group (segment.py:148-154); all groups advance round by round together
-            groups = {}
-            for i, t in enumerate(tags):
-                groups.setdefault(t, []).append(arr[i])
-            merged = self.merge_groups(groups)
+            eng = self.param_dict['engine']
+            if hasattr(eng, 'segment_regions'):
+                # native chunk grid + batched patches + stitching around the GPU batches (csrc/stitch.h)
+                regs = self.regions()
+                merged = dict(zip([f'{a}-{b}' for a, b in regs],
+                                  eng.segment_regions(regs, self.args.chunk_size, self.param_dict)))
+            else:
+                arr = eng.segment_many(list(zip(starts, ends)), self.param_dict)
+                # merge chunks from the same "tag" group (segment.py:148-154); all groups advance round by round together
+                groups = {}
+                for i, t in enumerate(tags):
+                    groups.setdefault(t, []).append(arr[i])
+                merged = self.merge_groups(groups)
         finally:
             if own_engine:
                 self.param_dict['engine'].close()
