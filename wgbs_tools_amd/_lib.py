@@ -51,6 +51,34 @@ class Timings(C.Structure):
 _lib = None
 _synth = None
 ERRLEN = 512
+_hip_preloaded = False
+
+
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP/HSA runtime.  The PyTorch wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7, the same as /opt/rocm's): whichever copy is loaded first serves both torch and this library,
+    but if ours came first torch would load a second runtime by file name and find no GPU.  So when torch is
+    installed and not yet imported, map its copy first (no `import torch`: that costs seconds)."""
+    global _hip_preloaded
+    if _hip_preloaded:
+        return
+    _hip_preloaded = True
+    import importlib.util
+    import sys
+    if 'torch' in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = op.join(op.dirname(spec.origin), 'lib', 'libamdhip64.so')
+    if op.isfile(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -61,6 +89,7 @@ def load():
     if not op.isfile(LIB_PATH):
         raise NativeLibraryError('%s is missing: build it with `python -m wgbs_tools_amd.build` (needs hipcc). '
                                  'There is no CPU fallback.' % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     L.wgbsseg_version.restype = i32
@@ -105,6 +134,7 @@ def load_synth():
     if _synth is None:
         if not op.isfile(SYNTH_LIB_PATH):
             raise NativeLibraryError('%s is missing: build it with `python -m wgbs_tools_amd.build`' % SYNTH_LIB_PATH)
+        _share_hip_runtime_with_torch()
         S = C.CDLL(SYNTH_LIB_PATH)
         S.wgbssynth_fill_betas.restype = C.c_int
         S.wgbssynth_fill_betas.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
