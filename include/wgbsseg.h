@@ -63,8 +63,10 @@ typedef struct wgbsseg_timings {
     int64_t scan_bytes;      /* algorithmic bytes of the scan pass: 2 * n_samples * sites              */
     int32_t max_window;      /* largest W_i                                                            */
     int32_t n_stages;
-    int32_t scan_launches;   /* kernel launches behind scan_ms (1 per call)                            */
+    int32_t scan_launches;   /* kernel launches behind scan_ms (1 per batch)                           */
     int32_t reserved;
+    double  scan_main_ms;    /* duration of the largest scan launch of the call (the batch holding the chunks) */
+    int64_t scan_main_bytes; /* its algorithmic bytes                                                  */
 } wgbsseg_timings;
 
 int wgbsseg_version(void);
@@ -115,7 +117,8 @@ int wgbsseg_segment_chunks(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const 
  * patch-doubling rules (segment.py:219-252); failed attempts are re-batched.  Output (CSR over regions): the
  * merged ABSOLUTE 1-based border list of each region (first region_start, last region_end); consecutive pairs
  * are the blocks (startCpG, endCpG) the reference writes (segment.py:154).  borders_cap >= sum(region lengths) +
- * n_regions always suffices.  stats (optional, 4 x int64): chunks, patch DPs run, GPU batches, junctions.
+ * n_regions always suffices.  stats (optional, 8 x int64): chunks, patch DPs run, GPU batches, patches planned up
+ * front, host wall microseconds of the whole call / of the first batch / of the follow-up batches, total borders.
  * wgbsseg_get_timings() afterwards returns the sums over all batches of the call.
  */
 int wgbsseg_segment_regions(wgbsseg_ctx* ctx, const int64_t* region_start, const int64_t* region_end, int64_t n_regions,

@@ -2,26 +2,29 @@
 // driven by a Python callback as the chunk engine, so the CPU suite can check it against the reference driver's
 // golden vectors without a GPU.  Build: g++ -O2 -std=c++17 -shared -fPIC.
 #include "../../wgbs_tools_amd/csrc/stitch.h"
+#include <cstdio>
 
 extern "C" {
 // callback: for `n` 1-based site ranges (starts/ends) fill CSR (out, off[n+1]) with ABSOLUTE borders; returns 0
 typedef int (*engine_cb)(const int64_t* starts, const int64_t* ends, int64_t n, int64_t* out, int64_t cap, int64_t* off);
 
 int stitch_segment_regions(const int64_t* rs, const int64_t* re, int64_t n_regions, int64_t chunk_size, engine_cb cb,
-                           int64_t* borders_out, int64_t cap, int64_t* borders_off, int64_t* stats, char* err, size_t errlen)
+                           int64_t* borders_out, int64_t cap, int64_t* borders_off, int64_t* stats, char* err, size_t errlen, int speculate)
 {
-    wgstitch::BatchFn fn = [&](const std::vector<wgstitch::Sites>& todo, std::vector<std::vector<int64_t>>& res, std::string& msg) -> int {
-        std::vector<int64_t> s(todo.size()), e(todo.size()), off(todo.size() + 1);
+    wgstitch::BatchFn fn = [&](const std::vector<wgstitch::Sites>& todo, wgstitch::BatchResult& res, std::string& msg) -> int {
+        std::vector<int64_t> s(todo.size()), e(todo.size());
+        res.off.resize(todo.size() + 1);
         int64_t c = 0;
         for (size_t i = 0; i < todo.size(); i++) { s[i] = todo[i].first; e[i] = todo[i].second; c += e[i] - s[i] + 1; }
         std::vector<int64_t> out((size_t)c);
-        if (cb(s.data(), e.data(), (int64_t)todo.size(), out.data(), c, off.data()) != 0) { msg = "engine callback failed"; return -1; }
-        res.resize(todo.size());
-        for (size_t i = 0; i < todo.size(); i++) res[i].assign(out.begin() + off[i], out.begin() + off[i + 1]);
+        if (cb(s.data(), e.data(), (int64_t)todo.size(), out.data(), c, res.off.data()) != 0) { msg = "engine callback failed"; return -1; }
+        res.flat.reset(new int32_t[(size_t)c]);
+        for (size_t i = 0; i < todo.size(); i++)
+            for (int64_t q = res.off[i]; q < res.off[i + 1]; q++) res.flat[(size_t)q] = (int32_t)(out[(size_t)q] - s[i]);   // relative, as the GPU path returns
         return 0;
     };
     std::string msg;
-    int rc = wgstitch::segment_regions(rs, re, n_regions, chunk_size, fn, borders_out, cap, borders_off, stats, msg);
+    int rc = wgstitch::segment_regions(rs, re, n_regions, chunk_size, fn, borders_out, cap, borders_off, stats, msg, speculate != 0);
     if (err && errlen) { snprintf(err, errlen, "%s", msg.c_str()); }
     return rc;
 }

@@ -259,7 +259,7 @@ def stitch_lib():
     return C.CDLL(lib)
 
 
-def native_segment_regions(stitch_lib, engine, params, regions, chunk_size):
+def native_segment_regions(stitch_lib, engine, params, regions, chunk_size, speculate=0):
     import ctypes as C
     CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64), C.c_int64,
                      C.POINTER(C.c_int64))
@@ -280,18 +280,19 @@ def native_segment_regions(stitch_lib, engine, params, regions, chunk_size):
     cap = int((re_ - rs).sum()) + len(regions)
     out = np.empty(cap, dtype=np.int64)
     off = np.empty(len(regions) + 1, dtype=np.int64)
-    stats = np.zeros(4, dtype=np.int64)
+    stats = np.zeros(8, dtype=np.int64)
     err = C.create_string_buffer(512)
     rc = stitch_lib.stitch_segment_regions(rs.ctypes.data_as(C.POINTER(C.c_int64)), re_.ctypes.data_as(C.POINTER(C.c_int64)),
                                            len(regions), C.c_int64(chunk_size), CB(cb), out.ctypes.data_as(C.POINTER(C.c_int64)),
                                            C.c_int64(cap), off.ctypes.data_as(C.POINTER(C.c_int64)),
-                                           stats.ctypes.data_as(C.POINTER(C.c_int64)), err, 512)
+                                           stats.ctypes.data_as(C.POINTER(C.c_int64)), err, 512, int(speculate))
     assert rc == 0, err.value
     return [out[off[r]:off[r + 1]].copy() for r in range(len(regions))], stats
 
 
+@pytest.mark.parametrize('speculate', [0, 1])
 @pytest.mark.parametrize('name', CASES)
-def test_native_stitching_matches_reference_driver(name, driver_golden, synth_world, stitch_lib):
+def test_native_stitching_matches_reference_driver(name, speculate, driver_golden, synth_world, stitch_lib):
     g = driver_golden['cases'][name]
     kw = dict(chunk_size=60000, pcount=15, min_cpg=1, max_cpg=1000, max_bp=2000)
     kw.update({k: v for k, v in g['args'].items() if k in kw})
@@ -303,11 +304,14 @@ def test_native_stitching_matches_reference_driver(name, driver_golden, synth_wo
             a, b = t.split('-')
             regions.append((int(a), int(b)))
     eng = OracleEngine(synth_world['betas'], synth_world['loci'])
-    res, stats = native_segment_regions(stitch_lib, eng, params, regions, kw['chunk_size'])
+    res, stats = native_segment_regions(stitch_lib, eng, params, regions, kw['chunk_size'], speculate)
     nch = len(g['chunks']['starts'])
     assert stats[0] == nch
     assert eng.calls[:nch] == list(zip(g['chunks']['starts'], g['chunks']['ends']))       # chunk grid
-    assert set(eng.calls[nch:]) == set(tuple(c) for c in g['patch_calls'])               # same patches, no extras
+    if speculate:       # second-attempt patches are computed ahead of need: a superset, same result
+        assert set(eng.calls[nch:]) >= set(tuple(c) for c in g['patch_calls'])
+    else:
+        assert set(eng.calls[nch:]) == set(tuple(c) for c in g['patch_calls'])            # same patches, no extras
     s = np.concatenate([r[:-1] for r in res]); e = np.concatenate([r[1:] for r in res])
     order = np.argsort(s, kind='stable'); s, e = s[order], e[order]
     keep = (e - s) > kw['min_cpg'] - 1

@@ -12,31 +12,34 @@ def windows(loci, max_cpg, max_bp):
     lo = np.maximum(np.searchsorted(l, l - max_bp, 'left'), i + 1 - max_cpg)
     return (i - lo + 1).astype(np.int64)
 
+def group_start(start0, k):
+    a = (start0 + k) & ~63
+    return 0 if a <= start0 else a - start0
+
 def emu_scan_carries(row, start0, ln):
-    """k_scan for one (chunk, sample) row: returns carry array (nG,2)."""
-    nG = ln // 64 + 1
+    """k_scan for one (chunk, sample) row: carry[g] at absolute 64-multiples (g>=1) / chunk start (g=0)."""
+    g0 = start0 >> 6
+    nG = ((start0 + ln - 1) >> 6) - g0 + 1
     carry = np.full((nG, 2), -1, dtype=np.int64)
+    carry[0] = 0
     n_total = row.shape[0]
     a_abs = start0 & ~7; head = start0 - a_abs; span = head + ln
     run = np.zeros(2, dtype=np.int64)
     for base in range(0, span, 512):
-        tot = np.zeros((64, 2), dtype=np.int64); part = np.zeros((64, 2), dtype=np.int64); jst = np.zeros(64, dtype=np.int64)
+        tot = np.zeros((64, 2), dtype=np.int64)
         for lane in range(64):
             off = base + lane * 8; rel0 = off - head
-            jstar = (-rel0) & 63; jst[lane] = jstar
             for j in range(8):
                 a = a_abs + off + j
                 m, c = (row[a] if (off < span and a < n_total) else (0, 0))
                 rel = rel0 + j
                 if not (0 <= rel < ln): m = c = 0
-                if j < jstar: part[lane] += (m, c)
                 tot[lane] += (m, c)
         incl = np.cumsum(tot, axis=0)
         for lane in range(64):
-            if jst[lane] < 8:
-                relb = base + lane * 8 - head + jst[lane]
-                if 0 <= relb <= ln:
-                    carry[relb >> 6] = run + incl[lane] - tot[lane] + part[lane]
+            off = base + lane * 8; rel0 = off - head; vabs = a_abs + off
+            if (vabs & 63) == 0 and 0 < rel0 < ln:
+                carry[(vabs >> 6) - g0] = run + incl[lane] - tot[lane]
         run += incl[63]
     return carry
 
@@ -44,8 +47,9 @@ def emu_stage_row(row, carry, start0, ln, A, cnt):
     """wg_stage_prefix_row: returns dst[0..cnt) (uint2)."""
     n_total = row.shape[0]
     dst = np.full((cnt, 2), -1, dtype=np.int64)
-    run = carry[A >> 6].copy()
-    abs0 = start0 + A; al = abs0 & ~3; hs = abs0 - al
+    abs0 = start0 + A
+    run = carry[(abs0 >> 6) - (start0 >> 6)].copy()
+    al = abs0 & ~3; hs = abs0 - al
     for p0 in range(0, cnt + hs, 256):
         tot = np.zeros((64, 2), dtype=np.int64); vals = np.zeros((64, 4, 2), dtype=np.int64)
         for lane in range(64):
@@ -66,7 +70,7 @@ def emu_stage_row(row, carry, start0, ln, A, cnt):
         run = run + incl[63]
     return dst
 
-def emu_cost_tiles(W, n, S, stage, TI, KT, TK, Wmax):
+def emu_cost_tiles(W, n, S, stage, TI, KT, TK, Wmax, start0=0):
     """k_cost tile decomposition for one chunk: yields (pairs list of (i,k)) per tile; checks K/I array bounds."""
     s0 = stage * S; s1 = min(s0 + S, n)
     if s0 >= n: return
@@ -86,10 +90,11 @@ def emu_cost_tiles(W, n, S, stage, TI, KT, TK, Wmax):
                 kmin = ks if kmin is None else min(kmin, ks)
                 pairs += [(i, k) for k in range(ks, ke + 1)]
         if not pairs: continue
-        kA = kmin & ~63
+        kA = group_start(start0, kmin)
+        assert kmin - kA <= 63
         assert kA >= 0
         if KT > 1:
-            iA = ia & ~63; Kcnt = kt_hi - kA; Icnt = ib + 1 - iA
+            iA = group_start(start0, ia); Kcnt = kt_hi - kA; Icnt = ib + 1 - iA
             assert Kcnt <= KS and Icnt <= IS, (Kcnt, KS, Icnt, IS)
             for (i, k) in pairs: assert 0 <= k - kA < Kcnt and 0 <= i + 1 - iA < Icnt
         else:
@@ -166,13 +171,17 @@ if __name__ == '__main__':
     # scan carries + staged prefix rows
     rng = np.random.default_rng(0)
     row = rng.integers(0, 200, (5000, 2)); row[:, 0] = np.minimum(row[:, 0], row[:, 1])
-    for start0, ln in [(0, 1), (3, 700), (8, 512), (13, 4000), (4990, 10), (1, 64), (7, 129)]:
+    for start0, ln in [(0, 1), (3, 700), (8, 512), (13, 4000), (4990, 10), (1, 64), (7, 129), (64, 200), (63, 2), (100, 1000)]:
         carry = emu_scan_carries(row, start0, ln)
         P = np.concatenate([[[0, 0]], np.cumsum(row[start0:start0 + ln], axis=0)])
-        for g in range(ln // 64 + 1):
-            if g * 64 < ln:
-                assert (carry[g] == P[g * 64]).all(), (start0, ln, g, carry[g], P[g * 64])
-        for A in range(0, ln, 64):
+        g0 = start0 >> 6
+        for g in range(carry.shape[0]):
+            pos = 0 if g == 0 else ((g0 + g) << 6) - start0
+            if g > 0 and pos >= ln: continue
+            assert (carry[g] == P[pos]).all(), (start0, ln, g, carry[g], P[pos])
+        for k in list(range(0, ln, 37)) + [ln - 1]:
+            A = group_start(start0, k)
+            assert 0 <= k - A <= 63
             for cnt in (1, 5, 64, 65, 200, 300):
                 dst = emu_stage_row(row, carry, start0, ln, A, cnt)
                 for x in range(cnt):

@@ -42,7 +42,8 @@ class Timings(C.Structure):
     _fields_ = [('scan_ms', C.c_double), ('window_ms', C.c_double), ('cost_ms', C.c_double), ('dp_ms', C.c_double),
                 ('trace_ms', C.c_double), ('total_ms', C.c_double), ('sites', C.c_int64), ('pairs', C.c_int64),
                 ('evals', C.c_int64), ('scan_bytes', C.c_int64), ('max_window', C.c_int32), ('n_stages', C.c_int32),
-                ('scan_launches', C.c_int32), ('reserved', C.c_int32)]
+                ('scan_launches', C.c_int32), ('reserved', C.c_int32), ('scan_main_ms', C.c_double),
+                ('scan_main_bytes', C.c_int64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != 'reserved'}
@@ -229,13 +230,14 @@ class Segmenter:
         cap = int((ends - starts).sum()) + n
         out = np.empty(cap, dtype=np.int64)
         off = np.empty(n + 1, dtype=np.int64)
-        stats = np.zeros(4, dtype=np.int64)
+        stats = np.zeros(8, dtype=np.int64)
         p = Params(float(pcount), int(max_cpg), int(max_bp))
         _check(self._L.wgbsseg_segment_regions(self._h, starts.ctypes.data, ends.ctypes.data, n, int(chunk_size), C.byref(p),
                                                out.ctypes.data, cap, off.ctypes.data, stats.ctypes.data, self._err, ERRLEN),
                self._err)
         res = [out[off[r]:off[r + 1]] for r in range(n)]
-        return res, dict(chunks=int(stats[0]), patch_dps=int(stats[1]), batches=int(stats[2]), junctions=int(stats[3]))
+        return res, dict(chunks=int(stats[0]), patch_dps=int(stats[1]), batches=int(stats[2]), patches_planned=int(stats[3]),
+                         wall_us=int(stats[4]), first_batch_us=int(stats[5]), later_batches_us=int(stats[6]))
 
     def prefix_sums(self, start0, length):
         out = np.empty((self.n_samples, length + 1, 2), dtype=np.uint32)

@@ -17,7 +17,8 @@
 #include "exact_log2.h"
 #include "wave_prims.h"
 
-#define WG_CARRY_G      64          // a carry (exclusive prefix) is stored every 64 sites of a chunk
+#define WG_CARRY_G      64          // a carry (chunk-relative exclusive prefix) is stored at every absolute site index
+                                    // that is a multiple of 64 inside the chunk, plus (group 0) at the chunk start itself
 #define WG_BLOCK        256
 #define WG_RMAX         16          // candidate blocks per thread held in registers by k_cost
 #define WG_PAIR_CAP     (WG_BLOCK * WG_RMAX)
@@ -28,7 +29,7 @@ struct ChunkDesc {
     int64_t site_off;    // offset of this chunk in the job-site arrays (W16, cum32, back16)
     int64_t carry_off;   // offset (in uint2) of this chunk's carries: [n_samples][nG]
     int32_t len;
-    int32_t nG;          // len / 64 + 1
+    int32_t nG;          // 64-site groups of ABSOLUTE site index the chunk touches: ((start0+len-1)>>6) - (start0>>6) + 1
 };
 
 struct JobView {
@@ -81,6 +82,26 @@ __device__ __forceinline__ uint4 wg_load16_guarded(const uint8_t* row, int64_t a
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// Sums of the 8 (#meth, #cov) byte pairs of a 16-byte vector, and whether any pair has #meth > #cov.
+// A dword holds two sites: bytes (m0, c0, m1, c1).  Even bytes / odd bytes are summed in two 16-bit lanes.
+__device__ __forceinline__ void wg_sum8(const uint4 v, uint32_t& tm, uint32_t& tt, bool& anybad)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t sm = 0, sc = 0, ok = 0x01000100u;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t m = w[d] & 0x00ff00ffu, c = (w[d] >> 8) & 0x00ff00ffu;
+        sm += m; sc += c;                                  // <= 4*255 per 16-bit lane
+        ok &= (c | 0x01000100u) - m;                       // bit 8 / 24 stays set iff c >= m in that lane
+    }
+    tm = (sm & 0xffffu) + (sm >> 16);
+    tt = (sc & 0xffffu) + (sc >> 16);
+    anybad = (ok & 0x01000100u) != 0x01000100u;
+}
+
+// One wavefront streams one (chunk, sample) row, 64 lanes x 16 B = 512 sites per iteration, two iterations in
+// flight.  Lane vectors are 16-byte aligned in the sample row, so every 8th lane starts on an absolute site index
+// that is a multiple of 64: that lane stores the carry of its group, no intra-vector partial sums needed.
 __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
 {
     const int lane = threadIdx.x & 63;
@@ -96,46 +117,51 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
     const int64_t a_abs = cd.start0 & ~7LL;           // first 16-byte aligned site of the stream
     const int head = (int)(cd.start0 - a_abs);        // sites of the first vector that precede the chunk
     const int64_t span = (int64_t)head + cd.len;      // sites from a_abs to the chunk end
+    const int64_t g0 = cd.start0 >> 6;
     uint32_t run_m = 0, run_t = 0;
-    bool bad = false;
-    int64_t bad_abs = 0;
+    int64_t bad_abs = -1;
+    if (lane == 0) carry[0] = make_uint2(0u, 0u);     // group 0: the chunk start
 
-    uint4 cur = make_uint4(0, 0, 0, 0);
+    uint4 cur = make_uint4(0, 0, 0, 0), nxt = make_uint4(0, 0, 0, 0);
     if ((int64_t)lane * 8 < span) cur = wg_load16_guarded(row, a_abs + (int64_t)lane * 8, J.n_total);
+    if ((int64_t)lane * 8 + 512 < span) nxt = wg_load16_guarded(row, a_abs + (int64_t)lane * 8 + 512, J.n_total);
     for (int64_t base = 0; base < span; base += 512) {
         const int64_t off = base + (int64_t)lane * 8;  // site offset of this lane's vector from a_abs
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (off + 512 < span) nxt = wg_load16_guarded(row, a_abs + off + 512, J.n_total);   // prefetch
+        uint4 nn = make_uint4(0, 0, 0, 0);
+        if (off + 1024 < span) nn = wg_load16_guarded(row, a_abs + off + 1024, J.n_total);   // two iterations ahead
 
-        const uint32_t w[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint4 v = cur;
         const int64_t rel0 = off - head;               // chunk-relative index of the vector's first site
-        // position of a 64-site boundary inside this vector (8 = none)
-        const int jstar = (int)((uint64_t)(-rel0) & 63);
-        uint32_t tm = 0, tt = 0, pm = 0, pt = 0;
+        if (rel0 < 0 || rel0 + 8 > cd.len) {           // edge vector: blank the sites outside the chunk
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t h = w[j >> 1] >> (16 * (j & 1));
-            uint32_t m = h & 0xffu, cv = (h >> 8) & 0xffu;
-            const int64_t rel = rel0 + j;
-            const bool in = rel >= 0 && rel < cd.len;
-            if (!in) { m = 0; cv = 0; }
-            if (m > cv && !bad) { bad = true; bad_abs = cd.start0 + rel; }
-            if (j < jstar) { pm += m; pt += cv; }
-            tm += m; tt += cv;
+            for (int j = 0; j < 8; j++) {
+                const int64_t rel = rel0 + j;
+                if (rel < 0 || rel >= cd.len) w[j >> 1] &= ~(0xffffu << (16 * (j & 1)));
+            }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        // wave-wide exclusive prefix of the lane totals (two 32-bit DPP scans)
+        uint32_t tm, tt;
+        bool anybad;
+        wg_sum8(v, tm, tt, anybad);
+        if (anybad && bad_abs < 0) {                   // rare: find the first offending site of this vector
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            for (int j = 7; j >= 0; j--) {
+                const uint32_t h = w[j >> 1] >> (16 * (j & 1));
+                if ((h & 0xffu) > ((h >> 8) & 0xffu)) bad_abs = cd.start0 + rel0 + j;
+            }
+        }
+        // wave-wide inclusive prefix of the lane totals (two 32-bit DPP scans)
         const uint32_t im = wg_wave_incl_scan_dpp_u32(tm);
         const uint32_t it = wg_wave_incl_scan_dpp_u32(tt);
-        if (jstar < 8) {
-            const int64_t relb = rel0 + jstar;
-            if (relb >= 0 && relb <= cd.len)
-                carry[relb >> 6] = make_uint2(run_m + (im - tm) + pm, run_t + (it - tt) + pt);
-        }
+        const int64_t vabs = a_abs + off;              // absolute index of the vector's first site
+        if ((vabs & 63) == 0 && rel0 > 0 && rel0 < cd.len)
+            carry[(vabs >> 6) - g0] = make_uint2(run_m + (im - tm), run_t + (it - tt));
         run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
         run_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
-        cur = nxt;
+        cur = nxt; nxt = nn;
     }
-    if (bad) atomicMin(&st->first_bad, ((unsigned long long)s << 40) | (unsigned long long)bad_abs);
+    if (bad_abs >= 0) atomicMin(&st->first_bad, ((unsigned long long)s << 40) | (unsigned long long)bad_abs);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -257,14 +283,15 @@ struct CostArgs {
 };
 
 // Stage `cnt` exclusive prefixes P[A+x], x = 0..cnt-1, of sample row `row` into dst (one wavefront).
-// A is chunk-relative and a multiple of 64, so the 64-site carry of k_scan seeds the scan.
+// A is chunk-relative; start0+A is either the chunk start or a multiple of 64 (wg_group_start), so a carry of
+// k_scan seeds the scan.
 __device__ __forceinline__ void wg_stage_prefix_row(uint2* __restrict__ dst, const uint8_t* __restrict__ row,
                                                     const uint2* __restrict__ carry, const ChunkDesc& cd,
                                                     int64_t n_total, int A, int cnt, int lane)
 {
-    const uint2 c0 = carry[A >> 6];
-    uint32_t run_m = c0.x, run_t = c0.y;
     const int64_t abs0 = cd.start0 + A;
+    const uint2 c0 = carry[(abs0 >> 6) - (cd.start0 >> 6)];
+    uint32_t run_m = c0.x, run_t = c0.y;
     const int64_t al = abs0 & ~3LL;                    // 8-byte aligned
     const int hs = (int)(abs0 - al);
     for (int p0 = 0; p0 < cnt + hs; p0 += 256) {
@@ -305,6 +332,13 @@ __device__ __forceinline__ void wg_stage_prefix_row(uint2* __restrict__ dst, con
         const uint32_t wt = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         run_m += wt & 0xffffu; run_t += wt >> 16;
     }
+}
+
+// Largest carry position <= chunk-relative site k: the 64-aligned absolute index below it, or the chunk start.
+__device__ __forceinline__ int wg_group_start(const ChunkDesc& cd, int k)
+{
+    const int64_t a = (cd.start0 + k) & ~63LL;
+    return a <= cd.start0 ? 0 : (int)(a - cd.start0);
 }
 
 template <int TI>
@@ -376,11 +410,11 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     __syncthreads();
     const int Q = offs[TI < ni ? TI : ni];
     if (Q == 0) return;
-    const int kA = misc[0] & ~63;                        // 64-aligned start of the K array
+    const int kA = wg_group_start(cd, misc[0]);          // carry position at or below the first candidate start
     int iA, ioff;                                        // I entries: index (i+1) - iA = il + ioff
     const uint2* Ibase;
     int Istride;
-    if (A.KT > 1) { iA = ia & ~63; Ibase = It; Istride = A.IS; }
+    if (A.KT > 1) { iA = wg_group_start(cd, ia); Ibase = It; Istride = A.IS; }
     else          { iA = kA;       Ibase = Kt; Istride = A.KS; }
     ioff = ia + 1 - iA;
     const int Kcnt = ((A.KT > 1) ? kt_hi : ib + 1) - kA;  // entries needed in the K array
@@ -447,16 +481,52 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_dp: one wavefront per chunk.
+// k_dp: one workgroup of two wavefronts per chunk.  Wave 0 owns the chunk's recurrence; wave 1 is its loader: while
+// wave 0 sweeps the 64 steps of batch b out of LDS, wave 1 copies the scored-block rows and the per-step metadata
+// of batch b+1 (contiguous in the CSR) from HBM into the other LDS slot.  One s_barrier per 64 steps.
 // ------------------------------------------------------------------------------------------------------------
-struct DpArgs { int32_t ringN; int32_t pad; };
+struct DpArgs { int32_t ringN; int32_t slot_cap; };     // slot_cap: doubles per staged batch (0: never stage)
 
-__global__ __launch_bounds__(64) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
-                                           double* __restrict__ state)
+struct DpMeta {               // per LDS slot
+    uint32_t w[64];           // window length of each step of the batch
+    uint32_t rel[64];         // row offset of each step inside the stage's cost rows of this chunk
+    uint32_t first;           // rel of the batch's first step
+    uint32_t staged;          // 1: rows [first, first+span) are in the slot
+    uint32_t pad[2];
+};
+
+__device__ __forceinline__ void wg_dp_load_batch(const double* __restrict__ cb, const uint16_t* __restrict__ Wp,
+                                                 const uint32_t* __restrict__ Cp, uint32_t cum0, int base, int s1,
+                                                 int slot_cap, double* __restrict__ slot, DpMeta* __restrict__ meta, int lane)
+{
+    const int il = base + lane;
+    const bool inb = il < s1;
+    const uint32_t w = inb ? (uint32_t)Wp[il] : 0u;
+    const uint32_t rel = inb ? Cp[il] - cum0 : 0u;
+    const int nst = (s1 - base < 64) ? s1 - base : 64;
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)rel, 0);
+    const uint32_t last_rel = (uint32_t)__builtin_amdgcn_readlane((int)rel, nst - 1);
+    const uint32_t last_w = (uint32_t)__builtin_amdgcn_readlane((int)w, nst - 1);
+    const uint32_t span = last_rel + last_w - first;
+    const bool staged = span <= (uint32_t)slot_cap;
+    meta->w[lane] = inb ? w : 1u;
+    meta->rel[lane] = rel;
+    if (lane == 0) { meta->first = first; meta->staged = staged ? 1u : 0u; }
+    if (staged) {
+        const double* src = cb + first;
+        for (uint32_t x = (uint32_t)lane; x < span; x += 64) slot[x] = src[x];
+    }
+}
+
+__global__ __launch_bounds__(128) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
+                                            double* __restrict__ state)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_dp[];
     double* ring = reinterpret_cast<double*>(smem_dp);       // M[k] at slot k & (ringN-1), last >= max(64,max_cpg) values
-    const int lane = threadIdx.x;
+    double* slots = ring + A.ringN;                           // [2][slot_cap]
+    DpMeta* metas = reinterpret_cast<DpMeta*>(slots + 2 * (size_t)A.slot_cap);
+    const int lane = threadIdx.x & 63;
+    const bool loader = threadIdx.x >= 64;
     const int c = blockIdx.x;
     const int nC = J.n_chunks;
     const ChunkDesc cd = J.chunks[c];
@@ -465,80 +535,96 @@ __global__ __launch_bounds__(64) void k_dp(JobView J, StageView SV, const double
     const int s1 = (s0 + SV.S < cd.len) ? s0 + SV.S : cd.len;
     const int rmask = A.ringN - 1;
     double* gs = state + (int64_t)c * A.ringN;
-    if (s0 == 0) { for (int x = lane; x < A.ringN; x += 64) ring[x] = 0.0; }       // M[0] = 0 (segmentor.cpp:97)
-    else         { for (int x = lane; x < A.ringN; x += 64) ring[x] = gs[x]; }
-    __syncthreads();
-    double mreg;                                         // M[k] of the latest k <= i with k == lane (mod 64)
-    { const int k = s0 - ((s0 - lane) & 63); mreg = (k >= 0) ? ring[k & rmask] : 0.0; }
-
     const double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
     const uint16_t* Wp = J.W16 + cd.site_off;
     const uint32_t* Cp = J.cum32 + cd.site_off;
     const double NEG_INF = -__builtin_inf();
+    const int nb = (s1 - s0 + 63) >> 6;
 
-    for (int base = s0; base < s1; base += 64) {
-        const int il = base + lane;
-        const bool inb = il < s1;
-        const uint32_t w_l = inb ? (uint32_t)Wp[il] : 1u;
-        const uint32_t rel_l = inb ? Cp[il] - cum0 : 0u;
-        uint32_t tbk = 0;
-        const int nst = (s1 - base < 64) ? s1 - base : 64;
-        for (int g = 0; g < nst; g += 8) {
-            double cv[8];
-            uint32_t ws[8], rs[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {                 // issue the loads of 8 steps up front
-                const int stp = g + u;
-                cv[u] = 0.0; ws[u] = 1; rs[u] = 0;
-                if (stp < nst) {
-                    ws[u] = (uint32_t)__builtin_amdgcn_readlane((int)w_l, stp);
-                    rs[u] = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, stp);
-                    const int i = base + stp;
-                    const int lo = i - (int)ws[u] + 1;
-                    const uint32_t j = (uint32_t)(lane - lo) & 63u;
-                    if (ws[u] <= 64u && j < ws[u]) cv[u] = cb[(int64_t)rs[u] + j];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int stp = g + u;
-                if (stp < nst) {
-                    const int i = base + stp;
-                    const uint32_t w = ws[u];
-                    const int lo = i - (int)w + 1;
-                    double vmax;
-                    int kbest;
-                    if (w <= 64u) {
-                        const uint32_t j = (uint32_t)(lane - lo) & 63u;
-                        const double v = (j < w) ? mreg + cv[u] : NEG_INF;
-                        vmax = wg_wave_max_f64(v);
-                        const unsigned long long eq = __ballot(v == vmax);
-                        const int rot = lo & 63;
-                        const unsigned long long rm = rot ? ((eq >> rot) | (eq << (64 - rot))) : eq;
-                        kbest = lo + __builtin_ctzll(rm);          // first maximum in ascending k (segmentor.cpp:148)
-                    } else {
-                        double best = NEG_INF;
-                        uint32_t bk = 0xffffffffu;
-                        for (uint32_t jj = (uint32_t)lane; jj < w; jj += 64) {
-                            const int k = lo + (int)jj;
-                            const double v = ring[k & rmask] + cb[(int64_t)rs[u] + jj];
-                            if (v > best) { best = v; bk = (uint32_t)k; }
-                        }
-                        vmax = wg_wave_max_f64(best);
-                        kbest = (int)wg_wave_min_u32(best == vmax ? bk : 0xffffffffu);
-                    }
-                    if (lane == ((i + 1) & 63)) mreg = vmax;
-                    if (lane == 0) ring[(i + 1) & rmask] = vmax;
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane == stp) tbk = (uint32_t)(i + 1 - kbest);
-                }
-            }
-        }
-        if (inb) J.back16[cd.site_off + il] = (uint16_t)tbk;
+    if (loader) {
+        wg_dp_load_batch(cb, Wp, Cp, cum0, s0, s1, A.slot_cap, slots, metas, lane);
+    } else {
+        if (s0 == 0) { for (int x = lane; x < A.ringN; x += 64) ring[x] = 0.0; }       // M[0] = 0 (segmentor.cpp:97)
+        else         { for (int x = lane; x < A.ringN; x += 64) ring[x] = gs[x]; }
     }
     __syncthreads();
-    if (s1 < cd.len) for (int x = lane; x < A.ringN; x += 64) gs[x] = ring[x];
+    double mreg = 0.0;                                   // M[k] of the latest k <= i with k == lane (mod 64)
+    if (!loader) { const int k = s0 - ((s0 - lane) & 63); mreg = (k >= 0) ? ring[k & rmask] : 0.0; }
+
+    for (int b = 0; b < nb; b++) {
+        const int base = s0 + (b << 6);
+        if (loader) {
+            if (b + 1 < nb)
+                wg_dp_load_batch(cb, Wp, Cp, cum0, base + 64, s1, A.slot_cap, slots + (size_t)((b + 1) & 1) * A.slot_cap,
+                                 metas + ((b + 1) & 1), lane);
+        } else {
+            const DpMeta* meta = metas + (b & 1);
+            const double* slot = slots + (size_t)(b & 1) * A.slot_cap;
+            const uint32_t w_l = meta->w[lane];
+            const uint32_t rel_l = meta->rel[lane];
+            const uint32_t first = meta->first;
+            const bool staged = meta->staged != 0;
+            const int il = base + lane;
+            const bool inb = il < s1;
+            uint32_t tbk = 0;
+            const int nst = (s1 - base < 64) ? s1 - base : 64;
+            for (int g = 0; g < nst; g += 8) {
+                double cv[8];
+                uint32_t ws[8], rs[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {                 // fetch the candidates of 8 steps up front
+                    const int stp = g + u;
+                    cv[u] = 0.0; ws[u] = 1; rs[u] = 0;
+                    if (stp < nst) {
+                        ws[u] = (uint32_t)__builtin_amdgcn_readlane((int)w_l, stp);
+                        rs[u] = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, stp);
+                        const int i = base + stp;
+                        const int lo = i - (int)ws[u] + 1;
+                        const uint32_t j = (uint32_t)(lane - lo) & 63u;
+                        if (ws[u] <= 64u && j < ws[u]) cv[u] = staged ? slot[rs[u] - first + j] : cb[(int64_t)rs[u] + j];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int stp = g + u;
+                    if (stp < nst) {
+                        const int i = base + stp;
+                        const uint32_t w = ws[u];
+                        const int lo = i - (int)w + 1;
+                        double vmax;
+                        int kbest;
+                        if (w <= 64u) {
+                            const uint32_t j = (uint32_t)(lane - lo) & 63u;
+                            const double v = (j < w) ? mreg + cv[u] : NEG_INF;
+                            vmax = wg_wave_max_f64(v);
+                            const unsigned long long eq = __ballot(v == vmax);
+                            const int rot = lo & 63;
+                            const unsigned long long rm = rot ? ((eq >> rot) | (eq << (64 - rot))) : eq;
+                            kbest = lo + __builtin_ctzll(rm);          // first maximum in ascending k (segmentor.cpp:148)
+                        } else {
+                            double best = NEG_INF;
+                            uint32_t bk = 0xffffffffu;
+                            for (uint32_t jj = (uint32_t)lane; jj < w; jj += 64) {
+                                const int k = lo + (int)jj;
+                                const double v = ring[k & rmask] + cb[(int64_t)rs[u] + jj];
+                                if (v > best) { best = v; bk = (uint32_t)k; }
+                            }
+                            vmax = wg_wave_max_f64(best);
+                            kbest = (int)wg_wave_min_u32(best == vmax ? bk : 0xffffffffu);
+                        }
+                        if (lane == ((i + 1) & 63)) mreg = vmax;
+                        if (lane == 0) ring[(i + 1) & rmask] = vmax;
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == stp) tbk = (uint32_t)(i + 1 - kbest);
+                    }
+                }
+            }
+            if (inb) J.back16[cd.site_off + il] = (uint16_t)tbk;
+        }
+        __syncthreads();
+    }
+    if (!loader && s1 < cd.len) for (int x = lane; x < A.ringN; x += 64) gs[x] = ring[x];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -645,7 +731,7 @@ __global__ void k_debug_log2(uint32_t first, int64_t count, uint32_t* out_f, uin
 }
 
 // Materialise P[t], t = 0..len, for one range of one sample from the carries (test / block-sum helper):
-// one wavefront per (sample, 64-site group).
+// one wavefront per (sample, 64-site group of absolute site index).
 __global__ __launch_bounds__(64) void k_prefix_materialise(JobView J, int nG, uint32_t* __restrict__ out, int len)
 {
     const int lane = threadIdx.x;
@@ -653,12 +739,13 @@ __global__ __launch_bounds__(64) void k_prefix_materialise(JobView J, int nG, ui
     const ChunkDesc cd = J.chunks[0];
     const uint8_t* row = J.betas + (int64_t)s * J.pitch;
     const uint2 c0 = J.carry[cd.carry_off + (int64_t)s * cd.nG + g];
-    const int x = g * 64 + lane;
+    const int64_t gabs = (((cd.start0 >> 6) + g) << 6);
+    const int64_t x = gabs + lane - cd.start0;             // chunk-relative site of this lane
     uint32_t m = 0, t = 0;
-    if (x < len) { m = row[2 * (cd.start0 + x)]; t = row[2 * (cd.start0 + x) + 1]; }
+    if (x >= 0 && x < len) { m = row[2 * (cd.start0 + x)]; t = row[2 * (cd.start0 + x) + 1]; }
     const uint32_t im = wg_wave_incl_scan_dpp_u32(m), it = wg_wave_incl_scan_dpp_u32(t);
     uint32_t* o = out + ((int64_t)s * (len + 1)) * 2;
-    if (x < len) { o[2 * (x + 1)] = c0.x + im; o[2 * (x + 1) + 1] = c0.y + it; }
+    if (x >= 0 && x < len) { o[2 * (x + 1)] = c0.x + im; o[2 * (x + 1) + 1] = c0.y + it; }
     if (g == 0 && lane == 0) { o[0] = 0; o[1] = 0; }
     (void)nG;
 }

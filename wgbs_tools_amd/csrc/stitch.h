@@ -11,31 +11,35 @@
 // the same batch as the chunks; only failed attempts (doubling) need a follow-up batch.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
 
 namespace wgstitch {
 
-struct Run { const int64_t* p; int64_t n; };            // n >= 1, values strictly ascending, also across runs
+// A run of borders: value x = p[x] + add (chunk DPs return int32 borders relative to their start; `add` = that start).
+struct Run { const int32_t* p; int64_t n; int64_t add; };   // n >= 1, values strictly ascending, also across runs
 
 struct Rope {
     std::vector<Run> runs;
-    int64_t front() const { return runs.front().p[0]; }
-    int64_t back() const { return runs.back().p[runs.back().n - 1]; }
+    int64_t front() const { return runs.front().p[0] + runs.front().add; }
+    int64_t back() const { return runs.back().p[runs.back().n - 1] + runs.back().add; }
     int64_t span() const { return back() - front(); }
     // is value x present?  (binary search over runs, then inside the run)
     bool contains(int64_t x, size_t* run_idx = nullptr, int64_t* pos = nullptr) const
     {
         size_t lo = 0, hi = runs.size();                 // last run with first value <= x
-        while (hi - lo > 1) { size_t mid = (lo + hi) / 2; if (runs[mid].p[0] <= x) lo = mid; else hi = mid; }
+        while (hi - lo > 1) { size_t mid = (lo + hi) / 2; if (runs[mid].p[0] + runs[mid].add <= x) lo = mid; else hi = mid; }
         const Run& r = runs[lo];
-        if (r.p[0] > x) return false;
-        const int64_t* e = std::lower_bound(r.p, r.p + r.n, x);
-        if (e == r.p + r.n || *e != x) return false;
+        const int64_t xr = x - r.add;
+        if (r.p[0] > xr) return false;
+        const int32_t* e = std::lower_bound(r.p, r.p + r.n, xr, [](int32_t a, int64_t b) { return (int64_t)a < b; });
+        if (e == r.p + r.n || (int64_t)*e != xr) return false;
         if (run_idx) *run_idx = lo;
         if (pos) *pos = e - r.p;
         return true;
@@ -53,11 +57,11 @@ struct Rope {
     {
         size_t ri = 0; int64_t pos = 0;
         o.contains(x, &ri, &pos);
-        if (pos + 1 < o.runs[ri].n) runs.push_back(Run{o.runs[ri].p + pos + 1, o.runs[ri].n - pos - 1});
+        if (pos + 1 < o.runs[ri].n) runs.push_back(Run{o.runs[ri].p + pos + 1, o.runs[ri].n - pos - 1, o.runs[ri].add});
         for (size_t q = ri + 1; q < o.runs.size(); q++) runs.push_back(o.runs[q]);
     }
     int64_t size() const { int64_t s = 0; for (auto& r : runs) s += r.n; return s; }
-    void flatten(int64_t* out) const { for (auto& r : runs) { std::copy(r.p, r.p + r.n, out); out += r.n; } }
+    void flatten(int64_t* out) const { for (auto& r : runs) { for (int64_t q = 0; q < r.n; q++) out[q] = (int64_t)r.p[q] + r.add; out += r.n; } }
 };
 
 inline int64_t increase_patch(int64_t pre, int64_t maxval)    // segment.py:249-252
@@ -93,13 +97,13 @@ struct Stitch {
         sites = {b1.back() - p1, b1.back() + p2};
         return true;
     }
-    void feed(const int64_t* patch, int64_t np)
+    void feed(const int32_t* patch, int64_t np, int64_t add)      // patch value q = patch[q] + add
     {
         // is_2_overlap(b1, patch) / (patch, b2): a common value exists (segment.py:235-240)
         int64_t x1 = 0, x2 = 0;
         bool o1 = false, o2 = false;
-        for (int64_t q = 0; q < np && !o1; q++) if (b1.contains(patch[q])) { o1 = true; x1 = patch[q]; }   // smallest common value
-        for (int64_t q = 0; q < np && !o2; q++) if (b2.contains(patch[q])) { o2 = true; x2 = patch[q]; }
+        for (int64_t q = 0; q < np && !o1; q++) if (b1.contains(patch[q] + add)) { o1 = true; x1 = patch[q] + add; }   // smallest common value
+        for (int64_t q = 0; q < np && !o2; q++) if (b2.contains(patch[q] + add)) { o2 = true; x2 = patch[q] + add; }
         if (o1 && o2) {
             // merge2(merge2(b1, patch), b2) (segment.py:221,243-246):
             //   m = b1[.. x1] + patch[> x1];   the first element of m that occurs in b2 is the junction value itself
@@ -110,9 +114,9 @@ struct Stitch {
             if (x1 == junction) {
                 result.append_after(b2, junction);
             } else {
-                const int64_t* a = std::upper_bound(patch, patch + np, x1);
-                const int64_t* b = std::lower_bound(patch, patch + np, x2);     // x2 >= junction > x1
-                if (b + 1 > a) result.runs.push_back(Run{a, (b + 1) - a});
+                const int32_t* a = std::upper_bound(patch, patch + np, x1 - add, [](int64_t v, int32_t e) { return v < (int64_t)e; });
+                const int32_t* b = std::lower_bound(patch, patch + np, x2 - add, [](int32_t e, int64_t v) { return (int64_t)e < v; });   // x2 >= junction > x1
+                if (b + 1 > a) result.runs.push_back(Run{a, (b + 1) - a, add});
                 result.append_after(b2, x2);
             }
             done = true;
@@ -125,7 +129,7 @@ struct Stitch {
 
 // First-attempt patch of every junction of a region cut into chunks of lengths `lens` starting at 1-based `start`:
 // the pairwise tree fixes the operand spans and with them p1, p2.
-inline void upfront_patches(int64_t start, const std::vector<int64_t>& lens, std::vector<std::pair<int64_t, int64_t>>& out)
+inline void upfront_patches(int64_t start, const std::vector<int64_t>& lens, bool speculate, std::vector<std::pair<int64_t, int64_t>>& out)
 {
     struct Seg { int64_t a, b; };                              // site range [a, b)
     std::vector<Seg> segs;
@@ -135,8 +139,15 @@ inline void upfront_patches(int64_t start, const std::vector<int64_t>& lens, std
         std::vector<Seg> nxt;
         for (size_t i = 1; i < segs.size(); i += 2) {
             const Seg &L = segs[i - 1], &R = segs[i];
-            const int64_t p1 = std::min<int64_t>(50, L.b - L.a), p2 = std::min<int64_t>(50, R.b - R.a);
+            const int64_t n1 = L.b - L.a, n2 = R.b - R.a;
+            const int64_t p1 = std::min<int64_t>(50, n1), p2 = std::min<int64_t>(50, n2);
             out.push_back({L.b - p1, L.b + p2});
+            if (speculate) {                                   // the three possible second attempts (segment.py:222-227)
+                const int64_t q1 = increase_patch(p1, n1), q2 = increase_patch(p2, n2);
+                if (q1 <= n1) out.push_back({L.b - q1, L.b + p2});
+                if (q2 <= n2) out.push_back({L.b - p1, L.b + q2});
+                if (q1 <= n1 && q2 <= n2) out.push_back({L.b - q1, L.b + q2});
+            }
             nxt.push_back({L.a, R.b});
         }
         if (segs.size() % 2) nxt.push_back(segs.back());
@@ -145,16 +156,29 @@ inline void upfront_patches(int64_t start, const std::vector<int64_t>& lens, std
 }
 
 typedef std::pair<int64_t, int64_t> Sites;                     // 1-based [start, end)
-// Runs one batch of chunk DPs: res[i] = absolute border list of todo[i] (first = start, last = end).  0 on success.
-typedef std::function<int(const std::vector<Sites>&, std::vector<std::vector<int64_t>>&, std::string&)> BatchFn;
+// Result of one batch of chunk DPs: CSR of int32 borders RELATIVE to each item's start (first 0, last end-start).
+struct BatchResult {
+    std::unique_ptr<int32_t[]> flat;
+    std::vector<int64_t> off;
+};
+typedef std::function<int(const std::vector<Sites>&, BatchResult&, std::string&)> BatchFn;
 enum { E_ARG = -1, E_CAPACITY = -6 };
 
 // The whole driver loop of segment.py:137-165 over `n_regions` regions; see include/wgbsseg.h wgbsseg_segment_regions.
 inline int segment_regions(const int64_t* region_start, const int64_t* region_end, int64_t n_regions, int64_t chunk_size,
                            const BatchFn& run_batch, int64_t* borders_out, int64_t borders_cap, int64_t* borders_off,
-                           int64_t* stats, std::string& err)
+                           int64_t* stats, std::string& err, bool speculate = true)
 {
     if (!region_start || !region_end || n_regions < 1 || chunk_size < 1 || !borders_out || !borders_off) { err = "bad arguments to segment_regions"; return E_ARG; }
+    typedef std::chrono::steady_clock Clock;
+    const Clock::time_point t_begin = Clock::now();
+    int64_t us_batches = 0;
+    auto timed_batch = [&](const std::vector<Sites>& todo, BatchResult& res) -> int {
+        const Clock::time_point t0 = Clock::now();
+        const int r = run_batch(todo, res, err);
+        us_batches += std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - t0).count();
+        return r;
+    };
     // ---- chunk grid (segment.py:124-135) and first-attempt patches ---------------------------------------------
     std::vector<Sites> items;                                  // chunks first, then patches
     std::vector<int64_t> region_first_chunk((size_t)n_regions + 1);
@@ -165,26 +189,30 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
         region_first_chunk[(size_t)r] = (int64_t)items.size();
         std::vector<int64_t> lens;
         for (int64_t s = a; s < b; s += chunk_size) { const int64_t e = std::min(s + chunk_size, b); items.push_back({s, e}); lens.push_back(e - s); }
-        upfront_patches(a, lens, patches);
+        upfront_patches(a, lens, speculate, patches);
     }
     region_first_chunk[(size_t)n_regions] = (int64_t)items.size();
     const int64_t n_chunks = (int64_t)items.size();
-    std::map<Sites, std::vector<int64_t>> cache;               // patch results; node addresses are stable
-    for (auto& p : patches) if (!cache.count(p)) { cache[p]; items.push_back(p); }
+    struct Patch { const int32_t* p; int64_t n; };             // into a BatchResult kept alive in `keep`
+    std::map<Sites, Patch> cache;
+    for (auto& p : patches) if (!cache.count(p)) { cache[p] = Patch{nullptr, 0}; items.push_back(p); }
     int64_t n_batches = 0, n_patch_dp = 0;
+    std::vector<std::unique_ptr<BatchResult>> keep;
 
-    std::vector<std::vector<int64_t>> first;
-    int rc = run_batch(items, first, err);
+    keep.emplace_back(new BatchResult());
+    BatchResult& first = *keep.back();
+    int rc = timed_batch(items, first);
+    const int64_t us_first = us_batches;
     if (rc != 0) return rc;
     n_batches++;
-    for (size_t i = (size_t)n_chunks; i < items.size(); i++) { cache[items[i]] = std::move(first[i]); n_patch_dp++; }
+    for (size_t i = (size_t)n_chunks; i < items.size(); i++) { cache[items[i]] = Patch{first.flat.get() + first.off[i], first.off[i + 1] - first.off[i]}; n_patch_dp++; }
 
     // ---- pairwise-tree stitching (segment.py:157-165), all regions advancing round by round ------------------------
     std::vector<std::vector<Rope>> lists((size_t)n_regions);
     for (int64_t r = 0; r < n_regions; r++)
         for (int64_t q = region_first_chunk[(size_t)r]; q < region_first_chunk[(size_t)r + 1]; q++) {
             Rope rp;
-            rp.runs.push_back(Run{first[(size_t)q].data(), (int64_t)first[(size_t)q].size()});
+            rp.runs.push_back(Run{first.flat.get() + first.off[(size_t)q], first.off[(size_t)q + 1] - first.off[(size_t)q], items[(size_t)q].first});
             lists[(size_t)r].push_back(std::move(rp));
         }
     for (;;) {
@@ -213,21 +241,22 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                 if (s.done) continue;
                 Sites w;
                 if (!s.want(w, err)) return E_ARG;
-                if (!cache.count(w)) { cache[w]; need.push_back(w); }
+                if (!cache.count(w)) { cache[w] = Patch{nullptr, 0}; need.push_back(w); }
             }
             if (!need.empty()) {
-                std::vector<std::vector<int64_t>> res;
-                rc = run_batch(need, res, err);
+                keep.emplace_back(new BatchResult());
+                BatchResult& res = *keep.back();
+                rc = timed_batch(need, res);
                 if (rc != 0) return rc;
                 n_batches++;
-                for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = std::move(res[i]); n_patch_dp++; }
+                for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = Patch{res.flat.get() + res.off[i], res.off[i + 1] - res.off[i]}; n_patch_dp++; }
             }
             for (auto& s : st) {
                 if (s.done) continue;
                 Sites w;
                 s.want(w, err);
-                const std::vector<int64_t>& pv = cache[w];
-                s.feed(pv.data(), (int64_t)pv.size());
+                const Patch& pv = cache[w];
+                s.feed(pv.p, pv.n, w.first);
                 pending = pending || !s.done;
             }
             if (!pending) break;
@@ -241,7 +270,13 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     borders_off[n_regions] = total;
     if (total > borders_cap) { err = "borders_out too small: need " + std::to_string(total); return E_CAPACITY; }
     for (int64_t r = 0; r < n_regions; r++) lists[(size_t)r][0].flatten(borders_out + borders_off[r]);
-    if (stats) { stats[0] = n_chunks; stats[1] = n_patch_dp; stats[2] = n_batches; stats[3] = (int64_t)patches.size(); }
+    if (stats) {
+        stats[0] = n_chunks; stats[1] = n_patch_dp; stats[2] = n_batches; stats[3] = (int64_t)patches.size();
+        stats[4] = std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - t_begin).count();   // whole call, host wall
+        stats[5] = us_first;                                                                                // first (main) batch
+        stats[6] = us_batches - us_first;                                                                   // follow-up batches
+        stats[7] = total;
+    }
     return 0;
 }
 

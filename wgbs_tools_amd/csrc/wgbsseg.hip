@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -232,7 +234,7 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
             return WGBSSEG_E_ARG;
         }
         ChunkDesc& d = job.h[(size_t)i];
-        d.start0 = start0[i]; d.len = len[i]; d.site_off = so; d.carry_off = co; d.nG = len[i] / WG_CARRY_G + 1;
+        d.start0 = start0[i]; d.len = len[i]; d.site_off = so; d.carry_off = co; d.nG = (int32_t)(((start0[i] + len[i] - 1) >> 6) - (start0[i] >> 6) + 1);
         so += len[i];
         co += (int64_t)d.nG * c->n_samples;
         job.max_len = std::max(job.max_len, len[i]);
@@ -295,11 +297,15 @@ void grow_events(std::vector<hipEvent_t>& v, size_t n)
 
 extern "C" {
 
-int wgbsseg_segment_chunks(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
-                           const wgbsseg_params* P, int32_t* borders_out, int64_t borders_cap, int64_t* borders_off,
-                           char* err, size_t errlen)
+}  // extern "C"
+
+namespace {
+typedef std::function<int32_t*(int64_t)> BorderAlloc;       // total border count -> destination (NULL: too small)
+
+int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
+                        const wgbsseg_params* P, const BorderAlloc& alloc, int64_t* borders_off, char* err, size_t errlen)
 {
-    if (!P || !borders_out || !borders_off) { set_err(err, errlen, "NULL params/borders pointer"); return WGBSSEG_E_ARG; }
+    if (!P || !borders_off) { set_err(err, errlen, "NULL params/borders pointer"); return WGBSSEG_E_ARG; }
     if (P->max_bp == 0) { set_err(err, errlen, "max_bp must be >= 1 (the reference reads uninitialised loci when it is 0: segmentor.cpp:38,114)"); return WGBSSEG_E_ARG; }
     if (P->max_cpg < 1) { set_err(err, errlen, "max_cpg must be >= 1"); return WGBSSEG_E_ARG; }
     if (255ull * P->max_cpg >= (1ull << 24) || P->max_cpg > 16384) {
@@ -399,7 +405,13 @@ int wgbsseg_segment_chunks(wgbsseg_ctx* c, const int64_t* chunk_start0, const in
     StageView sv;
     sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbase = c->plan_tbase.as<int64_t>();
     sv.S = S;
-    DpArgs da = {ringN, 0};
+    // LDS of k_dp: M ring + two staged batches of scored-block rows (64 steps x up to 64 candidates) + their metadata
+    int slot_cap = 64 * std::min(Wmax, 64);
+    if (Wmax > 64) slot_cap = 1024;                          // wide windows take the direct path almost always
+    slot_cap = std::min(slot_cap, 4096);
+    while (slot_cap > 64 && (size_t)ringN * 8 + (size_t)slot_cap * 16 + 2 * sizeof(DpMeta) > 150 * 1024) slot_cap /= 2;
+    DpArgs da = {ringN, slot_cap};
+    const size_t lds_dp = (size_t)ringN * 8 + (size_t)slot_cap * 16 + 2 * sizeof(DpMeta);
     for (int stg = 0; stg < n_stages; stg++) {
         sv.stage = stg;
         double* cbuf = c->cost[stg % nbuf].as<double>();
@@ -415,7 +427,7 @@ int wgbsseg_segment_chunks(wgbsseg_ctx* c, const int64_t* chunk_start0, const in
         HIP_TRY(hipEventRecord(c->ev_cost1[stg], c->sA));
         HIP_TRY(hipStreamWaitEvent(c->sB, c->ev_cost1[stg], 0));
         HIP_TRY(hipEventRecord(c->ev_dp0[stg], c->sB));
-        hipLaunchKernelGGL(k_dp, dim3((unsigned)nC), dim3(64), (size_t)ringN * 8, c->sB, v, sv, cbuf, da, c->dpstate.as<double>());
+        hipLaunchKernelGGL(k_dp, dim3((unsigned)nC), dim3(128), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_dp1[stg], c->sB));
     }
@@ -432,7 +444,8 @@ int wgbsseg_segment_chunks(wgbsseg_ctx* c, const int64_t* chunk_start0, const in
     HIP_TRY(hipMemcpyAsync(borders_off, c->boff.p, (size_t)(nC + 1) * 8, hipMemcpyDeviceToHost, c->sB));
     HIP_TRY(hipStreamSynchronize(c->sB));
     const int64_t total_b = borders_off[nC];
-    if (total_b > borders_cap) { set_err(err, errlen, "borders_out too small: need %lld ints, have %lld", (long long)total_b, (long long)borders_cap); return WGBSSEG_E_CAPACITY; }
+    int32_t* borders_out = alloc(total_b);
+    if (!borders_out) { set_err(err, errlen, "borders_out too small: need %lld ints", (long long)total_b); return WGBSSEG_E_CAPACITY; }
     HIP_TRY(hipMemcpyAsync(borders_out, c->out_borders.p, (size_t)total_b * 4, hipMemcpyDeviceToHost, c->sB));
     HIP_TRY(hipEventRecord(c->ev[6], c->sB));
     HIP_TRY(hipStreamSynchronize(c->sB));
@@ -443,6 +456,7 @@ int wgbsseg_segment_chunks(wgbsseg_ctx* c, const int64_t* chunk_start0, const in
     if (!c->accumulate) memset(&T, 0, sizeof(T));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); T.scan_ms += ms;
+    if (2 * J * c->n_samples > T.scan_main_bytes) { T.scan_main_bytes = 2 * J * c->n_samples; T.scan_main_ms = ms; }
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); T.window_ms += ms;
     for (int stg = 0; stg < n_stages; stg++) {
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_cost0[stg], c->ev_cost1[stg])); T.cost_ms += ms;
@@ -455,6 +469,18 @@ int wgbsseg_segment_chunks(wgbsseg_ctx* c, const int64_t* chunk_start0, const in
     T.n_stages = std::max<int32_t>(T.n_stages, n_stages); T.scan_launches += 1;
     c->last_sites = J; c->last_pairs = total_pairs; c->last_stages = n_stages; c->last_valid = true;
     return WGBSSEG_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int wgbsseg_segment_chunks(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
+                           const wgbsseg_params* P, int32_t* borders_out, int64_t borders_cap, int64_t* borders_off,
+                           char* err, size_t errlen)
+{
+    if (!borders_out) { set_err(err, errlen, "NULL borders pointer"); return WGBSSEG_E_ARG; }
+    BorderAlloc alloc = [&](int64_t total) -> int32_t* { return total <= borders_cap ? borders_out : nullptr; };
+    return segment_chunks_impl(c, chunk_start0, chunk_len, n_chunks, P, alloc, borders_off, err, errlen);
 }
 
 int wgbsseg_segment_chunks_host(const uint8_t* betas, int64_t n_samples, int64_t sample_pitch_bytes, int64_t n_sites_total,
@@ -483,34 +509,28 @@ int wgbsseg_segment_regions(wgbsseg_ctx* c, const int64_t* region_start, const i
     const bool acc_before = c->accumulate;
     int64_t n_batches = 0;
     // one GPU batch of 1-based site ranges -> absolute int64 border lists
-    wgstitch::BatchFn run_batch = [&](const std::vector<wgstitch::Sites>& todo, std::vector<std::vector<int64_t>>& res, std::string& msg) -> int {
+    wgstitch::BatchFn run_batch = [&](const std::vector<wgstitch::Sites>& todo, wgstitch::BatchResult& res, std::string& msg) -> int {
         std::vector<int64_t> st0(todo.size());
         std::vector<int32_t> ln(todo.size());
-        int64_t cap = 0;
         for (size_t i = 0; i < todo.size(); i++) {
             st0[i] = todo[i].first - 1;
             if (todo[i].second - todo[i].first > 0x7fffffff) { msg = "chunk too long"; return WGBSSEG_E_ARG; }
             ln[i] = (int32_t)(todo[i].second - todo[i].first);
-            cap += ln[i] + 1;
         }
-        std::vector<int32_t> flat((size_t)cap);
-        std::vector<int64_t> off(todo.size() + 1);
+        res.off.resize(todo.size() + 1);
+        BorderAlloc alloc = [&](int64_t total) -> int32_t* { res.flat.reset(new int32_t[(size_t)std::max<int64_t>(total, 1)]); return res.flat.get(); };
         char ebuf[512] = {0};
         c->accumulate = n_batches > 0;
-        const int rc = wgbsseg_segment_chunks(c, st0.data(), ln.data(), (int64_t)todo.size(), P, flat.data(), cap, off.data(), ebuf, sizeof(ebuf));
+        const int rc = segment_chunks_impl(c, st0.data(), ln.data(), (int64_t)todo.size(), P, alloc, res.off.data(), ebuf, sizeof(ebuf));
         c->accumulate = acc_before;
         if (rc != WGBSSEG_OK) { msg = ebuf; return rc; }
         n_batches++;
-        res.resize(todo.size());
-        for (size_t i = 0; i < todo.size(); i++) {
-            res[i].resize((size_t)(off[i + 1] - off[i]));
-            for (int64_t q = off[i]; q < off[i + 1]; q++) res[i][(size_t)(q - off[i])] = (int64_t)flat[(size_t)q] + todo[i].first;
-        }
         return WGBSSEG_OK;
     };
     std::string msg;
+    static const bool speculate = !(getenv("WGBSSEG_NO_SPECULATION") && atoi(getenv("WGBSSEG_NO_SPECULATION")));
     const int rc = wgstitch::segment_regions(region_start, region_end, n_regions, chunk_size, run_batch, borders_out, borders_cap,
-                                             borders_off, stats, msg);
+                                             borders_off, stats, msg, speculate);
     if (rc != 0) { set_err(err, errlen, "%s", msg.c_str()); return rc == wgstitch::E_CAPACITY ? WGBSSEG_E_CAPACITY : (rc < -1 ? rc : WGBSSEG_E_ARG); }
     return WGBSSEG_OK;
 }
@@ -550,7 +570,7 @@ int wgbsseg_prefix_sums(wgbsseg_ctx* c, int64_t start0, int64_t len, uint32_t* o
     if (rc != WGBSSEG_OK) return rc;
     const size_t bytes = (size_t)c->n_samples * (size_t)(len + 1) * 8;
     HIP_TRY(c->dbg_a.ensure(bytes));
-    const int nG = (int)((len + 63) / 64);
+    const int nG = job.h[0].nG;
     hipLaunchKernelGGL(k_prefix_materialise, dim3((unsigned)nG, (unsigned)c->n_samples), dim3(64), 0, c->sA, job.v, nG, c->dbg_a.as<uint32_t>(), l32);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->dbg_a.p, bytes, hipMemcpyDeviceToHost, c->sA));
