@@ -58,10 +58,10 @@ typedef struct wgbsseg_timings {
     double trace_ms;         /* traceback + compaction                                                 */
     double total_ms;         /* first kernel start -> borders on the host (device time line)           */
     int64_t sites;           /* sum of chunk lengths                                                   */
-    int64_t pairs;           /* sum over sites of window length W_i = candidate blocks scored          */
+    int64_t pairs;           /* sum over sites of the window F_k = candidate blocks scored             */
     int64_t evals;           /* pairs * n_samples = per-(block, sample) likelihood evaluations         */
     int64_t scan_bytes;      /* algorithmic bytes of the scan pass: 2 * n_samples * sites              */
-    int32_t max_window;      /* largest W_i                                                            */
+    int32_t max_window;      /* largest F_k                                                            */
     int32_t n_stages;
     int32_t scan_launches;   /* kernel launches behind scan_ms (1 per batch)                           */
     int32_t reserved;
@@ -155,9 +155,11 @@ int wgbsseg_get_timings(const wgbsseg_ctx* ctx, wgbsseg_timings* out);
 /*
  * Test hooks (used by tests/ to compare device intermediates with the oracle; not part of the drop-in surface).
  * wgbsseg_debug_fetch copies an intermediate of the LAST wgbsseg_segment_chunks() call to a host buffer:
- *   "window"  uint16[sites]   W_i            "cum"   uint32[sites]  exclusive prefix of W inside each chunk
- *   "back"    uint16[sites]   i+1-argmax     "cost"  double[pairs]  scored blocks, CSR by (chunk, site), only if
- *                                                     the call ran as a single stage
+ *   "window"  uint16[sites]   F_k (number of admissible ends of a block starting at k)
+ *   "cum"     uint32[sites]   exclusive prefix of F inside each chunk (row offset of start site k)
+ *   "back"    uint16[sites]   i+1-argmax_k of M[i+1]
+ *   "cost"    double[pairs]   scored blocks, start-major CSR (row k = ends k .. k+F_k-1), only if the call ran as a
+ *                             single stage
  * Returns the number of bytes written, or a negative code.
  * wgbsseg_debug_sample_terms evaluates the per-(block,sample) term on the device for arrays of (nmeth, ntotal).
  * wgbsseg_debug_log2 evaluates the device log2f / log2(1-p) restatements for `count` consecutive float bit

@@ -114,11 +114,12 @@ def test_04_meth_gt_cov_is_reported(seg):
 # 3. window extents, scored blocks, recurrence — against the oracle's intermediates
 # ---------------------------------------------------------------------------------------------------------
 def _numpy_windows(loci, max_cpg, max_bp):
+    """forward window F_k: number of admissible ends i >= k of a block starting at k (segmentor.cpp:111-117)"""
     l = loci.astype(np.int64)
-    i = np.arange(l.size)
-    lo = np.searchsorted(l, l - max_bp, 'left')
-    lo = np.maximum(lo, i + 1 - max_cpg)
-    return (i - lo + 1).astype(np.int64)
+    k = np.arange(l.size)
+    hi = np.searchsorted(l, l + max_bp, 'right') - 1
+    hi = np.minimum(np.minimum(hi, k + max_cpg - 1), l.size - 1)
+    return (hi - k + 1).astype(np.int64)
 
 
 @pytest.mark.parametrize('name', ['tiny', 'max_cpg_binds', 'dense_w_gt_64', 'equal_loci', 'zero_stretch', 'deep'])
@@ -140,17 +141,16 @@ def test_05_intermediates_match_oracle(name, golden_chunks):
         gcum = sg.debug_fetch('cum', np.uint32, n).astype(np.int64)
         assert _first_diff(gcum, cum) is None, 'cum: ' + _first_diff(gcum, cum)
         b, M, T, band = oracle.segment_chunk(slices, loci, spec['pcount'], max_cpg, spec['max_bp'], debug=True)
-        # oracle band[k, i-k] -> CSR rows by end site i, candidates k = i-W+1..i
+        # the device matrix is start-major like the oracle's band: row k = band[k, 0..F_k)
         gcost = sg.debug_fetch('cost', np.float64, int(W.sum()))
         want = np.empty(int(W.sum()), dtype=np.float64)
-        for i in range(n):
-            ks = np.arange(i - W[i] + 1, i + 1)
-            want[cum[i]:cum[i] + W[i]] = band[ks, i - ks]
+        for k in range(n):
+            want[cum[k]:cum[k] + W[k]] = band[k, :W[k]]
         d = _first_diff(gcost.view(np.uint64), want.view(np.uint64))
         if d is not None:
             j = int(np.flatnonzero(gcost.view(np.uint64) != want.view(np.uint64))[0])
-            i = int(np.searchsorted(cum, j, 'right') - 1)
-            raise AssertionError('cost: %s (end site %d, k %d): got %r want %r' % (d, i, i - W[i] + 1 + j - cum[i], gcost[j], want[j]))
+            k = int(np.searchsorted(cum, j, 'right') - 1)
+            raise AssertionError('cost: %s (start site %d, end %d): got %r want %r' % (d, k, k + j - cum[k], gcost[j], want[j]))
         gback = sg.debug_fetch('back', np.uint16, n).astype(np.int64)
         wback = np.arange(1, n + 1) - T[1:]
         assert _first_diff(gback, wback) is None, 'back-pointers: ' + _first_diff(gback, wback)

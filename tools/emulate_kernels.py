@@ -8,9 +8,11 @@ import cases
 from oracle import oracle
 
 def windows(loci, max_cpg, max_bp):
-    l = loci.astype(np.int64); i = np.arange(l.size)
-    lo = np.maximum(np.searchsorted(l, l - max_bp, 'left'), i + 1 - max_cpg)
-    return (i - lo + 1).astype(np.int64)
+    """forward window F_k"""
+    l = loci.astype(np.int64); k = np.arange(l.size)
+    hi = np.searchsorted(l, l + max_bp, 'right') - 1
+    hi = np.minimum(np.minimum(hi, k + max_cpg - 1), l.size - 1)
+    return (hi - k + 1).astype(np.int64)
 
 def group_start(start0, k):
     a = (start0 + k) & ~63
@@ -70,76 +72,64 @@ def emu_stage_row(row, carry, start0, ln, A, cnt):
         run = run + incl[63]
     return dst
 
-def emu_cost_tiles(W, n, S, stage, TI, KT, TK, Wmax, start0=0):
-    """k_cost tile decomposition for one chunk: yields (pairs list of (i,k)) per tile; checks K/I array bounds."""
+def emu_cost_tiles(F, n, S, stage, TI, KT, TK, Fmax, start0=0):
+    """k_cost tile decomposition (start-major) for one chunk: yields pairs (k,i) per tile; checks E/S array bounds."""
     s0 = stage * S; s1 = min(s0 + S, n)
     if s0 >= n: return
-    KS = TK + 64 if KT > 1 else TI + Wmax + 64
+    KS = TK + 64 if KT > 1 else TI + Fmax + 64
     IS = TI + 64 if KT > 1 else 0
     ntile = (s1 - s0 + TI - 1) // TI * KT
     for local in range(ntile):
-        it, kt = divmod(local, KT)
-        ia = s0 + it * TI; ib = min(ia + TI, s1); ni = ib - ia
-        kt_hi = ia + TI - (KT - 1 - kt) * TK if KT > 1 else ia + TI
-        kt_lo = kt_hi - TK if KT > 1 else -(1 << 30)
-        pairs = []; kmin = None
-        for il in range(ni):
-            i = ia + il; lo = i - W[i] + 1
-            ks = max(lo, kt_lo); ke = min(i, kt_hi - 1)
-            if ke >= ks:
-                kmin = ks if kmin is None else min(kmin, ks)
-                pairs += [(i, k) for k in range(ks, ke + 1)]
+        kti, et = divmod(local, KT)
+        ka = s0 + kti * TI; kb = min(ka + TI, s1); nk = kb - ka
+        et_lo = ka + et * TK if KT > 1 else 0
+        et_hi = et_lo + TK if KT > 1 else (1 << 30)
+        pairs = []; imin = None; imax = None
+        for kl in range(nk):
+            k = ka + kl
+            is_ = max(k, et_lo); ie = min(k + F[k], et_hi) - 1
+            if ie >= is_:
+                imin = is_ if imin is None else min(imin, is_); imax = ie if imax is None else max(imax, ie)
+                pairs += [(k, i) for i in range(is_, ie + 1)]
         if not pairs: continue
-        kA = group_start(start0, kmin)
-        assert kmin - kA <= 63
-        assert kA >= 0
+        eA = group_start(start0, imin + 1 if KT > 1 else ka)
+        Ecnt = imax + 2 - eA
+        assert 0 < Ecnt <= KS, (Ecnt, KS)
         if KT > 1:
-            iA = group_start(start0, ia); Kcnt = kt_hi - kA; Icnt = ib + 1 - iA
-            assert Kcnt <= KS and Icnt <= IS, (Kcnt, KS, Icnt, IS)
-            for (i, k) in pairs: assert 0 <= k - kA < Kcnt and 0 <= i + 1 - iA < Icnt
+            sA = group_start(start0, ka); Scnt = kb - sA
+            assert Scnt <= IS
+            for (k, i) in pairs: assert 0 <= i + 1 - eA < Ecnt and 0 <= k - sA < Scnt
         else:
-            Kcnt = ib + 1 - kA
-            assert Kcnt <= KS, (Kcnt, KS)
-            for (i, k) in pairs: assert 0 <= k - kA < Kcnt and 0 <= i + 1 - kA < Kcnt
+            for (k, i) in pairs: assert 0 <= i + 1 - eA < Ecnt and 0 <= k - eA < Ecnt
         assert len(pairs) <= 4096, len(pairs)
         yield pairs
 
-def emu_dp(W, cum, cost, n, S, max_cpg):
-    """k_dp over all stages; cost CSR (global cum). Returns back array."""
+def emu_dp(F, cum, cost, n, S):
+    """k_dp push form over all stages; cost start-major CSR. Returns back array."""
+    Fmax = int(F.max()); wide = Fmax > 64
     ringN = 1
-    while ringN < max(64, max_cpg): ringN <<= 1
+    while ringN < Fmax + 64: ringN <<= 1
     rmask = ringN - 1
-    ring = np.zeros(ringN); back = np.zeros(n, dtype=np.int64)
-    nst = (n + S - 1) // S
-    for stage in range(nst):
-        s0 = stage * S; s1 = min(s0 + S, n)
-        mreg = np.zeros(64)
+    pendB = np.full(ringN, -np.inf); pendA = np.zeros(ringN, dtype=np.int64)
+    best = np.full(64, -np.inf); arg = np.zeros(64, dtype=np.int64); back = np.zeros(n, dtype=np.int64)
+    Mk = 0.0
+    for k in range(n):
+        f = int(F[k]); stp = k & 63
         for lane in range(64):
-            k = s0 - ((s0 - lane) & 63)
-            mreg[lane] = ring[k & rmask] if k >= 0 else 0.0
-        for base in range(s0, s1, 64):
-            for stp in range(min(64, s1 - base)):
-                i = base + stp; w = int(W[i]); lo = i - w + 1
-                if w <= 64:
-                    v = np.full(64, -np.inf)
-                    for lane in range(64):
-                        j = (lane - lo) & 63
-                        if j < w: v[lane] = mreg[lane] + cost[cum[i] + j]
-                    vmax = v.max(); eq = 0
-                    for lane in range(64):
-                        if v[lane] == vmax: eq |= 1 << lane
-                    rot = lo & 63
-                    rm = ((eq >> rot) | (eq << (64 - rot))) & ((1 << 64) - 1) if rot else eq
-                    kbest = lo + ((rm & -rm).bit_length() - 1)
-                else:
-                    best = np.full(64, -np.inf); bk = np.full(64, 2**32 - 1, dtype=np.int64)
-                    for lane in range(64):
-                        for jj in range(lane, w, 64):
-                            k = lo + jj; vv = ring[k & rmask] + cost[cum[i] + jj]
-                            if vv > best[lane]: best[lane] = vv; bk[lane] = k
-                    vmax = best.max(); kbest = int(bk[best == vmax].min())
-                mreg[(i + 1) & 63] = vmax; ring[(i + 1) & rmask] = vmax
-                back[i] = i + 1 - kbest
+            j = (lane - stp) & 63
+            if j < f:
+                cand = Mk + cost[cum[k] + j]
+                if cand > best[lane]: best[lane] = cand; arg[lane] = k
+        if f > 64:
+            for jj in range(64, f):
+                sl = (k + jj) & rmask; cd = Mk + cost[cum[k] + jj]
+                if cd > pendB[sl]: pendB[sl] = cd; pendA[sl] = k
+        Mk = best[stp]
+        back[k] = k + 1 - arg[stp]
+        best[stp] = -np.inf
+        if wide:
+            sl = (k + 64) & rmask
+            best[stp] = pendB[sl]; arg[stp] = pendA[sl]; pendB[sl] = -np.inf
     return back
 
 def run_case(name, S=None, TIsel=None):
@@ -147,25 +137,26 @@ def run_case(name, S=None, TIsel=None):
     slices, loci = cases.build_case(spec)
     n, max_cpg, max_bp = spec['n'], spec['max_cpg'], spec['max_bp']
     b, M, T, band = oracle.segment_chunk(slices, loci, spec['pcount'], max_cpg, max_bp, debug=True)
-    W = windows(loci, max_cpg, max_bp); cum = np.concatenate([[0], np.cumsum(W)[:-1]]); Wmax = int(W.max())
-    if Wmax <= 64: TI, KT, TK = 64, 1, 0
-    elif Wmax <= 128: TI, KT, TK = 32, 1, 0
-    elif Wmax <= 256: TI, KT, TK = 16, 1, 0
-    else: TI, TK = 16, 256; KT = (Wmax - 1 + TI + TK - 1) // TK
+    F = windows(loci, max_cpg, max_bp); cum = np.concatenate([[0], np.cumsum(F)[:-1]]); Fmax = int(F.max())
+    # the oracle band agrees with the forward windows: finite exactly on j < F_k
+    for k in range(0, n, max(1, n // 200)):
+        row = band[k, :min(max_cpg, n - k)]
+        assert np.isfinite(row[:F[k]]).all() and not np.isfinite(row[F[k]:]).any()
+    if Fmax <= 64: TI, KT, TK = 64, 1, 0
+    elif Fmax <= 128: TI, KT, TK = 32, 1, 0
+    elif Fmax <= 256: TI, KT, TK = 16, 1, 0
+    else: TI, TK = 16, 256; KT = (Fmax - 1 + TI + TK - 1) // TK
     if S is None: S = ((n + 63) // 64) * 64
-    # tile coverage: every (i,k) exactly once
-    seen = np.zeros(int(W.sum()), dtype=np.int32)
+    seen = np.zeros(int(F.sum()), dtype=np.int32)
     for stage in range((n + S - 1) // S):
-        for pairs in emu_cost_tiles(W, n, S, stage, TI, KT, TK, Wmax):
-            for (i, k) in pairs: seen[cum[i] + k - (i - W[i] + 1)] += 1
+        for pairs in emu_cost_tiles(F, n, S, stage, TI, KT, TK, Fmax, start0=spec['a']):
+            for (k, i) in pairs: seen[cum[k] + i - k] += 1
     assert (seen == 1).all(), 'tile coverage broken'
-    # dp on oracle costs
-    cost = np.empty(int(W.sum()))
-    for i in range(n):
-        ks = np.arange(i - W[i] + 1, i + 1); cost[cum[i]:cum[i] + W[i]] = band[ks, i - ks]
-    back = emu_dp(W, cum, cost, n, S, max_cpg)
+    cost = np.empty(int(F.sum()))
+    for k in range(n): cost[cum[k]:cum[k] + F[k]] = band[k, :F[k]]
+    back = emu_dp(F, cum, cost, n, S)
     assert (back == np.arange(1, n + 1) - T[1:]).all(), 'dp emulation differs'
-    print(name, 'ok: Wmax', Wmax, 'TI', TI, 'KT', KT, 'S', S)
+    print(name, 'ok: Fmax', Fmax, 'TI', TI, 'KT', KT, 'S', S)
 
 if __name__ == '__main__':
     # scan carries + staged prefix rows

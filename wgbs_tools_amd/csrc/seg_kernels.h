@@ -3,13 +3,16 @@
 // Pipeline for one batch of chunks (a chunk = what one reference `segmentor` process handles, segmentor.cpp:193-214):
 //   k_scan    per-sample prefix scan of (#meth,#cov) with 64-site carries + the #meth<=#cov validation of
 //             read_beta_file (segmentor.cpp:179-188).  HBM-bound: reads every beta byte once, writes 1/16 of that.
-//   k_window  window extent W_i of every site from the loci (the bp/CpG limits of segmentor.cpp:111-117) and the
-//             CSR row offsets of the scored-block matrix.
+//   k_window  forward window F_k of every site from the loci (the bp/CpG limits of segmentor.cpp:111-117: the
+//             extensions of a block starting at k that are admissible) and the CSR row offsets of the scored-block
+//             matrix, which is START-major like the reference's own rows (segmentor.cpp:103-138).
 //   k_cost    block log-likelihoods (segmentor.cpp:119-137) for every (start k, end i) inside the window, scored
 //             from LDS-staged prefix tiles; samples are visited in file order inside each lane (the double
 //             accumulation order is part of the bit-exactness contract).  fp64-VALU bound.
-//   k_dp      the changepoint recurrence (segmentor.cpp:142-154): one wavefront owns one chunk, 64 candidate
-//             start sites per step live in registers, arg-max by DPP reduction, first maximum wins.
+//   k_dp      the changepoint recurrence (segmentor.cpp:142-154) in PUSH form: one wavefront owns one chunk; lane l
+//             holds the running maximum of the pending step i == l (mod 64); when M[k] is final, ONE vector add +
+//             compare folds candidate k into the 64 steps it can start (ascending k and strict '>' = the reference's
+//             first-maximum rule); M[k+1] is then read from lane k mod 64.  No cross-lane reduction on the chain.
 //   k_trace   traceback (segmentor.cpp:50-58) out of an LDS-resident window of back-pointers.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -39,9 +42,9 @@ struct JobView {
     const uint32_t* loci;     // [n_total]
     const ChunkDesc* chunks;
     uint2* carry;
-    uint16_t* W16;            // [job sites] window length of step i (candidates k = i-W+1 .. i)
-    uint32_t* cum32;          // [job sites] exclusive prefix of W inside the chunk
-    uint16_t* back16;         // [job sites] i + 1 - argmax_k for M[i+1]
+    uint16_t* W16;            // [job sites] forward window F_k: blocks starting at k may end at k .. k+F_k-1
+    uint32_t* cum32;          // [job sites] exclusive prefix of F inside the chunk = row offset of start site k
+    uint16_t* back16;         // [job sites] i + 1 - argmax_k for M[i+1]  (length of the best block ending at i)
     int64_t* chunk_pairs;     // [n_chunks] sum of W over the chunk
     int32_t n_samples;
     int32_t n_chunks;
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_window: one workgroup per chunk.  W_i = number of admissible block starts for a block ending at site i:
-//   k admissible  <=>  i-k < max_cpg  and  loci[i]-loci[k] <= max_bp      (segmentor.cpp:111-117, loci ascending)
+// k_window: one workgroup per chunk.  F_k = number of admissible ends of a block starting at site k:
+//   i admissible  <=>  k <= i < len,  i-k < max_cpg  and  loci[i]-loci[k] <= max_bp   (segmentor.cpp:111-117, loci ascending)
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, uint32_t max_cpg, uint32_t max_bp)
 {
@@ -179,21 +182,20 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, u
     uint32_t wmax = 0;
     bool disorder = false;
     for (int base = 0; base < cd.len; base += WG_BLOCK) {
-        const int i = base + tid;
+        const int k = base + tid;
         uint32_t w = 0;
-        if (i < cd.len) {
-            const int64_t li = loc[i];
-            if (i > 0 && (int64_t)loc[i - 1] > li) disorder = true;
-            const int64_t target = li - (int64_t)max_bp;
-            int lo = i + 1 - (int)max_cpg;
-            if (lo < 0) lo = 0;
-            int hi = i;                                  // loc[i] >= target always
-            while (lo < hi) {                            // first k in [lo, i] with loc[k] >= target
-                const int mid = (lo + hi) >> 1;
-                if ((int64_t)loc[mid] >= target) hi = mid; else lo = mid + 1;
+        if (k < cd.len) {
+            const int64_t lk = loc[k];
+            if (k > 0 && (int64_t)loc[k - 1] > lk) disorder = true;
+            const int64_t limit = lk + (int64_t)max_bp;
+            int lo = k;                                   // loc[k] <= limit always
+            int hi = (int)((int64_t)k + max_cpg - 1 < cd.len - 1 ? (int64_t)k + max_cpg - 1 : cd.len - 1);
+            while (lo < hi) {                             // last i in [k, hi] with loc[i] <= limit
+                const int mid = (lo + hi + 1) >> 1;
+                if ((int64_t)loc[mid] <= limit) lo = mid; else hi = mid - 1;
             }
-            w = (uint32_t)(i - lo + 1);
-            J.W16[cd.site_off + i] = (uint16_t)w;
+            w = (uint32_t)(lo - k + 1);
+            J.W16[cd.site_off + k] = (uint16_t)w;
             if (w > wmax) wmax = w;
         }
         const uint32_t incl = wg_wave_incl_scan_dpp_u32(w);
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, u
 #pragma unroll
         for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) woff += wsum[q]; btot += wsum[q]; }
         __syncthreads();
-        if (i < cd.len) J.cum32[cd.site_off + i] = (uint32_t)(run + woff + (incl - w));
+        if (k < cd.len) J.cum32[cd.site_off + k] = (uint32_t)(run + woff + (incl - w));
         run += btot;
     }
     wmax = wg_wave_max_u32(wmax);
@@ -270,14 +272,16 @@ __global__ __launch_bounds__(WG_BLOCK) void k_stage_plan(JobView J, PlanArgs P, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_cost
+// k_cost: one workgroup scores the blocks of TI consecutive START sites (times one tile of end sites when windows are
+// wide).  LDS holds, per sample of the current group, the exclusive prefixes P[x] of (#meth, #cov) over the sites the
+// tile touches: a block (k, i) is then P[i+1] - P[k].
 // ------------------------------------------------------------------------------------------------------------
 struct CostArgs {
     float pc, pc2;
-    int32_t KT;        // k-tiles per i-tile (1: the whole window of the tile in one LDS array)
-    int32_t TK;        // sites per k-tile (KT > 1)
-    int32_t KS;        // uint2 entries per sample row of the K array
-    int32_t IS;        // entries per sample row of the I array (KT > 1), else 0
+    int32_t KT;        // end-site tiles per start tile (1: all ends of the tile in one LDS array together with the starts)
+    int32_t TK;        // end sites per tile (KT > 1)
+    int32_t KS;        // uint2 entries per sample row of the E array (ends; with KT == 1 it also holds the starts)
+    int32_t IS;        // entries per sample row of the S array (starts, KT > 1), else 0
     int32_t NS;        // samples per LDS group
     int32_t pad;
 };
@@ -347,12 +351,12 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     wg_log_tables* tb = reinterpret_cast<wg_log_tables*>(smem);
-    uint2* Kt = reinterpret_cast<uint2*>(smem + sizeof(wg_log_tables));
-    uint2* It = Kt + (size_t)A.NS * A.KS;
-    int64_t* radj = reinterpret_cast<int64_t*>(It + (size_t)A.NS * A.IS);      // [TI]
+    uint2* Et = reinterpret_cast<uint2*>(smem + sizeof(wg_log_tables));          // [NS][KS]  P[i+1] of the ends
+    uint2* St = Et + (size_t)A.NS * A.KS;                                        // [NS][IS]  P[k] of the starts (KT > 1)
+    int64_t* radj = reinterpret_cast<int64_t*>(St + (size_t)A.NS * A.IS);        // [TI]
     int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
-    int32_t* kst = offs + (TI + 1);                                              // [TI]
-    int32_t* misc = kst + TI;                                                    // [2]
+    int32_t* ist = offs + (TI + 1);                                              // [TI] first end of start kl in this unit
+    int32_t* misc = ist + TI;                                                    // [2]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nC = J.n_chunks;
@@ -368,15 +372,15 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int c = clo;
     const ChunkDesc cd = J.chunks[c];
     const int local = (int)(t - tbase[c]);
-    const int it = local / A.KT, kt = local - it * A.KT;
+    const int kti = local / A.KT, et = local - kti * A.KT;
     const int s0 = SV.stage * SV.S;
     const int s1 = (s0 + SV.S < cd.len) ? s0 + SV.S : cd.len;
-    const int ia = s0 + it * TI;
-    const int ib = (ia + TI < s1) ? ia + TI : s1;
-    const int ni = ib - ia;
-    // k-tile [kt_lo, kt_hi); the last tile ends at ia+TI.  KT == 1: no restriction.
-    const int kt_hi = (A.KT > 1) ? ia + TI - (A.KT - 1 - kt) * A.TK : ia + TI;
-    const int kt_lo = (A.KT > 1) ? kt_hi - A.TK : -(1 << 30);
+    const int ka = s0 + kti * TI;                        // start sites [ka, kb)
+    const int kb = (ka + TI < s1) ? ka + TI : s1;
+    const int nk = kb - ka;
+    // end-site tile [et_lo, et_hi); tile 0 begins at ka.  KT == 1: no restriction.
+    const int et_lo = (A.KT > 1) ? ka + et * A.TK : 0;
+    const int et_hi = (A.KT > 1) ? et_lo + A.TK : (1 << 30);
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
 
     {   // tables -> LDS
@@ -386,41 +390,44 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
         for (int x = tid; x < (int)(sizeof(wg_log_tables) / 8); x += WG_BLOCK) d[x] = src[x];
     }
     if (wv == 0) {
-        const int i = ia + lane;
-        const bool valid = lane < ni;
-        int cnt = 0, ks = 0;
+        const int k = ka + lane;
+        const bool valid = lane < nk;
+        int cnt = 0, is = 0, ie = -1;
         if (valid) {
-            const int w = J.W16[cd.site_off + i];
-            const int lo = i - w + 1;
-            ks = lo > kt_lo ? lo : kt_lo;
-            const int ke = (i < kt_hi - 1) ? i : kt_hi - 1;
-            cnt = ke - ks + 1;
+            const int f = J.W16[cd.site_off + k];
+            is = k > et_lo ? k : et_lo;                  // ends i in [k, k+f) cut to the tile
+            ie = (k + f < et_hi ? k + f : et_hi) - 1;
+            cnt = ie - is + 1;
             if (cnt < 0) cnt = 0;
             if (lane < TI) {
-                radj[lane] = (int64_t)(J.cum32[cd.site_off + i] - cum0) - lo;
-                kst[lane] = ks;
+                radj[lane] = (int64_t)(J.cum32[cd.site_off + k] - cum0) - k;      // row offset of k, minus k: + i addresses (k, i)
+                ist[lane] = is;
             }
         }
         const uint32_t incl = wg_wave_incl_scan_dpp_u32((uint32_t)cnt);
         if (lane < TI) offs[lane + 1] = (int32_t)incl;
         if (lane == 0) offs[0] = 0;
-        const uint32_t kmin = wg_wave_min_u32(cnt > 0 ? (uint32_t)ks : 0x7fffffffu);
-        if (lane == 0) misc[0] = (int32_t)kmin;
+        const uint32_t imin = wg_wave_min_u32(cnt > 0 ? (uint32_t)is : 0x7fffffffu);
+        const uint32_t imax = wg_wave_max_u32(cnt > 0 ? (uint32_t)ie : 0u);
+        if (lane == 0) { misc[0] = (int32_t)imin; misc[1] = (int32_t)imax; }
     }
     __syncthreads();
-    const int Q = offs[TI < ni ? TI : ni];
+    const int Q = offs[nk];
     if (Q == 0) return;
-    const int kA = wg_group_start(cd, misc[0]);          // carry position at or below the first candidate start
-    int iA, ioff;                                        // I entries: index (i+1) - iA = il + ioff
-    const uint2* Ibase;
-    int Istride;
-    if (A.KT > 1) { iA = wg_group_start(cd, ia); Ibase = It; Istride = A.IS; }
-    else          { iA = kA;       Ibase = Kt; Istride = A.KS; }
-    ioff = ia + 1 - iA;
-    const int Kcnt = ((A.KT > 1) ? kt_hi : ib + 1) - kA;  // entries needed in the K array
-    const int Icnt = ib + 1 - iA;
+    const int imin = misc[0], imax = misc[1];
+    // E array: P[x] for x = eA .. imax+1 (ends use P[i+1]); with KT == 1 the starts' P[k], k >= ka, live there too
+    // (imin >= ka, so every start of the tile is at or after eA only if eA <= ka: take the lower of the two).
+    const int eA = wg_group_start(cd, (A.KT > 1) ? imin + 1 : ka);
+    const int Ecnt = imax + 2 - eA;
+    int sA;                                              // S entries: index k - sA
+    const uint2* Sbase;
+    int Sstride;
+    if (A.KT > 1) { sA = wg_group_start(cd, ka); Sbase = St; Sstride = A.IS; }
+    else          { sA = eA;                     Sbase = Et; Sstride = A.KS; }
+    const int soff = ka - sA;                            // P[k] of start kl at S[soff + kl]
+    const int Scnt = kb - sA;
 
-    // my candidate blocks: q = tid + 256 r  ->  (il, k)
+    // my candidate blocks: q = tid + 256 r  ->  (kl, i)
     const int R = (Q + WG_BLOCK - 1) / WG_BLOCK;
     uint32_t pr[WG_RMAX];
     double acc[WG_RMAX];
@@ -431,10 +438,10 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
         if (r < R) {
             const int q = tid + WG_BLOCK * r;
             if (q < Q) {
-                int lo = 0, hi = ni;                       // largest il with offs[il] <= q
+                int lo = 0, hi = nk;                       // largest kl with offs[kl] <= q
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
-                const int k = kst[lo] + (q - offs[lo]);
-                pr[r] = (uint32_t)lo | ((uint32_t)(k - kA) << 8);
+                const int i = ist[lo] + (q - offs[lo]);
+                pr[r] = (uint32_t)lo | ((uint32_t)(i + 1 - eA) << 8);
             }
         }
     }
@@ -447,19 +454,19 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             const int s = g0 + rr;
             const uint8_t* row = J.betas + (int64_t)s * J.pitch;
             const uint2* carry = J.carry + cd.carry_off + (int64_t)s * cd.nG;
-            wg_stage_prefix_row(Kt + (size_t)rr * A.KS, row, carry, cd, J.n_total, kA, Kcnt, lane);
-            if (A.KT > 1) wg_stage_prefix_row(It + (size_t)rr * A.IS, row, carry, cd, J.n_total, iA, Icnt, lane);
+            wg_stage_prefix_row(Et + (size_t)rr * A.KS, row, carry, cd, J.n_total, eA, Ecnt, lane);
+            if (A.KT > 1) wg_stage_prefix_row(St + (size_t)rr * A.IS, row, carry, cd, J.n_total, sA, Scnt, lane);
         }
         __syncthreads();
         for (int sl = 0; sl < ns; sl++) {
-            const uint2* Krow = Kt + (size_t)sl * A.KS;
-            const uint2* Irow = Ibase + (size_t)sl * Istride + ioff;
+            const uint2* Erow = Et + (size_t)sl * A.KS;
+            const uint2* Srow = Sbase + (size_t)sl * Sstride + soff;
 #pragma unroll
             for (int r = 0; r < WG_RMAX; r++) {
                 if (r < R) {
                     if (pr[r] != 0xffffffffu) {
-                        const uint2 pi = Irow[pr[r] & 0xffu];
-                        const uint2 pk = Krow[pr[r] >> 8];
+                        const uint2 pi = Erow[pr[r] >> 8];
+                        const uint2 pk = Srow[pr[r] & 0xffu];
                         const float nm = (float)(pi.x - pk.x);
                         const float nt = (float)(pi.y - pk.y);
                         acc[r] += (double)wg_sample_term(nm, nt, pc, pc2, tb);   // segmentor.cpp:135
@@ -473,9 +480,9 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 #pragma unroll
     for (int r = 0; r < WG_RMAX; r++) {
         if (r < R && pr[r] != 0xffffffffu) {
-            const int il = (int)(pr[r] & 0xffu);
-            const int k = (int)(pr[r] >> 8) + kA;
-            cb[radj[il] + k] = (acc[r] != 0.0) ? acc[r] : 0.0;                    // segmentor.cpp:106,137
+            const int kl = (int)(pr[r] & 0xffu);
+            const int i = (int)(pr[r] >> 8) + eA - 1;
+            cb[radj[kl] + i] = (acc[r] != 0.0) ? acc[r] : 0.0;                    // segmentor.cpp:106,137
         }
     }
 }
@@ -484,11 +491,19 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 // k_dp: one workgroup of two wavefronts per chunk.  Wave 0 owns the chunk's recurrence; wave 1 is its loader: while
 // wave 0 sweeps the 64 steps of batch b out of LDS, wave 1 copies the scored-block rows and the per-step metadata
 // of batch b+1 (contiguous in the CSR) from HBM into the other LDS slot.  One s_barrier per 64 steps.
+//
+// Push form of segmentor.cpp:142-154.  Lane l of wave 0 holds (best, arg) of the pending step i == l (mod 64),
+// i.e. the running  max_k M[k] + cost(k, i)  over the candidates k seen so far.  Iteration k: M[k] is final;
+//   every lane with j = (l - k) mod 64 < F_k folds  M[k] + cost(k, k+j)  into its pending step (strict '>' in
+//   ascending k keeps the FIRST maximum, as the reference's scan does);  step i = k has now seen its last candidate,
+//   so M[k+1] = best of lane k mod 64, and that lane moves on to step k+64.
+// Blocks longer than 64 sites (F_k > 64) reach steps that no lane holds yet: those maxima are parked in LDS (pend)
+// and picked up when the lane moves on.
 // ------------------------------------------------------------------------------------------------------------
-struct DpArgs { int32_t ringN; int32_t slot_cap; };     // slot_cap: doubles per staged batch (0: never stage)
+struct DpArgs { int32_t ringN; int32_t slot_cap; int32_t wide; int32_t pad; };   // ringN: pend slots (pow2 >= max window), 0 if !wide
 
 struct DpMeta {               // per LDS slot
-    uint32_t w[64];           // window length of each step of the batch
+    uint32_t w[64];           // forward window F_k of each step of the batch
     uint32_t rel[64];         // row offset of each step inside the stage's cost rows of this chunk
     uint32_t first;           // rel of the batch's first step
     uint32_t staged;          // 1: rows [first, first+span) are in the slot
@@ -509,7 +524,7 @@ __device__ __forceinline__ void wg_dp_load_batch(const double* __restrict__ cb, 
     const uint32_t last_w = (uint32_t)__builtin_amdgcn_readlane((int)w, nst - 1);
     const uint32_t span = last_rel + last_w - first;
     const bool staged = span <= (uint32_t)slot_cap;
-    meta->w[lane] = inb ? w : 1u;
+    meta->w[lane] = w;
     meta->rel[lane] = rel;
     if (lane == 0) { meta->first = first; meta->staged = staged ? 1u : 0u; }
     if (staged) {
@@ -518,12 +533,15 @@ __device__ __forceinline__ void wg_dp_load_batch(const double* __restrict__ cb, 
     }
 }
 
+// state saved between stages, per chunk: [0] M[k] of the next step, [1..64] best, then 64 args (as doubles' bits),
+// then (wide) pendB[ringN], pendA[ringN]
 __global__ __launch_bounds__(128) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
-                                            double* __restrict__ state)
+                                            double* __restrict__ state, int64_t state_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_dp[];
-    double* ring = reinterpret_cast<double*>(smem_dp);       // M[k] at slot k & (ringN-1), last >= max(64,max_cpg) values
-    double* slots = ring + A.ringN;                           // [2][slot_cap]
+    double* pendB = reinterpret_cast<double*>(smem_dp);                       // [ringN]
+    int32_t* pendA = reinterpret_cast<int32_t*>(pendB + A.ringN);             // [ringN]
+    double* slots = reinterpret_cast<double*>(pendA + A.ringN + (A.ringN & 1));   // [2][slot_cap], 8-byte aligned
     DpMeta* metas = reinterpret_cast<DpMeta*>(slots + 2 * (size_t)A.slot_cap);
     const int lane = threadIdx.x & 63;
     const bool loader = threadIdx.x >= 64;
@@ -534,23 +552,34 @@ __global__ __launch_bounds__(128) void k_dp(JobView J, StageView SV, const doubl
     if (s0 >= cd.len) return;
     const int s1 = (s0 + SV.S < cd.len) ? s0 + SV.S : cd.len;
     const int rmask = A.ringN - 1;
-    double* gs = state + (int64_t)c * A.ringN;
+    double* gs = state + (int64_t)c * state_stride;
     const double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
     const uint16_t* Wp = J.W16 + cd.site_off;
     const uint32_t* Cp = J.cum32 + cd.site_off;
     const double NEG_INF = -__builtin_inf();
     const int nb = (s1 - s0 + 63) >> 6;
+    const bool wide = A.wide != 0;
 
+    double best = NEG_INF;                              // pending step of this lane (wave 0)
+    int32_t arg = 0;
+    double Mk = 0.0;                                    // M[k] of the step about to run; M[0] = 0 (segmentor.cpp:97)
     if (loader) {
         wg_dp_load_batch(cb, Wp, Cp, cum0, s0, s1, A.slot_cap, slots, metas, lane);
     } else {
-        if (s0 == 0) { for (int x = lane; x < A.ringN; x += 64) ring[x] = 0.0; }       // M[0] = 0 (segmentor.cpp:97)
-        else         { for (int x = lane; x < A.ringN; x += 64) ring[x] = gs[x]; }
+        if (s0 == 0) {
+            if (wide) for (int x = lane; x < A.ringN; x += 64) { pendB[x] = NEG_INF; pendA[x] = 0; }
+        } else {
+            Mk = gs[0];
+            best = gs[1 + lane];
+            arg = (int32_t)__double_as_longlong(gs[65 + lane]);
+            if (wide) for (int x = lane; x < A.ringN; x += 64) {
+                pendB[x] = gs[129 + x];
+                pendA[x] = (int32_t)__double_as_longlong(gs[129 + A.ringN + x]);
+            }
+        }
     }
     __syncthreads();
-    double mreg = 0.0;                                   // M[k] of the latest k <= i with k == lane (mod 64)
-    if (!loader) { const int k = s0 - ((s0 - lane) & 63); mreg = (k >= 0) ? ring[k & rmask] : 0.0; }
 
     for (int b = 0; b < nb; b++) {
         const int base = s0 + (b << 6);
@@ -571,52 +600,47 @@ __global__ __launch_bounds__(128) void k_dp(JobView J, StageView SV, const doubl
             const int nst = (s1 - base < 64) ? s1 - base : 64;
             for (int g = 0; g < nst; g += 8) {
                 double cv[8];
-                uint32_t ws[8], rs[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {                 // fetch the candidates of 8 steps up front
-                    const int stp = g + u;
-                    cv[u] = 0.0; ws[u] = 1; rs[u] = 0;
+                for (int u = 0; u < 8; u++) {                 // fetch the rows of 8 steps up front
+                    const int stp = g + u;                    // == k & 63 (batches start on multiples of 64)
+                    cv[u] = 0.0;
                     if (stp < nst) {
-                        ws[u] = (uint32_t)__builtin_amdgcn_readlane((int)w_l, stp);
-                        rs[u] = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, stp);
-                        const int i = base + stp;
-                        const int lo = i - (int)ws[u] + 1;
-                        const uint32_t j = (uint32_t)(lane - lo) & 63u;
-                        if (ws[u] <= 64u && j < ws[u]) cv[u] = staged ? slot[rs[u] - first + j] : cb[(int64_t)rs[u] + j];
+                        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w_l, stp);
+                        const uint32_t rel = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, stp);
+                        const uint32_t j = (uint32_t)(lane - stp) & 63u;
+                        if (j < f) cv[u] = staged ? slot[rel - first + j] : cb[(int64_t)rel + j];
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int stp = g + u;
                     if (stp < nst) {
-                        const int i = base + stp;
-                        const uint32_t w = ws[u];
-                        const int lo = i - (int)w + 1;
-                        double vmax;
-                        int kbest;
-                        if (w <= 64u) {
-                            const uint32_t j = (uint32_t)(lane - lo) & 63u;
-                            const double v = (j < w) ? mreg + cv[u] : NEG_INF;
-                            vmax = wg_wave_max_f64(v);
-                            const unsigned long long eq = __ballot(v == vmax);
-                            const int rot = lo & 63;
-                            const unsigned long long rm = rot ? ((eq >> rot) | (eq << (64 - rot))) : eq;
-                            kbest = lo + __builtin_ctzll(rm);          // first maximum in ascending k (segmentor.cpp:148)
-                        } else {
-                            double best = NEG_INF;
-                            uint32_t bk = 0xffffffffu;
-                            for (uint32_t jj = (uint32_t)lane; jj < w; jj += 64) {
-                                const int k = lo + (int)jj;
-                                const double v = ring[k & rmask] + cb[(int64_t)rs[u] + jj];
-                                if (v > best) { best = v; bk = (uint32_t)k; }
+                        const int k = base + stp;
+                        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w_l, stp);
+                        const uint32_t j = (uint32_t)(lane - stp) & 63u;
+                        const double cand = Mk + cv[u];
+                        const bool upd = (j < f) && (cand > best);            // strict: first maximum wins (segmentor.cpp:148)
+                        best = upd ? cand : best;
+                        arg = upd ? k : arg;
+                        if (f > 64u) {                                        // blocks reaching beyond the 64 pending steps
+                            const uint32_t rel = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, stp);
+                            for (uint32_t jj = 64u + (uint32_t)lane; jj < f; jj += 64) {
+                                const int slotx = (k + (int)jj) & rmask;
+                                const double cd2 = Mk + cb[(int64_t)rel + jj];
+                                if (cd2 > pendB[slotx]) { pendB[slotx] = cd2; pendA[slotx] = k; }
                             }
-                            vmax = wg_wave_max_f64(best);
-                            kbest = (int)wg_wave_min_u32(best == vmax ? bk : 0xffffffffu);
                         }
-                        if (lane == ((i + 1) & 63)) mreg = vmax;
-                        if (lane == 0) ring[(i + 1) & rmask] = vmax;
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane == stp) tbk = (uint32_t)(i + 1 - kbest);
+                        // step i = k has seen its last candidate: M[k+1]
+                        Mk = wg_readlane_f64(best, stp);
+                        if (lane == stp) {
+                            tbk = (uint32_t)(k + 1 - arg);
+                            best = NEG_INF;
+                            if (wide) {                                       // hand over to step k+64: pick up parked maxima
+                                const int slotx = (k + 64) & rmask;
+                                best = pendB[slotx]; arg = pendA[slotx];
+                                pendB[slotx] = NEG_INF;
+                            }
+                        }
                     }
                 }
             }
@@ -624,7 +648,15 @@ __global__ __launch_bounds__(128) void k_dp(JobView J, StageView SV, const doubl
         }
         __syncthreads();
     }
-    if (!loader && s1 < cd.len) for (int x = lane; x < A.ringN; x += 64) gs[x] = ring[x];
+    if (!loader && s1 < cd.len) {
+        if (lane == 0) gs[0] = Mk;
+        gs[1 + lane] = best;
+        gs[65 + lane] = __longlong_as_double((long long)arg);
+        if (wide) for (int x = lane; x < A.ringN; x += 64) {
+            gs[129 + x] = pendB[x];
+            gs[129 + A.ringN + x] = __longlong_as_double((long long)pendA[x]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -308,8 +308,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     if (!P || !borders_off) { set_err(err, errlen, "NULL params/borders pointer"); return WGBSSEG_E_ARG; }
     if (P->max_bp == 0) { set_err(err, errlen, "max_bp must be >= 1 (the reference reads uninitialised loci when it is 0: segmentor.cpp:38,114)"); return WGBSSEG_E_ARG; }
     if (P->max_cpg < 1) { set_err(err, errlen, "max_cpg must be >= 1"); return WGBSSEG_E_ARG; }
-    if (255ull * P->max_cpg >= (1ull << 24) || P->max_cpg > 16384) {
-        set_err(err, errlen, "max_cpg %u unsupported: block sums must stay exact in float (255*max_cpg < 2^24) and the DP ring must fit LDS (max_cpg <= 16384)", P->max_cpg);
+    if (255ull * P->max_cpg >= (1ull << 24) || P->max_cpg > 8000) {
+        set_err(err, errlen, "max_cpg %u unsupported: block sums must stay exact in float (255*max_cpg < 2^24) and the DP's pending ring must fit LDS (max_cpg <= 8000)", P->max_cpg);
         return WGBSSEG_E_ARG;
     }
     if (!(P->pseudo_count >= 0.0f)) { set_err(err, errlen, "pseudo_count must be >= 0"); return WGBSSEG_E_ARG; }
@@ -391,8 +391,11 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     for (auto x : stage_pairs) max_stage_pairs = std::max(max_stage_pairs, x);
     const int nbuf = n_stages > 1 ? 2 : 1;
     for (int b = 0; b < nbuf; b++) HIP_TRY(c->cost[b].ensure((size_t)max_stage_pairs * 8));
-    const int ringN = ceil_pow2(std::max<int>(64, (int)P->max_cpg));
-    if (n_stages > 1) HIP_TRY(c->dpstate.ensure((size_t)nC * ringN * 8));
+    // k_dp: blocks longer than 64 sites park their maxima in an LDS ring of `ringN` pending steps
+    const bool wide = Wmax > 64;
+    const int ringN = wide ? ceil_pow2(Wmax + 64) : 0;
+    const int64_t state_stride = 129 + 2 * (int64_t)ringN;      // doubles per chunk saved between stages
+    if (n_stages > 1) HIP_TRY(c->dpstate.ensure((size_t)nC * (size_t)state_stride * 8));
     HIP_TRY(c->tmp_borders.ensure((size_t)(J + nC) * 4));
     HIP_TRY(c->nb.ensure((size_t)nC * 4));
     HIP_TRY(c->boff.ensure((size_t)(nC + 1) * 8));
@@ -405,13 +408,14 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     StageView sv;
     sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbase = c->plan_tbase.as<int64_t>();
     sv.S = S;
-    // LDS of k_dp: M ring + two staged batches of scored-block rows (64 steps x up to 64 candidates) + their metadata
+    // LDS of k_dp: pend ring (wide windows only) + two staged batches of scored-block rows (64 steps x up to 64 ends) + metadata
     int slot_cap = 64 * std::min(Wmax, 64);
-    if (Wmax > 64) slot_cap = 1024;                          // wide windows take the direct path almost always
+    if (wide) slot_cap = 2048;                               // rows beyond the cap are read straight from HBM
     slot_cap = std::min(slot_cap, 4096);
-    while (slot_cap > 64 && (size_t)ringN * 8 + (size_t)slot_cap * 16 + 2 * sizeof(DpMeta) > 150 * 1024) slot_cap /= 2;
-    DpArgs da = {ringN, slot_cap};
-    const size_t lds_dp = (size_t)ringN * 8 + (size_t)slot_cap * 16 + 2 * sizeof(DpMeta);
+    const size_t lds_ring = (size_t)ringN * 12 + 8;
+    while (slot_cap > 64 && lds_ring + (size_t)slot_cap * 16 + 2 * sizeof(DpMeta) > 150 * 1024) slot_cap /= 2;
+    DpArgs da = {ringN, slot_cap, wide ? 1 : 0, 0};
+    const size_t lds_dp = lds_ring + (size_t)slot_cap * 16 + 2 * sizeof(DpMeta);
     for (int stg = 0; stg < n_stages; stg++) {
         sv.stage = stg;
         double* cbuf = c->cost[stg % nbuf].as<double>();
@@ -427,7 +431,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipEventRecord(c->ev_cost1[stg], c->sA));
         HIP_TRY(hipStreamWaitEvent(c->sB, c->ev_cost1[stg], 0));
         HIP_TRY(hipEventRecord(c->ev_dp0[stg], c->sB));
-        hipLaunchKernelGGL(k_dp, dim3((unsigned)nC), dim3(128), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>());
+        hipLaunchKernelGGL(k_dp, dim3((unsigned)nC), dim3(128), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_dp1[stg], c->sB));
     }
