@@ -50,29 +50,6 @@ def parse():
     return ap.parse_args()
 
 
-def shard_pieces(names, sizes, chunk, world):
-    """Cut the chunk grid into `world` contiguous runs of chunks balanced by site count.  Returns per rank a list
-    of (start, end) 1-based half-open pieces; every piece starts on its chromosome's chunk grid."""
-    chunks = []                                   # (chrom idx, start, end)
-    pos = 1
-    for ci, sz in enumerate(sizes):
-        for s in range(pos, pos + sz, chunk):
-            chunks.append((ci, s, min(s + chunk, pos + sz)))
-        pos += sz
-    total = sum(e - s for _, s, e in chunks)
-    out, acc, r = [[] for _ in range(world)], 0, 0
-    for ci, s, e in chunks:
-        while r < world - 1 and acc >= total * (r + 1) / world:
-            r += 1
-        p = out[r]
-        if p and p[-1][2] == s and p[-1][0] == ci:
-            p[-1] = (ci, p[-1][1], e)
-        else:
-            p.append((ci, s, e))
-        acc += e - s
-    return [[(s, e) for _, s, e in p] for p in out], len(chunks)
-
-
 def cpu_baseline(args, buf, sizes, loci, seg, params):
     """The reference `segmentor` (oracle/_ref, built from the reference's own sources) on this host's cores over a
     bounded sample of the same workload: rounds of `cores` default-size chunks taken evenly from the genome's chunk
@@ -182,10 +159,11 @@ def main():
     seg.set_betas_device(buf.data_ptr(), args.samples, pitch, args.sites, keepalive=buf)
     seg.set_loci(loci)
 
-    pieces, n_chunks_total = shard_pieces(names, sizes, args.chunk, world)
+    from wgbs_tools_amd import parallel
+    pieces, n_chunks_total = parallel.shard_pieces(sizes, args.chunk, world)
     mine = pieces[rank]
-    st = np.array([p[0] for p in mine], dtype=np.int64)
-    en = np.array([p[1] for p in mine], dtype=np.int64)
+    st = np.array([p[1] for p in mine], dtype=np.int64)
+    en = np.array([p[2] for p in mine], dtype=np.int64)
     my_sites = int((en - st).sum())
 
     def step():
