@@ -162,13 +162,15 @@ int wgbsseg_get_timings(const wgbsseg_ctx* ctx, wgbsseg_timings* out);
  *                             single stage
  * Returns the number of bytes written, or a negative code.
  * wgbsseg_debug_sample_terms evaluates the per-(block,sample) term on the device for arrays of (nmeth, ntotal).
- * wgbsseg_debug_log2 evaluates the device log2f / log2(1-p) restatements for `count` consecutive float bit
- * patterns starting at `first_bits` (out_f: uint32 bits of log2f(p); out_d: uint64 bits of log2(1.0-(double)p)).
+ * wgbsseg_debug_log2 evaluates the device arithmetic for `count` consecutive float bit patterns p starting at
+ * `first_bits`: out_f = uint32 bits of log2f(p); out_d = uint64 bits of the exact log2(1.0-(double)p) restatement;
+ * out_fast = uint64 bits of the bounded-error fast log2 the scoring kernel tries first (any of them may be NULL).
  */
 int64_t wgbsseg_debug_fetch(wgbsseg_ctx* ctx, const char* what, void* out, int64_t cap_bytes);
 int wgbsseg_debug_sample_terms(wgbsseg_ctx* ctx, const float* nmeth, const float* ntotal, int64_t count,
                                float pseudo_count, float* out);
-int wgbsseg_debug_log2(wgbsseg_ctx* ctx, uint32_t first_bits, int64_t count, uint32_t* out_f, uint64_t* out_d);
+int wgbsseg_debug_log2(wgbsseg_ctx* ctx, uint32_t first_bits, int64_t count, uint32_t* out_f, uint64_t* out_d,
+                       uint64_t* out_fast);
 
 #ifdef __cplusplus
 }

@@ -83,3 +83,34 @@ uint64_t probe_log2f_compare(uint32_t first, uint64_t count, const uint32_t *can
 
 uint64_t probe_log2_1mp_compare(uint32_t first, uint64_t count, const uint64_t *cand, int threads, uint32_t *first_bad)
 { return run_probe(first, count, 1, cand, NULL, threads, first_bad); }
+
+/* largest |cand[q] - libm| in units of the last place (bit patterns compared as integers; same sign assumed),
+ * for log2(1.0 - (double)p): the error bound of the HIP path's fast log2 is established with this. */
+typedef struct { uint32_t first; uint64_t a, b; const uint64_t *cand; uint64_t maxulp; } ulp_job;
+static void *ulp_worker(void *arg)
+{
+    ulp_job *jb = (ulp_job *)arg;
+    uint64_t mx = 0;
+    for (uint64_t q = jb->a; q < jb->b; q++) {
+        float p = f_from_bits(jb->first + (uint32_t)q);
+        uint64_t r = bits_of_d(log2(1.0 - (double)p)), c = jb->cand[q];
+        uint64_t d = r > c ? r - c : c - r;
+        if (d > mx) mx = d;
+    }
+    jb->maxulp = mx;
+    return NULL;
+}
+uint64_t probe_log2_1mp_maxulp(uint32_t first, uint64_t count, const uint64_t *cand, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t th[256]; ulp_job jb[256];
+    for (int t = 0; t < threads; t++) {
+        jb[t].first = first; jb[t].cand = cand; jb[t].maxulp = 0;
+        jb[t].a = count * (uint64_t)t / (uint64_t)threads; jb[t].b = count * (uint64_t)(t + 1) / (uint64_t)threads;
+        pthread_create(&th[t], NULL, ulp_worker, &jb[t]);
+    }
+    uint64_t mx = 0;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); if (jb[t].maxulp > mx) mx = jb[t].maxulp; }
+    return mx;
+}

@@ -56,6 +56,8 @@ def lib():
         L.probe_log2f_compare.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
         L.probe_log2_1mp_compare.restype = C.c_uint64
         L.probe_log2_1mp_compare.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]
+        L.probe_log2_1mp_maxulp.restype = C.c_uint64
+        L.probe_log2_1mp_maxulp.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 

@@ -23,6 +23,46 @@ void exact_log2f_fill(uint32_t first, uint64_t count, uint32_t* out, int threads
         for (uint64_t q = a; q < b; q++) out[q] = wg_f2u(wg_log2f(wg_u2f(first + (uint32_t)q), g_tab.f_tab));
     });
 }
+void exact_log2f_nofma_fill(uint32_t first, uint64_t count, uint32_t* out, int threads)
+{
+    par_for(count, threads, [=](uint64_t a, uint64_t b) {
+        for (uint64_t q = a; q < b; q++) out[q] = wg_f2u(wg_log2f_nofma(wg_u2f(first + (uint32_t)q), g_tab.f_tab));
+    });
+}
+void fast_log2_1mp_fill(uint32_t first, uint64_t count, uint64_t* out, int threads)
+{
+    par_for(count, threads, [=](uint64_t a, uint64_t b) {
+        for (uint64_t q = a; q < b; q++) out[q] = wg_d2u(wg_fast_log2(1.0 - (double)wg_u2f(first + (uint32_t)q), g_tab.d_tab));
+    });
+}
+void exact_sample_terms_plain(const float* nmeth, const float* ntotal, int64_t count, float pc, float* out)
+{
+    float pc2 = pc + pc;
+    for (int64_t q = 0; q < count; q++) out[q] = wg_sample_term_plain(nmeth[q], ntotal[q], pc, pc2, &g_tab);
+}
+// largest distance, in ulps of the double sum, between the fast-path sum s' and the exact sum s of wg_sample_term's
+// second term (the quantity its 6-ulp bound / 16-ulp guard band is about)
+uint64_t sum_ulp_gap(const float* nmeth, const float* ntotal, int64_t count, float pc)
+{
+    const float pc2 = pc + pc;
+    uint64_t mx = 0;
+    for (int64_t q = 0; q < count; q++) {
+        const float m = nmeth[q], t = ntotal[q];
+        if (t == 0.0f) continue;
+        const float p = (m + pc) / (t + pc2);
+        float ll = 0.0f;
+        if (p > 0.0f) ll += m * wg_log2f(p, g_tab.f_tab);
+        const float df = t - m;
+        if (!(p < 1.0f) || df == 0.0f) continue;
+        const double xx = 1.0 - (double)p;
+        const double s1 = (double)ll + (double)df * wg_fast_log2(xx, g_tab.d_tab);
+        const double s0 = (double)ll + (double)df * wg_log2(xx, g_tab.d_tab, g_tab.d_tab2);
+        const uint64_t a = wg_d2u(s1), b = wg_d2u(s0);
+        const uint64_t d = a > b ? a - b : b - a;
+        if (d > mx) mx = d;
+    }
+    return mx;
+}
 void exact_log2_1mp_fill(uint32_t first, uint64_t count, uint64_t* out, int threads)
 {
     par_for(count, threads, [=](uint64_t a, uint64_t b) {

@@ -1,6 +1,13 @@
-"""The bit-exact restatements of glibc's log2f / log2 (wgbs_tools_amd/csrc/exact_log2.h), HOST build, against the
-live libm over the path's whole input domain: every float p in (0,1] for log2f(p) — plus every subnormal — and
-every float p in (0,1) for log2(1.0-(double)p).  Third-party arithmetic pinned by ourselves."""
+"""The arithmetic of the scoring kernel (wgbs_tools_amd/csrc/exact_log2.h), HOST build, against the LIVE libm over the
+path's whole input domain (third-party arithmetic pinned by ourselves):
+
+  * wg_log2f (fused form, used by the kernels) and wg_log2f_nofma (operation-by-operation form): bit-identical to
+    libm's log2f for every float in (0, 1] and every subnormal;
+  * wg_log2: bit-identical to libm's log2(1.0-(double)p) for every float p in (0, 1);
+  * wg_fast_log2: within 1 ulp of libm's log2 on that same domain — the measured bound the Ziv-style rounding test of
+    wg_sample_term relies on;
+  * wg_sample_term (fast path + exact fallback) == wg_sample_term_plain == the oracle's term, bit for bit.
+"""
 import ctypes as C
 import os
 import os.path as op
@@ -17,15 +24,24 @@ LIB = op.join(ROOT, 'tests', 'native', 'libexact_host.so')
 HDR = op.join(ROOT, 'wgbs_tools_amd', 'csrc', 'exact_log2.h')
 
 
-@pytest.fixture(scope='module')
-def exact():
+def load_exact():
     if not op.isfile(LIB) or op.getmtime(LIB) < max(op.getmtime(SRC), op.getmtime(HDR)):
         subprocess.check_call(['g++', '-O2', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC', '-pthread', SRC, '-o', LIB])
     L = C.CDLL(LIB)
-    L.exact_log2f_fill.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
-    L.exact_log2_1mp_fill.argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
-    L.exact_sample_terms.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
+    for f in ('exact_log2f_fill', 'exact_log2f_nofma_fill'):
+        getattr(L, f).argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
+    for f in ('exact_log2_1mp_fill', 'fast_log2_1mp_fill'):
+        getattr(L, f).argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
+    for f in ('exact_sample_terms', 'exact_sample_terms_plain'):
+        getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
+    L.sum_ulp_gap.restype = C.c_uint64
+    L.sum_ulp_gap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]
     return L
+
+
+@pytest.fixture(scope='module')
+def exact():
+    return load_exact()
 
 
 def test_log2f_and_log2_exhaustive_vs_libm(exact):
@@ -33,32 +49,53 @@ def test_log2f_and_log2_exhaustive_vs_libm(exact):
     th = os.cpu_count() or 1
     first, last = 0x00000001, 0x3f800000            # subnormals, normals below 1, and 1.0 itself
     B = 1 << 26
-    bad_f = bad_d = 0
+    bad_f = bad_n = bad_d = 0
+    max_ulp = 0
     q = first
     while q <= last:
         cnt = min(B, last - q + 1)
         a = np.empty(cnt, np.uint32)
-        exact.exact_log2f_fill(q, cnt, a.ctypes.data, th)
         fb = C.c_uint32(0)
+        exact.exact_log2f_fill(q, cnt, a.ctypes.data, th)
         bad_f += O.probe_log2f_compare(q, cnt, a.ctypes.data, th, C.byref(fb))
+        exact.exact_log2f_nofma_fill(q, cnt, a.ctypes.data, th)
+        bad_n += O.probe_log2f_compare(q, cnt, a.ctypes.data, th, C.byref(fb))
         if q + cnt - 1 >= 0x00800000:               # log2(1-p): normal p < 1 (tiny p gives log2(1.0) = 0 either way)
             lo = max(q, 0x00800000)
             c2 = q + cnt - lo - (1 if q + cnt - 1 == last else 0)
             d = np.empty(c2, np.uint64)
             exact.exact_log2_1mp_fill(lo, c2, d.ctypes.data, th)
             bad_d += O.probe_log2_1mp_compare(lo, c2, d.ctypes.data, th, C.byref(fb))
+            exact.fast_log2_1mp_fill(lo, c2, d.ctypes.data, th)
+            max_ulp = max(max_ulp, int(O.probe_log2_1mp_maxulp(lo, c2, d.ctypes.data, th)))
         q += cnt
-    assert bad_f == 0 and bad_d == 0
+    assert bad_f == 0 and bad_n == 0 and bad_d == 0
+    assert max_ulp <= 1, 'fast log2 strays %d ulp from libm: the 6-ulp bound of wg_sample_term no longer holds' % max_ulp
 
 
-@pytest.mark.parametrize('pcount', [15.0, 0.0, 0.5, 1.0, 3.25])
-def test_sample_term_host_build_matches_oracle(exact, pcount):
-    rng = np.random.default_rng(11)
-    t = np.concatenate([np.arange(0, 5000), rng.integers(0, 255 * 1000, 1000000)]).astype(np.float32)
+def _term_inputs(seed, n_random):
+    rng = np.random.default_rng(seed)
+    t = np.concatenate([np.arange(0, 5000), rng.integers(0, 255 * 1000, n_random),
+                        rng.integers(0, 4000, n_random)]).astype(np.float32)
     m = np.minimum(np.floor(rng.random(t.size) * (t + 1)), t).astype(np.float32)
     m[:5000:3] = 0
     m[1:5000:3] = t[1:5000:3]
-    got = np.empty_like(t)
-    exact.exact_sample_terms(m.ctypes.data, t.ctypes.data, t.size, C.c_float(pcount), got.ctypes.data)
+    return m, t
+
+
+@pytest.mark.parametrize('pcount', [15.0, 0.0, 0.5, 1.0, 3.25, 1e-30])
+def test_sample_term_forms_match_oracle(exact, pcount):
+    m, t = _term_inputs(11, 1000000)
     want = oracle.sample_terms(m, t, pcount)
-    assert (got.view(np.uint32) == want.view(np.uint32)).all()
+    for fn in (exact.exact_sample_terms, exact.exact_sample_terms_plain):
+        got = np.empty_like(t)
+        fn(m.ctypes.data, t.ctypes.data, t.size, C.c_float(pcount), got.ctypes.data)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), fn
+
+
+@pytest.mark.parametrize('pcount', [15.0, 0.5, 0.0])
+def test_fast_sum_stays_inside_the_guard_band(exact, pcount):
+    """|s' - s| of the second term, measured on 8 M blocks: must respect the derived 6-ulp bound (guard band is 16)."""
+    m, t = _term_inputs(5, 4000000)
+    gap = int(exact.sum_ulp_gap(m.ctypes.data, t.ctypes.data, t.size, C.c_float(pcount)))
+    assert gap <= 6, gap

@@ -43,17 +43,21 @@ def _load_case(seg, spec):
 # 1. arithmetic: the device restatement of the platform libm, and the per-(block, sample) term
 # ---------------------------------------------------------------------------------------------------------
 def test_01_device_log2_matches_host_libm_exhaustively(seg):
-    """log2f(p) for every float in (0,1] and log2(1-(double)p) for every float in (0,1): device == live libm."""
+    """Every float p in (0,1]: device log2f(p) == live libm; device exact log2(1-(double)p) == live libm; device fast
+    log2 == the host build of the same code bit for bit (IEEE fma), hence within the 1 ulp measured on the host."""
+    from test_exact_log2_cpu import load_exact
+    H = load_exact()
     O = oracle.lib()
     threads = os.cpu_count() or 1
     first, last = 0x00800000, 0x3f800000
     B = 1 << 25
-    bad_f = bad_d = 0
+    bad_f = bad_d = bad_g = 0
+    max_ulp = 0
     msg = ''
     q = first
     while q <= last:
         cnt = min(B, last - q + 1)
-        f, d = seg.debug_log2(q, cnt)
+        f, d, g = seg.debug_log2(q, cnt, want_fast=True)
         fb = C.c_uint32(0)
         nf = O.probe_log2f_compare(q, cnt, f.ctypes.data, threads, C.byref(fb))
         if nf and not msg:
@@ -62,22 +66,34 @@ def test_01_device_log2_matches_host_libm_exhaustively(seg):
         nd = O.probe_log2_1mp_compare(q, cnt_d, d.ctypes.data, threads, C.byref(fb)) if cnt_d else 0
         if nd and not msg:
             msg = 'log2(1-p) first bad bits 0x%08x' % fb.value
+        if cnt_d:
+            hg = np.empty(cnt_d, np.uint64)
+            H.fast_log2_1mp_fill(q, cnt_d, hg.ctypes.data, threads)
+            bad_g += int((hg != g[:cnt_d]).sum())
+            max_ulp = max(max_ulp, int(O.probe_log2_1mp_maxulp(q, cnt_d, g.ctypes.data, threads)))
         bad_f += nf
         bad_d += nd
         q += cnt
-    assert bad_f == 0 and bad_d == 0, 'log2f mismatches %d, log2(1-p) mismatches %d; %s' % (bad_f, bad_d, msg)
+    assert bad_f == 0 and bad_d == 0 and bad_g == 0 and max_ulp <= 1, \
+        'log2f mismatches %d, log2(1-p) mismatches %d, fast log2 device!=host %d, fast log2 max ulp %d; %s' % (bad_f, bad_d, bad_g, max_ulp, msg)
 
 
-@pytest.mark.parametrize('pcount', [15.0, 0.0, 0.5, 1.0])
+@pytest.mark.parametrize('pcount', [15.0, 0.0, 0.5, 1.0, 1e-30])
 def test_02_device_sample_term_matches_oracle(seg, pcount):
-    rng = np.random.default_rng(1234)
-    t = np.concatenate([np.arange(0, 3000), rng.integers(0, 255 * 1000, 400000)]).astype(np.float32)
-    m = np.floor(rng.random(t.size) * (t + 1)).astype(np.float32)
-    m = np.minimum(m, t)
-    m[:3000:3] = 0
-    m[1:3000:3] = t[1:3000:3]
+    """20 M (nmeth, ntotal) pairs per pseudo-count: the device term (fast log2 + exact fallback) == the oracle's."""
+    from test_exact_log2_cpu import _term_inputs
+    m, t = _term_inputs(1234, 10000000)
     got = seg.debug_sample_terms(m, t, pcount)
-    want = oracle.sample_terms(m, t, pcount)
+    want = np.empty_like(t)
+    th = os.cpu_count() or 1
+    import threading
+    parts = np.array_split(np.arange(t.size), th)
+
+    def work(ix):
+        want[ix] = oracle.sample_terms(m[ix], t[ix], pcount)
+    ths = [threading.Thread(target=work, args=(ix,)) for ix in parts]
+    [x.start() for x in ths]
+    [x.join() for x in ths]
     assert _first_diff(got.view(np.uint32), want.view(np.uint32)) is None, _first_diff(got.view(np.uint32), want.view(np.uint32))
 
 

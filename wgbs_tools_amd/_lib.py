@@ -125,7 +125,7 @@ def load():
     L.wgbsseg_debug_sample_terms.restype = i32
     L.wgbsseg_debug_sample_terms.argtypes = [vp, vp, vp, i64, C.c_float, vp]
     L.wgbsseg_debug_log2.restype = i32
-    L.wgbsseg_debug_log2.argtypes = [vp, C.c_uint32, i64, vp, vp]
+    L.wgbsseg_debug_log2.argtypes = [vp, C.c_uint32, i64, vp, vp, vp]
     _lib = L
     return L
 
@@ -275,14 +275,15 @@ class Segmenter:
             raise SegmentorError(rc, 'debug_sample_terms failed')
         return out
 
-    def debug_log2(self, first_bits, count, want_f=True, want_d=True):
+    def debug_log2(self, first_bits, count, want_f=True, want_d=True, want_fast=False):
         f = np.empty(count, dtype=np.uint32) if want_f else None
         d = np.empty(count, dtype=np.uint64) if want_d else None
+        g = np.empty(count, dtype=np.uint64) if want_fast else None
         rc = self._L.wgbsseg_debug_log2(self._h, int(first_bits), int(count), f.ctypes.data if want_f else None,
-                                        d.ctypes.data if want_d else None)
+                                        d.ctypes.data if want_d else None, g.ctypes.data if want_fast else None)
         if rc != OK:
             raise SegmentorError(rc, 'debug_log2 failed')
-        return f, d
+        return (f, d, g) if want_fast else (f, d)
 
 
 def segment_chunks_host(samples, loci, start0, lens, pcount, max_cpg, max_bp, device=0):

@@ -141,8 +141,11 @@ WG_HD float    wg_u2f(uint32_t u) { float f;    memcpy(&f, &u, 4); return f; }
 WG_HD uint64_t wg_d2u(double d)  { uint64_t u; memcpy(&u, &d, 8); return u; }
 WG_HD double   wg_u2d(uint64_t u) { double d;   memcpy(&d, &u, 8); return d; }
 
+#define WG_FMA(a, b, c) __builtin_fma((a), (b), (c))     // one IEEE fused multiply-add (v_fma_f64 on the device)
+
 // glibc 2.35 __log2f (sysdeps/ieee754/flt-32/e_log2f.c), positive finite inputs.  x == 1 -> +0.
-WG_HD float wg_log2f(float x, const wg_d2* __restrict__ ftab)
+// Evaluated without any fused multiply-add, operation by operation as the generic C source reads.
+WG_HD float wg_log2f_nofma(float x, const wg_d2* __restrict__ ftab)
 {
     uint32_t ix = wg_f2u(x);
     if (ix == 0x3f800000u) return 0.0f;
@@ -164,6 +167,35 @@ WG_HD float wg_log2f(float x, const wg_d2* __restrict__ ftab)
     y = WG_LOG2F_A0 * r2 + y;
     double p = WG_LOG2F_A3 * r + y0;
     y = y * r2 + p;
+    return (float)y;
+}
+
+// The same evaluation with every multiply-add fused (what glibc's FMA ifunc variant computes).  The double result
+// differs from the unfused one in its last bits, the FLOAT result never does: both forms are compared with the live
+// libm over every float in (0, 1] (and every subnormal) by tests/test_exact_log2_cpu.py — 0 mismatches each.
+// 7 fp64 operations instead of 12: this is the form the kernels use.
+WG_HD float wg_log2f(float x, const wg_d2* __restrict__ ftab)
+{
+    uint32_t ix = wg_f2u(x);
+    if (ix == 0x3f800000u) return 0.0f;
+    if (ix < 0x00800000u) {
+        ix = wg_f2u(x * 0x1p23f);
+        ix -= 23u << 23;
+    }
+    uint32_t tmp = ix - 0x3f330000u;
+    uint32_t i = (tmp >> 19) & 15u;
+    uint32_t top = tmp & 0xff800000u;
+    uint32_t iz = ix - top;
+    int32_t k = (int32_t)tmp >> 23;
+    double invc = ftab[i].a, logc = ftab[i].b;
+    double z = (double)wg_u2f(iz);
+    double r = WG_FMA(z, invc, -1.0);
+    double y0 = logc + (double)k;
+    double r2 = r * r;
+    double y = WG_FMA(WG_LOG2F_A1, r, WG_LOG2F_A2);
+    y = WG_FMA(WG_LOG2F_A0, r2, y);
+    double p = WG_FMA(WG_LOG2F_A3, r, y0);
+    y = WG_FMA(y, r2, p);
     return (float)y;
 }
 
@@ -212,19 +244,84 @@ WG_HD double wg_log2(double x, const wg_d2* __restrict__ dtab, const wg_d2* __re
     return y;
 }
 
+// A cheap log2 for the SAME arguments (x = 1.0 - (double)p, p a float in (0,1)): glibc's own table and polynomials,
+// evaluated by plain Horner with fused multiply-adds, without the hi/lo compensation and without tab2.
+// It is NOT bit-identical to libm, but its distance from libm's result is bounded: tests/test_exact_log2_cpu.py
+// measures |wg_fast_log2 - log2| <= 1 ulp over the WHOLE domain (all 1,056,964,608 floats p), exhaustively, for the
+// host build, and the gfx950 build is compared bit for bit with the host build (IEEE fma is deterministic).
+// 10-12 fp64 operations instead of 30-34.
+#define WG_LOG2_INVLN2 0x1.71547652b82fep+0
+WG_HD double wg_fast_log2(double x, const wg_d2* __restrict__ dtab)
+{
+    const uint64_t ix = wg_d2u(x);
+    const uint64_t LO = 0x3feea4af00000000ull, HI = 0x3ff0b55900000000ull;
+    if (ix - LO < HI - LO) {
+        if (ix == 0x3ff0000000000000ull) return 0.0;
+        const double r = x - 1.0;
+        double q = WG_LOG2_B9;
+        q = WG_FMA(q, r, WG_LOG2_B8); q = WG_FMA(q, r, WG_LOG2_B7); q = WG_FMA(q, r, WG_LOG2_B6);
+        q = WG_FMA(q, r, WG_LOG2_B5); q = WG_FMA(q, r, WG_LOG2_B4); q = WG_FMA(q, r, WG_LOG2_B3);
+        q = WG_FMA(q, r, WG_LOG2_B2); q = WG_FMA(q, r, WG_LOG2_B1); q = WG_FMA(q, r, WG_LOG2_B0);
+        q = WG_FMA(q, r, WG_LOG2_INVLN2);
+        return q * r;
+    }
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const uint32_t i = (uint32_t)(tmp >> 46) & 63u;
+    const int32_t k = (int32_t)((int64_t)tmp >> 52);
+    const uint64_t iz = ix - (tmp & (0xfffull << 52));
+    const double invc = dtab[i].a, logc = dtab[i].b;
+    const double r = WG_FMA(wg_u2d(iz), invc, -1.0);
+    double q = WG_LOG2_A5;
+    q = WG_FMA(q, r, WG_LOG2_A4); q = WG_FMA(q, r, WG_LOG2_A3); q = WG_FMA(q, r, WG_LOG2_A2);
+    q = WG_FMA(q, r, WG_LOG2_A1); q = WG_FMA(q, r, WG_LOG2_A0); q = WG_FMA(q, r, WG_LOG2_INVLN2);
+    return WG_FMA(q, r, (double)k + logc);
+}
+
 // The reference's per-(block, sample) log-likelihood term, segmentor.cpp:125-135, on exact integer counts.
 //   nmeth, ntotal : block sums of the sample (exact in float: 255*max_cpg < 2^24 is enforced by the ABI)
 //   pc, pc2       : pseudo_count and pseudo_count+pseudo_count (== the reference's float `2 * pseudo_count`)
 // Returns the float ll_k that the reference adds into its double ll_sum; 0 when the block has no coverage.
-WG_HD float wg_sample_term(float nmeth, float ntotal, float pc, float pc2, const wg_log_tables* __restrict__ tb)
+// Straightforward form: every operation as the reference performs it (exact libm restatements).
+WG_HD float wg_sample_term_plain(float nmeth, float ntotal, float pc, float pc2, const wg_log_tables* __restrict__ tb)
 {
     if (ntotal == 0.0f) return 0.0f;                               // :125
     float p = (nmeth + pc) / (ntotal + pc2);                       // :127 IEEE binary32 add, add, divide
     float ll = 0.0f;
-    if (p > 0.0f) ll += nmeth * wg_log2f(p, tb->f_tab);            // :129-131 (kept as 0 + x: -0 becomes +0)
+    if (p > 0.0f) ll += nmeth * wg_log2f_nofma(p, tb->f_tab);      // :129-131 (kept as 0 + x: -0 becomes +0)
     if (p < 1.0f) {                                                // :132-134
         double t = (double)(ntotal - nmeth) * wg_log2(1.0 - (double)p, tb->d_tab, tb->d_tab2);
         ll = (float)((double)ll + t);
+    }
+    return ll;
+}
+
+// Production form, identical results (Ziv's strategy).  The second term is
+//     ll = (float)( (double)ll + (double)(ntotal-nmeth) * L ),   L = libm log2(1 - p)
+// and only its FLOAT rounding is observable.  With L' = wg_fast_log2 (|L'-L| <= 1 ulp, measured exhaustively) the
+// double sum s' differs from the true s by at most 6 ulp(s): the products differ by <= (2^-52 + 2*2^-53)|prod|, both
+// addends are <= 0 so |prod| <= |s|, and each sum adds one rounding (2^-53|s|).  So (float)s' == (float)s unless s'
+// lies within 6 ulp of a float rounding midpoint (low 29 mantissa bits == 2^28); we use a 16-ulp guard band, and in
+// that band (probability 2^-24 per evaluation), or when the result could be a subnormal float, the exact
+// restatement decides.  When ntotal == nmeth the reference adds -0.0 and ll is unchanged.
+WG_HD float wg_sample_term(float nmeth, float ntotal, float pc, float pc2, const wg_log_tables* __restrict__ tb)
+{
+    if (ntotal == 0.0f) return 0.0f;                               // :125
+    const float p = (nmeth + pc) / (ntotal + pc2);                 // :127
+    float ll = 0.0f;
+    if (p > 0.0f) ll += nmeth * wg_log2f(p, tb->f_tab);            // :129-131
+    if (p < 1.0f) {                                                // :132-134
+        const float df = ntotal - nmeth;
+        if (df != 0.0f) {
+            const double x = 1.0 - (double)p;
+            const double s = (double)ll + (double)df * wg_fast_log2(x, tb->d_tab);
+            const uint64_t sb = wg_d2u(s);
+            const uint32_t tail = (uint32_t)sb & 0x1fffffffu;
+            const uint32_t ex = (uint32_t)(sb >> 52) & 0x7ffu;
+            float res = (float)s;
+            if ((uint32_t)(tail - (0x10000000u - 16u)) <= 32u || (ex < 1023u - 120u && (sb << 1) != 0))   // s' == 0 <=> L == 0: exact
+                res = (float)((double)ll + (double)df * wg_log2(x, tb->d_tab, tb->d_tab2));
+            ll = res;
+        }
     }
     return ll;
 }

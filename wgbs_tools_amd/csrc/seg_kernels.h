@@ -745,7 +745,7 @@ __global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, f
         out[q] = wg_sample_term(nm[q], nt[q], pc, pc2, &tb);
 }
 
-__global__ void k_debug_log2(uint32_t first, int64_t count, uint32_t* out_f, uint64_t* out_d)
+__global__ void k_debug_log2(uint32_t first, int64_t count, uint32_t* out_f, uint64_t* out_d, uint64_t* out_fast)
 {
     __shared__ wg_log_tables tb;
     {
@@ -759,6 +759,7 @@ __global__ void k_debug_log2(uint32_t first, int64_t count, uint32_t* out_f, uin
         const float p = wg_u2f(first + (uint32_t)q);
         if (out_f) out_f[q] = wg_f2u(wg_log2f(p, tb.f_tab));
         if (out_d) out_d[q] = wg_d2u(wg_log2(1.0 - (double)p, tb.d_tab, tb.d_tab2));
+        if (out_fast) out_fast[q] = wg_d2u(wg_fast_log2(1.0 - (double)p, tb.d_tab));
     }
 }
 

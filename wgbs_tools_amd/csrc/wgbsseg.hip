@@ -625,19 +625,21 @@ int wgbsseg_debug_sample_terms(wgbsseg_ctx* c, const float* nmeth, const float* 
     return WGBSSEG_OK;
 }
 
-int wgbsseg_debug_log2(wgbsseg_ctx* c, uint32_t first_bits, int64_t count, uint32_t* out_f, uint64_t* out_d)
+int wgbsseg_debug_log2(wgbsseg_ctx* c, uint32_t first_bits, int64_t count, uint32_t* out_f, uint64_t* out_d, uint64_t* out_fast)
 {
     char* err = nullptr; size_t errlen = 0;
-    if (!c || count < 1 || (!out_f && !out_d)) return WGBSSEG_E_ARG;
+    if (!c || count < 1 || (!out_f && !out_d && !out_fast)) return WGBSSEG_E_ARG;
     HIP_TRY(hipSetDevice(c->device));
     if (out_f) HIP_TRY(c->dbg_a.ensure((size_t)count * 4));
     if (out_d) HIP_TRY(c->dbg_b.ensure((size_t)count * 8));
+    if (out_fast) HIP_TRY(c->dbg_c.ensure((size_t)count * 8));
     const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 16384);
     hipLaunchKernelGGL(k_debug_log2, dim3(blocks), dim3(256), 0, c->sA, first_bits, count, out_f ? c->dbg_a.as<uint32_t>() : nullptr,
-                       out_d ? c->dbg_b.as<uint64_t>() : nullptr);
+                       out_d ? c->dbg_b.as<uint64_t>() : nullptr, out_fast ? c->dbg_c.as<uint64_t>() : nullptr);
     HIP_TRY(hipGetLastError());
     if (out_f) HIP_TRY(hipMemcpyAsync(out_f, c->dbg_a.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->sA));
     if (out_d) HIP_TRY(hipMemcpyAsync(out_d, c->dbg_b.p, (size_t)count * 8, hipMemcpyDeviceToHost, c->sA));
+    if (out_fast) HIP_TRY(hipMemcpyAsync(out_fast, c->dbg_c.p, (size_t)count * 8, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
     return WGBSSEG_OK;
 }
