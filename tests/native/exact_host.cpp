@@ -5,7 +5,8 @@
 #include <thread>
 #include <vector>
 
-static const wg_log_tables g_tab = WG_LOG_TABLES_INIT;
+static wg_log_tables make_tab() { wg_log_tables t = WG_LOG_TABLES_INIT; wg_tables_finish(&t); return t; }
+static const wg_log_tables g_tab = make_tab();
 
 template <class F> static void par_for(uint64_t count, int threads, F f)
 {
@@ -32,7 +33,7 @@ void exact_log2f_nofma_fill(uint32_t first, uint64_t count, uint32_t* out, int t
 void fast_log2_1mp_fill(uint32_t first, uint64_t count, uint64_t* out, int threads)
 {
     par_for(count, threads, [=](uint64_t a, uint64_t b) {
-        for (uint64_t q = a; q < b; q++) out[q] = wg_d2u(wg_fast_log2(1.0 - (double)wg_u2f(first + (uint32_t)q), g_tab.d_tab));
+        for (uint64_t q = a; q < b; q++) out[q] = wg_d2u(wg_fast_log2(1.0 - (double)wg_u2f(first + (uint32_t)q), g_tab.d_fast));
     });
 }
 void exact_sample_terms_plain(const float* nmeth, const float* ntotal, int64_t count, float pc, float* out)
@@ -55,7 +56,7 @@ uint64_t sum_ulp_gap(const float* nmeth, const float* ntotal, int64_t count, flo
         const float df = t - m;
         if (!(p < 1.0f) || df == 0.0f) continue;
         const double xx = 1.0 - (double)p;
-        const double s1 = (double)ll + (double)df * wg_fast_log2(xx, g_tab.d_tab);
+        const double s1 = (double)ll + (double)df * wg_fast_log2(xx, g_tab.d_fast);
         const double s0 = (double)ll + (double)df * wg_log2(xx, g_tab.d_tab, g_tab.d_tab2);
         const uint64_t a = wg_d2u(s1), b = wg_d2u(s0);
         const uint64_t d = a > b ? a - b : b - a;
@@ -73,6 +74,8 @@ void exact_log2_1mp_fill(uint32_t first, uint64_t count, uint64_t* out, int thre
 void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, float pc, float* out)
 {
     float pc2 = pc + pc;
-    for (int64_t q = 0; q < count; q++) out[q] = wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_tab);
+    const bool fast_ok = pc == 0.0f || pc >= WG_FAST_MIN_PC;       // same dispatch rule as the library
+    for (int64_t q = 0; q < count; q++)
+        out[q] = fast_ok ? wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_tab) : wg_sample_term_plain(nmeth[q], ntotal[q], pc, pc2, &g_tab);
 }
 }

@@ -133,8 +133,12 @@ struct wg_log_tables {
     wg_d2 f_tab[16];     // log2f {invc, logc}
     wg_d2 d_tab[64];     // log2  {invc, logc}
     wg_d2 d_tab2[64];    // log2  {chi, clo}
+    wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}: filled by wg_tables_finish()
 };
-#define WG_LOG_TABLES_INIT { WG_LOG2F_TAB, WG_LOG2_TAB, WG_LOG2_TAB2 }
+#define WG_LOG_TABLES_INIT { WG_LOG2F_TAB, WG_LOG2_TAB, WG_LOG2_TAB2, WG_LOG2_TAB }
+// The fast log2 uses d_tab with ONE entry changed: interval 39 = [0.9921875, 1) gets the centre exactly 1
+// (invc = 1, logc = 0), so that arguments just below 1 need no separate cancellation-free branch.
+#define WG_FAST_CENTRE_ENTRY 39
 
 WG_HD uint32_t wg_f2u(float f)   { uint32_t u; memcpy(&u, &f, 4); return u; }
 WG_HD float    wg_u2f(uint32_t u) { float f;    memcpy(&f, &u, 4); return f; }
@@ -178,10 +182,7 @@ WG_HD float wg_log2f(float x, const wg_d2* __restrict__ ftab)
 {
     uint32_t ix = wg_f2u(x);
     if (ix == 0x3f800000u) return 0.0f;
-    if (ix < 0x00800000u) {
-        ix = wg_f2u(x * 0x1p23f);
-        ix -= 23u << 23;
-    }
+    if (ix < 0x00800000u) return wg_log2f_nofma(x, ftab);       // subnormal p: never on real data, kept exact
     uint32_t tmp = ix - 0x3f330000u;
     uint32_t i = (tmp >> 19) & 15u;
     uint32_t top = tmp & 0xff800000u;
@@ -244,32 +245,34 @@ WG_HD double wg_log2(double x, const wg_d2* __restrict__ dtab, const wg_d2* __re
     return y;
 }
 
-// A cheap log2 for the SAME arguments (x = 1.0 - (double)p, p a float in (0,1)): glibc's own table and polynomials,
-// evaluated by plain Horner with fused multiply-adds, without the hi/lo compensation and without tab2.
+// Call once on a freshly initialised table set (host or, by one thread, in LDS).
+WG_HD void wg_tables_finish(wg_log_tables* tb)
+{
+    tb->d_fast[WG_FAST_CENTRE_ENTRY].a = 1.0;
+    tb->d_fast[WG_FAST_CENTRE_ENTRY].b = 0.0;
+}
+
+// A cheap log2 for the SAME arguments (x = 1.0 - (double)p, p a float in (0,1), so x in [2^-24, 1)): glibc's table
+// and main polynomial, evaluated by plain Horner with fused multiply-adds, without the hi/lo compensation, without
+// tab2, and without glibc's separate near-1 branch — instead the table interval just below 1 is centred exactly on 1
+// (WG_FAST_CENTRE_ENTRY), which keeps the relative error flat up to x -> 1.
 // It is NOT bit-identical to libm, but its distance from libm's result is bounded: tests/test_exact_log2_cpu.py
-// measures |wg_fast_log2 - log2| <= 1 ulp over the WHOLE domain (all 1,056,964,608 floats p), exhaustively, for the
-// host build, and the gfx950 build is compared bit for bit with the host build (IEEE fma is deterministic).
-// 10-12 fp64 operations instead of 30-34.
+// measures |wg_fast_log2 - log2| <= WG_FAST_LOG2_MAX_ULP over the WHOLE domain (all 1,056,964,607 floats p),
+// exhaustively, for the host build, and the gfx950 build is compared bit for bit with the host build (IEEE fma is
+// deterministic).  9 fp64 operations instead of 30-34, no divergent branch.
 #define WG_LOG2_INVLN2 0x1.71547652b82fep+0
-WG_HD double wg_fast_log2(double x, const wg_d2* __restrict__ dtab)
+#define WG_FAST_LOG2_MAX_ULP 1
+// `dfast` = wg_log_tables::d_fast after wg_tables_finish().
+WG_HD double wg_fast_log2(double x, const wg_d2* __restrict__ dfast)
 {
     const uint64_t ix = wg_d2u(x);
-    const uint64_t LO = 0x3feea4af00000000ull, HI = 0x3ff0b55900000000ull;
-    if (ix - LO < HI - LO) {
-        if (ix == 0x3ff0000000000000ull) return 0.0;
-        const double r = x - 1.0;
-        double q = WG_LOG2_B9;
-        q = WG_FMA(q, r, WG_LOG2_B8); q = WG_FMA(q, r, WG_LOG2_B7); q = WG_FMA(q, r, WG_LOG2_B6);
-        q = WG_FMA(q, r, WG_LOG2_B5); q = WG_FMA(q, r, WG_LOG2_B4); q = WG_FMA(q, r, WG_LOG2_B3);
-        q = WG_FMA(q, r, WG_LOG2_B2); q = WG_FMA(q, r, WG_LOG2_B1); q = WG_FMA(q, r, WG_LOG2_B0);
-        q = WG_FMA(q, r, WG_LOG2_INVLN2);
-        return q * r;
-    }
+    if (ix == 0x3ff0000000000000ull) return 0.0;
     const uint64_t tmp = ix - 0x3fe6000000000000ull;
-    const uint32_t i = (uint32_t)(tmp >> 46) & 63u;
-    const int32_t k = (int32_t)((int64_t)tmp >> 52);
-    const uint64_t iz = ix - (tmp & (0xfffull << 52));
-    const double invc = dtab[i].a, logc = dtab[i].b;
+    const uint32_t hi = (uint32_t)(tmp >> 32);
+    const uint32_t i = (hi >> 14) & 63u;
+    const int32_t k = (int32_t)hi >> 20;
+    const uint64_t iz = ix - ((uint64_t)(hi & 0xfff00000u) << 32);
+    const double invc = dfast[i].a, logc = dfast[i].b;
     const double r = WG_FMA(wg_u2d(iz), invc, -1.0);
     double q = WG_LOG2_A5;
     q = WG_FMA(q, r, WG_LOG2_A4); q = WG_FMA(q, r, WG_LOG2_A3); q = WG_FMA(q, r, WG_LOG2_A2);
@@ -301,8 +304,12 @@ WG_HD float wg_sample_term_plain(float nmeth, float ntotal, float pc, float pc2,
 // double sum s' differs from the true s by at most 6 ulp(s): the products differ by <= (2^-52 + 2*2^-53)|prod|, both
 // addends are <= 0 so |prod| <= |s|, and each sum adds one rounding (2^-53|s|).  So (float)s' == (float)s unless s'
 // lies within 6 ulp of a float rounding midpoint (low 29 mantissa bits == 2^28); we use a 16-ulp guard band, and in
-// that band (probability 2^-24 per evaluation), or when the result could be a subnormal float, the exact
-// restatement decides.  When ntotal == nmeth the reference adds -0.0 and ll is unchanged.
+// that band (probability 2^-24 per evaluation) the exact restatement decides.  When ntotal == nmeth the reference adds -0.0 and ll is unchanged.
+#define WG_GUARD_ULPS 16u
+// The guard-band test needs no exponent check when the sum cannot be a subnormal float: with pc == 0 or
+// pc >= WG_FAST_MIN_PC every non-zero sum is >= 2^-100 in magnitude (p >= pc / 2^25), and a zero sum is exact.
+// Callers with 0 < pc < WG_FAST_MIN_PC must use wg_sample_term_plain.
+#define WG_FAST_MIN_PC 0x1p-60f
 WG_HD float wg_sample_term(float nmeth, float ntotal, float pc, float pc2, const wg_log_tables* __restrict__ tb)
 {
     if (ntotal == 0.0f) return 0.0f;                               // :125
@@ -313,12 +320,10 @@ WG_HD float wg_sample_term(float nmeth, float ntotal, float pc, float pc2, const
         const float df = ntotal - nmeth;
         if (df != 0.0f) {
             const double x = 1.0 - (double)p;
-            const double s = (double)ll + (double)df * wg_fast_log2(x, tb->d_tab);
-            const uint64_t sb = wg_d2u(s);
-            const uint32_t tail = (uint32_t)sb & 0x1fffffffu;
-            const uint32_t ex = (uint32_t)(sb >> 52) & 0x7ffu;
+            const double s = (double)ll + (double)df * wg_fast_log2(x, tb->d_fast);
+            const uint32_t tail = (uint32_t)wg_d2u(s) & 0x1fffffffu;
             float res = (float)s;
-            if ((uint32_t)(tail - (0x10000000u - 16u)) <= 32u || (ex < 1023u - 120u && (sb << 1) != 0))   // s' == 0 <=> L == 0: exact
+            if ((uint32_t)(tail - (0x10000000u - WG_GUARD_ULPS)) <= 2u * WG_GUARD_ULPS)
                 res = (float)((double)ll + (double)df * wg_log2(x, tb->d_tab, tb->d_tab2));
             ll = res;
         }

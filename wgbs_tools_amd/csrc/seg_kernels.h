@@ -16,6 +16,7 @@
 //   k_trace   traceback (segmentor.cpp:50-58) out of an LDS-resident window of back-pointers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 #include "exact_log2.h"
 #include "wave_prims.h"
@@ -23,9 +24,24 @@
 #define WG_CARRY_G      64          // a carry (chunk-relative exclusive prefix) is stored at every absolute site index
                                     // that is a multiple of 64 inside the chunk, plus (group 0) at the chunk start itself
 #define WG_BLOCK        256
-#define WG_RMAX         16          // candidate blocks per thread held in registers by k_cost
-#define WG_PAIR_CAP     (WG_BLOCK * WG_RMAX)
+#define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)
 #define WG_TRACE_WIN    65536       // back-pointers staged in LDS by k_trace (128 KiB)
+
+// Copy the log tables into LDS (all threads of the workgroup), applying wg_tables_finish() on the fly.
+// The caller must __syncthreads() before using them.
+__device__ __forceinline__ void wg_tables_to_lds(wg_log_tables* tb, int tid, int nthreads)
+{
+    const wg_log_tables init = WG_LOG_TABLES_INIT;               // materialised from constant data
+    const double* src = reinterpret_cast<const double*>(&init);
+    double* d = reinterpret_cast<double*>(tb);
+    const int fix = (int)(offsetof(wg_log_tables, d_fast) / 8) + 2 * WG_FAST_CENTRE_ENTRY;
+    for (int x = tid; x < (int)(sizeof(wg_log_tables) / 8); x += nthreads) {
+        double v = src[x];
+        if (x == fix) v = 1.0;
+        if (x == fix + 1) v = 0.0;
+        d[x] = v;
+    }
+}
 
 struct ChunkDesc {
     int64_t start0;      // first site (0-based, absolute)
@@ -345,7 +361,7 @@ __device__ __forceinline__ int wg_group_start(const ChunkDesc& cd, int k)
     return a <= cd.start0 ? 0 : (int)(a - cd.start0);
 }
 
-template <int TI>
+template <int TI, bool FAST>
 __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, CostArgs A, double* __restrict__ cost,
                                                    int64_t n_tiles_padded)
 {
@@ -356,7 +372,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     int64_t* radj = reinterpret_cast<int64_t*>(St + (size_t)A.NS * A.IS);        // [TI]
     int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
     int32_t* ist = offs + (TI + 1);                                              // [TI] first end of start kl in this unit
-    int32_t* misc = ist + TI;                                                    // [2]
+    int32_t* misc = ist + TI;                                                    // [2 (+1 pad)]
+    double* accL = reinterpret_cast<double*>(misc + 3 + (TI & 1 ? 1 : 0));       // [QCAP] partial sums across sample groups
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nC = J.n_chunks;
@@ -383,12 +400,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int et_hi = (A.KT > 1) ? et_lo + A.TK : (1 << 30);
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
 
-    {   // tables -> LDS
-        const wg_log_tables init = WG_LOG_TABLES_INIT;   // materialised from constant data
-        const double* src = reinterpret_cast<const double*>(&init);
-        double* d = reinterpret_cast<double*>(tb);
-        for (int x = tid; x < (int)(sizeof(wg_log_tables) / 8); x += WG_BLOCK) d[x] = src[x];
-    }
+    wg_tables_to_lds(tb, tid, WG_BLOCK);
     if (wv == 0) {
         const int k = ka + lane;
         const bool valid = lane < nk;
@@ -427,28 +439,14 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int soff = ka - sA;                            // P[k] of start kl at S[soff + kl]
     const int Scnt = kb - sA;
 
-    // my candidate blocks: q = tid + 256 r  ->  (kl, i)
-    const int R = (Q + WG_BLOCK - 1) / WG_BLOCK;
-    uint32_t pr[WG_RMAX];
-    double acc[WG_RMAX];
-#pragma unroll
-    for (int r = 0; r < WG_RMAX; r++) {
-        pr[r] = 0xffffffffu;
-        acc[r] = 0.0;
-        if (r < R) {
-            const int q = tid + WG_BLOCK * r;
-            if (q < Q) {
-                int lo = 0, hi = nk;                       // largest kl with offs[kl] <= q
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
-                const int i = ist[lo] + (q - offs[lo]);
-                pr[r] = (uint32_t)lo | ((uint32_t)(i + 1 - eA) << 8);
-            }
-        }
-    }
-
+    // Blocks of the tile, flattened: q -> (kl, i).  Every thread walks its blocks q = tid, tid+256, ...; for each it
+    // runs the samples of the LDS-resident group IN FILE ORDER, carrying the double sum in a register (and, when the
+    // samples do not fit LDS at once, across groups in accL) — the accumulation order of segmentor.cpp:120-136.
     const float pc = A.pc, pc2 = A.pc2;
+    double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
     for (int g0 = 0; g0 < J.n_samples; g0 += A.NS) {
         const int ns = (J.n_samples - g0 < A.NS) ? J.n_samples - g0 : A.NS;
+        const bool firstg = g0 == 0, lastg = g0 + ns >= J.n_samples;
         __syncthreads();
         for (int rr = wv; rr < ns; rr += WG_BLOCK / 64) {
             const int s = g0 + rr;
@@ -458,31 +456,23 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             if (A.KT > 1) wg_stage_prefix_row(St + (size_t)rr * A.IS, row, carry, cd, J.n_total, sA, Scnt, lane);
         }
         __syncthreads();
-        for (int sl = 0; sl < ns; sl++) {
-            const uint2* Erow = Et + (size_t)sl * A.KS;
-            const uint2* Srow = Sbase + (size_t)sl * Sstride + soff;
-#pragma unroll
-            for (int r = 0; r < WG_RMAX; r++) {
-                if (r < R) {
-                    if (pr[r] != 0xffffffffu) {
-                        const uint2 pi = Erow[pr[r] >> 8];
-                        const uint2 pk = Srow[pr[r] & 0xffu];
-                        const float nm = (float)(pi.x - pk.x);
-                        const float nt = (float)(pi.y - pk.y);
-                        acc[r] += (double)wg_sample_term(nm, nt, pc, pc2, tb);   // segmentor.cpp:135
-                    }
-                }
+        for (int q = tid; q < Q; q += WG_BLOCK) {
+            int lo = 0, hi = nk;                           // largest kl with offs[kl] <= q
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
+            const int i = ist[lo] + (q - offs[lo]);
+            const uint2* Ep = Et + (i + 1 - eA);           // P[i+1] of sample sl at Ep[sl * KS]
+            const uint2* Sp = Sbase + soff + lo;           // P[k]   of sample sl at Sp[sl * Sstride]
+            double acc = firstg ? 0.0 : accL[q];
+            for (int sl = 0; sl < ns; sl++) {
+                const uint2 pi = Ep[(size_t)sl * A.KS];
+                const uint2 pk = Sp[(size_t)sl * Sstride];
+                const float nm = (float)(pi.x - pk.x);
+                const float nt = (float)(pi.y - pk.y);
+                const float ll = FAST ? wg_sample_term(nm, nt, pc, pc2, tb) : wg_sample_term_plain(nm, nt, pc, pc2, tb);
+                acc += (double)ll;                                               // segmentor.cpp:135
             }
-        }
-    }
-
-    double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
-#pragma unroll
-    for (int r = 0; r < WG_RMAX; r++) {
-        if (r < R && pr[r] != 0xffffffffu) {
-            const int kl = (int)(pr[r] & 0xffu);
-            const int i = (int)(pr[r] >> 8) + eA - 1;
-            cb[radj[kl] + i] = (acc[r] != 0.0) ? acc[r] : 0.0;                    // segmentor.cpp:106,137
+            if (lastg) cb[radj[lo] + i] = (acc != 0.0) ? acc : 0.0;              // segmentor.cpp:106,137
+            else accL[q] = acc;
         }
     }
 }
@@ -730,36 +720,26 @@ __global__ __launch_bounds__(WG_BLOCK) void k_gather_borders(JobView J, const in
 // ------------------------------------------------------------------------------------------------------------
 // test hooks
 // ------------------------------------------------------------------------------------------------------------
-__global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, float pc, float* out)
+__global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, float pc, float* out, int fast)
 {
     __shared__ wg_log_tables tb;
-    {
-        const wg_log_tables init = WG_LOG_TABLES_INIT;
-        const double* src = reinterpret_cast<const double*>(&init);
-        double* d = reinterpret_cast<double*>(&tb);
-        for (int x = threadIdx.x; x < (int)(sizeof(wg_log_tables) / 8); x += blockDim.x) d[x] = src[x];
-    }
+    wg_tables_to_lds(&tb, threadIdx.x, blockDim.x);
     __syncthreads();
     const float pc2 = pc + pc;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x)
-        out[q] = wg_sample_term(nm[q], nt[q], pc, pc2, &tb);
+        out[q] = fast ? wg_sample_term(nm[q], nt[q], pc, pc2, &tb) : wg_sample_term_plain(nm[q], nt[q], pc, pc2, &tb);
 }
 
 __global__ void k_debug_log2(uint32_t first, int64_t count, uint32_t* out_f, uint64_t* out_d, uint64_t* out_fast)
 {
     __shared__ wg_log_tables tb;
-    {
-        const wg_log_tables init = WG_LOG_TABLES_INIT;
-        const double* src = reinterpret_cast<const double*>(&init);
-        double* d = reinterpret_cast<double*>(&tb);
-        for (int x = threadIdx.x; x < (int)(sizeof(wg_log_tables) / 8); x += blockDim.x) d[x] = src[x];
-    }
+    wg_tables_to_lds(&tb, threadIdx.x, blockDim.x);
     __syncthreads();
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x) {
         const float p = wg_u2f(first + (uint32_t)q);
         if (out_f) out_f[q] = wg_f2u(wg_log2f(p, tb.f_tab));
         if (out_d) out_d[q] = wg_d2u(wg_log2(1.0 - (double)p, tb.d_tab, tb.d_tab2));
-        if (out_fast) out_fast[q] = wg_d2u(wg_fast_log2(1.0 - (double)p, tb.d_tab));
+        if (out_fast) out_fast[q] = wg_d2u(wg_fast_log2(1.0 - (double)p, tb.d_fast));
     }
 }
 

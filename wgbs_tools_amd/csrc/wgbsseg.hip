@@ -275,17 +275,25 @@ int report_bad_site(const wgbsseg_ctx* c, const JobStatus& st, char* err, size_t
     return WGBSSEG_E_METH_GT_COV;
 }
 
-template <int TI>
+template <int TI, bool FAST>
 hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a, double* cost, int64_t tiles, size_t lds, hipStream_t s)
 {
     const int64_t padded = round_up(tiles, 8);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cost<TI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cost<TI, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_cost<TI>, dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, cost, padded);
+    hipLaunchKernelGGL((k_cost<TI, FAST>), dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, cost, padded);
     return hipGetLastError();
+}
+
+template <bool FAST>
+hipError_t launch_cost_ti(int TI, const JobView& v, const StageView& sv, const CostArgs& a, double* cost, int64_t tiles, size_t lds, hipStream_t s)
+{
+    if (TI == 64) return launch_cost<64, FAST>(v, sv, a, cost, tiles, lds, s);
+    if (TI == 32) return launch_cost<32, FAST>(v, sv, a, cost, tiles, lds, s);
+    return launch_cost<16, FAST>(v, sv, a, cost, tiles, lds, s);
 }
 
 void grow_events(std::vector<hipEvent_t>& v, size_t n)
@@ -346,21 +354,40 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const int64_t total_pairs = (int64_t)st.total_pairs;
 
     // ---- tiling of the scoring kernel ----------------------------------------------------------------------
-    int TI, KT = 1, TK = 0;
-    if (Wmax <= 64) TI = 64; else if (Wmax <= 128) TI = 32; else if (Wmax <= 256) TI = 16;
-    else { TI = 16; TK = 256; KT = (Wmax - 1 + TI + TK - 1) / TK; }
+    // A tile = TI start sites (x one of KT end-site tiles of TK sites when windows are wide), at most WG_PAIR_CAP
+    // blocks.  LDS per workgroup: log tables + NS sample rows of prefixes + small per-tile arrays (+ partial sums
+    // when the samples need several groups).  Aim: <= ~50 KB so that three workgroups share a CU.
+    const size_t LDS_TARGET = 50 * 1024, LDS_MAX = 64 * 1024;
+    int TI = 64, KT = 1, TK = 0, NS = 0;
+    size_t lds_cost = 0;
     CostArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.pc = P->pseudo_count; ca.pc2 = P->pseudo_count + P->pseudo_count;
-    ca.KT = KT; ca.TK = TK;
+    auto lds_for = [&](int ti, int kt, int tk, int ns, bool multi) -> size_t {
+        const int ks = (kt > 1) ? tk + 64 : ti + Wmax + 64, is = (kt > 1) ? ti + 64 : 0;
+        const size_t qcap = (size_t)ti * (size_t)((kt > 1) ? tk : Wmax);
+        return sizeof(wg_log_tables) + (size_t)ns * (ks + is) * 8 + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24 +
+               (multi ? qcap * 8 : 0);
+    };
+    const int Nsmp = (int)c->n_samples;
+    if (Wmax > 256) { TI = 16; TK = 256; KT = (Wmax - 1 + TI + TK - 1) / TK; }
+    else { TI = 64; while (TI > 16 && TI * Wmax > WG_PAIR_CAP) TI >>= 1; }
+    bool chosen = false;
+    if (c->force_ns <= 0 && KT == 1) {                       // all samples in LDS at once, largest tile that fits the target
+        for (int ti = TI; ti >= 16 && !chosen; ti >>= 1)
+            if (lds_for(ti, 1, 0, Nsmp, false) <= LDS_TARGET) { TI = ti; NS = Nsmp; chosen = true; }
+    }
+    if (!chosen) {                                           // sample groups with partial sums in LDS
+        if (KT == 1 && TI > 32) TI = 32;
+        NS = std::min(c->force_ns > 0 ? c->force_ns : 16, Nsmp);
+        while (NS > 1 && lds_for(TI, KT, TK, NS, NS < Nsmp) > (KT > 1 ? LDS_MAX : LDS_TARGET)) NS--;
+    }
+    const bool multi = NS < Nsmp;
+    ca.KT = KT; ca.TK = TK; ca.NS = NS;
     ca.KS = (KT > 1) ? TK + 64 : TI + Wmax + 64;
     ca.IS = (KT > 1) ? TI + 64 : 0;
-    int NS = c->force_ns > 0 ? c->force_ns : 16;
-    NS = std::min(NS, (int)c->n_samples);
-    const size_t lds_fixed = sizeof(wg_log_tables) + (size_t)TI * 8 + (size_t)(TI + 1) * 4 + (size_t)TI * 4 + 16;
-    while (NS > 1 && lds_fixed + (size_t)NS * (ca.KS + ca.IS) * 8 > 60 * 1024) NS--;
-    ca.NS = NS;
-    const size_t lds_cost = round_up((int64_t)(lds_fixed + (size_t)NS * (ca.KS + ca.IS) * 8), 16);
+    lds_cost = (size_t)round_up((int64_t)lds_for(TI, KT, TK, NS, multi), 16);
+    const bool fast_terms = P->pseudo_count == 0.0f || P->pseudo_count >= WG_FAST_MIN_PC;
 
     // ---- stages: bound the scored-block buffer and overlap scoring (stream A) with the recurrence (stream B) --
     int n_stages = 1;
@@ -422,10 +449,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         if (stg >= nbuf) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev_dp1[stg - nbuf], 0));   // buffer free again
         HIP_TRY(hipEventRecord(c->ev_cost0[stg], c->sA));
         if (stage_tiles[stg] > 0) {
-            hipError_t e;
-            if (TI == 64) e = launch_cost<64>(v, sv, ca, cbuf, stage_tiles[stg], lds_cost, c->sA);
-            else if (TI == 32) e = launch_cost<32>(v, sv, ca, cbuf, stage_tiles[stg], lds_cost, c->sA);
-            else e = launch_cost<16>(v, sv, ca, cbuf, stage_tiles[stg], lds_cost, c->sA);
+            hipError_t e = fast_terms ? launch_cost_ti<true>(TI, v, sv, ca, cbuf, stage_tiles[stg], lds_cost, c->sA)
+                                      : launch_cost_ti<false>(TI, v, sv, ca, cbuf, stage_tiles[stg], lds_cost, c->sA);
             HIP_TRY(e);
         }
         HIP_TRY(hipEventRecord(c->ev_cost1[stg], c->sA));
@@ -618,7 +643,8 @@ int wgbsseg_debug_sample_terms(wgbsseg_ctx* c, const float* nmeth, const float* 
     HIP_TRY(hipMemcpyAsync(c->dbg_a.p, nmeth, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
     HIP_TRY(hipMemcpyAsync(c->dbg_b.p, ntotal, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
     const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 8192);
-    hipLaunchKernelGGL(k_debug_terms, dim3(blocks), dim3(256), 0, c->sA, c->dbg_a.as<float>(), c->dbg_b.as<float>(), count, pseudo_count, c->dbg_c.as<float>());
+    const int fast = (pseudo_count == 0.0f || pseudo_count >= WG_FAST_MIN_PC) ? 1 : 0;     // the library's own dispatch rule
+    hipLaunchKernelGGL(k_debug_terms, dim3(blocks), dim3(256), 0, c->sA, c->dbg_a.as<float>(), c->dbg_b.as<float>(), count, pseudo_count, c->dbg_c.as<float>(), fast);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->dbg_c.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
