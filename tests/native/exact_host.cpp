@@ -7,6 +7,8 @@
 
 static wg_log_tables make_tab() { wg_log_tables t = WG_LOG_TABLES_INIT; wg_tables_finish(&t); return t; }
 static const wg_log_tables g_tab = make_tab();
+static wg_fast_tables make_fast() { wg_fast_tables f; memcpy(f.f_tab, g_tab.f_tab, sizeof(f.f_tab)); memcpy(f.d_fast, g_tab.d_fast, sizeof(f.d_fast)); return f; }
+static const wg_fast_tables g_fast = make_fast();
 
 template <class F> static void par_for(uint64_t count, int threads, F f)
 {
@@ -76,6 +78,6 @@ void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, 
     float pc2 = pc + pc;
     const bool fast_ok = pc == 0.0f || pc >= WG_FAST_MIN_PC;       // same dispatch rule as the library
     for (int64_t q = 0; q < count; q++)
-        out[q] = fast_ok ? wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_tab) : wg_sample_term_plain(nmeth[q], ntotal[q], pc, pc2, &g_tab);
+        out[q] = fast_ok ? wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab) : wg_sample_term_plain(nmeth[q], ntotal[q], pc, pc2, &g_tab);
 }
 }

@@ -45,10 +45,11 @@ def emu_scan_carries(row, start0, ln):
         run += incl[63]
     return carry
 
-def emu_stage_row(row, carry, start0, ln, A, cnt):
+def emu_stage_row(row, carry, start0, ln, A, cnt, x0=0):
+    cnt0 = cnt; cnt = x0 + cnt0
     """wg_stage_prefix_row: returns dst[0..cnt) (uint2)."""
     n_total = row.shape[0]
-    dst = np.full((cnt, 2), -1, dtype=np.int64)
+    dst = np.full((cnt0, 2), -1, dtype=np.int64)
     abs0 = start0 + A
     run = carry[(abs0 >> 6) - (start0 >> 6)].copy()
     al = abs0 & ~3; hs = abs0 - al
@@ -67,7 +68,7 @@ def emu_stage_row(row, carry, start0, ln, A, cnt):
             e = run + incl[lane] - tot[lane]
             for j in range(4):
                 x = p0 + lane * 4 + j - hs
-                if 0 <= x < cnt: dst[x] = e
+                if x0 <= x < cnt: dst[x - x0] = e
                 e = e + vals[lane, j]
         run = run + incl[63]
     return dst
@@ -76,8 +77,8 @@ def emu_cost_tiles(F, n, S, stage, TI, KT, TK, Fmax, start0=0):
     """k_cost tile decomposition (start-major) for one chunk: yields pairs (k,i) per tile; checks E/S array bounds."""
     s0 = stage * S; s1 = min(s0 + S, n)
     if s0 >= n: return
-    KS = TK + 64 if KT > 1 else TI + Fmax + 64
-    IS = TI + 64 if KT > 1 else 0
+    KS = TK + 1 if KT > 1 else TI + Fmax + 1
+    IS = TI + 1 if KT > 1 else 0
     ntile = (s1 - s0 + TI - 1) // TI * KT
     for local in range(ntile):
         kti, et = divmod(local, KT)
@@ -92,11 +93,12 @@ def emu_cost_tiles(F, n, S, stage, TI, KT, TK, Fmax, start0=0):
                 imin = is_ if imin is None else min(imin, is_); imax = ie if imax is None else max(imax, ie)
                 pairs += [(k, i) for i in range(is_, ie + 1)]
         if not pairs: continue
-        eA = group_start(start0, imin + 1 if KT > 1 else ka)
+        eA = imin + 1 if KT > 1 else ka
+        eG = group_start(start0, eA); assert 0 <= eA - eG <= 63
         Ecnt = imax + 2 - eA
         assert 0 < Ecnt <= KS, (Ecnt, KS)
         if KT > 1:
-            sA = group_start(start0, ka); Scnt = kb - sA
+            sA = ka; Scnt = kb - sA
             assert Scnt <= IS
             for (k, i) in pairs: assert 0 <= i + 1 - eA < Ecnt and 0 <= k - sA < Scnt
         else:
@@ -174,9 +176,10 @@ if __name__ == '__main__':
             A = group_start(start0, k)
             assert 0 <= k - A <= 63
             for cnt in (1, 5, 64, 65, 200, 300):
-                dst = emu_stage_row(row, carry, start0, ln, A, cnt)
+                x0 = k - A
+                dst = emu_stage_row(row, carry, start0, ln, A, cnt, x0)
                 for x in range(cnt):
-                    want = P[min(A + x, ln)]
+                    want = P[min(k + x, ln)]
                     assert (dst[x] == want).all(), (start0, ln, A, cnt, x, dst[x], want)
     print('scan/stage emulation ok')
     for nm in ['tiny', 'n1', 'n2', 'n65', 'max_cpg2', 'max_cpg_binds', 'dense_w_gt_64', 'dense_small_bp', 'equal_loci']:

@@ -136,6 +136,12 @@ struct wg_log_tables {
     wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}: filled by wg_tables_finish()
 };
 #define WG_LOG_TABLES_INIT { WG_LOG2F_TAB, WG_LOG2_TAB, WG_LOG2_TAB2, WG_LOG2_TAB }
+// What the scoring kernel keeps in LDS: the log2f table and the fast-log2 table (1.3 KB).  The exact-log2 tables are
+// only needed by the rare fallback and stay in global/constant memory.
+struct wg_fast_tables {
+    wg_d2 f_tab[16];     // log2f {invc, logc}
+    wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}
+};
 // The fast log2 uses d_tab with ONE entry changed: interval 39 = [0.9921875, 1) gets the centre exactly 1
 // (invc = 1, logc = 0), so that arguments just below 1 need no separate cancellation-free branch.
 #define WG_FAST_CENTRE_ENTRY 39
@@ -310,21 +316,22 @@ WG_HD float wg_sample_term_plain(float nmeth, float ntotal, float pc, float pc2,
 // pc >= WG_FAST_MIN_PC every non-zero sum is >= 2^-100 in magnitude (p >= pc / 2^25), and a zero sum is exact.
 // Callers with 0 < pc < WG_FAST_MIN_PC must use wg_sample_term_plain.
 #define WG_FAST_MIN_PC 0x1p-60f
-WG_HD float wg_sample_term(float nmeth, float ntotal, float pc, float pc2, const wg_log_tables* __restrict__ tb)
+WG_HD float wg_sample_term(float nmeth, float ntotal, float pc, float pc2, const wg_fast_tables* __restrict__ ft,
+                           const wg_log_tables* __restrict__ xt)
 {
     if (ntotal == 0.0f) return 0.0f;                               // :125
     const float p = (nmeth + pc) / (ntotal + pc2);                 // :127
     float ll = 0.0f;
-    if (p > 0.0f) ll += nmeth * wg_log2f(p, tb->f_tab);            // :129-131
+    if (p > 0.0f) ll += nmeth * wg_log2f(p, ft->f_tab);            // :129-131
     if (p < 1.0f) {                                                // :132-134
         const float df = ntotal - nmeth;
         if (df != 0.0f) {
             const double x = 1.0 - (double)p;
-            const double s = (double)ll + (double)df * wg_fast_log2(x, tb->d_fast);
+            const double s = (double)ll + (double)df * wg_fast_log2(x, ft->d_fast);
             const uint32_t tail = (uint32_t)wg_d2u(s) & 0x1fffffffu;
             float res = (float)s;
             if ((uint32_t)(tail - (0x10000000u - WG_GUARD_ULPS)) <= 2u * WG_GUARD_ULPS)
-                res = (float)((double)ll + (double)df * wg_log2(x, tb->d_tab, tb->d_tab2));
+                res = (float)((double)ll + (double)df * wg_log2(x, xt->d_tab, xt->d_tab2));
             ll = res;
         }
     }

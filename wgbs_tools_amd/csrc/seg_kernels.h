@@ -27,19 +27,22 @@
 #define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)
 #define WG_TRACE_WIN    65536       // back-pointers staged in LDS by k_trace (128 KiB)
 
-// Copy the log tables into LDS (all threads of the workgroup), applying wg_tables_finish() on the fly.
-// The caller must __syncthreads() before using them.
-__device__ __forceinline__ void wg_tables_to_lds(wg_log_tables* tb, int tid, int nthreads)
+// Exact-restatement tables: global (constant) memory, read only by the rare guard-band fallback and by the plain kernel.
+__device__ const wg_log_tables g_wg_tables = WG_LOG_TABLES_INIT;
+
+// Fill the LDS-resident fast tables (all threads of the workgroup).  The caller must __syncthreads() before use.
+__device__ __forceinline__ void wg_fast_tables_to_lds(wg_fast_tables* ft, int tid, int nthreads)
 {
-    const wg_log_tables init = WG_LOG_TABLES_INIT;               // materialised from constant data
-    const double* src = reinterpret_cast<const double*>(&init);
-    double* d = reinterpret_cast<double*>(tb);
-    const int fix = (int)(offsetof(wg_log_tables, d_fast) / 8) + 2 * WG_FAST_CENTRE_ENTRY;
-    for (int x = tid; x < (int)(sizeof(wg_log_tables) / 8); x += nthreads) {
-        double v = src[x];
-        if (x == fix) v = 1.0;
-        if (x == fix + 1) v = 0.0;
-        d[x] = v;
+    const double* f = reinterpret_cast<const double*>(g_wg_tables.f_tab);
+    const double* d = reinterpret_cast<const double*>(g_wg_tables.d_tab);
+    double* of = reinterpret_cast<double*>(ft->f_tab);
+    double* od = reinterpret_cast<double*>(ft->d_fast);
+    for (int x = tid; x < 32; x += nthreads) of[x] = f[x];
+    for (int x = tid; x < 128; x += nthreads) {
+        double v = d[x];
+        if (x == 2 * WG_FAST_CENTRE_ENTRY) v = 1.0;              // wg_tables_finish(): interval just below 1 centred on 1
+        if (x == 2 * WG_FAST_CENTRE_ENTRY + 1) v = 0.0;
+        od[x] = v;
     }
 }
 
@@ -302,13 +305,14 @@ struct CostArgs {
     int32_t pad;
 };
 
-// Stage `cnt` exclusive prefixes P[A+x], x = 0..cnt-1, of sample row `row` into dst (one wavefront).
+// Stage the exclusive prefixes P[A+x], x = x0 .. x0+cnt-1, of sample row `row` into dst[0..cnt) (one wavefront).
 // A is chunk-relative; start0+A is either the chunk start or a multiple of 64 (wg_group_start), so a carry of
-// k_scan seeds the scan.
+// k_scan seeds the scan; the up to 63 sites between A and A+x0 are summed but not stored.
 __device__ __forceinline__ void wg_stage_prefix_row(uint2* __restrict__ dst, const uint8_t* __restrict__ row,
                                                     const uint2* __restrict__ carry, const ChunkDesc& cd,
-                                                    int64_t n_total, int A, int cnt, int lane)
+                                                    int64_t n_total, int A, int x0, int cnt0, int lane)
 {
+    const int cnt = x0 + cnt0;
     const int64_t abs0 = cd.start0 + A;
     const uint2 c0 = carry[(abs0 >> 6) - (cd.start0 >> 6)];
     uint32_t run_m = c0.x, run_t = c0.y;
@@ -346,7 +350,7 @@ __device__ __forceinline__ void wg_stage_prefix_row(uint2* __restrict__ dst, con
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int x = sidx + j - hs;
-            if (x >= 0 && x < cnt) dst[x] = make_uint2(em, et);
+            if (x >= x0 && x < cnt) dst[x - x0] = make_uint2(em, et);
             em += m[j]; et += t[j];
         }
         const uint32_t wt = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -366,8 +370,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                                                    int64_t n_tiles_padded)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    wg_log_tables* tb = reinterpret_cast<wg_log_tables*>(smem);
-    uint2* Et = reinterpret_cast<uint2*>(smem + sizeof(wg_log_tables));          // [NS][KS]  P[i+1] of the ends
+    wg_fast_tables* tb = reinterpret_cast<wg_fast_tables*>(smem);
+    uint2* Et = reinterpret_cast<uint2*>(smem + sizeof(wg_fast_tables));         // [NS][KS]  P[i+1] of the ends
     uint2* St = Et + (size_t)A.NS * A.KS;                                        // [NS][IS]  P[k] of the starts (KT > 1)
     int64_t* radj = reinterpret_cast<int64_t*>(St + (size_t)A.NS * A.IS);        // [TI]
     int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int et_hi = (A.KT > 1) ? et_lo + A.TK : (1 << 30);
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
 
-    wg_tables_to_lds(tb, tid, WG_BLOCK);
+    wg_fast_tables_to_lds(tb, tid, WG_BLOCK);
     if (wv == 0) {
         const int k = ka + lane;
         const bool valid = lane < nk;
@@ -427,15 +431,16 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int Q = offs[nk];
     if (Q == 0) return;
     const int imin = misc[0], imax = misc[1];
-    // E array: P[x] for x = eA .. imax+1 (ends use P[i+1]); with KT == 1 the starts' P[k], k >= ka, live there too
-    // (imin >= ka, so every start of the tile is at or after eA only if eA <= ka: take the lower of the two).
-    const int eA = wg_group_start(cd, (A.KT > 1) ? imin + 1 : ka);
+    // E array: P[x] for x = eA .. imax+1 (ends use P[i+1]); with KT == 1 the starts' P[k], k >= ka = eA, live there too.
+    const int eA = (A.KT > 1) ? imin + 1 : ka;
+    const int eG = wg_group_start(cd, eA);               // carry position the scan of the row starts from
     const int Ecnt = imax + 2 - eA;
     int sA;                                              // S entries: index k - sA
     const uint2* Sbase;
     int Sstride;
-    if (A.KT > 1) { sA = wg_group_start(cd, ka); Sbase = St; Sstride = A.IS; }
-    else          { sA = eA;                     Sbase = Et; Sstride = A.KS; }
+    if (A.KT > 1) { sA = ka; Sbase = St; Sstride = A.IS; }
+    else          { sA = eA; Sbase = Et; Sstride = A.KS; }
+    const int sG = wg_group_start(cd, sA);
     const int soff = ka - sA;                            // P[k] of start kl at S[soff + kl]
     const int Scnt = kb - sA;
 
@@ -452,8 +457,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             const int s = g0 + rr;
             const uint8_t* row = J.betas + (int64_t)s * J.pitch;
             const uint2* carry = J.carry + cd.carry_off + (int64_t)s * cd.nG;
-            wg_stage_prefix_row(Et + (size_t)rr * A.KS, row, carry, cd, J.n_total, eA, Ecnt, lane);
-            if (A.KT > 1) wg_stage_prefix_row(St + (size_t)rr * A.IS, row, carry, cd, J.n_total, sA, Scnt, lane);
+            wg_stage_prefix_row(Et + (size_t)rr * A.KS, row, carry, cd, J.n_total, eG, eA - eG, Ecnt, lane);
+            if (A.KT > 1) wg_stage_prefix_row(St + (size_t)rr * A.IS, row, carry, cd, J.n_total, sG, sA - sG, Scnt, lane);
         }
         __syncthreads();
         for (int q = tid; q < Q; q += WG_BLOCK) {
@@ -468,7 +473,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 const uint2 pk = Sp[(size_t)sl * Sstride];
                 const float nm = (float)(pi.x - pk.x);
                 const float nt = (float)(pi.y - pk.y);
-                const float ll = FAST ? wg_sample_term(nm, nt, pc, pc2, tb) : wg_sample_term_plain(nm, nt, pc, pc2, tb);
+                const float ll = FAST ? wg_sample_term(nm, nt, pc, pc2, tb, &g_wg_tables) : wg_sample_term_plain(nm, nt, pc, pc2, &g_wg_tables);
                 acc += (double)ll;                                               // segmentor.cpp:135
             }
             if (lastg) cb[radj[lo] + i] = (acc != 0.0) ? acc : 0.0;              // segmentor.cpp:106,137
@@ -722,23 +727,23 @@ __global__ __launch_bounds__(WG_BLOCK) void k_gather_borders(JobView J, const in
 // ------------------------------------------------------------------------------------------------------------
 __global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, float pc, float* out, int fast)
 {
-    __shared__ wg_log_tables tb;
-    wg_tables_to_lds(&tb, threadIdx.x, blockDim.x);
+    __shared__ wg_fast_tables tb;
+    wg_fast_tables_to_lds(&tb, threadIdx.x, blockDim.x);
     __syncthreads();
     const float pc2 = pc + pc;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x)
-        out[q] = fast ? wg_sample_term(nm[q], nt[q], pc, pc2, &tb) : wg_sample_term_plain(nm[q], nt[q], pc, pc2, &tb);
+        out[q] = fast ? wg_sample_term(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables) : wg_sample_term_plain(nm[q], nt[q], pc, pc2, &g_wg_tables);
 }
 
 __global__ void k_debug_log2(uint32_t first, int64_t count, uint32_t* out_f, uint64_t* out_d, uint64_t* out_fast)
 {
-    __shared__ wg_log_tables tb;
-    wg_tables_to_lds(&tb, threadIdx.x, blockDim.x);
+    __shared__ wg_fast_tables tb;
+    wg_fast_tables_to_lds(&tb, threadIdx.x, blockDim.x);
     __syncthreads();
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x) {
         const float p = wg_u2f(first + (uint32_t)q);
         if (out_f) out_f[q] = wg_f2u(wg_log2f(p, tb.f_tab));
-        if (out_d) out_d[q] = wg_d2u(wg_log2(1.0 - (double)p, tb.d_tab, tb.d_tab2));
+        if (out_d) out_d[q] = wg_d2u(wg_log2(1.0 - (double)p, g_wg_tables.d_tab, g_wg_tables.d_tab2));
         if (out_fast) out_fast[q] = wg_d2u(wg_fast_log2(1.0 - (double)p, tb.d_fast));
     }
 }

@@ -89,6 +89,7 @@ struct wgbsseg_ctx {
     long long cost_budget_bytes = 0;
     int force_stages = 0;
     int force_ns = 0;
+    int force_ti = 0;
     bool accumulate = false;   // add to `tim` instead of resetting it (region-level calls span several batches)
 };
 
@@ -133,6 +134,8 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     c->force_stages = fs ? atoi(fs) : 0;
     const char* fn = getenv("WGBSSEG_NS");
     c->force_ns = fn ? atoi(fn) : 0;
+    const char* ft = getenv("WGBSSEG_TI");
+    c->force_ti = ft ? atoi(ft) : 0;
     *out = c;
     return WGBSSEG_OK;
 }
@@ -355,38 +358,49 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
 
     // ---- tiling of the scoring kernel ----------------------------------------------------------------------
     // A tile = TI start sites (x one of KT end-site tiles of TK sites when windows are wide), at most WG_PAIR_CAP
-    // blocks.  LDS per workgroup: log tables + NS sample rows of prefixes + small per-tile arrays (+ partial sums
-    // when the samples need several groups).  Aim: <= ~50 KB so that three workgroups share a CU.
-    const size_t LDS_TARGET = 50 * 1024, LDS_MAX = 64 * 1024;
+    // blocks.  LDS per workgroup: fast log tables + NS sample rows of prefixes + small per-tile arrays (+ partial
+    // sums when the samples need several groups).  The kernel is a long dependent chain per evaluation, so resident
+    // wavefronts matter: pick the shape that maximises (workgroups per CU) x (lane occupancy of the block rounds).
     int TI = 64, KT = 1, TK = 0, NS = 0;
-    size_t lds_cost = 0;
     CostArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.pc = P->pseudo_count; ca.pc2 = P->pseudo_count + P->pseudo_count;
-    auto lds_for = [&](int ti, int kt, int tk, int ns, bool multi) -> size_t {
-        const int ks = (kt > 1) ? tk + 64 : ti + Wmax + 64, is = (kt > 1) ? ti + 64 : 0;
-        const size_t qcap = (size_t)ti * (size_t)((kt > 1) ? tk : Wmax);
-        return sizeof(wg_log_tables) + (size_t)ns * (ks + is) * 8 + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24 +
-               (multi ? qcap * 8 : 0);
-    };
     const int Nsmp = (int)c->n_samples;
-    if (Wmax > 256) { TI = 16; TK = 256; KT = (Wmax - 1 + TI + TK - 1) / TK; }
-    else { TI = 64; while (TI > 16 && TI * Wmax > WG_PAIR_CAP) TI >>= 1; }
-    bool chosen = false;
-    if (c->force_ns <= 0 && KT == 1) {                       // all samples in LDS at once, largest tile that fits the target
-        for (int ti = TI; ti >= 16 && !chosen; ti >>= 1)
-            if (lds_for(ti, 1, 0, Nsmp, false) <= LDS_TARGET) { TI = ti; NS = Nsmp; chosen = true; }
-    }
-    if (!chosen) {                                           // sample groups with partial sums in LDS
-        if (KT == 1 && TI > 32) TI = 32;
+    const double Favg = (double)total_pairs / (double)std::max<int64_t>(1, J);
+    auto lds_for = [&](int ti, int kt, int tk, int ns) -> size_t {
+        const int ks = (kt > 1) ? tk + 1 : ti + Wmax + 1, is = (kt > 1) ? ti + 1 : 0;
+        const size_t qcap = (size_t)ti * (size_t)((kt > 1) ? tk : Wmax);
+        return sizeof(wg_fast_tables) + (size_t)ns * (ks + is) * 8 + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24 +
+               (ns < Nsmp ? qcap * 8 : 0);
+    };
+    if (Wmax > 256) {
+        TI = 16; TK = 256; KT = (Wmax - 1 + TI + TK - 1) / TK;
         NS = std::min(c->force_ns > 0 ? c->force_ns : 16, Nsmp);
-        while (NS > 1 && lds_for(TI, KT, TK, NS, NS < Nsmp) > (KT > 1 ? LDS_MAX : LDS_TARGET)) NS--;
+        while (NS > 1 && lds_for(TI, KT, TK, NS) > 64 * 1024) NS--;
+    } else {
+        double best = -1;
+        for (int ti = 64; ti >= 16; ti >>= 1) {
+            if (ti * Wmax > WG_PAIR_CAP) continue;
+            if (c->force_ti > 0 && ti != c->force_ti) continue;
+            const int ns_opts[5] = {Nsmp, 32, 16, 8, 4};
+            for (int ns : ns_opts) {
+                if (ns > Nsmp) continue;
+                if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
+                const size_t l = lds_for(ti, 1, 0, ns);
+                if (l > 64 * 1024) continue;
+                const int wgs = (int)std::min<size_t>(6, (160 * 1024) / l);          // 6 waves/SIMD is the register limit
+                const double q = ti * Favg, eff = q / (256.0 * std::ceil(q / 256.0));
+                const double groups = std::ceil((double)Nsmp / ns);
+                const double score = wgs * eff / (1.0 + 0.02 * (groups - 1)) * (1.0 + 0.01 * (ti / 16));   // mild bias to big tiles
+                if (score > best) { best = score; TI = ti; NS = ns; }
+            }
+        }
+        if (best < 0) { TI = 16; NS = 1; }
     }
-    const bool multi = NS < Nsmp;
     ca.KT = KT; ca.TK = TK; ca.NS = NS;
-    ca.KS = (KT > 1) ? TK + 64 : TI + Wmax + 64;
-    ca.IS = (KT > 1) ? TI + 64 : 0;
-    lds_cost = (size_t)round_up((int64_t)lds_for(TI, KT, TK, NS, multi), 16);
+    ca.KS = (KT > 1) ? TK + 1 : TI + Wmax + 1;
+    ca.IS = (KT > 1) ? TI + 1 : 0;
+    const size_t lds_cost = (size_t)round_up((int64_t)lds_for(TI, KT, TK, NS), 16);
     const bool fast_terms = P->pseudo_count == 0.0f || P->pseudo_count >= WG_FAST_MIN_PC;
 
     // ---- stages: bound the scored-block buffer and overlap scoring (stream A) with the recurrence (stream B) --
