@@ -54,7 +54,8 @@ uint64_t sum_ulp_gap(const float* nmeth, const float* ntotal, int64_t count, flo
         if (t == 0.0f) continue;
         const float p = (m + pc) / (t + pc2);
         float ll = 0.0f;
-        if (p > 0.0f) ll += m * wg_log2f(p, g_tab.f_tab);
+        if (!(p > 0.0f)) continue;                                 // the fast form returns +0 here without any log
+        ll += m * wg_log2f_normal(p, g_tab.f_tab);
         const float df = t - m;
         if (!(p < 1.0f) || df == 0.0f) continue;
         const double xx = 1.0 - (double)p;

@@ -144,6 +144,7 @@ struct wg_fast_tables {
 };
 // The fast log2 uses d_tab with ONE entry changed: interval 39 = [0.9921875, 1) gets the centre exactly 1
 // (invc = 1, logc = 0), so that arguments just below 1 need no separate cancellation-free branch.
+// (Interval 40 = [1, 1.015625) cannot be treated the same way: it also serves z = 2^-k x for x in [0.5, 0.5078) etc.)
 #define WG_FAST_CENTRE_ENTRY 39
 
 WG_HD uint32_t wg_f2u(float f)   { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -186,8 +187,8 @@ WG_HD float wg_log2f_nofma(float x, const wg_d2* __restrict__ ftab)
 // 7 fp64 operations instead of 12: this is the form the kernels use.
 WG_HD float wg_log2f(float x, const wg_d2* __restrict__ ftab)
 {
+    // x == 1 needs no special case here: its table entry is {1, 0}, r = 0, and the polynomial returns +0 exactly.
     uint32_t ix = wg_f2u(x);
-    if (ix == 0x3f800000u) return 0.0f;
     if (ix < 0x00800000u) return wg_log2f_nofma(x, ftab);       // subnormal p: never on real data, kept exact
     uint32_t tmp = ix - 0x3f330000u;
     uint32_t i = (tmp >> 19) & 15u;
@@ -204,6 +205,24 @@ WG_HD float wg_log2f(float x, const wg_d2* __restrict__ ftab)
     double p = WG_FMA(WG_LOG2F_A3, r, y0);
     y = WG_FMA(y, r2, p);
     return (float)y;
+}
+
+// Same, for callers that guarantee a NORMAL x (the scoring kernel in fast mode: p >= 2^-85, see WG_FAST_MIN_PC).
+WG_HD float wg_log2f_normal(float x, const wg_d2* __restrict__ ftab)
+{
+    const uint32_t ix = wg_f2u(x);
+    const uint32_t tmp = ix - 0x3f330000u;
+    const uint32_t i = (tmp >> 19) & 15u;
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    const int32_t k = (int32_t)tmp >> 23;
+    const double invc = ftab[i].a, logc = ftab[i].b;
+    const double r = WG_FMA((double)wg_u2f(iz), invc, -1.0);
+    const double y0 = logc + (double)k;
+    const double r2 = r * r;
+    double y = WG_FMA(WG_LOG2F_A1, r, WG_LOG2F_A2);
+    y = WG_FMA(WG_LOG2F_A0, r2, y);
+    const double p = WG_FMA(WG_LOG2F_A3, r, y0);
+    return (float)WG_FMA(y, r2, p);
 }
 
 // glibc 2.35 __log2 (sysdeps/ieee754/dbl-64/e_log2.c, !__FP_FAST_FMA build), positive normal inputs.
@@ -258,12 +277,12 @@ WG_HD void wg_tables_finish(wg_log_tables* tb)
     tb->d_fast[WG_FAST_CENTRE_ENTRY].b = 0.0;
 }
 
-// A cheap log2 for the SAME arguments (x = 1.0 - (double)p, p a float in (0,1), so x in [2^-24, 1)): glibc's table
+// A cheap log2 for x = 1.0 - (double)p STRICTLY below 1 (p a float in [2^-53, 1), so x in [2^-24, 1 - 2^-53]): glibc's table
 // and main polynomial, evaluated by plain Horner with fused multiply-adds, without the hi/lo compensation, without
 // tab2, and without glibc's separate near-1 branch — instead the table interval just below 1 is centred exactly on 1
 // (WG_FAST_CENTRE_ENTRY), which keeps the relative error flat up to x -> 1.
 // It is NOT bit-identical to libm, but its distance from libm's result is bounded: tests/test_exact_log2_cpu.py
-// measures |wg_fast_log2 - log2| <= WG_FAST_LOG2_MAX_ULP over the WHOLE domain (all 1,056,964,607 floats p),
+// measures |wg_fast_log2 - log2| <= WG_FAST_LOG2_MAX_ULP over that WHOLE domain (all 612,368,383 floats p),
 // exhaustively, for the host build, and the gfx950 build is compared bit for bit with the host build (IEEE fma is
 // deterministic).  9 fp64 operations instead of 30-34, no divergent branch.
 #define WG_LOG2_INVLN2 0x1.71547652b82fep+0
@@ -272,7 +291,6 @@ WG_HD void wg_tables_finish(wg_log_tables* tb)
 WG_HD double wg_fast_log2(double x, const wg_d2* __restrict__ dfast)
 {
     const uint64_t ix = wg_d2u(x);
-    if (ix == 0x3ff0000000000000ull) return 0.0;
     const uint64_t tmp = ix - 0x3fe6000000000000ull;
     const uint32_t hi = (uint32_t)(tmp >> 32);
     const uint32_t i = (hi >> 14) & 63u;
@@ -312,20 +330,22 @@ WG_HD float wg_sample_term_plain(float nmeth, float ntotal, float pc, float pc2,
 // lies within 6 ulp of a float rounding midpoint (low 29 mantissa bits == 2^28); we use a 16-ulp guard band, and in
 // that band (probability 2^-24 per evaluation) the exact restatement decides.  When ntotal == nmeth the reference adds -0.0 and ll is unchanged.
 #define WG_GUARD_ULPS 16u
-// The guard-band test needs no exponent check when the sum cannot be a subnormal float: with pc == 0 or
-// pc >= WG_FAST_MIN_PC every non-zero sum is >= 2^-100 in magnitude (p >= pc / 2^25), and a zero sum is exact.
-// Callers with 0 < pc < WG_FAST_MIN_PC must use wg_sample_term_plain.
-#define WG_FAST_MIN_PC 0x1p-60f
+// Preconditions of the fast form (the library dispatches on them; otherwise wg_sample_term_plain is used):
+// pc == 0 or pc >= WG_FAST_MIN_PC.  Then (a) p == 0 exactly or p >= 2^-45: p is a normal float and, when p > 0,
+// x = 1 - p < 1 strictly (wg_fast_log2's domain); (b) every non-zero sum is >= 2^-60 in magnitude, so the float
+// result is never subnormal and the guard-band test needs no exponent check.  For p == 0 (pc == 0 and nmeth == 0)
+// the reference computes 0 + (ntotal-nmeth)*log2(1.0) = +0: ll stays +0.
+#define WG_FAST_MIN_PC 0x1p-20f
 WG_HD float wg_sample_term(float nmeth, float ntotal, float pc, float pc2, const wg_fast_tables* __restrict__ ft,
                            const wg_log_tables* __restrict__ xt)
 {
     if (ntotal == 0.0f) return 0.0f;                               // :125
     const float p = (nmeth + pc) / (ntotal + pc2);                 // :127
     float ll = 0.0f;
-    if (p > 0.0f) ll += nmeth * wg_log2f(p, ft->f_tab);            // :129-131
-    if (p < 1.0f) {                                                // :132-134
+    if (p > 0.0f) {
+        ll += nmeth * wg_log2f_normal(p, ft->f_tab);               // :129-131
         const float df = ntotal - nmeth;
-        if (df != 0.0f) {
+        if (p < 1.0f && df != 0.0f) {                              // :132-134 (df == 0 adds -0.0: ll unchanged)
             const double x = 1.0 - (double)p;
             const double s = (double)ll + (double)df * wg_fast_log2(x, ft->d_fast);
             const uint32_t tail = (uint32_t)wg_d2u(s) & 0x1fffffffu;

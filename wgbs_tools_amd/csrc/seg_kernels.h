@@ -556,6 +556,7 @@ __global__ __launch_bounds__(128) void k_dp(JobView J, StageView SV, const doubl
     const int nb = (s1 - s0 + 63) >> 6;
     const bool wide = A.wide != 0;
 
+    if (!loader) __builtin_amdgcn_s_setprio(3);        // the recurrence is one dependent chain: let it win issue arbitration
     double best = NEG_INF;                              // pending step of this lane (wave 0)
     int32_t arg = 0;
     double Mk = 0.0;                                    // M[k] of the step about to run; M[0] = 0 (segmentor.cpp:97)

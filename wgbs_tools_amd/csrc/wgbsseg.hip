@@ -90,6 +90,7 @@ struct wgbsseg_ctx {
     int force_stages = 0;
     int force_ns = 0;
     int force_ti = 0;
+    int min_stages = 6;
     bool accumulate = false;   // add to `tim` instead of resetting it (region-level calls span several batches)
 };
 
@@ -126,7 +127,12 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     if (!c) { set_err(err, errlen, "out of host memory"); return WGBSSEG_E_NOMEM; }
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->sA, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->sB, hipStreamNonBlocking));
+    {   // the recurrence stream outranks the scoring stream: its 483 latency-bound workgroups should never queue behind
+        // the hundreds of thousands of throughput-bound scoring tiles
+        int lo_p = 0, hi_p = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+        HIP_TRY(hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, hi_p));
+    }
     for (auto& v : c->ev) HIP_TRY(hipEventCreate(&v));
     const char* b = getenv("WGBSSEG_COST_BUDGET_MB");
     c->cost_budget_bytes = (b && atoll(b) > 0 ? atoll(b) : 6144LL) << 20;
@@ -136,6 +142,8 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     c->force_ns = fn ? atoi(fn) : 0;
     const char* ft = getenv("WGBSSEG_TI");
     c->force_ti = ft ? atoi(ft) : 0;
+    const char* ms = getenv("WGBSSEG_MIN_STAGES");
+    if (ms && atoi(ms) > 0) c->min_stages = atoi(ms);
     *out = c;
     return WGBSSEG_OK;
 }
@@ -391,7 +399,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
                 const int wgs = (int)std::min<size_t>(6, (160 * 1024) / l);          // 6 waves/SIMD is the register limit
                 const double q = ti * Favg, eff = q / (256.0 * std::ceil(q / 256.0));
                 const double groups = std::ceil((double)Nsmp / ns);
-                const double score = wgs * eff / (1.0 + 0.02 * (groups - 1)) * (1.0 + 0.01 * (ti / 16));   // mild bias to big tiles
+                const double score = wgs * eff / (1.0 + 0.02 * (groups - 1)) * (1.0 + 0.04 * (ti / 16));   // bias to big tiles (less staging, friendlier to k_dp)
                 if (score > best) { best = score; TI = ti; NS = ns; }
             }
         }
@@ -408,7 +416,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     {
         const long long bytes = total_pairs * 8;
         n_stages = (int)std::max<long long>(1, (bytes + c->cost_budget_bytes - 1) / c->cost_budget_bytes);
-        if (job.max_len >= 8192) n_stages = std::max(n_stages, 4);
+        if (job.max_len >= 8192) n_stages = std::max(n_stages, c->min_stages);
         if (c->force_stages > 0) n_stages = c->force_stages;
         n_stages = std::min<int>(n_stages, std::max(1, (job.max_len + 63) / 64));
     }
