@@ -501,10 +501,15 @@ struct DpMeta {               // per LDS slot
     uint32_t w[64];           // forward window F_k of each step of the batch
     uint32_t rel[64];         // row offset of each step inside the stage's cost rows of this chunk
     uint32_t first;           // rel of the batch's first step
-    uint32_t staged;          // 1: rows [first, first+span) are in the slot
-    uint32_t pad[2];
+    uint32_t staged;          // 1: rows [first, first+span) are in the slot, contiguous (as in HBM)
+    uint32_t simple;          // 1: full batch, every F_k <= 64: the slot holds the ARRANGED form [64 steps][64 lanes]
+    uint32_t pad;
 };
 
+// Loader wave: metadata of the 64 steps starting at `base`, and their scored-block rows into the LDS slot.
+// Arranged form (full batch, all windows <= 64): slot[s*64 + l] = cost(k, k+j), k = base+s, j = (l - s) mod 64, for
+// j < F_k, and -inf for the lanes that hold no candidate of step s — so the DP wave needs no predicate at all:
+// M[k] + (-inf) can never beat a pending maximum.
 __device__ __forceinline__ void wg_dp_load_batch(const double* __restrict__ cb, const uint16_t* __restrict__ Wp,
                                                  const uint32_t* __restrict__ Cp, uint32_t cum0, int base, int s1,
                                                  int slot_cap, double* __restrict__ slot, DpMeta* __restrict__ meta, int lane)
@@ -518,14 +523,41 @@ __device__ __forceinline__ void wg_dp_load_batch(const double* __restrict__ cb, 
     const uint32_t last_rel = (uint32_t)__builtin_amdgcn_readlane((int)rel, nst - 1);
     const uint32_t last_w = (uint32_t)__builtin_amdgcn_readlane((int)w, nst - 1);
     const uint32_t span = last_rel + last_w - first;
-    const bool staged = span <= (uint32_t)slot_cap;
+    const bool simple = nst == 64 && slot_cap >= 4096 && wg_wave_max_u32(w) <= 64u;
+    const bool staged = !simple && span <= (uint32_t)slot_cap;
     meta->w[lane] = w;
     meta->rel[lane] = rel;
-    if (lane == 0) { meta->first = first; meta->staged = staged ? 1u : 0u; }
-    if (staged) {
+    if (lane == 0) { meta->first = first; meta->staged = staged ? 1u : 0u; meta->simple = simple ? 1u : 0u; }
+    if (simple) {
+        const double NEG_INF = -__builtin_inf();
+#pragma unroll 8
+        for (int sidx = 0; sidx < 64; sidx++) {
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w, sidx);
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rel, sidx);
+            const uint32_t j = (uint32_t)(lane - sidx) & 63u;
+            double v = NEG_INF;
+            if (j < f) v = cb[(int64_t)r + j];
+            slot[sidx * 64 + lane] = v;
+        }
+    } else if (staged) {
         const double* src = cb + first;
         for (uint32_t x = (uint32_t)lane; x < span; x += 64) slot[x] = src[x];
     }
+}
+
+// One step of the fast path: fold M[k] into the 64 pending steps, read M[k+1] off lane `stp`, free that lane.
+__device__ __forceinline__ void wg_dp_fast_step(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double cv,
+                                                const int k, const int stp, const int lane)
+{
+    const double cand = Mk + cv;
+    const bool upd = cand > best;                      // strict: the first maximum wins (segmentor.cpp:148)
+    best = upd ? cand : best;
+    arg = upd ? k : arg;
+    Mk = wg_readlane_f64(best, stp);                   // M[k+1]
+    const int ak = __builtin_amdgcn_readlane(arg, stp);
+    const bool mine = lane == stp;                     // this lane moves on to step k+64
+    tbk = mine ? (uint32_t)(k + 1 - ak) : tbk;
+    best = mine ? -__builtin_inf() : best;
 }
 
 // state saved between stages, per chunk: [0] M[k] of the next step, [1..64] best, then 64 args (as doubles' bits),
@@ -586,61 +618,65 @@ __global__ __launch_bounds__(128) void k_dp(JobView J, StageView SV, const doubl
         } else {
             const DpMeta* meta = metas + (b & 1);
             const double* slot = slots + (size_t)(b & 1) * A.slot_cap;
-            const uint32_t w_l = meta->w[lane];
-            const uint32_t rel_l = meta->rel[lane];
-            const uint32_t first = meta->first;
-            const bool staged = meta->staged != 0;
-            const int il = base + lane;
-            const bool inb = il < s1;
             uint32_t tbk = 0;
-            const int nst = (s1 - base < 64) ? s1 - base : 64;
-            for (int g = 0; g < nst; g += 8) {
-                double cv[8];
+            if (meta->simple && !wide) {
+                // ---- fast path: 64 steps out of the arranged slot, 8 at a time, next 8 rows already in flight ----
+                const double* my = slot + lane;
+                double cur[8], nxt[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {                 // fetch the rows of 8 steps up front
-                    const int stp = g + u;                    // == k & 63 (batches start on multiples of 64)
-                    cv[u] = 0.0;
-                    if (stp < nst) {
-                        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w_l, stp);
-                        const uint32_t rel = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, stp);
-                        const uint32_t j = (uint32_t)(lane - stp) & 63u;
-                        if (j < f) cv[u] = staged ? slot[rel - first + j] : cb[(int64_t)rel + j];
+                for (int u = 0; u < 8; u++) cur[u] = my[u * 64];
+                for (int g = 0; g < 64; g += 8) {
+                    if (g + 8 < 64) {
+#pragma unroll
+                        for (int u = 0; u < 8; u++) nxt[u] = my[(g + 8 + u) * 64];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) wg_dp_fast_step(best, arg, tbk, Mk, cur[u], base + g + u, g + u, lane);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) cur[u] = nxt[u];
+                }
+                J.back16[cd.site_off + base + lane] = (uint16_t)tbk;
+            } else {
+                const uint32_t w_l = meta->w[lane];
+                const uint32_t rel_l = meta->rel[lane];
+                const uint32_t first = meta->first;
+                const bool staged = meta->staged != 0;
+                const bool arranged = meta->simple != 0;
+                const int il = base + lane;
+                const bool inb = il < s1;
+                const int nst = (s1 - base < 64) ? s1 - base : 64;
+                for (int stp = 0; stp < nst; stp++) {
+                    const int k = base + stp;
+                    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w_l, stp);
+                    const uint32_t rel = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, stp);
+                    const uint32_t j = (uint32_t)(lane - stp) & 63u;
+                    double cv = 0.0;
+                    if (j < f) cv = arranged ? slot[stp * 64 + lane] : (staged ? slot[rel - first + j] : cb[(int64_t)rel + j]);
+                    const double cand = Mk + cv;
+                    const bool upd = (j < f) && (cand > best);            // strict: first maximum wins (segmentor.cpp:148)
+                    best = upd ? cand : best;
+                    arg = upd ? k : arg;
+                    if (f > 64u) {                                        // blocks reaching beyond the 64 pending steps
+                        for (uint32_t jj = 64u + (uint32_t)lane; jj < f; jj += 64) {
+                            const int slotx = (k + (int)jj) & rmask;
+                            const double cd2 = Mk + cb[(int64_t)rel + jj];
+                            if (cd2 > pendB[slotx]) { pendB[slotx] = cd2; pendA[slotx] = k; }
+                        }
+                    }
+                    // step i = k has seen its last candidate: M[k+1]
+                    Mk = wg_readlane_f64(best, stp);
+                    if (lane == stp) {
+                        tbk = (uint32_t)(k + 1 - arg);
+                        best = NEG_INF;
+                        if (wide) {                                       // hand over to step k+64: pick up parked maxima
+                            const int slotx = (k + 64) & rmask;
+                            best = pendB[slotx]; arg = pendA[slotx];
+                            pendB[slotx] = NEG_INF;
+                        }
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int stp = g + u;
-                    if (stp < nst) {
-                        const int k = base + stp;
-                        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w_l, stp);
-                        const uint32_t j = (uint32_t)(lane - stp) & 63u;
-                        const double cand = Mk + cv[u];
-                        const bool upd = (j < f) && (cand > best);            // strict: first maximum wins (segmentor.cpp:148)
-                        best = upd ? cand : best;
-                        arg = upd ? k : arg;
-                        if (f > 64u) {                                        // blocks reaching beyond the 64 pending steps
-                            const uint32_t rel = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, stp);
-                            for (uint32_t jj = 64u + (uint32_t)lane; jj < f; jj += 64) {
-                                const int slotx = (k + (int)jj) & rmask;
-                                const double cd2 = Mk + cb[(int64_t)rel + jj];
-                                if (cd2 > pendB[slotx]) { pendB[slotx] = cd2; pendA[slotx] = k; }
-                            }
-                        }
-                        // step i = k has seen its last candidate: M[k+1]
-                        Mk = wg_readlane_f64(best, stp);
-                        if (lane == stp) {
-                            tbk = (uint32_t)(k + 1 - arg);
-                            best = NEG_INF;
-                            if (wide) {                                       // hand over to step k+64: pick up parked maxima
-                                const int slotx = (k + 64) & rmask;
-                                best = pendB[slotx]; arg = pendA[slotx];
-                                pendB[slotx] = NEG_INF;
-                            }
-                        }
-                    }
-                }
+                if (inb) J.back16[cd.site_off + il] = (uint16_t)tbk;
             }
-            if (inb) J.back16[cd.site_off + il] = (uint16_t)tbk;
         }
         __syncthreads();
     }

@@ -458,9 +458,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbase = c->plan_tbase.as<int64_t>();
     sv.S = S;
     // LDS of k_dp: pend ring (wide windows only) + two staged batches of scored-block rows (64 steps x up to 64 ends) + metadata
-    int slot_cap = 64 * std::min(Wmax, 64);
-    if (wide) slot_cap = 2048;                               // rows beyond the cap are read straight from HBM
-    slot_cap = std::min(slot_cap, 4096);
+    int slot_cap = 4096;                                     // 64 steps x 64 lanes: the arranged form of one batch
+    if (wide) slot_cap = 2048;                               // wide windows: contiguous staging only; longer rows come from HBM
     const size_t lds_ring = (size_t)ringN * 12 + 8;
     while (slot_cap > 64 && lds_ring + (size_t)slot_cap * 16 + 2 * sizeof(DpMeta) > 150 * 1024) slot_cap /= 2;
     DpArgs da = {ringN, slot_cap, wide ? 1 : 0, 0};
