@@ -483,9 +483,9 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_dp: one workgroup of two wavefronts per chunk.  Wave 0 owns the chunk's recurrence; wave 1 is its loader: while
-// wave 0 sweeps the 64 steps of batch b out of LDS, wave 1 copies the scored-block rows and the per-step metadata
-// of batch b+1 (contiguous in the CSR) from HBM into the other LDS slot.  One s_barrier per 64 steps.
+// k_dp: one workgroup of 1 + WG_DP_LOADERS wavefronts per chunk.  Wave 0 owns the chunk's recurrence; the others are
+// its loaders: while wave 0 sweeps the 64 steps of batch b out of LDS, they bring the scored-block rows and the
+// per-step metadata of batch b+1 from HBM into the other LDS slot.  One s_barrier per 64 steps.
 //
 // Push form of segmentor.cpp:142-154.  Lane l of wave 0 holds (best, arg) of the pending step i == l (mod 64),
 // i.e. the running  max_k M[k] + cost(k, i)  over the candidates k seen so far.  Iteration k: M[k] is final;
@@ -506,13 +506,16 @@ struct DpMeta {               // per LDS slot
     uint32_t pad;
 };
 
-// Loader wave: metadata of the 64 steps starting at `base`, and their scored-block rows into the LDS slot.
+#define WG_DP_LOADERS 3       // loader wavefronts per k_dp workgroup (wave 0 is the DP wave)
+
+// Loader waves: metadata of the 64 steps starting at `base`, and their scored-block rows into the LDS slot.
 // Arranged form (full batch, all windows <= 64): slot[s*64 + l] = cost(k, k+j), k = base+s, j = (l - s) mod 64, for
 // j < F_k, and -inf for the lanes that hold no candidate of step s — so the DP wave needs no predicate at all:
-// M[k] + (-inf) can never beat a pending maximum.
+// M[k] + (-inf) can never beat a pending maximum.  Loader wave `lw` arranges the steps s == lw (mod WG_DP_LOADERS),
+// all its HBM loads in flight before the first LDS store.
 __device__ __forceinline__ void wg_dp_load_batch(const double* __restrict__ cb, const uint16_t* __restrict__ Wp,
                                                  const uint32_t* __restrict__ Cp, uint32_t cum0, int base, int s1,
-                                                 int slot_cap, double* __restrict__ slot, DpMeta* __restrict__ meta, int lane)
+                                                 int slot_cap, double* __restrict__ slot, DpMeta* __restrict__ meta, int lane, int lw)
 {
     const int il = base + lane;
     const bool inb = il < s1;
@@ -525,23 +528,34 @@ __device__ __forceinline__ void wg_dp_load_batch(const double* __restrict__ cb, 
     const uint32_t span = last_rel + last_w - first;
     const bool simple = nst == 64 && slot_cap >= 4096 && wg_wave_max_u32(w) <= 64u;
     const bool staged = !simple && span <= (uint32_t)slot_cap;
-    meta->w[lane] = w;
-    meta->rel[lane] = rel;
-    if (lane == 0) { meta->first = first; meta->staged = staged ? 1u : 0u; meta->simple = simple ? 1u : 0u; }
+    if (lw == 0) {
+        meta->w[lane] = w;
+        meta->rel[lane] = rel;
+        if (lane == 0) { meta->first = first; meta->staged = staged ? 1u : 0u; meta->simple = simple ? 1u : 0u; }
+    }
     if (simple) {
         const double NEG_INF = -__builtin_inf();
-#pragma unroll 8
-        for (int sidx = 0; sidx < 64; sidx++) {
-            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w, sidx);
-            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rel, sidx);
-            const uint32_t j = (uint32_t)(lane - sidx) & 63u;
-            double v = NEG_INF;
-            if (j < f) v = cb[(int64_t)r + j];
-            slot[sidx * 64 + lane] = v;
+        constexpr int PER = (64 + WG_DP_LOADERS - 1) / WG_DP_LOADERS;
+        double v[PER];
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int sidx = lw + q * WG_DP_LOADERS;
+            v[q] = NEG_INF;
+            if (sidx < 64) {
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w, sidx);
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rel, sidx);
+                const uint32_t j = (uint32_t)(lane - sidx) & 63u;
+                if (j < f) v[q] = cb[(int64_t)r + j];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int sidx = lw + q * WG_DP_LOADERS;
+            if (sidx < 64) slot[sidx * 64 + lane] = v[q];
         }
     } else if (staged) {
         const double* src = cb + first;
-        for (uint32_t x = (uint32_t)lane; x < span; x += 64) slot[x] = src[x];
+        for (uint32_t x = (uint32_t)(lw * 64 + lane); x < span; x += 64 * WG_DP_LOADERS) slot[x] = src[x];
     }
 }
 
@@ -562,7 +576,7 @@ __device__ __forceinline__ void wg_dp_fast_step(double& best, int32_t& arg, uint
 
 // state saved between stages, per chunk: [0] M[k] of the next step, [1..64] best, then 64 args (as doubles' bits),
 // then (wide) pendB[ringN], pendA[ringN]
-__global__ __launch_bounds__(128) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
+__global__ __launch_bounds__(64 * (1 + WG_DP_LOADERS)) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
                                             double* __restrict__ state, int64_t state_stride)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_dp[];
@@ -572,6 +586,7 @@ __global__ __launch_bounds__(128) void k_dp(JobView J, StageView SV, const doubl
     DpMeta* metas = reinterpret_cast<DpMeta*>(slots + 2 * (size_t)A.slot_cap);
     const int lane = threadIdx.x & 63;
     const bool loader = threadIdx.x >= 64;
+    const int lw = (int)(threadIdx.x >> 6) - 1;       // loader wave index (0..WG_DP_LOADERS-1)
     const int c = blockIdx.x;
     const int nC = J.n_chunks;
     const ChunkDesc cd = J.chunks[c];
@@ -593,7 +608,7 @@ __global__ __launch_bounds__(128) void k_dp(JobView J, StageView SV, const doubl
     int32_t arg = 0;
     double Mk = 0.0;                                    // M[k] of the step about to run; M[0] = 0 (segmentor.cpp:97)
     if (loader) {
-        wg_dp_load_batch(cb, Wp, Cp, cum0, s0, s1, A.slot_cap, slots, metas, lane);
+        wg_dp_load_batch(cb, Wp, Cp, cum0, s0, s1, A.slot_cap, slots, metas, lane, lw);
     } else {
         if (s0 == 0) {
             if (wide) for (int x = lane; x < A.ringN; x += 64) { pendB[x] = NEG_INF; pendA[x] = 0; }
@@ -614,7 +629,7 @@ __global__ __launch_bounds__(128) void k_dp(JobView J, StageView SV, const doubl
         if (loader) {
             if (b + 1 < nb)
                 wg_dp_load_batch(cb, Wp, Cp, cum0, base + 64, s1, A.slot_cap, slots + (size_t)((b + 1) & 1) * A.slot_cap,
-                                 metas + ((b + 1) & 1), lane);
+                                 metas + ((b + 1) & 1), lane, lw);
         } else {
             const DpMeta* meta = metas + (b & 1);
             const double* slot = slots + (size_t)(b & 1) * A.slot_cap;

@@ -477,7 +477,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipEventRecord(c->ev_cost1[stg], c->sA));
         HIP_TRY(hipStreamWaitEvent(c->sB, c->ev_cost1[stg], 0));
         HIP_TRY(hipEventRecord(c->ev_dp0[stg], c->sB));
-        hipLaunchKernelGGL(k_dp, dim3((unsigned)nC), dim3(128), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
+        hipLaunchKernelGGL(k_dp, dim3((unsigned)nC), dim3(64 * (1 + WG_DP_LOADERS)), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_dp1[stg], c->sB));
     }
