@@ -90,7 +90,8 @@ struct wgbsseg_ctx {
     int force_stages = 0;
     int force_ns = 0;
     int force_ti = 0;
-    int min_stages = 6;
+    int min_stages = 1;      // stages exist to bound the scored-block buffer; k_dp alone (3.9 ms per 60k-site chunk) is
+                             // faster than k_dp competing with k_cost for CUs, so no overlap is sought by default
     bool accumulate = false;   // add to `tim` instead of resetting it (region-level calls span several batches)
 };
 
