@@ -136,10 +136,16 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    ndev = torch.cuda.device_count()
+    oversub = world > 1 and ndev < world            # test mode: more ranks than GPUs (e.g. 2 ranks on a 1-GPU box)
+    local = local % max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
+        if oversub:
+            dist.init_process_group('gloo')          # RCCL refuses two ranks on one device; the barrier is all we need
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     names, sizes = synth.genome_shape(args.sites, 25 if args.sites >= 2500000 else max(1, min(25, args.sites // 100000)))
     sizes = [int(s) for s in sizes]
@@ -172,7 +178,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local])
+            dist.barrier() if oversub else dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -190,7 +196,7 @@ def main():
                 acc[k] = max(acc[k], t[k]) if k in ('max_window', 'n_stages', 'scan_main_bytes') else acc[k] + t[k]
     barrier()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device='cpu' if oversub else dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
@@ -205,6 +211,16 @@ def main():
         scan_gbs = acc['scan_main_bytes'] / (main_ms * 1e-3) / 1e9
         scan_all_gbs = acc['scan_bytes'] / (acc['scan_ms'] * 1e-3) / 1e9
         evals_s = acc['evals'] / (acc['cost_ms'] * 1e-3)
+        # HBM traffic of that launch from the PMC counters (collected separately with rocprofv3, profiles/): only
+        # reported when the committed measurement is for exactly this workload
+        traffic, traffic_note = None, 'traffic: PMC pass not available for this workload'
+        tj = op.join(ROOT, 'profiles', 'r01_scan_traffic.json')
+        if op.isfile(tj) and world == 1:
+            tr = json.load(open(tj))
+            if abs(tr['algorithmic_bytes'] - acc['scan_main_bytes']) <= 0.001 * acc['scan_main_bytes']:
+                traffic = tr['traffic_bytes']
+                traffic_note = ('traffic (bytes per launch) = 2 x FETCH_SIZE + WRITE_SIZE from profiles/r01_scan_traffic.json '
+                                '(rocprofv3 PMC passes of this same command; gfx950 FETCH_SIZE x2 correction)')
         out = {
             'metric': 'CpG-sites/sec segmented',
             'value': value, 'unit': 'CpG-sites/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -218,12 +234,12 @@ def main():
                        'rank0_sites': my_sites, 'rank0_stats': stats, 'rank0_blocks': n_blocks},
             'roofline': {'kernel': 'k_scan (per-sample prefix scan + meth<=cov validation)', 'bound': 'hbm',
                          'achieved': scan_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': scan_gbs / HBM_PEAK_GBS,
-                         'traffic': None,
+                         'traffic': traffic,
                          'algorithmic_bytes_per_launch': acc['scan_main_bytes'], 'avg_launch_ms': main_ms,
                          'launches_timed': args.steps,
                          'all_launches': {'count': acc['scan_launches'], 'bytes': acc['scan_bytes'], 'ms': acc['scan_ms'],
                                           'GB/s': scan_all_gbs},
-                         'note': 'rank 0, HIP events on the kernel stream inside the timed steps; traffic: see profiles/'},
+                         'note': 'rank 0, HIP events on the kernel stream inside the timed steps; ' + traffic_note},
             'scoring': {'kernel': 'k_cost (block log-likelihoods, fp64 VALU bound)', 'evals_per_s': evals_s,
                         'evals_per_step': acc['evals'] / args.steps, 'pairs_per_step': acc['pairs'] / args.steps,
                         'max_window': acc['max_window'], 'stages': acc['n_stages']},
@@ -239,7 +255,7 @@ def main():
         print(json.dumps(out), flush=True)
     seg.close()
     if world > 1:
-        dist.barrier(device_ids=[local])
+        dist.barrier() if oversub else dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 
