@@ -173,7 +173,7 @@ def main():
     my_sites = int((en - st).sum())
 
     def step():
-        return seg.segment_regions(st, en, args.chunk, args.pcount, max_cpg, args.max_bp)
+        return seg.segment_regions(st, en, args.chunk, args.pcount, max_cpg, args.max_bp, copy=False)
 
     def barrier():
         torch.cuda.synchronize()

@@ -115,7 +115,7 @@ int wgbsseg_segment_chunks(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const 
  * junction's first-attempt patch [b-p1, b+p2), p = min(50, operand span) (segment.py:209-216) go to the GPU as one
  * batch, then the junctions are stitched in the reference's pairwise order with its overlap / merge2 /
  * patch-doubling rules (segment.py:219-252); failed attempts are re-batched.  Output (CSR over regions): the
- * merged ABSOLUTE 1-based border list of each region (first region_start, last region_end); consecutive pairs
+ * merged ABSOLUTE 1-based border list of each region as int32 (first region_start, last region_end); consecutive pairs
  * are the blocks (startCpG, endCpG) the reference writes (segment.py:154).  borders_cap >= sum(region lengths) +
  * n_regions always suffices.  stats (optional, 8 x int64): chunks, patch DPs run, GPU batches, patches planned up
  * front, host wall microseconds of the whole call / of the first batch / of the follow-up batches, total borders.
@@ -123,7 +123,7 @@ int wgbsseg_segment_chunks(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const 
  */
 int wgbsseg_segment_regions(wgbsseg_ctx* ctx, const int64_t* region_start, const int64_t* region_end, int64_t n_regions,
                             int64_t chunk_size, const wgbsseg_params* params,
-                            int64_t* borders_out, int64_t borders_cap, int64_t* borders_off, int64_t* stats,
+                            int32_t* borders_out, int64_t borders_cap, int64_t* borders_off, int64_t* stats,
                             char* err, size_t errlen);
 
 /*

@@ -278,16 +278,16 @@ def native_segment_regions(stitch_lib, engine, params, regions, chunk_size, spec
     rs = np.array([r[0] for r in regions], dtype=np.int64)
     re_ = np.array([r[1] for r in regions], dtype=np.int64)
     cap = int((re_ - rs).sum()) + len(regions)
-    out = np.empty(cap, dtype=np.int64)
+    out = np.empty(cap, dtype=np.int32)
     off = np.empty(len(regions) + 1, dtype=np.int64)
     stats = np.zeros(8, dtype=np.int64)
     err = C.create_string_buffer(512)
     rc = stitch_lib.stitch_segment_regions(rs.ctypes.data_as(C.POINTER(C.c_int64)), re_.ctypes.data_as(C.POINTER(C.c_int64)),
-                                           len(regions), C.c_int64(chunk_size), CB(cb), out.ctypes.data_as(C.POINTER(C.c_int64)),
+                                           len(regions), C.c_int64(chunk_size), CB(cb), out.ctypes.data_as(C.POINTER(C.c_int32)),
                                            C.c_int64(cap), off.ctypes.data_as(C.POINTER(C.c_int64)),
                                            stats.ctypes.data_as(C.POINTER(C.c_int64)), err, 512, int(speculate))
     assert rc == 0, err.value
-    return [out[off[r]:off[r + 1]].copy() for r in range(len(regions))], stats
+    return [out[off[r]:off[r + 1]].astype(np.int64) for r in range(len(regions))], stats
 
 
 @pytest.mark.parametrize('speculate', [0, 1])

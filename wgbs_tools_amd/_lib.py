@@ -163,6 +163,7 @@ class Segmenter:
         _check(self._L.wgbsseg_create(int(device), C.byref(self._h), self._err, ERRLEN), self._err)
         self.n_sites = 0
         self.n_samples = 0
+        self._rbuf = None
 
     def close(self):
         if self._h:
@@ -221,21 +222,24 @@ class Segmenter:
                                               out.ctypes.data, cap, off.ctypes.data, self._err, ERRLEN), self._err)
         return out[:off[n]], off
 
-    def segment_regions(self, starts, ends, chunk_size, pcount, max_cpg, max_bp):
+    def segment_regions(self, starts, ends, chunk_size, pcount, max_cpg, max_bp, copy=True):
         """starts/ends: 1-based half-open CpG ranges RELATIVE TO THE RESIDENT DATA (site 1 = first resident site).
-        -> (list of int64 arrays: merged absolute border list of each region, stats dict)."""
+        -> (list of arrays: merged absolute border list of each region, stats dict).  copy=True: int64 copies;
+        copy=False: int32 views into a buffer that the next call overwrites."""
         starts = np.ascontiguousarray(starts, dtype=np.int64)
         ends = np.ascontiguousarray(ends, dtype=np.int64)
         n = starts.size
         cap = int((ends - starts).sum()) + n
-        out = np.empty(cap, dtype=np.int64)
+        if self._rbuf is None or self._rbuf.size < cap:       # reused across calls: no 100+ MB allocation per call
+            self._rbuf = np.empty(cap, dtype=np.int32)
+        out = self._rbuf
         off = np.empty(n + 1, dtype=np.int64)
         stats = np.zeros(8, dtype=np.int64)
         p = Params(float(pcount), int(max_cpg), int(max_bp))
         _check(self._L.wgbsseg_segment_regions(self._h, starts.ctypes.data, ends.ctypes.data, n, int(chunk_size), C.byref(p),
                                                out.ctypes.data, cap, off.ctypes.data, stats.ctypes.data, self._err, ERRLEN),
                self._err)
-        res = [out[off[r]:off[r + 1]] for r in range(n)]
+        res = [out[off[r]:off[r + 1]].astype(np.int64) if copy else out[off[r]:off[r + 1]] for r in range(n)]
         return res, dict(chunks=int(stats[0]), patch_dps=int(stats[1]), batches=int(stats[2]), patches_planned=int(stats[3]),
                          wall_us=int(stats[4]), first_batch_us=int(stats[5]), later_batches_us=int(stats[6]))
 

@@ -187,51 +187,71 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_window: one workgroup per chunk.  F_k = number of admissible ends of a block starting at site k:
+// k_window: F_k = number of admissible ends of a block starting at site k:
 //   i admissible  <=>  k <= i < len,  i-k < max_cpg  and  loci[i]-loci[k] <= max_bp   (segmentor.cpp:111-117, loci ascending)
+// One thread per site (grid: 256-site tiles, `wtile_off` = exclusive prefix of tiles per chunk); k_window_scan then
+// turns F into the CSR row offsets, one workgroup per chunk.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, uint32_t max_cpg, uint32_t max_bp)
+__global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, const int64_t* __restrict__ wtile_off,
+                                                     uint32_t max_cpg, uint32_t max_bp)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int nC = J.n_chunks;
+    const int64_t t = blockIdx.x;
+    int clo = 0, chi = nC;                               // last chunk with wtile_off[c] <= t
+    while (chi - clo > 1) { const int mid = (clo + chi) >> 1; if (wtile_off[mid] <= t) clo = mid; else chi = mid; }
+    const int c = clo;
+    const ChunkDesc cd = J.chunks[c];
+    const uint32_t* loc = J.loci + cd.start0;
+    const int k = (int)(t - wtile_off[c]) * WG_BLOCK + tid;
+    uint32_t w = 0;
+    bool disorder = false;
+    if (k < cd.len) {
+        const int64_t lk = loc[k];
+        if (k > 0 && (int64_t)loc[k - 1] > lk) disorder = true;
+        const int64_t limit = lk + (int64_t)max_bp;
+        int lo = k;                                       // loc[k] <= limit always
+        int hi = (int)((int64_t)k + max_cpg - 1 < cd.len - 1 ? (int64_t)k + max_cpg - 1 : cd.len - 1);
+        while (lo < hi) {                                 // last i in [k, hi] with loc[i] <= limit
+            const int mid = (lo + hi + 1) >> 1;
+            if ((int64_t)loc[mid] <= limit) lo = mid; else hi = mid - 1;
+        }
+        w = (uint32_t)(lo - k + 1);
+        J.W16[cd.site_off + k] = (uint16_t)w;
+    }
+    const uint32_t wmax = wg_wave_max_u32(w);
+    const bool any_dis = __any(disorder);
+    if (lane == 0) {
+        atomicMax(&st->max_window, wmax);
+        if (any_dis) atomicMax(&st->loci_disorder, (unsigned int)(c + 1));
+    }
+}
+
+__global__ __launch_bounds__(WG_BLOCK) void k_window_scan(JobView J, JobStatus* st)
 {
     __shared__ uint32_t wsum[WG_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = blockIdx.x;
     const ChunkDesc cd = J.chunks[c];
-    const uint32_t* loc = J.loci + cd.start0;
+    const uint16_t* W = J.W16 + cd.site_off;
+    uint32_t* C = J.cum32 + cd.site_off;
     uint64_t run = 0;
-    uint32_t wmax = 0;
-    bool disorder = false;
-    for (int base = 0; base < cd.len; base += WG_BLOCK) {
-        const int k = base + tid;
-        uint32_t w = 0;
-        if (k < cd.len) {
-            const int64_t lk = loc[k];
-            if (k > 0 && (int64_t)loc[k - 1] > lk) disorder = true;
-            const int64_t limit = lk + (int64_t)max_bp;
-            int lo = k;                                   // loc[k] <= limit always
-            int hi = (int)((int64_t)k + max_cpg - 1 < cd.len - 1 ? (int64_t)k + max_cpg - 1 : cd.len - 1);
-            while (lo < hi) {                             // last i in [k, hi] with loc[i] <= limit
-                const int mid = (lo + hi + 1) >> 1;
-                if ((int64_t)loc[mid] <= limit) lo = mid; else hi = mid - 1;
-            }
-            w = (uint32_t)(lo - k + 1);
-            J.W16[cd.site_off + k] = (uint16_t)w;
-            if (w > wmax) wmax = w;
-        }
-        const uint32_t incl = wg_wave_incl_scan_dpp_u32(w);
+    for (int base = 0; base < cd.len; base += WG_BLOCK * 8) {         // 8 consecutive sites per thread
+        const int k0 = base + tid * 8;
+        uint32_t w[8], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { w[j] = (k0 + j < cd.len) ? (uint32_t)W[k0 + j] : 0u; tot += w[j]; }
+        const uint32_t incl = wg_wave_incl_scan_dpp_u32(tot);
         if (lane == 63) wsum[wv] = incl;
         __syncthreads();
         uint32_t woff = 0, btot = 0;
 #pragma unroll
         for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) woff += wsum[q]; btot += wsum[q]; }
         __syncthreads();
-        if (k < cd.len) J.cum32[cd.site_off + k] = (uint32_t)(run + woff + (incl - w));
+        uint32_t e = (uint32_t)(run + woff + (incl - tot));
+#pragma unroll
+        for (int j = 0; j < 8; j++) { if (k0 + j < cd.len) C[k0 + j] = e; e += w[j]; }
         run += btot;
-    }
-    wmax = wg_wave_max_u32(wmax);
-    const bool any_dis = __any(disorder);
-    if (lane == 0) {
-        atomicMax(&st->max_window, wmax);
-        if (any_dis) atomicMax(&st->loci_disorder, (unsigned int)(c + 1));
     }
     if (tid == 0) {
         J.chunk_pairs[c] = (int64_t)run;

@@ -11,12 +11,14 @@
 // the same batch as the chunks; only failed attempts (doubling) need a follow-up batch.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <functional>
 #include <map>
 #include <memory>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -61,7 +63,7 @@ struct Rope {
         for (size_t q = ri + 1; q < o.runs.size(); q++) runs.push_back(o.runs[q]);
     }
     int64_t size() const { int64_t s = 0; for (auto& r : runs) s += r.n; return s; }
-    void flatten(int64_t* out) const { for (auto& r : runs) { for (int64_t q = 0; q < r.n; q++) out[q] = (int64_t)r.p[q] + r.add; out += r.n; } }
+    void flatten(int32_t* out) const { for (auto& r : runs) { const int32_t a = (int32_t)r.add; for (int64_t q = 0; q < r.n; q++) out[q] = r.p[q] + a; out += r.n; } }
 };
 
 inline int64_t increase_patch(int64_t pre, int64_t maxval)    // segment.py:249-252
@@ -158,7 +160,8 @@ inline void upfront_patches(int64_t start, const std::vector<int64_t>& lens, boo
 typedef std::pair<int64_t, int64_t> Sites;                     // 1-based [start, end)
 // Result of one batch of chunk DPs: CSR of int32 borders RELATIVE to each item's start (first 0, last end-start).
 struct BatchResult {
-    std::unique_ptr<int32_t[]> flat;
+    int32_t* flat = nullptr;                 // must stay valid until segment_regions returns
+    std::unique_ptr<int32_t[]> owned;        // optional owner of `flat`
     std::vector<int64_t> off;
 };
 typedef std::function<int(const std::vector<Sites>&, BatchResult&, std::string&)> BatchFn;
@@ -166,7 +169,7 @@ enum { E_ARG = -1, E_CAPACITY = -6 };
 
 // The whole driver loop of segment.py:137-165 over `n_regions` regions; see include/wgbsseg.h wgbsseg_segment_regions.
 inline int segment_regions(const int64_t* region_start, const int64_t* region_end, int64_t n_regions, int64_t chunk_size,
-                           const BatchFn& run_batch, int64_t* borders_out, int64_t borders_cap, int64_t* borders_off,
+                           const BatchFn& run_batch, int32_t* borders_out, int64_t borders_cap, int64_t* borders_off,
                            int64_t* stats, std::string& err, bool speculate = true)
 {
     if (!region_start || !region_end || n_regions < 1 || chunk_size < 1 || !borders_out || !borders_off) { err = "bad arguments to segment_regions"; return E_ARG; }
@@ -185,7 +188,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     std::vector<Sites> patches;
     for (int64_t r = 0; r < n_regions; r++) {
         const int64_t a = region_start[r], b = region_end[r];
-        if (a < 1 || b <= a) { err = "region " + std::to_string(r) + " is empty or starts before site 1"; return E_ARG; }
+        if (a < 1 || b <= a || b > 0x7fffffff) { err = "region " + std::to_string(r) + " is empty, starts before site 1 or ends beyond 2^31"; return E_ARG; }
         region_first_chunk[(size_t)r] = (int64_t)items.size();
         std::vector<int64_t> lens;
         for (int64_t s = a; s < b; s += chunk_size) { const int64_t e = std::min(s + chunk_size, b); items.push_back({s, e}); lens.push_back(e - s); }
@@ -205,14 +208,14 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     const int64_t us_first = us_batches;
     if (rc != 0) return rc;
     n_batches++;
-    for (size_t i = (size_t)n_chunks; i < items.size(); i++) { cache[items[i]] = Patch{first.flat.get() + first.off[i], first.off[i + 1] - first.off[i]}; n_patch_dp++; }
+    for (size_t i = (size_t)n_chunks; i < items.size(); i++) { cache[items[i]] = Patch{first.flat + first.off[i], first.off[i + 1] - first.off[i]}; n_patch_dp++; }
 
     // ---- pairwise-tree stitching (segment.py:157-165), all regions advancing round by round ------------------------
     std::vector<std::vector<Rope>> lists((size_t)n_regions);
     for (int64_t r = 0; r < n_regions; r++)
         for (int64_t q = region_first_chunk[(size_t)r]; q < region_first_chunk[(size_t)r + 1]; q++) {
             Rope rp;
-            rp.runs.push_back(Run{first.flat.get() + first.off[(size_t)q], first.off[(size_t)q + 1] - first.off[(size_t)q], items[(size_t)q].first});
+            rp.runs.push_back(Run{first.flat + first.off[(size_t)q], first.off[(size_t)q + 1] - first.off[(size_t)q], items[(size_t)q].first});
             lists[(size_t)r].push_back(std::move(rp));
         }
     for (;;) {
@@ -249,7 +252,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                 rc = timed_batch(need, res);
                 if (rc != 0) return rc;
                 n_batches++;
-                for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = Patch{res.flat.get() + res.off[i], res.off[i + 1] - res.off[i]}; n_patch_dp++; }
+                for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = Patch{res.flat + res.off[i], res.off[i + 1] - res.off[i]}; n_patch_dp++; }
             }
             for (auto& s : st) {
                 if (s.done) continue;
@@ -269,7 +272,18 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     for (int64_t r = 0; r < n_regions; r++) { borders_off[r] = total; total += lists[(size_t)r][0].size(); }
     borders_off[n_regions] = total;
     if (total > borders_cap) { err = "borders_out too small: need " + std::to_string(total); return E_CAPACITY; }
-    for (int64_t r = 0; r < n_regions; r++) lists[(size_t)r][0].flatten(borders_out + borders_off[r]);
+    {   // regions are independent: flatten them on a few threads when there is enough to copy
+        const int nth = (total > (1 << 20) && n_regions > 1) ? (int)std::min<int64_t>(4, n_regions) : 1;
+        if (nth == 1) {
+            for (int64_t r = 0; r < n_regions; r++) lists[(size_t)r][0].flatten(borders_out + borders_off[r]);
+        } else {
+            std::vector<std::thread> th;
+            std::atomic<int64_t> next(0);
+            for (int t = 0; t < nth; t++)
+                th.emplace_back([&]() { for (int64_t r; (r = next.fetch_add(1)) < n_regions;) lists[(size_t)r][0].flatten(borders_out + borders_off[r]); });
+            for (auto& x : th) x.join();
+        }
+    }
     if (stats) {
         stats[0] = n_chunks; stats[1] = n_patch_dp; stats[2] = n_batches; stats[3] = (int64_t)patches.size();
         stats[4] = std::chrono::duration_cast<std::chrono::microseconds>(Clock::now() - t_begin).count();   // whole call, host wall

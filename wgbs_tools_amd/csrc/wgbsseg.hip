@@ -64,6 +64,21 @@ inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 }  // namespace
 
+struct PinnedBuf {          // grow-only page-locked host buffer (fast, truly asynchronous D2H)
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct wgbsseg_ctx {
     int device = 0;
     hipStream_t sA = nullptr, sB = nullptr;
@@ -75,8 +90,9 @@ struct wgbsseg_ctx {
     const uint32_t* loci = nullptr;
     int64_t n_loci = 0;
     // scratch
-    DevBuf chunks, carry, W16, cum32, back16, chunk_pairs, status;
+    DevBuf chunks, wtile, carry, W16, cum32, back16, chunk_pairs, status;
     DevBuf plan_cbase, plan_cum0, plan_tbase, plan_pairs, plan_tiles;
+    std::vector<PinnedBuf> pinned;
     DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders, dbg_a, dbg_b, dbg_c;
     // events
     hipEvent_t ev[8] = {};
@@ -154,11 +170,12 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs,
+    DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->wtile, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs,
                      &c->status, &c->plan_cbase, &c->plan_cum0, &c->plan_tbase, &c->plan_pairs, &c->plan_tiles,
                      &c->cost[0], &c->cost[1], &c->dpstate, &c->tmp_borders, &c->nb, &c->boff, &c->out_borders,
                      &c->dbg_a, &c->dbg_b, &c->dbg_c};
     for (auto* b : all) b->release();
+    for (auto& pb : c->pinned) pb.release();
     for (auto& v : c->ev) if (v) (void)hipEventDestroy(v);
     for (auto* vec : {&c->ev_cost0, &c->ev_cost1, &c->ev_dp0, &c->ev_dp1}) for (auto v : *vec) (void)hipEventDestroy(v);
     if (c->sA) (void)hipStreamDestroy(c->sA);
@@ -224,6 +241,7 @@ namespace {
 // Host copy of the chunk table + job-wide offsets; uploads it and builds the JobView.
 struct Job {
     std::vector<ChunkDesc> h;
+    std::vector<int64_t> wtile_off;     // exclusive prefix of 256-site tiles per chunk (+ total)
     int64_t sites = 0, carry_entries = 0;
     int32_t max_len = 0;
     JobStatus st0;          // source of an async H2D copy: must outlive the call's stream work
@@ -238,7 +256,8 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
     if (need_loci && (!c->loci || c->n_loci != c->n_total)) { set_err(err, errlen, "loci not set or length differs from the betas (%lld vs %lld)", (long long)c->n_loci, (long long)c->n_total); return WGBSSEG_E_STATE; }
     if (!start0 || !len || n_chunks < 1 || n_chunks > 0x7fffffff) { set_err(err, errlen, "bad chunk list"); return WGBSSEG_E_ARG; }
     job.h.resize((size_t)n_chunks);
-    int64_t so = 0, co = 0;
+    job.wtile_off.resize((size_t)n_chunks + 1);
+    int64_t so = 0, co = 0, wt = 0;
     for (int64_t i = 0; i < n_chunks; i++) {
         if (len[i] < 1 || start0[i] < 0 || start0[i] + len[i] > c->n_total) {
             set_err(err, errlen, "chunk %lld = [%lld, +%d) is empty or outside the %lld sites of the beta files",
@@ -247,16 +266,21 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
         }
         ChunkDesc& d = job.h[(size_t)i];
         d.start0 = start0[i]; d.len = len[i]; d.site_off = so; d.carry_off = co; d.nG = (int32_t)(((start0[i] + len[i] - 1) >> 6) - (start0[i] >> 6) + 1);
+        job.wtile_off[(size_t)i] = wt;
+        wt += (len[i] + WG_BLOCK - 1) / WG_BLOCK;
         so += len[i];
         co += (int64_t)d.nG * c->n_samples;
         job.max_len = std::max(job.max_len, len[i]);
     }
+    job.wtile_off[(size_t)n_chunks] = wt;
     job.sites = so; job.carry_entries = co;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(c->chunks.ensure(sizeof(ChunkDesc) * (size_t)n_chunks));
     HIP_TRY(c->carry.ensure(sizeof(uint2) * (size_t)co));
     HIP_TRY(c->status.ensure(sizeof(JobStatus)));
     HIP_TRY(hipMemcpyAsync(c->chunks.p, job.h.data(), sizeof(ChunkDesc) * (size_t)n_chunks, hipMemcpyHostToDevice, c->sA));
+    HIP_TRY(c->wtile.ensure(8 * ((size_t)n_chunks + 1)));
+    HIP_TRY(hipMemcpyAsync(c->wtile.p, job.wtile_off.data(), 8 * ((size_t)n_chunks + 1), hipMemcpyHostToDevice, c->sA));
     memset(&job.st0, 0, sizeof(job.st0));
     job.st0.first_bad = ~0ULL;
     HIP_TRY(hipMemcpyAsync(c->status.p, &job.st0, sizeof(job.st0), hipMemcpyHostToDevice, c->sA));
@@ -353,7 +377,11 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     rc = launch_scan(c, job, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
-    hipLaunchKernelGGL(k_window, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, c->status.as<JobStatus>(), P->max_cpg, P->max_bp);
+    if (job.wtile_off[(size_t)nC] > 0x7fffffff) { set_err(err, errlen, "too many sites in one call"); return WGBSSEG_E_ARG; }
+    hipLaunchKernelGGL(k_window, dim3((unsigned)job.wtile_off[(size_t)nC]), dim3(WG_BLOCK), 0, c->sA, v, c->status.as<JobStatus>(),
+                       c->wtile.as<int64_t>(), P->max_cpg, P->max_bp);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_window_scan, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, c->status.as<JobStatus>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[2], c->sA));
     JobStatus st;
@@ -553,7 +581,7 @@ int wgbsseg_segment_chunks_host(const uint8_t* betas, int64_t n_samples, int64_t
 }
 
 int wgbsseg_segment_regions(wgbsseg_ctx* c, const int64_t* region_start, const int64_t* region_end, int64_t n_regions,
-                            int64_t chunk_size, const wgbsseg_params* P, int64_t* borders_out, int64_t borders_cap,
+                            int64_t chunk_size, const wgbsseg_params* P, int32_t* borders_out, int64_t borders_cap,
                             int64_t* borders_off, int64_t* stats, char* err, size_t errlen)
 {
     if (!c || !P) { set_err(err, errlen, "bad arguments to segment_regions"); return WGBSSEG_E_ARG; }
@@ -569,7 +597,14 @@ int wgbsseg_segment_regions(wgbsseg_ctx* c, const int64_t* region_start, const i
             ln[i] = (int32_t)(todo[i].second - todo[i].first);
         }
         res.off.resize(todo.size() + 1);
-        BorderAlloc alloc = [&](int64_t total) -> int32_t* { res.flat.reset(new int32_t[(size_t)std::max<int64_t>(total, 1)]); return res.flat.get(); };
+        // pinned, grow-only, one buffer per batch of the call (they must all stay alive while the ropes point into them)
+        BorderAlloc alloc = [&](int64_t total) -> int32_t* {
+            if (c->pinned.size() <= (size_t)n_batches) c->pinned.resize((size_t)n_batches + 1);
+            PinnedBuf& pb = c->pinned[(size_t)n_batches];
+            res.flat = pb.ensure((size_t)std::max<int64_t>(total, 1) * 4) ? reinterpret_cast<int32_t*>(pb.p) : nullptr;
+            if (!res.flat) { res.owned.reset(new int32_t[(size_t)std::max<int64_t>(total, 1)]); res.flat = res.owned.get(); }   // pageable fallback
+            return res.flat;
+        };
         char ebuf[512] = {0};
         c->accumulate = n_batches > 0;
         const int rc = segment_chunks_impl(c, st0.data(), ln.data(), (int64_t)todo.size(), P, alloc, res.off.data(), ebuf, sizeof(ebuf));
