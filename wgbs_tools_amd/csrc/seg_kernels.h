@@ -222,7 +222,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, c
     const uint32_t wmax = wg_wave_max_u32(w);
     const bool any_dis = __any(disorder);
     if (lane == 0) {
-        atomicMax(&st->max_window, wmax);
+        // hundreds of thousands of wavefronts: touch the shared word only when it would change
+        if (wmax > __hip_atomic_load(&st->max_window, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_window, wmax);
         if (any_dis) atomicMax(&st->loci_disorder, (unsigned int)(c + 1));
     }
 }
