@@ -97,3 +97,21 @@ def test_python_stitching_path_equals_native_path(driver_golden, world, tmp_path
         eng.close()
     a, b = open(str(tmp_path / 'a.bed')).read(), open(str(tmp_path / 'b.bed')).read()
     assert a == b and a.count('\n') == g['n_blocks']
+
+
+def test_two_ranks_one_process_per_gpu_cli(driver_golden, world, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 wgbstools segment ...`: the sharded product path (two ranks;
+    on a 1-GPU box both map to device 0) must write the same BED as the reference driver."""
+    import subprocess
+    import sys
+    g = driver_golden['cases']['wg_c20000']
+    out = str(tmp_path / 'sharded.bed')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', op.join(ROOT, 'wgbstools'), 'segment', '--betas'] + world['paths'] + \
+          ['--genome', world['refdir'], '-c', '20000', '-o', out]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert res.returncode == 0, res.stdout.decode()[-3000:]
+    rows = [l.rstrip('\n').split('\t') for l in open(out)]
+    table = np.array([[int(r[3]), int(r[4])] for r in rows], dtype=np.int64).reshape(-1, 2)
+    assert table.shape[0] == g['n_blocks']
+    assert hashlib.sha1(table.tobytes()).hexdigest() == g['table_sha1']

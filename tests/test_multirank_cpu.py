@@ -81,3 +81,47 @@ def test_shard_pieces_tile_the_grid():
                 assert (s - pos) % 100 == 0
             pos += sz
         assert nch == sum(-(-s // 100) for s in sizes)
+
+
+WORKER2 = textwrap.dedent('''
+    import os, sys, argparse, io, contextlib
+    import numpy as np
+    sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+    from wgbs_tools_amd import synth, segment as S, parallel
+    from test_driver_cpu import OracleEngine
+    rank, world, local = parallel.env_rank_world()
+    d = %(tmp)r
+    names = ['chr1', 'chr2', 'chr3']; sizes = [30017, 21040, 9007]
+    loci = synth.synth_loci(78, sizes); total = sum(sizes)
+    betas = [synth.synth_betas(78, s, 0, total) for s in range(3)]
+    refdir = os.path.join(d, 'references', 'g')
+    paths = [os.path.join(d, 's%%d.beta' %% i) for i in range(3)]
+    if rank == 0:
+        synth.write_genome(refdir, names, sizes, loci)
+        for p, b in zip(paths, betas): synth.write_beta(p, b)
+    parallel.init_host_group().barrier()
+    args = argparse.Namespace(sites=None, region=None, array_id=None, bed_file=None, genome=refdir, betas=paths, beta_file=None,
+                              chunk_size=7000, pcount=15, min_cpg=1, max_cpg=1000, max_bp=2000,
+                              out_path=os.path.join(d, 'sharded.bed'), threads=1, device=0)
+    with contextlib.redirect_stderr(io.StringIO()):
+        S.SegmentByChunks(args, paths, engine=None).run_sharded(rank, world, local, engine_factory=lambda sr: OracleEngine(betas, loci))
+        if rank == 0:
+            args.out_path = os.path.join(d, 'single.bed')
+            os.environ['WORLD_SIZE'] = '1'
+            S.SegmentByChunks(args, paths, engine=OracleEngine(betas, loci)).run()
+    if rank == 0:
+        a, b = open(os.path.join(d, 'sharded.bed')).read(), open(os.path.join(d, 'single.bed')).read()
+        print('SHARDED_CLI_OK' if (a == b and a.count('\\n') > 1000) else 'SHARDED_CLI_DIFF', a.count('\\n'), b.count('\\n'), flush=True)
+''')
+
+
+def test_sharded_driver_equals_single_rank(tmp_path):
+    script = tmp_path / 'worker2.py'
+    script.write_text(WORKER2 % dict(root=ROOT, tmp=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29532', str(script)]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = res.stdout.decode()
+    assert res.returncode == 0, out[-3000:]
+    assert 'SHARDED_CLI_OK' in out, out[-3000:]

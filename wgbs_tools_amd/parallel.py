@@ -9,33 +9,45 @@ between two ranks with the reference's own rule (segment.py:199-232) and concate
 import numpy as np
 
 
-def chunk_grid(sizes, chunk):
-    """[(chrom idx, start, end)] 1-based half-open, the reference's grid (segment.py:124-135) over whole chromosomes."""
-    chunks, pos = [], 1
-    for ci, sz in enumerate(sizes):
-        sz = int(sz)
-        for s in range(pos, pos + sz, chunk):
-            chunks.append((ci, s, min(s + chunk, pos + sz)))
-        pos += sz
+def regions_of_sizes(sizes):
+    """Whole chromosomes as 1-based half-open CpG ranges (segment.py:115-119)."""
+    out, pos = [], 1
+    for sz in sizes:
+        out.append((pos, pos + int(sz)))
+        pos += int(sz)
+    return out
+
+
+def chunk_grid(regions, chunk):
+    """[(region idx, start, end)] 1-based half-open: the reference's grid (segment.py:124-135) over the regions."""
+    chunks = []
+    for ri, (a, b) in enumerate(regions):
+        for s in range(int(a), int(b), chunk):
+            chunks.append((ri, s, min(s + chunk, int(b))))
     return chunks
 
 
-def shard_pieces(sizes, chunk, world):
-    """-> (pieces per rank: [[(chrom idx, start, end), ...], ...], number of chunks).  A piece is a maximal run of
-    consecutive chunks of one chromosome owned by one rank."""
-    chunks = chunk_grid(sizes, chunk)
+def shard_regions(regions, chunk, world):
+    """-> (pieces per rank: [[(region idx, start, end), ...], ...], number of chunks).  A piece is a maximal run of
+    consecutive chunks of one region owned by one rank; pieces start on the region's chunk grid."""
+    chunks = chunk_grid(regions, chunk)
     total = sum(e - s for _, s, e in chunks)
     out, acc, r = [[] for _ in range(world)], 0, 0
-    for ci, s, e in chunks:
+    for ri, s, e in chunks:
         while r < world - 1 and acc >= total * (r + 1) / world:
             r += 1
         p = out[r]
-        if p and p[-1][2] == s and p[-1][0] == ci:
-            p[-1] = (ci, p[-1][1], e)
+        if p and p[-1][2] == s and p[-1][0] == ri:
+            p[-1] = (ri, p[-1][1], e)
         else:
-            p.append((ci, s, e))
+            p.append((ri, s, e))
         acc += e - s
     return out, len(chunks)
+
+
+def shard_pieces(sizes, chunk, world):
+    """shard_regions over whole chromosomes of the given CpG counts."""
+    return shard_regions(regions_of_sizes(sizes), chunk, world)
 
 
 def stitch_across_ranks(gathered, stitch_fn):
@@ -64,3 +76,17 @@ def gather_to_rank0(local, rank, world):
     out = [None] * world if rank == 0 else None
     dist.gather_object(local, out, dst=0)
     return out
+
+
+def env_rank_world():
+    """(rank, world, local_rank) from the torch.distributed.run environment; (0, 1, 0) outside it."""
+    import os
+    return int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('LOCAL_RANK', '0'))
+
+
+def init_host_group():
+    """The only communication of a multi-GPU segment run is the final host-side gather of border lists: a gloo group."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group('gloo')
+    return dist

@@ -251,7 +251,11 @@ class SegmentByChunks:
 
     def run(self):
         tags, starts, ends = self.break_to_chunks()
+        from . import parallel
+        rank, world, local = parallel.env_rank_world()
         own_engine = self.param_dict['engine'] is None
+        if world > 1:
+            return self.run_sharded(rank, world, local)
         if own_engine:
             lo = min(starts) - 1 if starts else 0
             hi = max(ends) - 1 if ends else 0
@@ -278,6 +282,53 @@ class SegmentByChunks:
         s = np.concatenate([m[:-1] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
         e = np.concatenate([m[1:] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
         self.dump_result(s, e)
+
+    def run_sharded(self, rank, world, local, engine_factory=None):
+        """One process per GPU (python -m torch.distributed.run ... wgbstools segment ...): the chunk grid is cut into
+        `world` contiguous pieces, every rank segments and stitches its own pieces on its own GPU, the border lists
+        are gathered on the host of rank 0 (no collective on the data path), which stitches the junctions between
+        ranks with the reference's rule and writes the BED.  The other ranks produce no output."""
+        from . import parallel
+        regs = self.regions()
+        pieces, _ = parallel.shard_regions(regs, self.args.chunk_size, world)
+        mine = pieces[rank]
+        dist = parallel.init_host_group()
+        if engine_factory is None:
+            def engine_factory(site_range):
+                import torch
+                ndev = max(1, torch.cuda.device_count())
+                return HipEngine(self.betas, self.genome, device=local % ndev, site_range=site_range)
+        # every rank needs its own pieces; rank 0 also the junction neighbourhoods between ranks: keep it simple, one range
+        lo = min(a for a, _ in regs) - 1
+        hi = max(b for _, b in regs) - 1
+        if mine and rank != 0:
+            lo, hi = min(p[1] for p in mine) - 1, max(p[2] for p in mine) - 1
+        eng = engine_factory((lo, hi)) if (mine or rank == 0) else None
+        try:
+            local_res = []
+            if mine:
+                res = eng.segment_regions([(s, e) for _, s, e in mine], self.args.chunk_size, self.param_dict) \
+                    if hasattr(eng, 'segment_regions') else None
+                if res is None:
+                    res = []
+                    for _, s, e in mine:
+                        bords = list(range(s, e, self.args.chunk_size)) + [e]
+                        arr = eng.segment_many(list(zip(bords[:-1], bords[1:])), self.param_dict)
+                        self.param_dict['engine'] = eng
+                        res.append(self.merge_df_list(arr))
+                local_res = [(ri, s, e, np.asarray(b)) for (ri, s, e), b in zip(mine, res)]
+            gathered = parallel.gather_to_rank0(local_res, rank, world)
+            if rank == 0:
+                pd = dict(self.param_dict, engine=eng)
+                merged = parallel.stitch_across_ranks(gathered, lambda a, b: stitch_2_dfs(a, b, pd))
+                s_ = np.concatenate([m[:-1] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
+                e_ = np.concatenate([m[1:] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
+                self.dump_result(s_, e_)
+        finally:
+            if eng is not None and hasattr(eng, 'close'):
+                eng.close()
+            self.param_dict['engine'] = None
+            dist.barrier()
 
     def merge_groups(self, groups):
         """merge_df_list (segment.py:157-165) for every tag at once: the pairing order inside a tag is the
