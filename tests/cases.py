@@ -23,6 +23,16 @@ def _loci_for(spec):
         idx = np.arange(a, a + n, dtype=np.int64)
         gap = 2 + (synth.hash_at(spec.get('loci_seed', SEED), 77, idx) & np.uint64(7)).astype(np.int64)
         return (10000 + np.cumsum(gap)).astype(np.uint32)
+    if kind == 'hg19like_islands':
+        # sparse background with a CpG island (gaps 2..9 bp, ~360 CpGs inside max_bp=2000) every 3000 sites:
+        # batches of the DP with and without windows > 64 alternate inside one chunk
+        idx = np.arange(a, a + n, dtype=np.int64)
+        total = a + n
+        base = np.diff(np.concatenate([[0], synth.synth_loci(spec.get('loci_seed', SEED), [total]).astype(np.int64)]))[a:a + n]
+        dense = 2 + (synth.hash_at(spec.get('loci_seed', SEED), 79, idx) & np.uint64(7)).astype(np.int64)
+        island = (idx % 3000) >= 2600
+        gap = np.where(island, dense, np.maximum(base, 2))
+        return (10000 + np.cumsum(gap)).astype(np.uint32)
     if kind == 'equal_runs':
         # repeated positions (distance 0) -- legal for the reference: dists[i+j]-dists[i] == 0 <= max_bp
         idx = np.arange(a, a + n, dtype=np.int64)
@@ -73,6 +83,7 @@ CHUNK_CASES = {
     'dense_w_gt_64':  dict(n=3000, a=0, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=2000, loci='dense'),
     'dense_small_bp': dict(n=3000, a=0, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=300, loci='dense'),
     'equal_loci':     dict(n=1500, a=0, samples=[0, 1], pcount=15.0, max_cpg=1000, max_bp=2000, loci='equal_runs'),
+    'island_mix':     dict(n=20000, a=0, samples=[0, 1, 2, 3], pcount=15.0, max_cpg=1000, max_bp=2000, loci='hg19like_islands'),
     'deep':           dict(n=6000, a=120000, samples=[0, 1, 2, 3], pcount=15.0, max_cpg=5000, max_bp=100000000),
     'n33_samples':    dict(n=2000, a=130000, samples=list(range(33)), pcount=15.0, max_cpg=1000, max_bp=2000),
     'default_chunk':  dict(n=60000, a=200000, samples=list(range(8)), pcount=15.0, max_cpg=1000, max_bp=2000),

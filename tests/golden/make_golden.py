@@ -33,6 +33,20 @@ def gen_chunk_cases():
     oracle.build(ref=True)
     assert oracle.have_ref(), 'reference binary not built'
     out = {}
+    only = [a for a in sys.argv[1:] if a.startswith('case=')]
+    if only:                                               # add / refresh single cases without touching the others
+        with open(op.join(HERE, 'chunk_cases.json')) as f:
+            out = json.load(f)
+        for o in only:
+            name = o[5:]
+            spec = cases.CHUNK_CASES[name]
+            slices, loci = cases.build_case(spec)
+            b = oracle.ref_segment_arrays(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp'])
+            out[name] = dict(spec=spec, input_crc32=cases.case_checksum(slices, loci), borders=b.tolist())
+            print('%-16s n=%-6d N=%-3d borders=%d' % (name, spec['n'], len(spec['samples']), len(b)), flush=True)
+        with open(op.join(HERE, 'chunk_cases.json'), 'w') as f:
+            json.dump(out, f, separators=(',', ':'))
+        return
     for name, spec in cases.CHUNK_CASES.items():
         slices, loci = cases.build_case(spec)
         b = oracle.ref_segment_arrays(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp'])
@@ -63,7 +77,7 @@ def gen_chunk_cases():
 
 
 if __name__ == '__main__':
-    what = sys.argv[1:] or ['chunks', 'driver']
+    what = [a for a in sys.argv[1:] if not a.startswith('case=')] or ['chunks', 'driver']
     if 'chunks' in what:
         gen_chunk_cases()
     if 'driver' in what:

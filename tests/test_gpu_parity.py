@@ -141,7 +141,7 @@ def _numpy_windows(loci, max_cpg, max_bp):
     return (hi - k + 1).astype(np.int64)
 
 
-@pytest.mark.parametrize('name', ['tiny', 'max_cpg_binds', 'dense_w_gt_64', 'equal_loci', 'zero_stretch', 'deep'])
+@pytest.mark.parametrize('name', ['tiny', 'max_cpg_binds', 'dense_w_gt_64', 'equal_loci', 'zero_stretch', 'island_mix', 'deep'])
 def test_05_intermediates_match_oracle(name, golden_chunks):
     os.environ['WGBSSEG_FORCE_STAGES'] = '1'
     try:

@@ -182,6 +182,6 @@ if __name__ == '__main__':
                     want = P[min(k + x, ln)]
                     assert (dst[x] == want).all(), (start0, ln, A, cnt, x, dst[x], want)
     print('scan/stage emulation ok')
-    for nm in ['tiny', 'n1', 'n2', 'n65', 'max_cpg2', 'max_cpg_binds', 'dense_w_gt_64', 'dense_small_bp', 'equal_loci']:
+    for nm in ['tiny', 'n1', 'n2', 'n65', 'max_cpg2', 'max_cpg_binds', 'dense_w_gt_64', 'dense_small_bp', 'equal_loci', 'island_mix']:
         run_case(nm)
     run_case('tiny', S=64); run_case('dense_w_gt_64', S=128); run_case('max_cpg_binds', S=192)

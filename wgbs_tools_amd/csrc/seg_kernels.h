@@ -580,9 +580,10 @@ __device__ __forceinline__ void wg_dp_load_batch(const double* __restrict__ cb, 
     }
 }
 
-// One step of the fast path: fold M[k] into the 64 pending steps, read M[k+1] off lane `stp`, free that lane.
+// One step of the fast path: fold M[k] into the 64 pending steps, read M[k+1] off lane `stp`, and let that lane move
+// on to step k+64 with whatever earlier, longer blocks have parked for it (pb, pa; -inf when nothing was parked).
 __device__ __forceinline__ void wg_dp_fast_step(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double cv,
-                                                const int k, const int stp, const int lane)
+                                                const int k, const int stp, const int lane, const double pb, const int32_t pa)
 {
     const double cand = Mk + cv;
     const bool upd = cand > best;                      // strict: the first maximum wins (segmentor.cpp:148)
@@ -592,7 +593,8 @@ __device__ __forceinline__ void wg_dp_fast_step(double& best, int32_t& arg, uint
     const int ak = __builtin_amdgcn_readlane(arg, stp);
     const bool mine = lane == stp;                     // this lane moves on to step k+64
     tbk = mine ? (uint32_t)(k + 1 - ak) : tbk;
-    best = mine ? -__builtin_inf() : best;
+    best = mine ? pb : best;
+    arg = mine ? pa : arg;
 }
 
 // state saved between stages, per chunk: [0] M[k] of the next step, [1..64] best, then 64 args (as doubles' bits),
@@ -655,19 +657,29 @@ __global__ __launch_bounds__(64 * (1 + WG_DP_LOADERS)) void k_dp(JobView J, Stag
             const DpMeta* meta = metas + (b & 1);
             const double* slot = slots + (size_t)(b & 1) * A.slot_cap;
             uint32_t tbk = 0;
-            if (meta->simple && !wide) {
+            if (meta->simple) {
                 // ---- fast path: 64 steps out of the arranged slot, 8 at a time, next 8 rows already in flight ----
+                // No step of this batch reaches beyond 64 sites, so what longer blocks of EARLIER batches parked for
+                // the steps base+64 .. base+127 is final: each lane fetches its hand-over value once, up front.
+                double pb = NEG_INF;
+                int32_t pa = 0;
+                if (wide) {
+                    const int slotx = (base + lane + 64) & rmask;
+                    pb = pendB[slotx]; pa = pendA[slotx];
+                    pendB[slotx] = NEG_INF;
+                }
                 const double* my = slot + lane;
                 double cur[8], nxt[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) cur[u] = my[u * 64];
+#pragma unroll 1
                 for (int g = 0; g < 64; g += 8) {
                     if (g + 8 < 64) {
 #pragma unroll
                         for (int u = 0; u < 8; u++) nxt[u] = my[(g + 8 + u) * 64];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; u++) wg_dp_fast_step(best, arg, tbk, Mk, cur[u], base + g + u, g + u, lane);
+                    for (int u = 0; u < 8; u++) wg_dp_fast_step(best, arg, tbk, Mk, cur[u], base + g + u, g + u, lane, pb, pa);
 #pragma unroll
                     for (int u = 0; u < 8; u++) cur[u] = nxt[u];
                 }

@@ -488,8 +488,9 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     sv.S = S;
     // LDS of k_dp: pend ring (wide windows only) + two staged batches of scored-block rows (64 steps x up to 64 ends) + metadata
     int slot_cap = 4096;                                     // 64 steps x 64 lanes: the arranged form of one batch
-    if (wide) slot_cap = 2048;                               // wide windows: contiguous staging only; longer rows come from HBM
     const size_t lds_ring = (size_t)ringN * 12 + 8;
+    // keep two workgroups per CU when possible; a very wide ring (deep mode) leaves room for contiguous staging only
+    if (lds_ring + 4096 * 16 + 2 * sizeof(DpMeta) > 80 * 1024) slot_cap = 2048;
     while (slot_cap > 64 && lds_ring + (size_t)slot_cap * 16 + 2 * sizeof(DpMeta) > 150 * 1024) slot_cap /= 2;
     DpArgs da = {ringN, slot_cap, wide ? 1 : 0, 0};
     const size_t lds_dp = lds_ring + (size_t)slot_cap * 16 + 2 * sizeof(DpMeta);
