@@ -154,6 +154,21 @@ WG_HD double   wg_u2d(uint64_t u) { double d;   memcpy(&d, &u, 8); return d; }
 
 #define WG_FMA(a, b, c) __builtin_fma((a), (b), (c))     // one IEEE fused multiply-add (v_fma_f64 on the device)
 
+// a*b + K with K a compile-time constant (a polynomial coefficient).  Same IEEE operation as WG_FMA; on the device it
+// is spelled as the 3-operand VOP3 form with K in a scalar register pair, because hipcc otherwise emits
+// v_mov_b64 tmp, K ; v_fmac_f64 tmp, a, b  for every Horner step (the fmac form overwrites its addend).
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ double wg_fma_k(double a, double b, double k)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+    return d;
+}
+#define WG_FMA_K(a, b, k) wg_fma_k((a), (b), (k))
+#else
+#define WG_FMA_K(a, b, k) __builtin_fma((a), (b), (k))
+#endif
+
 // glibc 2.35 __log2f (sysdeps/ieee754/flt-32/e_log2f.c), positive finite inputs.  x == 1 -> +0.
 // Evaluated without any fused multiply-add, operation by operation as the generic C source reads.
 WG_HD float wg_log2f_nofma(float x, const wg_d2* __restrict__ ftab)
@@ -216,10 +231,10 @@ WG_HD float wg_log2f_normal(float x, const wg_d2* __restrict__ ftab)
     const uint32_t iz = ix - (tmp & 0xff800000u);
     const int32_t k = (int32_t)tmp >> 23;
     const double invc = ftab[i].a, logc = ftab[i].b;
-    const double r = WG_FMA((double)wg_u2f(iz), invc, -1.0);
+    const double r = WG_FMA_K((double)wg_u2f(iz), invc, -1.0);
     const double y0 = logc + (double)k;
     const double r2 = r * r;
-    double y = WG_FMA(WG_LOG2F_A1, r, WG_LOG2F_A2);
+    double y = WG_FMA_K(r, WG_LOG2F_A1, WG_LOG2F_A2);          // (same products as A1*r + A2 etc.: multiplication commutes exactly)
     y = WG_FMA(WG_LOG2F_A0, r2, y);
     const double p = WG_FMA(WG_LOG2F_A3, r, y0);
     return (float)WG_FMA(y, r2, p);
@@ -297,10 +312,10 @@ WG_HD double wg_fast_log2(double x, const wg_d2* __restrict__ dfast)
     const int32_t k = (int32_t)hi >> 20;
     const uint64_t iz = ix - ((uint64_t)(hi & 0xfff00000u) << 32);
     const double invc = dfast[i].a, logc = dfast[i].b;
-    const double r = WG_FMA(wg_u2d(iz), invc, -1.0);
+    const double r = WG_FMA_K(wg_u2d(iz), invc, -1.0);
     double q = WG_LOG2_A5;
-    q = WG_FMA(q, r, WG_LOG2_A4); q = WG_FMA(q, r, WG_LOG2_A3); q = WG_FMA(q, r, WG_LOG2_A2);
-    q = WG_FMA(q, r, WG_LOG2_A1); q = WG_FMA(q, r, WG_LOG2_A0); q = WG_FMA(q, r, WG_LOG2_INVLN2);
+    q = WG_FMA_K(q, r, WG_LOG2_A4); q = WG_FMA_K(q, r, WG_LOG2_A3); q = WG_FMA_K(q, r, WG_LOG2_A2);
+    q = WG_FMA_K(q, r, WG_LOG2_A1); q = WG_FMA_K(q, r, WG_LOG2_A0); q = WG_FMA_K(q, r, WG_LOG2_INVLN2);
     return WG_FMA(q, r, (double)k + logc);
 }
 
