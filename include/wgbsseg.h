@@ -171,6 +171,9 @@ int wgbsseg_debug_sample_terms(wgbsseg_ctx* ctx, const float* nmeth, const float
                                float pseudo_count, float* out);
 int wgbsseg_debug_log2(wgbsseg_ctx* ctx, uint32_t first_bits, int64_t count, uint32_t* out_f, uint64_t* out_d,
                        uint64_t* out_fast);
+/* wgbsseg_debug_div: the scoring kernel's 8-instruction fp32 division core and the compiler's IEEE `/`, both evaluated
+ * on the device for `count` operand pairs (uint32 bit patterns out). */
+int wgbsseg_debug_div(wgbsseg_ctx* ctx, const float* a, const float* b, int64_t count, uint32_t* out_fast, uint32_t* out_ieee);
 
 #ifdef __cplusplus
 }

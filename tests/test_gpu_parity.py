@@ -100,6 +100,27 @@ def test_02_device_sample_term_matches_oracle(seg, pcount):
     assert _first_diff(got.view(np.uint32), want.view(np.uint32)) is None, _first_diff(got.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize('pcount', [15.0, 0.0, 0.5, 1.0, 2e-6, 3.25])
+def test_02b_division_core_equals_ieee_division(seg, pcount):
+    """p = (nmeth+pc)/(ntotal+2pc): the kernel's 8-instruction division core vs the compiler's IEEE `/`, on the device,
+    for EVERY (nmeth, ntotal) with ntotal <= 4000 (8 M pairs) plus 8 M random pairs up to 255*1000."""
+    pc = np.float32(pcount)
+    t = np.repeat(np.arange(1, 4001, dtype=np.int64), np.arange(2, 4002))
+    m = np.concatenate([np.arange(0, tt + 1) for tt in range(1, 4001)])
+    rng = np.random.default_rng(3)
+    t2 = rng.integers(1, 255 * 1000 + 1, 8000000)
+    m2 = (rng.random(t2.size) * (t2 + 1)).astype(np.int64)
+    t = np.concatenate([t, t2]).astype(np.float32)
+    m = np.minimum(np.concatenate([m, m2]), t).astype(np.float32)
+    a = (m + pc).astype(np.float32)
+    b = (t + (pc + pc)).astype(np.float32)
+    fast, ieee = seg.debug_div(a, b)
+    assert _first_diff(fast, ieee) is None, _first_diff(fast, ieee)
+    # and the device's IEEE division is numpy's
+    want = (a / b).astype(np.float32).view(np.uint32)
+    assert _first_diff(ieee, want) is None
+
+
 # ---------------------------------------------------------------------------------------------------------
 # 2. scan pass
 # ---------------------------------------------------------------------------------------------------------

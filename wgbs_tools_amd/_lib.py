@@ -18,7 +18,8 @@ OK, E_ARG, E_METH_GT_COV, E_NOMEM, E_HIP, E_LOCI_ORDER, E_CAPACITY, E_STATE = 0,
 EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg_destroy',
            'wgbsseg_set_betas_host', 'wgbsseg_set_betas_device', 'wgbsseg_set_loci_host', 'wgbsseg_set_loci_device',
            'wgbsseg_segment_chunks', 'wgbsseg_segment_regions', 'wgbsseg_segment_chunks_host', 'wgbsseg_prefix_sums', 'wgbsseg_scan_only',
-           'wgbsseg_get_timings', 'wgbsseg_debug_fetch', 'wgbsseg_debug_sample_terms', 'wgbsseg_debug_log2']
+           'wgbsseg_get_timings', 'wgbsseg_debug_fetch', 'wgbsseg_debug_sample_terms', 'wgbsseg_debug_log2',
+           'wgbsseg_debug_div']
 
 
 class NativeLibraryError(RuntimeError):
@@ -126,6 +127,8 @@ def load():
     L.wgbsseg_debug_sample_terms.argtypes = [vp, vp, vp, i64, C.c_float, vp]
     L.wgbsseg_debug_log2.restype = i32
     L.wgbsseg_debug_log2.argtypes = [vp, C.c_uint32, i64, vp, vp, vp]
+    L.wgbsseg_debug_div.restype = i32
+    L.wgbsseg_debug_div.argtypes = [vp, vp, vp, i64, vp, vp]
     _lib = L
     return L
 
@@ -278,6 +281,16 @@ class Segmenter:
         if rc != OK:
             raise SegmentorError(rc, 'debug_sample_terms failed')
         return out
+
+    def debug_div(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        f = np.empty(a.size, dtype=np.uint32)
+        g = np.empty(a.size, dtype=np.uint32)
+        rc = self._L.wgbsseg_debug_div(self._h, a.ctypes.data, b.ctypes.data, a.size, f.ctypes.data, g.ctypes.data)
+        if rc != OK:
+            raise SegmentorError(rc, 'debug_div failed')
+        return f, g
 
     def debug_log2(self, first_bits, count, want_f=True, want_d=True, want_fast=False):
         f = np.empty(count, dtype=np.uint32) if want_f else None

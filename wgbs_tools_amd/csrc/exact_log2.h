@@ -345,6 +345,27 @@ WG_HD float wg_sample_term_plain(float nmeth, float ntotal, float pc, float pc2,
 // lies within 6 ulp of a float rounding midpoint (low 29 mantissa bits == 2^28); we use a 16-ulp guard band, and in
 // that band (probability 2^-24 per evaluation) the exact restatement decides.  When ntotal == nmeth the reference adds -0.0 and ll is unchanged.
 #define WG_GUARD_ULPS 16u
+// IEEE-754 binary32 division a / b for operands in a "comfortable" range (0 <= a <= b, 2^-20 <= b < 2^26, or a == 0).
+// On the device this is the core of the sequence hipcc emits for `/` (v_rcp_f32, one Newton step on the reciprocal,
+// two residual corrections of the quotient) WITHOUT v_div_scale (a no-op unless an operand or the quotient sits near
+// the exponent limits) and v_div_fixup (special values only): 8 instructions instead of 11, same intermediate values,
+// hence the same correctly rounded quotient.  tests/test_gpu_parity.py::test_02b compares it with `/` on the device.
+WG_HD float wg_div_f32(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = a * r;
+    float res = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(res, r, q);
+    res = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(res, r, q);
+#else
+    return a / b;
+#endif
+}
+
 // Preconditions of the fast form (the library dispatches on them; otherwise wg_sample_term_plain is used):
 // pc == 0 or pc >= WG_FAST_MIN_PC.  Then (a) p == 0 exactly or p >= 2^-45: p is a normal float and, when p > 0,
 // x = 1 - p < 1 strictly (wg_fast_log2's domain); (b) every non-zero sum is >= 2^-60 in magnitude, so the float
@@ -355,7 +376,7 @@ WG_HD float wg_sample_term(float nmeth, float ntotal, float pc, float pc2, const
                            const wg_log_tables* __restrict__ xt)
 {
     if (ntotal == 0.0f) return 0.0f;                               // :125
-    const float p = (nmeth + pc) / (ntotal + pc2);                 // :127
+    const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127 (pc == 0 or pc >= 2^-20: operands in range)
     float ll = 0.0f;
     if (p > 0.0f) {
         ll += nmeth * wg_log2f_normal(p, ft->f_tab);               // :129-131

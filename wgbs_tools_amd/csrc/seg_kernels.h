@@ -820,6 +820,15 @@ __global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, f
         out[q] = fast ? wg_sample_term(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables) : wg_sample_term_plain(nm[q], nt[q], pc, pc2, &g_wg_tables);
 }
 
+// test hook: wg_div_f32 vs the compiler's IEEE division, both on the device
+__global__ void k_debug_div(const float* a, const float* b, int64_t count, uint32_t* out_fast, uint32_t* out_ieee)
+{
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x) {
+        out_fast[q] = wg_f2u(wg_div_f32(a[q], b[q]));
+        out_ieee[q] = wg_f2u(a[q] / b[q]);
+    }
+}
+
 __global__ void k_debug_log2(uint32_t first, int64_t count, uint32_t* out_f, uint64_t* out_d, uint64_t* out_fast)
 {
     __shared__ wg_fast_tables tb;

@@ -709,6 +709,25 @@ int wgbsseg_debug_sample_terms(wgbsseg_ctx* c, const float* nmeth, const float* 
     return WGBSSEG_OK;
 }
 
+int wgbsseg_debug_div(wgbsseg_ctx* c, const float* a, const float* b, int64_t count, uint32_t* out_fast, uint32_t* out_ieee)
+{
+    char* err = nullptr; size_t errlen = 0;
+    if (!c || !a || !b || !out_fast || !out_ieee || count < 1) return WGBSSEG_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->dbg_a.ensure((size_t)count * 8)); HIP_TRY(c->dbg_b.ensure((size_t)count * 8));
+    float* da = c->dbg_a.as<float>(); float* db = da + count;
+    uint32_t* o1 = c->dbg_b.as<uint32_t>(); uint32_t* o2 = o1 + count;
+    HIP_TRY(hipMemcpyAsync(da, a, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
+    HIP_TRY(hipMemcpyAsync(db, b, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
+    const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_debug_div, dim3(blocks), dim3(256), 0, c->sA, da, db, count, o1, o2);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_fast, o1, (size_t)count * 4, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipMemcpyAsync(out_ieee, o2, (size_t)count * 4, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    return WGBSSEG_OK;
+}
+
 int wgbsseg_debug_log2(wgbsseg_ctx* c, uint32_t first_bits, int64_t count, uint32_t* out_f, uint64_t* out_d, uint64_t* out_fast)
 {
     char* err = nullptr; size_t errlen = 0;
