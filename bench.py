@@ -46,6 +46,7 @@ def parse():
     ap.add_argument('--max-cpg', type=int, default=1000)
     ap.add_argument('--max-bp', type=int, default=2000)
     ap.add_argument('--pcount', type=float, default=15.0)
+    ap.add_argument('--islands', action='store_true', help='add CpG islands to the synthetic loci (windows of several hundred sites; not the BASELINE workload)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target wall time of the CPU baseline sample (0: skip)')
     return ap.parse_args()
 
@@ -149,7 +150,7 @@ def main():
 
     names, sizes = synth.genome_shape(args.sites, 25 if args.sites >= 2500000 else max(1, min(25, args.sites // 100000)))
     sizes = [int(s) for s in sizes]
-    loci = synth.synth_loci(SEED, sizes)
+    loci = synth.synth_loci(SEED, sizes, islands=args.islands)
     max_cpg = min(args.max_cpg, args.max_bp // 2)            # segment.py:65
     params = dict(max_cpg=max_cpg)
 
@@ -228,8 +229,8 @@ def main():
             'dtype': 'u8 counts -> u32 prefix sums -> f32/f64 log-likelihood (bit-exact with the reference)',
             'data': 'synthetic (seeded hg19-shaped genome and betas, generated on the device)',
             'config': {'workload': 'hg19-shaped %d CpGs x %d betas, whole-genome segment, chunk_size %d, max_cpg %d, max_bp %d, pcount %g'
-                                   % (args.sites, args.samples, args.chunk, args.max_cpg, args.max_bp, args.pcount),
-                       'baseline_config': 'BASELINE.json configs[2]' if (args.sites, args.samples) == (28217448, 32) else 'custom',
+                                   % (args.sites, args.samples, args.chunk, args.max_cpg, args.max_bp, args.pcount) + (' + CpG islands in the loci' if args.islands else ''),
+                       'baseline_config': 'BASELINE.json configs[2]' if (args.sites, args.samples, args.islands) == (28217448, 32, False) else 'custom',
                        'chunks': n_chunks_total, 'chromosomes': len(sizes), 'sharding': 'contiguous chunk ranges per rank, no collective',
                        'rank0_sites': my_sites, 'rank0_stats': stats, 'rank0_blocks': n_blocks},
             'roofline': {'kernel': 'k_scan (per-sample prefix scan + meth<=cov validation)', 'bound': 'hbm',

@@ -83,8 +83,10 @@ CHUNK_CASES = {
     'dense_w_gt_64':  dict(n=3000, a=0, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=2000, loci='dense'),
     'dense_small_bp': dict(n=3000, a=0, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=300, loci='dense'),
     'equal_loci':     dict(n=1500, a=0, samples=[0, 1], pcount=15.0, max_cpg=1000, max_bp=2000, loci='equal_runs'),
+    'dense_bp500':    dict(n=5000, a=0, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=500, loci='dense'),
     'island_mix':     dict(n=20000, a=0, samples=[0, 1, 2, 3], pcount=15.0, max_cpg=1000, max_bp=2000, loci='hg19like_islands'),
     'deep':           dict(n=6000, a=120000, samples=[0, 1, 2, 3], pcount=15.0, max_cpg=5000, max_bp=100000000),
+    'deep_long':      dict(n=20000, a=300000, samples=[0, 1, 2], pcount=15.0, max_cpg=3000, max_bp=100000000),
     'n33_samples':    dict(n=2000, a=130000, samples=list(range(33)), pcount=15.0, max_cpg=1000, max_bp=2000),
     'default_chunk':  dict(n=60000, a=200000, samples=list(range(8)), pcount=15.0, max_cpg=1000, max_bp=2000),
 }

@@ -231,6 +231,37 @@ def test_07_staging_does_not_change_borders(stages, golden_chunks):
         sg.close()
 
 
+@pytest.mark.parametrize('mode,stages', [(1, 0), (2, 0), (1, 3), (2, 2), (1, 64)])
+def test_07b_wide_window_recurrence_on_every_case(mode, stages, golden_chunks):
+    """The recurrence has three builds (64-step batches; 32-step batches with a second pending register and worker
+    pushes for blocks > 128 sites; the same with 15 worker waves).  The launcher picks by the job's widest window;
+    here the wide builds are forced onto EVERY golden case, alone and across stage boundaries."""
+    os.environ['WGBSSEG_DP_MODE'] = str(mode)
+    if stages: os.environ['WGBSSEG_FORCE_STAGES'] = str(stages)
+    try:
+        sg = _lib.Segmenter(0)
+    finally:
+        del os.environ['WGBSSEG_DP_MODE']
+        os.environ.pop('WGBSSEG_FORCE_STAGES', None)
+    try:
+        for name in cases.CHUNK_CASES:
+            g = golden_chunks[name]
+            spec = g['spec']
+            _load_case(sg, spec)
+            got = sg.segment_chunks([0], [spec['n']], spec['pcount'], spec['max_cpg'], spec['max_bp'])[0]
+            assert got.tolist() == g['borders'], '%s, dp mode %d, %d stages: %s' % (name, mode, stages, _first_diff(got, np.array(g['borders'])))
+        g = golden_chunks['chr21']
+        spec = g['spec']
+        _load_case(sg, spec)
+        starts = np.array(g['starts'], dtype=np.int64)
+        lens = np.minimum(spec['chunk'], spec['n'] - starts).astype(np.int32)
+        res = sg.segment_chunks(starts, lens, spec['pcount'], spec['max_cpg'], spec['max_bp'])
+        for c, (got, want) in enumerate(zip(res, g['borders'])):
+            assert got.tolist() == want, 'chr21 chunk %d, dp mode %d: %s' % (c, mode, _first_diff(got, np.array(want)))
+    finally:
+        sg.close()
+
+
 def test_08_chr21_shaped_multichunk_matches_reference_golden(seg, golden_chunks):
     """BASELINE.json configs[1]: 400,000 CpGs x 8 betas, default chunk grid, bit-exact vs the CPU reference."""
     g = golden_chunks['chr21']

@@ -73,65 +73,144 @@ def emu_stage_row(row, carry, start0, ln, A, cnt, x0=0):
         run = run + incl[63]
     return dst
 
-def emu_cost_tiles(F, n, S, stage, TI, KT, TK, Fmax, start0=0):
-    """k_cost tile decomposition (start-major) for one chunk: yields pairs (k,i) per tile; checks E/S array bounds."""
+def emu_tile_plan(F, n, S, stage, TI, WA, TK):
+    """k_tile_count / k_tile_emit for one chunk: -> (narrow tiles [(ka, nk)], wide tiles [(k0, nk, et_lo)])"""
     s0 = stage * S; s1 = min(s0 + S, n)
-    if s0 >= n: return
-    KS = TK + 1 if KT > 1 else TI + Fmax + 1
-    IS = TI + 1 if KT > 1 else 0
-    ntile = (s1 - s0 + TI - 1) // TI * KT
-    for local in range(ntile):
-        kti, et = divmod(local, KT)
-        ka = s0 + kti * TI; kb = min(ka + TI, s1); nk = kb - ka
-        et_lo = ka + et * TK if KT > 1 else 0
-        et_hi = et_lo + TK if KT > 1 else (1 << 30)
-        pairs = []; imin = None; imax = None
-        for kl in range(nk):
-            k = ka + kl
-            is_ = max(k, et_lo); ie = min(k + F[k], et_hi) - 1
-            if ie >= is_:
-                imin = is_ if imin is None else min(imin, is_); imax = ie if imax is None else max(imax, ie)
-                pairs += [(k, i) for i in range(is_, ie + 1)]
-        if not pairs: continue
-        eA = imin + 1 if KT > 1 else ka
-        eG = group_start(start0, eA); assert 0 <= eA - eG <= 63
-        Ecnt = imax + 2 - eA
-        assert 0 < Ecnt <= KS, (Ecnt, KS)
-        if KT > 1:
-            sA = ka; Scnt = kb - sA
-            assert Scnt <= IS
-            for (k, i) in pairs: assert 0 <= i + 1 - eA < Ecnt and 0 <= k - sA < Scnt
+    A, B = [], []
+    if s0 >= n: return A, B
+    umax = [int(F[u * 16:min(u * 16 + 16, n)].max()) for u in range((n + 15) // 16)]
+    for ka in range(s0, s1, TI):
+        kb = min(ka + TI, s1)
+        units = [(k0, min(16, kb - k0), umax[k0 >> 4]) for k0 in range(ka, kb, 16)]
+        if max(u[2] for u in units) <= WA:
+            A.append((ka, kb - ka))
         else:
-            for (k, i) in pairs: assert 0 <= i + 1 - eA < Ecnt and 0 <= k - eA < Ecnt
-        assert len(pairs) <= 4096, len(pairs)
-        yield pairs
+            for (k0, nk, um) in units:
+                kt = (nk - 1 + um + TK - 1) // TK
+                B += [(k0, nk, k0 + e * TK) for e in range(kt)]
+    return A, B
 
-def emu_dp(F, cum, cost, n, S):
-    """k_dp push form over all stages; cost start-major CSR. Returns back array."""
-    Fmax = int(F.max()); wide = Fmax > 64
+def emu_cost_tiles(F, n, S, stage, TI, WA, TK, start0=0):
+    """k_cost tile decomposition (start-major) for one chunk: yields pairs (k,i) per tile; checks E/S array bounds."""
+    A, B = emu_tile_plan(F, n, S, stage, TI, WA, TK)
+    for split, tiles in ((False, [(ka, nk, 0) for (ka, nk) in A]), (True, B)):
+        KS = TK + 1 if split else TI + WA + 1
+        IS = 17 if split else 0
+        for (ka, nk, et_lo) in tiles:
+            kb = ka + nk
+            if not split: et_lo = 0
+            et_hi = et_lo + TK if split else (1 << 30)
+            pairs = []; imin = None; imax = None
+            for kl in range(nk):
+                k = ka + kl
+                is_ = max(k, et_lo); ie = min(k + F[k], et_hi) - 1
+                if ie >= is_:
+                    imin = is_ if imin is None else min(imin, is_); imax = ie if imax is None else max(imax, ie)
+                    pairs += [(k, i) for i in range(is_, ie + 1)]
+            if not pairs: continue
+            eA = imin + 1 if split else ka
+            eG = group_start(start0, eA); assert 0 <= eA - eG <= 63
+            Ecnt = imax + 2 - eA
+            assert 0 < Ecnt <= KS, (Ecnt, KS)
+            if split:
+                sA = ka; Scnt = kb - sA
+                assert Scnt <= IS
+                for (k, i) in pairs: assert 0 <= i + 1 - eA < Ecnt and 0 <= k - sA < Scnt
+            else:
+                for (k, i) in pairs: assert 0 <= i + 1 - eA < Ecnt and 0 <= k - eA < Ecnt
+            assert len(pairs) <= 4096, len(pairs)
+            yield pairs
+
+NEG = -np.inf
+
+def emu_dp(F, cum, cost, n, S, BL=32):
+    """k_dp<NW, BL> over all stages: push form with two pending registers per lane, worker pushes for blocks > 128
+    sites one batch behind the recurrence, ring merge at the start of the finishing batch.  Returns back array."""
+    Fmax = int(F.max())
     ringN = 1
-    while ringN < Fmax + 64: ringN <<= 1
+    while ringN < Fmax + 2 * BL: ringN <<= 1
     rmask = ringN - 1
-    pendB = np.full(ringN, -np.inf); pendA = np.zeros(ringN, dtype=np.int64)
-    best = np.full(64, -np.inf); arg = np.zeros(64, dtype=np.int64); back = np.zeros(n, dtype=np.int64)
+    pendB = np.full(ringN, NEG); pendA = np.zeros(ringN, dtype=np.int64)
+    bestA = np.full(64, NEG); argA = np.zeros(64, dtype=np.int64)
+    bestB = np.full(64, NEG); argB = np.zeros(64, dtype=np.int64)
+    Mring = np.full(128, np.nan)
+    back = np.zeros(n, dtype=np.int64)
     Mk = 0.0
-    for k in range(n):
-        f = int(F[k]); stp = k & 63
-        for lane in range(64):
-            j = (lane - stp) & 63
-            if j < f:
-                cand = Mk + cost[cum[k] + j]
-                if cand > best[lane]: best[lane] = cand; arg[lane] = k
-        if f > 64:
-            for jj in range(64, f):
-                sl = (k + jj) & rmask; cd = Mk + cost[cum[k] + jj]
-                if cd > pendB[sl]: pendB[sl] = cd; pendA[sl] = k
-        Mk = best[stp]
-        back[k] = k + 1 - arg[stp]
-        best[stp] = -np.inf
-        if wide:
-            sl = (k + 64) & rmask
-            best[stp] = pendB[sl]; arg[stp] = pendA[sl]; pendB[sl] = -np.inf
+    def far(base, s1):
+        # workers: far pushes (j >= 128) of the sources of batch [base, base+BL)
+        ks = [k for k in range(base, min(base + BL, s1))]
+        fm = max([int(F[k]) for k in ks] + [0])
+        if fm <= 128: return []
+        touched = []
+        for t in range(base + 128, base + BL - 1 + fm):
+            b_, a_ = pendB[t & rmask], pendA[t & rmask]
+            for k in ks:
+                j = t - k
+                if j >= 128 and j < F[k]:
+                    cand = Mring[k & 127] + cost[cum[k] + j]
+                    if cand > b_: b_ = cand; a_ = k
+            pendB[t & rmask] = b_; pendA[t & rmask] = a_; touched.append(t)
+        return touched
+    for s0 in range(0, n, S):
+        s1 = min(s0 + S, n)
+        nb = (s1 - s0 + BL - 1) // BL
+        Mring[s0 & 127] = Mk
+        # pend of batch 0's steps
+        lanes0 = [(s0 + x) & 63 for x in range(BL)]
+        pb = np.full(64, NEG); pa = np.zeros(64, dtype=np.int64)
+        for x in range(BL):
+            t = s0 + x; pb[t & 63] = pendB[t & rmask]; pa[t & 63] = pendA[t & rmask]; pendB[t & rmask] = NEG
+        for b in range(nb):
+            base = s0 + b * BL
+            # merge
+            for x in range(BL):
+                l = (base + x) & 63
+                if pb[l] >= bestA[l] and pb[l] > NEG: bestA[l] = pb[l]; argA[l] = pa[l]
+            # prefetch the pend entries of batch b+1 (as early as the hardware could do it)
+            npb = np.full(64, NEG); npa = np.zeros(64, dtype=np.int64); pre = []
+            if b + 1 < nb:
+                for x in range(BL):
+                    t = base + BL + x; npb[t & 63] = pendB[t & rmask]; npa[t & 63] = pendA[t & rmask]; pendB[t & rmask] = NEG; pre.append(t & rmask)
+            # workers: far work of batch b-1, concurrently
+            if b >= 1:
+                tt = far(base - BL, s1)
+                assert not (set(x & rmask for x in tt) & set(pre)), 'far work races with the prefetch'
+            # DP wave: BL steps
+            wideb = max(int(F[k]) for k in range(base, min(base + BL, s1))) > 64
+            Mfin = np.full(64, np.nan)
+            for s in range(BL):
+                k = base + s
+                if k >= s1: break
+                f = int(F[k]); stp = k & 63
+                for lane in range(64):
+                    j = (lane - k) & 63
+                    if j < f:
+                        cand = Mk + cost[cum[k] + j]
+                        if cand > bestA[lane]: bestA[lane] = cand; argA[lane] = k
+                    if wideb and j + 64 < f:
+                        cand = Mk + cost[cum[k] + j + 64]
+                        if cand > bestB[lane]: bestB[lane] = cand; argB[lane] = k
+                Mk = bestA[stp]; back[k] = k + 1 - argA[stp]
+                Mfin[stp] = Mk
+                bestA[stp] = bestB[stp]; argA[stp] = argB[stp]; bestB[stp] = NEG
+                Mring[(k + 1) & 127] = Mk
+            pb, pa = npb, npa
+        # far work of the stage's last batch
+        far(s0 + (nb - 1) * BL, s1)
+    return back
+
+def plain_dp(F, cum, cost, n):
+    """segmentor.cpp:142-154 as written (pull form, ascending k, strict '>')"""
+    M = np.zeros(n + 1); back = np.zeros(n, dtype=np.int64)
+    # pull form, ascending k strict >
+    lo = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        best = NEG; arg = -1
+        for k in range(max(0, i - 6000), i + 1):
+            if i - k < F[k]:
+                v = M[k] + cost[cum[k] + i - k]
+                if v > best: best = v; arg = k
+        M[i + 1] = best; back[i] = i + 1 - arg
     return back
 
 def run_case(name, S=None, TIsel=None):
@@ -144,21 +223,19 @@ def run_case(name, S=None, TIsel=None):
     for k in range(0, n, max(1, n // 200)):
         row = band[k, :min(max_cpg, n - k)]
         assert np.isfinite(row[:F[k]]).all() and not np.isfinite(row[F[k]:]).any()
-    if Fmax <= 64: TI, KT, TK = 64, 1, 0
-    elif Fmax <= 128: TI, KT, TK = 32, 1, 0
-    elif Fmax <= 256: TI, KT, TK = 16, 1, 0
-    else: TI, TK = 16, 256; KT = (Fmax - 1 + TI + TK - 1) // TK
+    TI = TIsel or 64; WA = min(Fmax, 64); TK = 128
     if S is None: S = ((n + 63) // 64) * 64
     seen = np.zeros(int(F.sum()), dtype=np.int32)
     for stage in range((n + S - 1) // S):
-        for pairs in emu_cost_tiles(F, n, S, stage, TI, KT, TK, Fmax, start0=spec['a']):
+        for pairs in emu_cost_tiles(F, n, S, stage, TI, WA, TK, start0=spec['a']):
             for (k, i) in pairs: seen[cum[k] + i - k] += 1
     assert (seen == 1).all(), 'tile coverage broken'
     cost = np.empty(int(F.sum()))
     for k in range(n): cost[cum[k]:cum[k] + F[k]] = band[k, :F[k]]
-    back = emu_dp(F, cum, cost, n, S)
+    back = emu_dp(F, cum, cost, n, S, 64 if Fmax <= 64 else 32)
+    assert (emu_dp(F, cum, cost, n, S, 32) == back).all()
     assert (back == np.arange(1, n + 1) - T[1:]).all(), 'dp emulation differs'
-    print(name, 'ok: Fmax', Fmax, 'TI', TI, 'KT', KT, 'S', S)
+    print(name, 'ok: Fmax', Fmax, 'TI', TI, 'WA', WA, 'S', S)
 
 if __name__ == '__main__':
     # scan carries + staged prefix rows
@@ -182,6 +259,20 @@ if __name__ == '__main__':
                     want = P[min(k + x, ln)]
                     assert (dst[x] == want).all(), (start0, ln, A, cnt, x, dst[x], want)
     print('scan/stage emulation ok')
+    # recurrence emulation on random windows with integer costs (ties everywhere), incl. stage boundaries
+    rng = np.random.default_rng(1)
+    for trial in range(12):
+        n = int(rng.integers(1, 700)); Fm = [40, 200, 700][trial % 3]
+        F = np.minimum(rng.integers(1, Fm + 1, n), n - np.arange(n))
+        if trial % 3 == 1: F = np.maximum(np.where((np.arange(n) // 97) % 2 == 0, np.minimum(F, 30), F), 1)
+        cum = np.concatenate([[0], np.cumsum(F)[:-1]])
+        cost = -rng.integers(0, 4, int(F.sum())).astype(float)
+        want = plain_dp(F, cum, cost, n)
+        for S in (64 * ((n + 63) // 64), 64, 192):
+            for BL in ((32, 64) if F.max() <= 64 else (32,)):
+                assert (emu_dp(F, cum, cost, n, S, BL) == want).all(), (trial, n, S, BL)
+    print('recurrence emulation ok')
     for nm in ['tiny', 'n1', 'n2', 'n65', 'max_cpg2', 'max_cpg_binds', 'dense_w_gt_64', 'dense_small_bp', 'equal_loci', 'island_mix']:
         run_case(nm)
     run_case('tiny', S=64); run_case('dense_w_gt_64', S=128); run_case('max_cpg_binds', S=192)
+    run_case('island_mix', TIsel=32); run_case('dense_small_bp', TIsel=16, S=64); run_case('dense_bp500')

@@ -13,6 +13,7 @@
 //             holds the running maximum of the pending step i == l (mod 64); when M[k] is final, ONE vector add +
 //             compare folds candidate k into the 64 steps it can start (ascending k and strict '>' = the reference's
 //             first-maximum rule); M[k+1] is then read from lane k mod 64.  No cross-lane reduction on the chain.
+//             Blocks of 65..128 sites use a second pending register; longer ones are pushed by the worker waves.
 //   k_trace   traceback (segmentor.cpp:50-58) out of an LDS-resident window of back-pointers.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -50,6 +51,7 @@ struct ChunkDesc {
     int64_t start0;      // first site (0-based, absolute)
     int64_t site_off;    // offset of this chunk in the job-site arrays (W16, cum32, back16)
     int64_t carry_off;   // offset (in uint2) of this chunk's carries: [n_samples][nG]
+    int64_t unit_off;    // offset of this chunk in umax16: one entry per 16 sites of the chunk
     int32_t len;
     int32_t nG;          // 64-site groups of ABSOLUTE site index the chunk touches: ((start0+len-1)>>6) - (start0>>6) + 1
 };
@@ -64,6 +66,7 @@ struct JobView {
     uint16_t* W16;            // [job sites] forward window F_k: blocks starting at k may end at k .. k+F_k-1
     uint32_t* cum32;          // [job sites] exclusive prefix of F inside the chunk = row offset of start site k
     uint16_t* back16;         // [job sites] i + 1 - argmax_k for M[i+1]  (length of the best block ending at i)
+    uint16_t* umax16;         // [job 16-site units] largest F_k of the unit: decides the unit's k_cost tile class
     int64_t* chunk_pairs;     // [n_chunks] sum of W over the chunk
     int32_t n_samples;
     int32_t n_chunks;
@@ -75,13 +78,14 @@ struct JobStatus {            // zeroed (first_bad = ~0) before every call
     unsigned int max_window;
     unsigned int loci_disorder;     // 1 + chunk index of a chunk whose loci are not ascending
     unsigned int overflow;          // a chunk's pair count does not fit 32 bits
-    unsigned int pad;
+    unsigned int wide_units;        // 16-site units with a window > 64 sites
 };
 
 struct StageView {            // tables produced by k_stage_plan, row `stage` of each
     const int64_t* cbase;     // [n_stages][n_chunks] element offset of the chunk's rows in the stage's cost buffer
     const uint32_t* cum0;     // [n_stages][n_chunks] cum32 at the chunk's first site of the stage
-    const int64_t* tbase;     // [n_stages][n_chunks+1] exclusive prefix of k_cost tiles
+    const int64_t* tbaseA;    // [n_stages][n_chunks+1] exclusive prefix of the narrow k_cost tiles
+    const int64_t* tbaseB;    // [n_stages][n_chunks+1] exclusive prefix of the wide k_cost tiles
     int32_t stage;
     int32_t S;                // sites of each chunk per stage (multiple of 64)
 };
@@ -219,6 +223,10 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, c
         w = (uint32_t)(lo - k + 1);
         J.W16[cd.site_off + k] = (uint16_t)w;
     }
+    uint32_t um = w;                                      // largest window of each 16-site unit (tiles of 256 sites: aligned)
+    um = max(um, (uint32_t)__shfl_xor((int)um, 1)); um = max(um, (uint32_t)__shfl_xor((int)um, 2));
+    um = max(um, (uint32_t)__shfl_xor((int)um, 4)); um = max(um, (uint32_t)__shfl_xor((int)um, 8));
+    if ((lane & 15) == 0 && k < cd.len) J.umax16[cd.unit_off + (k >> 4)] = (uint16_t)um;
     const uint32_t wmax = wg_wave_max_u32(w);
     const bool any_dis = __any(disorder);
     if (lane == 0) {
@@ -254,6 +262,10 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window_scan(JobView J, JobStatus* 
         for (int j = 0; j < 8; j++) { if (k0 + j < cd.len) C[k0 + j] = e; e += w[j]; }
         run += btot;
     }
+    uint32_t nwide = 0;
+    for (int u = tid; u < (cd.len + 15) >> 4; u += WG_BLOCK) nwide += J.umax16[cd.unit_off + u] > 64u ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) nwide += (uint32_t)__shfl_down((int)nwide, o);
+    if (lane == 0 && nwide) atomicAdd(&st->wide_units, nwide);
     if (tid == 0) {
         J.chunk_pairs[c] = (int64_t)run;
         atomicAdd(&st->total_pairs, (unsigned long long)run);
@@ -262,22 +274,76 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window_scan(JobView J, JobStatus* 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_stage_plan: one workgroup per stage; per chunk the number of scored blocks in the stage and of k_cost tiles,
-// and their exclusive prefixes over chunks.
+// Tile plan of the scoring kernel.  Windows differ by an order of magnitude along a genome (a few CpGs per 2 kb in
+// open sea, hundreds inside a CpG island), so the start sites are scored in two classes of tiles:
+//   narrow (A): TI consecutive start sites (aligned), all with F_k <= WA: starts and ends share one LDS prefix row;
+//   wide   (B): 16 consecutive start sites x one tile of TK end sites, as many end tiles as the unit's widest block needs.
+// An aligned group of TI starts is narrow when every 16-site unit in it has umax16 <= WA, else all its units are wide.
+// k_tile_count counts the tiles of each class per (stage, chunk); k_stage_plan turns the counts into per-stage
+// prefixes over the chunks; k_tile_emit writes the tile descriptors in site order.
 // ------------------------------------------------------------------------------------------------------------
-struct PlanArgs { int32_t S, TI, KT, n_stages; };
+struct PlanArgs { int32_t S, TI, WA, TK, n_stages; };
 
-__global__ __launch_bounds__(WG_BLOCK) void k_stage_plan(JobView J, PlanArgs P, int64_t* cbase, uint32_t* cum0,
-                                                         int64_t* tbase, int64_t* stage_pairs, int64_t* stage_tiles)
+struct TileDesc { int32_t chunk, ka, nk, et_lo; };     // start sites [ka, ka+nk); wide tiles: end sites [et_lo, et_lo+TK)
+
+__device__ __forceinline__ void wg_group_tiles(const JobView& J, const ChunkDesc& cd, const PlanArgs& P, int ka, int s1,
+                                               uint32_t& nA, uint32_t& nB)
 {
-    __shared__ uint64_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64];
+    const int kb = (ka + P.TI < s1) ? ka + P.TI : s1;
+    uint32_t m = 0, tb = 0;
+    for (int k0 = ka; k0 < kb; k0 += 16) {
+        const uint32_t um = J.umax16[cd.unit_off + (k0 >> 4)];
+        const int nk = (kb - k0 < 16) ? kb - k0 : 16;
+        m = um > m ? um : m;
+        tb += ((uint32_t)(nk - 1) + um + (uint32_t)P.TK - 1u) / (uint32_t)P.TK;     // ends k0 .. k0+nk-1+um-1
+    }
+    const bool narrow = m <= (uint32_t)P.WA;
+    nA = narrow ? 1u : 0u;
+    nB = narrow ? 0u : tb;
+}
+
+__global__ __launch_bounds__(WG_BLOCK) void k_tile_count(JobView J, PlanArgs P, uint32_t* __restrict__ cntA, uint32_t* __restrict__ cntB)
+{
+    __shared__ uint32_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = blockIdx.x, stg = blockIdx.y;
+    const ChunkDesc cd = J.chunks[c];
+    const int s0 = stg * P.S;
+    uint32_t a = 0, b = 0;
+    if (s0 < cd.len) {
+        const int s1 = (s0 + P.S < cd.len) ? s0 + P.S : cd.len;
+        const int nU = (s1 - s0 + P.TI - 1) / P.TI;
+        for (int u = tid; u < nU; u += WG_BLOCK) {
+            uint32_t na, nb;
+            wg_group_tiles(J, cd, P, s0 + u * P.TI, s1, na, nb);
+            a += na; b += nb;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { a += (uint32_t)__shfl_down((int)a, o); b += (uint32_t)__shfl_down((int)b, o); }
+    if (lane == 0) { wa[wv] = a; wb[wv] = b; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t ta = 0, tb = 0;
+        for (int q = 0; q < WG_BLOCK / 64; q++) { ta += wa[q]; tb += wb[q]; }
+        cntA[(int64_t)stg * J.n_chunks + c] = ta;
+        cntB[(int64_t)stg * J.n_chunks + c] = tb;
+    }
+}
+
+// one workgroup per stage; per chunk the number of scored blocks in the stage, and the exclusive prefixes over the
+// chunks of the blocks and of the tiles of both classes
+__global__ __launch_bounds__(WG_BLOCK) void k_stage_plan(JobView J, PlanArgs P, const uint32_t* __restrict__ cntA,
+                                                         const uint32_t* __restrict__ cntB, int64_t* cbase, uint32_t* cum0,
+                                                         int64_t* tbaseA, int64_t* tbaseB, int64_t* stage_pairs, int64_t* stage_tiles)
+{
+    __shared__ uint64_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64], wc[WG_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int stg = blockIdx.x;
     const int nC = J.n_chunks;
-    uint64_t runA = 0, runB = 0;
+    uint64_t runA = 0, runB = 0, runC = 0;
     for (int base = 0; base < nC; base += WG_BLOCK) {
         const int c = base + tid;
-        uint64_t sz = 0, nt = 0;
+        uint64_t sz = 0, nt = 0, nu = 0;
         uint32_t c0 = 0;
         if (c < nC) {
             const ChunkDesc cd = J.chunks[c];
@@ -287,41 +353,91 @@ __global__ __launch_bounds__(WG_BLOCK) void k_stage_plan(JobView J, PlanArgs P, 
                 c0 = J.cum32[cd.site_off + s0];
                 const uint64_t cend = (s1 < cd.len) ? (uint64_t)J.cum32[cd.site_off + s1] : (uint64_t)J.chunk_pairs[c];
                 sz = cend - c0;
-                nt = (uint64_t)((s1 - s0 + P.TI - 1) / P.TI) * (uint64_t)P.KT;
+                nt = cntA[(int64_t)stg * nC + c];
+                nu = cntB[(int64_t)stg * nC + c];
             }
         }
-        const uint64_t ia = wg_wave_incl_scan_u64(sz, lane), ib = wg_wave_incl_scan_u64(nt, lane);
-        if (lane == 63) { wa[wv] = ia; wb[wv] = ib; }
+        const uint64_t ia = wg_wave_incl_scan_u64(sz, lane), ib = wg_wave_incl_scan_u64(nt, lane), ic = wg_wave_incl_scan_u64(nu, lane);
+        if (lane == 63) { wa[wv] = ia; wb[wv] = ib; wc[wv] = ic; }
         __syncthreads();
-        uint64_t oa = 0, ob = 0, ta = 0, tb2 = 0;
+        uint64_t oa = 0, ob = 0, oc = 0, ta = 0, tb2 = 0, tc = 0;
 #pragma unroll
-        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) { oa += wa[q]; ob += wb[q]; } ta += wa[q]; tb2 += wb[q]; }
+        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) { oa += wa[q]; ob += wb[q]; oc += wc[q]; } ta += wa[q]; tb2 += wb[q]; tc += wc[q]; }
         __syncthreads();
         if (c < nC) {
             cbase[(int64_t)stg * nC + c] = (int64_t)(runA + oa + ia - sz);
             cum0[(int64_t)stg * nC + c] = c0;
-            tbase[(int64_t)stg * (nC + 1) + c] = (int64_t)(runB + ob + ib - nt);
+            tbaseA[(int64_t)stg * (nC + 1) + c] = (int64_t)(runB + ob + ib - nt);
+            tbaseB[(int64_t)stg * (nC + 1) + c] = (int64_t)(runC + oc + ic - nu);
         }
-        runA += ta; runB += tb2;
+        runA += ta; runB += tb2; runC += tc;
     }
     if (tid == 0) {
-        tbase[(int64_t)stg * (nC + 1) + nC] = (int64_t)runB;
+        tbaseA[(int64_t)stg * (nC + 1) + nC] = (int64_t)runB;
+        tbaseB[(int64_t)stg * (nC + 1) + nC] = (int64_t)runC;
         stage_pairs[stg] = (int64_t)runA;
-        stage_tiles[stg] = (int64_t)runB;
+        stage_tiles[2 * stg] = (int64_t)runB;
+        stage_tiles[2 * stg + 1] = (int64_t)runC;
+    }
+}
+
+// one workgroup per chunk (of one stage): the tile descriptors of both classes, in site order
+__global__ __launch_bounds__(WG_BLOCK) void k_tile_emit(JobView J, PlanArgs P, int stg, const int64_t* __restrict__ tbaseA,
+                                                        const int64_t* __restrict__ tbaseB, TileDesc* __restrict__ tilesA,
+                                                        TileDesc* __restrict__ tilesB)
+{
+    __shared__ uint32_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = blockIdx.x;
+    const int nC = J.n_chunks;
+    const ChunkDesc cd = J.chunks[c];
+    const int s0 = stg * P.S;
+    if (s0 >= cd.len) return;
+    const int s1 = (s0 + P.S < cd.len) ? s0 + P.S : cd.len;
+    const int nU = (s1 - s0 + P.TI - 1) / P.TI;
+    int64_t runA = tbaseA[(int64_t)stg * (nC + 1) + c], runB = tbaseB[(int64_t)stg * (nC + 1) + c];
+    for (int base = 0; base < nU; base += WG_BLOCK) {
+        const int u = base + tid;
+        const int ka = s0 + u * P.TI;
+        uint32_t na = 0, nb = 0;
+        if (u < nU) wg_group_tiles(J, cd, P, ka, s1, na, nb);
+        const uint32_t ia = wg_wave_incl_scan_dpp_u32(na), ib = wg_wave_incl_scan_dpp_u32(nb);
+        if (lane == 63) { wa[wv] = ia; wb[wv] = ib; }
+        __syncthreads();
+        uint32_t oa = 0, ob = 0, ta = 0, tb = 0;
+#pragma unroll
+        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) { oa += wa[q]; ob += wb[q]; } ta += wa[q]; tb += wb[q]; }
+        __syncthreads();
+        if (u < nU) {
+            const int kb = (ka + P.TI < s1) ? ka + P.TI : s1;
+            if (na) {
+                TileDesc d = {c, ka, kb - ka, 0};
+                tilesA[runA + oa + ia - na] = d;
+            } else {
+                int64_t o = runB + ob + ib - nb;
+                for (int k0 = ka; k0 < kb; k0 += 16) {
+                    const uint32_t um = J.umax16[cd.unit_off + (k0 >> 4)];
+                    const int nk = (kb - k0 < 16) ? kb - k0 : 16;
+                    const int kt = (int)(((uint32_t)(nk - 1) + um + (uint32_t)P.TK - 1u) / (uint32_t)P.TK);
+                    for (int e = 0; e < kt; e++) { TileDesc d = {c, k0, nk, k0 + e * P.TK}; tilesB[o++] = d; }
+                }
+            }
+        }
+        runA += ta; runB += tb;
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_cost: one workgroup scores the blocks of TI consecutive START sites (times one tile of end sites when windows are
-// wide).  LDS holds, per sample of the current group, the exclusive prefixes P[x] of (#meth, #cov) over the sites the
+// k_cost: one workgroup scores the blocks of one tile: up to TI consecutive START sites (times one tile of end sites
+// in the wide class).  LDS holds, per sample of the current group, the exclusive prefixes P[x] of (#meth, #cov) over the sites the
 // tile touches: a block (k, i) is then P[i+1] - P[k].
 // ------------------------------------------------------------------------------------------------------------
 struct CostArgs {
     float pc, pc2;
-    int32_t KT;        // end-site tiles per start tile (1: all ends of the tile in one LDS array together with the starts)
-    int32_t TK;        // end sites per tile (KT > 1)
-    int32_t KS;        // uint2 entries per sample row of the E array (ends; with KT == 1 it also holds the starts)
-    int32_t IS;        // entries per sample row of the S array (starts, KT > 1), else 0
+    int32_t split;     // 0: narrow tiles, all ends of the tile in one LDS array together with the starts; 1: wide tiles
+    int32_t TK;        // end sites per wide tile
+    int32_t KS;        // uint2 entries per sample row of the E array (ends; narrow tiles: also the starts)
+    int32_t IS;        // entries per sample row of the S array (starts of a wide tile), else 0
     int32_t NS;        // samples per LDS group
     int32_t pad;
 };
@@ -387,13 +503,13 @@ __device__ __forceinline__ int wg_group_start(const ChunkDesc& cd, int k)
 }
 
 template <int TI, bool FAST>
-__global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, CostArgs A, double* __restrict__ cost,
-                                                   int64_t n_tiles_padded)
+__global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, CostArgs A, const TileDesc* __restrict__ tiles,
+                                                   int64_t n_tiles, double* __restrict__ cost, int64_t n_tiles_padded)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     wg_fast_tables* tb = reinterpret_cast<wg_fast_tables*>(smem);
     uint2* Et = reinterpret_cast<uint2*>(smem + sizeof(wg_fast_tables));         // [NS][KS]  P[i+1] of the ends
-    uint2* St = Et + (size_t)A.NS * A.KS;                                        // [NS][IS]  P[k] of the starts (KT > 1)
+    uint2* St = Et + (size_t)A.NS * A.KS;                                        // [NS][IS]  P[k] of the starts (wide tiles)
     int64_t* radj = reinterpret_cast<int64_t*>(St + (size_t)A.NS * A.IS);        // [TI]
     int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
     int32_t* ist = offs + (TI + 1);                                              // [TI] first end of start kl in this unit
@@ -402,27 +518,17 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nC = J.n_chunks;
-    const int64_t* tbase = SV.tbase + (int64_t)SV.stage * (nC + 1);
-    const int64_t n_tiles = tbase[nC];
     // XCD-aware remap: consecutive tiles (which share halo sites) land on the same XCD's L2
     const int64_t per = n_tiles_padded >> 3;
     const int64_t t = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (t >= n_tiles) return;
-
-    int clo = 0, chi = nC;                               // last chunk with tbase[c] <= t
-    while (chi - clo > 1) { const int mid = (clo + chi) >> 1; if (tbase[mid] <= t) clo = mid; else chi = mid; }
-    const int c = clo;
+    const TileDesc td = tiles[t];
+    const int c = td.chunk;
     const ChunkDesc cd = J.chunks[c];
-    const int local = (int)(t - tbase[c]);
-    const int kti = local / A.KT, et = local - kti * A.KT;
-    const int s0 = SV.stage * SV.S;
-    const int s1 = (s0 + SV.S < cd.len) ? s0 + SV.S : cd.len;
-    const int ka = s0 + kti * TI;                        // start sites [ka, kb)
-    const int kb = (ka + TI < s1) ? ka + TI : s1;
-    const int nk = kb - ka;
-    // end-site tile [et_lo, et_hi); tile 0 begins at ka.  KT == 1: no restriction.
-    const int et_lo = (A.KT > 1) ? ka + et * A.TK : 0;
-    const int et_hi = (A.KT > 1) ? et_lo + A.TK : (1 << 30);
+    const int ka = td.ka, nk = td.nk, kb = ka + nk;      // start sites [ka, kb)
+    // end-site tile [et_lo, et_hi) of a wide tile; narrow tiles: no restriction
+    const int et_lo = A.split ? td.et_lo : 0;
+    const int et_hi = A.split ? et_lo + A.TK : (1 << 30);
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
 
     wg_fast_tables_to_lds(tb, tid, WG_BLOCK);
@@ -452,14 +558,14 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int Q = offs[nk];
     if (Q == 0) return;
     const int imin = misc[0], imax = misc[1];
-    // E array: P[x] for x = eA .. imax+1 (ends use P[i+1]); with KT == 1 the starts' P[k], k >= ka = eA, live there too.
-    const int eA = (A.KT > 1) ? imin + 1 : ka;
+    // E array: P[x] for x = eA .. imax+1 (ends use P[i+1]); in a narrow tile the starts' P[k], k >= ka = eA, live there too.
+    const int eA = A.split ? imin + 1 : ka;
     const int eG = wg_group_start(cd, eA);               // carry position the scan of the row starts from
     const int Ecnt = imax + 2 - eA;
     int sA;                                              // S entries: index k - sA
     const uint2* Sbase;
     int Sstride;
-    if (A.KT > 1) { sA = ka; Sbase = St; Sstride = A.IS; }
+    if (A.split) { sA = ka; Sbase = St; Sstride = A.IS; }
     else          { sA = eA; Sbase = Et; Sstride = A.KS; }
     const int sG = wg_group_start(cd, sA);
     const int soff = ka - sA;                            // P[k] of start kl at S[soff + kl]
@@ -479,7 +585,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             const uint8_t* row = J.betas + (int64_t)s * J.pitch;
             const uint2* carry = J.carry + cd.carry_off + (int64_t)s * cd.nG;
             wg_stage_prefix_row(Et + (size_t)rr * A.KS, row, carry, cd, J.n_total, eG, eA - eG, Ecnt, lane);
-            if (A.KT > 1) wg_stage_prefix_row(St + (size_t)rr * A.IS, row, carry, cd, J.n_total, sG, sA - sG, Scnt, lane);
+            if (A.split) wg_stage_prefix_row(St + (size_t)rr * A.IS, row, carry, cd, J.n_total, sG, sA - sG, Scnt, lane);
         }
         __syncthreads();
         for (int q = tid; q < Q; q += WG_BLOCK) {
@@ -504,84 +610,124 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_dp: one workgroup of 1 + WG_DP_LOADERS wavefronts per chunk.  Wave 0 owns the chunk's recurrence; the others are
-// its loaders: while wave 0 sweeps the 64 steps of batch b out of LDS, they bring the scored-block rows and the
-// per-step metadata of batch b+1 from HBM into the other LDS slot.  One s_barrier per 64 steps.
+// k_dp<NW, BL>: one workgroup of 1 + NW wavefronts per chunk.  Wave 0 owns the chunk's recurrence; the others are its
+// workers: while wave 0 sweeps the BL steps of batch b out of LDS, they bring the scored-block rows of batch b+1 from
+// HBM into the other LDS slot.  One s_barrier per batch.
 //
 // Push form of segmentor.cpp:142-154.  Lane l of wave 0 holds (best, arg) of the pending step i == l (mod 64),
 // i.e. the running  max_k M[k] + cost(k, i)  over the candidates k seen so far.  Iteration k: M[k] is final;
 //   every lane with j = (l - k) mod 64 < F_k folds  M[k] + cost(k, k+j)  into its pending step (strict '>' in
 //   ascending k keeps the FIRST maximum, as the reference's scan does);  step i = k has now seen its last candidate,
 //   so M[k+1] = best of lane k mod 64, and that lane moves on to step k+64.
-// Blocks longer than 64 sites (F_k > 64) reach steps that no lane holds yet: those maxima are parked in LDS (pend)
-// and picked up when the lane moves on.
+//
+// BL = 64: every window of the job is <= 64 sites, the above is everything.
+// BL = 32 (some F_k > 64 somewhere in the job): blocks of 65..128 sites are folded the same way into a SECOND pending
+//   register per lane (bestB: step i+64), which becomes the first when the lane moves on.  Blocks longer than 128 sites
+//   are pushed by the WORKER waves, one batch behind the recurrence, target-major (one thread per end site, sources
+//   in ascending k: no races, first maximum kept), into a ring of pending maxima in global memory (L2).  The
+//   recurrence merges a step's ring entry when the batch that finishes the step begins: every ring candidate has a
+//   smaller k than any candidate still to come, so '>=' on the merge followed by '>' keeps the reference's rule.
+//   Timeline, batch b = steps [base, base+32): sources of batch b are pushed during batch b+1 (targets >= base+128),
+//   the ring entries of batch b+2 are fetched (and reset) during batch b+1 — always disjoint from the pushes.
 // ------------------------------------------------------------------------------------------------------------
-struct DpArgs { int32_t ringN; int32_t slot_cap; int32_t wide; int32_t pad; };   // ringN: pend slots (pow2 >= max window), 0 if !wide
+struct DpArgs { int32_t ringN; int32_t pad[3]; };      // ringN: pending-step ring (pow2 >= max window + 128), 0 if BL == 64
 
-struct DpMeta {               // per LDS slot
-    uint32_t w[64];           // forward window F_k of each step of the batch
-    uint32_t rel[64];         // row offset of each step inside the stage's cost rows of this chunk
-    uint32_t first;           // rel of the batch's first step
-    uint32_t staged;          // 1: rows [first, first+span) are in the slot, contiguous (as in HBM)
-    uint32_t simple;          // 1: full batch, every F_k <= 64: the slot holds the ARRANGED form [64 steps][64 lanes]
-    uint32_t pad;
-};
+#define WG_DP_STATE_HDR 257   // doubles of per-chunk state ahead of the ring: M[k], bestA[64], argA[64], bestB[64], argB[64]
 
-#define WG_DP_LOADERS 3       // loader wavefronts per k_dp workgroup (wave 0 is the DP wave)
+__device__ __forceinline__ double wg_ld_l2_f64(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t wg_ld_l2_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Loader waves: metadata of the 64 steps starting at `base`, and their scored-block rows into the LDS slot.
-// Arranged form (full batch, all windows <= 64): slot[s*64 + l] = cost(k, k+j), k = base+s, j = (l - s) mod 64, for
-// j < F_k, and -inf for the lanes that hold no candidate of step s — so the DP wave needs no predicate at all:
-// M[k] + (-inf) can never beat a pending maximum.  Loader wave `lw` arranges the steps s == lw (mod WG_DP_LOADERS),
-// all its HBM loads in flight before the first LDS store.
+// Worker waves: the scored-block rows of the BL steps starting at `base` into an LDS slot, ARRANGED for the push form:
+//   slotA[s*64 + l] = cost(k, k+j),      k = base+s, j = (l - k) mod 64, for j < F_k,        else -inf
+//   slotB[s*64 + l] = cost(k, k+64+j)                                     for 64+j < F_k,     else -inf   (wide batch only)
+// so the recurrence needs no predicate at all: M[k] + (-inf) can never beat a pending maximum.  Worker `lw` arranges
+// the steps s == lw (mod NW), all its HBM loads in flight before the first LDS store.
+template <int NW, int BL>
 __device__ __forceinline__ void wg_dp_load_batch(const double* __restrict__ cb, const uint16_t* __restrict__ Wp,
                                                  const uint32_t* __restrict__ Cp, uint32_t cum0, int base, int s1,
-                                                 int slot_cap, double* __restrict__ slot, DpMeta* __restrict__ meta, int lane, int lw)
+                                                 double* __restrict__ slotA, double* __restrict__ slotB, uint32_t* __restrict__ kind,
+                                                 int lane, int lw)
 {
+    constexpr bool WIDEJOB = BL < 64;
+    constexpr int PER = (BL + NW - 1) / NW;
+    const double NEG_INF = -__builtin_inf();
     const int il = base + lane;
-    const bool inb = il < s1;
+    const bool inb = lane < BL && il < s1;
     const uint32_t w = inb ? (uint32_t)Wp[il] : 0u;
     const uint32_t rel = inb ? Cp[il] - cum0 : 0u;
-    const int nst = (s1 - base < 64) ? s1 - base : 64;
-    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)rel, 0);
-    const uint32_t last_rel = (uint32_t)__builtin_amdgcn_readlane((int)rel, nst - 1);
-    const uint32_t last_w = (uint32_t)__builtin_amdgcn_readlane((int)w, nst - 1);
-    const uint32_t span = last_rel + last_w - first;
-    const bool simple = nst == 64 && slot_cap >= 4096 && wg_wave_max_u32(w) <= 64u;
-    const bool staged = !simple && span <= (uint32_t)slot_cap;
-    if (lw == 0) {
-        meta->w[lane] = w;
-        meta->rel[lane] = rel;
-        if (lane == 0) { meta->first = first; meta->staged = staged ? 1u : 0u; meta->simple = simple ? 1u : 0u; }
+    const bool wideb = WIDEJOB && wg_wave_max_u32(w) > 64u;
+    if (lw == 0 && lane == 0) *kind = wideb ? 1u : 0u;
+    const int stp0 = base & 63;
+    double va[PER], vb[PER];
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int sidx = lw + q * NW;
+        va[q] = NEG_INF; vb[q] = NEG_INF;
+        if (sidx < BL) {
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w, sidx);
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rel, sidx);
+            const uint32_t j = (uint32_t)(lane - stp0 - sidx) & 63u;
+            if (j < f) va[q] = cb[(int64_t)r + j];
+            if (WIDEJOB && wideb && j + 64u < f) vb[q] = cb[(int64_t)r + j + 64u];
+        }
     }
-    if (simple) {
-        const double NEG_INF = -__builtin_inf();
-        constexpr int PER = (64 + WG_DP_LOADERS - 1) / WG_DP_LOADERS;
-        double v[PER];
 #pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const int sidx = lw + q * WG_DP_LOADERS;
-            v[q] = NEG_INF;
-            if (sidx < 64) {
-                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w, sidx);
-                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rel, sidx);
-                const uint32_t j = (uint32_t)(lane - sidx) & 63u;
-                if (j < f) v[q] = cb[(int64_t)r + j];
-            }
+    for (int q = 0; q < PER; q++) {
+        const int sidx = lw + q * NW;
+        if (sidx < BL) {
+            slotA[sidx * 64 + lane] = va[q];
+            if (WIDEJOB && wideb) slotB[sidx * 64 + lane] = vb[q];
         }
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const int sidx = lw + q * WG_DP_LOADERS;
-            if (sidx < 64) slot[sidx * 64 + lane] = v[q];
-        }
-    } else if (staged) {
-        const double* src = cb + first;
-        for (uint32_t x = (uint32_t)(lw * 64 + lane); x < span; x += 64 * WG_DP_LOADERS) slot[x] = src[x];
     }
 }
 
-// One step of the fast path: fold M[k] into the 64 pending steps, read M[k+1] off lane `stp`, and let that lane move
-// on to step k+64 with whatever earlier, longer blocks have parked for it (pb, pa; -inf when nothing was parked).
+// Worker waves: blocks longer than 128 sites that START in the batch at `base` (whose M[k] the recurrence has left in
+// Mring), folded target-major into the ring.
+template <int NW, int BL>
+__device__ __forceinline__ void wg_dp_far(const double* __restrict__ cb, const uint16_t* __restrict__ Wp, const uint32_t* __restrict__ Cp,
+                                          uint32_t cum0, int base, int s1, const double* __restrict__ Mring,
+                                          double* __restrict__ pendB, int32_t* __restrict__ pendA, int rmask, int lane, int lw)
+{
+    const double NEG_INF = -__builtin_inf();
+    const int il = base + lane;
+    const bool inb = lane < BL && il < s1;
+    const uint32_t w = inb ? (uint32_t)Wp[il] : 0u;
+    const uint32_t rel = inb ? Cp[il] - cum0 : 0u;
+    const uint32_t fmax = wg_wave_max_u32(w);
+    if (fmax <= 128u) return;
+    const double m = inb ? Mring[il & 127] : 0.0;
+    const int thi = base + BL - 1 + (int)fmax;            // targets are < thi
+    for (int t0 = base + 128 + lw * 64; t0 < thi; t0 += 64 * NW) {
+        const int t = t0 + lane;
+        const int sl = t & rmask;
+        double best = wg_ld_l2_f64(pendB + sl);
+        int32_t arg = wg_ld_l2_i32(pendA + sl);
+        bool any = false;
+#pragma unroll 1
+        for (int g = 0; g < BL; g += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w, g + u);
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rel, g + u);
+                const uint32_t j = (uint32_t)(t - (base + g + u));          // >= 97
+                v[u] = NEG_INF;
+                if (f > 128u && j >= 128u && j < f) { v[u] = cb[(int64_t)r + j]; any = true; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const double cand = wg_readlane_f64(m, g + u) + v[u];
+                const bool upd = cand > best;                                // ascending k, strict: first maximum
+                best = upd ? cand : best;
+                arg = upd ? base + g + u : arg;
+            }
+        }
+        if (any) { pendB[sl] = best; pendA[sl] = arg; }
+    }
+}
+
+// One step of a batch without blocks longer than 64 sites: fold M[k] into the 64 pending steps, read M[k+1] off lane
+// `stp`, and let that lane move on to step k+64 with what earlier 65..128-site blocks left for it (pb, pa).
 __device__ __forceinline__ void wg_dp_fast_step(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double cv,
                                                 const int k, const int stp, const int lane, const double pb, const int32_t pa)
 {
@@ -597,19 +743,44 @@ __device__ __forceinline__ void wg_dp_fast_step(double& best, int32_t& arg, uint
     arg = mine ? pa : arg;
 }
 
-// state saved between stages, per chunk: [0] M[k] of the next step, [1..64] best, then 64 args (as doubles' bits),
-// then (wide) pendB[ringN], pendA[ringN]
-__global__ __launch_bounds__(64 * (1 + WG_DP_LOADERS)) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
-                                            double* __restrict__ state, int64_t state_stride)
+// One step of a batch with blocks of up to 128 sites in the registers (longer ones are the workers' business).
+__device__ __forceinline__ void wg_dp_wide_step(double& best, int32_t& arg, double& bestB, int32_t& argB, uint32_t& tbk, double& Mfin,
+                                                double& Mk, const double ca, const double cb2, const int k, const int stp, const int lane)
 {
+    const double NEG_INF = -__builtin_inf();
+    const double candA = Mk + ca;
+    const bool updA = candA > best;
+    best = updA ? candA : best;
+    arg = updA ? k : arg;
+    const double candB = Mk + cb2;
+    const bool updB = candB > bestB;
+    bestB = updB ? candB : bestB;
+    argB = updB ? k : argB;
+    Mk = wg_readlane_f64(best, stp);                   // M[k+1]
+    const int ak = __builtin_amdgcn_readlane(arg, stp);
+    const bool mine = lane == stp;
+    tbk = mine ? (uint32_t)(k + 1 - ak) : tbk;
+    Mfin = mine ? best : Mfin;                         // M[k+1] stays with the lane for the workers
+    best = mine ? bestB : best;
+    arg = mine ? argB : arg;
+    bestB = mine ? NEG_INF : bestB;
+}
+
+// state kept per chunk in global memory: [0] M[k] of the next step, [1..64] best, [65..128] arg, [129..192] bestB,
+// [193..256] argB (args as doubles' bits) — written only between stages — then the ring: ringN doubles, ringN int32
+template <int NW, int BL>
+__global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
+                                                      double* __restrict__ state, int64_t state_stride)
+{
+    constexpr bool WIDEJOB = BL < 64;
+    constexpr int SLOT = BL * 64 * (WIDEJOB ? 2 : 1);                         // doubles per LDS slot: A (+ B)
     extern __shared__ __attribute__((aligned(16))) char smem_dp[];
-    double* pendB = reinterpret_cast<double*>(smem_dp);                       // [ringN]
-    int32_t* pendA = reinterpret_cast<int32_t*>(pendB + A.ringN);             // [ringN]
-    double* slots = reinterpret_cast<double*>(pendA + A.ringN + (A.ringN & 1));   // [2][slot_cap], 8-byte aligned
-    DpMeta* metas = reinterpret_cast<DpMeta*>(slots + 2 * (size_t)A.slot_cap);
+    double* slots = reinterpret_cast<double*>(smem_dp);                       // [2][SLOT]
+    double* Mring = slots + 2 * SLOT;                                         // [128] M[k] of the last batches' steps
+    uint32_t* kinds = reinterpret_cast<uint32_t*>(Mring + 128);               // [2] 1: the slot holds a wide batch (A and B)
     const int lane = threadIdx.x & 63;
-    const bool loader = threadIdx.x >= 64;
-    const int lw = (int)(threadIdx.x >> 6) - 1;       // loader wave index (0..WG_DP_LOADERS-1)
+    const bool worker = threadIdx.x >= 64;
+    const int lw = (int)(threadIdx.x >> 6) - 1;       // worker index (0..NW-1)
     const int c = blockIdx.x;
     const int nC = J.n_chunks;
     const ChunkDesc cd = J.chunks[c];
@@ -618,123 +789,123 @@ __global__ __launch_bounds__(64 * (1 + WG_DP_LOADERS)) void k_dp(JobView J, Stag
     const int s1 = (s0 + SV.S < cd.len) ? s0 + SV.S : cd.len;
     const int rmask = A.ringN - 1;
     double* gs = state + (int64_t)c * state_stride;
+    double* pendB = gs + WG_DP_STATE_HDR;                                     // [ringN]
+    int32_t* pendA = reinterpret_cast<int32_t*>(pendB + A.ringN);             // [ringN]
     const double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
     const uint16_t* Wp = J.W16 + cd.site_off;
     const uint32_t* Cp = J.cum32 + cd.site_off;
     const double NEG_INF = -__builtin_inf();
-    const int nb = (s1 - s0 + 63) >> 6;
-    const bool wide = A.wide != 0;
+    const int nb = (s1 - s0 + BL - 1) / BL;
 
-    if (!loader) __builtin_amdgcn_s_setprio(3);        // the recurrence is one dependent chain: let it win issue arbitration
-    double best = NEG_INF;                              // pending step of this lane (wave 0)
-    int32_t arg = 0;
+    if (!worker) __builtin_amdgcn_s_setprio(3);        // the recurrence is one dependent chain: let it win issue arbitration
+    double best = NEG_INF, bestB = NEG_INF;             // pending steps of this lane (wave 0)
+    int32_t arg = 0, argB = 0;
+    double pb = NEG_INF;                                // ring entry of the step this lane finishes in the coming batch
+    int32_t pa = 0;
     double Mk = 0.0;                                    // M[k] of the step about to run; M[0] = 0 (segmentor.cpp:97)
-    if (loader) {
-        wg_dp_load_batch(cb, Wp, Cp, cum0, s0, s1, A.slot_cap, slots, metas, lane, lw);
-    } else {
-        if (s0 == 0) {
-            if (wide) for (int x = lane; x < A.ringN; x += 64) { pendB[x] = NEG_INF; pendA[x] = 0; }
-        } else {
-            Mk = gs[0];
-            best = gs[1 + lane];
-            arg = (int32_t)__double_as_longlong(gs[65 + lane]);
-            if (wide) for (int x = lane; x < A.ringN; x += 64) {
-                pendB[x] = gs[129 + x];
-                pendA[x] = (int32_t)__double_as_longlong(gs[129 + A.ringN + x]);
+    if (worker) {
+        if (WIDEJOB && s0 == 0)
+            for (int x = (int)threadIdx.x - 64; x < A.ringN; x += 64 * NW) pendB[x] = NEG_INF;
+        wg_dp_load_batch<NW, BL>(cb, Wp, Cp, cum0, s0, s1, slots, slots + BL * 64, kinds, lane, lw);
+    } else if (s0 != 0) {
+        Mk = gs[0];
+        best = gs[1 + lane];
+        arg = (int32_t)__double_as_longlong(gs[65 + lane]);
+        if (WIDEJOB) {
+            bestB = gs[129 + lane];
+            argB = (int32_t)__double_as_longlong(gs[193 + lane]);
+            const int d = (lane - s0) & 63;
+            if (d < BL) {
+                const int sl = (s0 + d) & rmask;
+                pb = wg_ld_l2_f64(pendB + sl); pa = wg_ld_l2_i32(pendA + sl);
+                pendB[sl] = NEG_INF;
             }
         }
     }
     __syncthreads();
 
     for (int b = 0; b < nb; b++) {
-        const int base = s0 + (b << 6);
-        if (loader) {
+        const int base = s0 + b * BL;
+        if (worker) {
             if (b + 1 < nb)
-                wg_dp_load_batch(cb, Wp, Cp, cum0, base + 64, s1, A.slot_cap, slots + (size_t)((b + 1) & 1) * A.slot_cap,
-                                 metas + ((b + 1) & 1), lane, lw);
+                wg_dp_load_batch<NW, BL>(cb, Wp, Cp, cum0, base + BL, s1, slots + (size_t)((b + 1) & 1) * SLOT,
+                                         slots + (size_t)((b + 1) & 1) * SLOT + BL * 64, kinds + ((b + 1) & 1), lane, lw);
+            if (WIDEJOB && b >= 1)
+                wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, base - BL, s1, Mring, pendB, pendA, rmask, lane, lw);
         } else {
-            const DpMeta* meta = metas + (b & 1);
-            const double* slot = slots + (size_t)(b & 1) * A.slot_cap;
-            uint32_t tbk = 0;
-            if (meta->simple) {
-                // ---- fast path: 64 steps out of the arranged slot, 8 at a time, next 8 rows already in flight ----
-                // No step of this batch reaches beyond 64 sites, so what longer blocks of EARLIER batches parked for
-                // the steps base+64 .. base+127 is final: each lane fetches its hand-over value once, up front.
-                double pb = NEG_INF;
-                int32_t pa = 0;
-                if (wide) {
-                    const int slotx = (base + lane + 64) & rmask;
-                    pb = pendB[slotx]; pa = pendA[slotx];
-                    pendB[slotx] = NEG_INF;
+            const double* slot = slots + (size_t)(b & 1) * SLOT;
+            const bool wideb = WIDEJOB && kinds[b & 1] != 0u;
+            const int stp0 = WIDEJOB ? (base & 63) : 0;          // lane of the batch's first step
+            const int d = (lane - stp0) & 63;                    // this lane finishes step base + d (in this batch iff d < BL)
+            const bool fin = d < BL;
+            double npb = NEG_INF;
+            int32_t npa = 0;
+            if (WIDEJOB) {
+                // ring entry of the step this lane is about to finish: all its candidates precede the ones to come
+                const bool mrg = fin && pb >= best;
+                best = mrg ? pb : best;
+                arg = mrg ? pa : arg;
+                if (b + 1 < nb && !fin) {                         // entries of the next batch's steps: in flight during this one
+                    const int sl = (base + d) & rmask;
+                    npb = wg_ld_l2_f64(pendB + sl); npa = wg_ld_l2_i32(pendA + sl);
+                    pendB[sl] = NEG_INF;
                 }
-                const double* my = slot + lane;
+            }
+            uint32_t tbk = 0;
+            const double* my = slot + lane;
+            if (!wideb) {
+                // ---- no block of the batch is longer than 64 sites: BL steps, 8 at a time, next 8 rows in flight ----
                 double cur[8], nxt[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) cur[u] = my[u * 64];
 #pragma unroll 1
-                for (int g = 0; g < 64; g += 8) {
-                    if (g + 8 < 64) {
+                for (int g = 0; g < BL; g += 8) {
+                    if (g + 8 < BL) {
 #pragma unroll
                         for (int u = 0; u < 8; u++) nxt[u] = my[(g + 8 + u) * 64];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; u++) wg_dp_fast_step(best, arg, tbk, Mk, cur[u], base + g + u, g + u, lane, pb, pa);
+                    for (int u = 0; u < 8; u++) wg_dp_fast_step(best, arg, tbk, Mk, cur[u], base + g + u, stp0 + g + u, lane, bestB, argB);
 #pragma unroll
                     for (int u = 0; u < 8; u++) cur[u] = nxt[u];
                 }
-                J.back16[cd.site_off + base + lane] = (uint16_t)tbk;
+                if (WIDEJOB) bestB = fin ? NEG_INF : bestB;
             } else {
-                const uint32_t w_l = meta->w[lane];
-                const uint32_t rel_l = meta->rel[lane];
-                const uint32_t first = meta->first;
-                const bool staged = meta->staged != 0;
-                const bool arranged = meta->simple != 0;
-                const int il = base + lane;
-                const bool inb = il < s1;
-                const int nst = (s1 - base < 64) ? s1 - base : 64;
-                for (int stp = 0; stp < nst; stp++) {
-                    const int k = base + stp;
-                    const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w_l, stp);
-                    const uint32_t rel = (uint32_t)__builtin_amdgcn_readlane((int)rel_l, stp);
-                    const uint32_t j = (uint32_t)(lane - stp) & 63u;
-                    double cv = 0.0;
-                    if (j < f) cv = arranged ? slot[stp * 64 + lane] : (staged ? slot[rel - first + j] : cb[(int64_t)rel + j]);
-                    const double cand = Mk + cv;
-                    const bool upd = (j < f) && (cand > best);            // strict: first maximum wins (segmentor.cpp:148)
-                    best = upd ? cand : best;
-                    arg = upd ? k : arg;
-                    if (f > 64u) {                                        // blocks reaching beyond the 64 pending steps
-                        for (uint32_t jj = 64u + (uint32_t)lane; jj < f; jj += 64) {
-                            const int slotx = (k + (int)jj) & rmask;
-                            const double cd2 = Mk + cb[(int64_t)rel + jj];
-                            if (cd2 > pendB[slotx]) { pendB[slotx] = cd2; pendA[slotx] = k; }
-                        }
+                const double* myB = my + BL * 64;
+                double Mfin = 0.0;
+                if (lane == 0) Mring[base & 127] = Mk;
+                double cur[4], curB[4], nxt[4], nxtB[4];          // 4 steps (~0.4 us) cover the LDS latency; 8 would spill at 16 waves
+#pragma unroll
+                for (int u = 0; u < 4; u++) { cur[u] = my[u * 64]; curB[u] = myB[u * 64]; }
+#pragma unroll 1
+                for (int g = 0; g < BL; g += 4) {
+                    if (g + 4 < BL) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { nxt[u] = my[(g + 4 + u) * 64]; nxtB[u] = myB[(g + 4 + u) * 64]; }
                     }
-                    // step i = k has seen its last candidate: M[k+1]
-                    Mk = wg_readlane_f64(best, stp);
-                    if (lane == stp) {
-                        tbk = (uint32_t)(k + 1 - arg);
-                        best = NEG_INF;
-                        if (wide) {                                       // hand over to step k+64: pick up parked maxima
-                            const int slotx = (k + 64) & rmask;
-                            best = pendB[slotx]; arg = pendA[slotx];
-                            pendB[slotx] = NEG_INF;
-                        }
-                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        wg_dp_wide_step(best, arg, bestB, argB, tbk, Mfin, Mk, cur[u], curB[u], base + g + u, stp0 + g + u, lane);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { cur[u] = nxt[u]; curB[u] = nxtB[u]; }
                 }
-                if (inb) J.back16[cd.site_off + il] = (uint16_t)tbk;
+                if (fin) Mring[(base + d + 1) & 127] = Mfin;      // M[k+1] of the batch's steps, for the workers
             }
+            if (fin && base + d < s1) J.back16[cd.site_off + base + d] = (uint16_t)tbk;
+            pb = npb; pa = npa;
         }
         __syncthreads();
     }
-    if (!loader && s1 < cd.len) {
+    if (WIDEJOB && worker)
+        wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, s0 + (nb - 1) * BL, s1, Mring, pendB, pendA, rmask, lane, lw);
+    if (!worker && s1 < cd.len) {
         if (lane == 0) gs[0] = Mk;
         gs[1 + lane] = best;
         gs[65 + lane] = __longlong_as_double((long long)arg);
-        if (wide) for (int x = lane; x < A.ringN; x += 64) {
-            gs[129 + x] = pendB[x];
-            gs[129 + A.ringN + x] = __longlong_as_double((long long)pendA[x]);
+        if (WIDEJOB) {
+            gs[129 + lane] = bestB;
+            gs[193 + lane] = __longlong_as_double((long long)argB);
         }
     }
 }

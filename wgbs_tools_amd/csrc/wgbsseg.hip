@@ -91,7 +91,7 @@ struct wgbsseg_ctx {
     int64_t n_loci = 0;
     // scratch
     DevBuf chunks, wtile, carry, W16, cum32, back16, chunk_pairs, status;
-    DevBuf plan_cbase, plan_cum0, plan_tbase, plan_pairs, plan_tiles;
+    DevBuf plan_cbase, plan_cum0, plan_tbase, plan_pairs, plan_tiles, plan_cnt, tilesA, tilesB, umax16;
     std::vector<PinnedBuf> pinned;
     DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders, dbg_a, dbg_b, dbg_c;
     // events
@@ -104,6 +104,7 @@ struct wgbsseg_ctx {
     bool last_valid = false;
     long long cost_budget_bytes = 0;
     int force_stages = 0;
+    int force_dp_mode = 0;   // WGBSSEG_DP_MODE: 1 = 32-step batches (wide-window path), 2 = the same with 15 worker waves
     int force_ns = 0;
     int force_ti = 0;
     int min_stages = 1;      // stages exist to bound the scored-block buffer; k_dp alone (3.9 ms per 60k-site chunk) is
@@ -155,6 +156,7 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     c->cost_budget_bytes = (b && atoll(b) > 0 ? atoll(b) : 6144LL) << 20;
     const char* fs = getenv("WGBSSEG_FORCE_STAGES");
     c->force_stages = fs ? atoi(fs) : 0;
+    { const char* e = getenv("WGBSSEG_DP_MODE"); c->force_dp_mode = e ? std::min(2, std::max(0, atoi(e))) : 0; }
     const char* fn = getenv("WGBSSEG_NS");
     c->force_ns = fn ? atoi(fn) : 0;
     const char* ft = getenv("WGBSSEG_TI");
@@ -171,7 +173,7 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->wtile, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs,
-                     &c->status, &c->plan_cbase, &c->plan_cum0, &c->plan_tbase, &c->plan_pairs, &c->plan_tiles,
+                     &c->status, &c->plan_cbase, &c->plan_cum0, &c->plan_tbase, &c->plan_pairs, &c->plan_tiles, &c->plan_cnt, &c->tilesA, &c->tilesB, &c->umax16,
                      &c->cost[0], &c->cost[1], &c->dpstate, &c->tmp_borders, &c->nb, &c->boff, &c->out_borders,
                      &c->dbg_a, &c->dbg_b, &c->dbg_c};
     for (auto* b : all) b->release();
@@ -242,7 +244,7 @@ namespace {
 struct Job {
     std::vector<ChunkDesc> h;
     std::vector<int64_t> wtile_off;     // exclusive prefix of 256-site tiles per chunk (+ total)
-    int64_t sites = 0, carry_entries = 0;
+    int64_t sites = 0, carry_entries = 0, units = 0;
     int32_t max_len = 0;
     JobStatus st0;          // source of an async H2D copy: must outlive the call's stream work
     JobView v = {};
@@ -257,7 +259,7 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
     if (!start0 || !len || n_chunks < 1 || n_chunks > 0x7fffffff) { set_err(err, errlen, "bad chunk list"); return WGBSSEG_E_ARG; }
     job.h.resize((size_t)n_chunks);
     job.wtile_off.resize((size_t)n_chunks + 1);
-    int64_t so = 0, co = 0, wt = 0;
+    int64_t so = 0, co = 0, wt = 0, uo = 0;
     for (int64_t i = 0; i < n_chunks; i++) {
         if (len[i] < 1 || start0[i] < 0 || start0[i] + len[i] > c->n_total) {
             set_err(err, errlen, "chunk %lld = [%lld, +%d) is empty or outside the %lld sites of the beta files",
@@ -265,15 +267,16 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
             return WGBSSEG_E_ARG;
         }
         ChunkDesc& d = job.h[(size_t)i];
-        d.start0 = start0[i]; d.len = len[i]; d.site_off = so; d.carry_off = co; d.nG = (int32_t)(((start0[i] + len[i] - 1) >> 6) - (start0[i] >> 6) + 1);
+        d.start0 = start0[i]; d.len = len[i]; d.site_off = so; d.carry_off = co; d.unit_off = uo; d.nG = (int32_t)(((start0[i] + len[i] - 1) >> 6) - (start0[i] >> 6) + 1);
         job.wtile_off[(size_t)i] = wt;
         wt += (len[i] + WG_BLOCK - 1) / WG_BLOCK;
         so += len[i];
+        uo += (len[i] + 15) / 16;
         co += (int64_t)d.nG * c->n_samples;
         job.max_len = std::max(job.max_len, len[i]);
     }
     job.wtile_off[(size_t)n_chunks] = wt;
-    job.sites = so; job.carry_entries = co;
+    job.sites = so; job.carry_entries = co; job.units = uo;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(c->chunks.ensure(sizeof(ChunkDesc) * (size_t)n_chunks));
     HIP_TRY(c->carry.ensure(sizeof(uint2) * (size_t)co));
@@ -312,7 +315,7 @@ int report_bad_site(const wgbsseg_ctx* c, const JobStatus& st, char* err, size_t
 }
 
 template <int TI, bool FAST>
-hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a, double* cost, int64_t tiles, size_t lds, hipStream_t s)
+hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
     const int64_t padded = round_up(tiles, 8);
     static bool attr_done = false;
@@ -320,16 +323,16 @@ hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a,
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cost<TI, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_cost<TI, FAST>), dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, cost, padded);
+    hipLaunchKernelGGL((k_cost<TI, FAST>), dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, td, tiles, cost, padded);
     return hipGetLastError();
 }
 
 template <bool FAST>
-hipError_t launch_cost_ti(int TI, const JobView& v, const StageView& sv, const CostArgs& a, double* cost, int64_t tiles, size_t lds, hipStream_t s)
+hipError_t launch_cost_ti(int TI, const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
-    if (TI == 64) return launch_cost<64, FAST>(v, sv, a, cost, tiles, lds, s);
-    if (TI == 32) return launch_cost<32, FAST>(v, sv, a, cost, tiles, lds, s);
-    return launch_cost<16, FAST>(v, sv, a, cost, tiles, lds, s);
+    if (TI == 64) return launch_cost<64, FAST>(v, sv, a, td, tiles, cost, lds, s);
+    if (TI == 32) return launch_cost<32, FAST>(v, sv, a, td, tiles, cost, lds, s);
+    return launch_cost<16, FAST>(v, sv, a, td, tiles, cost, lds, s);
 }
 
 void grow_events(std::vector<hipEvent_t>& v, size_t n)
@@ -369,8 +372,9 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(c->cum32.ensure((size_t)J * 4));
     HIP_TRY(c->back16.ensure((size_t)J * 2));
     HIP_TRY(c->chunk_pairs.ensure((size_t)nC * 8));
+    HIP_TRY(c->umax16.ensure((size_t)job.units * 2));
     v.W16 = c->W16.as<uint16_t>(); v.cum32 = c->cum32.as<uint32_t>(); v.back16 = c->back16.as<uint16_t>();
-    v.chunk_pairs = c->chunk_pairs.as<int64_t>();
+    v.chunk_pairs = c->chunk_pairs.as<int64_t>(); v.umax16 = c->umax16.as<uint16_t>();
 
     // ---- scan + validate, window extents -------------------------------------------------------------------
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
@@ -394,50 +398,62 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const int64_t total_pairs = (int64_t)st.total_pairs;
 
     // ---- tiling of the scoring kernel ----------------------------------------------------------------------
-    // A tile = TI start sites (x one of KT end-site tiles of TK sites when windows are wide), at most WG_PAIR_CAP
-    // blocks.  LDS per workgroup: fast log tables + NS sample rows of prefixes + small per-tile arrays (+ partial
-    // sums when the samples need several groups).  The kernel is a long dependent chain per evaluation, so resident
-    // wavefronts matter: pick the shape that maximises (workgroups per CU) x (lane occupancy of the block rounds).
-    int TI = 64, KT = 1, TK = 0, NS = 0;
-    CostArgs ca;
-    memset(&ca, 0, sizeof(ca));
-    ca.pc = P->pseudo_count; ca.pc2 = P->pseudo_count + P->pseudo_count;
+    // Narrow tiles (class A): TI aligned start sites whose windows are all <= WA = min(widest window, 64); LDS per
+    // workgroup: fast log tables + NS sample rows of TI+WA+1 prefixes + small per-tile arrays (+ partial sums when the
+    // samples need several groups).  The kernel is a long dependent chain per evaluation, so resident wavefronts
+    // matter: pick the shape that maximises (workgroups per CU) x (lane occupancy of the block rounds).
+    // Wide tiles (class B): 16 start sites x TK end sites, for every 16-site unit that shares an aligned TI-group with
+    // a window > WA (CpG islands; everything in deep mode).
     const int Nsmp = (int)c->n_samples;
     const double Favg = (double)total_pairs / (double)std::max<int64_t>(1, J);
-    auto lds_for = [&](int ti, int kt, int tk, int ns) -> size_t {
-        const int ks = (kt > 1) ? tk + 1 : ti + Wmax + 1, is = (kt > 1) ? ti + 1 : 0;
-        const size_t qcap = (size_t)ti * (size_t)((kt > 1) ? tk : Wmax);
+    const int WA = std::min(Wmax, 64);
+    const int TKB = 128;
+    auto lds_for = [&](int ti, bool split, int w, int ns) -> size_t {
+        const int ks = split ? TKB + 1 : ti + w + 1, is = split ? ti + 1 : 0;
+        const size_t qcap = (size_t)ti * (size_t)(split ? TKB : w);
         return sizeof(wg_fast_tables) + (size_t)ns * (ks + is) * 8 + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24 +
                (ns < Nsmp ? qcap * 8 : 0);
     };
-    if (Wmax > 256) {
-        TI = 16; TK = 256; KT = (Wmax - 1 + TI + TK - 1) / TK;
-        NS = std::min(c->force_ns > 0 ? c->force_ns : 16, Nsmp);
-        while (NS > 1 && lds_for(TI, KT, TK, NS) > 64 * 1024) NS--;
-    } else {
+    int TI = 64, NSA = 1, NSB = 1;
+    {
         double best = -1;
         for (int ti = 64; ti >= 16; ti >>= 1) {
-            if (ti * Wmax > WG_PAIR_CAP) continue;
             if (c->force_ti > 0 && ti != c->force_ti) continue;
             const int ns_opts[5] = {Nsmp, 32, 16, 8, 4};
             for (int ns : ns_opts) {
                 if (ns > Nsmp) continue;
                 if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
-                const size_t l = lds_for(ti, 1, 0, ns);
+                const size_t l = lds_for(ti, false, WA, ns);
                 if (l > 64 * 1024) continue;
                 const int wgs = (int)std::min<size_t>(6, (160 * 1024) / l);          // 6 waves/SIMD is the register limit
-                const double q = ti * Favg, eff = q / (256.0 * std::ceil(q / 256.0));
+                const double q = ti * std::min<double>(Favg, WA), eff = q / (256.0 * std::ceil(q / 256.0));
                 const double groups = std::ceil((double)Nsmp / ns);
-                const double score = wgs * eff / (1.0 + 0.02 * (groups - 1)) * (1.0 + 0.04 * (ti / 16));   // bias to big tiles (less staging, friendlier to k_dp)
-                if (score > best) { best = score; TI = ti; NS = ns; }
+                const double score = wgs * eff / (1.0 + 0.02 * (groups - 1)) * (1.0 + 0.04 * (ti / 16));   // bias to big tiles (less staging)
+                if (score > best) { best = score; TI = ti; NSA = ns; }
             }
         }
-        if (best < 0) { TI = 16; NS = 1; }
+        if (best < 0) { TI = 16; NSA = 1; }
+        best = -1;
+        const int ns_opts[6] = {Nsmp, 32, 16, 8, 4, 1};
+        for (int ns : ns_opts) {
+            if (ns > Nsmp) continue;
+            if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
+            const size_t l = lds_for(16, true, 0, ns);
+            if (l > 64 * 1024) continue;
+            const int wgs = (int)std::min<size_t>(6, (160 * 1024) / l);
+            const double groups = std::ceil((double)Nsmp / ns);
+            const double score = wgs / (1.0 + 0.02 * (groups - 1));
+            if (score > best) { best = score; NSB = ns; }
+        }
     }
-    ca.KT = KT; ca.TK = TK; ca.NS = NS;
-    ca.KS = (KT > 1) ? TK + 1 : TI + Wmax + 1;
-    ca.IS = (KT > 1) ? TI + 1 : 0;
-    const size_t lds_cost = (size_t)round_up((int64_t)lds_for(TI, KT, TK, NS), 16);
+    CostArgs caA, caB;
+    memset(&caA, 0, sizeof(caA));
+    caA.pc = P->pseudo_count; caA.pc2 = P->pseudo_count + P->pseudo_count;
+    caB = caA;
+    caA.split = 0; caA.TK = 0; caA.KS = TI + WA + 1; caA.IS = 0; caA.NS = NSA;
+    caB.split = 1; caB.TK = TKB; caB.KS = TKB + 1; caB.IS = 17; caB.NS = NSB;
+    const size_t ldsA = (size_t)round_up((int64_t)lds_for(TI, false, WA, NSA), 16);
+    const size_t ldsB = (size_t)round_up((int64_t)lds_for(16, true, 0, NSB), 16);
     const bool fast_terms = P->pseudo_count == 0.0f || P->pseudo_count >= WG_FAST_MIN_PC;
 
     // ---- stages: bound the scored-block buffer and overlap scoring (stream A) with the recurrence (stream B) --
@@ -453,27 +469,49 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     n_stages = (job.max_len + S - 1) / S;
     HIP_TRY(c->plan_cbase.ensure((size_t)n_stages * nC * 8));
     HIP_TRY(c->plan_cum0.ensure((size_t)n_stages * nC * 4));
-    HIP_TRY(c->plan_tbase.ensure((size_t)n_stages * (nC + 1) * 8));
+    HIP_TRY(c->plan_tbase.ensure((size_t)n_stages * (nC + 1) * 8 * 2));
+    HIP_TRY(c->plan_cnt.ensure((size_t)n_stages * nC * 4 * 2));
     HIP_TRY(c->plan_pairs.ensure((size_t)n_stages * 8));
-    HIP_TRY(c->plan_tiles.ensure((size_t)n_stages * 8));
-    PlanArgs pa = {S, TI, KT, n_stages};
-    hipLaunchKernelGGL(k_stage_plan, dim3((unsigned)n_stages), dim3(WG_BLOCK), 0, c->sA, v, pa, c->plan_cbase.as<int64_t>(),
-                       c->plan_cum0.as<uint32_t>(), c->plan_tbase.as<int64_t>(), c->plan_pairs.as<int64_t>(), c->plan_tiles.as<int64_t>());
+    HIP_TRY(c->plan_tiles.ensure((size_t)n_stages * 8 * 2));
+    PlanArgs pa = {S, TI, WA, TKB, n_stages};
+    uint32_t* cntA = c->plan_cnt.as<uint32_t>();
+    uint32_t* cntB = cntA + (size_t)n_stages * nC;
+    int64_t* tbaseA = c->plan_tbase.as<int64_t>();
+    int64_t* tbaseB = tbaseA + (size_t)n_stages * (nC + 1);
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)nC, (unsigned)n_stages), dim3(WG_BLOCK), 0, c->sA, v, pa, cntA, cntB);
     HIP_TRY(hipGetLastError());
-    std::vector<int64_t> stage_pairs((size_t)n_stages), stage_tiles((size_t)n_stages);
+    hipLaunchKernelGGL(k_stage_plan, dim3((unsigned)n_stages), dim3(WG_BLOCK), 0, c->sA, v, pa, cntA, cntB, c->plan_cbase.as<int64_t>(),
+                       c->plan_cum0.as<uint32_t>(), tbaseA, tbaseB, c->plan_pairs.as<int64_t>(), c->plan_tiles.as<int64_t>());
+    HIP_TRY(hipGetLastError());
+    std::vector<int64_t> stage_pairs((size_t)n_stages), stage_tiles((size_t)n_stages * 2);
     HIP_TRY(hipMemcpyAsync(stage_pairs.data(), c->plan_pairs.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
-    HIP_TRY(hipMemcpyAsync(stage_tiles.data(), c->plan_tiles.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
-    HIP_TRY(hipEventRecord(c->ev[3], c->sA));
+    HIP_TRY(hipMemcpyAsync(stage_tiles.data(), c->plan_tiles.p, (size_t)n_stages * 16, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
+    std::vector<int64_t> tileA0((size_t)n_stages + 1, 0), tileB0((size_t)n_stages + 1, 0);
+    for (int stg = 0; stg < n_stages; stg++) {
+        tileA0[(size_t)stg + 1] = tileA0[(size_t)stg] + stage_tiles[2 * (size_t)stg];
+        tileB0[(size_t)stg + 1] = tileB0[(size_t)stg] + stage_tiles[2 * (size_t)stg + 1];
+    }
+    if (tileA0[(size_t)n_stages] > 0x7fffffffLL || tileB0[(size_t)n_stages] > 0x7fffffffLL) { set_err(err, errlen, "too many scoring tiles in one call"); return WGBSSEG_E_ARG; }
+    HIP_TRY(c->tilesA.ensure((size_t)std::max<int64_t>(1, tileA0[(size_t)n_stages]) * sizeof(TileDesc)));
+    HIP_TRY(c->tilesB.ensure((size_t)std::max<int64_t>(1, tileB0[(size_t)n_stages]) * sizeof(TileDesc)));
+    for (int stg = 0; stg < n_stages; stg++) {
+        hipLaunchKernelGGL(k_tile_emit, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, pa, stg, tbaseA, tbaseB,
+                           c->tilesA.as<TileDesc>() + tileA0[(size_t)stg], c->tilesB.as<TileDesc>() + tileB0[(size_t)stg]);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev[3], c->sA));
     int64_t max_stage_pairs = 1;
     for (auto x : stage_pairs) max_stage_pairs = std::max(max_stage_pairs, x);
     const int nbuf = n_stages > 1 ? 2 : 1;
     for (int b = 0; b < nbuf; b++) HIP_TRY(c->cost[b].ensure((size_t)max_stage_pairs * 8));
-    // k_dp: blocks longer than 64 sites park their maxima in an LDS ring of `ringN` pending steps
-    const bool wide = Wmax > 64;
-    const int ringN = wide ? ceil_pow2(Wmax + 64) : 0;
-    const int64_t state_stride = 129 + 2 * (int64_t)ringN;      // doubles per chunk saved between stages
-    if (n_stages > 1) HIP_TRY(c->dpstate.ensure((size_t)nC * (size_t)state_stride * 8));
+    // k_dp: 64-step batches when no window of the job exceeds 64 sites; otherwise 32-step batches with a second pending
+    // register per lane and, for blocks longer than 128 sites, a ring of pending maxima per chunk in global memory
+    int dp_mode = Wmax > 512 ? 2 : (Wmax > 64 ? 1 : 0);           // 0: <3,64>  1: <3,32>  2: <15,32> (deep windows: more workers)
+    if (c->force_dp_mode > dp_mode) dp_mode = c->force_dp_mode;
+    const int ringN = dp_mode ? ceil_pow2(Wmax + 128) : 0;
+    const int64_t state_stride = round_up(WG_DP_STATE_HDR + (int64_t)ringN + (ringN + 1) / 2, 2);   // doubles per chunk
+    if (n_stages > 1 || dp_mode) HIP_TRY(c->dpstate.ensure((size_t)nC * (size_t)state_stride * 8));
     HIP_TRY(c->tmp_borders.ensure((size_t)(J + nC) * 4));
     HIP_TRY(c->nb.ensure((size_t)nC * 4));
     HIP_TRY(c->boff.ensure((size_t)(nC + 1) * 8));
@@ -481,33 +519,41 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     grow_events(c->ev_cost0, n_stages); grow_events(c->ev_cost1, n_stages);
     grow_events(c->ev_dp0, n_stages); grow_events(c->ev_dp1, n_stages);
     static bool dp_attr = false;
-    if (!dp_attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); dp_attr = true; }
-
+    if (!dp_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<3, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<15, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        dp_attr = true;
+    }
     StageView sv;
-    sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbase = c->plan_tbase.as<int64_t>();
+    sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbaseA = tbaseA; sv.tbaseB = tbaseB;
     sv.S = S;
-    // LDS of k_dp: pend ring (wide windows only) + two staged batches of scored-block rows (64 steps x up to 64 ends) + metadata
-    int slot_cap = 4096;                                     // 64 steps x 64 lanes: the arranged form of one batch
-    const size_t lds_ring = (size_t)ringN * 12 + 8;
-    // keep two workgroups per CU when possible; a very wide ring (deep mode) leaves room for contiguous staging only
-    if (lds_ring + 4096 * 16 + 2 * sizeof(DpMeta) > 80 * 1024) slot_cap = 2048;
-    while (slot_cap > 64 && lds_ring + (size_t)slot_cap * 16 + 2 * sizeof(DpMeta) > 150 * 1024) slot_cap /= 2;
-    DpArgs da = {ringN, slot_cap, wide ? 1 : 0, 0};
-    const size_t lds_dp = lds_ring + (size_t)slot_cap * 16 + 2 * sizeof(DpMeta);
+    // LDS of k_dp: two arranged batches (64 steps x 64 lanes, or 32 steps x 64 lanes x {A, B}) + M ring + flags
+    DpArgs da = {ringN, {0, 0, 0}};
+    const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 16;
     for (int stg = 0; stg < n_stages; stg++) {
         sv.stage = stg;
         double* cbuf = c->cost[stg % nbuf].as<double>();
         if (stg >= nbuf) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev_dp1[stg - nbuf], 0));   // buffer free again
         HIP_TRY(hipEventRecord(c->ev_cost0[stg], c->sA));
-        if (stage_tiles[stg] > 0) {
-            hipError_t e = fast_terms ? launch_cost_ti<true>(TI, v, sv, ca, cbuf, stage_tiles[stg], lds_cost, c->sA)
-                                      : launch_cost_ti<false>(TI, v, sv, ca, cbuf, stage_tiles[stg], lds_cost, c->sA);
+        if (stage_tiles[2 * (size_t)stg] > 0) {
+            const TileDesc* td = c->tilesA.as<TileDesc>() + tileA0[(size_t)stg];
+            hipError_t e = fast_terms ? launch_cost_ti<true>(TI, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
+                                      : launch_cost_ti<false>(TI, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA);
+            HIP_TRY(e);
+        }
+        if (stage_tiles[2 * (size_t)stg + 1] > 0) {
+            const TileDesc* td = c->tilesB.as<TileDesc>() + tileB0[(size_t)stg];
+            hipError_t e = fast_terms ? launch_cost_ti<true>(16, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
+                                      : launch_cost_ti<false>(16, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA);
             HIP_TRY(e);
         }
         HIP_TRY(hipEventRecord(c->ev_cost1[stg], c->sA));
         HIP_TRY(hipStreamWaitEvent(c->sB, c->ev_cost1[stg], 0));
         HIP_TRY(hipEventRecord(c->ev_dp0[stg], c->sB));
-        hipLaunchKernelGGL(k_dp, dim3((unsigned)nC), dim3(64 * (1 + WG_DP_LOADERS)), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
+        if (dp_mode == 0)      hipLaunchKernelGGL((k_dp<3, 64>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
+        else if (dp_mode == 1) hipLaunchKernelGGL((k_dp<3, 32>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
+        else                   hipLaunchKernelGGL((k_dp<15, 32>), dim3((unsigned)nC), dim3(64 * 16), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_dp1[stg], c->sB));
     }

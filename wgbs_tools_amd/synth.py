@@ -33,6 +33,7 @@ FORCE_BLOCK = 4096          # a block start is forced at every multiple of this 
 BLOCK_ODDS = 40             # P(block start) = 1/40 per site
 ZERO_COV_THRESH = 3277      # of 65536 -> 5 %
 S_BLOCK, S_LEVEL, S_LOCI_KIND, S_LOCI_U = 1, 2, 5, 6
+S_ISLAND, S_ISLAND_GAP = 7, 8
 S_SAMPLE0 = 16              # streams 16+4*s+{0: block jitter, 1: coverage, 2: bernoulli bytes}
 
 # hg19 chromosome lengths chr1-22,X,Y,M -- CpG counts are made proportional to these
@@ -126,8 +127,22 @@ def genome_shape(total_sites=HG19_NR_SITES, n_chroms=25):
     return HG19_NAMES[:n_chroms], sizes
 
 
-def synth_loci(seed, chrom_sizes):
-    """uint32 bp position of every CpG; positions restart at each chromosome (strictly ascending inside one)."""
+def island_mask(seed, total):
+    """CpG-island-like stretches: one per 1024 sites, 20..620 sites long (exponential tail, mean ~80) — about the
+    count and CpG content of the hg19 island track (28 k islands, 2.1 M CpGs).  Not part of the default genome."""
+    idx = np.arange(total, dtype=np.int64)
+    blk = idx >> 10
+    h = hash_at(seed, S_ISLAND, blk)
+    off = (h & U64(1023)).astype(np.int64) % 900
+    u = ((h >> U64(11)).astype(np.float64) + 1.0) / 9007199254740992.0
+    ln = 20 + np.minimum(600, np.floor(-60.0 * np.log(u))).astype(np.int64)
+    x = idx & 1023
+    return (x >= off) & (x < off + ln)
+
+
+def synth_loci(seed, chrom_sizes, islands=False):
+    """uint32 bp position of every CpG; positions restart at each chromosome (strictly ascending inside one).
+    islands=True adds CpG islands (gaps 2 + Geom(1/8) bp): forward windows of several hundred sites."""
     total = int(np.sum(chrom_sizes))
     idx = np.arange(total, dtype=np.int64)
     dense = (hash_at(seed, S_LOCI_KIND, idx) & U64(3)) == 0
@@ -135,6 +150,10 @@ def synth_loci(seed, chrom_sizes):
     p = np.where(dense, 1.0 / 10.0, 1.0 / 140.0)
     gap = 2 + np.floor(np.log(u) / np.log1p(-p)).astype(np.int64)
     gap = np.minimum(gap, 50000)
+    if islands:
+        ui = ((hash_at(seed, S_ISLAND_GAP, idx) >> U64(11)).astype(np.float64) + 1.0) / 9007199254740992.0
+        gi = 2 + np.floor(np.log(ui) / np.log1p(-1.0 / 8.0)).astype(np.int64)
+        gap = np.where(island_mask(seed, total), gi, gap)
     loci = np.empty(total, dtype=np.int64)
     pos = 0
     for sz in chrom_sizes:
