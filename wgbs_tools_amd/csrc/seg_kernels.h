@@ -641,48 +641,60 @@ __device__ __forceinline__ int32_t wg_ld_l2_i32(const int32_t* p) { return __hip
 //   slotA[s*64 + l] = cost(k, k+j),      k = base+s, j = (l - k) mod 64, for j < F_k,        else -inf
 //   slotB[s*64 + l] = cost(k, k+64+j)                                     for 64+j < F_k,     else -inf   (wide batch only)
 // so the recurrence needs no predicate at all: M[k] + (-inf) can never beat a pending maximum.  Worker `lw` arranges
-// the steps s == lw (mod NW), all its HBM loads in flight before the first LDS store.
+// the steps s == lw (mod NW).  Two phases, one batch apart: the HBM loads of batch b+2 are issued (into registers)
+// while the recurrence sweeps batch b, and stored to the LDS slot during batch b+1 — a full batch to land.
 template <int NW, int BL>
-__device__ __forceinline__ void wg_dp_load_batch(const double* __restrict__ cb, const uint16_t* __restrict__ Wp,
-                                                 const uint32_t* __restrict__ Cp, uint32_t cum0, int base, int s1,
-                                                 double* __restrict__ slotA, double* __restrict__ slotB, uint32_t* __restrict__ kind,
-                                                 int lane, int lw)
+struct DpRows {                                          // one worker's share of a batch, in registers
+    static constexpr int PER = (BL + NW - 1) / NW;
+    double va[PER], vb[PER];
+    bool wideb;
+};
+
+template <int NW, int BL>
+__device__ __forceinline__ void wg_dp_rows_issue(DpRows<NW, BL>& R, const double* __restrict__ cb, const uint16_t* __restrict__ Wp,
+                                                 const uint32_t* __restrict__ Cp, uint32_t cum0, int base, int s1, int lane, int lw)
 {
     constexpr bool WIDEJOB = BL < 64;
-    constexpr int PER = (BL + NW - 1) / NW;
     const double NEG_INF = -__builtin_inf();
     const int il = base + lane;
     const bool inb = lane < BL && il < s1;
     const uint32_t w = inb ? (uint32_t)Wp[il] : 0u;
     const uint32_t rel = inb ? Cp[il] - cum0 : 0u;
-    const bool wideb = WIDEJOB && wg_wave_max_u32(w) > 64u;
-    if (lw == 0 && lane == 0) *kind = wideb ? 1u : 0u;
+    R.wideb = WIDEJOB && wg_wave_max_u32(w) > 64u;
     const int stp0 = base & 63;
-    double va[PER], vb[PER];
 #pragma unroll
-    for (int q = 0; q < PER; q++) {
+    for (int q = 0; q < DpRows<NW, BL>::PER; q++) {
         const int sidx = lw + q * NW;
-        va[q] = NEG_INF; vb[q] = NEG_INF;
+        R.va[q] = NEG_INF; R.vb[q] = NEG_INF;
         if (sidx < BL) {
             const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w, sidx);
             const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rel, sidx);
             const uint32_t j = (uint32_t)(lane - stp0 - sidx) & 63u;
-            if (j < f) va[q] = cb[(int64_t)r + j];
-            if (WIDEJOB && wideb && j + 64u < f) vb[q] = cb[(int64_t)r + j + 64u];
+            if (j < f) R.va[q] = cb[(int64_t)r + j];
+            if (WIDEJOB && R.wideb && j + 64u < f) R.vb[q] = cb[(int64_t)r + j + 64u];
         }
     }
+}
+
+template <int NW, int BL>
+__device__ __forceinline__ void wg_dp_rows_commit(const DpRows<NW, BL>& R, double* __restrict__ slotA, double* __restrict__ slotB,
+                                                  uint32_t* __restrict__ kind, int lane, int lw)
+{
+    constexpr bool WIDEJOB = BL < 64;
+    if (lw == 0 && lane == 0) *kind = R.wideb ? 1u : 0u;
 #pragma unroll
-    for (int q = 0; q < PER; q++) {
+    for (int q = 0; q < DpRows<NW, BL>::PER; q++) {
         const int sidx = lw + q * NW;
         if (sidx < BL) {
-            slotA[sidx * 64 + lane] = va[q];
-            if (WIDEJOB && wideb) slotB[sidx * 64 + lane] = vb[q];
+            slotA[sidx * 64 + lane] = R.va[q];
+            if (WIDEJOB && R.wideb) slotB[sidx * 64 + lane] = R.vb[q];
         }
     }
 }
 
 // Worker waves: blocks longer than 128 sites that START in the batch at `base` (whose M[k] the recurrence has left in
-// Mring), folded target-major into the ring.
+// Mring), folded target-major into the ring.  A ring entry is always updated by the same wave (64-target tile t>>6
+// belongs to worker (t>>6) mod NW), so its read-modify-write sequence is one wave's program order.
 template <int NW, int BL>
 __device__ __forceinline__ void wg_dp_far(const double* __restrict__ cb, const uint16_t* __restrict__ Wp, const uint32_t* __restrict__ Cp,
                                           uint32_t cum0, int base, int s1, const double* __restrict__ Mring,
@@ -697,8 +709,10 @@ __device__ __forceinline__ void wg_dp_far(const double* __restrict__ cb, const u
     if (fmax <= 128u) return;
     const double m = inb ? Mring[il & 127] : 0.0;
     const int thi = base + BL - 1 + (int)fmax;            // targets are < thi
-    for (int t0 = base + 128 + lw * 64; t0 < thi; t0 += 64 * NW) {
-        const int t = t0 + lane;
+    int tile = (base + 128) >> 6;
+    tile += (lw - tile % NW + NW) % NW;                   // first tile at or after it that this worker owns
+    for (; (tile << 6) < thi; tile += NW) {
+        const int t = (tile << 6) + lane;
         const int sl = t & rmask;
         double best = wg_ld_l2_f64(pendB + sl);
         int32_t arg = wg_ld_l2_i32(pendA + sl);
@@ -710,7 +724,7 @@ __device__ __forceinline__ void wg_dp_far(const double* __restrict__ cb, const u
             for (int u = 0; u < 8; u++) {
                 const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w, g + u);
                 const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rel, g + u);
-                const uint32_t j = (uint32_t)(t - (base + g + u));          // >= 97
+                const uint32_t j = (uint32_t)(t - (base + g + u));          // > 0
                 v[u] = NEG_INF;
                 if (f > 128u && j >= 128u && j < f) { v[u] = cb[(int64_t)r + j]; any = true; }
             }
@@ -777,7 +791,9 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     extern __shared__ __attribute__((aligned(16))) char smem_dp[];
     double* slots = reinterpret_cast<double*>(smem_dp);                       // [2][SLOT]
     double* Mring = slots + 2 * SLOT;                                         // [128] M[k] of the last batches' steps
-    uint32_t* kinds = reinterpret_cast<uint32_t*>(Mring + 128);               // [2] 1: the slot holds a wide batch (A and B)
+    double* pendLB = Mring + 128;                                             // [2][32] ring entries of the next batches' steps
+    int32_t* pendLA = reinterpret_cast<int32_t*>(pendLB + 64);                // [2][32]
+    uint32_t* kinds = reinterpret_cast<uint32_t*>(pendLA + 64);               // [2] 1: the slot holds a wide batch (A and B)
     const int lane = threadIdx.x & 63;
     const bool worker = threadIdx.x >= 64;
     const int lw = (int)(threadIdx.x >> 6) - 1;       // worker index (0..NW-1)
@@ -801,13 +817,24 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     if (!worker) __builtin_amdgcn_s_setprio(3);        // the recurrence is one dependent chain: let it win issue arbitration
     double best = NEG_INF, bestB = NEG_INF;             // pending steps of this lane (wave 0)
     int32_t arg = 0, argB = 0;
-    double pb = NEG_INF;                                // ring entry of the step this lane finishes in the coming batch
-    int32_t pa = 0;
     double Mk = 0.0;                                    // M[k] of the step about to run; M[0] = 0 (segmentor.cpp:97)
+    DpRows<NW, BL> rows;                                // (workers) rows of the batch after the next, in flight
     if (worker) {
         if (WIDEJOB && s0 == 0)
             for (int x = (int)threadIdx.x - 64; x < A.ringN; x += 64 * NW) pendB[x] = NEG_INF;
-        wg_dp_load_batch<NW, BL>(cb, Wp, Cp, cum0, s0, s1, slots, slots + BL * 64, kinds, lane, lw);
+        wg_dp_rows_issue<NW, BL>(rows, cb, Wp, Cp, cum0, s0, s1, lane, lw);
+        wg_dp_rows_commit<NW, BL>(rows, slots, slots + BL * 64, kinds, lane, lw);
+        if (nb > 1) wg_dp_rows_issue<NW, BL>(rows, cb, Wp, Cp, cum0, s0 + BL, s1, lane, lw);
+        if (WIDEJOB && lw == 0 && lane < BL) {
+            double v = NEG_INF;
+            int32_t a = 0;
+            if (s0 != 0) {
+                const int sl = (s0 + lane) & rmask;
+                v = wg_ld_l2_f64(pendB + sl); a = wg_ld_l2_i32(pendA + sl);
+                pendB[sl] = NEG_INF;
+            }
+            pendLB[lane] = v; pendLA[lane] = a;
+        }
     } else if (s0 != 0) {
         Mk = gs[0];
         best = gs[1 + lane];
@@ -815,42 +842,47 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
         if (WIDEJOB) {
             bestB = gs[129 + lane];
             argB = (int32_t)__double_as_longlong(gs[193 + lane]);
-            const int d = (lane - s0) & 63;
-            if (d < BL) {
-                const int sl = (s0 + d) & rmask;
-                pb = wg_ld_l2_f64(pendB + sl); pa = wg_ld_l2_i32(pendA + sl);
-                pendB[sl] = NEG_INF;
-            }
         }
+        // have the loaded state in registers HERE: otherwise the wait for it is placed inside the loop, where it would
+        // also sit out the latency of the loop's own global stores, every batch
+        asm volatile("" : "+v"(Mk), "+v"(best), "+v"(arg), "+v"(bestB), "+v"(argB));
     }
     __syncthreads();
 
     for (int b = 0; b < nb; b++) {
         const int base = s0 + b * BL;
         if (worker) {
+            // rows of batch b+1 (loaded during the previous batch) into the free slot; loads of batch b+2 take off
             if (b + 1 < nb)
-                wg_dp_load_batch<NW, BL>(cb, Wp, Cp, cum0, base + BL, s1, slots + (size_t)((b + 1) & 1) * SLOT,
-                                         slots + (size_t)((b + 1) & 1) * SLOT + BL * 64, kinds + ((b + 1) & 1), lane, lw);
+                wg_dp_rows_commit<NW, BL>(rows, slots + (size_t)((b + 1) & 1) * SLOT, slots + (size_t)((b + 1) & 1) * SLOT + BL * 64,
+                                          kinds + ((b + 1) & 1), lane, lw);
+            const bool fetch = WIDEJOB && b + 1 < nb && lw == 0 && lane < BL;
+            const int fsl = (base + BL + lane) & rmask;
+            double fv = NEG_INF;
+            int32_t fa = 0;
+            if (fetch) { fv = wg_ld_l2_f64(pendB + fsl); fa = wg_ld_l2_i32(pendA + fsl); }
+            if (b + 2 < nb) wg_dp_rows_issue<NW, BL>(rows, cb, Wp, Cp, cum0, base + 2 * BL, s1, lane, lw);
             if (WIDEJOB && b >= 1)
                 wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, base - BL, s1, Mring, pendB, pendA, rmask, lane, lw);
+            if (fetch) {
+                // ring entries of the next batch's steps (complete: their sources lie >= 128 sites back), fetched and reset
+                pendLB[((b + 1) & 1) * 32 + lane] = fv;
+                pendLA[((b + 1) & 1) * 32 + lane] = fa;
+                pendB[fsl] = NEG_INF;
+            }
         } else {
             const double* slot = slots + (size_t)(b & 1) * SLOT;
             const bool wideb = WIDEJOB && kinds[b & 1] != 0u;
             const int stp0 = WIDEJOB ? (base & 63) : 0;          // lane of the batch's first step
             const int d = (lane - stp0) & 63;                    // this lane finishes step base + d (in this batch iff d < BL)
             const bool fin = d < BL;
-            double npb = NEG_INF;
-            int32_t npa = 0;
-            if (WIDEJOB) {
+            if (WIDEJOB && fin) {
                 // ring entry of the step this lane is about to finish: all its candidates precede the ones to come
-                const bool mrg = fin && pb >= best;
+                const double pb = pendLB[(b & 1) * 32 + d];
+                const int32_t pa = pendLA[(b & 1) * 32 + d];
+                const bool mrg = pb >= best;
                 best = mrg ? pb : best;
                 arg = mrg ? pa : arg;
-                if (b + 1 < nb && !fin) {                         // entries of the next batch's steps: in flight during this one
-                    const int sl = (base + d) & rmask;
-                    npb = wg_ld_l2_f64(pendB + sl); npa = wg_ld_l2_i32(pendA + sl);
-                    pendB[sl] = NEG_INF;
-                }
             }
             uint32_t tbk = 0;
             const double* my = slot + lane;
@@ -893,9 +925,13 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
                 if (fin) Mring[(base + d + 1) & 127] = Mfin;      // M[k+1] of the batch's steps, for the workers
             }
             if (fin && base + d < s1) J.back16[cd.site_off + base + d] = (uint16_t)tbk;
-            pb = npb; pa = npa;
         }
-        __syncthreads();
+        // LDS is all that must be settled at the barrier.  Global memory: nobody in the workgroup reads what the
+        // recurrence wave stores; a ring entry is only ever updated by its owner wave, and fetched (by worker 0) no
+        // sooner than two barriers after its last update — by then the updating wave has waited for later loads of its
+        // own, and vector memory operations of a wave complete in order.  Waiting for store latency here, every 32
+        // steps, would cost more than the steps themselves.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (WIDEJOB && worker)
         wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, s0 + (nb - 1) * BL, s1, Mring, pendB, pendA, rmask, lane, lw);
