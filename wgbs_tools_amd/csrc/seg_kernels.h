@@ -742,19 +742,55 @@ __device__ __forceinline__ void wg_dp_far(const double* __restrict__ cb, const u
 
 // One step of a batch without blocks longer than 64 sites: fold M[k] into the 64 pending steps, read M[k+1] off lane
 // `stp`, and let that lane move on to step k+64 with what earlier 65..128-site blocks left for it (pb, pa).
+template <bool WIDEJOB>
 __device__ __forceinline__ void wg_dp_fast_step(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double cv,
                                                 const int k, const int stp, const int lane, const double pb, const int32_t pa)
 {
+    // On the chain: add -> max -> readlane (-> next add).  The comparison that maintains `arg` reads the OLD best and
+    // runs beside it (strict: the first maximum wins, segmentor.cpp:148).  No NaN can occur (finite scores, -inf fill),
+    // so the bare instruction stands for fmax.
     const double cand = Mk + cv;
-    const bool upd = cand > best;                      // strict: the first maximum wins (segmentor.cpp:148)
-    best = upd ? cand : best;
+    const bool upd = cand > best;
+    double nbest;
+    asm("v_max_f64 %0, %1, %2" : "=v"(nbest) : "v"(best), "v"(cand));
+    Mk = wg_readlane_f64(nbest, stp);                  // M[k+1]
     arg = upd ? k : arg;
-    Mk = wg_readlane_f64(best, stp);                   // M[k+1]
     const int ak = __builtin_amdgcn_readlane(arg, stp);
     const bool mine = lane == stp;                     // this lane moves on to step k+64
-    tbk = mine ? (uint32_t)(k + 1 - ak) : tbk;
-    best = mine ? pb : best;
-    arg = mine ? pa : arg;
+    tbk = mine ? (uint32_t)(k + 1 - ak) : tbk;         // length of the best block ending at k
+    best = mine ? pb : nbest;
+    if (WIDEJOB) arg = mine ? pa : arg;                // (otherwise -inf is waiting: the first candidate replaces arg)
+}
+
+// The same step for a job whose windows are all <= 64 sites, with the lane of the step known at compile time (64-step
+// batches start at lane 0): lane selects and the source mark become inline constants.  `arg` holds the LANE of the
+// best source (a source is at most 63 steps back, so (STP - arg) mod 64 is the distance), the finished lane is
+// re-armed with -inf by two v_writelane, and the block length goes to its lane of tbk by a third.  10 VALU per step:
+//   v_add_f64  v_cmp_gt_f64  v_max_f64  v_cndmask  3 x v_readlane  3 x v_writelane
+template <int STP>
+__device__ __forceinline__ void wg_dp_step64(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double cv, const uint32_t ninf_hi)
+{
+    const double cand = Mk + cv;
+    const bool upd = cand > best;                      // strict: the first maximum wins (segmentor.cpp:148)
+    double nbest;
+    asm("v_max_f64 %0, %1, %2" : "=v"(nbest) : "v"(best), "v"(cand));
+    Mk = wg_readlane_f64(nbest, STP);                  // M[k+1]
+    arg = upd ? STP : arg;
+    const int ak = __builtin_amdgcn_readlane(arg, STP);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(tbk) : "s"(((STP - ak) & 63) + 1), "n"(STP));
+    uint32_t lo = (uint32_t)__double_as_longlong(nbest), hi = (uint32_t)(__double_as_longlong(nbest) >> 32);
+    asm("v_writelane_b32 %0, 0, %1" : "+v"(lo) : "n"(STP));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(ninf_hi), "n"(STP));
+    best = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <int G>
+__device__ __forceinline__ void wg_dp_group64(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double (&cur)[8], const uint32_t ninf_hi)
+{
+    wg_dp_step64<G + 0>(best, arg, tbk, Mk, cur[0], ninf_hi); wg_dp_step64<G + 1>(best, arg, tbk, Mk, cur[1], ninf_hi);
+    wg_dp_step64<G + 2>(best, arg, tbk, Mk, cur[2], ninf_hi); wg_dp_step64<G + 3>(best, arg, tbk, Mk, cur[3], ninf_hi);
+    wg_dp_step64<G + 4>(best, arg, tbk, Mk, cur[4], ninf_hi); wg_dp_step64<G + 5>(best, arg, tbk, Mk, cur[5], ninf_hi);
+    wg_dp_step64<G + 6>(best, arg, tbk, Mk, cur[6], ninf_hi); wg_dp_step64<G + 7>(best, arg, tbk, Mk, cur[7], ninf_hi);
 }
 
 // One step of a batch with blocks of up to 128 sites in the registers (longer ones are the workers' business).
@@ -891,16 +927,29 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
                 double cur[8], nxt[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) cur[u] = my[u * 64];
+                if (!WIDEJOB) {
+                    const uint32_t ninf_hi = 0xfff00000u;
+#define WG_DP_GROUP64(G)                                                                             \
+                    if ((G) + 8 < 64) {                                                              \
+                        _Pragma("unroll") for (int u = 0; u < 8; u++) nxt[u] = my[((G) + 8 + u) * 64]; \
+                    }                                                                                \
+                    wg_dp_group64<(G)>(best, arg, tbk, Mk, cur, ninf_hi);                            \
+                    _Pragma("unroll") for (int u = 0; u < 8; u++) cur[u] = nxt[u];
+                    WG_DP_GROUP64(0) WG_DP_GROUP64(8) WG_DP_GROUP64(16) WG_DP_GROUP64(24)
+                    WG_DP_GROUP64(32) WG_DP_GROUP64(40) WG_DP_GROUP64(48) WG_DP_GROUP64(56)
+#undef WG_DP_GROUP64
+                } else {
 #pragma unroll 1
-                for (int g = 0; g < BL; g += 8) {
-                    if (g + 8 < BL) {
+                    for (int g = 0; g < BL; g += 8) {
+                        if (g + 8 < BL) {
 #pragma unroll
-                        for (int u = 0; u < 8; u++) nxt[u] = my[(g + 8 + u) * 64];
+                            for (int u = 0; u < 8; u++) nxt[u] = my[(g + 8 + u) * 64];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) wg_dp_fast_step<WIDEJOB>(best, arg, tbk, Mk, cur[u], base + g + u, stp0 + g + u, lane, bestB, argB);
+#pragma unroll
+                        for (int u = 0; u < 8; u++) cur[u] = nxt[u];
                     }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) wg_dp_fast_step(best, arg, tbk, Mk, cur[u], base + g + u, stp0 + g + u, lane, bestB, argB);
-#pragma unroll
-                    for (int u = 0; u < 8; u++) cur[u] = nxt[u];
                 }
                 if (WIDEJOB) bestB = fin ? NEG_INF : bestB;
             } else {

@@ -107,8 +107,7 @@ struct wgbsseg_ctx {
     int force_dp_mode = 0;   // WGBSSEG_DP_MODE: 1 = 32-step batches (wide-window path), 2 = the same with 15 worker waves
     int force_ns = 0;
     int force_ti = 0;
-    int min_stages = 1;      // stages exist to bound the scored-block buffer; k_dp alone (3.9 ms per 60k-site chunk) is
-                             // faster than k_dp competing with k_cost for CUs, so no overlap is sought by default
+    int min_stages = 0;      // WGBSSEG_MIN_STAGES; 0: decided per call from the number of chunks
     bool accumulate = false;   // add to `tim` instead of resetting it (region-level calls span several batches)
 };
 
@@ -461,7 +460,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     {
         const long long bytes = total_pairs * 8;
         n_stages = (int)std::max<long long>(1, (bytes + c->cost_budget_bytes - 1) / c->cost_budget_bytes);
-        if (job.max_len >= 8192) n_stages = std::max(n_stages, c->min_stages);
+        // Few chunks (one rank's share of a sharded genome): the recurrence occupies a fraction of the CUs, so let it
+        // chase the scoring kernel stage by stage (measured: 71 chunks 10.1 -> 8.7 ms, 132 chunks 16.2 -> 15.0 ms).  With
+        // hundreds of chunks k_dp alone (3.9 ms per 60k-site chunk, all chunks at once) beats k_dp competing for CUs.
+        if (job.max_len >= 8192) n_stages = std::max(n_stages, c->min_stages > 0 ? c->min_stages : (nC <= 160 ? 8 : 1));
         if (c->force_stages > 0) n_stages = c->force_stages;
         n_stages = std::min<int>(n_stages, std::max(1, (job.max_len + 63) / 64));
     }
