@@ -14,7 +14,8 @@
 //             compare folds candidate k into the 64 steps it can start (ascending k and strict '>' = the reference's
 //             first-maximum rule); M[k+1] is then read from lane k mod 64.  No cross-lane reduction on the chain.
 //             Blocks of 65..128 sites use a second pending register; longer ones are pushed by the worker waves.
-//   k_trace   traceback (segmentor.cpp:50-58) out of an LDS-resident window of back-pointers.
+//   k_trace   traceback (segmentor.cpp:50-58) out of an LDS-resident window of back-pointers, cut into segments that
+//             are walked speculatively in parallel and joined by one short sequential pass.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -26,7 +27,8 @@
                                     // that is a multiple of 64 inside the chunk, plus (group 0) at the chunk start itself
 #define WG_BLOCK        256
 #define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)
-#define WG_TRACE_WIN    65536       // back-pointers staged in LDS by k_trace (128 KiB)
+#define WG_TRACE_WIN    32768       // back-pointers staged in LDS by k_trace (64 KiB)
+#define WG_TRACE_SEG    128         // speculative walks per window
 
 // Exact-restatement tables: global (constant) memory, read only by the rare guard-band fallback and by the plain kernel.
 __device__ const wg_log_tables g_wg_tables = WG_LOG_TABLES_INIT;
@@ -641,26 +643,39 @@ __device__ __forceinline__ int32_t wg_ld_l2_i32(const int32_t* p) { return __hip
 //   slotA[s*64 + l] = cost(k, k+j),      k = base+s, j = (l - k) mod 64, for j < F_k,        else -inf
 //   slotB[s*64 + l] = cost(k, k+64+j)                                     for 64+j < F_k,     else -inf   (wide batch only)
 // so the recurrence needs no predicate at all: M[k] + (-inf) can never beat a pending maximum.  Worker `lw` arranges
-// the steps s == lw (mod NW).  Two phases, one batch apart: the HBM loads of batch b+2 are issued (into registers)
-// while the recurrence sweeps batch b, and stored to the LDS slot during batch b+1 — a full batch to land.
+// the steps s == lw (mod NW).  Three phases, one batch apart each, so that no HBM latency is ever waited for: the
+// windows and row offsets of batch b+3 are loaded while the recurrence sweeps batch b; with them the row loads of
+// batch b+2 are issued (into registers); the rows of batch b+1 are stored to the free LDS slot.
 template <int NW, int BL>
 struct DpRows {                                          // one worker's share of a batch, in registers
     static constexpr int PER = (BL + NW - 1) / NW;
     double va[PER], vb[PER];
+    uint32_t fmax;                                       // widest window of the batch
     bool wideb;
 };
 
+struct DpMeta { uint32_t w, rel; };                      // lane l: window and row offset of step base + l of a batch
+
+template <int BL>
+__device__ __forceinline__ DpMeta wg_dp_meta_load(const uint16_t* __restrict__ Wp, const uint32_t* __restrict__ Cp, uint32_t cum0,
+                                                  int base, int s1, int lane)
+{
+    const int il = base + lane;
+    const bool inb = lane < BL && il < s1;
+    DpMeta m;
+    m.w = inb ? (uint32_t)Wp[il] : 0u;
+    m.rel = inb ? Cp[il] - cum0 : 0u;
+    return m;
+}
+
 template <int NW, int BL>
-__device__ __forceinline__ void wg_dp_rows_issue(DpRows<NW, BL>& R, const double* __restrict__ cb, const uint16_t* __restrict__ Wp,
-                                                 const uint32_t* __restrict__ Cp, uint32_t cum0, int base, int s1, int lane, int lw)
+__device__ __forceinline__ void wg_dp_rows_issue(DpRows<NW, BL>& R, const double* __restrict__ cb, const DpMeta M, int base, int lane, int lw)
 {
     constexpr bool WIDEJOB = BL < 64;
     const double NEG_INF = -__builtin_inf();
-    const int il = base + lane;
-    const bool inb = lane < BL && il < s1;
-    const uint32_t w = inb ? (uint32_t)Wp[il] : 0u;
-    const uint32_t rel = inb ? Cp[il] - cum0 : 0u;
-    R.wideb = WIDEJOB && wg_wave_max_u32(w) > 64u;
+    const uint32_t w = M.w, rel = M.rel;
+    R.fmax = wg_wave_max_u32(w);
+    R.wideb = WIDEJOB && R.fmax > 64u;
     const int stp0 = base & 63;
 #pragma unroll
     for (int q = 0; q < DpRows<NW, BL>::PER; q++) {
@@ -706,7 +721,6 @@ __device__ __forceinline__ void wg_dp_far(const double* __restrict__ cb, const u
     const uint32_t w = inb ? (uint32_t)Wp[il] : 0u;
     const uint32_t rel = inb ? Cp[il] - cum0 : 0u;
     const uint32_t fmax = wg_wave_max_u32(w);
-    if (fmax <= 128u) return;
     const double m = inb ? Mring[il & 127] : 0.0;
     const int thi = base + BL - 1 + (int)fmax;            // targets are < thi
     int tile = (base + 128) >> 6;
@@ -740,32 +754,117 @@ __device__ __forceinline__ void wg_dp_far(const double* __restrict__ cb, const u
     }
 }
 
-// One step of a batch without blocks longer than 64 sites: fold M[k] into the 64 pending steps, read M[k+1] off lane
-// `stp`, and let that lane move on to step k+64 with what earlier 65..128-site blocks left for it (pb, pa).
-template <bool WIDEJOB>
-__device__ __forceinline__ void wg_dp_fast_step(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double cv,
-                                                const int k, const int stp, const int lane, const double pb, const int32_t pa)
+// One step of a batch without blocks longer than 64 sites, in a job that has wider windows elsewhere (32-step
+// batches; STP = lane of the step, known at compile time): fold M[k] into the 64 pending steps, read M[k+1] off lane
+// STP, and let that lane move on to step k+64 with what earlier 65..128-site blocks left for it in (bestB, argB).
+// On the chain: add -> max -> readlane (-> next add).  The comparison that maintains `arg` reads the OLD best and runs
+// beside it (strict: the first maximum wins, segmentor.cpp:148).  No NaN can occur (finite scores, -inf fill), so
+// the bare v_max_f64 stands for fmax.
+template <int STP>
+__device__ __forceinline__ void wg_dp_step32(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double cv,
+                                             const int k, const int lane, const double bestB, const int32_t argB)
 {
-    // On the chain: add -> max -> readlane (-> next add).  The comparison that maintains `arg` reads the OLD best and
-    // runs beside it (strict: the first maximum wins, segmentor.cpp:148).  No NaN can occur (finite scores, -inf fill),
-    // so the bare instruction stands for fmax.
     const double cand = Mk + cv;
     const bool upd = cand > best;
     double nbest;
     asm("v_max_f64 %0, %1, %2" : "=v"(nbest) : "v"(best), "v"(cand));
-    Mk = wg_readlane_f64(nbest, stp);                  // M[k+1]
+    Mk = wg_readlane_f64(nbest, STP);                  // M[k+1]
     arg = upd ? k : arg;
-    const int ak = __builtin_amdgcn_readlane(arg, stp);
-    const bool mine = lane == stp;                     // this lane moves on to step k+64
-    tbk = mine ? (uint32_t)(k + 1 - ak) : tbk;         // length of the best block ending at k
-    best = mine ? pb : nbest;
-    if (WIDEJOB) arg = mine ? pa : arg;                // (otherwise -inf is waiting: the first candidate replaces arg)
+    const int ak = __builtin_amdgcn_readlane(arg, STP);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(tbk) : "s"(ak), "n"(STP));             // start of the best block ending at k
+    const bool mine = lane == STP;                     // this lane moves on to step k+64
+    best = mine ? bestB : nbest;
+    arg = mine ? argB : arg;
+}
+
+// One step of a batch with blocks of up to 128 sites in the registers (longer ones are the workers' business): the
+// same, plus the fold into the second pending register, which is re-armed when the lane moves on; M[k+1] stays with
+// the lane (Mfin) for the workers.
+template <int STP>
+__device__ __forceinline__ void wg_dp_wide_step32(double& best, int32_t& arg, double& bestB, int32_t& argB, uint32_t& tbk,
+                                                  uint32_t& Mfin_lo, uint32_t& Mfin_hi, double& Mk, const double ca, const double cb2,
+                                                  const int k, const int lane, const uint32_t ninf_hi)
+{
+    const double candA = Mk + ca;
+    const double candB = Mk + cb2;
+    const bool updA = candA > best;
+    double nbest;
+    asm("v_max_f64 %0, %1, %2" : "=v"(nbest) : "v"(best), "v"(candA));
+    Mk = wg_readlane_f64(nbest, STP);                  // M[k+1]
+    arg = updA ? k : arg;
+    const bool updB = candB > bestB;
+    double nbestB;
+    asm("v_max_f64 %0, %1, %2" : "=v"(nbestB) : "v"(bestB), "v"(candB));
+    argB = updB ? k : argB;
+    const int ak = __builtin_amdgcn_readlane(arg, STP);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(tbk) : "s"(ak), "n"(STP));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(Mfin_lo) : "s"((uint32_t)__double_as_longlong(Mk)), "n"(STP));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(Mfin_hi) : "s"((uint32_t)(__double_as_longlong(Mk) >> 32)), "n"(STP));
+    const bool mine = lane == STP;
+    best = mine ? nbestB : nbest;
+    arg = mine ? argB : arg;
+    uint32_t lo = (uint32_t)__double_as_longlong(nbestB), hi = (uint32_t)(__double_as_longlong(nbestB) >> 32);
+    asm("v_writelane_b32 %0, 0, %1" : "+v"(lo) : "n"(STP));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(ninf_hi), "n"(STP));
+    bestB = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// 32 steps of a batch whose first step sits on lane STP0 (0 or 32), out of the arranged slot: 8 (4) rows at a time,
+// the next rows already in flight.
+template <int STP0>
+__device__ __forceinline__ void wg_dp_batch32(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double* __restrict__ my,
+                                              const int base, const int lane, const double bestB, const int32_t argB)
+{
+    double cur[8], nxt[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) cur[u] = my[u * 64];
+#define WG_DP_GROUP32(G)                                                                                   \
+    if ((G) + 8 < 32) {                                                                                    \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) nxt[u] = my[((G) + 8 + u) * 64];                     \
+    }                                                                                                      \
+    wg_dp_step32<STP0 + (G) + 0>(best, arg, tbk, Mk, cur[0], base + (G) + 0, lane, bestB, argB);           \
+    wg_dp_step32<STP0 + (G) + 1>(best, arg, tbk, Mk, cur[1], base + (G) + 1, lane, bestB, argB);           \
+    wg_dp_step32<STP0 + (G) + 2>(best, arg, tbk, Mk, cur[2], base + (G) + 2, lane, bestB, argB);           \
+    wg_dp_step32<STP0 + (G) + 3>(best, arg, tbk, Mk, cur[3], base + (G) + 3, lane, bestB, argB);           \
+    wg_dp_step32<STP0 + (G) + 4>(best, arg, tbk, Mk, cur[4], base + (G) + 4, lane, bestB, argB);           \
+    wg_dp_step32<STP0 + (G) + 5>(best, arg, tbk, Mk, cur[5], base + (G) + 5, lane, bestB, argB);           \
+    wg_dp_step32<STP0 + (G) + 6>(best, arg, tbk, Mk, cur[6], base + (G) + 6, lane, bestB, argB);           \
+    wg_dp_step32<STP0 + (G) + 7>(best, arg, tbk, Mk, cur[7], base + (G) + 7, lane, bestB, argB);           \
+    _Pragma("unroll") for (int u = 0; u < 8; u++) cur[u] = nxt[u];
+    WG_DP_GROUP32(0) WG_DP_GROUP32(8) WG_DP_GROUP32(16) WG_DP_GROUP32(24)
+#undef WG_DP_GROUP32
+}
+
+template <int STP0>
+__device__ __forceinline__ void wg_dp_wide_batch32(double& best, int32_t& arg, double& bestB, int32_t& argB, uint32_t& tbk, double& Mfin,
+                                                   double& Mk, const double* __restrict__ my, const double* __restrict__ myB,
+                                                   const int base, const int lane)
+{
+    const uint32_t ninf_hi = 0xfff00000u;
+    uint32_t mlo = 0, mhi = 0;
+    double cur[4], curB[4], nxt[4], nxtB[4];          // 4 steps (~0.3 us) cover the LDS latency; 8 would spill at 16 waves
+#pragma unroll
+    for (int u = 0; u < 4; u++) { cur[u] = my[u * 64]; curB[u] = myB[u * 64]; }
+#define WG_DP_WGROUP32(G)                                                                                                          \
+    if ((G) + 4 < 32) {                                                                                                            \
+        _Pragma("unroll") for (int u = 0; u < 4; u++) { nxt[u] = my[((G) + 4 + u) * 64]; nxtB[u] = myB[((G) + 4 + u) * 64]; }      \
+    }                                                                                                                              \
+    wg_dp_wide_step32<STP0 + (G) + 0>(best, arg, bestB, argB, tbk, mlo, mhi, Mk, cur[0], curB[0], base + (G) + 0, lane, ninf_hi);  \
+    wg_dp_wide_step32<STP0 + (G) + 1>(best, arg, bestB, argB, tbk, mlo, mhi, Mk, cur[1], curB[1], base + (G) + 1, lane, ninf_hi);  \
+    wg_dp_wide_step32<STP0 + (G) + 2>(best, arg, bestB, argB, tbk, mlo, mhi, Mk, cur[2], curB[2], base + (G) + 2, lane, ninf_hi);  \
+    wg_dp_wide_step32<STP0 + (G) + 3>(best, arg, bestB, argB, tbk, mlo, mhi, Mk, cur[3], curB[3], base + (G) + 3, lane, ninf_hi);  \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) { cur[u] = nxt[u]; curB[u] = nxtB[u]; }
+    WG_DP_WGROUP32(0) WG_DP_WGROUP32(4) WG_DP_WGROUP32(8) WG_DP_WGROUP32(12)
+    WG_DP_WGROUP32(16) WG_DP_WGROUP32(20) WG_DP_WGROUP32(24) WG_DP_WGROUP32(28)
+#undef WG_DP_WGROUP32
+    Mfin = __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
 }
 
 // The same step for a job whose windows are all <= 64 sites, with the lane of the step known at compile time (64-step
 // batches start at lane 0): lane selects and the source mark become inline constants.  `arg` holds the LANE of the
 // best source (a source is at most 63 steps back, so (STP - arg) mod 64 is the distance), the finished lane is
-// re-armed with -inf by two v_writelane, and the block length goes to its lane of tbk by a third.  10 VALU per step:
+// re-armed with -inf by two v_writelane, and the source's lane goes to its lane of tbk by a third (turned into the
+// block length once per batch).  10 VALU and no scalar arithmetic per step:
 //   v_add_f64  v_cmp_gt_f64  v_max_f64  v_cndmask  3 x v_readlane  3 x v_writelane
 template <int STP>
 __device__ __forceinline__ void wg_dp_step64(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double cv, const uint32_t ninf_hi)
@@ -777,7 +876,7 @@ __device__ __forceinline__ void wg_dp_step64(double& best, int32_t& arg, uint32_
     Mk = wg_readlane_f64(nbest, STP);                  // M[k+1]
     arg = upd ? STP : arg;
     const int ak = __builtin_amdgcn_readlane(arg, STP);
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(tbk) : "s"(((STP - ak) & 63) + 1), "n"(STP));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(tbk) : "s"(ak), "n"(STP));            // lane of the best source; decoded per batch
     uint32_t lo = (uint32_t)__double_as_longlong(nbest), hi = (uint32_t)(__double_as_longlong(nbest) >> 32);
     asm("v_writelane_b32 %0, 0, %1" : "+v"(lo) : "n"(STP));
     asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(ninf_hi), "n"(STP));
@@ -791,29 +890,6 @@ __device__ __forceinline__ void wg_dp_group64(double& best, int32_t& arg, uint32
     wg_dp_step64<G + 2>(best, arg, tbk, Mk, cur[2], ninf_hi); wg_dp_step64<G + 3>(best, arg, tbk, Mk, cur[3], ninf_hi);
     wg_dp_step64<G + 4>(best, arg, tbk, Mk, cur[4], ninf_hi); wg_dp_step64<G + 5>(best, arg, tbk, Mk, cur[5], ninf_hi);
     wg_dp_step64<G + 6>(best, arg, tbk, Mk, cur[6], ninf_hi); wg_dp_step64<G + 7>(best, arg, tbk, Mk, cur[7], ninf_hi);
-}
-
-// One step of a batch with blocks of up to 128 sites in the registers (longer ones are the workers' business).
-__device__ __forceinline__ void wg_dp_wide_step(double& best, int32_t& arg, double& bestB, int32_t& argB, uint32_t& tbk, double& Mfin,
-                                                double& Mk, const double ca, const double cb2, const int k, const int stp, const int lane)
-{
-    const double NEG_INF = -__builtin_inf();
-    const double candA = Mk + ca;
-    const bool updA = candA > best;
-    best = updA ? candA : best;
-    arg = updA ? k : arg;
-    const double candB = Mk + cb2;
-    const bool updB = candB > bestB;
-    bestB = updB ? candB : bestB;
-    argB = updB ? k : argB;
-    Mk = wg_readlane_f64(best, stp);                   // M[k+1]
-    const int ak = __builtin_amdgcn_readlane(arg, stp);
-    const bool mine = lane == stp;
-    tbk = mine ? (uint32_t)(k + 1 - ak) : tbk;
-    Mfin = mine ? best : Mfin;                         // M[k+1] stays with the lane for the workers
-    best = mine ? bestB : best;
-    arg = mine ? argB : arg;
-    bestB = mine ? NEG_INF : bestB;
 }
 
 // state kept per chunk in global memory: [0] M[k] of the next step, [1..64] best, [65..128] arg, [129..192] bestB,
@@ -854,13 +930,17 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     double best = NEG_INF, bestB = NEG_INF;             // pending steps of this lane (wave 0)
     int32_t arg = 0, argB = 0;
     double Mk = 0.0;                                    // M[k] of the step about to run; M[0] = 0 (segmentor.cpp:97)
-    DpRows<NW, BL> rows;                                // (workers) rows of the batch after the next, in flight
+    DpRows<NW, BL> rows;                                // (workers) rows of the next batch, in flight
+    DpMeta meta = {0u, 0u};                             // (workers) windows / row offsets of the batch after the next
+    uint32_t fm_prev = 0, fm_cur = 0, fm_n1 = 0;        // (workers) widest window of batches b-1, b, b+1
     if (worker) {
         if (WIDEJOB && s0 == 0)
             for (int x = (int)threadIdx.x - 64; x < A.ringN; x += 64 * NW) pendB[x] = NEG_INF;
-        wg_dp_rows_issue<NW, BL>(rows, cb, Wp, Cp, cum0, s0, s1, lane, lw);
+        wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_load<BL>(Wp, Cp, cum0, s0, s1, lane), s0, lane, lw);
         wg_dp_rows_commit<NW, BL>(rows, slots, slots + BL * 64, kinds, lane, lw);
-        if (nb > 1) wg_dp_rows_issue<NW, BL>(rows, cb, Wp, Cp, cum0, s0 + BL, s1, lane, lw);
+        fm_cur = rows.fmax;
+        if (nb > 1) { wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_load<BL>(Wp, Cp, cum0, s0 + BL, s1, lane), s0 + BL, lane, lw); fm_n1 = rows.fmax; }
+        if (nb > 2) meta = wg_dp_meta_load<BL>(Wp, Cp, cum0, s0 + 2 * BL, s1, lane);
         if (WIDEJOB && lw == 0 && lane < BL) {
             double v = NEG_INF;
             int32_t a = 0;
@@ -897,15 +977,20 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
             double fv = NEG_INF;
             int32_t fa = 0;
             if (fetch) { fv = wg_ld_l2_f64(pendB + fsl); fa = wg_ld_l2_i32(pendA + fsl); }
-            if (b + 2 < nb) wg_dp_rows_issue<NW, BL>(rows, cb, Wp, Cp, cum0, base + 2 * BL, s1, lane, lw);
-            if (WIDEJOB && b >= 1)
+            uint32_t fm_n2 = 0;
+            if (b + 2 < nb) { wg_dp_rows_issue<NW, BL>(rows, cb, meta, base + 2 * BL, lane, lw); fm_n2 = rows.fmax; }
+            if (WIDEJOB && b >= 1 && fm_prev > 128u)
                 wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, base - BL, s1, Mring, pendB, pendA, rmask, lane, lw);
+            fm_prev = fm_cur; fm_cur = fm_n1; fm_n1 = fm_n2;
             if (fetch) {
                 // ring entries of the next batch's steps (complete: their sources lie >= 128 sites back), fetched and reset
                 pendLB[((b + 1) & 1) * 32 + lane] = fv;
                 pendLA[((b + 1) & 1) * 32 + lane] = fa;
                 pendB[fsl] = NEG_INF;
             }
+            // LAST in program order, on purpose: the next batch waits for this load before its barrier, and vector memory
+            // operations of a wave complete in order — so every ring store above is in L2 one barrier from now
+            if (b + 3 < nb) meta = wg_dp_meta_load<BL>(Wp, Cp, cum0, base + 3 * BL, s1, lane);
         } else {
             const double* slot = slots + (size_t)(b & 1) * SLOT;
             const bool wideb = WIDEJOB && kinds[b & 1] != 0u;
@@ -938,51 +1023,33 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
                     WG_DP_GROUP64(0) WG_DP_GROUP64(8) WG_DP_GROUP64(16) WG_DP_GROUP64(24)
                     WG_DP_GROUP64(32) WG_DP_GROUP64(40) WG_DP_GROUP64(48) WG_DP_GROUP64(56)
 #undef WG_DP_GROUP64
+                    tbk = (((uint32_t)lane - tbk) & 63u) + 1u;        // source lane -> length of the best block ending here
+                } else if (stp0 == 0) {
+                    wg_dp_batch32<0>(best, arg, tbk, Mk, my, base, lane, bestB, argB);
                 } else {
-#pragma unroll 1
-                    for (int g = 0; g < BL; g += 8) {
-                        if (g + 8 < BL) {
-#pragma unroll
-                            for (int u = 0; u < 8; u++) nxt[u] = my[(g + 8 + u) * 64];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 8; u++) wg_dp_fast_step<WIDEJOB>(best, arg, tbk, Mk, cur[u], base + g + u, stp0 + g + u, lane, bestB, argB);
-#pragma unroll
-                        for (int u = 0; u < 8; u++) cur[u] = nxt[u];
-                    }
+                    wg_dp_batch32<32>(best, arg, tbk, Mk, my, base, lane, bestB, argB);
                 }
+                if (WIDEJOB) tbk = (uint32_t)(base + d + 1) - tbk;    // start of the best block -> its length
                 if (WIDEJOB) bestB = fin ? NEG_INF : bestB;
             } else {
                 const double* myB = my + BL * 64;
                 double Mfin = 0.0;
                 if (lane == 0) Mring[base & 127] = Mk;
-                double cur[4], curB[4], nxt[4], nxtB[4];          // 4 steps (~0.4 us) cover the LDS latency; 8 would spill at 16 waves
-#pragma unroll
-                for (int u = 0; u < 4; u++) { cur[u] = my[u * 64]; curB[u] = myB[u * 64]; }
-#pragma unroll 1
-                for (int g = 0; g < BL; g += 4) {
-                    if (g + 4 < BL) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) { nxt[u] = my[(g + 4 + u) * 64]; nxtB[u] = myB[(g + 4 + u) * 64]; }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        wg_dp_wide_step(best, arg, bestB, argB, tbk, Mfin, Mk, cur[u], curB[u], base + g + u, stp0 + g + u, lane);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { cur[u] = nxt[u]; curB[u] = nxtB[u]; }
-                }
+                if (stp0 == 0) wg_dp_wide_batch32<0>(best, arg, bestB, argB, tbk, Mfin, Mk, my, myB, base, lane);
+                else           wg_dp_wide_batch32<32>(best, arg, bestB, argB, tbk, Mfin, Mk, my, myB, base, lane);
+                tbk = (uint32_t)(base + d + 1) - tbk;
                 if (fin) Mring[(base + d + 1) & 127] = Mfin;      // M[k+1] of the batch's steps, for the workers
             }
             if (fin && base + d < s1) J.back16[cd.site_off + base + d] = (uint16_t)tbk;
         }
         // LDS is all that must be settled at the barrier.  Global memory: nobody in the workgroup reads what the
         // recurrence wave stores; a ring entry is only ever updated by its owner wave, and fetched (by worker 0) no
-        // sooner than two barriers after its last update — by then the updating wave has waited for later loads of its
-        // own, and vector memory operations of a wave complete in order.  Waiting for store latency here, every 32
-        // steps, would cost more than the steps themselves.
+        // sooner than two barriers after its last update — by then the updating wave has waited for a load it issued
+        // after that store (the window load that ends every batch), and vector memory operations of a wave complete in
+        // order.  Waiting for store latency here, every 32 steps, would cost more than the steps themselves.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
-    if (WIDEJOB && worker)
+    if (WIDEJOB && worker && fm_prev > 128u)
         wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, s0 + (nb - 1) * BL, s1, Mring, pendB, pendA, rmask, lane, lw);
     if (!worker && s1 < cd.len) {
         if (lane == 0) gs[0] = Mk;
@@ -998,37 +1065,95 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
 // ------------------------------------------------------------------------------------------------------------
 // k_trace / k_border_offsets / k_gather_borders
 // ------------------------------------------------------------------------------------------------------------
+// k_trace: one workgroup per chunk walks T[] back from the chunk's end (segmentor.cpp:50-58) and leaves the borders in
+// DESCENDING order in tmp.  The walk is a dependent chain of LDS reads, so it is cut into WG_TRACE_SEG segments per
+// LDS window of back-pointers:
+//   1. thread j walks, speculatively, from the top node of segment j down to the segment's end, marking the nodes it
+//      visits inside its own segment and remembering where it left;
+//   2. one thread follows the true path: inside a segment it steps only until it lands on a marked node — from there
+//      on the two walks are the same walk (each step depends only on the node), so it jumps to the segment's exit;
+//   3. thread j marks the part of its walk below the join as path; the marked nodes are emitted by a bit scan.
+// Paths of a changepoint recurrence join within a block or two, so step 2 costs a few reads per segment.
+__device__ __forceinline__ int wg_trace_step(const uint16_t* win, int i, int wlo)
+{
+    int stepb = (int)win[i - 1 - wlo];                       // i = T[i] (segmentor.cpp:55)
+    if (stepb < 1 || stepb > i) stepb = i;                   // never loops on a corrupt back-pointer (would show up as a parity failure)
+    return i - stepb;
+}
+
 __global__ __launch_bounds__(WG_BLOCK) void k_trace(JobView J, int32_t* __restrict__ tmp, int32_t* __restrict__ nb)
 {
-    __shared__ uint16_t win[WG_TRACE_WIN];
-    __shared__ int sh_cur, sh_cnt;
-    const int tid = threadIdx.x;
+    __shared__ uint16_t win[WG_TRACE_WIN];                   // back-pointer of node i (wlo < i <= hi) at win[i-1-wlo]
+    __shared__ uint32_t vis[WG_TRACE_WIN / 32 + 1];          // bit i-wlo: node visited by the speculative walk of its own segment
+    __shared__ uint32_t tp[WG_TRACE_WIN / 32 + 1];           // bit i-wlo: node is on the path
+    __shared__ int seg_exit[WG_TRACE_SEG], seg_join[WG_TRACE_SEG];
+    __shared__ uint32_t wsum[WG_BLOCK / 64];
+    __shared__ int sh_cur;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = blockIdx.x;
     const ChunkDesc cd = J.chunks[c];
-    int32_t* out = tmp + cd.site_off + c;                 // len+1 slots
+    int32_t* out = tmp + cd.site_off + c;                    // len+1 slots
     const uint16_t* bk = J.back16 + cd.site_off;
-    if (tid == 0) { sh_cur = cd.len; sh_cnt = 1; out[0] = cd.len; }
-    __syncthreads();
-    int hi = cd.len;
+    int hi = cd.len, cnt = 0;
     while (hi > 0) {
         const int wlo = (hi > WG_TRACE_WIN) ? hi - WG_TRACE_WIN : 0;
+        const int nw = (hi - wlo) / 32 + 1;                   // bitmap words in use
+        const int L = (hi - wlo + WG_TRACE_SEG - 1) / WG_TRACE_SEG;
         for (int x = tid; x < hi - wlo; x += WG_BLOCK) win[x] = bk[wlo + x];
+        for (int x = tid; x < nw; x += WG_BLOCK) { vis[x] = 0u; tp[x] = 0u; }
         __syncthreads();
-        if (tid == 0) {
-            int i = sh_cur, cnt = sh_cnt;
-            while (i > wlo) {                                  // i = T[i] (segmentor.cpp:55)
-                int stepb = (int)win[i - 1 - wlo];
-                if (stepb < 1 || stepb > i) stepb = i;         // never loops on a corrupt back-pointer (would show up as a parity failure)
-                i -= stepb;
-                out[cnt++] = i;
-            }
-            sh_cur = i; sh_cnt = cnt;
+        const int p = hi - tid * L;                           // top node of this thread's segment
+        const int lim = (p - L > wlo) ? p - L : wlo;
+        if (tid < WG_TRACE_SEG) {
+            int i = p;
+            while (i > lim) { atomicOr(&vis[(i - wlo) >> 5], 1u << ((i - wlo) & 31)); i = wg_trace_step(win, i, wlo); }
+            seg_exit[tid] = i;
+            seg_join[tid] = -1;
         }
         __syncthreads();
+        if (tid == 0) {
+            int i = hi;
+            while (i > wlo) {
+                if ((vis[(i - wlo) >> 5] >> ((i - wlo) & 31)) & 1u) {
+                    const int j = (hi - i) / L;
+                    seg_join[j] = i;
+                    i = seg_exit[j];
+                } else {
+                    tp[(i - wlo) >> 5] |= 1u << ((i - wlo) & 31);
+                    i = wg_trace_step(win, i, wlo);
+                }
+            }
+            sh_cur = i;
+        }
+        __syncthreads();
+        if (tid < WG_TRACE_SEG && seg_join[tid] >= 0) {
+            const int join = seg_join[tid];
+            int i = p;
+            while (i > lim) { if (i <= join) atomicOr(&tp[(i - wlo) >> 5], 1u << ((i - wlo) & 31)); i = wg_trace_step(win, i, wlo); }
+        }
+        __syncthreads();
+        // emit the window's path nodes, largest first: thread t owns the words nw-1-t*wpt .. (descending)
+        const int wpt = (nw + WG_BLOCK - 1) / WG_BLOCK;
+        uint32_t mine = 0;
+        for (int q = 0; q < wpt; q++) { const int w = nw - 1 - (tid * wpt + q); if (w >= 0) mine += (uint32_t)__popc(tp[w]); }
+        const uint32_t incl = wg_wave_incl_scan_dpp_u32(mine);
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t off = incl - mine, tot = 0;
+#pragma unroll
+        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) off += wsum[q]; tot += wsum[q]; }
+        int pos = cnt + (int)off;
+        for (int q = 0; q < wpt; q++) {
+            const int w = nw - 1 - (tid * wpt + q);
+            if (w < 0) break;
+            uint32_t bits = tp[w];
+            while (bits) { const int b = 31 - __clz((int)bits); out[pos++] = wlo + w * 32 + b; bits &= ~(1u << b); }
+        }
+        cnt += (int)tot;
         hi = sh_cur;
         __syncthreads();
     }
-    if (tid == 0) nb[c] = sh_cnt;
+    if (tid == 0) { out[cnt] = 0; nb[c] = cnt + 1; }          // the walk ends at border 0 (segmentor.cpp:54-57)
 }
 
 __global__ __launch_bounds__(WG_BLOCK) void k_border_offsets(const int32_t* __restrict__ nb, int n_chunks, int64_t* __restrict__ boff)
