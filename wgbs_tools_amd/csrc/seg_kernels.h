@@ -643,9 +643,8 @@ __device__ __forceinline__ int32_t wg_ld_l2_i32(const int32_t* p) { return __hip
 //   slotA[s*64 + l] = cost(k, k+j),      k = base+s, j = (l - k) mod 64, for j < F_k,        else -inf
 //   slotB[s*64 + l] = cost(k, k+64+j)                                     for 64+j < F_k,     else -inf   (wide batch only)
 // so the recurrence needs no predicate at all: M[k] + (-inf) can never beat a pending maximum.  Worker `lw` arranges
-// the steps s == lw (mod NW).  Three phases, one batch apart each, so that no HBM latency is ever waited for: the
-// windows and row offsets of batch b+3 are loaded while the recurrence sweeps batch b; with them the row loads of
-// batch b+2 are issued (into registers); the rows of batch b+1 are stored to the free LDS slot.
+// the steps s == lw (mod NW).  Two phases, one batch apart: the row loads of batch b+2 are issued (into registers) at
+// the end of batch b and stored to the free LDS slot at the end of batch b+1 — a full batch to land.
 template <int NW, int BL>
 struct DpRows {                                          // one worker's share of a batch, in registers
     static constexpr int PER = (BL + NW - 1) / NW;
@@ -656,15 +655,53 @@ struct DpRows {                                          // one worker's share o
 
 struct DpMeta { uint32_t w, rel; };                      // lane l: window and row offset of step base + l of a batch
 
-template <int BL>
-__device__ __forceinline__ DpMeta wg_dp_meta_load(const uint16_t* __restrict__ Wp, const uint32_t* __restrict__ Cp, uint32_t cum0,
-                                                  int base, int s1, int lane)
+// Windows and row offsets reach the workers through an LDS ring of 1024 steps, refilled 512 steps at a time (all
+// workers, a handful of loads each, every 512 steps): the per-batch work of a worker then has no global load whose
+// latency it must sit out — what it loads (rows, ring entries) it consumes a full batch later.
+#define WG_DP_META_RING   1024
+#define WG_DP_META_REGION 512
+
+template <int NW>
+struct DpRefill {
+    static constexpr int R = (WG_DP_META_REGION + 64 * NW - 1) / (64 * NW);
+    uint32_t w[R], c[R];
+};
+
+template <int NW>
+__device__ __forceinline__ void wg_dp_refill_issue(DpRefill<NW>& F, const uint16_t* __restrict__ Wp, const uint32_t* __restrict__ Cp,
+                                                   uint32_t cum0, int first, int s1, int lane, int lw)
 {
-    const int il = base + lane;
-    const bool inb = lane < BL && il < s1;
+#pragma unroll
+    for (int q = 0; q < DpRefill<NW>::R; q++) {
+        const int e = (q * NW + lw) * 64 + lane;
+        const int k = first + e;
+        const bool in = e < WG_DP_META_REGION && k < s1;
+        F.w[q] = in ? (uint32_t)Wp[k] : 0u;              // steps past the stage's end: no candidates
+        F.c[q] = in ? Cp[k] - cum0 : 0u;
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void wg_dp_refill_commit(const DpRefill<NW>& F, uint16_t* __restrict__ metaW, uint32_t* __restrict__ metaC,
+                                                    int first_rel, int lane, int lw)
+{
+#pragma unroll
+    for (int q = 0; q < DpRefill<NW>::R; q++) {
+        const int e = (q * NW + lw) * 64 + lane;
+        if (e < WG_DP_META_REGION) {
+            const int x = (first_rel + e) & (WG_DP_META_RING - 1);
+            metaW[x] = (uint16_t)F.w[q]; metaC[x] = F.c[q];
+        }
+    }
+}
+
+template <int BL>
+__device__ __forceinline__ DpMeta wg_dp_meta_lds(const uint16_t* __restrict__ metaW, const uint32_t* __restrict__ metaC, int base_rel, int lane)
+{
+    const int x = (base_rel + lane) & (WG_DP_META_RING - 1);
     DpMeta m;
-    m.w = inb ? (uint32_t)Wp[il] : 0u;
-    m.rel = inb ? Cp[il] - cum0 : 0u;
+    m.w = lane < BL ? (uint32_t)metaW[x] : 0u;
+    m.rel = metaC[x];
     return m;
 }
 
@@ -906,6 +943,8 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     double* pendLB = Mring + 128;                                             // [2][32] ring entries of the next batches' steps
     int32_t* pendLA = reinterpret_cast<int32_t*>(pendLB + 64);                // [2][32]
     uint32_t* kinds = reinterpret_cast<uint32_t*>(pendLA + 64);               // [2] 1: the slot holds a wide batch (A and B)
+    uint32_t* metaC = kinds + 4;                                              // [1024] row offsets of the coming steps
+    uint16_t* metaW = reinterpret_cast<uint16_t*>(metaC + WG_DP_META_RING);   // [1024] their windows
     const int lane = threadIdx.x & 63;
     const bool worker = threadIdx.x >= 64;
     const int lw = (int)(threadIdx.x >> 6) - 1;       // worker index (0..NW-1)
@@ -930,17 +969,17 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     double best = NEG_INF, bestB = NEG_INF;             // pending steps of this lane (wave 0)
     int32_t arg = 0, argB = 0;
     double Mk = 0.0;                                    // M[k] of the step about to run; M[0] = 0 (segmentor.cpp:97)
-    DpRows<NW, BL> rows;                                // (workers) rows of the next batch, in flight
-    DpMeta meta = {0u, 0u};                             // (workers) windows / row offsets of the batch after the next
+    DpRows<NW, BL> rows;                                // (workers) rows of the batch after the next, in flight
+    DpRefill<NW> refill;                                // (workers) a region of windows / row offsets, in flight
     uint32_t fm_prev = 0, fm_cur = 0, fm_n1 = 0;        // (workers) widest window of batches b-1, b, b+1
+    constexpr int RB = WG_DP_META_REGION / BL;          // batches per region of the meta ring
     if (worker) {
         if (WIDEJOB && s0 == 0)
             for (int x = (int)threadIdx.x - 64; x < A.ringN; x += 64 * NW) pendB[x] = NEG_INF;
-        wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_load<BL>(Wp, Cp, cum0, s0, s1, lane), s0, lane, lw);
-        wg_dp_rows_commit<NW, BL>(rows, slots, slots + BL * 64, kinds, lane, lw);
-        fm_cur = rows.fmax;
-        if (nb > 1) { wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_load<BL>(Wp, Cp, cum0, s0 + BL, s1, lane), s0 + BL, lane, lw); fm_n1 = rows.fmax; }
-        if (nb > 2) meta = wg_dp_meta_load<BL>(Wp, Cp, cum0, s0 + 2 * BL, s1, lane);
+        wg_dp_refill_issue<NW>(refill, Wp, Cp, cum0, s0, s1, lane, lw);
+        wg_dp_refill_commit<NW>(refill, metaW, metaC, 0, lane, lw);
+        wg_dp_refill_issue<NW>(refill, Wp, Cp, cum0, s0 + WG_DP_META_REGION, s1, lane, lw);
+        wg_dp_refill_commit<NW>(refill, metaW, metaC, WG_DP_META_REGION, lane, lw);
         if (WIDEJOB && lw == 0 && lane < BL) {
             double v = NEG_INF;
             int32_t a = 0;
@@ -964,33 +1003,50 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
         asm volatile("" : "+v"(Mk), "+v"(best), "+v"(arg), "+v"(bestB), "+v"(argB));
     }
     __syncthreads();
+    if (worker) {
+        wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, 0, lane), s0, lane, lw);
+        wg_dp_rows_commit<NW, BL>(rows, slots, slots + BL * 64, kinds, lane, lw);
+        fm_cur = rows.fmax;
+        if (nb > 1) { wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, BL, lane), s0 + BL, lane, lw); fm_n1 = rows.fmax; }
+    }
+    __syncthreads();
 
     for (int b = 0; b < nb; b++) {
         const int base = s0 + b * BL;
         if (worker) {
-            // rows of batch b+1 (loaded during the previous batch) into the free slot; loads of batch b+2 take off
-            if (b + 1 < nb)
-                wg_dp_rows_commit<NW, BL>(rows, slots + (size_t)((b + 1) & 1) * SLOT, slots + (size_t)((b + 1) & 1) * SLOT + BL * 64,
-                                          kinds + ((b + 1) & 1), lane, lw);
+            // Everything a worker loads it consumes a full batch later.  Order of the batch: (1) ring entries of the next
+            // batch's steps: loads, and the reset store right behind them (the memory pipeline keeps a wave's accesses
+            // to one address in order); (2) meta ring refill; (3) pushes of the blocks > 128 sites of batch b-1;
+            // (4) the rows of batch b+1, loaded a batch ago, into the free slot; (5) the loads of the rows of batch b+2.
+            // The row loads come LAST on purpose: the next batch waits for them before its barrier, and vector memory
+            // operations of a wave complete in order — so every ring store of this batch is in L2 one barrier from now.
             const bool fetch = WIDEJOB && b + 1 < nb && lw == 0 && lane < BL;
             const int fsl = (base + BL + lane) & rmask;
             double fv = NEG_INF;
             int32_t fa = 0;
-            if (fetch) { fv = wg_ld_l2_f64(pendB + fsl); fa = wg_ld_l2_i32(pendA + fsl); }
-            uint32_t fm_n2 = 0;
-            if (b + 2 < nb) { wg_dp_rows_issue<NW, BL>(rows, cb, meta, base + 2 * BL, lane, lw); fm_n2 = rows.fmax; }
-            if (WIDEJOB && b >= 1 && fm_prev > 128u)
-                wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, base - BL, s1, Mring, pendB, pendA, rmask, lane, lw);
-            fm_prev = fm_cur; fm_cur = fm_n1; fm_n1 = fm_n2;
-            if (fetch) {
-                // ring entries of the next batch's steps (complete: their sources lie >= 128 sites back), fetched and reset
-                pendLB[((b + 1) & 1) * 32 + lane] = fv;
-                pendLA[((b + 1) & 1) * 32 + lane] = fa;
+            if (fetch) {                                          // complete: their sources lie >= 128 sites back
+                fv = wg_ld_l2_f64(pendB + fsl); fa = wg_ld_l2_i32(pendA + fsl);
                 pendB[fsl] = NEG_INF;
             }
-            // LAST in program order, on purpose: the next batch waits for this load before its barrier, and vector memory
-            // operations of a wave complete in order — so every ring store above is in L2 one barrier from now
-            if (b + 3 < nb) meta = wg_dp_meta_load<BL>(Wp, Cp, cum0, base + 3 * BL, s1, lane);
+            // regions 0 and 1 are in the ring from the start; region r+1 replaces region r-1 when the row loads have
+            // moved on to region r (they run two batches ahead of b), and is first read RB-3 batches later
+            if (b >= RB && b % RB == 0)      wg_dp_refill_issue<NW>(refill, Wp, Cp, cum0, s0 + (b / RB + 1) * WG_DP_META_REGION, s1, lane, lw);
+            else if (b > RB && b % RB == 1)  wg_dp_refill_commit<NW>(refill, metaW, metaC, (b / RB + 1) * WG_DP_META_REGION, lane, lw);
+            if (WIDEJOB && b >= 1 && fm_prev > 128u)
+                wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, base - BL, s1, Mring, pendB, pendA, rmask, lane, lw);
+            if (b + 1 < nb)
+                wg_dp_rows_commit<NW, BL>(rows, slots + (size_t)((b + 1) & 1) * SLOT, slots + (size_t)((b + 1) & 1) * SLOT + BL * 64,
+                                          kinds + ((b + 1) & 1), lane, lw);
+            if (fetch) {
+                pendLB[((b + 1) & 1) * 32 + lane] = fv;
+                pendLA[((b + 1) & 1) * 32 + lane] = fa;
+            }
+            uint32_t fm_n2 = 0;
+            if (b + 2 < nb) {
+                wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, (b + 2) * BL, lane), base + 2 * BL, lane, lw);
+                fm_n2 = rows.fmax;
+            }
+            fm_prev = fm_cur; fm_cur = fm_n1; fm_n1 = fm_n2;
         } else {
             const double* slot = slots + (size_t)(b & 1) * SLOT;
             const bool wideb = WIDEJOB && kinds[b & 1] != 0u;
@@ -1044,8 +1100,8 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
         }
         // LDS is all that must be settled at the barrier.  Global memory: nobody in the workgroup reads what the
         // recurrence wave stores; a ring entry is only ever updated by its owner wave, and fetched (by worker 0) no
-        // sooner than two barriers after its last update — by then the updating wave has waited for a load it issued
-        // after that store (the window load that ends every batch), and vector memory operations of a wave complete in
+        // sooner than two barriers after its last update — by then the updating wave has waited for loads it issued
+        // after that store (the row loads that end every batch), and vector memory operations of a wave complete in
         // order.  Waiting for store latency here, every 32 steps, would cost more than the steps themselves.
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }

@@ -530,9 +530,9 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     StageView sv;
     sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbaseA = tbaseA; sv.tbaseB = tbaseB;
     sv.S = S;
-    // LDS of k_dp: two arranged batches (64 steps x 64 lanes, or 32 steps x 64 lanes x {A, B}) + M ring + fetched ring entries + flags
+    // LDS of k_dp: two arranged batches (64 steps x 64 lanes, or 32 steps x 64 lanes x {A, B}) + M ring + fetched ring entries + flags + ring of windows / row offsets
     DpArgs da = {ringN, {0, 0, 0}};
-    const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16;
+    const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16 + 1024 * 6;
     for (int stg = 0; stg < n_stages; stg++) {
         sv.stage = stg;
         double* cbuf = c->cost[stg % nbuf].as<double>();
