@@ -150,6 +150,21 @@ int wgbsseg_prefix_sums(wgbsseg_ctx* ctx, int64_t start0, int64_t len, uint32_t*
 int wgbsseg_scan_only(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
                       int repeat, double* ms_per_launch, int64_t* bytes_per_launch, char* err, size_t errlen);
 
+/*
+ * Blocks -> BED rows: the path's last step (segment.py:186-190 -> convert.py:242-248 add_bed_to_cpgs, which pipes the
+ * blocks through the reference's `add_loci` binary: src/cpg2bed/add_loci.cpp:22-57, cpg_dict.cpp:40-131).  Host-side,
+ * no device involved, no ctx needed.  For every block i (1-based half-open CpG interval) one row
+ *     chrom \t loci[startCpG-1] \t loci[endCpG-2]+1 \t startCpG \t endCpG \n        (start+2 when endCpG == startCpG)
+ * appended to `path` (NULL: stdout), in input order.  chrom_cum = cumulative CpG counts of the chromosomes in
+ * CpG.chrome.size order (last = n_sites).  Validations and messages are the reference's (add_loci.cpp:38-49,
+ * cpg_dict.cpp:130): on the first offending row the rows before it have been written and the call returns
+ * WGBSSEG_E_ARG with err = "[wt add_loci] line N: endCpG < startCpG | startCpG < 1 | endCpG < 1 | Cross chromosomes"
+ * or "[ cpg_dict ] Could not find chromosome for site: N".  threads <= 0: all host cores.
+ */
+int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom_cum, const char* const* chrom_names,
+                     int32_t n_chroms, const int64_t* start_cpg, const int64_t* end_cpg, int64_t n_blocks,
+                     const char* path, int32_t append, int32_t threads, char* err, size_t errlen);
+
 int wgbsseg_get_timings(const wgbsseg_ctx* ctx, wgbsseg_timings* out);
 
 /*

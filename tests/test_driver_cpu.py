@@ -233,6 +233,54 @@ def test_bed_writer_reproduces_reference_fixture(tmp_path):
     assert open(out).read() == raw
 
 
+def test_native_add_loci_rows_and_errors(tmp_path):
+    """wgbsseg_add_loci (the library's restatement of add_loci.cpp:22-57 + cpg_dict.cpp:118-131) against the numpy
+    statement of the same rules on random blocks (several formatting shards), and the reference's failure cases."""
+    from wgbs_tools_amd import _lib
+    rng = np.random.default_rng(5)
+    sizes = np.array([70000, 1, 50000, 30000])
+    names = ['chr1', 'chrTiny', 'chr_with_a_rather_long_name_' + 'x' * 80, 'chrM']
+    cum = np.cumsum(sizes)
+    n = int(cum[-1])
+    loci = np.concatenate([np.cumsum(rng.integers(2, 300, sz)) + 10000 for sz in sizes]).astype(np.uint32)
+
+    class Gen:
+        def get_chrom_cpg_sizes(self):
+            return names, sizes
+
+        def loci(self):
+            return loci
+    # blocks inside chromosomes, incl. empty blocks (end == start), chromosome-final blocks and the genome's last site
+    s_list, e_list = [], []
+    lo = 1
+    for c, hi in enumerate(cum):
+        b = np.unique(np.concatenate([[lo, hi + 1], rng.integers(lo, hi + 2, 20000)]))
+        s_list.append(b[:-1]); e_list.append(b[1:])
+        lo = hi + 1
+    s = np.concatenate(s_list + [np.array([5, n])]); e = np.concatenate(e_list + [np.array([5, n + 1])])
+    out = str(tmp_path / 'a.bed')
+    _lib.add_loci(loci, names, cum, s, e, out, threads=7)
+    chrom, start, end = G.blocks_to_bed_lines(Gen(), s, e)
+    want = ''.join('%s\t%d\t%d\t%d\t%d\n' % t for t in zip(chrom, start.tolist(), end.tolist(), s.tolist(), e.tolist()))
+    assert open(out).read() == want
+    _lib.add_loci(loci, names, cum, s[:3], e[:3], out, append=True, threads=1)          # append mode, one shard
+    assert open(out).read() == want + ''.join(want.splitlines(True)[:3])
+    # failures: message text of the reference, rows before the offending one are written
+    cases = [((np.array([3, 9, 8]), np.array([5, 8, 9])), '[wt add_loci] line 1: endCpG < startCpG'),
+             ((np.array([3, 0]), np.array([5, 4])), '[wt add_loci] line 1: startCpG < 1'),
+             ((np.array([69990]), np.array([70005])), '[wt add_loci] line 0: Cross chromosomes'),
+             ((np.array([n + 2]), np.array([n + 3])), '[ cpg_dict ] Could not find chromosome for site: %d' % (n + 2))]
+    for (bs, be), msg in cases:
+        with pytest.raises(_lib.SegmentorError) as ei:
+            _lib.add_loci(loci, names, cum, bs, be, out)
+        assert ei.value.msg == msg
+        with pytest.raises(RuntimeError):
+            G.blocks_to_bed_lines(Gen(), bs, be)
+    assert open(out).read() == ''                       # last case: nothing before the offending row
+    _lib.add_loci(loci, names, cum, np.array([69990]), np.array([70001]), out)      # ends ON the chromosome border: legal
+    assert open(out).read() == 'chr1\t%d\t%d\t69990\t70001\n' % (loci[69989], loci[69999] + 1)
+
+
 def test_cli_dispatch_and_native_required(synth_world, capsys):
     """`wgbstools segment` must fail loudly, not fall back, when no GPU/HIP library can serve it."""
     from wgbs_tools_amd import wgbs_tools, _lib

@@ -4,6 +4,7 @@ There is no Python/CPU implementation behind this module: if the HIP library is 
 visible, every entry point raises (``NativeLibraryError`` / ``SegmentorError``) -- loudly, never a fallback.
 """
 import ctypes as C
+import os
 import os.path as op
 
 import numpy as np
@@ -19,7 +20,7 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_set_betas_host', 'wgbsseg_set_betas_device', 'wgbsseg_set_loci_host', 'wgbsseg_set_loci_device',
            'wgbsseg_segment_chunks', 'wgbsseg_segment_regions', 'wgbsseg_segment_chunks_host', 'wgbsseg_prefix_sums', 'wgbsseg_scan_only',
            'wgbsseg_get_timings', 'wgbsseg_debug_fetch', 'wgbsseg_debug_sample_terms', 'wgbsseg_debug_log2',
-           'wgbsseg_debug_div']
+           'wgbsseg_debug_div', 'wgbsseg_add_loci']
 
 
 class NativeLibraryError(RuntimeError):
@@ -129,6 +130,8 @@ def load():
     L.wgbsseg_debug_log2.argtypes = [vp, C.c_uint32, i64, vp, vp, vp]
     L.wgbsseg_debug_div.restype = i32
     L.wgbsseg_debug_div.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.wgbsseg_add_loci.restype = i32
+    L.wgbsseg_add_loci.argtypes = [vp, i64, vp, C.POINTER(C.c_char_p), i32, vp, vp, i64, C.c_char_p, i32, i32, C.c_char_p, C.c_size_t]
     _lib = L
     return L
 
@@ -321,3 +324,17 @@ def segment_chunks_host(samples, loci, start0, lens, pcount, max_cpg, max_bp, de
                                          start0.ctypes.data, lens.ctypes.data, n, C.byref(p), int(device),
                                          out.ctypes.data, cap, off.ctypes.data, err, ERRLEN), err)
     return [out[off[c]:off[c + 1]].copy() for c in range(n)]
+
+
+def add_loci(loci, chrom_names, chrom_cum, start_cpg, end_cpg, path=None, append=False, threads=0):
+    """wgbsseg_add_loci: BED rows of the blocks appended to `path` (None: the process's stdout)."""
+    L = load()
+    loci = np.ascontiguousarray(loci, dtype=np.uint32)
+    cum = np.ascontiguousarray(chrom_cum, dtype=np.int64)
+    s = np.ascontiguousarray(start_cpg, dtype=np.int64)
+    e = np.ascontiguousarray(end_cpg, dtype=np.int64)
+    names = (C.c_char_p * len(chrom_names))(*[str(n).encode() for n in chrom_names])
+    err = C.create_string_buffer(ERRLEN)
+    rc = L.wgbsseg_add_loci(loci.ctypes.data, loci.size, cum.ctypes.data, names, len(chrom_names), s.ctypes.data, e.ctypes.data,
+                            s.size, None if path is None else os.fsencode(path), 1 if append else 0, int(threads), err, ERRLEN)
+    _check(rc, err)

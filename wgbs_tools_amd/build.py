@@ -15,10 +15,10 @@ HERE = op.dirname(op.abspath(__file__))
 CSRC = op.join(HERE, 'csrc')
 ARCH = 'gfx950'
 # -ffp-contract=off is part of the numerical contract (no fused multiply-add anywhere on the scoring path)
-HIPFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared']
+HIPFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-pthread']
 
 TARGETS = {
-    'libwgbsseg.so': (['wgbsseg.hip'], ['seg_kernels.h', 'wave_prims.h', 'exact_log2.h', '../../include/wgbsseg.h']),
+    'libwgbsseg.so': (['wgbsseg.hip'], ['seg_kernels.h', 'wave_prims.h', 'exact_log2.h', 'stitch.h', 'add_loci.h', '../../include/wgbsseg.h']),
     'libwgbssynth.so': (['synth.hip'], []),
 }
 

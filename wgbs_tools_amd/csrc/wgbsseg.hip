@@ -20,6 +20,7 @@
 #include "../../include/wgbsseg.h"
 #include "seg_kernels.h"
 #include "stitch.h"
+#include "add_loci.h"
 
 namespace {
 
@@ -714,6 +715,28 @@ int wgbsseg_prefix_sums(wgbsseg_ctx* c, int64_t start0, int64_t len, uint32_t* o
     HIP_TRY(hipStreamSynchronize(c->sA));
     if (st.first_bad != ~0ULL) return report_bad_site(c, st, err, errlen);
     c->last_valid = false;
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom_cum, const char* const* chrom_names,
+                     int32_t n_chroms, const int64_t* start_cpg, const int64_t* end_cpg, int64_t n_blocks,
+                     const char* path, int32_t append, int32_t threads, char* err, size_t errlen)
+{
+    if (!loci || !chrom_cum || !chrom_names || n_chroms < 1 || n_sites < 1 || n_blocks < 0 || (n_blocks && (!start_cpg || !end_cpg))) {
+        set_err(err, errlen, "add_loci: bad argument"); return WGBSSEG_E_ARG;
+    }
+    if (chrom_cum[n_chroms - 1] != n_sites) { set_err(err, errlen, "add_loci: chromosome sizes sum to %lld, loci has %lld sites", (long long)chrom_cum[n_chroms - 1], (long long)n_sites); return WGBSSEG_E_ARG; }
+    FILE* fp = stdout;
+    if (path) {
+        fp = fopen(path, append ? "ab" : "wb");
+        if (!fp) { set_err(err, errlen, "add_loci: cannot open %s", path); return WGBSSEG_E_ARG; }
+        setvbuf(fp, nullptr, _IOFBF, 1 << 22);
+    }
+    wgadd::Genome g = {loci, n_sites, chrom_cum, chrom_names, n_chroms};
+    std::string msg;
+    const int rc = wgadd::add_loci(g, start_cpg, end_cpg, n_blocks, fp, threads, msg);
+    if (path) { if (fclose(fp) != 0 && rc == 0) { set_err(err, errlen, "add_loci: write to %s failed", path); return WGBSSEG_E_ARG; } }
+    if (rc) { set_err(err, errlen, "%s", msg.c_str()); return WGBSSEG_E_ARG; }
     return WGBSSEG_OK;
 }
 

@@ -325,14 +325,16 @@ def blocks_to_bed_lines(genome, start_cpg, end_cpg):
 
 
 def write_bed(genome, start_cpg, end_cpg, out_path=None):
-    chrom, start, end = blocks_to_bed_lines(genome, start_cpg, end_cpg)
-    s = np.asarray(start_cpg, dtype=np.int64)
-    e = np.asarray(end_cpg, dtype=np.int64)
-    lines = [f'{c}\t{a}\t{b}\t{x}\t{y}\n' for c, a, b, x, y in zip(chrom, start.tolist(), end.tolist(), s.tolist(), e.tolist())]
-    text = ''.join(lines)
-    if out_path is None or out_path is sys.stdout:
-        sys.stdout.write(text)
+    """The blocks as BED rows into out_path (None / sys.stdout: standard output) through the library's add_loci
+    (include/wgbsseg.h: wgbsseg_add_loci), which restates the reference's add_loci binary; its validation failures
+    surface as RuntimeError with the reference's messages (blocks_to_bed_lines above is the same rule set in numpy,
+    kept for callers that want the columns rather than the text)."""
+    from . import _lib
+    names, sizes = genome.get_chrom_cpg_sizes()
+    to_stdout = out_path is None or out_path is sys.stdout
+    if to_stdout:
         sys.stdout.flush()
-    else:
-        with open(out_path, 'w') as f:
-            f.write(text)
+    try:
+        _lib.add_loci(genome.loci(), names, np.cumsum(sizes), start_cpg, end_cpg, None if to_stdout else out_path)
+    except _lib.SegmentorError as e:
+        raise RuntimeError(e.msg)

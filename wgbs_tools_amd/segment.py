@@ -15,6 +15,8 @@ import multiprocessing
 import os
 import sys
 
+import time
+
 import numpy as np
 
 from .genome import (GenomeRefPaths, GenomicRegion, IllegalArgumentError, beta_sanity_check, eprint, write_bed)
@@ -256,11 +258,13 @@ class SegmentByChunks:
         own_engine = self.param_dict['engine'] is None
         if world > 1:
             return self.run_sharded(rank, world, local)
+        prof = [('start', time.perf_counter())] if os.environ.get('WGBSSEG_PROFILE') else None
         if own_engine:
             lo = min(starts) - 1 if starts else 0
             hi = max(ends) - 1 if ends else 0
             self.param_dict['engine'] = HipEngine(self.betas, self.genome, device=getattr(self.args, 'device', 0),
                                                   site_range=(lo, hi))
+            if prof: prof.append(('loci + betas to the device', time.perf_counter()))
         try:
             eng = self.param_dict['engine']
             if hasattr(eng, 'segment_regions'):
@@ -279,9 +283,13 @@ class SegmentByChunks:
             if own_engine:
                 self.param_dict['engine'].close()
                 self.param_dict['engine'] = None
+        if prof: prof.append(('segmentation (device + stitching)', time.perf_counter()))
         s = np.concatenate([m[:-1] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
         e = np.concatenate([m[1:] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
         self.dump_result(s, e)
+        if prof:
+            prof.append(('blocks to BED', time.perf_counter()))
+            eprint('[wt segment] phases: ' + ', '.join('%s %.3f s' % (n, t - prof[i][1]) for i, (n, t) in enumerate(prof[1:])))
 
     def run_sharded(self, rank, world, local, engine_factory=None):
         """One process per GPU (python -m torch.distributed.run ... wgbstools segment ...): the chunk grid is cut into
