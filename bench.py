@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--max-bp', type=int, default=2000)
     ap.add_argument('--pcount', type=float, default=15.0)
     ap.add_argument('--islands', action='store_true', help='add CpG islands to the synthetic loci (windows of several hundred sites; not the BASELINE workload)')
+    ap.add_argument('--block-sums', action='store_true', help='also time the block reduction (beta_to_blocks / beta_to_table kernel) over the blocks just found')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target wall time of the CPU baseline sample (0: skip)')
     return ap.parse_args()
 
@@ -202,6 +203,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     n_blocks = int(sum(len(r) - 1 for r in res))
+    block_sums = None
+    if args.block_sums and rank == 0:
+        # the immediate consumer of the borders: (#meth, #cov) of every block in every sample.
+        # Algorithmic bytes = 2 * N * (sites covered); the D2H copy of the table is outside the kernel time.
+        bs = np.concatenate([np.asarray(r[:-1], dtype=np.int64) for r in res]) - 1
+        be = np.concatenate([np.asarray(r[1:], dtype=np.int64) for r in res]) - 1
+        times = []
+        for mode in (1, 1, 1, 3):
+            seg.block_sums(bs, be, mode=mode, min_cov=4)
+            times.append(seg.last_block_sums_ms())
+        covered = int((be - bs).sum())
+        block_sums = {'kernel': 'k_block_sums (per block, per sample sums of meth/cov; .bin rows or means)', 'blocks': int(bs.size),
+                      'ms_bin_rows': min(times[:3]), 'ms_means': times[3], 'algorithmic_bytes': 2 * covered * args.samples,
+                      'GB_per_s': 2 * covered * args.samples / (min(times[:3]) * 1e-3) / 1e9, 'frac_of_hbm_peak': 2 * covered * args.samples / (min(times[:3]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -241,6 +256,7 @@ def main():
                          'all_launches': {'count': acc['scan_launches'], 'bytes': acc['scan_bytes'], 'ms': acc['scan_ms'],
                                           'GB/s': scan_all_gbs},
                          'note': 'rank 0, HIP events on the kernel stream inside the timed steps; ' + traffic_note},
+            'block_sums': block_sums,
             'scoring': {'kernel': 'k_cost (block log-likelihoods, fp64 VALU bound)', 'evals_per_s': evals_s,
                         'evals_per_step': acc['evals'] / args.steps, 'pairs_per_step': acc['pairs'] / args.steps,
                         'max_window': acc['max_window'], 'stages': acc['n_stages']},

@@ -151,6 +151,22 @@ int wgbsseg_scan_only(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const int32
                       int repeat, double* ms_per_launch, int64_t* bytes_per_launch, char* err, size_t errlen);
 
 /*
+ * Block sums: (#meth, #cov) of every block in every resident sample — the reduction of the reference's
+ * beta_to_blocks / beta_to_table (beta_to_blocks.py:101-126 reduce_data: np.add.reduceat over the (meth, cov) rows,
+ * or the per-row slice sums of its slow_method for tables that are not "nice"), the immediate consumer of the BED this
+ * library produces.  Blocks are 0-based half-open site ranges [start0, end0) = [startCpG-1, endCpG-1); any order,
+ * overlaps and empty blocks (sum 0: the reference's NA rows) are allowed.  out is a HOST buffer [n_samples][n_blocks]:
+ *   mode 0  uint32[2]   the sums
+ *   mode 1  uint8[2]    .bin  rows: cov > 255   -> meth = trunc(meth / cov * 255),   cov = 255   (utils_wgbs.py:277-290)
+ *   mode 2  uint16[2]   .lbeta rows: the same with 65535
+ *   mode 3  double      meth / cov, NaN where cov < min_cov                                    (utils_wgbs.py:270-274)
+ */
+int wgbsseg_block_sums(wgbsseg_ctx* ctx, const int64_t* start0, const int64_t* end0, int64_t n_blocks, int32_t mode,
+                       uint32_t min_cov, void* out, char* err, size_t errlen);
+/* HIP-event time of the kernel of the last wgbsseg_block_sums call (ms) */
+double wgbsseg_last_block_sums_ms(const wgbsseg_ctx* ctx);
+
+/*
  * Blocks -> BED rows: the path's last step (segment.py:186-190 -> convert.py:242-248 add_bed_to_cpgs, which pipes the
  * blocks through the reference's `add_loci` binary: src/cpg2bed/add_loci.cpp:22-57, cpg_dict.cpp:40-131).  Host-side,
  * no device involved, no ctx needed.  For every block i (1-based half-open CpG interval) one row

@@ -1,0 +1,106 @@
+"""Block reduction on the GPU (k_block_sums behind wgbsseg_block_sums; the beta_to_blocks / beta_to_table mirrors)
+against the vectors captured from the reference's Python and against the oracle."""
+import base64
+import hashlib
+import json
+import os
+import os.path as op
+
+import numpy as np
+import pytest
+
+from oracle import block_sums as OB
+from wgbs_tools_amd import _lib, synth, wgbs_tools
+from test_blocks_cpu import world          # noqa: F401  (fixture: betas, blocks tables and goldens on disk)
+
+pytestmark = pytest.mark.gpu
+
+
+def _sha(text):
+    return hashlib.sha1(text.encode()).hexdigest()
+
+
+@pytest.mark.parametrize('name', ['nice', 'ragged'])
+def test_cli_outputs_match_reference(world, name, tmp_path):
+    """`wgbstools beta_to_blocks` (.bin, .lbeta, .bedGraph) and `wgbstools beta_to_table` byte for byte."""
+    rec = world['g']['tables'][name]
+    for lbeta in (False, True):
+        od = tmp_path / ('o%d' % lbeta)
+        od.mkdir()
+        argv = ['wgbstools', 'beta_to_blocks'] + world['betas'] + ['-b', world['blocks'][name], '-o', str(od), '--bedGraph'] + (['-l'] if lbeta else [])
+        assert wgbs_tools.main(argv) == 0
+        for b in world['betas']:
+            key = op.basename(b)
+            stem = str(od / op.splitext(key)[0])
+            got = open(stem + ('.lbeta' if lbeta else '.bin'), 'rb').read()
+            assert got == base64.b64decode(rec['lbeta' if lbeta else 'bin'][key]), (name, key, lbeta)
+            if not lbeta:
+                bg = open(stem + '.bedGraph').read()
+                assert bg[:600] == rec['bedgraph'][key]['head'] and _sha(bg) == rec['bedgraph'][key]['sha1']
+    for tag, extra in (('table_plain', ['-c', '4', '--digits', '2']), ('table_groups', ['-g', world['groups'], '-c', '10', '--digits', '3', '--chunk_size', '257'])):
+        out = str(tmp_path / (tag + '.tsv'))
+        assert wgbs_tools.main(['wgbstools', 'beta_to_table', world['blocks'][name], '--betas'] + world['betas'] + ['-o', out] + extra) == 0
+        text = open(out).read()
+        assert text[:600] == rec[tag]['head'], (name, tag)
+        assert len(text) == rec[tag]['len'] and _sha(text) == rec[tag]['sha1']
+    # second run without --force skips existing files (beta_to_blocks.py:168-178)
+    od = tmp_path / 'o0'
+    before = {f: os.stat(od / f).st_mtime_ns for f in os.listdir(od)}
+    assert wgbs_tools.main(['wgbstools', 'beta_to_blocks'] + world['betas'] + ['-b', world['blocks'][name], '-o', str(od)]) == 0
+    assert before == {f: os.stat(od / f).st_mtime_ns for f in os.listdir(od)}
+
+
+def test_block_sums_all_modes_against_oracle():
+    """Random tables on 1.2 M sites x 5 samples: unaligned edges, 1-site blocks, blocks of thousands of sites, empty
+    blocks, overlaps, the whole range; every mode bit for bit (mode 3: the doubles' bits, NaNs included)."""
+    n, N = 1200000, 5
+    seed = 4242
+    data = [synth.synth_betas(seed, s, 0, n) for s in range(N)]
+    data[3][5000:9000, :] = 255                                   # saturated stretch: sums that need the uint16 / uint8 trim
+    data[4][100000:100700, :] = 0
+    rng = np.random.default_rng(1)
+    s0 = rng.integers(0, n - 1, 150000)
+    ln = np.where(rng.random(150000) < 0.95, rng.integers(0, 40, 150000), rng.integers(40, 6000, 150000))
+    e0 = np.minimum(s0 + ln, n)
+    s0 = np.concatenate([s0, [0, n - 1, n, 0, 7, 8, 9]]); e0 = np.concatenate([e0, [n, n, n, 1, 8, 8, 25]])
+    sg = _lib.Segmenter(0)
+    try:
+        sg.set_betas(data)
+        raw = sg.block_sums(s0, e0, mode=0)
+        b8 = sg.block_sums(s0, e0, mode=1)
+        b16 = sg.block_sums(s0, e0, mode=2)
+        mean = sg.block_sums(s0, e0, mode=3, min_cov=7)
+        assert sg.last_block_sums_ms() > 0
+        for s in range(N):
+            want = OB.block_sums(data[s], s0, e0)
+            assert (raw[s].astype(np.int64) == want).all(), 'sample %d: first bad block %d' % (s, int(np.flatnonzero((raw[s] != want).any(1))[0]))
+            assert (b8[s] == OB.trim(want, False)).all() and (b16[s] == OB.trim(want, True)).all()
+            assert (mean[s].view(np.uint64) == OB.beta2vec(want, 7).view(np.uint64)).all() or \
+                   (np.isnan(mean[s]) == np.isnan(OB.beta2vec(want, 7))).all() and np.array_equal(mean[s][~np.isnan(mean[s])], OB.beta2vec(want, 7)[~np.isnan(mean[s])])
+        with pytest.raises(_lib.SegmentorError):
+            sg.block_sums([5], [n + 1])
+        with pytest.raises(_lib.SegmentorError):
+            sg.block_sums([9], [3])
+    finally:
+        sg.close()
+
+
+def test_block_sums_full_size_tiling_property():
+    """hg19-sized rows: any tiling of the sites sums to the column totals of the raw bytes (two granularities)."""
+    n, N = 28217448, 3
+    import ctypes as C
+    import torch
+    pitch = ((2 * n + 255) // 256) * 256 + 256
+    buf = torch.empty((N, pitch), dtype=torch.uint8, device='cuda:0')
+    assert _lib.load_synth().wgbssynth_fill_betas(C.c_void_p(buf.data_ptr()), pitch, n, 0, N, 77, None) == 0
+    sg = _lib.Segmenter(0)
+    try:
+        sg.set_betas_device(buf.data_ptr(), N, pitch, n, keepalive=buf)
+        host = buf[:, :2 * n].cpu().numpy().reshape(N, n, 2).astype(np.int64).sum(axis=1)
+        for step in (16, 997):
+            b = np.arange(0, n + step, step, dtype=np.int64).clip(max=n)
+            got = sg.block_sums(b[:-1], b[1:], mode=0).astype(np.int64).sum(axis=1)
+            assert (got == host).all(), (step, got, host)
+        print('k_block_sums: %.3f ms for %d blocks x %d samples' % (sg.last_block_sums_ms(), b.size - 1, N))
+    finally:
+        sg.close()

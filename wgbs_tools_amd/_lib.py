@@ -20,7 +20,7 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_set_betas_host', 'wgbsseg_set_betas_device', 'wgbsseg_set_loci_host', 'wgbsseg_set_loci_device',
            'wgbsseg_segment_chunks', 'wgbsseg_segment_regions', 'wgbsseg_segment_chunks_host', 'wgbsseg_prefix_sums', 'wgbsseg_scan_only',
            'wgbsseg_get_timings', 'wgbsseg_debug_fetch', 'wgbsseg_debug_sample_terms', 'wgbsseg_debug_log2',
-           'wgbsseg_debug_div', 'wgbsseg_add_loci']
+           'wgbsseg_debug_div', 'wgbsseg_add_loci', 'wgbsseg_block_sums', 'wgbsseg_last_block_sums_ms']
 
 
 class NativeLibraryError(RuntimeError):
@@ -130,6 +130,10 @@ def load():
     L.wgbsseg_debug_log2.argtypes = [vp, C.c_uint32, i64, vp, vp, vp]
     L.wgbsseg_debug_div.restype = i32
     L.wgbsseg_debug_div.argtypes = [vp, vp, vp, i64, vp, vp]
+    L.wgbsseg_block_sums.restype = i32
+    L.wgbsseg_block_sums.argtypes = [vp, vp, vp, i64, i32, C.c_uint32, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_last_block_sums_ms.restype = C.c_double
+    L.wgbsseg_last_block_sums_ms.argtypes = [vp]
     L.wgbsseg_add_loci.restype = i32
     L.wgbsseg_add_loci.argtypes = [vp, i64, vp, C.POINTER(C.c_char_p), i32, vp, vp, i64, C.c_char_p, i32, i32, C.c_char_p, C.c_size_t]
     _lib = L
@@ -261,6 +265,23 @@ class Segmenter:
         _check(self._L.wgbsseg_scan_only(self._h, start0.ctypes.data, lens.ctypes.data, start0.size, int(repeat),
                                          C.byref(ms), C.byref(nbytes), self._err, ERRLEN), self._err)
         return ms.value, nbytes.value
+
+    def block_sums(self, start0, end0, mode=0, min_cov=1):
+        """wgbsseg_block_sums over the resident samples: 0-based half-open site ranges -> array [n_samples][n_blocks]
+        of uint32 pairs (mode 0), uint8 pairs (1, .bin rows), uint16 pairs (2, .lbeta rows) or float64 means (3)."""
+        s = np.ascontiguousarray(start0, dtype=np.int64)
+        e = np.ascontiguousarray(end0, dtype=np.int64)
+        assert s.shape == e.shape and s.ndim == 1
+        n = s.size
+        shape, dt = {0: ((self.n_samples, n, 2), np.uint32), 1: ((self.n_samples, n, 2), np.uint8),
+                     2: ((self.n_samples, n, 2), np.uint16), 3: ((self.n_samples, n), np.float64)}[int(mode)]
+        out = np.empty(shape, dtype=dt)
+        _check(self._L.wgbsseg_block_sums(self._h, s.ctypes.data, e.ctypes.data, n, int(mode), int(min_cov), out.ctypes.data,
+                                          self._err, ERRLEN), self._err)
+        return out
+
+    def last_block_sums_ms(self):
+        return float(self._L.wgbsseg_last_block_sums_ms(self._h))
 
     def timings(self):
         t = Timings()

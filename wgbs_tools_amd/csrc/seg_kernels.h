@@ -1245,6 +1245,66 @@ __global__ __launch_bounds__(WG_BLOCK) void k_gather_borders(JobView J, const in
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_block_sums: (#meth, #cov) of every block of a blocks table in every sample — the reduction of
+// beta_to_blocks.py:101-126 (np.add.reduceat over the sample's (meth, cov) rows / the per-row slice sums of its
+// slow_method), with its output conversions:
+//   mode 0  uint32 pairs (the sums)
+//   mode 1  uint8  pairs (.bin):   utils_wgbs.py:277-290 trim_to_uint8: cov > 255   -> meth = trunc(meth / cov * 255), cov = 255
+//   mode 2  uint16 pairs (.lbeta): the same with 65535
+//   mode 3  double meth/cov, NaN where cov < min_cov (utils_wgbs.py:270-274 beta2vec)
+// One thread per (block, sample): the block's bytes in 16-byte vectors, SWAR sums, edges masked by site index.
+// HBM-bound: a blocks table that tiles the genome reads every beta byte once (2 N n bytes).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restrict__ betas, int64_t pitch, int64_t n_total,
+                                                         const int64_t* __restrict__ x0s, const int64_t* __restrict__ x1s, int64_t n_blocks,
+                                                         int mode, uint32_t min_cov, void* __restrict__ out)
+{
+    const int64_t b = (int64_t)blockIdx.x * WG_BLOCK + threadIdx.x;
+    const int s = blockIdx.y;
+    if (b >= n_blocks) return;
+    const int64_t x0 = x0s[b], x1 = x1s[b];
+    const uint8_t* row = betas + (int64_t)s * pitch;
+    uint64_t m = 0, c = 0;
+    if (x1 > x0) {
+        uint32_t sm = 0, sc = 0;
+        int pend = 0;
+        for (int64_t site = x0 & ~7LL; site < x1; site += 8) {             // 8 sites = one 16-byte vector, aligned in the row
+            const uint4 v = wg_load16_guarded(row, site, n_total);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const bool inner = site >= x0 && site + 8 <= x1;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                uint32_t x = w[d];
+                if (!inner) {
+                    const int64_t a = site + 2 * d;
+                    const uint32_t k0 = (a >= x0 && a < x1) ? 0x0000ffffu : 0u;
+                    const uint32_t k1 = (a + 1 >= x0 && a + 1 < x1) ? 0xffff0000u : 0u;
+                    x &= k0 | k1;
+                }
+                sm += x & 0x00ff00ffu;
+                sc += (x >> 8) & 0x00ff00ffu;
+            }
+            if (++pend == 32) {                                           // 16-bit lanes hold 128 x 255 at most
+                m += (sm & 0xffffu) + (sm >> 16); c += (sc & 0xffffu) + (sc >> 16);
+                sm = 0; sc = 0; pend = 0;
+            }
+        }
+        m += (sm & 0xffffu) + (sm >> 16); c += (sc & 0xffffu) + (sc >> 16);
+    }
+    const int64_t o = (int64_t)s * n_blocks + b;
+    if (mode == 0) {
+        reinterpret_cast<uint2*>(out)[o] = make_uint2((uint32_t)m, (uint32_t)c);
+    } else if (mode == 1 || mode == 2) {
+        const uint64_t maxv = mode == 1 ? 255u : 65535u;
+        if (c > maxv) { m = (uint64_t)((double)m / (double)c * (double)maxv); c = maxv; }
+        if (mode == 1) reinterpret_cast<uchar2*>(out)[o] = make_uchar2((unsigned char)m, (unsigned char)c);
+        else           reinterpret_cast<ushort2*>(out)[o] = make_ushort2((unsigned short)m, (unsigned short)c);
+    } else {
+        reinterpret_cast<double*>(out)[o] = (c >= (uint64_t)min_cov) ? (double)m / (double)c : __builtin_nan("");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // test hooks
 // ------------------------------------------------------------------------------------------------------------
 __global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, float pc, float* out, int fast)

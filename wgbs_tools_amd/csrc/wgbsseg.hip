@@ -109,6 +109,7 @@ struct wgbsseg_ctx {
     int force_ns = 0;
     int force_ti = 0;
     int min_stages = 0;      // WGBSSEG_MIN_STAGES; 0: decided per call from the number of chunks
+    double last_block_sums_ms = 0.0;
     bool accumulate = false;   // add to `tim` instead of resetting it (region-level calls span several batches)
 };
 
@@ -717,6 +718,46 @@ int wgbsseg_prefix_sums(wgbsseg_ctx* c, int64_t start0, int64_t len, uint32_t* o
     c->last_valid = false;
     return WGBSSEG_OK;
 }
+
+int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end0, int64_t n_blocks, int32_t mode,
+                       uint32_t min_cov, void* out, char* err, size_t errlen)
+{
+    if (!c) { set_err(err, errlen, "ctx is NULL"); return WGBSSEG_E_ARG; }
+    if (!c->betas) { set_err(err, errlen, "betas not set"); return WGBSSEG_E_STATE; }
+    if (n_blocks < 0 || mode < 0 || mode > 3 || (n_blocks && (!start0 || !end0 || !out))) { set_err(err, errlen, "bad arguments to block_sums"); return WGBSSEG_E_ARG; }
+    if (n_blocks == 0) return WGBSSEG_OK;
+    for (int64_t i = 0; i < n_blocks; i++)
+        if (start0[i] < 0 || end0[i] < start0[i] || end0[i] > c->n_total) {
+            set_err(err, errlen, "block %lld = sites [%lld, %lld) is outside the %lld sites of the beta files or reversed",
+                    (long long)i, (long long)start0[i], (long long)end0[i], (long long)c->n_total);
+            return WGBSSEG_E_ARG;
+        }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t esz = mode == 0 ? 8 : (mode == 1 ? 2 : (mode == 2 ? 4 : 8));
+    const size_t obytes = (size_t)c->n_samples * (size_t)n_blocks * esz;
+    HIP_TRY(c->dbg_a.ensure((size_t)n_blocks * 16));
+    HIP_TRY(c->dbg_b.ensure(obytes));
+    int64_t* dx0 = c->dbg_a.as<int64_t>();
+    int64_t* dx1 = dx0 + n_blocks;
+    HIP_TRY(hipMemcpyAsync(dx0, start0, (size_t)n_blocks * 8, hipMemcpyHostToDevice, c->sA));
+    HIP_TRY(hipMemcpyAsync(dx1, end0, (size_t)n_blocks * 8, hipMemcpyHostToDevice, c->sA));
+    const int64_t gx = (n_blocks + WG_BLOCK - 1) / WG_BLOCK;
+    if (gx > 0x7fffffff || c->n_samples > 65535) { set_err(err, errlen, "too many blocks / samples for one block_sums call"); return WGBSSEG_E_ARG; }
+    HIP_TRY(hipEventRecord(c->ev[0], c->sA));
+    hipLaunchKernelGGL(k_block_sums, dim3((unsigned)gx, (unsigned)c->n_samples), dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total,
+                       dx0, dx1, n_blocks, (int)mode, min_cov, c->dbg_b.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[1], c->sA));
+    HIP_TRY(hipMemcpyAsync(out, c->dbg_b.p, obytes, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->last_block_sums_ms = ms;
+    c->last_valid = false;
+    return WGBSSEG_OK;
+}
+
+double wgbsseg_last_block_sums_ms(const wgbsseg_ctx* c) { return c ? c->last_block_sums_ms : 0.0; }
 
 int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom_cum, const char* const* chrom_names,
                      int32_t n_chroms, const int64_t* start_cpg, const int64_t* end_cpg, int64_t n_blocks,

@@ -1,14 +1,15 @@
 #!/usr/bin/python3 -u
-"""`wgbstools <command>` dispatcher (reference: src/python/wgbs_tools.py:50-79).  This build carries ONE command,
-`segment` — the MI355X-native hot path; every other reference subcommand is out of scope and says so."""
+"""`wgbstools <command>` dispatcher (reference: src/python/wgbs_tools.py:50-79).  This build carries `segment` — the
+MI355X-native hot path — and the two consumers of its output that are the same reduction on the same resident data,
+`beta_to_blocks` and `beta_to_table`; every other reference subcommand is out of scope and says so."""
 import sys
 
 from .genome import IllegalArgumentError, eprint
 
 VERSION = '0.1.0-mi355x'
-COMMANDS = ['segment']
+COMMANDS = ['segment', 'beta_to_blocks', 'beta_to_table']
 # reference command list (wgbs_tools.py:11-48), for the "not in this build" message
-REFERENCE_ONLY = ['view', 'merge', 'cview', 'index', 'convert', 'beta_cov', 'beta_to_table', 'beta_to_blocks',
+REFERENCE_ONLY = ['view', 'merge', 'cview', 'index', 'convert', 'beta_cov',
                   'beta2bed', 'beta2bw', 'bam2pat', 'mbias', 'init_genome', 'set_default_ref', 'vis', 'pat_fig',
                   'find_markers', 'homog', 'test_bimodal', 'compare_betas', 'dmb', 'mix_pat', 'bed2beta',
                   'pat2beta', 'split_by_allele', 'split_by_meth', 'frag_len', 'add_cpg_counts', 'beta_to_450k']
@@ -33,14 +34,14 @@ def main(argv=None):
         return 0
     cmd = argv[1]
     if cmd in REFERENCE_ONLY:
-        eprint(f'wgbstools {cmd}: not part of this build (it carries only the MI355X-native `segment`)')
+        eprint(f'wgbstools {cmd}: not part of this build (it carries the MI355X-native `segment`, `beta_to_blocks`, `beta_to_table`)')
         return 1
     if cmd not in COMMANDS:
         eprint('Invalid command:', f'\033[01;31m{cmd}\033[00m')
         return print_help()
     try:
-        from . import segment
-        segment.main(argv[2:])
+        import importlib
+        importlib.import_module('.' + cmd, __package__).main(argv[2:])
         return 0
     except IllegalArgumentError as e:          # wgbs_tools.py:77-79
         eprint(f'Invalid input argument\n{e}')
