@@ -14,34 +14,43 @@ def windows(loci, max_cpg, max_bp):
     hi = np.minimum(np.minimum(hi, k + max_cpg - 1), l.size - 1)
     return (hi - k + 1).astype(np.int64)
 
+CARRY_SHIFT = 7                       # WG_CARRY_SHIFT: a carry every 128 sites of absolute index
+CARRY_G = 1 << CARRY_SHIFT
+
 def group_start(start0, k):
-    a = (start0 + k) & ~63
+    a = (start0 + k) & ~(CARRY_G - 1)
     return 0 if a <= start0 else a - start0
 
 def emu_scan_carries(row, start0, ln):
-    """k_scan for one (chunk, sample) row: carry[g] at absolute 64-multiples (g>=1) / chunk start (g=0)."""
-    g0 = start0 >> 6
-    nG = ((start0 + ln - 1) >> 6) - g0 + 1
+    """k_scan for one (chunk, sample) row: carry[g] at absolute multiples of CARRY_G (g>=1) / chunk start (g=0).
+    64 lanes x 16 sites per iteration; vectors past the row end are clamped onto the last readable one and blanked."""
+    g0 = start0 >> CARRY_SHIFT
+    nG = ((start0 + ln - 1) >> CARRY_SHIFT) - g0 + 1
     carry = np.full((nG, 2), -1, dtype=np.int64)
     carry[0] = 0
     n_total = row.shape[0]
-    a_abs = start0 & ~7; head = start0 - a_abs; span = head + ln
+    a_abs = start0 & ~15; head = start0 - a_abs; span = head + ln
+    A6 = a_abs & (CARRY_G - 1)
+    vlast = ((n_total - 1) >> 3) - (a_abs >> 3)
     run = np.zeros(2, dtype=np.int64)
-    for base in range(0, span, 512):
+    for base in range(0, span, 1024):
         tot = np.zeros((64, 2), dtype=np.int64)
         for lane in range(64):
-            off = base + lane * 8; rel0 = off - head
-            for j in range(8):
-                a = a_abs + off + j
-                m, c = (row[a] if (off < span and a < n_total) else (0, 0))
-                rel = rel0 + j
-                if not (0 <= rel < ln): m = c = 0
-                tot[lane] += (m, c)
+            off = base + lane * 16; rel0 = off - head
+            for h in range(2):
+                vi = min((off >> 3) + h, vlast)           # clamped vector index (from a_abs)
+                for j in range(8):
+                    a = a_abs + vi * 8 + j
+                    m, c = row[a] if a < n_total else (255, 0)      # garbage past the row: must be blanked
+                    rel = rel0 + 8 * h + j
+                    if not (0 <= rel < ln): m = c = 0
+                    else: assert a == start0 + rel, 'a clamped vector reached a site inside the chunk'
+                    tot[lane] += (m, c)
         incl = np.cumsum(tot, axis=0)
         for lane in range(64):
-            off = base + lane * 8; rel0 = off - head; vabs = a_abs + off
-            if (vabs & 63) == 0 and 0 < rel0 < ln:
-                carry[(vabs >> 6) - g0] = run + incl[lane] - tot[lane]
+            off = base + lane * 16; rel0 = off - head
+            if ((A6 + off) & (CARRY_G - 1)) == 0 and 0 < rel0 < ln:
+                carry[(A6 + off) >> CARRY_SHIFT] = run + incl[lane] - tot[lane]
         run += incl[63]
     return carry
 
@@ -51,7 +60,7 @@ def emu_stage_row(row, carry, start0, ln, A, cnt, x0=0):
     n_total = row.shape[0]
     dst = np.full((cnt0, 2), -1, dtype=np.int64)
     abs0 = start0 + A
-    run = carry[(abs0 >> 6) - (start0 >> 6)].copy()
+    run = carry[(abs0 >> CARRY_SHIFT) - (start0 >> CARRY_SHIFT)].copy()
     al = abs0 & ~3; hs = abs0 - al
     for p0 in range(0, cnt + hs, 256):
         tot = np.zeros((64, 2), dtype=np.int64); vals = np.zeros((64, 4, 2), dtype=np.int64)
@@ -109,7 +118,7 @@ def emu_cost_tiles(F, n, S, stage, TI, WA, TK, start0=0):
                     pairs += [(k, i) for i in range(is_, ie + 1)]
             if not pairs: continue
             eA = imin + 1 if split else ka
-            eG = group_start(start0, eA); assert 0 <= eA - eG <= 63
+            eG = group_start(start0, eA); assert 0 <= eA - eG <= CARRY_G - 1
             Ecnt = imax + 2 - eA
             assert 0 < Ecnt <= KS, (Ecnt, KS)
             if split:
@@ -244,14 +253,14 @@ if __name__ == '__main__':
     for start0, ln in [(0, 1), (3, 700), (8, 512), (13, 4000), (4990, 10), (1, 64), (7, 129), (64, 200), (63, 2), (100, 1000)]:
         carry = emu_scan_carries(row, start0, ln)
         P = np.concatenate([[[0, 0]], np.cumsum(row[start0:start0 + ln], axis=0)])
-        g0 = start0 >> 6
+        g0 = start0 >> CARRY_SHIFT
         for g in range(carry.shape[0]):
-            pos = 0 if g == 0 else ((g0 + g) << 6) - start0
+            pos = 0 if g == 0 else ((g0 + g) << CARRY_SHIFT) - start0
             if g > 0 and pos >= ln: continue
             assert (carry[g] == P[pos]).all(), (start0, ln, g, carry[g], P[pos])
         for k in list(range(0, ln, 37)) + [ln - 1]:
             A = group_start(start0, k)
-            assert 0 <= k - A <= 63
+            assert 0 <= k - A <= CARRY_G - 1
             for cnt in (1, 5, 64, 65, 200, 300):
                 x0 = k - A
                 dst = emu_stage_row(row, carry, start0, ln, A, cnt, x0)

@@ -1,7 +1,7 @@
 // seg_kernels.h — gfx950 kernels of the `wgbstools segment` hot path.
 //
 // Pipeline for one batch of chunks (a chunk = what one reference `segmentor` process handles, segmentor.cpp:193-214):
-//   k_scan    per-sample prefix scan of (#meth,#cov) with 64-site carries + the #meth<=#cov validation of
+//   k_scan    per-sample prefix scan of (#meth,#cov) with 128-site carries + the #meth<=#cov validation of
 //             read_beta_file (segmentor.cpp:179-188).  HBM-bound: reads every beta byte once, writes 1/16 of that.
 //   k_window  forward window F_k of every site from the loci (the bp/CpG limits of segmentor.cpp:111-117: the
 //             extensions of a block starting at k that are admissible) and the CSR row offsets of the scored-block
@@ -23,8 +23,9 @@
 #include "exact_log2.h"
 #include "wave_prims.h"
 
-#define WG_CARRY_G      64          // a carry (chunk-relative exclusive prefix) is stored at every absolute site index
-                                    // that is a multiple of 64 inside the chunk, plus (group 0) at the chunk start itself
+#define WG_CARRY_SHIFT  7
+#define WG_CARRY_G      (1 << WG_CARRY_SHIFT)   // a carry (chunk-relative exclusive prefix) is stored at every absolute site index
+                                    // that is a multiple of 128 inside the chunk, plus (group 0) at the chunk start itself
 #define WG_BLOCK        256
 #define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)
 #define WG_TRACE_WIN    32768       // back-pointers staged in LDS by k_trace (64 KiB)
@@ -55,7 +56,7 @@ struct ChunkDesc {
     int64_t carry_off;   // offset (in uint2) of this chunk's carries: [n_samples][nG]
     int64_t unit_off;    // offset of this chunk in umax16: one entry per 16 sites of the chunk
     int32_t len;
-    int32_t nG;          // 64-site groups of ABSOLUTE site index the chunk touches: ((start0+len-1)>>6) - (start0>>6) + 1
+    int32_t nG;          // carry groups (WG_CARRY_G sites of ABSOLUTE site index) the chunk touches: ((start0+len-1)>>S) - (start0>>S) + 1
 };
 
 struct JobView {
@@ -127,9 +128,33 @@ __device__ __forceinline__ void wg_sum8(const uint4 v, uint32_t& tm, uint32_t& t
     anybad = (ok & 0x01000100u) != 0x01000100u;
 }
 
-// One wavefront streams one (chunk, sample) row, 64 lanes x 16 B = 512 sites per iteration, two iterations in
-// flight.  Lane vectors are 16-byte aligned in the sample row, so every 8th lane starts on an absolute site index
-// that is a multiple of 64: that lane stores the carry of its group, no intra-vector partial sums needed.
+// One wavefront streams one (chunk, sample) row, 64 lanes x 32 B = 1024 sites per iteration, the next iteration in
+// flight.  Lane vectors are 32-byte aligned in the sample row, so every 8th lane starts on an absolute site index that
+// is a multiple of 128: that lane stores the carry of its group, no intra-vector partial sums needed; the two wave scans
+// are amortised over 2 KB.  Register-lean on purpose (32-bit chunk-relative indices, the rare paths out of line):
+// 8 wavefronts per SIMD, so that the 15,456 equally long rows of an hg19 x 32 job run in two rounds, not three.
+__device__ __noinline__ uint4 wg_blank_outside(uint4 v, int rel0, int len)
+{
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int rel = rel0 + j;
+        if (rel < 0 || rel >= len) w[j >> 1] &= ~(0xffffu << (16 * (j & 1)));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __noinline__ int wg_first_bad_site(uint4 v0, uint4 v1)      // index (0..15) of the first site with #meth > #cov
+{
+    const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    int bad = 16;
+    for (int j = 15; j >= 0; j--) {
+        const uint32_t h = w[j >> 1] >> (16 * (j & 1));
+        if ((h & 0xffu) > ((h >> 8) & 0xffu)) bad = j;
+    }
+    return bad;
+}
+
 __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
 {
     const int lane = threadIdx.x & 63;
@@ -139,57 +164,52 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
     const int c = (int)(rowid / J.n_samples);
     const int s = (int)(rowid - (int64_t)c * J.n_samples);
     const ChunkDesc cd = J.chunks[c];
-    const uint8_t* row = J.betas + (int64_t)s * J.pitch;
+    const int64_t a_abs = cd.start0 & ~15LL;          // first 32-byte aligned site of the stream
+    const int head = (int)(cd.start0 - a_abs);        // sites of the first lane vector that precede the chunk
+    const int len = cd.len;
+    const int span = head + len;                      // sites from a_abs to the chunk end (< 2^31: checked by the host)
+    // 16-byte vectors of the row from a_abs on; every vector that STARTS inside the row is readable (pitch is a
+    // multiple of 16 bytes >= 2 n_total), later ones are clamped onto the last readable one and blanked below
+    const uint4* rv = reinterpret_cast<const uint4*>(J.betas + (int64_t)s * J.pitch) + (a_abs >> 3);
+    const int64_t vl = ((J.n_total - 1) >> 3) - (a_abs >> 3);
+    const int vlast = vl > 0x7ffffff0 ? 0x7ffffff0 : (int)vl;
+    // a_abs and start0 share their carry group (rounding down to 16 never crosses a multiple of 128), so the carry of
+    // the group that begins at stream offset `off` is entry (A6 + off) >> WG_CARRY_SHIFT, A6 = a_abs mod the group size
     uint2* carry = J.carry + cd.carry_off + (int64_t)s * cd.nG;
-
-    const int64_t a_abs = cd.start0 & ~7LL;           // first 16-byte aligned site of the stream
-    const int head = (int)(cd.start0 - a_abs);        // sites of the first vector that precede the chunk
-    const int64_t span = (int64_t)head + cd.len;      // sites from a_abs to the chunk end
-    const int64_t g0 = cd.start0 >> 6;
+    const int A6 = (int)(a_abs & (WG_CARRY_G - 1));
     uint32_t run_m = 0, run_t = 0;
-    int64_t bad_abs = -1;
+    int bad_rel = 0x7fffffff;
     if (lane == 0) carry[0] = make_uint2(0u, 0u);     // group 0: the chunk start
 
-    uint4 cur = make_uint4(0, 0, 0, 0), nxt = make_uint4(0, 0, 0, 0);
-    if ((int64_t)lane * 8 < span) cur = wg_load16_guarded(row, a_abs + (int64_t)lane * 8, J.n_total);
-    if ((int64_t)lane * 8 + 512 < span) nxt = wg_load16_guarded(row, a_abs + (int64_t)lane * 8 + 512, J.n_total);
-    for (int64_t base = 0; base < span; base += 512) {
-        const int64_t off = base + (int64_t)lane * 8;  // site offset of this lane's vector from a_abs
-        uint4 nn = make_uint4(0, 0, 0, 0);
-        if (off + 1024 < span) nn = wg_load16_guarded(row, a_abs + off + 1024, J.n_total);   // two iterations ahead
-
-        uint4 v = cur;
-        const int64_t rel0 = off - head;               // chunk-relative index of the vector's first site
-        if (rel0 < 0 || rel0 + 8 > cd.len) {           // edge vector: blank the sites outside the chunk
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int64_t rel = rel0 + j;
-                if (rel < 0 || rel >= cd.len) w[j >> 1] &= ~(0xffffu << (16 * (j & 1)));
-            }
-            v = make_uint4(w[0], w[1], w[2], w[3]);
+    int vi = 2 * lane;                                // this lane's first vector of the current iteration
+    uint4 c0 = rv[vi < vlast ? vi : vlast], c1 = rv[vi + 1 < vlast ? vi + 1 : vlast];
+    for (int base = 0; base < span; base += 1024) {
+        const int vn = vi + 128;                      // one iteration ahead (clamped: never past the row)
+        const uint4 m0 = rv[vn < vlast ? vn : vlast], m1 = rv[vn + 1 < vlast ? vn + 1 : vlast];
+        uint4 v0 = c0, v1 = c1;
+        const int off = base + lane * 16;             // site offset of this lane's 16 sites from a_abs
+        const int rel0 = off - head;                  // chunk-relative index of the lane's first site
+        if (rel0 < 0 || rel0 + 16 > len) {            // edge lane: blank the sites outside the chunk
+            v0 = wg_blank_outside(v0, rel0, len);
+            v1 = wg_blank_outside(v1, rel0 + 8, len);
         }
-        uint32_t tm, tt;
-        bool anybad;
-        wg_sum8(v, tm, tt, anybad);
-        if (anybad && bad_abs < 0) {                   // rare: find the first offending site of this vector
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            for (int j = 7; j >= 0; j--) {
-                const uint32_t h = w[j >> 1] >> (16 * (j & 1));
-                if ((h & 0xffu) > ((h >> 8) & 0xffu)) bad_abs = cd.start0 + rel0 + j;
-            }
-        }
+        uint32_t tm0, tt0, tm1, tt1;
+        bool bad0, bad1;
+        wg_sum8(v0, tm0, tt0, bad0);
+        wg_sum8(v1, tm1, tt1, bad1);
+        if ((bad0 || bad1) && bad_rel == 0x7fffffff) bad_rel = rel0 + wg_first_bad_site(v0, v1);   // rare
+        const uint32_t tm = tm0 + tm1, tt = tt0 + tt1;
         // wave-wide inclusive prefix of the lane totals (two 32-bit DPP scans)
         const uint32_t im = wg_wave_incl_scan_dpp_u32(tm);
         const uint32_t it = wg_wave_incl_scan_dpp_u32(tt);
-        const int64_t vabs = a_abs + off;              // absolute index of the vector's first site
-        if ((vabs & 63) == 0 && rel0 > 0 && rel0 < cd.len)
-            carry[(vabs >> 6) - g0] = make_uint2(run_m + (im - tm), run_t + (it - tt));
+        if (((A6 + off) & (WG_CARRY_G - 1)) == 0 && rel0 > 0 && rel0 < len)
+            carry[(A6 + off) >> WG_CARRY_SHIFT] = make_uint2(run_m + (im - tm), run_t + (it - tt));
         run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
         run_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
-        cur = nxt; nxt = nn;
+        c0 = m0; c1 = m1; vi = vn;
     }
-    if (bad_abs >= 0) atomicMin(&st->first_bad, ((unsigned long long)s << 40) | (unsigned long long)bad_abs);
+    if (bad_rel != 0x7fffffff)
+        atomicMin(&st->first_bad, ((unsigned long long)s << 40) | (unsigned long long)(cd.start0 + bad_rel));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -445,7 +465,7 @@ struct CostArgs {
 };
 
 // Stage the exclusive prefixes P[A+x], x = x0 .. x0+cnt-1, of sample row `row` into dst[0..cnt) (one wavefront).
-// A is chunk-relative; start0+A is either the chunk start or a multiple of 64 (wg_group_start), so a carry of
+// A is chunk-relative; start0+A is either the chunk start or a multiple of WG_CARRY_G (wg_group_start), so a carry of
 // k_scan seeds the scan; the up to 63 sites between A and A+x0 are summed but not stored.
 __device__ __forceinline__ void wg_stage_prefix_row(uint2* __restrict__ dst, const uint8_t* __restrict__ row,
                                                     const uint2* __restrict__ carry, const ChunkDesc& cd,
@@ -453,7 +473,7 @@ __device__ __forceinline__ void wg_stage_prefix_row(uint2* __restrict__ dst, con
 {
     const int cnt = x0 + cnt0;
     const int64_t abs0 = cd.start0 + A;
-    const uint2 c0 = carry[(abs0 >> 6) - (cd.start0 >> 6)];
+    const uint2 c0 = carry[(abs0 >> WG_CARRY_SHIFT) - (cd.start0 >> WG_CARRY_SHIFT)];
     uint32_t run_m = c0.x, run_t = c0.y;
     const int64_t al = abs0 & ~3LL;                    // 8-byte aligned
     const int hs = (int)(abs0 - al);
@@ -500,7 +520,7 @@ __device__ __forceinline__ void wg_stage_prefix_row(uint2* __restrict__ dst, con
 // Largest carry position <= chunk-relative site k: the 64-aligned absolute index below it, or the chunk start.
 __device__ __forceinline__ int wg_group_start(const ChunkDesc& cd, int k)
 {
-    const int64_t a = (cd.start0 + k) & ~63LL;
+    const int64_t a = (cd.start0 + k) & ~(int64_t)(WG_CARRY_G - 1);
     return a <= cd.start0 ? 0 : (int)(a - cd.start0);
 }
 
@@ -1340,7 +1360,7 @@ __global__ void k_debug_log2(uint32_t first, int64_t count, uint32_t* out_f, uin
 }
 
 // Materialise P[t], t = 0..len, for one range of one sample from the carries (test / block-sum helper):
-// one wavefront per (sample, 64-site group of absolute site index).
+// one wavefront per (sample, carry group of absolute site index).
 __global__ __launch_bounds__(64) void k_prefix_materialise(JobView J, int nG, uint32_t* __restrict__ out, int len)
 {
     const int lane = threadIdx.x;
@@ -1348,13 +1368,18 @@ __global__ __launch_bounds__(64) void k_prefix_materialise(JobView J, int nG, ui
     const ChunkDesc cd = J.chunks[0];
     const uint8_t* row = J.betas + (int64_t)s * J.pitch;
     const uint2 c0 = J.carry[cd.carry_off + (int64_t)s * cd.nG + g];
-    const int64_t gabs = (((cd.start0 >> 6) + g) << 6);
-    const int64_t x = gabs + lane - cd.start0;             // chunk-relative site of this lane
-    uint32_t m = 0, t = 0;
-    if (x >= 0 && x < len) { m = row[2 * (cd.start0 + x)]; t = row[2 * (cd.start0 + x) + 1]; }
-    const uint32_t im = wg_wave_incl_scan_dpp_u32(m), it = wg_wave_incl_scan_dpp_u32(t);
+    const int64_t gabs = (((cd.start0 >> WG_CARRY_SHIFT) + g) << WG_CARRY_SHIFT);
     uint32_t* o = out + ((int64_t)s * (len + 1)) * 2;
-    if (x >= 0 && x < len) { o[2 * (x + 1)] = c0.x + im; o[2 * (x + 1) + 1] = c0.y + it; }
+    uint32_t run_m = c0.x, run_t = c0.y;
+    for (int q = 0; q < WG_CARRY_G; q += 64) {
+        const int64_t x = gabs + q + lane - cd.start0;      // chunk-relative site of this lane
+        uint32_t m = 0, t = 0;
+        if (x >= 0 && x < len) { m = row[2 * (cd.start0 + x)]; t = row[2 * (cd.start0 + x) + 1]; }
+        const uint32_t im = wg_wave_incl_scan_dpp_u32(m), it = wg_wave_incl_scan_dpp_u32(t);
+        if (x >= 0 && x < len) { o[2 * (x + 1)] = run_m + im; o[2 * (x + 1) + 1] = run_t + it; }
+        run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
+        run_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
+    }
     if (g == 0 && lane == 0) { o[0] = 0; o[1] = 0; }
     (void)nG;
 }

@@ -262,13 +262,13 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
     job.wtile_off.resize((size_t)n_chunks + 1);
     int64_t so = 0, co = 0, wt = 0, uo = 0;
     for (int64_t i = 0; i < n_chunks; i++) {
-        if (len[i] < 1 || start0[i] < 0 || start0[i] + len[i] > c->n_total) {
+        if (len[i] < 1 || len[i] > (1 << 30) || start0[i] < 0 || start0[i] + len[i] > c->n_total) {
             set_err(err, errlen, "chunk %lld = [%lld, +%d) is empty or outside the %lld sites of the beta files",
                     (long long)i, (long long)start0[i], (int)len[i], (long long)c->n_total);
             return WGBSSEG_E_ARG;
         }
         ChunkDesc& d = job.h[(size_t)i];
-        d.start0 = start0[i]; d.len = len[i]; d.site_off = so; d.carry_off = co; d.unit_off = uo; d.nG = (int32_t)(((start0[i] + len[i] - 1) >> 6) - (start0[i] >> 6) + 1);
+        d.start0 = start0[i]; d.len = len[i]; d.site_off = so; d.carry_off = co; d.unit_off = uo; d.nG = (int32_t)(((start0[i] + len[i] - 1) >> WG_CARRY_SHIFT) - (start0[i] >> WG_CARRY_SHIFT) + 1);
         job.wtile_off[(size_t)i] = wt;
         wt += (len[i] + WG_BLOCK - 1) / WG_BLOCK;
         so += len[i];
