@@ -77,8 +77,9 @@ void exact_log2_1mp_fill(uint32_t first, uint64_t count, uint64_t* out, int thre
 void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, float pc, float* out)
 {
     float pc2 = pc + pc;
-    const bool fast_ok = pc == 0.0f || pc >= WG_FAST_MIN_PC;       // same dispatch rule as the library
+    const int mode = wg_term_mode(pc);                              // same dispatch rule as the library
     for (int64_t q = 0; q < count; q++)
-        out[q] = fast_ok ? wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab) : wg_sample_term_plain(nmeth[q], ntotal[q], pc, pc2, &g_tab);
+        out[q] = mode == 2 ? wg_sample_term_pcpos(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab)
+               : (mode == 1 ? wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab) : wg_sample_term_plain(nmeth[q], ntotal[q], pc, pc2, &g_tab));
 }
 }

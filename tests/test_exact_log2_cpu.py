@@ -79,15 +79,20 @@ def test_log2f_and_log2_exhaustive_vs_libm(exact):
 
 def _term_inputs(seed, n_random):
     rng = np.random.default_rng(seed)
-    t = np.concatenate([np.arange(0, 5000), rng.integers(0, 255 * 1000, n_random),
+    big = np.repeat(np.array([255 * 8000, 255 * 8000 - 1, 255 * 1000, 2 ** 20, 2 ** 20 + 1, 65535, 65536]), 4)   # the ABI's largest sums
+    t = np.concatenate([np.arange(0, 5000), big, rng.integers(0, 255 * 1000, n_random),
                         rng.integers(0, 4000, n_random)]).astype(np.float32)
     m = np.minimum(np.floor(rng.random(t.size) * (t + 1)), t).astype(np.float32)
     m[:5000:3] = 0
     m[1:5000:3] = t[1:5000:3]
+    m[5000:5000 + big.size:4] = 0                       # nmeth = 0, = ntotal, = ntotal - 1, = 1 at the extremes
+    m[5001:5000 + big.size:4] = t[5001:5000 + big.size:4]
+    m[5002:5000 + big.size:4] = t[5002:5000 + big.size:4] - 1
+    m[5003:5000 + big.size:4] = 1
     return m, t
 
 
-@pytest.mark.parametrize('pcount', [15.0, 0.0, 0.5, 1.0, 3.25, 1e-30, 2e-6, 1e-7])
+@pytest.mark.parametrize('pcount', [15.0, 0.0, 0.5, 1.0, 3.25, 4.0, 3.9999998, 1000.0, 1e-30, 2e-6, 1e-7])
 def test_sample_term_forms_match_oracle(exact, pcount):
     m, t = _term_inputs(11, 1000000)
     want = oracle.sample_terms(m, t, pcount)

@@ -372,6 +372,30 @@ WG_HD float wg_div_f32(float a, float b)
 // result is never subnormal and the guard-band test needs no exponent check.  For p == 0 (pc == 0 and nmeth == 0)
 // the reference computes 0 + (ntotal-nmeth)*log2(1.0) = +0: ll stays +0.
 #define WG_FAST_MIN_PC 0x1p-20f
+// With a pseudo count >= 4 the guards of segmentor.cpp:129,132 are always true: 0 < p, and p < 1 even after both float
+// roundings ((nmeth+pc)/(ntotal+2pc) <= 1 - (pc-2)/(ntotal+2pc-1) with ntotal < 2^24: at least 2^-23 below 1).  The
+// `0 +` of :131 and the df == 0 exception fall away too: nmeth*log2f(p) is non-zero unless nmeth == 0, and then
+// df = ntotal > 0 makes the second term non-zero, so no sign of zero survives; df == 0 adds -0.0 to a non-zero ll.
+// Three compares, a move and two branch levels fewer per evaluation, same bits (tests: test_02, host twin).
+#define WG_POS_MIN_PC 4.0f
+WG_HD float wg_sample_term_pcpos(float nmeth, float ntotal, float pc, float pc2, const wg_fast_tables* __restrict__ ft,
+                                 const wg_log_tables* __restrict__ xt)
+{
+    if (ntotal == 0.0f) return 0.0f;                               // :125
+    const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
+    const float ll = nmeth * wg_log2f_normal(p, ft->f_tab);        // :129-131
+    const float df = ntotal - nmeth;
+    const double x = 1.0 - (double)p;                              // :132-134
+    const double s = (double)ll + (double)df * wg_fast_log2(x, ft->d_fast);
+    const uint32_t tail = (uint32_t)wg_d2u(s) & 0x1fffffffu;
+    float res = (float)s;
+    if ((uint32_t)(tail - (0x10000000u - WG_GUARD_ULPS)) <= 2u * WG_GUARD_ULPS)
+        res = (float)((double)ll + (double)df * wg_log2(x, xt->d_tab, xt->d_tab2));
+    return res;
+}
+
+// term mode of a pseudo count: 0 plain exact form, 1 fast form with the guards, 2 fast form without them
+WG_HD int wg_term_mode(float pc) { return pc >= WG_POS_MIN_PC ? 2 : ((pc == 0.0f || pc >= WG_FAST_MIN_PC) ? 1 : 0); }
 WG_HD float wg_sample_term(float nmeth, float ntotal, float pc, float pc2, const wg_fast_tables* __restrict__ ft,
                            const wg_log_tables* __restrict__ xt)
 {

@@ -524,7 +524,7 @@ __device__ __forceinline__ int wg_group_start(const ChunkDesc& cd, int k)
     return a <= cd.start0 ? 0 : (int)(a - cd.start0);
 }
 
-template <int TI, bool FAST>
+template <int TI, int FAST>      // FAST = wg_term_mode(pseudo count)
 __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, CostArgs A, const TileDesc* __restrict__ tiles,
                                                    int64_t n_tiles, double* __restrict__ cost, int64_t n_tiles_padded)
 {
@@ -622,7 +622,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 const uint2 pk = Sp[(size_t)sl * Sstride];
                 const float nm = (float)(pi.x - pk.x);
                 const float nt = (float)(pi.y - pk.y);
-                const float ll = FAST ? wg_sample_term(nm, nt, pc, pc2, tb, &g_wg_tables) : wg_sample_term_plain(nm, nt, pc, pc2, &g_wg_tables);
+                const float ll = FAST == 2 ? wg_sample_term_pcpos(nm, nt, pc, pc2, tb, &g_wg_tables)
+                               : (FAST == 1 ? wg_sample_term(nm, nt, pc, pc2, tb, &g_wg_tables) : wg_sample_term_plain(nm, nt, pc, pc2, &g_wg_tables));
                 acc += (double)ll;                                               // segmentor.cpp:135
             }
             if (lastg) cb[radj[lo] + i] = (acc != 0.0) ? acc : 0.0;              // segmentor.cpp:106,137
@@ -1334,7 +1335,8 @@ __global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, f
     __syncthreads();
     const float pc2 = pc + pc;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x)
-        out[q] = fast ? wg_sample_term(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables) : wg_sample_term_plain(nm[q], nt[q], pc, pc2, &g_wg_tables);
+        out[q] = fast == 2 ? wg_sample_term_pcpos(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables)
+               : (fast == 1 ? wg_sample_term(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables) : wg_sample_term_plain(nm[q], nt[q], pc, pc2, &g_wg_tables));
 }
 
 // test hook: wg_div_f32 vs the compiler's IEEE division, both on the device

@@ -315,7 +315,7 @@ int report_bad_site(const wgbsseg_ctx* c, const JobStatus& st, char* err, size_t
     return WGBSSEG_E_METH_GT_COV;
 }
 
-template <int TI, bool FAST>
+template <int TI, int FAST>
 hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
     const int64_t padded = round_up(tiles, 8);
@@ -328,7 +328,7 @@ hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a,
     return hipGetLastError();
 }
 
-template <bool FAST>
+template <int FAST>
 hipError_t launch_cost_ti(int TI, const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
     if (TI == 64) return launch_cost<64, FAST>(v, sv, a, td, tiles, cost, lds, s);
@@ -455,7 +455,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     caB.split = 1; caB.TK = TKB; caB.KS = TKB + 1; caB.IS = 17; caB.NS = NSB;
     const size_t ldsA = (size_t)round_up((int64_t)lds_for(TI, false, WA, NSA), 16);
     const size_t ldsB = (size_t)round_up((int64_t)lds_for(16, true, 0, NSB), 16);
-    const bool fast_terms = P->pseudo_count == 0.0f || P->pseudo_count >= WG_FAST_MIN_PC;
+    const int term_mode = wg_term_mode(P->pseudo_count);
 
     // ---- stages: bound the scored-block buffer and overlap scoring (stream A) with the recurrence (stream B) --
     int n_stages = 1;
@@ -542,14 +542,16 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipEventRecord(c->ev_cost0[stg], c->sA));
         if (stage_tiles[2 * (size_t)stg] > 0) {
             const TileDesc* td = c->tilesA.as<TileDesc>() + tileA0[(size_t)stg];
-            hipError_t e = fast_terms ? launch_cost_ti<true>(TI, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
-                                      : launch_cost_ti<false>(TI, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA);
+            hipError_t e = term_mode == 2 ? launch_cost_ti<2>(TI, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
+                         : (term_mode == 1 ? launch_cost_ti<1>(TI, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
+                                           : launch_cost_ti<0>(TI, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA));
             HIP_TRY(e);
         }
         if (stage_tiles[2 * (size_t)stg + 1] > 0) {
             const TileDesc* td = c->tilesB.as<TileDesc>() + tileB0[(size_t)stg];
-            hipError_t e = fast_terms ? launch_cost_ti<true>(16, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
-                                      : launch_cost_ti<false>(16, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA);
+            hipError_t e = term_mode == 2 ? launch_cost_ti<2>(16, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
+                         : (term_mode == 1 ? launch_cost_ti<1>(16, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
+                                           : launch_cost_ti<0>(16, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA));
             HIP_TRY(e);
         }
         HIP_TRY(hipEventRecord(c->ev_cost1[stg], c->sA));
@@ -813,7 +815,7 @@ int wgbsseg_debug_sample_terms(wgbsseg_ctx* c, const float* nmeth, const float* 
     HIP_TRY(hipMemcpyAsync(c->dbg_a.p, nmeth, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
     HIP_TRY(hipMemcpyAsync(c->dbg_b.p, ntotal, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
     const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 8192);
-    const int fast = (pseudo_count == 0.0f || pseudo_count >= WG_FAST_MIN_PC) ? 1 : 0;     // the library's own dispatch rule
+    const int fast = wg_term_mode(pseudo_count);                                         // the library's own dispatch rule
     hipLaunchKernelGGL(k_debug_terms, dim3(blocks), dim3(256), 0, c->sA, c->dbg_a.as<float>(), c->dbg_b.as<float>(), count, pseudo_count, c->dbg_c.as<float>(), fast);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->dbg_c.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->sA));
