@@ -394,6 +394,24 @@ WG_HD float wg_sample_term_pcpos(float nmeth, float ntotal, float pc, float pc2,
     return res;
 }
 
+// The same without the zero-coverage exception, for callers that ADD the term to a running sum (the scoring kernel):
+// with ntotal == 0, p = 1/2, ll = 0 * log2f = -0.0, df = 0, s = -0.0 + 0 * L = -0.0, and adding -0.0 to the running
+// double sum leaves it unchanged, bit for bit — the reference's `continue` (:125) without a branch.
+WG_HD float wg_sample_term_pcpos_nz(float nmeth, float ntotal, float pc, float pc2, const wg_fast_tables* __restrict__ ft,
+                                    const wg_log_tables* __restrict__ xt)
+{
+    const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
+    const float ll = nmeth * wg_log2f_normal(p, ft->f_tab);        // :129-131
+    const float df = ntotal - nmeth;
+    const double x = 1.0 - (double)p;                              // :132-134
+    const double s = (double)ll + (double)df * wg_fast_log2(x, ft->d_fast);
+    const uint32_t tail = (uint32_t)wg_d2u(s) & 0x1fffffffu;
+    float res = (float)s;
+    if ((uint32_t)(tail - (0x10000000u - WG_GUARD_ULPS)) <= 2u * WG_GUARD_ULPS)
+        res = (float)((double)ll + (double)df * wg_log2(x, xt->d_tab, xt->d_tab2));
+    return res;
+}
+
 // term mode of a pseudo count: 0 plain exact form, 1 fast form with the guards, 2 fast form without them
 WG_HD int wg_term_mode(float pc) { return pc >= WG_POS_MIN_PC ? 2 : ((pc == 0.0f || pc >= WG_FAST_MIN_PC) ? 1 : 0); }
 WG_HD float wg_sample_term(float nmeth, float ntotal, float pc, float pc2, const wg_fast_tables* __restrict__ ft,

@@ -622,7 +622,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 const uint2 pk = Sp[(size_t)sl * Sstride];
                 const float nm = (float)(pi.x - pk.x);
                 const float nt = (float)(pi.y - pk.y);
-                const float ll = FAST == 2 ? wg_sample_term_pcpos(nm, nt, pc, pc2, tb, &g_wg_tables)
+                const float ll = FAST == 2 ? wg_sample_term_pcpos_nz(nm, nt, pc, pc2, tb, &g_wg_tables)
                                : (FAST == 1 ? wg_sample_term(nm, nt, pc, pc2, tb, &g_wg_tables) : wg_sample_term_plain(nm, nt, pc, pc2, &g_wg_tables));
                 acc += (double)ll;                                               // segmentor.cpp:135
             }
@@ -1334,9 +1334,18 @@ __global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, f
     wg_fast_tables_to_lds(&tb, threadIdx.x, blockDim.x);
     __syncthreads();
     const float pc2 = pc + pc;
+    if (fast == 2) {
+        // the guard-free form, with and without the zero-coverage exception: the two may differ only in the sign of a
+        // zero (ntotal == 0: +0 vs -0, the same contribution to a sum); anything else comes back as NaN
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x) {
+            const float a = wg_sample_term_pcpos(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables);
+            const float b = wg_sample_term_pcpos_nz(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables);
+            out[q] = (wg_f2u(a) == wg_f2u(b) || (a == 0.0f && b == 0.0f && nt[q] == 0.0f)) ? a : __builtin_nanf("");
+        }
+        return;
+    }
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x)
-        out[q] = fast == 2 ? wg_sample_term_pcpos(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables)
-               : (fast == 1 ? wg_sample_term(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables) : wg_sample_term_plain(nm[q], nt[q], pc, pc2, &g_wg_tables));
+        out[q] = fast == 1 ? wg_sample_term(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables) : wg_sample_term_plain(nm[q], nt[q], pc, pc2, &g_wg_tables);
 }
 
 // test hook: wg_div_f32 vs the compiler's IEEE division, both on the device
