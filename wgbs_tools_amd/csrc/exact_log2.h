@@ -306,11 +306,11 @@ WG_HD void wg_tables_finish(wg_log_tables* tb)
 WG_HD double wg_fast_log2(double x, const wg_d2* __restrict__ dfast)
 {
     const uint64_t ix = wg_d2u(x);
-    const uint64_t tmp = ix - 0x3fe6000000000000ull;
-    const uint32_t hi = (uint32_t)(tmp >> 32);
+    const uint32_t xhi = (uint32_t)(ix >> 32);
+    const uint32_t hi = xhi - 0x3fe60000u;                  // high word of ix - 0x3fe6000000000000 (the low word of the constant is 0)
     const uint32_t i = (hi >> 14) & 63u;
     const int32_t k = (int32_t)hi >> 20;
-    const uint64_t iz = ix - ((uint64_t)(hi & 0xfff00000u) << 32);
+    const uint64_t iz = ((uint64_t)(xhi - (hi & 0xfff00000u)) << 32) | (uint32_t)ix;      // only the high word changes
     const double invc = dfast[i].a, logc = dfast[i].b;
     const double r = WG_FMA_K(wg_u2d(iz), invc, -1.0);
     double q = WG_LOG2_A5;
