@@ -27,6 +27,7 @@
 #define WG_CARRY_G      (1 << WG_CARRY_SHIFT)   // a carry (chunk-relative exclusive prefix) is stored at every absolute site index
                                     // that is a multiple of 128 inside the chunk, plus (group 0) at the chunk start itself
 #define WG_BLOCK        256
+#define WG_WIN_TILE     1024        // sites per k_window workgroup
 #define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)
 #define WG_TRACE_WIN    32768       // back-pointers staged in LDS by k_trace (64 KiB)
 #define WG_TRACE_SEG    128         // speculative walks per window
@@ -215,41 +216,80 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
 // ------------------------------------------------------------------------------------------------------------
 // k_window: F_k = number of admissible ends of a block starting at site k:
 //   i admissible  <=>  k <= i < len,  i-k < max_cpg  and  loci[i]-loci[k] <= max_bp   (segmentor.cpp:111-117, loci ascending)
-// One thread per site (grid: 256-site tiles, `wtile_off` = exclusive prefix of tiles per chunk); k_window_scan then
+// Four sites per thread (grid: 1024-site tiles, `wtile_off` = exclusive prefix of tiles per chunk); k_window_scan then
 // turns F into the CSR row offsets, one workgroup per chunk.
 // ------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, const int64_t* __restrict__ wtile_off,
-                                                     uint32_t max_cpg, uint32_t max_bp)
+                                                     const int32_t* __restrict__ wtile_hint, uint32_t max_cpg, uint32_t max_bp, int lds_cap)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     const int nC = J.n_chunks;
     const int64_t t = blockIdx.x;
-    int clo = 0, chi = nC;                               // last chunk with wtile_off[c] <= t
+    // chunk of this tile = the last c with wtile_off[c] <= t.  The host hands over the answer for every 256th tile
+    // (wtile_hint), so the search runs over the chunks 256 tiles can span: one or two for 60,000-site chunks — a
+    // full binary search would put nine DEPENDENT L2 loads in front of every one of the 110 k tiles of hg19
+    int clo = wtile_hint[t >> 8], chi = wtile_hint[(t >> 8) + 1] + 1;
     while (chi - clo > 1) { const int mid = (clo + chi) >> 1; if (wtile_off[mid] <= t) clo = mid; else chi = mid; }
     const int c = clo;
     const ChunkDesc cd = J.chunks[c];
     const uint32_t* loc = J.loci + cd.start0;
-    const int k = (int)(t - wtile_off[c]) * WG_BLOCK + tid;
-    uint32_t w = 0;
-    bool disorder = false;
-    if (k < cd.len) {
-        const int64_t lk = loc[k];
-        if (k > 0 && (int64_t)loc[k - 1] > lk) disorder = true;
-        const int64_t limit = lk + (int64_t)max_bp;
-        int lo = k;                                       // loc[k] <= limit always
-        int hi = (int)((int64_t)k + max_cpg - 1 < cd.len - 1 ? (int64_t)k + max_cpg - 1 : cd.len - 1);
-        while (lo < hi) {                                 // last i in [k, hi] with loc[i] <= limit
-            const int mid = (lo + hi + 1) >> 1;
-            if ((int64_t)loc[mid] <= limit) lo = mid; else hi = mid - 1;
-        }
-        w = (uint32_t)(lo - k + 1);
-        J.W16[cd.site_off + k] = (uint16_t)w;
+    const int k0 = (int)(t - wtile_off[c]) * WG_WIN_TILE;
+    // the loci the tile's searches can touch, [k0, k0 + tile + max_cpg - 1), staged in LDS when they fit (lds_cap
+    // entries): the dependent probes of a search then cost LDS latency instead of L2 latency; every thread runs the
+    // searches of WG_WIN_TILE / 256 sites side by side, so the tile's fixed latencies are paid once per 1024 sites
+    extern __shared__ uint32_t sloc[];
+    const int64_t want = (int64_t)WG_WIN_TILE + max_cpg - 1;
+    const int span = (int)((int64_t)cd.len - k0 < want ? (int64_t)cd.len - k0 : want);
+    const bool staged = span <= lds_cap;
+    if (staged) {
+        for (int x = tid; x < span; x += WG_BLOCK) sloc[x] = loc[k0 + x];
+        __syncthreads();
     }
-    uint32_t um = w;                                      // largest window of each 16-site unit (tiles of 256 sites: aligned)
-    um = max(um, (uint32_t)__shfl_xor((int)um, 1)); um = max(um, (uint32_t)__shfl_xor((int)um, 2));
-    um = max(um, (uint32_t)__shfl_xor((int)um, 4)); um = max(um, (uint32_t)__shfl_xor((int)um, 8));
-    if ((lane & 15) == 0 && k < cd.len) J.umax16[cd.unit_off + (k >> 4)] = (uint16_t)um;
-    const uint32_t wmax = wg_wave_max_u32(w);
+    constexpr int NPT = WG_WIN_TILE / WG_BLOCK;
+    int lo[NPT], hi[NPT];
+    int64_t limit[NPT];
+    bool disorder = false;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        const int k = k0 + j * WG_BLOCK + tid;
+        lo[j] = k; hi[j] = k - 1; limit[j] = 0;
+        if (k < cd.len) {
+            const int64_t lk = staged ? sloc[k - k0] : loc[k];
+            const int64_t lprev = k > 0 ? ((staged && k > k0) ? sloc[k - 1 - k0] : loc[k - 1]) : lk;
+            if (lprev > lk) disorder = true;
+            limit[j] = lk + (int64_t)max_bp;
+            hi[j] = (int)((int64_t)k + max_cpg - 1 < cd.len - 1 ? (int64_t)k + max_cpg - 1 : cd.len - 1);
+        }
+    }
+    bool more = true;
+    while (more) {                                        // last i in [k, hi] with loc[i] <= limit (loc[k] <= limit always)
+        more = false;
+#pragma unroll
+        for (int j = 0; j < NPT; j++) {
+            if (lo[j] < hi[j]) {
+                const int mid = (lo[j] + hi[j] + 1) >> 1;
+                const int64_t lm = staged ? sloc[mid - k0] : loc[mid];
+                if (lm <= limit[j]) lo[j] = mid; else hi[j] = mid - 1;
+                more = more || lo[j] < hi[j];
+            }
+        }
+    }
+    uint32_t wmax_t = 0;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        const int k = k0 + j * WG_BLOCK + tid;
+        uint32_t w = 0;
+        if (k < cd.len) {
+            w = (uint32_t)(lo[j] - k + 1);
+            J.W16[cd.site_off + k] = (uint16_t)w;
+        }
+        uint32_t um = w;                                  // largest window of each 16-site unit (16 consecutive lanes)
+        um = max(um, (uint32_t)__shfl_xor((int)um, 1)); um = max(um, (uint32_t)__shfl_xor((int)um, 2));
+        um = max(um, (uint32_t)__shfl_xor((int)um, 4)); um = max(um, (uint32_t)__shfl_xor((int)um, 8));
+        if ((lane & 15) == 0 && k < cd.len) J.umax16[cd.unit_off + (k >> 4)] = (uint16_t)um;
+        wmax_t = max(wmax_t, w);
+    }
+    const uint32_t wmax = wg_wave_max_u32(wmax_t);
     const bool any_dis = __any(disorder);
     if (lane == 0) {
         // hundreds of thousands of wavefronts: touch the shared word only when it would change

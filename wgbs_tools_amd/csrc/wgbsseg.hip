@@ -244,8 +244,8 @@ namespace {
 // Host copy of the chunk table + job-wide offsets; uploads it and builds the JobView.
 struct Job {
     std::vector<ChunkDesc> h;
-    std::vector<int64_t> wtile_off;     // exclusive prefix of 256-site tiles per chunk (+ total)
-    int64_t sites = 0, carry_entries = 0, units = 0;
+    std::vector<int64_t> wtile_off;     // exclusive prefix of 256-site tiles per chunk (+ total), then (as int32 pairs) the chunk of every 256th tile
+    int64_t sites = 0, carry_entries = 0, units = 0, n_hint = 0;
     int32_t max_len = 0;
     JobStatus st0;          // source of an async H2D copy: must outlive the call's stream work
     JobView v = {};
@@ -270,21 +270,33 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
         ChunkDesc& d = job.h[(size_t)i];
         d.start0 = start0[i]; d.len = len[i]; d.site_off = so; d.carry_off = co; d.unit_off = uo; d.nG = (int32_t)(((start0[i] + len[i] - 1) >> WG_CARRY_SHIFT) - (start0[i] >> WG_CARRY_SHIFT) + 1);
         job.wtile_off[(size_t)i] = wt;
-        wt += (len[i] + WG_BLOCK - 1) / WG_BLOCK;
+        wt += (len[i] + WG_WIN_TILE - 1) / WG_WIN_TILE;
         so += len[i];
         uo += (len[i] + 15) / 16;
         co += (int64_t)d.nG * c->n_samples;
         job.max_len = std::max(job.max_len, len[i]);
     }
     job.wtile_off[(size_t)n_chunks] = wt;
+    {   // hint table for k_window: chunk of tile 256*h, for h = 0 .. tiles/256 + 1 (int32, packed behind the prefix)
+        const int64_t nh = (wt >> 8) + 2;
+        job.n_hint = nh;
+        job.wtile_off.resize((size_t)n_chunks + 1 + (size_t)((nh + 1) / 2));
+        int32_t* hint = reinterpret_cast<int32_t*>(job.wtile_off.data() + n_chunks + 1);
+        int64_t cix = 0;
+        for (int64_t h = 0; h < nh; h++) {
+            const int64_t tile = h << 8;
+            while (cix + 1 < n_chunks && job.wtile_off[(size_t)cix + 1] <= tile) cix++;
+            hint[h] = (int32_t)cix;
+        }
+    }
     job.sites = so; job.carry_entries = co; job.units = uo;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(c->chunks.ensure(sizeof(ChunkDesc) * (size_t)n_chunks));
     HIP_TRY(c->carry.ensure(sizeof(uint2) * (size_t)co));
     HIP_TRY(c->status.ensure(sizeof(JobStatus)));
     HIP_TRY(hipMemcpyAsync(c->chunks.p, job.h.data(), sizeof(ChunkDesc) * (size_t)n_chunks, hipMemcpyHostToDevice, c->sA));
-    HIP_TRY(c->wtile.ensure(8 * ((size_t)n_chunks + 1)));
-    HIP_TRY(hipMemcpyAsync(c->wtile.p, job.wtile_off.data(), 8 * ((size_t)n_chunks + 1), hipMemcpyHostToDevice, c->sA));
+    HIP_TRY(c->wtile.ensure(8 * job.wtile_off.size()));
+    HIP_TRY(hipMemcpyAsync(c->wtile.p, job.wtile_off.data(), 8 * job.wtile_off.size(), hipMemcpyHostToDevice, c->sA));
     memset(&job.st0, 0, sizeof(job.st0));
     job.st0.first_bad = ~0ULL;
     HIP_TRY(hipMemcpyAsync(c->status.p, &job.st0, sizeof(job.st0), hipMemcpyHostToDevice, c->sA));
@@ -383,8 +395,11 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     if (rc != WGBSSEG_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
     if (job.wtile_off[(size_t)nC] > 0x7fffffff) { set_err(err, errlen, "too many sites in one call"); return WGBSSEG_E_ARG; }
-    hipLaunchKernelGGL(k_window, dim3((unsigned)job.wtile_off[(size_t)nC]), dim3(WG_BLOCK), 0, c->sA, v, c->status.as<JobStatus>(),
-                       c->wtile.as<int64_t>(), P->max_cpg, P->max_bp);
+    // loci of a 1024-site tile and of everything its windows can reach, in LDS (<= 48 KB; deeper windows search in L2)
+    const int win_cap = (int)std::min<int64_t>((int64_t)WG_WIN_TILE + P->max_cpg - 1, 12288);
+    const int win_lds = ((int64_t)WG_WIN_TILE + P->max_cpg - 1 <= 12288) ? win_cap : 0;
+    hipLaunchKernelGGL(k_window, dim3((unsigned)job.wtile_off[(size_t)nC]), dim3(WG_BLOCK), (size_t)win_lds * 4, c->sA, v, c->status.as<JobStatus>(),
+                       c->wtile.as<int64_t>(), reinterpret_cast<const int32_t*>(c->wtile.as<int64_t>() + nC + 1), P->max_cpg, P->max_bp, win_lds);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_window_scan, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, c->status.as<JobStatus>());
     HIP_TRY(hipGetLastError());
