@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""HBM traffic of the dominant k_scan launch from the PMC counters, the way MI355X_MICROARCH.md prescribes: FETCH_SIZE
+and WRITE_SIZE in SEPARATE rocprofv3 passes (with --kernel-trace only), units KB = 1024 B, FETCH_SIZE doubled on gfx950
+for wide coalesced streaming reads.  Runs on the GPU box; writes gpurun_out/scan_traffic.json (copy it to profiles/).
+
+    cd /tmp && TMPDIR=/tmp python $REPO/tools/pmc_scan_traffic.py
+"""
+import csv
+import glob
+import json
+import os
+import os.path as op
+import subprocess
+import sys
+
+ROOT = op.dirname(op.dirname(op.abspath(__file__)))
+OUT = op.join(ROOT, 'gpurun_out')
+
+
+def one_pass(counter):
+    d = op.join(OUT, 'pmc_' + counter)
+    cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
+           sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0']
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'))
+    best = None
+    for f in glob.glob(op.join(d, '**', '*counter_collection.csv'), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get('Counter_Name') != counter or not row.get('Kernel_Name', '').startswith('k_scan'):
+                    continue
+                grid = int(row['Grid_Size'])
+                val = float(row['Counter_Value'])
+                if best is None or grid > best[0]:
+                    best = (grid, val)
+    assert best, 'no k_scan dispatch with ' + counter
+    return best
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    gf, fetch = one_pass('FETCH_SIZE')
+    gw, write = one_pass('WRITE_SIZE')
+    assert gf == gw
+    n_sites, n_samples = 28217448, 32
+    alg = 2 * n_samples * (n_sites + 1832 * 100 + 0)        # chunks + the upfront patches of the main batch (approx.; bench.py reports the exact figure)
+    rec = {'kernel': 'k_scan', 'workload': 'hg19-shaped 28217448 CpGs x 32 betas, main batch (483 chunks + upfront patches)',
+           'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), gfx950, ROCm 7.2; largest k_scan dispatch of `python bench.py --steps 1 --warmup 0 --cpu-seconds 0`',
+           'grid_size': gf, 'FETCH_SIZE_KB': fetch, 'WRITE_SIZE_KB': write,
+           'correction': 'MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane) -> doubled; WRITE_SIZE taken as is; units KB = 1024 B',
+           'read_bytes': 2 * fetch * 1024, 'write_bytes': write * 1024, 'traffic_bytes': 2 * fetch * 1024 + write * 1024}
+    json.dump(rec, open(op.join(OUT, 'scan_traffic.json'), 'w'), indent=1)
+    print(json.dumps(rec))
+
+
+if __name__ == '__main__':
+    main()
