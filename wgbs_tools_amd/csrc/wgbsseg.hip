@@ -97,6 +97,7 @@ struct wgbsseg_ctx {
     DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders, dbg_a, dbg_b, dbg_c;
     // events
     hipEvent_t ev[8] = {};
+    PinnedBuf h_status;      // page-locked landing area of the status words: D2H copies that really are asynchronous
     std::vector<hipEvent_t> ev_cost0, ev_cost1, ev_dp0, ev_dp1;
     // last-call info
     wgbsseg_timings tim = {};
@@ -179,6 +180,7 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
                      &c->dbg_a, &c->dbg_b, &c->dbg_c};
     for (auto* b : all) b->release();
     for (auto& pb : c->pinned) pb.release();
+    c->h_status.release();
     for (auto& v : c->ev) if (v) (void)hipEventDestroy(v);
     for (auto* vec : {&c->ev_cost0, &c->ev_cost1, &c->ev_dp0, &c->ev_dp1}) for (auto v : *vec) (void)hipEventDestroy(v);
     if (c->sA) (void)hipStreamDestroy(c->sA);
@@ -389,11 +391,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     v.W16 = c->W16.as<uint16_t>(); v.cum32 = c->cum32.as<uint32_t>(); v.back16 = c->back16.as<uint16_t>();
     v.chunk_pairs = c->chunk_pairs.as<int64_t>(); v.umax16 = c->umax16.as<uint16_t>();
 
-    // ---- scan + validate, window extents -------------------------------------------------------------------
+    // ---- window extents, then scan + validate ----------------------------------------------------------------
+    // The host needs the window statistics to plan the scoring tiles; the windows go first so that this round trip
+    // hides behind the scan pass (whose own verdict, meth > cov, is read with the plan totals further down).
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
-    rc = launch_scan(c, job, err, errlen);
-    if (rc != WGBSSEG_OK) return rc;
-    HIP_TRY(hipEventRecord(c->ev[1], c->sA));
     if (job.wtile_off[(size_t)nC] > 0x7fffffff) { set_err(err, errlen, "too many sites in one call"); return WGBSSEG_E_ARG; }
     // loci of a 1024-site tile and of everything its windows can reach, in LDS (<= 48 KB; deeper windows search in L2)
     const int win_cap = (int)std::min<int64_t>((int64_t)WG_WIN_TILE + P->max_cpg - 1, 12288);
@@ -403,13 +404,24 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_window_scan, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, c->status.as<JobStatus>());
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[1], c->sA));
+    if (!c->h_status.ensure(4 * sizeof(JobStatus))) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
+    JobStatus* hst = reinterpret_cast<JobStatus*>(c->h_status.p);
+    HIP_TRY(hipMemcpyAsync(&hst[0], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipEventRecord(c->ev[7], c->sA));
+    rc = launch_scan(c, job, err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], c->sA));
-    JobStatus st;
-    HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, c->sA));
-    HIP_TRY(hipStreamSynchronize(c->sA));
-    if (st.first_bad != ~0ULL) return report_bad_site(c, st, err, errlen);
-    if (st.loci_disorder) { set_err(err, errlen, "loci are not ascending inside chunk %u (a chunk must not cross chromosomes)", st.loci_disorder - 1); return WGBSSEG_E_LOCI_ORDER; }
-    if (st.overflow) { set_err(err, errlen, "a chunk scores more than 2^32 blocks; use a smaller chunk_size"); return WGBSSEG_E_ARG; }
+    HIP_TRY(hipEventSynchronize(c->ev[7]));                    // window statistics are here; the scan is still running
+    const JobStatus st = hst[0];
+    if (st.loci_disorder || st.overflow) {
+        JobStatus st2;                                        // the scan's verdict takes precedence, as it always has
+        HIP_TRY(hipMemcpyAsync(&st2, c->status.p, sizeof(st2), hipMemcpyDeviceToHost, c->sA));
+        HIP_TRY(hipStreamSynchronize(c->sA));
+        if (st2.first_bad != ~0ULL) return report_bad_site(c, st2, err, errlen);
+        if (st.loci_disorder) { set_err(err, errlen, "loci are not ascending inside chunk %u (a chunk must not cross chromosomes)", st.loci_disorder - 1); return WGBSSEG_E_LOCI_ORDER; }
+        set_err(err, errlen, "a chunk scores more than 2^32 blocks; use a smaller chunk_size"); return WGBSSEG_E_ARG;
+    }
     const int Wmax = (int)st.max_window;
     const int64_t total_pairs = (int64_t)st.total_pairs;
 
@@ -505,7 +517,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     std::vector<int64_t> stage_pairs((size_t)n_stages), stage_tiles((size_t)n_stages * 2);
     HIP_TRY(hipMemcpyAsync(stage_pairs.data(), c->plan_pairs.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipMemcpyAsync(stage_tiles.data(), c->plan_tiles.p, (size_t)n_stages * 16, hipMemcpyDeviceToHost, c->sA));
+    JobStatus st_scan;
+    HIP_TRY(hipMemcpyAsync(&st_scan, c->status.p, sizeof(st_scan), hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
+    if (st_scan.first_bad != ~0ULL) return report_bad_site(c, st_scan, err, errlen);
     std::vector<int64_t> tileA0((size_t)n_stages + 1, 0), tileB0((size_t)n_stages + 1, 0);
     for (int stg = 0; stg < n_stages; stg++) {
         tileA0[(size_t)stg + 1] = tileA0[(size_t)stg] + stage_tiles[2 * (size_t)stg];
@@ -602,9 +617,9 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     wgbsseg_timings& T = c->tim;
     if (!c->accumulate) memset(&T, 0, sizeof(T));
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); T.scan_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[7], c->ev[2])); T.scan_ms += ms;
     if (2 * J * c->n_samples > T.scan_main_bytes) { T.scan_main_bytes = 2 * J * c->n_samples; T.scan_main_ms = ms; }
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[1], c->ev[2])); T.window_ms += ms;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); T.window_ms += ms;
     for (int stg = 0; stg < n_stages; stg++) {
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_cost0[stg], c->ev_cost1[stg])); T.cost_ms += ms;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_dp0[stg], c->ev_dp1[stg])); T.dp_ms += ms;
