@@ -959,35 +959,61 @@ __device__ __forceinline__ void wg_dp_wide_batch32(double& best, int32_t& arg, d
 }
 
 // The same step for a job whose windows are all <= 64 sites, with the lane of the step known at compile time (64-step
-// batches start at lane 0): lane selects and the source mark become inline constants.  `arg` holds the LANE of the
-// best source (a source is at most 63 steps back, so (STP - arg) mod 64 is the distance), the finished lane is
-// re-armed with -inf by two v_writelane, and the source's lane goes to its lane of tbk by a third (turned into the
-// block length once per batch).  10 VALU and no scalar arithmetic per step:
-//   v_add_f64  v_cmp_gt_f64  v_max_f64  v_cndmask  3 x v_readlane  3 x v_writelane
-template <int STP>
-__device__ __forceinline__ void wg_dp_step64(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double cv, const uint32_t ninf_hi)
-{
-    const double cand = Mk + cv;
-    const bool upd = cand > best;                      // strict: the first maximum wins (segmentor.cpp:148)
-    double nbest;
-    asm("v_max_f64 %0, %1, %2" : "=v"(nbest) : "v"(best), "v"(cand));
-    Mk = wg_readlane_f64(nbest, STP);                  // M[k+1]
-    arg = upd ? STP : arg;
-    const int ak = __builtin_amdgcn_readlane(arg, STP);
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(tbk) : "s"(ak), "n"(STP));            // lane of the best source; decoded per batch
-    uint32_t lo = (uint32_t)__double_as_longlong(nbest), hi = (uint32_t)(__double_as_longlong(nbest) >> 32);
-    asm("v_writelane_b32 %0, 0, %1" : "+v"(lo) : "n"(STP));
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(ninf_hi), "n"(STP));
-    best = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
+// batches start at lane 0): lane selects and the source mark are inline constants.  `arg` holds the LANE of the best
+// source (a source is at most 63 steps back, so (STP - arg) mod 64 is the distance), the finished lane is re-armed
+// with -inf by two v_writelane, and the source's lane goes to its lane of tbk by a third (turned into the block
+// length once per batch).  10 VALU and no scalar arithmetic per step:
+//     A  v_add_f64   cand = M[k] + row            C  v_cmp_gt_f64  upd = cand > best  (strict: first maximum, :148)
+//     X  v_max_f64   best = max(best, cand)       D  v_cndmask     arg  = upd ? STP : arg
+//     R  2 x v_readlane  M[k+1] = best[STP]       W  2 x v_writelane  best[STP] = -inf
+//     K  v_readlane  ak = arg[STP]                T  v_writelane   tbk[STP] = ak
+// Eight steps are one hand-scheduled asm block on fixed registers (best v[2:3], arg v4, tbk v5, cand v[6:7], M s[20:21],
+// ak s22, the high word of -inf s23; the eight rows in v[8:23] or v[24:39], alternating between groups so that the
+// next group's LDS reads land while this one runs).  Order per step: A C T(prev) X D Rlo Rhi Wlo Whi K — the chain
+// A -> X -> R -> A(next) has independent instructions between its links, and the gfx940-family wait-state rules hold
+// without a single s_nop inside: VALU-written VGPR -> v_readlane of it >= 1 instruction apart (X,D,R / D..K), VALU-written
+// SGPR -> VALU reading it >= 2 apart (R..W,W,K..A / K,A,C,T).  A stand-alone wave issues this sequence in 18 ns per step
+// (tools/micro/dp_chain.hip).
+#define WG_DP64_STEP(CV, P, TPREV)                      \
+    "v_add_f64 v[6:7], s[20:21], " CV "\n"              \
+    "v_cmp_gt_f64 vcc, v[6:7], v[2:3]\n"                \
+    TPREV                                               \
+    "v_max_f64 v[2:3], v[2:3], v[6:7]\n"                \
+    "v_cndmask_b32_e64 v4, v4, %[" P "], vcc\n"         \
+    "v_readlane_b32 s20, v2, %[" P "]\n"                \
+    "v_readlane_b32 s21, v3, %[" P "]\n"                \
+    "v_writelane_b32 v2, 0, %[" P "]\n"                 \
+    "v_writelane_b32 v3, s23, %[" P "]\n"               \
+    "v_readlane_b32 s22, v4, %[" P "]\n"
+#define WG_DP64_T(P) "v_writelane_b32 v5, s22, %[" P "]\n"
 
-template <int G>
+template <int G, int SET>
 __device__ __forceinline__ void wg_dp_group64(double& best, int32_t& arg, uint32_t& tbk, double& Mk, const double (&cur)[8], const uint32_t ninf_hi)
 {
-    wg_dp_step64<G + 0>(best, arg, tbk, Mk, cur[0], ninf_hi); wg_dp_step64<G + 1>(best, arg, tbk, Mk, cur[1], ninf_hi);
-    wg_dp_step64<G + 2>(best, arg, tbk, Mk, cur[2], ninf_hi); wg_dp_step64<G + 3>(best, arg, tbk, Mk, cur[3], ninf_hi);
-    wg_dp_step64<G + 4>(best, arg, tbk, Mk, cur[4], ninf_hi); wg_dp_step64<G + 5>(best, arg, tbk, Mk, cur[5], ninf_hi);
-    wg_dp_step64<G + 6>(best, arg, tbk, Mk, cur[6], ninf_hi); wg_dp_step64<G + 7>(best, arg, tbk, Mk, cur[7], ninf_hi);
+    if (SET == 0)
+        asm volatile(
+            WG_DP64_STEP("v[8:9]", "p0", "")             WG_DP64_STEP("v[10:11]", "p1", WG_DP64_T("p0"))
+            WG_DP64_STEP("v[12:13]", "p2", WG_DP64_T("p1")) WG_DP64_STEP("v[14:15]", "p3", WG_DP64_T("p2"))
+            WG_DP64_STEP("v[16:17]", "p4", WG_DP64_T("p3")) WG_DP64_STEP("v[18:19]", "p5", WG_DP64_T("p4"))
+            WG_DP64_STEP("v[20:21]", "p6", WG_DP64_T("p5")) WG_DP64_STEP("v[22:23]", "p7", WG_DP64_T("p6"))
+            "s_nop 1\n" WG_DP64_T("p7")
+            : "+{v[2:3]}"(best), "+{v4}"(arg), "+{v5}"(tbk), "+{s[20:21]}"(Mk)
+            : "{v[8:9]}"(cur[0]), "{v[10:11]}"(cur[1]), "{v[12:13]}"(cur[2]), "{v[14:15]}"(cur[3]),
+              "{v[16:17]}"(cur[4]), "{v[18:19]}"(cur[5]), "{v[20:21]}"(cur[6]), "{v[22:23]}"(cur[7]), "{s23}"(ninf_hi),
+              [p0] "n"(G + 0), [p1] "n"(G + 1), [p2] "n"(G + 2), [p3] "n"(G + 3), [p4] "n"(G + 4), [p5] "n"(G + 5), [p6] "n"(G + 6), [p7] "n"(G + 7)
+            : "v6", "v7", "s22", "vcc");
+    else
+        asm volatile(
+            WG_DP64_STEP("v[24:25]", "p0", "")             WG_DP64_STEP("v[26:27]", "p1", WG_DP64_T("p0"))
+            WG_DP64_STEP("v[28:29]", "p2", WG_DP64_T("p1")) WG_DP64_STEP("v[30:31]", "p3", WG_DP64_T("p2"))
+            WG_DP64_STEP("v[32:33]", "p4", WG_DP64_T("p3")) WG_DP64_STEP("v[34:35]", "p5", WG_DP64_T("p4"))
+            WG_DP64_STEP("v[36:37]", "p6", WG_DP64_T("p5")) WG_DP64_STEP("v[38:39]", "p7", WG_DP64_T("p6"))
+            "s_nop 1\n" WG_DP64_T("p7")
+            : "+{v[2:3]}"(best), "+{v4}"(arg), "+{v5}"(tbk), "+{s[20:21]}"(Mk)
+            : "{v[24:25]}"(cur[0]), "{v[26:27]}"(cur[1]), "{v[28:29]}"(cur[2]), "{v[30:31]}"(cur[3]),
+              "{v[32:33]}"(cur[4]), "{v[34:35]}"(cur[5]), "{v[36:37]}"(cur[6]), "{v[38:39]}"(cur[7]), "{s23}"(ninf_hi),
+              [p0] "n"(G + 0), [p1] "n"(G + 1), [p2] "n"(G + 2), [p3] "n"(G + 3), [p4] "n"(G + 4), [p5] "n"(G + 5), [p6] "n"(G + 6), [p7] "n"(G + 7)
+            : "v6", "v7", "s22", "vcc");
 }
 
 // state kept per chunk in global memory: [0] M[k] of the next step, [1..64] best, [65..128] arg, [129..192] bestB,
@@ -1126,20 +1152,22 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
             const double* my = slot + lane;
             if (!wideb) {
                 // ---- no block of the batch is longer than 64 sites: BL steps, 8 at a time, next 8 rows in flight ----
-                double cur[8], nxt[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) cur[u] = my[u * 64];
                 if (!WIDEJOB) {
                     const uint32_t ninf_hi = 0xfff00000u;
-#define WG_DP_GROUP64(G)                                                                             \
-                    if ((G) + 8 < 64) {                                                              \
-                        _Pragma("unroll") for (int u = 0; u < 8; u++) nxt[u] = my[((G) + 8 + u) * 64]; \
-                    }                                                                                \
-                    wg_dp_group64<(G)>(best, arg, tbk, Mk, cur, ninf_hi);                            \
-                    _Pragma("unroll") for (int u = 0; u < 8; u++) cur[u] = nxt[u];
-                    WG_DP_GROUP64(0) WG_DP_GROUP64(8) WG_DP_GROUP64(16) WG_DP_GROUP64(24)
-                    WG_DP_GROUP64(32) WG_DP_GROUP64(40) WG_DP_GROUP64(48) WG_DP_GROUP64(56)
-#undef WG_DP_GROUP64
+                    double Ms = wg_readlane_f64(Mk, 0);   // M[k] is wave-uniform: the asm blocks want it in scalar registers
+                    double ra[8], rb[8];                  // the rows of two consecutive groups of 8 steps (register sets 0 and 1)
+#pragma unroll
+                    for (int u = 0; u < 8; u++) ra[u] = my[u * 64];
+#define WG_DP_PAIR64(G)                                                                                   \
+                    _Pragma("unroll") for (int u = 0; u < 8; u++) rb[u] = my[((G) + 8 + u) * 64];         \
+                    wg_dp_group64<(G), 0>(best, arg, tbk, Ms, ra, ninf_hi);                               \
+                    if ((G) + 16 < 64) {                                                                  \
+                        _Pragma("unroll") for (int u = 0; u < 8; u++) ra[u] = my[((G) + 16 + u) * 64];    \
+                    }                                                                                     \
+                    wg_dp_group64<(G) + 8, 1>(best, arg, tbk, Ms, rb, ninf_hi);
+                    WG_DP_PAIR64(0) WG_DP_PAIR64(16) WG_DP_PAIR64(32) WG_DP_PAIR64(48)
+#undef WG_DP_PAIR64
+                    Mk = Ms;
                     tbk = (((uint32_t)lane - tbk) & 63u) + 1u;        // source lane -> length of the best block ending here
                 } else if (stp0 == 0) {
                     wg_dp_batch32<0>(best, arg, tbk, Mk, my, base, lane, bestB, argB);
