@@ -453,7 +453,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
                 if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
                 const size_t l = lds_for(ti, false, WA, ns);
                 if (l > 64 * 1024) continue;
-                const int wgs = (int)std::min<size_t>(6, (160 * 1024) / l);          // 6 waves/SIMD is the register limit
+                const int wgs = (int)std::min<size_t>(4, (160 * 1024) / l);          // 4 workgroups = 4 waves/SIMD already saturate the VALU (measured: TI 64 at 4 beats TI 32 at 6 by 4 %)
                 const double q = ti * std::min<double>(Favg, WA), eff = q / (256.0 * std::ceil(q / 256.0));
                 const double groups = std::ceil((double)Nsmp / ns);
                 const double score = wgs * eff / (1.0 + 0.02 * (groups - 1)) * (1.0 + 0.04 * (ti / 16));   // bias to big tiles (less staging)
