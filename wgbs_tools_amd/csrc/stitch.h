@@ -46,19 +46,48 @@ struct Rope {
         if (pos) *pos = e - r.p;
         return true;
     }
-    // keep everything up to and including value x (x must be present)
+    // The same question for a value expected within a few dozen entries of the rope's END / START (a junction's
+    // neighbourhood): walk in from that end, so that only the cache lines next to the junction are touched — the
+    // border arrays have just arrived by DMA and a binary search would take a cold miss at almost every probe.
+    bool contains_near_back(int64_t x, size_t* run_idx = nullptr, int64_t* pos = nullptr) const
+    {
+        int budget = 96;
+        for (size_t ri = runs.size(); ri-- > 0 && budget > 0;) {
+            const Run& r = runs[ri];
+            const int64_t xr = x - r.add;
+            for (int64_t q = r.n - 1; q >= 0 && budget > 0; q--, budget--) {
+                if ((int64_t)r.p[q] == xr) { if (run_idx) *run_idx = ri; if (pos) *pos = q; return true; }
+                if ((int64_t)r.p[q] < xr) return false;
+            }
+        }
+        return budget > 0 ? false : contains(x, run_idx, pos);
+    }
+    bool contains_near_front(int64_t x, size_t* run_idx = nullptr, int64_t* pos = nullptr) const
+    {
+        int budget = 96;
+        for (size_t ri = 0; ri < runs.size() && budget > 0; ri++) {
+            const Run& r = runs[ri];
+            const int64_t xr = x - r.add;
+            for (int64_t q = 0; q < r.n && budget > 0; q++, budget--) {
+                if ((int64_t)r.p[q] == xr) { if (run_idx) *run_idx = ri; if (pos) *pos = q; return true; }
+                if ((int64_t)r.p[q] > xr) return false;
+            }
+        }
+        return budget > 0 ? false : contains(x, run_idx, pos);
+    }
+    // keep everything up to and including value x (x must be present; it lies near the end)
     void truncate_after(int64_t x)
     {
         size_t ri = 0; int64_t pos = 0;
-        contains(x, &ri, &pos);
+        contains_near_back(x, &ri, &pos);
         runs.resize(ri + 1);
         runs[ri].n = pos + 1;
     }
-    // append the elements of `o` that are > x (x must be present in o)
+    // append the elements of `o` that are > x (x must be present in o; it lies near o's start)
     void append_after(const Rope& o, int64_t x)
     {
         size_t ri = 0; int64_t pos = 0;
-        o.contains(x, &ri, &pos);
+        o.contains_near_front(x, &ri, &pos);
         if (pos + 1 < o.runs[ri].n) runs.push_back(Run{o.runs[ri].p + pos + 1, o.runs[ri].n - pos - 1, o.runs[ri].add});
         for (size_t q = ri + 1; q < o.runs.size(); q++) runs.push_back(o.runs[q]);
     }
@@ -104,8 +133,8 @@ struct Stitch {
         // is_2_overlap(b1, patch) / (patch, b2): a common value exists (segment.py:235-240)
         int64_t x1 = 0, x2 = 0;
         bool o1 = false, o2 = false;
-        for (int64_t q = 0; q < np && !o1; q++) if (b1.contains(patch[q] + add)) { o1 = true; x1 = patch[q] + add; }   // smallest common value
-        for (int64_t q = 0; q < np && !o2; q++) if (b2.contains(patch[q] + add)) { o2 = true; x2 = patch[q] + add; }
+        for (int64_t q = 0; q < np && !o1; q++) if (b1.contains_near_back(patch[q] + add)) { o1 = true; x1 = patch[q] + add; }   // smallest common value
+        for (int64_t q = 0; q < np && !o2; q++) if (b2.contains_near_front(patch[q] + add)) { o2 = true; x2 = patch[q] + add; }
         if (o1 && o2) {
             // merge2(merge2(b1, patch), b2) (segment.py:221,243-246):
             //   m = b1[.. x1] + patch[> x1];   the first element of m that occurs in b2 is the junction value itself
@@ -176,6 +205,10 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     typedef std::chrono::steady_clock Clock;
     const Clock::time_point t_begin = Clock::now();
     int64_t us_batches = 0;
+    const bool prof = getenv("WGBSSEG_PROFILE_STITCH") != nullptr;
+    std::vector<std::pair<const char*, Clock::time_point>> marks;
+    auto mark = [&](const char* what) { if (prof) marks.emplace_back(what, Clock::now()); };
+    mark("begin");
     auto timed_batch = [&](const std::vector<Sites>& todo, BatchResult& res) -> int {
         const Clock::time_point t0 = Clock::now();
         const int r = run_batch(todo, res, err);
@@ -202,9 +235,11 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     int64_t n_batches = 0, n_patch_dp = 0;
     std::vector<std::unique_ptr<BatchResult>> keep;
 
+    mark("grid + patch list");
     keep.emplace_back(new BatchResult());
     BatchResult& first = *keep.back();
     int rc = timed_batch(items, first);
+    mark("first batch");
     const int64_t us_first = us_batches;
     if (rc != 0) return rc;
     n_batches++;
@@ -267,6 +302,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
         for (size_t i = 0; i < st.size(); i++) lists[(size_t)owner[i]].push_back(std::move(st[i].result));
         for (int64_t r = 0; r < n_regions; r++) if (has_left[(size_t)r]) lists[(size_t)r].push_back(std::move(leftover[(size_t)r]));
     }
+    mark("stitching (incl. follow-up batches)");
     // ---- flatten --------------------------------------------------------------------------------------------------
     int64_t total = 0;
     for (int64_t r = 0; r < n_regions; r++) { borders_off[r] = total; total += lists[(size_t)r][0].size(); }
@@ -283,6 +319,12 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                 th.emplace_back([&]() { for (int64_t r; (r = next.fetch_add(1)) < n_regions;) lists[(size_t)r][0].flatten(borders_out + borders_off[r]); });
             for (auto& x : th) x.join();
         }
+    }
+    mark("flatten");
+    if (prof) {
+        for (size_t i = 1; i < marks.size(); i++)
+            fprintf(stderr, "[stitch] %-38s %8.1f us\n", marks[i].first, std::chrono::duration<double, std::micro>(marks[i].second - marks[i - 1].second).count());
+        fprintf(stderr, "[stitch] of which device batches %lld us (first %lld)\n", (long long)us_batches, (long long)us_first);
     }
     if (stats) {
         stats[0] = n_chunks; stats[1] = n_patch_dp; stats[2] = n_batches; stats[3] = (int64_t)patches.size();
