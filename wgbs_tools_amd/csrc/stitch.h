@@ -186,6 +186,24 @@ inline void upfront_patches(int64_t start, const std::vector<int64_t>& lens, boo
     }
 }
 
+// The junctions of the same tree, each with the two chunks that touch it and the spans of its operands.
+struct Junction { int64_t left_item, right_item, n1, n2; };
+inline void junctions_of_region(const std::vector<int64_t>& lens, int64_t first_item, std::vector<Junction>& out)
+{
+    struct Seg { int64_t len, lo, hi; };                       // items [lo, hi]
+    std::vector<Seg> segs;
+    for (size_t i = 0; i < lens.size(); i++) segs.push_back({lens[i], first_item + (int64_t)i, first_item + (int64_t)i});
+    while (segs.size() > 1) {
+        std::vector<Seg> nxt;
+        for (size_t i = 1; i < segs.size(); i += 2) {
+            out.push_back({segs[i - 1].hi, segs[i].lo, segs[i - 1].len, segs[i].len});
+            nxt.push_back({segs[i - 1].len + segs[i].len, segs[i - 1].lo, segs[i].hi});
+        }
+        if (segs.size() % 2) nxt.push_back(segs.back());
+        segs.swap(nxt);
+    }
+}
+
 typedef std::pair<int64_t, int64_t> Sites;                     // 1-based [start, end)
 // Result of one batch of chunk DPs: CSR of int32 borders RELATIVE to each item's start (first 0, last end-start).
 struct BatchResult {
@@ -219,6 +237,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     std::vector<Sites> items;                                  // chunks first, then patches
     std::vector<int64_t> region_first_chunk((size_t)n_regions + 1);
     std::vector<Sites> patches;
+    std::vector<Junction> junctions;
     for (int64_t r = 0; r < n_regions; r++) {
         const int64_t a = region_start[r], b = region_end[r];
         if (a < 1 || b <= a || b > 0x7fffffff) { err = "region " + std::to_string(r) + " is empty, starts before site 1 or ends beyond 2^31"; return E_ARG; }
@@ -226,6 +245,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
         std::vector<int64_t> lens;
         for (int64_t s = a; s < b; s += chunk_size) { const int64_t e = std::min(s + chunk_size, b); items.push_back({s, e}); lens.push_back(e - s); }
         upfront_patches(a, lens, speculate, patches);
+        junctions_of_region(lens, region_first_chunk[(size_t)r], junctions);
     }
     region_first_chunk[(size_t)n_regions] = (int64_t)items.size();
     const int64_t n_chunks = (int64_t)items.size();
@@ -245,6 +265,58 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     n_batches++;
     for (size_t i = (size_t)n_chunks; i < items.size(); i++) { cache[items[i]] = Patch{first.flat + first.off[i], first.off[i + 1] - first.off[i]}; n_patch_dp++; }
 
+    // ---- rehearsal ---------------------------------------------------------------------------------------------------
+    // The tree below meets its junctions level by level, and a junction whose cached attempts all fail costs a
+    // follow-up batch at ITS level — up to one small, latency-bound batch per level.  But a junction's fate depends only
+    // on the borders next to it, i.e. on the two chunks that touch it (patches are far smaller than chunks): so play
+    // every junction now against those two chunks, collect ALL missing patches, and fetch them in one batch (repeat while
+    // something is missing).  Only the cache is filled here; the tree then does the real work and, where the rehearsal
+    // could not foresee a request (a patch outgrowing its chunk), still asks for it.
+    if (speculate) {
+        std::vector<Junction> pend = junctions;
+        for (int pass = 0; pass < 4 && !pend.empty(); pass++) {
+            std::vector<Sites> need;
+            std::vector<Junction> still;
+            for (const Junction& jn : pend) {
+                const size_t li = (size_t)jn.left_item, ri = (size_t)jn.right_item;
+                const int64_t llen = items[li].second - items[li].first, rlen = items[ri].second - items[ri].first;
+                Stitch t;
+                Rope a, b;
+                a.runs.push_back(Run{first.flat + first.off[li], first.off[li + 1] - first.off[li], items[li].first});
+                b.runs.push_back(Run{first.flat + first.off[ri], first.off[ri + 1] - first.off[ri], items[ri].first});
+                std::string e2;
+                if (!t.init(std::move(a), std::move(b), e2)) continue;
+                t.n1 = jn.n1; t.n2 = jn.n2;
+                t.p1 = std::min<int64_t>(50, t.n1); t.p2 = std::min<int64_t>(50, t.n2);
+                while (!t.done) {
+                    Sites w;
+                    if (!t.want(w, e2) || t.p1 > llen || t.p2 > rlen) break;       // the tree will deal with it
+                    auto it = cache.find(w);
+                    if (it == cache.end() || it->second.p == nullptr) {
+                        if (it == cache.end()) { cache[w] = Patch{nullptr, 0}; need.push_back(w); }
+                        const int64_t j = t.b1.back();
+                        const int64_t q1 = increase_patch(t.p1, t.n1), q2 = increase_patch(t.p2, t.n2);
+                        const Sites alt[3] = {{j - q1, j + t.p2}, {j - t.p1, j + q2}, {j - q1, j + q2}};
+                        const bool ok[3] = {q1 <= t.n1, q2 <= t.n2, q1 <= t.n1 && q2 <= t.n2};
+                        for (int k = 0; k < 3; k++)
+                            if (ok[k] && !cache.count(alt[k])) { cache[alt[k]] = Patch{nullptr, 0}; need.push_back(alt[k]); }
+                        still.push_back(jn);
+                        break;
+                    }
+                    t.feed(it->second.p, it->second.n, w.first);
+                }
+            }
+            if (need.empty()) break;
+            keep.emplace_back(new BatchResult());
+            BatchResult& res = *keep.back();
+            rc = timed_batch(need, res);
+            if (rc != 0) return rc;
+            n_batches++;
+            for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = Patch{res.flat + res.off[i], res.off[i + 1] - res.off[i]}; n_patch_dp++; }
+            pend.swap(still);
+        }
+    }
+    mark("rehearsal (incl. its batches)");
     // ---- pairwise-tree stitching (segment.py:157-165), all regions advancing round by round ------------------------
     std::vector<std::vector<Rope>> lists((size_t)n_regions);
     for (int64_t r = 0; r < n_regions; r++)
@@ -279,7 +351,16 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                 if (s.done) continue;
                 Sites w;
                 if (!s.want(w, err)) return E_ARG;
-                if (!cache.count(w)) { cache[w] = Patch{nullptr, 0}; need.push_back(w); }
+                if (cache.count(w)) continue;
+                cache[w] = Patch{nullptr, 0}; need.push_back(w);
+                if (speculate) {                               // a follow-up batch is due anyway: add what the junction will ask for if this attempt fails too
+                    const int64_t j = s.b1.back();
+                    const int64_t q1 = increase_patch(s.p1, s.n1), q2 = increase_patch(s.p2, s.n2);
+                    const Sites alt[3] = {{j - q1, j + s.p2}, {j - s.p1, j + q2}, {j - q1, j + q2}};
+                    const bool ok[3] = {q1 <= s.n1, q2 <= s.n2, q1 <= s.n1 && q2 <= s.n2};
+                    for (int a = 0; a < 3; a++)
+                        if (ok[a] && !cache.count(alt[a])) { cache[alt[a]] = Patch{nullptr, 0}; need.push_back(alt[a]); }
+                }
             }
             if (!need.empty()) {
                 keep.emplace_back(new BatchResult());
