@@ -1357,8 +1357,9 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
     if (x1 > x0) {
         uint32_t sm = 0, sc = 0;
         int pend = 0;
-        for (int64_t site = x0 & ~7LL; site < x1; site += 8) {             // 8 sites = one 16-byte vector, aligned in the row
-            const uint4 v = wg_load16_guarded(row, site, n_total);
+        // 8 sites = one 16-byte vector, aligned in the row; the first four vectors of a block (all of a typical block)
+        // are requested before any is used
+        auto fold = [&](const uint4 v, const int64_t site) {
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             const bool inner = site >= x0 && site + 8 <= x1;
 #pragma unroll
@@ -1373,7 +1374,16 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
                 sm += x & 0x00ff00ffu;
                 sc += (x >> 8) & 0x00ff00ffu;
             }
-            if (++pend == 32) {                                           // 16-bit lanes hold 128 x 255 at most
+        };
+        const int64_t s0 = x0 & ~7LL;
+        uint4 v4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v4[q] = (s0 + 8 * q < x1) ? wg_load16_guarded(row, s0 + 8 * q, n_total) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (s0 + 8 * q < x1) fold(v4[q], s0 + 8 * q);
+        for (int64_t site = s0 + 32; site < x1; site += 8) {
+            fold(wg_load16_guarded(row, site, n_total), site);
+            if (++pend == 28) {                                           // 16-bit lanes hold 128 x 255 at most (4 + 28 vectors)
                 m += (sm & 0xffffu) + (sm >> 16); c += (sc & 0xffffu) + (sc >> 16);
                 sm = 0; sc = 0; pend = 0;
             }
