@@ -7,7 +7,13 @@
 
 static wg_log_tables make_tab() { wg_log_tables t = WG_LOG_TABLES_INIT; wg_tables_finish(&t); return t; }
 static const wg_log_tables g_tab = make_tab();
-static wg_fast_tables make_fast() { wg_fast_tables f; memcpy(f.f_tab, g_tab.f_tab, sizeof(f.f_tab)); memcpy(f.d_fast, g_tab.d_fast, sizeof(f.d_fast)); return f; }
+static wg_fast_tables make_fast()
+{
+    wg_fast_tables f;
+    memcpy(f.f_tab, g_tab.f_tab, sizeof(f.f_tab)); memcpy(f.d_fast, g_tab.d_fast, sizeof(f.d_fast));
+    for (int x = 0; x < (WG_Y0_KMIN + 1) * 16; x++) f.f_y0[x] = g_tab.f_tab[x & 15].b + (double)((x >> 4) - WG_Y0_KMIN);
+    return f;
+}
 static const wg_fast_tables g_fast = make_fast();
 
 template <class F> static void par_for(uint64_t count, int threads, F f)
@@ -78,8 +84,16 @@ void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, 
 {
     float pc2 = pc + pc;
     const int mode = wg_term_mode(pc);                              // same dispatch rule as the library
-    for (int64_t q = 0; q < count; q++)
-        out[q] = mode == 2 ? wg_sample_term_pcpos(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab)
-               : (mode == 1 ? wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab) : wg_sample_term_plain(nmeth[q], ntotal[q], pc, pc2, &g_tab));
+    for (int64_t q = 0; q < count; q++) {
+        if (mode == 2) {
+            // the guard-free form with and without the zero-coverage exception (the latter is what the kernel runs, with
+            // the y0 table): they may differ only in the sign of a zero when ntotal == 0; anything else comes back as NaN
+            const float a = wg_sample_term_pcpos(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab);
+            const float b = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab);
+            out[q] = (wg_f2u(a) == wg_f2u(b) || (a == 0.0f && b == 0.0f && ntotal[q] == 0.0f)) ? a : __builtin_nanf("");
+        } else {
+            out[q] = mode == 1 ? wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab) : wg_sample_term_plain(nmeth[q], ntotal[q], pc, pc2, &g_tab);
+        }
+    }
 }
 }

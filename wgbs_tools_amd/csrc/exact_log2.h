@@ -136,11 +136,13 @@ struct wg_log_tables {
     wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}: filled by wg_tables_finish()
 };
 #define WG_LOG_TABLES_INIT { WG_LOG2F_TAB, WG_LOG2_TAB, WG_LOG2_TAB2, WG_LOG2_TAB }
-// What the scoring kernel keeps in LDS: the log2f table and the fast-log2 table (1.3 KB).  The exact-log2 tables are
+// What the scoring kernel keeps in LDS: the log2f table, the fast-log2 table and log2f's y0 table (4.6 KB).  The exact-log2 tables are
 // only needed by the rare fallback and stay in global/constant memory.
+#define WG_Y0_KMIN 25        // rows of f_y0: exponents k = -25 .. 0
 struct wg_fast_tables {
     wg_d2 f_tab[16];     // log2f {invc, logc}
     wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}
+    double f_y0[(WG_Y0_KMIN + 1) * 16];   // log2f's y0 = logc[i] + (double)k at [(k + 25) * 16 + i]: the SAME addition, done once
 };
 // The fast log2 uses d_tab with ONE entry changed: interval 39 = [0.9921875, 1) gets the centre exactly 1
 // (invc = 1, logc = 0), so that arguments just below 1 need no separate cancellation-free branch.
@@ -235,6 +237,25 @@ WG_HD float wg_log2f_normal(float x, const wg_d2* __restrict__ ftab)
     const double y0 = logc + (double)k;
     const double r2 = r * r;
     double y = WG_FMA_K(r, WG_LOG2F_A1, WG_LOG2F_A2);          // (same products as A1*r + A2 etc.: multiplication commutes exactly)
+    y = WG_FMA(WG_LOG2F_A0, r2, y);
+    const double p = WG_FMA(WG_LOG2F_A3, r, y0);
+    return (float)WG_FMA(y, r2, p);
+}
+
+// Same again for x in [2^-25, 1] (the guard-free form: p > 2^-22), with y0 = logc + k looked up instead of computed:
+// (tmp >> 19) arithmetically IS k * 16 + i.  Saves the int->double conversion and the addition per evaluation; the
+// table entry is the result of that very addition, so the bits are the same.
+WG_HD float wg_log2f_y0(float x, const wg_d2* __restrict__ ftab, const double* __restrict__ y0tab)
+{
+    const uint32_t ix = wg_f2u(x);
+    const uint32_t tmp = ix - 0x3f330000u;
+    const int32_t ki = (int32_t)tmp >> 19;                       // k * 16 + i, k in [-25, 0]
+    const uint32_t iz = ix - (tmp & 0xff800000u);
+    const double invc = ftab[ki & 15].a;
+    const double y0 = y0tab[ki + WG_Y0_KMIN * 16];
+    const double r = WG_FMA_K((double)wg_u2f(iz), invc, -1.0);
+    const double r2 = r * r;
+    double y = WG_FMA_K(r, WG_LOG2F_A1, WG_LOG2F_A2);
     y = WG_FMA(WG_LOG2F_A0, r2, y);
     const double p = WG_FMA(WG_LOG2F_A3, r, y0);
     return (float)WG_FMA(y, r2, p);
@@ -401,7 +422,7 @@ WG_HD float wg_sample_term_pcpos_nz(float nmeth, float ntotal, float pc, float p
                                     const wg_log_tables* __restrict__ xt)
 {
     const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
-    const float ll = nmeth * wg_log2f_normal(p, ft->f_tab);        // :129-131
+    const float ll = nmeth * wg_log2f_y0(p, ft->f_tab, ft->f_y0);  // :129-131
     const float df = ntotal - nmeth;
     const double x = 1.0 - (double)p;                              // :132-134
     const double s = (double)ll + (double)df * wg_fast_log2(x, ft->d_fast);

@@ -49,6 +49,8 @@ __device__ __forceinline__ void wg_fast_tables_to_lds(wg_fast_tables* ft, int ti
         if (x == 2 * WG_FAST_CENTRE_ENTRY + 1) v = 0.0;
         od[x] = v;
     }
+    for (int x = tid; x < (WG_Y0_KMIN + 1) * 16; x += nthreads)
+        ft->f_y0[x] = f[2 * (x & 15) + 1] + (double)((x >> 4) - WG_Y0_KMIN);      // logc[i] + k, exactly as wg_log2f_normal adds them
 }
 
 struct ChunkDesc {
