@@ -358,6 +358,10 @@ def test_native_stitching_matches_reference_driver(name, speculate, driver_golde
     assert eng.calls[:nch] == list(zip(g['chunks']['starts'], g['chunks']['ends']))       # chunk grid
     if speculate:       # second-attempt patches are computed ahead of need: a superset, same result
         assert set(eng.calls[nch:]) >= set(tuple(c) for c in g['patch_calls'])
+        # ... and the junction rehearsal gathers what is still missing: never more device batches than the plain order
+        eng2 = OracleEngine(synth_world['betas'], synth_world['loci'])
+        _, stats2 = native_segment_regions(stitch_lib, eng2, params, regions, kw['chunk_size'], False)
+        assert stats[2] <= stats2[2], (stats[2], stats2[2])
     else:
         assert set(eng.calls[nch:]) == set(tuple(c) for c in g['patch_calls'])            # same patches, no extras
     s = np.concatenate([r[:-1] for r in res]); e = np.concatenate([r[1:] for r in res])
