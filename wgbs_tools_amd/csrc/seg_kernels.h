@@ -578,7 +578,6 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
     int32_t* ist = offs + (TI + 1);                                              // [TI] first end of start kl in this unit
     int32_t* misc = ist + TI;                                                    // [2 (+1 pad)]
-    double* accL = reinterpret_cast<double*>(misc + 3 + (TI & 1 ? 1 : 0));       // [QCAP] partial sums across sample groups
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nC = J.n_chunks;
@@ -637,9 +636,11 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 
     // Blocks of the tile, flattened: q -> (kl, i).  Every thread walks its blocks q = tid, tid+256, ...; for each it
     // runs the samples of the LDS-resident group IN FILE ORDER, carrying the double sum in a register (and, when the
-    // samples do not fit LDS at once, across groups in accL) — the accumulation order of segmentor.cpp:120-136.
+    // samples do not fit LDS at once, across groups in a register array indexed by the block's round) — the accumulation
+    // order of segmentor.cpp:120-136.
     const float pc = A.pc, pc2 = A.pc2;
     double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
+    double accR[WG_PAIR_CAP / WG_BLOCK];                 // partial sums of this thread's blocks across sample groups
     for (int g0 = 0; g0 < J.n_samples; g0 += A.NS) {
         const int ns = (J.n_samples - g0 < A.NS) ? J.n_samples - g0 : A.NS;
         const bool firstg = g0 == 0, lastg = g0 + ns >= J.n_samples;
@@ -652,13 +653,14 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             if (A.split) wg_stage_prefix_row(St + (size_t)rr * A.IS, row, carry, cd, J.n_total, sG, sA - sG, Scnt, lane);
         }
         __syncthreads();
-        for (int q = tid; q < Q; q += WG_BLOCK) {
+        int qi = 0;
+        for (int q = tid; q < Q; q += WG_BLOCK, qi++) {
             int lo = 0, hi = nk;                           // largest kl with offs[kl] <= q
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
             const int i = ist[lo] + (q - offs[lo]);
             const uint2* Ep = Et + (i + 1 - eA);           // P[i+1] of sample sl at Ep[sl * KS]
             const uint2* Sp = Sbase + soff + lo;           // P[k]   of sample sl at Sp[sl * Sstride]
-            double acc = firstg ? 0.0 : accL[q];
+            double acc = firstg ? 0.0 : accR[qi];
             for (int sl = 0; sl < ns; sl++) {
                 const uint2 pi = Ep[(size_t)sl * A.KS];
                 const uint2 pk = Sp[(size_t)sl * Sstride];
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 acc += (double)ll;                                               // segmentor.cpp:135
             }
             if (lastg) cb[radj[lo] + i] = (acc != 0.0) ? acc : 0.0;              // segmentor.cpp:106,137
-            else accL[q] = acc;
+            else accR[qi] = acc;
         }
     }
 }

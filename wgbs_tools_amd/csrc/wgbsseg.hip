@@ -438,9 +438,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const int TKB = 128;
     auto lds_for = [&](int ti, bool split, int w, int ns) -> size_t {
         const int ks = split ? TKB + 1 : ti + w + 1, is = split ? ti + 1 : 0;
-        const size_t qcap = (size_t)ti * (size_t)(split ? TKB : w);
-        return sizeof(wg_fast_tables) + (size_t)ns * (ks + is) * 8 + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24 +
-               (ns < Nsmp ? qcap * 8 : 0);
+        return sizeof(wg_fast_tables) + (size_t)ns * (ks + is) * 8 + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24;
     };
     int TI = 64, NSA = 1, NSB = 1;
     {
