@@ -277,6 +277,15 @@ def test_native_add_loci_rows_and_errors(tmp_path):
         with pytest.raises(RuntimeError):
             G.blocks_to_bed_lines(Gen(), bs, be)
     assert open(out).read() == ''                       # last case: nothing before the offending row
+    # a failing row deep in a later formatting shard: every row before it is written, none after
+    bad = 40001                                         # shards hold 32768 rows
+    assert bad < s.size
+    s2, e2 = s.copy(), e.copy()
+    e2[bad] = s2[bad] - 1
+    with pytest.raises(_lib.SegmentorError) as ei:
+        _lib.add_loci(loci, names, cum, s2, e2, out, threads=5)
+    assert ei.value.msg == '[wt add_loci] line %d: endCpG < startCpG' % bad
+    assert open(out).read() == ''.join(want.splitlines(True)[:bad])
     _lib.add_loci(loci, names, cum, np.array([69990]), np.array([70001]), out)      # ends ON the chromosome border: legal
     assert open(out).read() == 'chr1\t%d\t%d\t69990\t70001\n' % (loci[69989], loci[69999] + 1)
 

@@ -3,12 +3,17 @@
 // with start = loci[startCpG-1], end = loci[endCpG-2]+1 (start+2 for an empty block), the chromosome looked up in the
 // cumulative CpG counts, and the reference's validations in the reference's order.  Replaces the `add_loci` binary the
 // reference pipes its blocks through (src/cpg2bed/add_loci.cpp:22-57, cpg_dict.cpp:118-131), without the 25 tabix
-// processes that binary needs to load the loci.  Formatting is sharded over host threads; rows are written in order.
+// processes that binary needs to load the loci.  Formatting is sharded over host threads; rows are written in order
+// while later shards are still being formatted.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -57,25 +62,29 @@ inline int check_row(const Genome& g, int64_t s, int64_t e, int& c1, std::string
     return 0;
 }
 
-struct Shard { std::string text; int64_t bad_line = -1; int bad_kind = 0; std::string msg; };
+// Text of one shard of rows.  Raw storage (not std::string): resize() would zero-fill ~100 bytes per row first.
+struct Shard {
+    char* buf = nullptr; size_t len = 0;
+    int64_t bad_line = -1; int bad_kind = 0; std::string msg;
+    Shard() {}
+    Shard(const Shard&) = delete;
+    Shard& operator=(const Shard&) = delete;
+    ~Shard() { free(buf); }
+    void release() { free(buf); buf = nullptr; len = 0; }
+};
 
-inline void format_range(const Genome& g, const int64_t* s, const int64_t* e, int64_t lo, int64_t hi, Shard& out)
+inline void format_range(const Genome& g, const int64_t* s, const int64_t* e, int64_t lo, int64_t hi, size_t max_name, Shard& out)
 {
-    out.text.resize((size_t)(hi - lo) * 96 + 16);
-    char* base = &out.text[0];
-    char* p = base;
-    size_t cap = out.text.size();
+    const size_t row_cap = max_name + 4 * 20 + 5;              // name, four numbers of <= 20 digits, 4 tabs + newline
+    out.buf = static_cast<char*>(malloc((size_t)(hi - lo) * row_cap + 1));
+    if (!out.buf) { out.bad_line = lo; out.bad_kind = 3; out.msg = "out of memory"; return; }
+    char* p = out.buf;
     for (int64_t r = lo; r < hi; r++) {
         int c1 = 0;
         const int kind = check_row(g, s[r], e[r], c1, out.msg);
         if (kind) { out.bad_line = r; out.bad_kind = kind; break; }
         const char* nm = g.names[c1];
         const size_t nl = strlen(nm);
-        if ((size_t)(p - base) + nl + 90 > cap) {               // long chromosome names: grow
-            const size_t used = (size_t)(p - base);
-            out.text.resize(cap * 2 + nl + 128);
-            base = &out.text[0]; p = base + used; cap = out.text.size();
-        }
         const uint64_t start = g.loci[s[r] - 1];
         const uint64_t end = (e[r] == s[r]) ? start + 2 : (uint64_t)g.loci[e[r] - 2] + 1;
         memcpy(p, nm, nl); p += nl;
@@ -85,37 +94,66 @@ inline void format_range(const Genome& g, const int64_t* s, const int64_t* e, in
         *p++ = '\t'; p = put_u64(p, (uint64_t)e[r]);
         *p++ = '\n';
     }
-    out.text.resize((size_t)(p - base));
+    out.len = (size_t)(p - out.buf);
 }
 
 // Writes the rows to `fp`.  Returns 0; 1 with err = "[wt add_loci] line N: ..." ; 2 with err = the cpg_dict message; 3 on I/O error.
 // Rows before a failing row are written, as the reference's streaming loop would have.
+// Shards of WG_ADD_SHARD rows are formatted by a pool of threads (next shard from a shared counter) while the calling
+// thread writes finished shards in order: the wall time is max(formatting, writing), not their sum.
+#define WG_ADD_SHARD 32768
 inline int add_loci(const Genome& g, const int64_t* s, const int64_t* e, int64_t n, FILE* fp, int threads, std::string& err)
 {
     if (n <= 0) return 0;
     int T = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
-    T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(T, 64), n / 20000 + 1));
-    std::vector<Shard> sh((size_t)T);
+    const int64_t n_shards = (n + WG_ADD_SHARD - 1) / WG_ADD_SHARD;
+    T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(T, 32), n_shards));
+    size_t max_name = 0;
+    for (int i = 0; i < g.n_chroms; i++) max_name = std::max(max_name, strlen(g.names[i]));
+    std::vector<Shard> sh((size_t)n_shards);
+    std::vector<std::atomic<int>> done((size_t)n_shards);
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    std::atomic<int64_t> next(0);
+    std::atomic<int64_t> stop_at(n_shards);                       // no shard >= this needs formatting (a row before it failed)
+    std::mutex mu;
+    std::condition_variable cv;
+    auto worker = [&]() {
+        for (;;) {
+            const int64_t k = next.fetch_add(1);
+            if (k >= n_shards || k > stop_at.load()) break;
+            format_range(g, s, e, k * WG_ADD_SHARD, std::min<int64_t>(n, (k + 1) * WG_ADD_SHARD), max_name, sh[(size_t)k]);
+            if (sh[(size_t)k].bad_line >= 0) {
+                int64_t cur = stop_at.load();
+                while (k < cur && !stop_at.compare_exchange_weak(cur, k)) {}
+            }
+            { std::lock_guard<std::mutex> lk(mu); done[(size_t)k].store(1, std::memory_order_release); }
+            cv.notify_one();
+        }
+    };
     std::vector<std::thread> th;
-    for (int t = 0; t < T; t++) {
-        const int64_t lo = n * t / T, hi = n * (t + 1) / T;
-        if (T == 1) format_range(g, s, e, lo, hi, sh[0]);
-        else th.emplace_back(format_range, std::cref(g), s, e, lo, hi, std::ref(sh[(size_t)t]));
-    }
-    for (auto& x : th) x.join();
-    for (int t = 0; t < T; t++) {
-        if (!sh[(size_t)t].text.empty() && fwrite(sh[(size_t)t].text.data(), 1, sh[(size_t)t].text.size(), fp) != sh[(size_t)t].text.size()) {
-            err = "write failed"; return 3;
+    if (T > 1) for (int t = 0; t < T; t++) th.emplace_back(worker);
+    int rc = 0;
+    for (int64_t k = 0; k < n_shards && rc == 0; k++) {
+        if (T == 1) {
+            format_range(g, s, e, k * WG_ADD_SHARD, std::min<int64_t>(n, (k + 1) * WG_ADD_SHARD), max_name, sh[(size_t)k]);
+        } else {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done[(size_t)k].load(std::memory_order_acquire) != 0; });
         }
-        if (sh[(size_t)t].bad_line >= 0) {
-            if (sh[(size_t)t].bad_kind == 1) err = "[wt add_loci] line " + std::to_string(sh[(size_t)t].bad_line) + ": " + sh[(size_t)t].msg;
-            else err = sh[(size_t)t].msg;
-            fflush(fp);
-            return sh[(size_t)t].bad_kind;
+        Shard& x = sh[(size_t)k];
+        if (x.bad_kind == 3) { err = x.msg; rc = 3; break; }
+        if (x.len && fwrite(x.buf, 1, x.len, fp) != x.len) { err = "write failed"; rc = 3; break; }
+        if (x.bad_line >= 0) {
+            if (x.bad_kind == 1) err = "[wt add_loci] line " + std::to_string(x.bad_line) + ": " + x.msg;
+            else err = x.msg;
+            rc = x.bad_kind;
         }
+        x.release();
     }
-    if (fflush(fp) != 0) { err = "write failed"; return 3; }
-    return 0;
+    if (rc != 0) { int64_t cur = stop_at.load(); while (cur > -1 && !stop_at.compare_exchange_weak(cur, -1)) {} }   // let the pool drain
+    for (auto& t : th) t.join();
+    if (fflush(fp) != 0 && rc == 0) { err = "write failed"; rc = 3; }
+    return rc;
 }
 
 }  // namespace wgadd
