@@ -8,6 +8,8 @@
 // (no fused multiply-add anywhere; SURVEY.md 7 hard part 2).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +17,7 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/wgbsseg.h"
@@ -24,17 +27,24 @@
 
 namespace {
 
+inline double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// WGBSSEG_PROFILE=1: where the host time of a call goes (allocations, upload), on stderr
+inline bool profiling() { static const bool on = getenv("WGBSSEG_PROFILE") && atoi(getenv("WGBSSEG_PROFILE")); return on; }
+std::atomic<long long> g_alloc_us(0), g_alloc_bytes(0), g_alloc_calls(0);
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes)
     {
         if (bytes <= cap) return hipSuccess;
+        const double t0 = profiling() ? wall_s() : 0.0;
         if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
         if (e == hipSuccess) cap = want;
+        if (profiling()) { g_alloc_us += (long long)((wall_s() - t0) * 1e6); g_alloc_bytes += (long long)want; g_alloc_calls += 1; }
         return e;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -71,10 +81,20 @@ struct PinnedBuf {          // grow-only page-locked host buffer (fast, truly as
     bool ensure(size_t bytes)
     {
         if (bytes <= cap) return true;
+        const double t0 = profiling() ? wall_s() : 0.0;
         if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
         const size_t want = bytes + bytes / 4 + 4096;
         if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
         cap = want;
+        if (profiling()) { g_alloc_us += (long long)((wall_s() - t0) * 1e6); g_alloc_bytes += (long long)want; g_alloc_calls += 1; }
+        return true;
+    }
+    bool ensure_exact(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        cap = bytes;
         return true;
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
@@ -94,6 +114,7 @@ struct wgbsseg_ctx {
     DevBuf chunks, wtile, carry, W16, cum32, back16, chunk_pairs, status;
     DevBuf plan_cbase, plan_cum0, plan_tbase, plan_pairs, plan_tiles, plan_cnt, tilesA, tilesB, umax16;
     std::vector<PinnedBuf> pinned;
+    std::vector<PinnedBuf> up_stage;   // two page-locked staging pieces per upload thread (set_betas_host)
     DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders, dbg_a, dbg_b, dbg_c;
     // events
     hipEvent_t ev[8] = {};
@@ -113,6 +134,67 @@ struct wgbsseg_ctx {
     double last_block_sums_ms = 0.0;
     bool accumulate = false;   // add to `tim` instead of resetting it (region-level calls span several batches)
 };
+
+namespace {
+
+// Pageable host rows (typically memory-mapped .beta files) -> HBM: dst + r * dst_pitch <- rows[r][0 .. row_bytes).
+// One thread drives ~33 GB/s of that (page faults + the copy into page-locked staging); a few threads, each with its
+// own stream and two 4 MB staging pieces, fill the link (measured 46 GB/s with 4; more threads only contend).
+int upload_rows(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const uint8_t* const* rows, int64_t n_rows, int64_t row_bytes,
+                const char* what, char* err, size_t errlen)
+{
+    const double t0 = wall_s();
+    int64_t piece = 4 << 20;
+    { const char* e = getenv("WGBSSEG_UPLOAD_PIECE_KB"); if (e && atoi(e) >= 64) piece = (int64_t)atoi(e) << 10; }
+    const int64_t pieces_per_row = (row_bytes + piece - 1) / piece, n_pieces = pieces_per_row * n_rows;
+    int T = 4;
+    { const char* e = getenv("WGBSSEG_UPLOAD_THREADS"); if (e && atoi(e) > 0) T = atoi(e); }
+    T = (int)std::min<int64_t>(std::min<int64_t>(T, 64), std::max<int64_t>(1, std::min<int64_t>(n_pieces / 2, (row_bytes * n_rows) >> 24)));   // small inputs: the plain copy
+    if (T <= 1) {
+        for (int64_t r = 0; r < n_rows; r++)
+            HIP_TRY(hipMemcpyAsync(dst + r * dst_pitch, rows[r], (size_t)row_bytes, hipMemcpyHostToDevice, c->sA));
+        HIP_TRY(hipStreamSynchronize(c->sA));
+    } else {
+        if (c->up_stage.size() < (size_t)(2 * T)) c->up_stage.resize((size_t)(2 * T));
+        for (int i = 0; i < 2 * T; i++)
+            if (!c->up_stage[(size_t)i].ensure_exact((size_t)piece)) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
+        std::atomic<int64_t> next(0);
+        std::vector<hipError_t> terr((size_t)T, hipSuccess);
+        auto worker = [&](int t) {
+            hipError_t e = hipSetDevice(c->device);
+            hipStream_t st = nullptr;
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+            bool busy[2] = {false, false};
+            int k = 0;
+            while (e == hipSuccess) {
+                const int64_t it = next.fetch_add(1);
+                if (it >= n_pieces) break;
+                const int64_t r = it / pieces_per_row, o = (it % pieces_per_row) * piece, b = std::min<int64_t>(piece, row_bytes - o);
+                void* stg = c->up_stage[(size_t)(2 * t + k)].p;
+                if (busy[k]) { e = hipEventSynchronize(ev[k]); if (e != hipSuccess) break; }      // its previous copy has left the piece
+                memcpy(stg, rows[r] + o, (size_t)b);
+                e = hipMemcpyAsync(dst + r * dst_pitch + o, stg, (size_t)b, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipEventRecord(ev[k], st);
+                busy[k] = true;
+                k ^= 1;
+            }
+            if (st) { const hipError_t e2 = hipStreamSynchronize(st); if (e == hipSuccess) e = e2; (void)hipStreamDestroy(st); }
+            for (auto& x : ev) if (x) (void)hipEventDestroy(x);
+            terr[(size_t)t] = e;
+        };
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) th.emplace_back(worker, t);
+        for (auto& x : th) x.join();
+        for (int t = 0; t < T; t++) HIP_TRY(terr[(size_t)t]);
+    }
+    if (profiling()) fprintf(stderr, "[wgbsseg] %s to the device: %.1f ms, %.1f GB/s (%d upload threads)\n", what, (wall_s() - t0) * 1e3,
+                             (double)row_bytes * n_rows / (wall_s() - t0) * 1e-9, T);
+    return WGBSSEG_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -172,6 +254,7 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
 void wgbsseg_destroy(wgbsseg_ctx* c)
 {
     if (!c) return;
+    const double t0 = wall_s();
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->wtile, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs,
@@ -180,12 +263,14 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
                      &c->dbg_a, &c->dbg_b, &c->dbg_c};
     for (auto* b : all) b->release();
     for (auto& pb : c->pinned) pb.release();
+    for (auto& pb : c->up_stage) pb.release();
     c->h_status.release();
     for (auto& v : c->ev) if (v) (void)hipEventDestroy(v);
     for (auto* vec : {&c->ev_cost0, &c->ev_cost1, &c->ev_dp0, &c->ev_dp1}) for (auto v : *vec) (void)hipEventDestroy(v);
     if (c->sA) (void)hipStreamDestroy(c->sA);
     if (c->sB) (void)hipStreamDestroy(c->sB);
     delete c;
+    if (profiling()) fprintf(stderr, "[wgbsseg] destroy: %.1f ms\n", (wall_s() - t0) * 1e3);
 }
 
 int wgbsseg_set_betas_host(wgbsseg_ctx* c, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites,
@@ -195,11 +280,10 @@ int wgbsseg_set_betas_host(wgbsseg_ctx* c, const uint8_t* const* samples, int64_
     HIP_TRY(hipSetDevice(c->device));
     const int64_t pitch = round_up(2 * n_sites, 256) + 256;      // slack: vector loads may run past the last site
     HIP_TRY(c->betas_own.ensure((size_t)pitch * (size_t)n_samples));
-    for (int64_t s = 0; s < n_samples; s++) {
+    for (int64_t s = 0; s < n_samples; s++)
         if (!samples[s]) { set_err(err, errlen, "samples[%lld] is NULL", (long long)s); return WGBSSEG_E_ARG; }
-        HIP_TRY(hipMemcpyAsync(c->betas_own.as<uint8_t>() + s * pitch, samples[s], (size_t)(2 * n_sites), hipMemcpyHostToDevice, c->sA));
-    }
-    HIP_TRY(hipStreamSynchronize(c->sA));
+    const int rc = upload_rows(c, c->betas_own.as<uint8_t>(), pitch, samples, n_samples, 2 * n_sites, "betas", err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
     c->betas = c->betas_own.as<uint8_t>();
     c->pitch = pitch; c->n_total = n_sites; c->n_samples = (int32_t)n_samples;
     c->last_valid = false;
@@ -222,8 +306,9 @@ int wgbsseg_set_loci_host(wgbsseg_ctx* c, const uint32_t* loci, int64_t n_sites,
     if (!c || !loci || n_sites < 1) { set_err(err, errlen, "bad arguments to set_loci_host"); return WGBSSEG_E_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(c->loci_own.ensure((size_t)n_sites * 4));
-    HIP_TRY(hipMemcpyAsync(c->loci_own.p, loci, (size_t)n_sites * 4, hipMemcpyHostToDevice, c->sA));
-    HIP_TRY(hipStreamSynchronize(c->sA));
+    const uint8_t* row = reinterpret_cast<const uint8_t*>(loci);
+    const int rc = upload_rows(c, c->loci_own.as<uint8_t>(), 0, &row, 1, n_sites * 4, "loci", err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
     c->loci = c->loci_own.as<uint32_t>();
     c->n_loci = n_sites;
     c->last_valid = false;
@@ -698,6 +783,12 @@ int wgbsseg_segment_regions(wgbsseg_ctx* c, const int64_t* region_start, const i
     static const bool speculate = !(getenv("WGBSSEG_NO_SPECULATION") && atoi(getenv("WGBSSEG_NO_SPECULATION")));
     const int rc = wgstitch::segment_regions(region_start, region_end, n_regions, chunk_size, run_batch, borders_out, borders_cap,
                                              borders_off, stats, msg, speculate);
+    if (profiling()) {
+        fprintf(stderr, "[wgbsseg] segment_regions: %lld batches; allocations since the last report: %lld calls, %.1f MB, %.1f ms; "
+                "device ms: scan %.2f window %.2f cost %.2f dp %.2f trace %.2f, time line %.2f\n",
+                (long long)n_batches, g_alloc_calls.exchange(0), (double)g_alloc_bytes.exchange(0) * 1e-6, (double)g_alloc_us.exchange(0) * 1e-3,
+                c->tim.scan_ms, c->tim.window_ms, c->tim.cost_ms, c->tim.dp_ms, c->tim.trace_ms, c->tim.total_ms);
+    }
     if (rc != 0) { set_err(err, errlen, "%s", msg.c_str()); return rc == wgstitch::E_CAPACITY ? WGBSSEG_E_CAPACITY : (rc < -1 ? rc : WGBSSEG_E_ARG); }
     return WGBSSEG_OK;
 }

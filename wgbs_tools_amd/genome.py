@@ -132,7 +132,7 @@ class GenomeRefPaths:
             cache = op.join(self.refdir, 'loci.u32')
             n = self.get_nr_sites()
             if op.isfile(cache) and op.getsize(cache) == 4 * n and op.getmtime(cache) >= op.getmtime(self.dict_path):
-                self._loci = np.fromfile(cache, dtype=np.uint32)
+                self._loci = np.memmap(cache, dtype=np.uint32, mode='r')     # pages come in as the upload / the BED writer touch them
             else:
                 self._loci = _parse_dict_loci(self.dict_path, n)
                 try:

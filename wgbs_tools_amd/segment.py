@@ -14,7 +14,7 @@ import argparse
 import multiprocessing
 import os
 import sys
-
+import threading
 import time
 
 import numpy as np
@@ -280,13 +280,20 @@ class SegmentByChunks:
                     groups.setdefault(t, []).append(arr[i])
                 merged = self.merge_groups(groups)
         finally:
+            closer = None
             if own_engine:
-                self.param_dict['engine'].close()
+                # releasing ~10 GB of device buffers takes as long as writing the BED: do both at once
+                closer = threading.Thread(target=self.param_dict['engine'].close)
+                closer.start()
                 self.param_dict['engine'] = None
-        if prof: prof.append(('segmentation (device + stitching)', time.perf_counter()))
-        s = np.concatenate([m[:-1] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
-        e = np.concatenate([m[1:] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
-        self.dump_result(s, e)
+        try:
+            if prof: prof.append(('segmentation (device + stitching)', time.perf_counter()))
+            s = np.concatenate([m[:-1] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
+            e = np.concatenate([m[1:] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
+            self.dump_result(s, e)
+        finally:
+            if closer is not None:
+                closer.join()
         if prof:
             prof.append(('blocks to BED', time.perf_counter()))
             eprint('[wt segment] phases: ' + ', '.join('%s %.3f s' % (n, t - prof[i][1]) for i, (n, t) in enumerate(prof[1:])))
