@@ -346,3 +346,70 @@ def test_12_device_generator_equals_numpy_generator():
     for s in range(N):
         want = synth.synth_betas(cases.SEED, s, 0, n).reshape(-1)
         assert _first_diff(host[s, :2 * n], want) is None, 'sample %d: %s' % (s, _first_diff(host[s, :2 * n], want))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 13. randomised parameters and adversarial inputs against the oracle
+# ---------------------------------------------------------------------------------------------------------
+def _fuzz_world(rng, n, n_samples):
+    """Random loci (dense runs, equal positions, long gaps) and counts (zeros, saturated bytes, meth == cov)."""
+    kind = rng.integers(0, 4, n)
+    gap = np.where(kind == 0, 0, np.where(kind == 1, rng.integers(1, 12, n), np.where(kind == 2, rng.integers(2, 300, n), rng.integers(300, 9000, n))))
+    loci = (np.cumsum(gap) + 1000).astype(np.uint32)
+    slices = []
+    for _ in range(n_samples):
+        cov = rng.integers(0, 256, n)
+        mode = rng.integers(0, 6, n)
+        cov = np.where(mode == 0, 0, np.where(mode == 1, 255, cov))
+        meth = np.minimum(cov, np.where(mode == 2, cov, np.where(mode == 3, 0, rng.integers(0, 256, n))))
+        slices.append(np.stack([meth, cov], axis=1).astype(np.uint8))
+    return slices, loci
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_13_random_parameters_and_adversarial_inputs_match_oracle(seg, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(3000, 9000))
+    n_samples = int(rng.choice([1, 2, 3, 7, 33, 40]))
+    slices, loci = _fuzz_world(rng, n, n_samples)
+    seg.set_betas(slices)
+    seg.set_loci(loci)
+    for _ in range(4):
+        pcount = float(rng.choice([0.0, 0.25, 1.0, 3.9999998, 4.0, 15.0, 100.0, 1e-3]))
+        max_cpg = int(rng.choice([1, 2, 17, 64, 65, 129, 300, 1000]))
+        max_bp = int(rng.choice([1, 2, 50, 700, 2000, 100000]))
+        starts, lens = [], []
+        for _ in range(12):
+            ln = int(rng.integers(1, min(n, 2500)))
+            st = int(rng.integers(0, n - ln + 1))
+            starts.append(st)
+            lens.append(ln)
+        got = seg.segment_chunks(starts, lens, pcount, max_cpg, max_bp)
+        want = oracle.segment_chunks(slices, loci, starts, lens, pcount, max_cpg, max_bp, threads=os.cpu_count() or 1)
+        for c, (a, b) in enumerate(zip(got, want)):
+            assert a.tolist() == b.tolist(), 'seed %d pcount %r max_cpg %d max_bp %d chunk [%d,+%d): %s' % (
+                seed, pcount, max_cpg, max_bp, starts[c], lens[c], _first_diff(a, b))
+
+
+def test_14_threaded_upload_places_every_byte(monkeypatch):
+    """wgbsseg_set_betas_host above 32 MB goes through several threads and page-locked staging pieces: odd row length,
+    small pieces, a sample count that does not divide by the threads; every byte must land (checked through the scan)."""
+    monkeypatch.setenv('WGBSSEG_UPLOAD_THREADS', '3')
+    monkeypatch.setenv('WGBSSEG_UPLOAD_PIECE_KB', '96')
+    n = 3_400_001
+    slices = [synth.synth_betas(cases.SEED + 1, s, 0, n) for s in range(5)]          # 34 MB
+    with _lib.Segmenter(0) as s:
+        s.set_betas(slices)
+        for start0, length in [(0, 70000), (49152 - 20, 100), (n - 60000, 60000), (1_700_000, 65536)]:
+            got = s.prefix_sums(start0, length)
+            for k, sl in enumerate(slices):
+                want = np.zeros((length + 1, 2), dtype=np.uint32)
+                want[1:] = np.cumsum(sl[start0:start0 + length].astype(np.uint32), axis=0)
+                assert _first_diff(got[k], want) is None, 'sample %d range [%d,+%d): %s' % (k, start0, length, _first_diff(got[k], want))
+        # and whole-row checksums through the block reduction (one block per 1,000,000 sites)
+        b = np.arange(0, n + 1, 1_000_000, dtype=np.int64)
+        b[-1] = n
+        sums = s.block_sums(b[:-1], b[1:], mode=0)
+        for k, sl in enumerate(slices):
+            want = np.stack([sl[a:e].astype(np.uint64).sum(axis=0) for a, e in zip(b[:-1], b[1:])])
+            assert np.array_equal(np.asarray(sums)[k].astype(np.uint64), want), 'sample %d block sums differ' % k
