@@ -11,7 +11,7 @@ static wg_fast_tables make_fast()
 {
     wg_fast_tables f;
     memcpy(f.f_tab, g_tab.f_tab, sizeof(f.f_tab)); memcpy(f.d_fast, g_tab.d_fast, sizeof(f.d_fast));
-    for (int x = 0; x < (WG_Y0_KMIN + 1) * 16; x++) f.f_y0[x] = g_tab.f_tab[x & 15].b + (double)((x >> 4) - WG_Y0_KMIN);
+    for (int x = 0; x < (WG_Y0_KMIN + 1) * 16; x++) { f.f_iy[x].a = g_tab.f_tab[x & 15].a; f.f_iy[x].b = g_tab.f_tab[x & 15].b + (double)((x >> 4) - WG_Y0_KMIN); }
     return f;
 }
 static const wg_fast_tables g_fast = make_fast();

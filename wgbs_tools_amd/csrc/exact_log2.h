@@ -142,7 +142,7 @@ struct wg_log_tables {
 struct wg_fast_tables {
     wg_d2 f_tab[16];     // log2f {invc, logc}
     wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}
-    double f_y0[(WG_Y0_KMIN + 1) * 16];   // log2f's y0 = logc[i] + (double)k at [(k + 25) * 16 + i]: the SAME addition, done once
+    wg_d2 f_iy[(WG_Y0_KMIN + 1) * 16];    // log2f: {invc[i], y0 = logc[i] + (double)k} at [(k + 25) * 16 + i] — the SAME addition, done once; one 16-byte read
 };
 // The fast log2 uses d_tab with ONE entry changed: interval 39 = [0.9921875, 1) gets the centre exactly 1
 // (invc = 1, logc = 0), so that arguments just below 1 need no separate cancellation-free branch.
@@ -245,14 +245,14 @@ WG_HD float wg_log2f_normal(float x, const wg_d2* __restrict__ ftab)
 // Same again for x in [2^-25, 1] (the guard-free form: p > 2^-22), with y0 = logc + k looked up instead of computed:
 // (tmp >> 19) arithmetically IS k * 16 + i.  Saves the int->double conversion and the addition per evaluation; the
 // table entry is the result of that very addition, so the bits are the same.
-WG_HD float wg_log2f_y0(float x, const wg_d2* __restrict__ ftab, const double* __restrict__ y0tab)
+WG_HD float wg_log2f_y0(float x, const wg_d2* __restrict__ iytab)
 {
     const uint32_t ix = wg_f2u(x);
     const uint32_t tmp = ix - 0x3f330000u;
     const int32_t ki = (int32_t)tmp >> 19;                       // k * 16 + i, k in [-25, 0]
     const uint32_t iz = ix - (tmp & 0xff800000u);
-    const double invc = ftab[ki & 15].a;
-    const double y0 = y0tab[ki + WG_Y0_KMIN * 16];
+    const wg_d2 e = iytab[ki + WG_Y0_KMIN * 16];                 // one shift-add for the address, one read for both
+    const double invc = e.a, y0 = e.b;
     const double r = WG_FMA_K((double)wg_u2f(iz), invc, -1.0);
     const double r2 = r * r;
     double y = WG_FMA_K(r, WG_LOG2F_A1, WG_LOG2F_A2);
@@ -329,10 +329,19 @@ WG_HD double wg_fast_log2(double x, const wg_d2* __restrict__ dfast)
     const uint64_t ix = wg_d2u(x);
     const uint32_t xhi = (uint32_t)(ix >> 32);
     const uint32_t hi = xhi - 0x3fe60000u;                  // high word of ix - 0x3fe6000000000000 (the low word of the constant is 0)
-    const uint32_t i = (hi >> 14) & 63u;
     const int32_t k = (int32_t)hi >> 20;
     const uint64_t iz = ((uint64_t)(xhi - (hi & 0xfff00000u)) << 32) | (uint32_t)ix;      // only the high word changes
+#if defined(__HIP_DEVICE_COMPILE__)
+    // bit-field extract, then shift-add onto the table base: two instructions where shift / mask / add would be three
+    // (inline asm: the optimiser rewrites the builtin back into shift + mask)
+    uint32_t i6;
+    asm("v_bfe_u32 %0, %1, 14, 6" : "=v"(i6) : "v"(hi));
+    const wg_d2* ent = reinterpret_cast<const wg_d2*>(reinterpret_cast<const char*>(dfast) + (i6 << 4));
+    const double invc = ent->a, logc = ent->b;
+#else
+    const uint32_t i = (hi >> 14) & 63u;
     const double invc = dfast[i].a, logc = dfast[i].b;
+#endif
     const double r = WG_FMA_K(wg_u2d(iz), invc, -1.0);
     double q = WG_LOG2_A5;
     q = WG_FMA_K(q, r, WG_LOG2_A4); q = WG_FMA_K(q, r, WG_LOG2_A3); q = WG_FMA_K(q, r, WG_LOG2_A2);
@@ -366,11 +375,26 @@ WG_HD float wg_sample_term_plain(float nmeth, float ntotal, float pc, float pc2,
 // lies within 6 ulp of a float rounding midpoint (low 29 mantissa bits == 2^28); we use a 16-ulp guard band, and in
 // that band (probability 2^-24 per evaluation) the exact restatement decides.  When ntotal == nmeth the reference adds -0.0 and ll is unchanged.
 #define WG_GUARD_ULPS 16u
+// "low 29 bits of s within WG_GUARD_ULPS of 2^28", as one shift-add and one compare: with tail = lo & (2^29-1) and
+// C = 2^28 - G, (tail - C) mod 2^32 <= 2G  <=>  (8*tail - 8*C) mod 2^32 <= 16G, and 8*tail mod 2^32 is just lo << 3.
+WG_HD bool wg_in_guard_band(double s)
+{
+    const uint32_t t3 = ((uint32_t)wg_d2u(s) << 3) + (0u - ((0x10000000u - WG_GUARD_ULPS) << 3));
+    return t3 <= 16u * WG_GUARD_ULPS;
+}
 // IEEE-754 binary32 division a / b for operands in a "comfortable" range (0 <= a <= b, 2^-20 <= b < 2^26, or a == 0).
 // On the device this is the core of the sequence hipcc emits for `/` (v_rcp_f32, one Newton step on the reciprocal,
 // two residual corrections of the quotient) WITHOUT v_div_scale (a no-op unless an operand or the quotient sits near
 // the exponent limits) and v_div_fixup (special values only): 8 instructions instead of 11, same intermediate values,
 // hence the same correctly rounded quotient.  tests/test_gpu_parity.py::test_02b compares it with `/` on the device.
+// A copy of v the optimiser cannot see through (keeps a value from being held in registers for a rare path).
+WG_HD float wg_opaque_f32(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
 WG_HD float wg_div_f32(float a, float b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -422,14 +446,13 @@ WG_HD float wg_sample_term_pcpos_nz(float nmeth, float ntotal, float pc, float p
                                     const wg_log_tables* __restrict__ xt)
 {
     const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
-    const float ll = nmeth * wg_log2f_y0(p, ft->f_tab, ft->f_y0);  // :129-131
+    const float ll = nmeth * wg_log2f_y0(p, ft->f_iy);  // :129-131
     const float df = ntotal - nmeth;
     const double x = 1.0 - (double)p;                              // :132-134
     const double s = (double)ll + (double)df * wg_fast_log2(x, ft->d_fast);
-    const uint32_t tail = (uint32_t)wg_d2u(s) & 0x1fffffffu;
     float res = (float)s;
-    if ((uint32_t)(tail - (0x10000000u - WG_GUARD_ULPS)) <= 2u * WG_GUARD_ULPS)
-        res = (float)((double)ll + (double)df * wg_log2(x, xt->d_tab, xt->d_tab2));
+    if (wg_in_guard_band(s))
+        res = (float)((double)ll + (double)df * wg_log2(1.0 - (double)wg_opaque_f32(p), xt->d_tab, xt->d_tab2));   // x recomputed: not kept live for the rare path
     return res;
 }
 

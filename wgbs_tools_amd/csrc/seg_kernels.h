@@ -49,8 +49,10 @@ __device__ __forceinline__ void wg_fast_tables_to_lds(wg_fast_tables* ft, int ti
         if (x == 2 * WG_FAST_CENTRE_ENTRY + 1) v = 0.0;
         od[x] = v;
     }
-    for (int x = tid; x < (WG_Y0_KMIN + 1) * 16; x += nthreads)
-        ft->f_y0[x] = f[2 * (x & 15) + 1] + (double)((x >> 4) - WG_Y0_KMIN);      // logc[i] + k, exactly as wg_log2f_normal adds them
+    for (int x = tid; x < (WG_Y0_KMIN + 1) * 16; x += nthreads) {
+        ft->f_iy[x].a = f[2 * (x & 15)];
+        ft->f_iy[x].b = f[2 * (x & 15) + 1] + (double)((x >> 4) - WG_Y0_KMIN);     // logc[i] + k, exactly as wg_log2f_normal adds them
+    }
 }
 
 struct ChunkDesc {
@@ -498,10 +500,6 @@ __global__ __launch_bounds__(WG_BLOCK) void k_tile_emit(JobView J, PlanArgs P, i
 // ------------------------------------------------------------------------------------------------------------
 struct CostArgs {
     float pc, pc2;
-    int32_t split;     // 0: narrow tiles, all ends of the tile in one LDS array together with the starts; 1: wide tiles
-    int32_t TK;        // end sites per wide tile
-    int32_t KS;        // uint2 entries per sample row of the E array (ends; narrow tiles: also the starts)
-    int32_t IS;        // entries per sample row of the S array (starts of a wide tile), else 0
     int32_t NS;        // samples per LDS group
     int32_t pad;
 };
@@ -566,15 +564,81 @@ __device__ __forceinline__ int wg_group_start(const ChunkDesc& cd, int k)
     return a <= cd.start0 ? 0 : (int)(a - cd.start0);
 }
 
-template <int TI, int FAST>      // FAST = wg_term_mode(pseudo count)
+// Narrow tiles: TILE-LOCAL exclusive prefixes L[x] = sum of the sites ka .. ka+x-1, x = 0 .. cnt-1, of `ns` sample rows,
+// (meth | cov << 16) packed in one dword each — a narrow tile spans <= WG_NARROW_ROW - 1 <= 124 sites, so both sums
+// stay below 2^15, and a block's counts are a difference of two entries of the same row: no carry of k_scan needed.
+// Two sample rows per wavefront pass (one per 32-lane half, 4 sites per lane, 8-byte loads), wave `wv` of 4.
+template <int ROW>
+__device__ __forceinline__ void wg_stage_local_rows(uint32_t* __restrict__ Et, const uint8_t* __restrict__ betas, int64_t pitch,
+                                                    int s_first, int ns, const ChunkDesc& cd, int64_t n_total, int ka, int cnt,
+                                                    int lane, int wv)
+{
+    const int half = lane >> 5, l5 = lane & 31;
+    const int64_t abs0 = cd.start0 + ka;
+    const int64_t al = abs0 & ~3LL;                    // 8-byte aligned
+    const int hs = (int)(abs0 - al);
+    const int sidx = l5 * 4;                           // site offset of this lane from `al`
+    const int64_t a = al + sidx;
+    const int nsite = cnt - 1;                         // sites ka .. ka+cnt-2 are summed
+    for (int r0 = wv * 2; r0 < ns; r0 += 2 * (WG_BLOCK / 64)) {
+        const int rr = r0 + half;
+        const bool act = rr < ns;
+        uint32_t w0 = 0, w1 = 0;
+        if (act && sidx < nsite + hs) {
+            const uint8_t* row = betas + (int64_t)(s_first + rr) * pitch;
+            if (a + 4 <= n_total) {
+                const uint2 v = *reinterpret_cast<const uint2*>(row + 2 * a);
+                w0 = v.x; w1 = v.y;
+            } else {
+                for (int j = 0; j < 4; j++) if (a + j < n_total) {
+                    const uint32_t h = (uint32_t)row[2 * (a + j)] | ((uint32_t)row[2 * (a + j) + 1] << 8);
+                    if (j < 2) w0 |= h << (16 * j); else w1 |= h << (16 * (j - 2));
+                }
+            }
+        }
+        uint32_t mt[4];
+        uint32_t tot = 0;                              // packed lane total: meth | cov << 16 (<= 1020 each)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t h = ((j < 2) ? w0 : w1) >> (16 * (j & 1));
+            const int x = sidx + j - hs;               // site index relative to ka
+            const bool in = x >= 0 && x < nsite;
+            mt[j] = in ? ((h & 0xffu) | ((h & 0xff00u) << 8)) : 0u;
+            tot += mt[j];
+        }
+        const uint32_t incl = wg_half_incl_scan_dpp_u32(tot);    // <= 32*1020 per field: no carry between the fields
+        uint32_t e = incl - tot;
+        uint32_t* dst = Et + (size_t)rr * ROW;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = sidx + j - hs;
+            if (act && x >= 0 && x < cnt) dst[x] = e;
+            e += mt[j];
+        }
+    }
+}
+
+#define WG_NARROW_WMAX  60          // widest window of a narrow tile: TI + 60 + 1 <= 125 entries, + 3 of alignment <= 128 = 32 lanes x 4 sites
+#define WG_WIDE_TK      128         // end sites per wide tile
+#define WG_WIDE_TS      16          // start sites per wide tile
+
+// Scored blocks of one tile.  SPLIT 0: narrow tile, TI start sites whose windows are all <= WG_NARROW_WMAX, prefixes
+// tile-local and packed (wg_stage_local_rows).  SPLIT 1: wide tile, WG_WIDE_TS start sites x WG_WIDE_TK end sites,
+// prefixes of starts and ends staged separately from the carries of k_scan.  The LDS row strides are compile-time
+// constants: the sample loop is unrolled by four with the row offsets in the instructions' offset fields.
+template <int TI, int FAST, int SPLIT>      // FAST = wg_term_mode(pseudo count)
 __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, CostArgs A, const TileDesc* __restrict__ tiles,
                                                    int64_t n_tiles, double* __restrict__ cost, int64_t n_tiles_padded)
 {
+    constexpr int KS = SPLIT ? WG_WIDE_TK + 1 : TI + WG_NARROW_WMAX + 1;   // entries per sample row of the E array
+    constexpr int IS = SPLIT ? WG_WIDE_TS + 1 : 0;                         // entries per sample row of the S array
     extern __shared__ __attribute__((aligned(16))) char smem[];
     wg_fast_tables* tb = reinterpret_cast<wg_fast_tables*>(smem);
-    uint2* Et = reinterpret_cast<uint2*>(smem + sizeof(wg_fast_tables));         // [NS][KS]  P[i+1] of the ends
-    uint2* St = Et + (size_t)A.NS * A.KS;                                        // [NS][IS]  P[k] of the starts (wide tiles)
-    int64_t* radj = reinterpret_cast<int64_t*>(St + (size_t)A.NS * A.IS);        // [TI]
+    uint2* Et = reinterpret_cast<uint2*>(smem + sizeof(wg_fast_tables));         // wide: [NS][KS] P[i+1] of the ends
+    uint2* St = Et + (size_t)A.NS * KS;                                          // wide: [NS][IS] P[k] of the starts
+    uint32_t* Lt = reinterpret_cast<uint32_t*>(smem + sizeof(wg_fast_tables));   // narrow: [NS][KS] packed local prefixes
+    char* after = SPLIT ? reinterpret_cast<char*>(St + (size_t)A.NS * IS) : reinterpret_cast<char*>(Lt + (((size_t)A.NS * KS + 1) & ~(size_t)1));
+    int64_t* radj = reinterpret_cast<int64_t*>(after);                           // [TI]
     int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
     int32_t* ist = offs + (TI + 1);                                              // [TI] first end of start kl in this unit
     int32_t* misc = ist + TI;                                                    // [2 (+1 pad)]
@@ -590,8 +654,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const ChunkDesc cd = J.chunks[c];
     const int ka = td.ka, nk = td.nk, kb = ka + nk;      // start sites [ka, kb)
     // end-site tile [et_lo, et_hi) of a wide tile; narrow tiles: no restriction
-    const int et_lo = A.split ? td.et_lo : 0;
-    const int et_hi = A.split ? et_lo + A.TK : (1 << 30);
+    const int et_lo = SPLIT ? td.et_lo : 0;
+    const int et_hi = SPLIT ? et_lo + WG_WIDE_TK : (1 << 30);
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
 
     wg_fast_tables_to_lds(tb, tid, WG_BLOCK);
@@ -621,18 +685,13 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int Q = offs[nk];
     if (Q == 0) return;
     const int imin = misc[0], imax = misc[1];
-    // E array: P[x] for x = eA .. imax+1 (ends use P[i+1]); in a narrow tile the starts' P[k], k >= ka = eA, live there too.
-    const int eA = A.split ? imin + 1 : ka;
-    const int eG = wg_group_start(cd, eA);               // carry position the scan of the row starts from
+    // wide: E array = P[x] for x = eA .. imax+1 (ends use P[i+1]), S array = P[k] for k = ka .. kb-1.
+    // narrow: one array L[x - ka], x = ka .. imax+1, serves both.
+    const int eA = SPLIT ? imin + 1 : ka;
+    const int eG = wg_group_start(cd, eA);               // carry position the scan of a wide row starts from
     const int Ecnt = imax + 2 - eA;
-    int sA;                                              // S entries: index k - sA
-    const uint2* Sbase;
-    int Sstride;
-    if (A.split) { sA = ka; Sbase = St; Sstride = A.IS; }
-    else          { sA = eA; Sbase = Et; Sstride = A.KS; }
-    const int sG = wg_group_start(cd, sA);
-    const int soff = ka - sA;                            // P[k] of start kl at S[soff + kl]
-    const int Scnt = kb - sA;
+    const int sG = wg_group_start(cd, ka);
+    const int Scnt = kb - ka;
 
     // Blocks of the tile, flattened: q -> (kl, i).  Every thread walks its blocks q = tid, tid+256, ...; for each it
     // runs the samples of the LDS-resident group IN FILE ORDER, carrying the double sum in a register (and, when the
@@ -645,12 +704,16 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
         const int ns = (J.n_samples - g0 < A.NS) ? J.n_samples - g0 : A.NS;
         const bool firstg = g0 == 0, lastg = g0 + ns >= J.n_samples;
         __syncthreads();
-        for (int rr = wv; rr < ns; rr += WG_BLOCK / 64) {
-            const int s = g0 + rr;
-            const uint8_t* row = J.betas + (int64_t)s * J.pitch;
-            const uint2* carry = J.carry + cd.carry_off + (int64_t)s * cd.nG;
-            wg_stage_prefix_row(Et + (size_t)rr * A.KS, row, carry, cd, J.n_total, eG, eA - eG, Ecnt, lane);
-            if (A.split) wg_stage_prefix_row(St + (size_t)rr * A.IS, row, carry, cd, J.n_total, sG, sA - sG, Scnt, lane);
+        if (SPLIT) {
+            for (int rr = wv; rr < ns; rr += WG_BLOCK / 64) {
+                const int s = g0 + rr;
+                const uint8_t* row = J.betas + (int64_t)s * J.pitch;
+                const uint2* carry = J.carry + cd.carry_off + (int64_t)s * cd.nG;
+                wg_stage_prefix_row(Et + (size_t)rr * KS, row, carry, cd, J.n_total, eG, eA - eG, Ecnt, lane);
+                wg_stage_prefix_row(St + (size_t)rr * IS, row, carry, cd, J.n_total, sG, ka - sG, Scnt, lane);
+            }
+        } else {
+            wg_stage_local_rows<KS>(Lt, J.betas, J.pitch, g0, ns, cd, J.n_total, ka, Ecnt, lane, wv);
         }
         __syncthreads();
         int qi = 0;
@@ -658,17 +721,35 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             int lo = 0, hi = nk;                           // largest kl with offs[kl] <= q
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
             const int i = ist[lo] + (q - offs[lo]);
-            const uint2* Ep = Et + (i + 1 - eA);           // P[i+1] of sample sl at Ep[sl * KS]
-            const uint2* Sp = Sbase + soff + lo;           // P[k]   of sample sl at Sp[sl * Sstride]
             double acc = firstg ? 0.0 : accR[qi];
-            for (int sl = 0; sl < ns; sl++) {
-                const uint2 pi = Ep[(size_t)sl * A.KS];
-                const uint2 pk = Sp[(size_t)sl * Sstride];
-                const float nm = (float)(pi.x - pk.x);
-                const float nt = (float)(pi.y - pk.y);
+            // sample loop, unrolled by four by hand (the optimiser leaves a loop with the rare exact path inside alone):
+            // one address update per four evaluations, the row offsets sit in the instructions' offset fields
+            auto term = [&](float nm, float nt) -> double {
                 const float ll = FAST == 2 ? wg_sample_term_pcpos_nz(nm, nt, pc, pc2, tb, &g_wg_tables)
                                : (FAST == 1 ? wg_sample_term(nm, nt, pc, pc2, tb, &g_wg_tables) : wg_sample_term_plain(nm, nt, pc, pc2, &g_wg_tables));
-                acc += (double)ll;                                               // segmentor.cpp:135
+                return (double)ll;                                               // segmentor.cpp:135 adds the float term to the double sum
+            };
+            if (SPLIT) {
+                const uint2* Ep = Et + (i + 1 - eA);       // P[i+1] of sample sl at Ep[sl * KS]
+                const uint2* Sp = St + lo;                 // P[k]   of sample sl at Sp[sl * IS]
+                auto one = [&](int sl) {
+                    const uint2 pi = Ep[sl * KS];
+                    const uint2 pk = Sp[sl * IS];
+                    acc += term((float)(pi.x - pk.x), (float)(pi.y - pk.y));
+                };
+                int sl = 0;
+                for (; sl + 4 <= ns; sl += 4) { one(sl); one(sl + 1); one(sl + 2); one(sl + 3); }
+                for (; sl < ns; sl++) one(sl);
+            } else {
+                const uint32_t* Ep = Lt + (i + 1 - ka);    // L[i+1-ka] of sample sl at Ep[sl * KS]
+                const uint32_t* Sp = Lt + lo;              // L[k-ka]
+                auto one = [&](int sl) {
+                    const uint32_t d = Ep[sl * KS] - Sp[sl * KS];                // both fields at once: no borrow, L is monotone per field
+                    acc += term((float)(d & 0xffffu), (float)(d >> 16));
+                };
+                int sl = 0;
+                for (; sl + 4 <= ns; sl += 4) { one(sl); one(sl + 1); one(sl + 2); one(sl + 3); }
+                for (; sl < ns; sl++) one(sl);
             }
             if (lastg) cb[radj[lo] + i] = (acc != 0.0) ? acc : 0.0;              // segmentor.cpp:106,137
             else accR[qi] = acc;

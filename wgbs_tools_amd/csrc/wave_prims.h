@@ -92,6 +92,17 @@ __device__ __forceinline__ uint32_t wg_wave_incl_scan_dpp_u32(uint32_t v)
     return v;
 }
 
+// The same within each 32-lane half of the wavefront (two independent scans): the last broadcast step is left out.
+__device__ __forceinline__ uint32_t wg_half_incl_scan_dpp_u32(uint32_t v)
+{
+    v += wg_dpp_or0_u32<WG_DPP_ROW_SHR(1), 0xf>(v);
+    v += wg_dpp_or0_u32<WG_DPP_ROW_SHR(2), 0xf>(v);
+    v += wg_dpp_or0_u32<WG_DPP_ROW_SHR(4), 0xf>(v);
+    v += wg_dpp_or0_u32<WG_DPP_ROW_SHR(8), 0xf>(v);
+    v += wg_dpp_or0_u32<WG_DPP_BCAST15, 0xa>(v);
+    return v;
+}
+
 // Inclusive prefix sum over the 64 lanes (uint32, wrap-around).  Kogge-Stone with ds_bpermute-free shuffles:
 // __shfl_up is used here (LDS-crossbar permute); this primitive sits in bandwidth/latency-tolerant kernels.
 __device__ __forceinline__ uint32_t wg_wave_incl_scan_u32(uint32_t v, int lane)

@@ -414,25 +414,27 @@ int report_bad_site(const wgbsseg_ctx* c, const JobStatus& st, char* err, size_t
     return WGBSSEG_E_METH_GT_COV;
 }
 
-template <int TI, int FAST>
+template <int TI, int FAST, int SPLIT>
 hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
     const int64_t padded = round_up(tiles, 8);
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cost<TI, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cost<TI, FAST, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_cost<TI, FAST>), dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, td, tiles, cost, padded);
+    hipLaunchKernelGGL((k_cost<TI, FAST, SPLIT>), dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, td, tiles, cost, padded);
     return hipGetLastError();
 }
 
+// narrow tiles: TI start sites (64 / 32 / 16); wide tiles: WG_WIDE_TS start sites x WG_WIDE_TK end sites
 template <int FAST>
-hipError_t launch_cost_ti(int TI, const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
+hipError_t launch_cost_ti(int TI, bool wide, const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
-    if (TI == 64) return launch_cost<64, FAST>(v, sv, a, td, tiles, cost, lds, s);
-    if (TI == 32) return launch_cost<32, FAST>(v, sv, a, td, tiles, cost, lds, s);
-    return launch_cost<16, FAST>(v, sv, a, td, tiles, cost, lds, s);
+    if (wide) return launch_cost<WG_WIDE_TS, FAST, 1>(v, sv, a, td, tiles, cost, lds, s);
+    if (TI == 64) return launch_cost<64, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
+    if (TI == 32) return launch_cost<32, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
+    return launch_cost<16, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
 }
 
 void grow_events(std::vector<hipEvent_t>& v, size_t n)
@@ -511,19 +513,20 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const int64_t total_pairs = (int64_t)st.total_pairs;
 
     // ---- tiling of the scoring kernel ----------------------------------------------------------------------
-    // Narrow tiles (class A): TI aligned start sites whose windows are all <= WA = min(widest window, 64); LDS per
-    // workgroup: fast log tables + NS sample rows of TI+WA+1 prefixes + small per-tile arrays (+ partial sums when the
-    // samples need several groups).  The kernel is a long dependent chain per evaluation, so resident wavefronts
-    // matter: pick the shape that maximises (workgroups per CU) x (lane occupancy of the block rounds).
-    // Wide tiles (class B): 16 start sites x TK end sites, for every 16-site unit that shares an aligned TI-group with
-    // a window > WA (CpG islands; everything in deep mode).
+    // Narrow tiles (class A): TI aligned start sites whose windows are all <= WA = min(widest window, WG_NARROW_WMAX);
+    // LDS per workgroup: fast log tables + NS sample rows of TI+61 tile-local prefixes (one packed dword each) + small
+    // per-tile arrays.  The kernel is a long dependent chain per evaluation, so resident wavefronts matter: pick the
+    // shape that maximises (workgroups per CU) x (lane occupancy of the block rounds).
+    // Wide tiles (class B): 16 start sites x 128 end sites, for every 16-site unit that shares an aligned TI-group with
+    // a window > WA (CpG islands; everything in deep mode); prefixes of starts and ends as (meth, cov) dword pairs.
     const int Nsmp = (int)c->n_samples;
     const double Favg = (double)total_pairs / (double)std::max<int64_t>(1, J);
-    const int WA = std::min(Wmax, 64);
-    const int TKB = 128;
-    auto lds_for = [&](int ti, bool split, int w, int ns) -> size_t {
-        const int ks = split ? TKB + 1 : ti + w + 1, is = split ? ti + 1 : 0;
-        return sizeof(wg_fast_tables) + (size_t)ns * (ks + is) * 8 + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24;
+    const int WA = std::min(Wmax, WG_NARROW_WMAX);
+    const int TKB = WG_WIDE_TK;
+    auto lds_for = [&](int ti, bool split, int ns) -> size_t {
+        const size_t rows = split ? (size_t)ns * (WG_WIDE_TK + 1 + WG_WIDE_TS + 1) * 8                      // P of the ends + P of the starts, (meth, cov) as two dwords
+                                  : ((((size_t)ns * (ti + WG_NARROW_WMAX + 1) + 1) & ~(size_t)1) * 4);     // tile-local prefixes, packed in one dword
+        return sizeof(wg_fast_tables) + rows + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24;
     };
     int TI = 64, NSA = 1, NSB = 1;
     {
@@ -534,7 +537,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
             for (int ns : ns_opts) {
                 if (ns > Nsmp) continue;
                 if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
-                const size_t l = lds_for(ti, false, WA, ns);
+                const size_t l = lds_for(ti, false, ns);
                 if (l > 64 * 1024) continue;
                 const int wgs = (int)std::min<size_t>(4, (160 * 1024) / l);          // 4 workgroups = 4 waves/SIMD already saturate the VALU (measured: TI 64 at 4 beats TI 32 at 6 by 4 %)
                 const double q = ti * std::min<double>(Favg, WA), eff = q / (256.0 * std::ceil(q / 256.0));
@@ -549,7 +552,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         for (int ns : ns_opts) {
             if (ns > Nsmp) continue;
             if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
-            const size_t l = lds_for(16, true, 0, ns);
+            const size_t l = lds_for(WG_WIDE_TS, true, ns);
             if (l > 64 * 1024) continue;
             const int wgs = (int)std::min<size_t>(6, (160 * 1024) / l);
             const double groups = std::ceil((double)Nsmp / ns);
@@ -561,10 +564,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     memset(&caA, 0, sizeof(caA));
     caA.pc = P->pseudo_count; caA.pc2 = P->pseudo_count + P->pseudo_count;
     caB = caA;
-    caA.split = 0; caA.TK = 0; caA.KS = TI + WA + 1; caA.IS = 0; caA.NS = NSA;
-    caB.split = 1; caB.TK = TKB; caB.KS = TKB + 1; caB.IS = 17; caB.NS = NSB;
-    const size_t ldsA = (size_t)round_up((int64_t)lds_for(TI, false, WA, NSA), 16);
-    const size_t ldsB = (size_t)round_up((int64_t)lds_for(16, true, 0, NSB), 16);
+    caA.NS = NSA;
+    caB.NS = NSB;
+    const size_t ldsA = (size_t)round_up((int64_t)lds_for(TI, false, NSA), 16);
+    const size_t ldsB = (size_t)round_up((int64_t)lds_for(WG_WIDE_TS, true, NSB), 16);
     const int term_mode = wg_term_mode(P->pseudo_count);
 
     // ---- stages: bound the scored-block buffer and overlap scoring (stream A) with the recurrence (stream B) --
@@ -655,16 +658,16 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipEventRecord(c->ev_cost0[stg], c->sA));
         if (stage_tiles[2 * (size_t)stg] > 0) {
             const TileDesc* td = c->tilesA.as<TileDesc>() + tileA0[(size_t)stg];
-            hipError_t e = term_mode == 2 ? launch_cost_ti<2>(TI, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
-                         : (term_mode == 1 ? launch_cost_ti<1>(TI, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
-                                           : launch_cost_ti<0>(TI, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA));
+            hipError_t e = term_mode == 2 ? launch_cost_ti<2>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
+                         : (term_mode == 1 ? launch_cost_ti<1>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
+                                           : launch_cost_ti<0>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA));
             HIP_TRY(e);
         }
         if (stage_tiles[2 * (size_t)stg + 1] > 0) {
             const TileDesc* td = c->tilesB.as<TileDesc>() + tileB0[(size_t)stg];
-            hipError_t e = term_mode == 2 ? launch_cost_ti<2>(16, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
-                         : (term_mode == 1 ? launch_cost_ti<1>(16, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
-                                           : launch_cost_ti<0>(16, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA));
+            hipError_t e = term_mode == 2 ? launch_cost_ti<2>(TI, true, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
+                         : (term_mode == 1 ? launch_cost_ti<1>(TI, true, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
+                                           : launch_cost_ti<0>(TI, true, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA));
             HIP_TRY(e);
         }
         HIP_TRY(hipEventRecord(c->ev_cost1[stg], c->sA));
