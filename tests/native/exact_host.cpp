@@ -15,6 +15,13 @@ static wg_fast_tables make_fast()
     return f;
 }
 static const wg_fast_tables g_fast = make_fast();
+static wg_ky_table make_ky()
+{
+    wg_ky_table t;
+    for (int x = 0; x < (WG_KY_KMIN + 1) * 64; x++) { t.d_ky[x].a = g_tab.d_fast[x & 63].a; t.d_ky[x].b = (double)((x >> 6) - WG_KY_KMIN) + g_tab.d_fast[x & 63].b; }
+    return t;
+}
+static const wg_ky_table g_ky = make_ky();
 
 template <class F> static void par_for(uint64_t count, int threads, F f)
 {
@@ -80,6 +87,27 @@ void exact_log2_1mp_fill(uint32_t first, uint64_t count, uint64_t* out, int thre
             out[q] = wg_d2u(wg_log2(1.0 - (double)wg_u2f(first + (uint32_t)q), g_tab.d_tab, g_tab.d_tab2));
     });
 }
+// wg_fast_log2_ky against wg_fast_log2 on x = 1 - p for `count` consecutive floats p from `first`: number of mismatches
+// (inputs whose exponent lies below the table's first row are skipped and counted in *skipped)
+uint64_t exact_fast_log2_ky_mismatches(uint32_t first, uint64_t count, int threads, uint64_t* skipped)
+{
+    std::vector<uint64_t> bad((size_t)(threads < 1 ? 1 : threads), 0), skip(bad.size(), 0);
+    std::vector<std::thread> th;
+    const int T = (int)bad.size();
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t]() {
+            for (uint64_t q = count * t / T; q < count * (t + 1) / T; q++) {
+                const double x = 1.0 - (double)wg_u2f(first + (uint32_t)q);
+                if (!(x > 0.6875 * 0x1p-13)) { skip[(size_t)t]++; continue; }
+                if (wg_d2u(wg_fast_log2_ky(x, g_ky.d_ky)) != wg_d2u(wg_fast_log2(x, g_tab.d_fast))) bad[(size_t)t]++;
+            }
+        });
+    for (auto& x : th) x.join();
+    uint64_t b = 0, sk = 0;
+    for (int t = 0; t < T; t++) { b += bad[(size_t)t]; sk += skip[(size_t)t]; }
+    if (skipped) *skipped = sk;
+    return b;
+}
 void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, float pc, float* out)
 {
     float pc2 = pc + pc;
@@ -91,6 +119,11 @@ void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, 
             const float a = wg_sample_term_pcpos(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab);
             const float b = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab);
             out[q] = (wg_f2u(a) == wg_f2u(b) || (a == 0.0f && b == 0.0f && ntotal[q] == 0.0f)) ? a : __builtin_nanf("");
+            // and with (double)k + logc looked up (narrow scoring tiles: blocks of <= 60 sites): bit-identical to the computed form
+            if (ntotal[q] <= 255.0f * 60.0f) {
+                const float c = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab, g_ky.d_ky);
+                if (wg_f2u(c) != wg_f2u(b)) out[q] = __builtin_nanf("");
+            }
         } else {
             out[q] = mode == 1 ? wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab) : wg_sample_term_plain(nmeth[q], ntotal[q], pc, pc2, &g_tab);
         }

@@ -144,6 +144,11 @@ struct wg_fast_tables {
     wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}
     wg_d2 f_iy[(WG_Y0_KMIN + 1) * 16];    // log2f: {invc[i], y0 = logc[i] + (double)k} at [(k + 25) * 16 + i] — the SAME addition, done once; one 16-byte read
 };
+// Narrow scoring tiles with a pseudo count >= 4 (guard-free form) also keep, per (k, i), {invc[i], (double)k + logc[i]} of the
+// fast log2 — again the very addition wg_fast_log2 performs, done once: 1 - p >= pc / (255 * 60 + 2 pc) > 0.6875 * 2^-12
+// there, so its exponent k lies in [-12, 0]; rows k = -WG_KY_KMIN .. 0.
+#define WG_KY_KMIN 13
+struct wg_ky_table { wg_d2 d_ky[(WG_KY_KMIN + 1) * 64]; };     // 14 KB
 // The fast log2 uses d_tab with ONE entry changed: interval 39 = [0.9921875, 1) gets the centre exactly 1
 // (invc = 1, logc = 0), so that arguments just below 1 need no separate cancellation-free branch.
 // (Interval 40 = [1, 1.015625) cannot be treated the same way: it also serves z = 2^-k x for x in [0.5, 0.5078) etc.)
@@ -349,6 +354,23 @@ WG_HD double wg_fast_log2(double x, const wg_d2* __restrict__ dfast)
     return WG_FMA(q, r, (double)k + logc);
 }
 
+// wg_fast_log2 with (double)k + logc looked up (wg_ky_table) instead of computed: (hi >> 14) arithmetically IS k * 64 + i.
+// Same operations on the same values otherwise, hence the same bits; x must have its exponent k >= -WG_KY_KMIN.
+WG_HD double wg_fast_log2_ky(double x, const wg_d2* __restrict__ ky)
+{
+    const uint64_t ix = wg_d2u(x);
+    const uint32_t xhi = (uint32_t)(ix >> 32);
+    const uint32_t hi = xhi - 0x3fe60000u;
+    const int32_t ki = (int32_t)hi >> 14;                        // k * 64 + i
+    const uint64_t iz = ((uint64_t)(xhi - (hi & 0xfff00000u)) << 32) | (uint32_t)ix;
+    const wg_d2 e = ky[ki + WG_KY_KMIN * 64];
+    const double r = WG_FMA_K(wg_u2d(iz), e.a, -1.0);
+    double q = WG_LOG2_A5;
+    q = WG_FMA_K(q, r, WG_LOG2_A4); q = WG_FMA_K(q, r, WG_LOG2_A3); q = WG_FMA_K(q, r, WG_LOG2_A2);
+    q = WG_FMA_K(q, r, WG_LOG2_A1); q = WG_FMA_K(q, r, WG_LOG2_A0); q = WG_FMA_K(q, r, WG_LOG2_INVLN2);
+    return WG_FMA(q, r, e.b);
+}
+
 // The reference's per-(block, sample) log-likelihood term, segmentor.cpp:125-135, on exact integer counts.
 //   nmeth, ntotal : block sums of the sample (exact in float: 255*max_cpg < 2^24 is enforced by the ABI)
 //   pc, pc2       : pseudo_count and pseudo_count+pseudo_count (== the reference's float `2 * pseudo_count`)
@@ -442,14 +464,15 @@ WG_HD float wg_sample_term_pcpos(float nmeth, float ntotal, float pc, float pc2,
 // The same without the zero-coverage exception, for callers that ADD the term to a running sum (the scoring kernel):
 // with ntotal == 0, p = 1/2, ll = 0 * log2f = -0.0, df = 0, s = -0.0 + 0 * L = -0.0, and adding -0.0 to the running
 // double sum leaves it unchanged, bit for bit — the reference's `continue` (:125) without a branch.
+// ky: NULL, or the wg_ky_table of a caller whose blocks are short enough for it (narrow scoring tiles).
 WG_HD float wg_sample_term_pcpos_nz(float nmeth, float ntotal, float pc, float pc2, const wg_fast_tables* __restrict__ ft,
-                                    const wg_log_tables* __restrict__ xt)
+                                    const wg_log_tables* __restrict__ xt, const wg_d2* __restrict__ ky = nullptr)
 {
     const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
     const float ll = nmeth * wg_log2f_y0(p, ft->f_iy);  // :129-131
     const float df = ntotal - nmeth;
     const double x = 1.0 - (double)p;                              // :132-134
-    const double s = (double)ll + (double)df * wg_fast_log2(x, ft->d_fast);
+    const double s = (double)ll + (double)df * (ky ? wg_fast_log2_ky(x, ky) : wg_fast_log2(x, ft->d_fast));
     float res = (float)s;
     if (wg_in_guard_band(s))
         res = (float)((double)ll + (double)df * wg_log2(1.0 - (double)wg_opaque_f32(p), xt->d_tab, xt->d_tab2));   // x recomputed: not kept live for the rare path

@@ -55,6 +55,18 @@ __device__ __forceinline__ void wg_fast_tables_to_lds(wg_fast_tables* ft, int ti
     }
 }
 
+// The {invc, k + logc} table of wg_fast_log2_ky, from the fast-log2 table of the same workgroup's ft (global source: no barrier needed).
+__device__ __forceinline__ void wg_ky_table_to_lds(wg_ky_table* kt, int tid, int nthreads)
+{
+    const double* d = reinterpret_cast<const double*>(g_wg_tables.d_tab);
+    for (int x = tid; x < (WG_KY_KMIN + 1) * 64; x += nthreads) {
+        const int i = x & 63;
+        const bool centre = i == WG_FAST_CENTRE_ENTRY;           // wg_tables_finish(): interval just below 1 centred on 1
+        kt->d_ky[x].a = centre ? 1.0 : d[2 * i];
+        kt->d_ky[x].b = (double)((x >> 6) - WG_KY_KMIN) + (centre ? 0.0 : d[2 * i + 1]);   // (double)k + logc, exactly as wg_fast_log2 adds them
+    }
+}
+
 struct ChunkDesc {
     int64_t start0;      // first site (0-based, absolute)
     int64_t site_off;    // offset of this chunk in the job-site arrays (W16, cum32, back16)
@@ -632,11 +644,15 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 {
     constexpr int KS = SPLIT ? WG_WIDE_TK + 1 : TI + WG_NARROW_WMAX + 1;   // entries per sample row of the E array
     constexpr int IS = SPLIT ? WG_WIDE_TS + 1 : 0;                         // entries per sample row of the S array
+    constexpr bool KY = (FAST == 2) && !SPLIT;                                   // blocks of <= 60 sites, pseudo count >= 4: k + logc looked up
+    constexpr size_t TB = sizeof(wg_fast_tables) + (KY ? sizeof(wg_ky_table) : 0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     wg_fast_tables* tb = reinterpret_cast<wg_fast_tables*>(smem);
-    uint2* Et = reinterpret_cast<uint2*>(smem + sizeof(wg_fast_tables));         // wide: [NS][KS] P[i+1] of the ends
+    wg_ky_table* kyt = reinterpret_cast<wg_ky_table*>(smem + sizeof(wg_fast_tables));
+    const wg_d2* ky = KY ? kyt->d_ky : nullptr;
+    uint2* Et = reinterpret_cast<uint2*>(smem + TB);                             // wide: [NS][KS] P[i+1] of the ends
     uint2* St = Et + (size_t)A.NS * KS;                                          // wide: [NS][IS] P[k] of the starts
-    uint32_t* Lt = reinterpret_cast<uint32_t*>(smem + sizeof(wg_fast_tables));   // narrow: [NS][KS] packed local prefixes
+    uint32_t* Lt = reinterpret_cast<uint32_t*>(smem + TB);                       // narrow: [NS][KS] packed local prefixes
     char* after = SPLIT ? reinterpret_cast<char*>(St + (size_t)A.NS * IS) : reinterpret_cast<char*>(Lt + (((size_t)A.NS * KS + 1) & ~(size_t)1));
     int64_t* radj = reinterpret_cast<int64_t*>(after);                           // [TI]
     int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
@@ -659,6 +675,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
 
     wg_fast_tables_to_lds(tb, tid, WG_BLOCK);
+    if (KY) wg_ky_table_to_lds(kyt, tid, WG_BLOCK);
     if (wv == 0) {
         const int k = ka + lane;
         const bool valid = lane < nk;
@@ -725,7 +742,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             // sample loop, unrolled by four by hand (the optimiser leaves a loop with the rare exact path inside alone):
             // one address update per four evaluations, the row offsets sit in the instructions' offset fields
             auto term = [&](float nm, float nt) -> double {
-                const float ll = FAST == 2 ? wg_sample_term_pcpos_nz(nm, nt, pc, pc2, tb, &g_wg_tables)
+                const float ll = FAST == 2 ? wg_sample_term_pcpos_nz(nm, nt, pc, pc2, tb, &g_wg_tables, ky)
                                : (FAST == 1 ? wg_sample_term(nm, nt, pc, pc2, tb, &g_wg_tables) : wg_sample_term_plain(nm, nt, pc, pc2, &g_wg_tables));
                 return (double)ll;                                               // segmentor.cpp:135 adds the float term to the double sum
             };

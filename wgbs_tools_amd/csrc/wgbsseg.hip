@@ -526,7 +526,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     auto lds_for = [&](int ti, bool split, int ns) -> size_t {
         const size_t rows = split ? (size_t)ns * (WG_WIDE_TK + 1 + WG_WIDE_TS + 1) * 8                      // P of the ends + P of the starts, (meth, cov) as two dwords
                                   : ((((size_t)ns * (ti + WG_NARROW_WMAX + 1) + 1) & ~(size_t)1) * 4);     // tile-local prefixes, packed in one dword
-        return sizeof(wg_fast_tables) + rows + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24;
+        const size_t ky = (!split && wg_term_mode(P->pseudo_count) == 2) ? sizeof(wg_ky_table) : 0;     // k_cost's KY table
+        return sizeof(wg_fast_tables) + ky + rows + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24;
     };
     int TI = 64, NSA = 1, NSB = 1;
     {
