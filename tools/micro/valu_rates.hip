@@ -1,0 +1,59 @@
+// Issue cost (cycles per wavefront instruction per SIMD) of the VALU instructions k_cost's evaluation is made of,
+// measured with every SIMD holding 4 wavefronts of independent instruction streams:
+//   hipcc --offload-arch=gfx950 -O3 -o _build/valu_rates valu_rates.hip && _build/valu_rates
+// cycles = elapsed * clock / (instructions per wavefront * wavefronts per SIMD); clock from the v_add_f32 row (= 4).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+#define REP8(X) X X X X X X X X
+template <int OP>
+__global__ __launch_bounds__(256) void k(int iters, float* out, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
+    double d0 = a0, d1 = a1, d2 = a2, d3 = a3;
+    int i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3;
+    for (int it = 0; it < iters; it++) {
+        if (OP == 0) { REP8(asm volatile("v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if (OP == 1) { REP8(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if (OP == 2) { REP8(asm volatile("v_fma_f64 %0, %0, %0, %0\n v_fma_f64 %1, %1, %1, %1\n v_fma_f64 %2, %2, %2, %2\n v_fma_f64 %3, %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));) }
+        if (OP == 3) { REP8(asm volatile("v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %6\n v_cvt_f64_f32 %3, %7" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));) }
+        if (OP == 4) { REP8(asm volatile("v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %1, %5\n v_cvt_f32_f64 %2, %6\n v_cvt_f32_f64 %3, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(d0), "v"(d1), "v"(d2), "v"(d3));) }
+        if (OP == 5) { REP8(asm volatile("v_cvt_f64_i32 %0, %4\n v_cvt_f64_i32 %1, %5\n v_cvt_f64_i32 %2, %6\n v_cvt_f64_i32 %3, %7" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
+        if (OP == 6) { REP8(asm volatile("v_add_f64 %0, %0, %0\n v_add_f64 %1, %1, %1\n v_add_f64 %2, %2, %2\n v_add_f64 %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));) }
+        if (OP == 7) { REP8(asm volatile("v_mul_f64 %0, %0, %0\n v_mul_f64 %1, %1, %1\n v_mul_f64 %2, %2, %2\n v_mul_f64 %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));) }
+        if (OP == 8) { REP8(asm volatile("v_cvt_f32_u32 %0, %4\n v_cvt_f32_u32 %1, %5\n v_cvt_f32_u32 %2, %6\n v_cvt_f32_u32 %3, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
+        if (OP == 9) { REP8(asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if (OP == 10) { REP8(asm volatile("v_lshl_add_u32 %0, %0, 3, %0\n v_lshl_add_u32 %1, %1, 3, %1\n v_lshl_add_u32 %2, %2, 3, %2\n v_lshl_add_u32 %3, %3, 3, %3" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 11) { REP8(asm volatile("v_cvt_f32_u32_sdwa %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %1, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %2, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %3, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
+    }
+    if (a0 + a1 + a2 + a3 + (float)(d0 + d1 + d2 + d3) + (float)(i0 + i1 + i2 + i3) == 12345.678f) out[0] = a0;
+}
+
+template <int OP> double run(const char* name, float* out, double clock_hz)
+{
+    const int iters = 4000, wgs = 256 * 4;          // 4 workgroups of 4 wavefronts per CU: 4 wavefronts per SIMD
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<OP>, wgs, 256, 0, 0, 10, out, 1.5f);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<OP>, wgs, 256, 0, 0, iters, out, 1.5f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double per_simd = (double)iters * 32 * 4;  // wavefront instructions per SIMD
+    const double cyc = ms * 1e-3 * clock_hz / per_simd;
+    printf("%-22s %8.3f ms  %6.2f cycles per wavefront instruction (at %.2f GHz)\n", name, ms, cyc, clock_hz * 1e-9);
+    return ms * 1e-3 / per_simd;
+}
+
+int main()
+{
+    float* out; hipMalloc(&out, 4);
+    const double t_add = run<0>("v_add_f32 (warm-up)", out, 2.4e9);
+    const double clock = 4.0 / t_add;               // v_add_f32 is 4 cycles by definition of the machine
+    printf("effective clock under this load: %.2f GHz\n", clock * 1e-9);
+    run<0>("v_add_f32", out, clock); run<9>("v_fma_f32", out, clock); run<10>("v_lshl_add_u32", out, clock);
+    run<1>("v_rcp_f32", out, clock); run<8>("v_cvt_f32_u32", out, clock); run<11>("v_cvt_f32_u32 sdwa", out, clock);
+    run<2>("v_fma_f64", out, clock); run<6>("v_add_f64", out, clock); run<7>("v_mul_f64", out, clock);
+    run<3>("v_cvt_f64_f32", out, clock); run<4>("v_cvt_f32_f64", out, clock); run<5>("v_cvt_f64_i32", out, clock);
+    return 0;
+}
