@@ -15,13 +15,16 @@ static wg_fast_tables make_fast()
     return f;
 }
 static const wg_fast_tables g_fast = make_fast();
-static wg_ky_table make_ky()
+struct ky_table { wg_d2 d_ky[(WG_KY_KMIN + 1) * 64]; };
+static ky_table make_ky()
 {
-    wg_ky_table t;
+    ky_table t;
     for (int x = 0; x < (WG_KY_KMIN + 1) * 64; x++) { t.d_ky[x].a = g_tab.d_fast[x & 63].a; t.d_ky[x].b = (double)((x >> 6) - WG_KY_KMIN) + g_tab.d_fast[x & 63].b; }
     return t;
 }
-static const wg_ky_table g_ky = make_ky();
+static const ky_table g_ky = make_ky();
+static const wg_d2* const g_ky0 = g_ky.d_ky + WG_KY_KMIN * 64;       // row k = 0
+static const wg_d2* const g_iy0 = g_fast.f_iy + WG_Y0_KMIN * 16;
 
 template <class F> static void par_for(uint64_t count, int threads, F f)
 {
@@ -99,7 +102,7 @@ uint64_t exact_fast_log2_ky_mismatches(uint32_t first, uint64_t count, int threa
             for (uint64_t q = count * t / T; q < count * (t + 1) / T; q++) {
                 const double x = 1.0 - (double)wg_u2f(first + (uint32_t)q);
                 if (!(x > 0.6875 * 0x1p-13)) { skip[(size_t)t]++; continue; }
-                if (wg_d2u(wg_fast_log2_ky(x, g_ky.d_ky)) != wg_d2u(wg_fast_log2(x, g_tab.d_fast))) bad[(size_t)t]++;
+                if (wg_d2u(wg_fast_log2_ky(x, g_ky0)) != wg_d2u(wg_fast_log2(x, g_tab.d_fast))) bad[(size_t)t]++;
             }
         });
     for (auto& x : th) x.join();
@@ -117,12 +120,17 @@ void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, 
             // the guard-free form with and without the zero-coverage exception (the latter is what the kernel runs, with
             // the y0 table): they may differ only in the sign of a zero when ntotal == 0; anything else comes back as NaN
             const float a = wg_sample_term_pcpos(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab);
-            const float b = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab);
+            const float b = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, g_iy0, g_fast.d_fast, nullptr, false, &g_tab);
             out[q] = (wg_f2u(a) == wg_f2u(b) || (a == 0.0f && b == 0.0f && ntotal[q] == 0.0f)) ? a : __builtin_nanf("");
             // and with (double)k + logc looked up (narrow scoring tiles: blocks of <= 60 sites): bit-identical to the computed form
+            // ... from tables holding exactly the rows wg_lookup_rows() grants this pseudo count (reads outside them are caught)
             if (ntotal[q] <= 255.0f * 60.0f) {
-                const float c = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab, g_ky.d_ky);
-                if (wg_f2u(c) != wg_f2u(b)) out[q] = __builtin_nanf("");
+                const int rows = wg_lookup_rows(pc, 255.0 * 60.0);
+                const float p = (nmeth[q] + pc) / (ntotal[q] + pc2);
+                const double x = 1.0 - (double)p;
+                const int kf = (int32_t)(wg_f2u(p) - 0x3f330000u) >> 23, kd = (int32_t)((uint32_t)(wg_d2u(x) >> 32) - 0x3fe60000u) >> 20;
+                const float c = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, g_iy0, nullptr, g_ky0, true, &g_tab);
+                if (wg_f2u(c) != wg_f2u(b) || rows > WG_KY_KMIN + 1 || kf > 0 || kd > 0 || kf < -(rows - 1) || kd < -(rows - 1)) out[q] = __builtin_nanf("");
             }
         } else {
             out[q] = mode == 1 ? wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab) : wg_sample_term_plain(nmeth[q], ntotal[q], pc, pc2, &g_tab);

@@ -146,9 +146,9 @@ struct wg_fast_tables {
 };
 // Narrow scoring tiles with a pseudo count >= 4 (guard-free form) also keep, per (k, i), {invc[i], (double)k + logc[i]} of the
 // fast log2 — again the very addition wg_fast_log2 performs, done once: 1 - p >= pc / (255 * 60 + 2 pc) > 0.6875 * 2^-12
-// there, so its exponent k lies in [-12, 0]; rows k = -WG_KY_KMIN .. 0.
+// there, so its exponent k lies in [-12, 0]: at most WG_KY_KMIN + 1 rows; how many a pseudo count really needs is
+// wg_lookup_rows() (11 at the default 15).  Those kernels size both lookup tables to that.
 #define WG_KY_KMIN 13
-struct wg_ky_table { wg_d2 d_ky[(WG_KY_KMIN + 1) * 64]; };     // 14 KB
 // The fast log2 uses d_tab with ONE entry changed: interval 39 = [0.9921875, 1) gets the centre exactly 1
 // (invc = 1, logc = 0), so that arguments just below 1 need no separate cancellation-free branch.
 // (Interval 40 = [1, 1.015625) cannot be treated the same way: it also serves z = 2^-k x for x in [0.5, 0.5078) etc.)
@@ -256,7 +256,7 @@ WG_HD float wg_log2f_y0(float x, const wg_d2* __restrict__ iytab)
     const uint32_t tmp = ix - 0x3f330000u;
     const int32_t ki = (int32_t)tmp >> 19;                       // k * 16 + i, k in [-25, 0]
     const uint32_t iz = ix - (tmp & 0xff800000u);
-    const wg_d2 e = iytab[ki + WG_Y0_KMIN * 16];                 // one shift-add for the address, one read for both
+    const wg_d2 e = iytab[ki];                                   // iytab points at the row of k = 0; one shift-add for the address, one read for both
     const double invc = e.a, y0 = e.b;
     const double r = WG_FMA_K((double)wg_u2f(iz), invc, -1.0);
     const double r2 = r * r;
@@ -355,7 +355,8 @@ WG_HD double wg_fast_log2(double x, const wg_d2* __restrict__ dfast)
 }
 
 // wg_fast_log2 with (double)k + logc looked up (wg_ky_table) instead of computed: (hi >> 14) arithmetically IS k * 64 + i.
-// Same operations on the same values otherwise, hence the same bits; x must have its exponent k >= -WG_KY_KMIN.
+// Same operations on the same values otherwise, hence the same bits; `ky` points at the entry of (k = 0, i = 0) and the
+// table must reach down to x's exponent k.
 WG_HD double wg_fast_log2_ky(double x, const wg_d2* __restrict__ ky)
 {
     const uint64_t ix = wg_d2u(x);
@@ -363,7 +364,7 @@ WG_HD double wg_fast_log2_ky(double x, const wg_d2* __restrict__ ky)
     const uint32_t hi = xhi - 0x3fe60000u;
     const int32_t ki = (int32_t)hi >> 14;                        // k * 64 + i
     const uint64_t iz = ((uint64_t)(xhi - (hi & 0xfff00000u)) << 32) | (uint32_t)ix;
-    const wg_d2 e = ky[ki + WG_KY_KMIN * 64];
+    const wg_d2 e = ky[ki];                                      // ky points at the row of k = 0
     const double r = WG_FMA_K(wg_u2d(iz), e.a, -1.0);
     double q = WG_LOG2_A5;
     q = WG_FMA_K(q, r, WG_LOG2_A4); q = WG_FMA_K(q, r, WG_LOG2_A3); q = WG_FMA_K(q, r, WG_LOG2_A2);
@@ -464,19 +465,32 @@ WG_HD float wg_sample_term_pcpos(float nmeth, float ntotal, float pc, float pc2,
 // The same without the zero-coverage exception, for callers that ADD the term to a running sum (the scoring kernel):
 // with ntotal == 0, p = 1/2, ll = 0 * log2f = -0.0, df = 0, s = -0.0 + 0 * L = -0.0, and adding -0.0 to the running
 // double sum leaves it unchanged, bit for bit — the reference's `continue` (:125) without a branch.
-// ky: NULL, or the wg_ky_table of a caller whose blocks are short enough for it (narrow scoring tiles).
-WG_HD float wg_sample_term_pcpos_nz(float nmeth, float ntotal, float pc, float pc2, const wg_fast_tables* __restrict__ ft,
-                                    const wg_log_tables* __restrict__ xt, const wg_d2* __restrict__ ky = nullptr)
+// iy0: log2f's {invc, y0} table at its row k = 0; dfast: the fast-log2 table; ky0 (use_ky): the {invc, k + logc} table at its
+// row k = 0 of a caller whose blocks are short enough for the rows it holds (narrow scoring tiles) — then dfast is unused.
+// (use_ky is a compile-time constant at every call site: the other table's code folds away.)
+WG_HD float wg_sample_term_pcpos_nz(float nmeth, float ntotal, float pc, float pc2, const wg_d2* __restrict__ iy0,
+                                    const wg_d2* __restrict__ dfast, const wg_d2* __restrict__ ky0, const bool use_ky,
+                                    const wg_log_tables* __restrict__ xt)
 {
     const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
-    const float ll = nmeth * wg_log2f_y0(p, ft->f_iy);  // :129-131
+    const float ll = nmeth * wg_log2f_y0(p, iy0);                  // :129-131
     const float df = ntotal - nmeth;
     const double x = 1.0 - (double)p;                              // :132-134
-    const double s = (double)ll + (double)df * (ky ? wg_fast_log2_ky(x, ky) : wg_fast_log2(x, ft->d_fast));
+    const double s = (double)ll + (double)df * (use_ky ? wg_fast_log2_ky(x, ky0) : wg_fast_log2(x, dfast));
     float res = (float)s;
     if (wg_in_guard_band(s))
         res = (float)((double)ll + (double)df * wg_log2(1.0 - (double)wg_opaque_f32(p), xt->d_tab, xt->d_tab2));   // x recomputed: not kept live for the rare path
     return res;
+}
+// Rows (exponents k = -(rows-1) .. 0) the two lookup tables need when every block has ntotal <= max_total and the pseudo
+// count is pc >= 4: p and 1 - p are both >= pc / (max_total + 2 pc) (less one float rounding, covered by the margin), and
+// an argument v has k = floor(log2(v / 0.6875)) in wg_fast_log2 and floor(log2(v / 0.69921875)) in wg_log2f.
+static inline int wg_lookup_rows(float pc, double max_total)
+{
+    const double vmin = (double)pc / (max_total + 2.0 * (double)pc) * (1.0 - 0x1p-18);
+    int rows = 1;
+    for (double lo = 0.6875; lo > vmin; lo *= 0.5) rows++;       // 0.6875 <= 0.69921875: the smaller base bounds both
+    return rows;
 }
 
 // term mode of a pseudo count: 0 plain exact form, 1 fast form with the guards, 2 fast form without them

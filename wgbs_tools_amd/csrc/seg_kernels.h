@@ -55,15 +55,22 @@ __device__ __forceinline__ void wg_fast_tables_to_lds(wg_fast_tables* ft, int ti
     }
 }
 
-// The {invc, k + logc} table of wg_fast_log2_ky, from the fast-log2 table of the same workgroup's ft (global source: no barrier needed).
-__device__ __forceinline__ void wg_ky_table_to_lds(wg_ky_table* kt, int tid, int nthreads)
+// The two lookup tables of the narrow guard-free scoring kernel, `rows` exponents each (k = -(rows-1) .. 0), from the
+// constant tables in global memory:  iy[(k + rows-1) * 16 + i] = {invc_f[i], logc_f[i] + k}  (wg_log2f_y0) and
+// ky[(k + rows-1) * 64 + i] = {invc_d[i], k + logc_d[i]}  (wg_fast_log2_ky, interval WG_FAST_CENTRE_ENTRY centred on 1).
+__device__ __forceinline__ void wg_lookup_tables_to_lds(wg_d2* iy, wg_d2* ky, int rows, int tid, int nthreads)
 {
+    const double* f = reinterpret_cast<const double*>(g_wg_tables.f_tab);
     const double* d = reinterpret_cast<const double*>(g_wg_tables.d_tab);
-    for (int x = tid; x < (WG_KY_KMIN + 1) * 64; x += nthreads) {
+    for (int x = tid; x < rows * 16; x += nthreads) {
+        iy[x].a = f[2 * (x & 15)];
+        iy[x].b = f[2 * (x & 15) + 1] + (double)((x >> 4) - (rows - 1));          // logc[i] + k, exactly as wg_log2f_normal adds them
+    }
+    for (int x = tid; x < rows * 64; x += nthreads) {
         const int i = x & 63;
         const bool centre = i == WG_FAST_CENTRE_ENTRY;           // wg_tables_finish(): interval just below 1 centred on 1
-        kt->d_ky[x].a = centre ? 1.0 : d[2 * i];
-        kt->d_ky[x].b = (double)((x >> 6) - WG_KY_KMIN) + (centre ? 0.0 : d[2 * i + 1]);   // (double)k + logc, exactly as wg_fast_log2 adds them
+        ky[x].a = centre ? 1.0 : d[2 * i];
+        ky[x].b = (double)((x >> 6) - (rows - 1)) + (centre ? 0.0 : d[2 * i + 1]);   // (double)k + logc, exactly as wg_fast_log2 adds them
     }
 }
 
@@ -513,7 +520,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_tile_emit(JobView J, PlanArgs P, i
 struct CostArgs {
     float pc, pc2;
     int32_t NS;        // samples per LDS group
-    int32_t pad;
+    int32_t rows;      // narrow guard-free kernel: exponents held by its two lookup tables (wg_lookup_rows)
 };
 
 // Stage the exclusive prefixes P[A+x], x = x0 .. x0+cnt-1, of sample row `row` into dst[0..cnt) (one wavefront).
@@ -644,12 +651,15 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 {
     constexpr int KS = SPLIT ? WG_WIDE_TK + 1 : TI + WG_NARROW_WMAX + 1;   // entries per sample row of the E array
     constexpr int IS = SPLIT ? WG_WIDE_TS + 1 : 0;                         // entries per sample row of the S array
-    constexpr bool KY = (FAST == 2) && !SPLIT;                                   // blocks of <= 60 sites, pseudo count >= 4: k + logc looked up
-    constexpr size_t TB = sizeof(wg_fast_tables) + (KY ? sizeof(wg_ky_table) : 0);
+    constexpr bool KY = (FAST == 2) && !SPLIT;                                   // blocks of <= 60 sites, pseudo count >= 4: both logs' exponent terms looked up
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // KY: only the two lookup tables, A.rows exponents each; otherwise the general fast tables
+    const size_t TB = KY ? (size_t)A.rows * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
     wg_fast_tables* tb = reinterpret_cast<wg_fast_tables*>(smem);
-    wg_ky_table* kyt = reinterpret_cast<wg_ky_table*>(smem + sizeof(wg_fast_tables));
-    const wg_d2* ky = KY ? kyt->d_ky : nullptr;
+    wg_d2* iyt = reinterpret_cast<wg_d2*>(smem);
+    wg_d2* kyt = iyt + (size_t)A.rows * 16;
+    const wg_d2* iy0 = KY ? iyt + (A.rows - 1) * 16 : tb->f_iy + WG_Y0_KMIN * 16;   // the rows of k = 0
+    const wg_d2* ky0 = KY ? kyt + (A.rows - 1) * 64 : nullptr;
     uint2* Et = reinterpret_cast<uint2*>(smem + TB);                             // wide: [NS][KS] P[i+1] of the ends
     uint2* St = Et + (size_t)A.NS * KS;                                          // wide: [NS][IS] P[k] of the starts
     uint32_t* Lt = reinterpret_cast<uint32_t*>(smem + TB);                       // narrow: [NS][KS] packed local prefixes
@@ -674,8 +684,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int et_hi = SPLIT ? et_lo + WG_WIDE_TK : (1 << 30);
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
 
-    wg_fast_tables_to_lds(tb, tid, WG_BLOCK);
-    if (KY) wg_ky_table_to_lds(kyt, tid, WG_BLOCK);
+    if (KY) wg_lookup_tables_to_lds(iyt, kyt, A.rows, tid, WG_BLOCK);
+    else wg_fast_tables_to_lds(tb, tid, WG_BLOCK);
     if (wv == 0) {
         const int k = ka + lane;
         const bool valid = lane < nk;
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             // sample loop, unrolled by four by hand (the optimiser leaves a loop with the rare exact path inside alone):
             // one address update per four evaluations, the row offsets sit in the instructions' offset fields
             auto term = [&](float nm, float nt) -> double {
-                const float ll = FAST == 2 ? wg_sample_term_pcpos_nz(nm, nt, pc, pc2, tb, &g_wg_tables, ky)
+                const float ll = FAST == 2 ? wg_sample_term_pcpos_nz(nm, nt, pc, pc2, iy0, tb->d_fast, ky0, KY, &g_wg_tables)
                                : (FAST == 1 ? wg_sample_term(nm, nt, pc, pc2, tb, &g_wg_tables) : wg_sample_term_plain(nm, nt, pc, pc2, &g_wg_tables));
                 return (double)ll;                                               // segmentor.cpp:135 adds the float term to the double sum
             };
@@ -1519,7 +1529,7 @@ __global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, f
         // zero (ntotal == 0: +0 vs -0, the same contribution to a sum); anything else comes back as NaN
         for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x) {
             const float a = wg_sample_term_pcpos(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables);
-            const float b = wg_sample_term_pcpos_nz(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables);
+            const float b = wg_sample_term_pcpos_nz(nm[q], nt[q], pc, pc2, tb.f_iy + WG_Y0_KMIN * 16, tb.d_fast, nullptr, false, &g_wg_tables);
             out[q] = (wg_f2u(a) == wg_f2u(b) || (a == 0.0f && b == 0.0f && nt[q] == 0.0f)) ? a : __builtin_nanf("");
         }
         return;
