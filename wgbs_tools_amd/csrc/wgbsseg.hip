@@ -582,7 +582,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         // Few chunks (one rank's share of a sharded genome): the recurrence occupies a fraction of the CUs, so let it
         // chase the scoring kernel stage by stage (measured: 71 chunks 10.1 -> 8.7 ms, 132 chunks 16.2 -> 15.0 ms).  With
         // hundreds of chunks k_dp alone (3.9 ms per 60k-site chunk, all chunks at once) beats k_dp competing for CUs.
-        if (job.max_len >= 8192) n_stages = std::max(n_stages, c->min_stages > 0 ? c->min_stages : (nC <= 160 ? 8 : 1));
+        // (the junction patches that ride along in the batch are a few hundred sites each: they do not count)
+        int n_long = 0;
+        for (const ChunkDesc& d : job.h) n_long += d.len >= 8192;
+        if (job.max_len >= 8192) n_stages = std::max(n_stages, c->min_stages > 0 ? c->min_stages : (n_long <= 160 ? 8 : 1));
         if (c->force_stages > 0) n_stages = c->force_stages;
         n_stages = std::min<int>(n_stages, std::max(1, (job.max_len + 63) / 64));
     }
