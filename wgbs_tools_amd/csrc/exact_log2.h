@@ -494,7 +494,14 @@ static inline int wg_lookup_rows(float pc, double max_total)
 }
 
 // term mode of a pseudo count: 0 plain exact form, 1 fast form with the guards, 2 fast form without them
-WG_HD int wg_term_mode(float pc) { return pc >= WG_POS_MIN_PC ? 2 : ((pc == 0.0f || pc >= WG_FAST_MIN_PC) ? 1 : 0); }
+// Above WG_FAST_MAX_PC the plain exact form is used as well: the division core is validated for divisors below 2^26
+// (ntotal + 2 pc with ntotal < 2^24), and a pseudo count whose double overflows makes p == 0, which the guard-free form excludes.
+#define WG_FAST_MAX_PC 0x1p24f
+WG_HD int wg_term_mode(float pc)
+{
+    if (!(pc <= WG_FAST_MAX_PC)) return 0;
+    return pc >= WG_POS_MIN_PC ? 2 : ((pc == 0.0f || pc >= WG_FAST_MIN_PC) ? 1 : 0);
+}
 WG_HD float wg_sample_term(float nmeth, float ntotal, float pc, float pc2, const wg_fast_tables* __restrict__ ft,
                            const wg_log_tables* __restrict__ xt)
 {
