@@ -82,6 +82,37 @@ def emu_stage_row(row, carry, start0, ln, A, cnt, x0=0):
         run = run + incl[63]
     return dst
 
+NARROW_WMAX = 60                      # WG_NARROW_WMAX: widest window of a narrow tile
+
+def emu_stage_local_rows(rows, start0, ln, ka, nsite):
+    """wg_stage_local_rows: tile-local packed prefixes L[x] = sum of sites ka..ka+x-1 (meth | cov << 16), x = 0..nsite,
+    for a list of sample rows; two rows per pass (32-lane halves, 4 sites per lane).  Returns [len(rows)][nsite+1]."""
+    n_total = rows[0].shape[0]
+    out = np.full((len(rows), nsite + 1), -1, dtype=np.int64)
+    abs0 = start0 + ka; al = abs0 & ~3; hs = abs0 - al
+    assert nsite + hs <= 128, (nsite, hs)
+    for r0 in range(0, len(rows), 2):
+        for half in range(2):
+            rr = r0 + half
+            if rr >= len(rows): continue
+            tot = np.zeros(32, dtype=np.int64); mt = np.zeros((32, 4), dtype=np.int64)
+            for l5 in range(32):
+                for j in range(4):
+                    a = al + l5 * 4 + j; x = l5 * 4 + j - hs
+                    if l5 * 4 < nsite + hs and a < n_total and 0 <= x < nsite:
+                        m, c = rows[rr][a]
+                        mt[l5, j] = int(m) | (int(c) << 16)
+                tot[l5] = mt[l5].sum()
+            incl = np.cumsum(tot)
+            for l5 in range(32):
+                e = incl[l5] - tot[l5]
+                for j in range(4):
+                    x = l5 * 4 + j - hs
+                    if 0 <= x <= nsite: out[rr, x] = e
+                    e += mt[l5, j]
+    assert (out >= 0).all() and (out & 0xffff).max() < 32768 and (out >> 16).max() < 32768
+    return out
+
 def emu_tile_plan(F, n, S, stage, TI, WA, TK):
     """k_tile_count / k_tile_emit for one chunk: -> (narrow tiles [(ka, nk)], wide tiles [(k0, nk, et_lo)])"""
     s0 = stage * S; s1 = min(s0 + S, n)
@@ -103,7 +134,7 @@ def emu_cost_tiles(F, n, S, stage, TI, WA, TK, start0=0):
     """k_cost tile decomposition (start-major) for one chunk: yields pairs (k,i) per tile; checks E/S array bounds."""
     A, B = emu_tile_plan(F, n, S, stage, TI, WA, TK)
     for split, tiles in ((False, [(ka, nk, 0) for (ka, nk) in A]), (True, B)):
-        KS = TK + 1 if split else TI + WA + 1
+        KS = TK + 1 if split else TI + NARROW_WMAX + 1
         IS = 17 if split else 0
         for (ka, nk, et_lo) in tiles:
             kb = ka + nk
@@ -121,6 +152,9 @@ def emu_cost_tiles(F, n, S, stage, TI, WA, TK, start0=0):
             eG = group_start(start0, eA); assert 0 <= eA - eG <= CARRY_G - 1
             Ecnt = imax + 2 - eA
             assert 0 < Ecnt <= KS, (Ecnt, KS)
+            if not split:                                      # narrow: everything a window could reach is staged, cut to the chunk
+                nsite = min(KS - 1, n - ka)
+                assert Ecnt - 1 <= nsite and nsite + ((start0 + ka) & 3) <= 128
             if split:
                 sA = ka; Scnt = kb - sA
                 assert Scnt <= IS
@@ -232,7 +266,7 @@ def run_case(name, S=None, TIsel=None):
     for k in range(0, n, max(1, n // 200)):
         row = band[k, :min(max_cpg, n - k)]
         assert np.isfinite(row[:F[k]]).all() and not np.isfinite(row[F[k]:]).any()
-    TI = TIsel or 64; WA = min(Fmax, 64); TK = 128
+    TI = TIsel or 64; WA = min(Fmax, NARROW_WMAX); TK = 128
     if S is None: S = ((n + 63) // 64) * 64
     seen = np.zeros(int(F.sum()), dtype=np.int32)
     for stage in range((n + S - 1) // S):
@@ -267,6 +301,14 @@ if __name__ == '__main__':
                 for x in range(cnt):
                     want = P[min(k + x, ln)]
                     assert (dst[x] == want).all(), (start0, ln, A, cnt, x, dst[x], want)
+    # tile-local packed staging of the narrow tiles
+    rows = [rng.integers(0, 256, (5000, 2)) for _ in range(5)]
+    for r in rows: r[:, 0] = np.minimum(r[:, 0], r[:, 1])
+    for start0, ln, ka, nsite in [(0, 300, 0, 124), (3, 700, 64, 124), (13, 200, 128, 72), (4990, 10, 0, 10), (1, 64, 63, 1), (7, 129, 64, 65), (4872, 128, 0, 124)]:
+        L = emu_stage_local_rows(rows, start0, ln, ka, nsite)
+        for rr, r in enumerate(rows):
+            P = np.concatenate([[[0, 0]], np.cumsum(r[start0 + ka:start0 + ka + nsite], axis=0)])
+            assert ((L[rr] & 0xffff) == P[:, 0]).all() and ((L[rr] >> 16) == P[:, 1]).all(), (start0, ln, ka, nsite, rr)
     print('scan/stage emulation ok')
     # recurrence emulation on random windows with integer costs (ties everywhere), incl. stage boundaries
     rng = np.random.default_rng(1)
