@@ -15,15 +15,24 @@ static wg_fast_tables make_fast()
     return f;
 }
 static const wg_fast_tables g_fast = make_fast();
-struct ky_table { wg_d2 d_ky[(WG_KY_KMIN + 1) * 64]; };
-static ky_table make_ky()
+// k-scaled lookup tables of the narrow scoring kernel, all WG_KY_KMIN + 1 rows (the kernel builds wg_lookup_rows() of them)
+struct ks_tables { wg_d2 iy[(WG_KY_KMIN + 1) * 16], ky[(WG_KY_KMIN + 1) * 64]; };
+static ks_tables make_ks()
 {
-    ky_table t;
-    for (int x = 0; x < (WG_KY_KMIN + 1) * 64; x++) { t.d_ky[x].a = g_tab.d_fast[x & 63].a; t.d_ky[x].b = (double)((x >> 6) - WG_KY_KMIN) + g_tab.d_fast[x & 63].b; }
+    ks_tables t;
+    for (int x = 0; x < (WG_KY_KMIN + 1) * 16; x++) {
+        const int k = (x >> 4) - WG_KY_KMIN;
+        t.iy[x].a = g_tab.f_tab[x & 15].a * (double)(1u << -k); t.iy[x].b = g_tab.f_tab[x & 15].b + (double)k;
+    }
+    for (int x = 0; x < (WG_KY_KMIN + 1) * 64; x++) {
+        const int k = (x >> 6) - WG_KY_KMIN;
+        t.ky[x].a = g_tab.d_fast[x & 63].a * (double)(1u << -k); t.ky[x].b = (double)k + g_tab.d_fast[x & 63].b;
+    }
     return t;
 }
-static const ky_table g_ky = make_ky();
-static const wg_d2* const g_ky0 = g_ky.d_ky + WG_KY_KMIN * 64;       // row k = 0
+static const ks_tables g_ks = make_ks();
+static const wg_d2* const g_iys0 = g_ks.iy + WG_KY_KMIN * 16;        // rows k = 0
+static const wg_d2* const g_kys0 = g_ks.ky + WG_KY_KMIN * 64;
 static const wg_d2* const g_iy0 = g_fast.f_iy + WG_Y0_KMIN * 16;
 
 template <class F> static void par_for(uint64_t count, int threads, F f)
@@ -90,9 +99,10 @@ void exact_log2_1mp_fill(uint32_t first, uint64_t count, uint64_t* out, int thre
             out[q] = wg_d2u(wg_log2(1.0 - (double)wg_u2f(first + (uint32_t)q), g_tab.d_tab, g_tab.d_tab2));
     });
 }
-// wg_fast_log2_ky against wg_fast_log2 on x = 1 - p for `count` consecutive floats p from `first`: number of mismatches
-// (inputs whose exponent lies below the table's first row are skipped and counted in *skipped)
-uint64_t exact_fast_log2_ky_mismatches(uint32_t first, uint64_t count, int threads, uint64_t* skipped)
+// The k-scaled forms against the originals, for `count` consecutive floats p from `first`: number of mismatches of
+// wg_fast_log2_ks(1 - p) vs wg_fast_log2(1 - p) plus those of wg_log2f_ks(p) vs wg_log2f(p) (the libm restatement).
+// Arguments whose exponent lies below the tables' first row are skipped and counted in *skipped.
+uint64_t exact_ks_mismatches(uint32_t first, uint64_t count, int threads, uint64_t* skipped)
 {
     std::vector<uint64_t> bad((size_t)(threads < 1 ? 1 : threads), 0), skip(bad.size(), 0);
     std::vector<std::thread> th;
@@ -100,9 +110,12 @@ uint64_t exact_fast_log2_ky_mismatches(uint32_t first, uint64_t count, int threa
     for (int t = 0; t < T; t++)
         th.emplace_back([&, t]() {
             for (uint64_t q = count * t / T; q < count * (t + 1) / T; q++) {
-                const double x = 1.0 - (double)wg_u2f(first + (uint32_t)q);
-                if (!(x > 0.6875 * 0x1p-13)) { skip[(size_t)t]++; continue; }
-                if (wg_d2u(wg_fast_log2_ky(x, g_ky0)) != wg_d2u(wg_fast_log2(x, g_tab.d_fast))) bad[(size_t)t]++;
+                const float p = wg_u2f(first + (uint32_t)q);
+                const double x = 1.0 - (double)p;
+                if (x > 0.6875 * 0x1p-13) { if (wg_d2u(wg_fast_log2_ks(x, g_kys0)) != wg_d2u(wg_fast_log2(x, g_tab.d_fast))) bad[(size_t)t]++; }
+                else skip[(size_t)t]++;
+                if (p > 0.69921875f * 0x1p-13f) { if (wg_f2u(wg_log2f_ks(p, (double)p, g_iys0)) != wg_f2u(wg_log2f(p, g_tab.f_tab))) bad[(size_t)t]++; }
+                else skip[(size_t)t]++;
             }
         });
     for (auto& x : th) x.join();
@@ -120,16 +133,17 @@ void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, 
             // the guard-free form with and without the zero-coverage exception (the latter is what the kernel runs, with
             // the y0 table): they may differ only in the sign of a zero when ntotal == 0; anything else comes back as NaN
             const float a = wg_sample_term_pcpos(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab);
-            const float b = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, g_iy0, g_fast.d_fast, nullptr, false, &g_tab);
+            const float b = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, g_iy0, g_fast.d_fast, &g_tab);
             out[q] = (wg_f2u(a) == wg_f2u(b) || (a == 0.0f && b == 0.0f && ntotal[q] == 0.0f)) ? a : __builtin_nanf("");
             // and with (double)k + logc looked up (narrow scoring tiles: blocks of <= 60 sites): bit-identical to the computed form
-            // ... from tables holding exactly the rows wg_lookup_rows() grants this pseudo count (reads outside them are caught)
+            // and the k-scaled form of the narrow scoring tiles (blocks of <= 60 sites): bit-identical, and every table index
+            // inside the rows wg_lookup_rows() grants this pseudo count
             if (ntotal[q] <= 255.0f * 60.0f) {
                 const int rows = wg_lookup_rows(pc, 255.0 * 60.0);
                 const float p = (nmeth[q] + pc) / (ntotal[q] + pc2);
                 const double x = 1.0 - (double)p;
                 const int kf = (int32_t)(wg_f2u(p) - 0x3f330000u) >> 23, kd = (int32_t)((uint32_t)(wg_d2u(x) >> 32) - 0x3fe60000u) >> 20;
-                const float c = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, g_iy0, nullptr, g_ky0, true, &g_tab);
+                const float c = wg_sample_term_pcpos_ks(nmeth[q], ntotal[q], (double)(ntotal[q] - nmeth[q]), pc, pc2, g_iys0, g_kys0, &g_tab);
                 if (wg_f2u(c) != wg_f2u(b) || rows > WG_KY_KMIN + 1 || kf > 0 || kd > 0 || kf < -(rows - 1) || kd < -(rows - 1)) out[q] = __builtin_nanf("");
             }
         } else {

@@ -35,8 +35,8 @@ def load_exact():
         getattr(L, f).argtypes = [C.c_uint32, C.c_uint64, C.c_void_p, C.c_int]
     for f in ('exact_sample_terms', 'exact_sample_terms_plain'):
         getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
-    L.exact_fast_log2_ky_mismatches.restype = C.c_uint64
-    L.exact_fast_log2_ky_mismatches.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
+    L.exact_ks_mismatches.restype = C.c_uint64
+    L.exact_ks_mismatches.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
     L.sum_ulp_gap.restype = C.c_uint64
     L.sum_ulp_gap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]
     return L
@@ -104,14 +104,16 @@ def test_sample_term_forms_match_oracle(exact, pcount):
         assert (got.view(np.uint32) == want.view(np.uint32)).all(), fn
 
 
-def test_fast_log2_with_looked_up_exponent_term_is_the_same_function(exact):
-    """wg_fast_log2_ky ((double)k + logc from a table; the narrow scoring tiles) against wg_fast_log2 on 1 - p for EVERY
-    float p in [2^-53, 1) whose 1 - p is covered by the table (exponent >= -13): bit-identical."""
+def test_k_scaled_table_forms_are_the_same_functions(exact):
+    """wg_fast_log2_ks / wg_log2f_ks (normalisation and exponent term folded into per-(k, i) tables; the narrow scoring
+    tiles) against wg_fast_log2(1 - p) and the libm restatement wg_log2f(p) for EVERY float p in [2^-53, 1) whose
+    argument the tables cover (exponent >= -13): bit-identical."""
     skipped = C.c_uint64(0)
     count = 0x3f800000 - FAST_FIRST
-    bad = exact.exact_fast_log2_ky_mismatches(FAST_FIRST, count, os.cpu_count() or 1, C.byref(skipped))
+    bad = exact.exact_ks_mismatches(FAST_FIRST, count, os.cpu_count() or 1, C.byref(skipped))
     assert bad == 0
-    assert skipped.value < 2000, skipped.value          # only p within 2^-13.5 of 1
+    n_small_p = 0x39000000 - FAST_FIRST                 # p below ~0.7 * 2^-13: outside the log2f table
+    assert skipped.value < n_small_p + 0x800000 + 2000, skipped.value
 
 
 @pytest.mark.parametrize('pcount', [15.0, 0.5, 0.0])

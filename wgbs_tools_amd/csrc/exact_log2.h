@@ -144,10 +144,10 @@ struct wg_fast_tables {
     wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}
     wg_d2 f_iy[(WG_Y0_KMIN + 1) * 16];    // log2f: {invc[i], y0 = logc[i] + (double)k} at [(k + 25) * 16 + i] — the SAME addition, done once; one 16-byte read
 };
-// Narrow scoring tiles with a pseudo count >= 4 (guard-free form) also keep, per (k, i), {invc[i], (double)k + logc[i]} of the
-// fast log2 — again the very addition wg_fast_log2 performs, done once: 1 - p >= pc / (255 * 60 + 2 pc) > 0.6875 * 2^-12
-// there, so its exponent k lies in [-12, 0]: at most WG_KY_KMIN + 1 rows; how many a pseudo count really needs is
-// wg_lookup_rows() (11 at the default 15).  Those kernels size both lookup tables to that.
+// Narrow scoring tiles with a pseudo count >= 4 (guard-free form) use per-(k, i) tables for both logs instead
+// (wg_log2f_ks / wg_fast_log2_ks below): p and 1 - p are >= pc / (255 * 60 + 2 pc) > 0.6875 * 2^-12 there, so the exponent k
+// lies in [-12, 0]: at most WG_KY_KMIN + 1 rows; how many a pseudo count really needs is wg_lookup_rows() (11 at the
+// default 15).  Those kernels size both tables to that.
 #define WG_KY_KMIN 13
 // The fast log2 uses d_tab with ONE entry changed: interval 39 = [0.9921875, 1) gets the centre exactly 1
 // (invc = 1, logc = 0), so that arguments just below 1 need no separate cancellation-free branch.
@@ -354,18 +354,33 @@ WG_HD double wg_fast_log2(double x, const wg_d2* __restrict__ dfast)
     return WG_FMA(q, r, (double)k + logc);
 }
 
-// wg_fast_log2 with (double)k + logc looked up (wg_ky_table) instead of computed: (hi >> 14) arithmetically IS k * 64 + i.
-// Same operations on the same values otherwise, hence the same bits; `ky` points at the entry of (k = 0, i = 0) and the
-// table must reach down to x's exponent k.
-WG_HD double wg_fast_log2_ky(double x, const wg_d2* __restrict__ ky)
+// The two logs with BOTH the argument's normalisation and its exponent term folded into per-(k, i) tables (the narrow
+// scoring kernel; wg_lookup_rows() rows each, pointers at the entries of k = 0, i = 0):
+//   log2f:      entry (k, i) = {invc_f[i] * 2^-k, logc_f[i] + k}   index (tmp >> 19) = k * 16 + i
+//   fast log2:  entry (k, i) = {invc_d[i] * 2^-k, k + logc_d[i]}   index (hi >> 14)  = k * 64 + i
+// The reduced argument of either log is r = z * invc - 1 with z = v * 2^-k (exact); v * (invc * 2^-k) is the same real
+// number (both scalings are by a power of two, exact), so the ONE rounding of the fused multiply-add gives the same r bit
+// for bit — without extracting k, rebuilding z and (log2f) converting it to double.  The second table entry is the
+// addition of the exponent, done once per entry with the operation the original performs per call.  Everything after r
+// is the original code.  `xd` is (double)x, which the caller has anyway.
+WG_HD float wg_log2f_ks(float x, double xd, const wg_d2* __restrict__ iys0)
 {
-    const uint64_t ix = wg_d2u(x);
-    const uint32_t xhi = (uint32_t)(ix >> 32);
-    const uint32_t hi = xhi - 0x3fe60000u;
+    const uint32_t tmp = wg_f2u(x) - 0x3f330000u;
+    const int32_t ki = (int32_t)tmp >> 19;                       // k * 16 + i
+    const wg_d2 e = iys0[ki];
+    const double r = WG_FMA_K(xd, e.a, -1.0);
+    const double r2 = r * r;
+    double y = WG_FMA_K(r, WG_LOG2F_A1, WG_LOG2F_A2);
+    y = WG_FMA(WG_LOG2F_A0, r2, y);
+    const double p = WG_FMA(WG_LOG2F_A3, r, e.b);
+    return (float)WG_FMA(y, r2, p);
+}
+WG_HD double wg_fast_log2_ks(double x, const wg_d2* __restrict__ kys0)
+{
+    const uint32_t hi = (uint32_t)(wg_d2u(x) >> 32) - 0x3fe60000u;
     const int32_t ki = (int32_t)hi >> 14;                        // k * 64 + i
-    const uint64_t iz = ((uint64_t)(xhi - (hi & 0xfff00000u)) << 32) | (uint32_t)ix;
-    const wg_d2 e = ky[ki];                                      // ky points at the row of k = 0
-    const double r = WG_FMA_K(wg_u2d(iz), e.a, -1.0);
+    const wg_d2 e = kys0[ki];
+    const double r = WG_FMA_K(x, e.a, -1.0);
     double q = WG_LOG2_A5;
     q = WG_FMA_K(q, r, WG_LOG2_A4); q = WG_FMA_K(q, r, WG_LOG2_A3); q = WG_FMA_K(q, r, WG_LOG2_A2);
     q = WG_FMA_K(q, r, WG_LOG2_A1); q = WG_FMA_K(q, r, WG_LOG2_A0); q = WG_FMA_K(q, r, WG_LOG2_INVLN2);
@@ -465,21 +480,33 @@ WG_HD float wg_sample_term_pcpos(float nmeth, float ntotal, float pc, float pc2,
 // The same without the zero-coverage exception, for callers that ADD the term to a running sum (the scoring kernel):
 // with ntotal == 0, p = 1/2, ll = 0 * log2f = -0.0, df = 0, s = -0.0 + 0 * L = -0.0, and adding -0.0 to the running
 // double sum leaves it unchanged, bit for bit — the reference's `continue` (:125) without a branch.
-// iy0: log2f's {invc, y0} table at its row k = 0; dfast: the fast-log2 table; ky0 (use_ky): the {invc, k + logc} table at its
-// row k = 0 of a caller whose blocks are short enough for the rows it holds (narrow scoring tiles) — then dfast is unused.
-// (use_ky is a compile-time constant at every call site: the other table's code folds away.)
+// iy0: log2f's {invc, y0} table at its row k = 0; dfast: the fast-log2 table.
 WG_HD float wg_sample_term_pcpos_nz(float nmeth, float ntotal, float pc, float pc2, const wg_d2* __restrict__ iy0,
-                                    const wg_d2* __restrict__ dfast, const wg_d2* __restrict__ ky0, const bool use_ky,
-                                    const wg_log_tables* __restrict__ xt)
+                                    const wg_d2* __restrict__ dfast, const wg_log_tables* __restrict__ xt)
 {
     const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
     const float ll = nmeth * wg_log2f_y0(p, iy0);                  // :129-131
     const float df = ntotal - nmeth;
     const double x = 1.0 - (double)p;                              // :132-134
-    const double s = (double)ll + (double)df * (use_ky ? wg_fast_log2_ky(x, ky0) : wg_fast_log2(x, dfast));
+    const double s = (double)ll + (double)df * wg_fast_log2(x, dfast);
     float res = (float)s;
     if (wg_in_guard_band(s))
         res = (float)((double)ll + (double)df * wg_log2(1.0 - (double)wg_opaque_f32(p), xt->d_tab, xt->d_tab2));   // x recomputed: not kept live for the rare path
+    return res;
+}
+// The same on the k-scaled tables (narrow scoring tiles: blocks short enough for the rows the tables hold).  dfd is
+// (double)(ntotal - nmeth), which the caller gets straight from the integer counts.
+WG_HD float wg_sample_term_pcpos_ks(float nmeth, float ntotal, double dfd, float pc, float pc2, const wg_d2* __restrict__ iys0,
+                                    const wg_d2* __restrict__ kys0, const wg_log_tables* __restrict__ xt)
+{
+    const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
+    const double pd = (double)p;
+    const float ll = nmeth * wg_log2f_ks(p, pd, iys0);             // :129-131
+    const double x = 1.0 - pd;                                     // :132-134
+    const double s = (double)ll + dfd * wg_fast_log2_ks(x, kys0);
+    float res = (float)s;
+    if (wg_in_guard_band(s))
+        res = (float)((double)ll + dfd * wg_log2(1.0 - (double)wg_opaque_f32(p), xt->d_tab, xt->d_tab2));
     return res;
 }
 // Rows (exponents k = -(rows-1) .. 0) the two lookup tables need when every block has ntotal <= max_total and the pseudo

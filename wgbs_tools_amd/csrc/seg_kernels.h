@@ -55,22 +55,24 @@ __device__ __forceinline__ void wg_fast_tables_to_lds(wg_fast_tables* ft, int ti
     }
 }
 
-// The two lookup tables of the narrow guard-free scoring kernel, `rows` exponents each (k = -(rows-1) .. 0), from the
-// constant tables in global memory:  iy[(k + rows-1) * 16 + i] = {invc_f[i], logc_f[i] + k}  (wg_log2f_y0) and
-// ky[(k + rows-1) * 64 + i] = {invc_d[i], k + logc_d[i]}  (wg_fast_log2_ky, interval WG_FAST_CENTRE_ENTRY centred on 1).
+// The two k-scaled lookup tables of the narrow guard-free scoring kernel (wg_log2f_ks / wg_fast_log2_ks), `rows` exponents
+// each (k = -(rows-1) .. 0), from the constant tables in global memory:
+//   iy[(k + rows-1) * 16 + i] = {invc_f[i] * 2^-k, logc_f[i] + k}     ky[(k + rows-1) * 64 + i] = {invc_d[i] * 2^-k, k + logc_d[i]}
+// (interval WG_FAST_CENTRE_ENTRY of the fast log2 centred on 1, as in wg_tables_finish()).
 __device__ __forceinline__ void wg_lookup_tables_to_lds(wg_d2* iy, wg_d2* ky, int rows, int tid, int nthreads)
 {
     const double* f = reinterpret_cast<const double*>(g_wg_tables.f_tab);
     const double* d = reinterpret_cast<const double*>(g_wg_tables.d_tab);
     for (int x = tid; x < rows * 16; x += nthreads) {
-        iy[x].a = f[2 * (x & 15)];
-        iy[x].b = f[2 * (x & 15) + 1] + (double)((x >> 4) - (rows - 1));          // logc[i] + k, exactly as wg_log2f_normal adds them
+        const int k = (x >> 4) - (rows - 1);
+        iy[x].a = f[2 * (x & 15)] * (double)(1u << -k);                           // exact: a power of two
+        iy[x].b = f[2 * (x & 15) + 1] + (double)k;                                // logc[i] + k, exactly as wg_log2f_normal adds them
     }
     for (int x = tid; x < rows * 64; x += nthreads) {
-        const int i = x & 63;
-        const bool centre = i == WG_FAST_CENTRE_ENTRY;           // wg_tables_finish(): interval just below 1 centred on 1
-        ky[x].a = centre ? 1.0 : d[2 * i];
-        ky[x].b = (double)((x >> 6) - (rows - 1)) + (centre ? 0.0 : d[2 * i + 1]);   // (double)k + logc, exactly as wg_fast_log2 adds them
+        const int i = x & 63, k = (x >> 6) - (rows - 1);
+        const bool centre = i == WG_FAST_CENTRE_ENTRY;
+        ky[x].a = (centre ? 1.0 : d[2 * i]) * (double)(1u << -k);
+        ky[x].b = (double)k + (centre ? 0.0 : d[2 * i + 1]);                      // (double)k + logc, exactly as wg_fast_log2 adds them
     }
 }
 
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             // sample loop, unrolled by four by hand (the optimiser leaves a loop with the rare exact path inside alone):
             // one address update per four evaluations, the row offsets sit in the instructions' offset fields
             auto term = [&](float nm, float nt) -> double {
-                const float ll = FAST == 2 ? wg_sample_term_pcpos_nz(nm, nt, pc, pc2, iy0, tb->d_fast, ky0, KY, &g_wg_tables)
+                const float ll = FAST == 2 ? wg_sample_term_pcpos_nz(nm, nt, pc, pc2, iy0, tb->d_fast, &g_wg_tables)
                                : (FAST == 1 ? wg_sample_term(nm, nt, pc, pc2, tb, &g_wg_tables) : wg_sample_term_plain(nm, nt, pc, pc2, &g_wg_tables));
                 return (double)ll;                                               // segmentor.cpp:135 adds the float term to the double sum
             };
@@ -772,7 +774,9 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 const uint32_t* Sp = Lt + lo;              // L[k-ka]
                 auto one = [&](int sl) {
                     const uint32_t d = Ep[sl * KS] - Sp[sl * KS];                // both fields at once: no borrow, L is monotone per field
-                    acc += term((float)(d & 0xffffu), (float)(d >> 16));
+                    if (KY) acc += (double)wg_sample_term_pcpos_ks((float)(d & 0xffffu), (float)(d >> 16), (double)(int)((d >> 16) - (d & 0xffffu)),
+                                                                   pc, pc2, iy0, ky0, &g_wg_tables);
+                    else acc += term((float)(d & 0xffffu), (float)(d >> 16));
                 };
                 int sl = 0;
                 for (; sl + 4 <= ns; sl += 4) { one(sl); one(sl + 1); one(sl + 2); one(sl + 3); }
@@ -1529,7 +1533,7 @@ __global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, f
         // zero (ntotal == 0: +0 vs -0, the same contribution to a sum); anything else comes back as NaN
         for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x) {
             const float a = wg_sample_term_pcpos(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables);
-            const float b = wg_sample_term_pcpos_nz(nm[q], nt[q], pc, pc2, tb.f_iy + WG_Y0_KMIN * 16, tb.d_fast, nullptr, false, &g_wg_tables);
+            const float b = wg_sample_term_pcpos_nz(nm[q], nt[q], pc, pc2, tb.f_iy + WG_Y0_KMIN * 16, tb.d_fast, &g_wg_tables);
             out[q] = (wg_f2u(a) == wg_f2u(b) || (a == 0.0f && b == 0.0f && nt[q] == 0.0f)) ? a : __builtin_nanf("");
         }
         return;
