@@ -112,7 +112,7 @@ uint64_t exact_ks_mismatches(uint32_t first, uint64_t count, int threads, uint64
             for (uint64_t q = count * t / T; q < count * (t + 1) / T; q++) {
                 const float p = wg_u2f(first + (uint32_t)q);
                 const double x = 1.0 - (double)p;
-                if (x > 0.6875 * 0x1p-13) { if (wg_d2u(wg_fast_log2_ks(x, g_kys0)) != wg_d2u(wg_fast_log2(x, g_tab.d_fast))) bad[(size_t)t]++; }
+                if (x > 0.6875 * 0x1p-13) { if (wg_d2u(wg_fast_log2_ks<true>(x, g_kys0)) != wg_d2u(wg_fast_log2(x, g_tab.d_fast))) bad[(size_t)t]++; }
                 else skip[(size_t)t]++;
                 if (p > 0.69921875f * 0x1p-13f) { if (wg_f2u(wg_log2f_ks(p, (double)p, g_iys0)) != wg_f2u(wg_log2f(p, g_tab.f_tab))) bad[(size_t)t]++; }
                 else skip[(size_t)t]++;
@@ -123,6 +123,49 @@ uint64_t exact_ks_mismatches(uint32_t first, uint64_t count, int threads, uint64
     for (int t = 0; t < T; t++) { b += bad[(size_t)t]; sk += skip[(size_t)t]; }
     if (skipped) *skipped = sk;
     return b;
+}
+// Largest distance in ulps between the shortened polynomial wg_fast_log2_ks<false>(1 - p) and the libm restatement
+// wg_log2(1 - p), over `count` consecutive floats p from `first` (arguments below the tables' first row skipped).
+uint64_t ks_log2_max_ulp(uint32_t first, uint64_t count, int threads)
+{
+    std::vector<uint64_t> mx((size_t)(threads < 1 ? 1 : threads), 0);
+    std::vector<std::thread> th;
+    const int T = (int)mx.size();
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t]() {
+            for (uint64_t q = count * t / T; q < count * (t + 1) / T; q++) {
+                const double x = 1.0 - (double)wg_u2f(first + (uint32_t)q);
+                if (!(x > 0.6875 * 0x1p-13) || !(x < 1.0)) continue;
+                const uint64_t a = wg_d2u(wg_fast_log2_ks<false>(x, g_kys0)), b = wg_d2u(wg_log2(x, g_tab.d_tab, g_tab.d_tab2));
+                const uint64_t d = a > b ? a - b : b - a;
+                if (d > mx[(size_t)t]) mx[(size_t)t] = d;
+            }
+        });
+    for (auto& x : th) x.join();
+    uint64_t m = 0;
+    for (auto v : mx) m = v > m ? v : m;
+    return m;
+}
+// Largest distance, in ulps of the double sum, between the sum wg_sample_term_pcpos_ks rounds (fused, shortened
+// polynomial) and the reference's fl(ll + fl(df * log2(1 - p))), on blocks of <= 60 sites.
+uint64_t ks_sum_ulp_gap(const float* nmeth, const float* ntotal, int64_t count, float pc)
+{
+    const float pc2 = pc + pc;
+    uint64_t mx = 0;
+    for (int64_t q = 0; q < count; q++) {
+        const float m = nmeth[q], t = ntotal[q];
+        if (t > 255.0f * 60.0f) continue;
+        const float p = (m + pc) / (t + pc2);
+        const float ll = m * wg_log2f_ks(p, (double)p, g_iys0);
+        const float df = t - m;
+        const double xx = 1.0 - (double)p;
+        const double s1 = WG_FMA((double)df, wg_fast_log2_ks<false>(xx, g_kys0), (double)ll);
+        const double s0 = (double)ll + (double)df * wg_log2(xx, g_tab.d_tab, g_tab.d_tab2);
+        const uint64_t a = wg_d2u(s1), b = wg_d2u(s0);
+        const uint64_t d = a > b ? a - b : b - a;
+        if (d > mx) mx = d;
+    }
+    return mx;
 }
 void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, float pc, float* out)
 {
@@ -143,7 +186,7 @@ void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, 
                 const float p = (nmeth[q] + pc) / (ntotal[q] + pc2);
                 const double x = 1.0 - (double)p;
                 const int kf = (int32_t)(wg_f2u(p) - 0x3f330000u) >> 23, kd = (int32_t)((uint32_t)(wg_d2u(x) >> 32) - 0x3fe60000u) >> 20;
-                const float c = wg_sample_term_pcpos_ks(nmeth[q], ntotal[q], (double)(ntotal[q] - nmeth[q]), pc, pc2, g_iys0, g_kys0, &g_tab);
+                const float c = wg_sample_term_pcpos_ks(nmeth[q], ntotal[q], pc, pc2, g_iys0, g_kys0, &g_tab);
                 if (wg_f2u(c) != wg_f2u(b) || rows > WG_KY_KMIN + 1 || kf > 0 || kd > 0 || kf < -(rows - 1) || kd < -(rows - 1)) out[q] = __builtin_nanf("");
             }
         } else {

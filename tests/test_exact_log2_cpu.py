@@ -37,6 +37,10 @@ def load_exact():
         getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
     L.exact_ks_mismatches.restype = C.c_uint64
     L.exact_ks_mismatches.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
+    L.ks_log2_max_ulp.restype = C.c_uint64
+    L.ks_log2_max_ulp.argtypes = [C.c_uint32, C.c_uint64, C.c_int]
+    L.ks_sum_ulp_gap.restype = C.c_uint64
+    L.ks_sum_ulp_gap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]
     L.sum_ulp_gap.restype = C.c_uint64
     L.sum_ulp_gap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float]
     return L
@@ -114,6 +118,27 @@ def test_k_scaled_table_forms_are_the_same_functions(exact):
     assert bad == 0
     n_small_p = 0x39000000 - FAST_FIRST                 # p below ~0.7 * 2^-13: outside the log2f table
     assert skipped.value < n_small_p + 0x800000 + 2000, skipped.value
+
+
+def _hdr_const(name):
+    import re
+    m = re.search(r'#define\s+%s\s+(\d+)' % name, open(HDR).read())
+    return int(m.group(1))
+
+
+def test_shortened_log2_polynomial_error_and_guard_band(exact):
+    """The narrow scoring tiles' log2(1 - p) drops the highest polynomial term: its distance from libm, measured over EVERY
+    float p the tables cover, must stay within WG_KS_LOG2_MAX_ULP, and the guard band must cover the derived 2E + 2 bound;
+    the sums actually rounded stay inside it on 8 M blocks per pseudo count."""
+    e_max, guard = _hdr_const('WG_KS_LOG2_MAX_ULP'), _hdr_const('WG_GUARD_ULPS_KS')
+    got = int(exact.ks_log2_max_ulp(FAST_FIRST, 0x3f800000 - FAST_FIRST, os.cpu_count() or 1))
+    assert 1 < got <= e_max, got
+    assert guard >= 2 * e_max + 4
+    m, t = _term_inputs(5, 4000000)
+    t2 = np.minimum(t, np.float32(255 * 60)); m2 = np.minimum(m, t2)
+    for pcount in (15.0, 4.0, 100.0):
+        gap = int(exact.ks_sum_ulp_gap(m2.ctypes.data, t2.ctypes.data, t2.size, C.c_float(pcount)))
+        assert gap <= 2 * e_max + 2, (pcount, gap)
 
 
 @pytest.mark.parametrize('pcount', [15.0, 0.5, 0.0])

@@ -375,14 +375,21 @@ WG_HD float wg_log2f_ks(float x, double xd, const wg_d2* __restrict__ iys0)
     const double p = WG_FMA(WG_LOG2F_A3, r, e.b);
     return (float)WG_FMA(y, r2, p);
 }
+// FULL = true: every polynomial term of wg_fast_log2 (bit-identical to it).  FULL = false: the highest term (A5 r^7,
+// |r| <= 2^-7) left out — one multiply-add fewer, up to WG_KS_LOG2_MAX_ULP ulp from libm instead of 1 (measured
+// exhaustively, tests/test_exact_log2_cpu.py); the caller's guard band is widened to match (WG_GUARD_ULPS_KS).
+#define WG_KS_LOG2_MAX_ULP 256
+#define WG_GUARD_ULPS_KS 1024u      // >= 2 * WG_KS_LOG2_MAX_ULP + 4 (see wg_sample_term_pcpos_ks); band hit: 2^-18 per evaluation
+template <bool FULL>
 WG_HD double wg_fast_log2_ks(double x, const wg_d2* __restrict__ kys0)
 {
     const uint32_t hi = (uint32_t)(wg_d2u(x) >> 32) - 0x3fe60000u;
     const int32_t ki = (int32_t)hi >> 14;                        // k * 64 + i
     const wg_d2 e = kys0[ki];
     const double r = WG_FMA_K(x, e.a, -1.0);
-    double q = WG_LOG2_A5;
-    q = WG_FMA_K(q, r, WG_LOG2_A4); q = WG_FMA_K(q, r, WG_LOG2_A3); q = WG_FMA_K(q, r, WG_LOG2_A2);
+    double q = WG_LOG2_A4;
+    if (FULL) { q = WG_LOG2_A5; q = WG_FMA_K(q, r, WG_LOG2_A4); }
+    q = WG_FMA_K(q, r, WG_LOG2_A3); q = WG_FMA_K(q, r, WG_LOG2_A2);
     q = WG_FMA_K(q, r, WG_LOG2_A1); q = WG_FMA_K(q, r, WG_LOG2_A0); q = WG_FMA_K(q, r, WG_LOG2_INVLN2);
     return WG_FMA(q, r, e.b);
 }
@@ -415,10 +422,10 @@ WG_HD float wg_sample_term_plain(float nmeth, float ntotal, float pc, float pc2,
 #define WG_GUARD_ULPS 16u
 // "low 29 bits of s within WG_GUARD_ULPS of 2^28", as one shift-add and one compare: with tail = lo & (2^29-1) and
 // C = 2^28 - G, (tail - C) mod 2^32 <= 2G  <=>  (8*tail - 8*C) mod 2^32 <= 16G, and 8*tail mod 2^32 is just lo << 3.
-WG_HD bool wg_in_guard_band(double s)
+WG_HD bool wg_in_guard_band(double s, const uint32_t guard_ulps = WG_GUARD_ULPS)
 {
-    const uint32_t t3 = ((uint32_t)wg_d2u(s) << 3) + (0u - ((0x10000000u - WG_GUARD_ULPS) << 3));
-    return t3 <= 16u * WG_GUARD_ULPS;
+    const uint32_t t3 = ((uint32_t)wg_d2u(s) << 3) + (0u - ((0x10000000u - guard_ulps) << 3));
+    return t3 <= 16u * guard_ulps;
 }
 // IEEE-754 binary32 division a / b for operands in a "comfortable" range (0 <= a <= b, 2^-20 <= b < 2^26, or a == 0).
 // On the device this is the core of the sequence hipcc emits for `/` (v_rcp_f32, one Newton step on the reciprocal,
@@ -494,19 +501,23 @@ WG_HD float wg_sample_term_pcpos_nz(float nmeth, float ntotal, float pc, float p
         res = (float)((double)ll + (double)df * wg_log2(1.0 - (double)wg_opaque_f32(p), xt->d_tab, xt->d_tab2));   // x recomputed: not kept live for the rare path
     return res;
 }
-// The same on the k-scaled tables (narrow scoring tiles: blocks short enough for the rows the tables hold).  dfd is
-// (double)(ntotal - nmeth), which the caller gets straight from the integer counts.
-WG_HD float wg_sample_term_pcpos_ks(float nmeth, float ntotal, double dfd, float pc, float pc2, const wg_d2* __restrict__ iys0,
+// The same on the k-scaled tables (narrow scoring tiles: blocks short enough for the rows the tables hold), with a
+// cheaper approximate sum: L' = wg_fast_log2_ks<false> is within E = WG_KS_LOG2_MAX_ULP ulp of libm's L, and the sum is ONE
+// fused multiply-add.  Against the reference's s = fl(ll + fl(df L)):  |df L' - fl(df L)| <= (E 2^-52 + 2^-53) |df L|,
+// |df L| <= |s| (both addends <= 0), one more rounding of at most half an ulp, and ulp(s) >= 2^-53 |s|: |s' - s| <=
+// (2 E + 2) ulp(s) < WG_GUARD_ULPS_KS.  Inside that band around a float rounding midpoint the exact form decides, as ever.
+WG_HD float wg_sample_term_pcpos_ks(float nmeth, float ntotal, float pc, float pc2, const wg_d2* __restrict__ iys0,
                                     const wg_d2* __restrict__ kys0, const wg_log_tables* __restrict__ xt)
 {
     const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
     const double pd = (double)p;
     const float ll = nmeth * wg_log2f_ks(p, pd, iys0);             // :129-131
+    const float df = wg_opaque_f32(ntotal) - nmeth;                // (opaque: or the subtraction moves to the integers the counts came from, one conversion more)
     const double x = 1.0 - pd;                                     // :132-134
-    const double s = (double)ll + dfd * wg_fast_log2_ks(x, kys0);
+    const double s = WG_FMA((double)df, wg_fast_log2_ks<false>(x, kys0), (double)ll);
     float res = (float)s;
-    if (wg_in_guard_band(s))
-        res = (float)((double)ll + dfd * wg_log2(1.0 - (double)wg_opaque_f32(p), xt->d_tab, xt->d_tab2));
+    if (wg_in_guard_band(s, WG_GUARD_ULPS_KS))
+        res = (float)((double)ll + (double)df * wg_log2(1.0 - (double)wg_opaque_f32(p), xt->d_tab, xt->d_tab2));
     return res;
 }
 // Rows (exponents k = -(rows-1) .. 0) the two lookup tables need when every block has ntotal <= max_total and the pseudo

@@ -774,8 +774,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 const uint32_t* Sp = Lt + lo;              // L[k-ka]
                 auto one = [&](int sl) {
                     const uint32_t d = Ep[sl * KS] - Sp[sl * KS];                // both fields at once: no borrow, L is monotone per field
-                    if (KY) acc += (double)wg_sample_term_pcpos_ks((float)(d & 0xffffu), (float)(d >> 16), (double)(int)((d >> 16) - (d & 0xffffu)),
-                                                                   pc, pc2, iy0, ky0, &g_wg_tables);
+                    if (KY) acc += (double)wg_sample_term_pcpos_ks((float)(d & 0xffffu), (float)(d >> 16), pc, pc2, iy0, ky0, &g_wg_tables);
                     else acc += term((float)(d & 0xffffu), (float)(d >> 16));
                 };
                 int sl = 0;
