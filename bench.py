@@ -260,12 +260,12 @@ def main():
             'scoring': {'kernel': 'k_cost (block log-likelihoods, fp64 VALU bound)', 'evals_per_s': evals_s,
                         'evals_per_step': acc['evals'] / args.steps, 'pairs_per_step': acc['pairs'] / args.steps,
                         'max_window': acc['max_window'], 'stages': acc['n_stages'],
-                        # neither HBM- nor MFMA-bound: the bound is VALU issue.  45.5 = VALU instructions per evaluation on the
-                        # common path of the guard-free form in the gfx950 ISA (tools/micro/count_cost_loop.py: 42 + 14/4 of
+                        # neither HBM- nor MFMA-bound: the bound is VALU issue.  44.5 = VALU instructions per evaluation on the
+                        # common path of the guard-free form in the gfx950 ISA (tools/micro/count_cost_loop.py: 41 + 14/4 of
                         # the 4-fold unrolled sample loop); peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
-                        'valu_instr_per_eval': 45.5, 'valu_lane_ops_per_s': evals_s * 45.5,
+                        'valu_instr_per_eval': 44.5, 'valu_lane_ops_per_s': evals_s * 44.5,
                         'valu_issue_peak_lane_ops_per_s': 256 * 4 * 16 * 2.4e9,
-                        'valu_issue_frac': evals_s * 45.5 / (256 * 4 * 16 * 2.4e9)},
+                        'valu_issue_frac': evals_s * 44.5 / (256 * 4 * 16 * 2.4e9)},
             'device_ms_per_step': {k: acc[k] / args.steps for k in ('scan_ms', 'window_ms', 'cost_ms', 'dp_ms', 'trace_ms', 'total_ms')},
         }
         if world == 1 and args.cpu_seconds > 0:

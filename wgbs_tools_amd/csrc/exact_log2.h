@@ -383,9 +383,16 @@ WG_HD float wg_log2f_ks(float x, double xd, const wg_d2* __restrict__ iys0)
 template <bool FULL>
 WG_HD double wg_fast_log2_ks(double x, const wg_d2* __restrict__ kys0)
 {
-    const uint32_t hi = (uint32_t)(wg_d2u(x) >> 32) - 0x3fe60000u;
-    const int32_t ki = (int32_t)hi >> 14;                        // k * 64 + i
-    const wg_d2 e = kys0[ki];
+    // index k * 64 + i = (xhi - 0x3fe60000) >> 14 = (xhi >> 14) - (0x3fe60000 >> 14), the constant having no bits below 14:
+    // its subtraction moves into the table pointer (x > 0: the shift is a plain bit-field extract)
+    const uint32_t xhi = (uint32_t)(wg_d2u(x) >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t kiu;
+    asm("v_bfe_u32 %0, %1, 14, 18" : "=v"(kiu) : "v"(xhi));      // (inline asm: the optimiser would rebuild shift + add)
+#else
+    const uint32_t kiu = xhi >> 14;
+#endif
+    const wg_d2 e = (kys0 - (0x3fe60000u >> 14))[kiu];
     const double r = WG_FMA_K(x, e.a, -1.0);
     double q = WG_LOG2_A4;
     if (FULL) { q = WG_LOG2_A5; q = WG_FMA_K(q, r, WG_LOG2_A4); }
