@@ -112,9 +112,9 @@ uint64_t exact_ks_mismatches(uint32_t first, uint64_t count, int threads, uint64
             for (uint64_t q = count * t / T; q < count * (t + 1) / T; q++) {
                 const float p = wg_u2f(first + (uint32_t)q);
                 const double x = 1.0 - (double)p;
-                if (x > 0.6875 * 0x1p-13) { if (wg_d2u(wg_fast_log2_ks<true>(x, g_kys0)) != wg_d2u(wg_fast_log2(x, g_tab.d_fast))) bad[(size_t)t]++; }
+                if (x > 0.6875 * 0x1p-23) { if (wg_d2u(wg_fast_log2_ks<true>(x, g_kys0)) != wg_d2u(wg_fast_log2(x, g_tab.d_fast))) bad[(size_t)t]++; }
                 else skip[(size_t)t]++;
-                if (p > 0.69921875f * 0x1p-13f) { if (wg_f2u(wg_log2f_ks(p, (double)p, g_iys0)) != wg_f2u(wg_log2f(p, g_tab.f_tab))) bad[(size_t)t]++; }
+                if (p > 0.69921875f * 0x1p-23f) { if (wg_f2u(wg_log2f_ks(p, (double)p, g_iys0)) != wg_f2u(wg_log2f(p, g_tab.f_tab))) bad[(size_t)t]++; }
                 else skip[(size_t)t]++;
             }
         });
@@ -135,7 +135,7 @@ uint64_t ks_log2_max_ulp(uint32_t first, uint64_t count, int threads)
         th.emplace_back([&, t]() {
             for (uint64_t q = count * t / T; q < count * (t + 1) / T; q++) {
                 const double x = 1.0 - (double)wg_u2f(first + (uint32_t)q);
-                if (!(x > 0.6875 * 0x1p-13) || !(x < 1.0)) continue;
+                if (!(x > 0.6875 * 0x1p-23) || !(x < 1.0)) continue;
                 const uint64_t a = wg_d2u(wg_fast_log2_ks<false>(x, g_kys0)), b = wg_d2u(wg_log2(x, g_tab.d_tab, g_tab.d_tab2));
                 const uint64_t d = a > b ? a - b : b - a;
                 if (d > mx[(size_t)t]) mx[(size_t)t] = d;
@@ -147,14 +147,13 @@ uint64_t ks_log2_max_ulp(uint32_t first, uint64_t count, int threads)
     return m;
 }
 // Largest distance, in ulps of the double sum, between the sum wg_sample_term_pcpos_ks rounds (fused, shortened
-// polynomial) and the reference's fl(ll + fl(df * log2(1 - p))), on blocks of <= 60 sites.
+// polynomial) and the reference's fl(ll + fl(df * log2(1 - p))).
 uint64_t ks_sum_ulp_gap(const float* nmeth, const float* ntotal, int64_t count, float pc)
 {
     const float pc2 = pc + pc;
     uint64_t mx = 0;
     for (int64_t q = 0; q < count; q++) {
         const float m = nmeth[q], t = ntotal[q];
-        if (t > 255.0f * 60.0f) continue;
         const float p = (m + pc) / (t + pc2);
         const float ll = m * wg_log2f_ks(p, (double)p, g_iys0);
         const float df = t - m;
@@ -179,10 +178,12 @@ void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, 
             const float b = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, g_iy0, g_fast.d_fast, &g_tab);
             out[q] = (wg_f2u(a) == wg_f2u(b) || (a == 0.0f && b == 0.0f && ntotal[q] == 0.0f)) ? a : __builtin_nanf("");
             // and with (double)k + logc looked up (narrow scoring tiles: blocks of <= 60 sites): bit-identical to the computed form
-            // and the k-scaled form of the narrow scoring tiles (blocks of <= 60 sites): bit-identical, and every table index
-            // inside the rows wg_lookup_rows() grants this pseudo count
-            if (ntotal[q] <= 255.0f * 60.0f) {
-                const int rows = wg_lookup_rows(pc, 255.0 * 60.0);
+            // and the k-scaled form of the scoring kernels: bit-identical, and every table index inside the rows wg_lookup_rows()
+            // grants this pseudo count and longest block
+            for (int cls = 0; cls < 2; cls++) {                       // narrow tiles (blocks <= 60 sites), wide tiles (the ABI's longest)
+                const double max_total = cls ? 255.0 * 8000.0 : 255.0 * 60.0;
+                if ((double)ntotal[q] > max_total) continue;
+                const int rows = wg_lookup_rows(pc, max_total);
                 const float p = (nmeth[q] + pc) / (ntotal[q] + pc2);
                 const double x = 1.0 - (double)p;
                 const int kf = (int32_t)(wg_f2u(p) - 0x3f330000u) >> 23, kd = (int32_t)((uint32_t)(wg_d2u(x) >> 32) - 0x3fe60000u) >> 20;

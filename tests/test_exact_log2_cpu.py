@@ -111,12 +111,12 @@ def test_sample_term_forms_match_oracle(exact, pcount):
 def test_k_scaled_table_forms_are_the_same_functions(exact):
     """wg_fast_log2_ks / wg_log2f_ks (normalisation and exponent term folded into per-(k, i) tables; the narrow scoring
     tiles) against wg_fast_log2(1 - p) and the libm restatement wg_log2f(p) for EVERY float p in [2^-53, 1) whose
-    argument the tables cover (exponent >= -13): bit-identical."""
+    argument the tables cover (exponent >= -23): bit-identical."""
     skipped = C.c_uint64(0)
     count = 0x3f800000 - FAST_FIRST
     bad = exact.exact_ks_mismatches(FAST_FIRST, count, os.cpu_count() or 1, C.byref(skipped))
     assert bad == 0
-    n_small_p = 0x39000000 - FAST_FIRST                 # p below ~0.7 * 2^-13: outside the log2f table
+    n_small_p = 0x34000000 - FAST_FIRST                 # p below ~0.7 * 2^-23: outside the log2f table
     assert skipped.value < n_small_p + 0x800000 + 2000, skipped.value
 
 
@@ -135,9 +135,8 @@ def test_shortened_log2_polynomial_error_and_guard_band(exact):
     assert 1 < got <= e_max, got
     assert guard >= 2 * e_max + 4
     m, t = _term_inputs(5, 4000000)
-    t2 = np.minimum(t, np.float32(255 * 60)); m2 = np.minimum(m, t2)
     for pcount in (15.0, 4.0, 100.0):
-        gap = int(exact.ks_sum_ulp_gap(m2.ctypes.data, t2.ctypes.data, t2.size, C.c_float(pcount)))
+        gap = int(exact.ks_sum_ulp_gap(m.ctypes.data, t.ctypes.data, t.size, C.c_float(pcount)))
         assert gap <= 2 * e_max + 2, (pcount, gap)
 
 

@@ -144,11 +144,12 @@ struct wg_fast_tables {
     wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}
     wg_d2 f_iy[(WG_Y0_KMIN + 1) * 16];    // log2f: {invc[i], y0 = logc[i] + (double)k} at [(k + 25) * 16 + i] — the SAME addition, done once; one 16-byte read
 };
-// Narrow scoring tiles with a pseudo count >= 4 (guard-free form) use per-(k, i) tables for both logs instead
-// (wg_log2f_ks / wg_fast_log2_ks below): p and 1 - p are >= pc / (255 * 60 + 2 pc) > 0.6875 * 2^-12 there, so the exponent k
-// lies in [-12, 0]: at most WG_KY_KMIN + 1 rows; how many a pseudo count really needs is wg_lookup_rows() (11 at the
-// default 15).  Those kernels size both tables to that.
-#define WG_KY_KMIN 13
+// With a pseudo count >= 4 (guard-free form) the scoring kernels use per-(k, i) tables for both logs instead
+// (wg_log2f_ks / wg_fast_log2_ks below): p and 1 - p are >= pc / (ntotal + 2 pc), so with blocks of at most 60 sites
+// (narrow tiles) the exponent k lies in [-12, 0], with the ABI's longest blocks (255 * 8000) in [-20, 0]: at most
+// WG_KY_KMIN + 1 rows; how many a pseudo count and a longest block really need is wg_lookup_rows() (11 for the default
+// 15 and narrow tiles).  The kernels size both tables to that.
+#define WG_KY_KMIN 23
 // The fast log2 uses d_tab with ONE entry changed: interval 39 = [0.9921875, 1) gets the centre exactly 1
 // (invc = 1, logc = 0), so that arguments just below 1 need no separate cancellation-free branch.
 // (Interval 40 = [1, 1.015625) cannot be treated the same way: it also serves z = 2^-k x for x in [0.5, 0.5078) etc.)

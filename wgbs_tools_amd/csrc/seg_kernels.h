@@ -522,7 +522,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_tile_emit(JobView J, PlanArgs P, i
 struct CostArgs {
     float pc, pc2;
     int32_t NS;        // samples per LDS group
-    int32_t rows;      // narrow guard-free kernel: exponents held by its two lookup tables (wg_lookup_rows)
+    int32_t rows;      // guard-free kernels: exponents held by the two lookup tables (wg_lookup_rows for the longest block of the tile class)
 };
 
 // Stage the exclusive prefixes P[A+x], x = x0 .. x0+cnt-1, of sample row `row` into dst[0..cnt) (one wavefront).
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 {
     constexpr int KS = SPLIT ? WG_WIDE_TK + 1 : TI + WG_NARROW_WMAX + 1;   // entries per sample row of the E array
     constexpr int IS = SPLIT ? WG_WIDE_TS + 1 : 0;                         // entries per sample row of the S array
-    constexpr bool KY = (FAST == 2) && !SPLIT;                                   // blocks of <= 60 sites, pseudo count >= 4: both logs' exponent terms looked up
+    constexpr bool KY = (FAST == 2);                                             // pseudo count >= 4: both logs on their k-scaled lookup tables, A.rows exponents each (sized by the host to the longest block of the tile class)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // KY: only the two lookup tables, A.rows exponents each; otherwise the general fast tables
     const size_t TB = KY ? (size_t)A.rows * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
@@ -764,7 +764,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 auto one = [&](int sl) {
                     const uint2 pi = Ep[sl * KS];
                     const uint2 pk = Sp[sl * IS];
-                    acc += term((float)(pi.x - pk.x), (float)(pi.y - pk.y));
+                    if (KY) acc += (double)wg_sample_term_pcpos_ks((float)(pi.x - pk.x), (float)(pi.y - pk.y), pc, pc2, iy0, ky0, &g_wg_tables);
+                    else acc += term((float)(pi.x - pk.x), (float)(pi.y - pk.y));
                 };
                 int sl = 0;
                 for (; sl + 4 <= ns; sl += 4) { one(sl); one(sl + 1); one(sl + 2); one(sl + 3); }

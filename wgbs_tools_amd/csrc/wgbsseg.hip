@@ -523,13 +523,17 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const double Favg = (double)total_pairs / (double)std::max<int64_t>(1, J);
     const int WA = std::min(Wmax, WG_NARROW_WMAX);
     const int TKB = WG_WIDE_TK;
-    const int lookup_rows = wg_term_mode(P->pseudo_count) == 2 ? wg_lookup_rows(P->pseudo_count, 255.0 * WG_NARROW_WMAX) : 0;
-    if (lookup_rows > WG_KY_KMIN + 1) { set_err(err, errlen, "internal: %d lookup rows", lookup_rows); return WGBSSEG_E_ARG; }
+    // exponent rows of the k-scaled log tables (pseudo count >= 4): narrow tiles score blocks of <= WG_NARROW_WMAX sites,
+    // wide tiles blocks up to the job's widest window
+    const bool ks = wg_term_mode(P->pseudo_count) == 2;
+    const int rowsA = ks ? wg_lookup_rows(P->pseudo_count, 255.0 * WG_NARROW_WMAX) : 0;
+    const int rowsB = ks ? wg_lookup_rows(P->pseudo_count, 255.0 * std::max(Wmax, 1)) : 0;
+    if (rowsA > WG_KY_KMIN + 1 || rowsB > WG_KY_KMIN + 1) { set_err(err, errlen, "internal: %d / %d lookup rows", rowsA, rowsB); return WGBSSEG_E_ARG; }
     auto lds_for = [&](int ti, bool split, int ns) -> size_t {
         const size_t rows = split ? (size_t)ns * (WG_WIDE_TK + 1 + WG_WIDE_TS + 1) * 8                      // P of the ends + P of the starts, (meth, cov) as two dwords
                                   : ((((size_t)ns * (ti + WG_NARROW_WMAX + 1) + 1) & ~(size_t)1) * 4);     // tile-local prefixes, packed in one dword
-        // narrow guard-free kernel: just its two lookup tables, sized to the pseudo count; otherwise the general fast tables
-        const size_t tabs = (!split && wg_term_mode(P->pseudo_count) == 2) ? (size_t)lookup_rows * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
+        // guard-free kernels: just the two lookup tables, sized to the pseudo count and the tile class; otherwise the general fast tables
+        const size_t tabs = ks ? (size_t)(split ? rowsB : rowsA) * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
         return tabs + rows + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24;
     };
     int TI = 64, NSA = 1, NSB = 1;
@@ -558,7 +562,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
             if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
             const size_t l = lds_for(WG_WIDE_TS, true, ns);
             if (l > 64 * 1024) continue;
-            const int wgs = (int)std::min<size_t>(6, (160 * 1024) / l);
+            const int wgs = (int)std::min<size_t>(4, (160 * 1024) / l);      // 103 VGPRs: 4 workgroups per CU at most
             const double groups = std::ceil((double)Nsmp / ns);
             const double score = wgs / (1.0 + 0.02 * (groups - 1));
             if (score > best) { best = score; NSB = ns; }
@@ -568,8 +572,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     memset(&caA, 0, sizeof(caA));
     caA.pc = P->pseudo_count; caA.pc2 = P->pseudo_count + P->pseudo_count;
     caB = caA;
-    caA.NS = NSA; caA.rows = lookup_rows;
-    caB.NS = NSB; caB.rows = 0;
+    caA.NS = NSA; caA.rows = rowsA;
+    caB.NS = NSB; caB.rows = rowsB;
     const size_t ldsA = (size_t)round_up((int64_t)lds_for(TI, false, NSA), 16);
     const size_t ldsB = (size_t)round_up((int64_t)lds_for(WG_WIDE_TS, true, NSB), 16);
     const int term_mode = wg_term_mode(P->pseudo_count);
