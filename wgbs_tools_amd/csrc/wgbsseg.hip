@@ -652,6 +652,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     static bool dp_attr = false;
     if (!dp_attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<7, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<7, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<3, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<15, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         dp_attr = true;
@@ -684,8 +686,13 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipEventRecord(c->ev_cost1[stg], c->sA));
         HIP_TRY(hipStreamWaitEvent(c->sB, c->ev_cost1[stg], 0));
         HIP_TRY(hipEventRecord(c->ev_dp0[stg], c->sB));
-        if (dp_mode == 0)      hipLaunchKernelGGL((k_dp<3, 64>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
-        else if (dp_mode == 1) hipLaunchKernelGGL((k_dp<3, 32>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
+        // worker waves per chunk, measured: 64-step batches (no window > 64): 7 (whole genome 3 -> 2.14 ms, 7 -> 1.77 ms,
+        // 5 / 11 / 15 -> 2.8-3.1 ms); 32-step batches (islands): 3 (4.8 ms; 7 -> 5.8 ms).  WGBSSEG_DP_NW overrides (tests, tuning).
+        static const int dp_nw = getenv("WGBSSEG_DP_NW") ? atoi(getenv("WGBSSEG_DP_NW")) : 0;
+        if (dp_mode == 0 && dp_nw == 3)      hipLaunchKernelGGL((k_dp<3, 64>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
+        else if (dp_mode == 0)               hipLaunchKernelGGL((k_dp<7, 64>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
+        else if (dp_mode == 1 && dp_nw == 7) hipLaunchKernelGGL((k_dp<7, 32>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
+        else if (dp_mode == 1)               hipLaunchKernelGGL((k_dp<3, 32>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else                   hipLaunchKernelGGL((k_dp<15, 32>), dim3((unsigned)nC), dim3(64 * 16), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_dp1[stg], c->sB));
