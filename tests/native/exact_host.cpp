@@ -11,7 +11,6 @@ static wg_fast_tables make_fast()
 {
     wg_fast_tables f;
     memcpy(f.f_tab, g_tab.f_tab, sizeof(f.f_tab)); memcpy(f.d_fast, g_tab.d_fast, sizeof(f.d_fast));
-    for (int x = 0; x < (WG_Y0_KMIN + 1) * 16; x++) { f.f_iy[x].a = g_tab.f_tab[x & 15].a; f.f_iy[x].b = g_tab.f_tab[x & 15].b + (double)((x >> 4) - WG_Y0_KMIN); }
     return f;
 }
 static const wg_fast_tables g_fast = make_fast();
@@ -33,7 +32,6 @@ static ks_tables make_ks()
 static const ks_tables g_ks = make_ks();
 static const wg_d2* const g_iys0 = g_ks.iy + WG_KY_KMIN * 16;        // rows k = 0
 static const wg_d2* const g_kys0 = g_ks.ky + WG_KY_KMIN * 64;
-static const wg_d2* const g_iy0 = g_fast.f_iy + WG_Y0_KMIN * 16;
 
 template <class F> static void par_for(uint64_t count, int threads, F f)
 {
@@ -172,14 +170,11 @@ void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, 
     const int mode = wg_term_mode(pc);                              // same dispatch rule as the library
     for (int64_t q = 0; q < count; q++) {
         if (mode == 2) {
-            // the guard-free form with and without the zero-coverage exception (the latter is what the kernel runs, with
-            // the y0 table): they may differ only in the sign of a zero when ntotal == 0; anything else comes back as NaN
+            // the guard-free form with the zero-coverage exception against what the scoring kernels run (k-scaled tables, no
+            // exception): they may differ only in the sign of a zero when ntotal == 0; anything else comes back as NaN, and so
+            // does any table index outside the rows wg_lookup_rows() grants this pseudo count and longest block
             const float a = wg_sample_term_pcpos(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab);
-            const float b = wg_sample_term_pcpos_nz(nmeth[q], ntotal[q], pc, pc2, g_iy0, g_fast.d_fast, &g_tab);
-            out[q] = (wg_f2u(a) == wg_f2u(b) || (a == 0.0f && b == 0.0f && ntotal[q] == 0.0f)) ? a : __builtin_nanf("");
-            // and with (double)k + logc looked up (narrow scoring tiles: blocks of <= 60 sites): bit-identical to the computed form
-            // and the k-scaled form of the scoring kernels: bit-identical, and every table index inside the rows wg_lookup_rows()
-            // grants this pseudo count and longest block
+            out[q] = a;
             for (int cls = 0; cls < 2; cls++) {                       // narrow tiles (blocks <= 60 sites), wide tiles (the ABI's longest)
                 const double max_total = cls ? 255.0 * 8000.0 : 255.0 * 60.0;
                 if ((double)ntotal[q] > max_total) continue;
@@ -188,7 +183,8 @@ void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, 
                 const double x = 1.0 - (double)p;
                 const int kf = (int32_t)(wg_f2u(p) - 0x3f330000u) >> 23, kd = (int32_t)((uint32_t)(wg_d2u(x) >> 32) - 0x3fe60000u) >> 20;
                 const float c = wg_sample_term_pcpos_ks(nmeth[q], ntotal[q], pc, pc2, g_iys0, g_kys0, &g_tab);
-                if (wg_f2u(c) != wg_f2u(b) || rows > WG_KY_KMIN + 1 || kf > 0 || kd > 0 || kf < -(rows - 1) || kd < -(rows - 1)) out[q] = __builtin_nanf("");
+                const bool same = wg_f2u(c) == wg_f2u(a) || (a == 0.0f && c == 0.0f && ntotal[q] == 0.0f);
+                if (!same || rows > WG_KY_KMIN + 1 || kf > 0 || kd > 0 || kf < -(rows - 1) || kd < -(rows - 1)) out[q] = __builtin_nanf("");
             }
         } else {
             out[q] = mode == 1 ? wg_sample_term(nmeth[q], ntotal[q], pc, pc2, &g_fast, &g_tab) : wg_sample_term_plain(nmeth[q], ntotal[q], pc, pc2, &g_tab);

@@ -136,13 +136,11 @@ struct wg_log_tables {
     wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}: filled by wg_tables_finish()
 };
 #define WG_LOG_TABLES_INIT { WG_LOG2F_TAB, WG_LOG2_TAB, WG_LOG2_TAB2, WG_LOG2_TAB }
-// What the scoring kernel keeps in LDS: the log2f table, the fast-log2 table and log2f's y0 table (4.6 KB).  The exact-log2 tables are
-// only needed by the rare fallback and stay in global/constant memory.
-#define WG_Y0_KMIN 25        // rows of f_y0: exponents k = -25 .. 0
+// What the scoring kernels of the general fast form (pseudo count 0 or in [2^-20, 4)) keep in LDS: the log2f table and the
+// fast-log2 table (1.3 KB).  The exact-log2 tables are only needed by the rare fallback and stay in global/constant memory.
 struct wg_fast_tables {
     wg_d2 f_tab[16];     // log2f {invc, logc}
     wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}
-    wg_d2 f_iy[(WG_Y0_KMIN + 1) * 16];    // log2f: {invc[i], y0 = logc[i] + (double)k} at [(k + 25) * 16 + i] — the SAME addition, done once; one 16-byte read
 };
 // With a pseudo count >= 4 (guard-free form) the scoring kernels use per-(k, i) tables for both logs instead
 // (wg_log2f_ks / wg_fast_log2_ks below): p and 1 - p are >= pc / (ntotal + 2 pc), so with blocks of at most 60 sites
@@ -243,25 +241,6 @@ WG_HD float wg_log2f_normal(float x, const wg_d2* __restrict__ ftab)
     const double y0 = logc + (double)k;
     const double r2 = r * r;
     double y = WG_FMA_K(r, WG_LOG2F_A1, WG_LOG2F_A2);          // (same products as A1*r + A2 etc.: multiplication commutes exactly)
-    y = WG_FMA(WG_LOG2F_A0, r2, y);
-    const double p = WG_FMA(WG_LOG2F_A3, r, y0);
-    return (float)WG_FMA(y, r2, p);
-}
-
-// Same again for x in [2^-25, 1] (the guard-free form: p > 2^-22), with y0 = logc + k looked up instead of computed:
-// (tmp >> 19) arithmetically IS k * 16 + i.  Saves the int->double conversion and the addition per evaluation; the
-// table entry is the result of that very addition, so the bits are the same.
-WG_HD float wg_log2f_y0(float x, const wg_d2* __restrict__ iytab)
-{
-    const uint32_t ix = wg_f2u(x);
-    const uint32_t tmp = ix - 0x3f330000u;
-    const int32_t ki = (int32_t)tmp >> 19;                       // k * 16 + i, k in [-25, 0]
-    const uint32_t iz = ix - (tmp & 0xff800000u);
-    const wg_d2 e = iytab[ki];                                   // iytab points at the row of k = 0; one shift-add for the address, one read for both
-    const double invc = e.a, y0 = e.b;
-    const double r = WG_FMA_K((double)wg_u2f(iz), invc, -1.0);
-    const double r2 = r * r;
-    double y = WG_FMA_K(r, WG_LOG2F_A1, WG_LOG2F_A2);
     y = WG_FMA(WG_LOG2F_A0, r2, y);
     const double p = WG_FMA(WG_LOG2F_A3, r, y0);
     return (float)WG_FMA(y, r2, p);
@@ -492,25 +471,11 @@ WG_HD float wg_sample_term_pcpos(float nmeth, float ntotal, float pc, float pc2,
     return res;
 }
 
-// The same without the zero-coverage exception, for callers that ADD the term to a running sum (the scoring kernel):
-// with ntotal == 0, p = 1/2, ll = 0 * log2f = -0.0, df = 0, s = -0.0 + 0 * L = -0.0, and adding -0.0 to the running
-// double sum leaves it unchanged, bit for bit — the reference's `continue` (:125) without a branch.
-// iy0: log2f's {invc, y0} table at its row k = 0; dfast: the fast-log2 table.
-WG_HD float wg_sample_term_pcpos_nz(float nmeth, float ntotal, float pc, float pc2, const wg_d2* __restrict__ iy0,
-                                    const wg_d2* __restrict__ dfast, const wg_log_tables* __restrict__ xt)
-{
-    const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
-    const float ll = nmeth * wg_log2f_y0(p, iy0);                  // :129-131
-    const float df = ntotal - nmeth;
-    const double x = 1.0 - (double)p;                              // :132-134
-    const double s = (double)ll + (double)df * wg_fast_log2(x, dfast);
-    float res = (float)s;
-    if (wg_in_guard_band(s))
-        res = (float)((double)ll + (double)df * wg_log2(1.0 - (double)wg_opaque_f32(p), xt->d_tab, xt->d_tab2));   // x recomputed: not kept live for the rare path
-    return res;
-}
-// The same on the k-scaled tables (narrow scoring tiles: blocks short enough for the rows the tables hold), with a
-// cheaper approximate sum: L' = wg_fast_log2_ks<false> is within E = WG_KS_LOG2_MAX_ULP ulp of libm's L, and the sum is ONE
+// What the scoring kernels run for pseudo counts >= 4: the guard-free form WITHOUT the zero-coverage exception — the
+// callers ADD the term to a running sum, and with ntotal == 0: p = 1/2, ll = 0 * log2f = -0.0, df = 0, s = -0.0 + 0 * L
+// = -0.0, and adding -0.0 to the running double sum leaves it unchanged, bit for bit: the reference's `continue` (:125)
+// without a branch — on the k-scaled tables (which must hold the rows wg_lookup_rows() names for the longest block
+// scored), with a cheaper approximate sum: L' = wg_fast_log2_ks<false> is within E = WG_KS_LOG2_MAX_ULP ulp of libm's L, and the sum is ONE
 // fused multiply-add.  Against the reference's s = fl(ll + fl(df L)):  |df L' - fl(df L)| <= (E 2^-52 + 2^-53) |df L|,
 // |df L| <= |s| (both addends <= 0), one more rounding of at most half an ulp, and ulp(s) >= 2^-53 |s|: |s' - s| <=
 // (2 E + 2) ulp(s) < WG_GUARD_ULPS_KS.  Inside that band around a float rounding midpoint the exact form decides, as ever.

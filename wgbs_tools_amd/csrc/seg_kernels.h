@@ -49,13 +49,9 @@ __device__ __forceinline__ void wg_fast_tables_to_lds(wg_fast_tables* ft, int ti
         if (x == 2 * WG_FAST_CENTRE_ENTRY + 1) v = 0.0;
         od[x] = v;
     }
-    for (int x = tid; x < (WG_Y0_KMIN + 1) * 16; x += nthreads) {
-        ft->f_iy[x].a = f[2 * (x & 15)];
-        ft->f_iy[x].b = f[2 * (x & 15) + 1] + (double)((x >> 4) - WG_Y0_KMIN);     // logc[i] + k, exactly as wg_log2f_normal adds them
-    }
 }
 
-// The two k-scaled lookup tables of the narrow guard-free scoring kernel (wg_log2f_ks / wg_fast_log2_ks), `rows` exponents
+// The two k-scaled lookup tables of the guard-free scoring kernels (wg_log2f_ks / wg_fast_log2_ks), `rows` exponents
 // each (k = -(rows-1) .. 0), from the constant tables in global memory:
 //   iy[(k + rows-1) * 16 + i] = {invc_f[i] * 2^-k, logc_f[i] + k}     ky[(k + rows-1) * 64 + i] = {invc_d[i] * 2^-k, k + logc_d[i]}
 // (interval WG_FAST_CENTRE_ENTRY of the fast log2 centred on 1, as in wg_tables_finish()).
@@ -662,8 +658,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     wg_fast_tables* tb = reinterpret_cast<wg_fast_tables*>(smem);
     wg_d2* iyt = reinterpret_cast<wg_d2*>(smem);
     wg_d2* kyt = iyt + (size_t)A.rows * 16;
-    const wg_d2* iy0 = KY ? iyt + (A.rows - 1) * 16 : tb->f_iy + WG_Y0_KMIN * 16;   // the rows of k = 0
-    const wg_d2* ky0 = KY ? kyt + (A.rows - 1) * 64 : nullptr;
+    const wg_d2* iy0 = iyt + (A.rows - 1) * 16;                                  // (KY) the rows of k = 0
+    const wg_d2* ky0 = kyt + (A.rows - 1) * 64;
     uint2* Et = reinterpret_cast<uint2*>(smem + TB);                             // wide: [NS][KS] P[i+1] of the ends
     uint2* St = Et + (size_t)A.NS * KS;                                          // wide: [NS][IS] P[k] of the starts
     uint32_t* Lt = reinterpret_cast<uint32_t*>(smem + TB);                       // narrow: [NS][KS] packed local prefixes
@@ -756,8 +752,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             // sample loop, unrolled by four by hand (the optimiser leaves a loop with the rare exact path inside alone):
             // one address update per four evaluations, the row offsets sit in the instructions' offset fields
             auto term = [&](float nm, float nt) -> double {
-                const float ll = FAST == 2 ? wg_sample_term_pcpos_nz(nm, nt, pc, pc2, iy0, tb->d_fast, &g_wg_tables)
-                               : (FAST == 1 ? wg_sample_term(nm, nt, pc, pc2, tb, &g_wg_tables) : wg_sample_term_plain(nm, nt, pc, pc2, &g_wg_tables));
+                const float ll = FAST == 1 ? wg_sample_term(nm, nt, pc, pc2, tb, &g_wg_tables) : wg_sample_term_plain(nm, nt, pc, pc2, &g_wg_tables);
                 return (double)ll;                                               // segmentor.cpp:135 adds the float term to the double sum
             };
             if (SPLIT) {
@@ -1524,18 +1519,24 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
 // ------------------------------------------------------------------------------------------------------------
 // test hooks
 // ------------------------------------------------------------------------------------------------------------
-__global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, float pc, float* out, int fast)
+// fast == 2: `rows` = wg_lookup_rows(pc, the ABI's largest block total), the k-scaled tables the scoring kernels would build
+__global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, float pc, float* out, int fast, int rows)
 {
     __shared__ wg_fast_tables tb;
+    __shared__ wg_d2 iyt[(WG_KY_KMIN + 1) * 16], kyt[(WG_KY_KMIN + 1) * 64];
     wg_fast_tables_to_lds(&tb, threadIdx.x, blockDim.x);
+    if (fast == 2) wg_lookup_tables_to_lds(iyt, kyt, rows, threadIdx.x, blockDim.x);
     __syncthreads();
     const float pc2 = pc + pc;
     if (fast == 2) {
-        // the guard-free form, with and without the zero-coverage exception: the two may differ only in the sign of a
-        // zero (ntotal == 0: +0 vs -0, the same contribution to a sum); anything else comes back as NaN
+        // the guard-free form with the zero-coverage exception against what the scoring kernels run (k-scaled tables, no
+        // exception): the two may differ only in the sign of a zero (ntotal == 0: +0 vs -0, the same contribution to a
+        // sum); anything else comes back as NaN
+        const wg_d2* iy0 = iyt + (rows - 1) * 16;
+        const wg_d2* ky0 = kyt + (rows - 1) * 64;
         for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x) {
             const float a = wg_sample_term_pcpos(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables);
-            const float b = wg_sample_term_pcpos_nz(nm[q], nt[q], pc, pc2, tb.f_iy + WG_Y0_KMIN * 16, tb.d_fast, &g_wg_tables);
+            const float b = wg_sample_term_pcpos_ks(nm[q], nt[q], pc, pc2, iy0, ky0, &g_wg_tables);
             out[q] = (wg_f2u(a) == wg_f2u(b) || (a == 0.0f && b == 0.0f && nt[q] == 0.0f)) ? a : __builtin_nanf("");
         }
         return;

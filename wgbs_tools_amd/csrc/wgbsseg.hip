@@ -956,7 +956,9 @@ int wgbsseg_debug_sample_terms(wgbsseg_ctx* c, const float* nmeth, const float* 
     HIP_TRY(hipMemcpyAsync(c->dbg_b.p, ntotal, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
     const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 8192);
     const int fast = wg_term_mode(pseudo_count);                                         // the library's own dispatch rule
-    hipLaunchKernelGGL(k_debug_terms, dim3(blocks), dim3(256), 0, c->sA, c->dbg_a.as<float>(), c->dbg_b.as<float>(), count, pseudo_count, c->dbg_c.as<float>(), fast);
+    const int rows = fast == 2 ? wg_lookup_rows(pseudo_count, 255.0 * 8000.0) : 0;       // the ABI's longest block (max_cpg <= 8000)
+    if (rows > WG_KY_KMIN + 1) return WGBSSEG_E_ARG;
+    hipLaunchKernelGGL(k_debug_terms, dim3(blocks), dim3(256), 0, c->sA, c->dbg_a.as<float>(), c->dbg_b.as<float>(), count, pseudo_count, c->dbg_c.as<float>(), fast, rows);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->dbg_c.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
