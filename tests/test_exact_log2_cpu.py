@@ -98,7 +98,7 @@ def _term_inputs(seed, n_random):
     return m, t
 
 
-@pytest.mark.parametrize('pcount', [15.0, 0.0, 0.5, 1.0, 3.25, 4.0, 3.9999998, 1000.0, 16777216.0, 16777218.0, 1e30, 3e38, 1e-30, 2e-6, 1e-7])
+@pytest.mark.parametrize('pcount', [15.0, 0.0, 0.5, 0.99999994, 1.0, 3.25, 4.0, 3.9999998, 1000.0, 16777216.0, 16777218.0, 1e30, 3e38, 1e-30, 2e-6, 1e-7])
 def test_sample_term_forms_match_oracle(exact, pcount):
     m, t = _term_inputs(11, 1000000)
     want = oracle.sample_terms(m, t, pcount)

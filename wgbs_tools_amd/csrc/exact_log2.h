@@ -142,9 +142,9 @@ struct wg_fast_tables {
     wg_d2 f_tab[16];     // log2f {invc, logc}
     wg_d2 d_fast[64];    // d_tab with entry WG_FAST_CENTRE_ENTRY replaced by {1, 0}
 };
-// With a pseudo count >= 4 (guard-free form) the scoring kernels use per-(k, i) tables for both logs instead
+// With a pseudo count >= 1 (guard-free form) the scoring kernels use per-(k, i) tables for both logs instead
 // (wg_log2f_ks / wg_fast_log2_ks below): p and 1 - p are >= pc / (ntotal + 2 pc), so with blocks of at most 60 sites
-// (narrow tiles) the exponent k lies in [-12, 0], with the ABI's longest blocks (255 * 8000) in [-20, 0]: at most
+// (narrow tiles) the exponent k lies in [-14, 0], with the ABI's longest blocks (255 * 8000) in [-21, 0]: at most
 // WG_KY_KMIN + 1 rows; how many a pseudo count and a longest block really need is wg_lookup_rows() (11 for the default
 // 15 and narrow tiles).  The kernels size both tables to that.
 #define WG_KY_KMIN 23
@@ -449,12 +449,14 @@ WG_HD float wg_div_f32(float a, float b)
 // result is never subnormal and the guard-band test needs no exponent check.  For p == 0 (pc == 0 and nmeth == 0)
 // the reference computes 0 + (ntotal-nmeth)*log2(1.0) = +0: ll stays +0.
 #define WG_FAST_MIN_PC 0x1p-20f
-// With a pseudo count >= 4 the guards of segmentor.cpp:129,132 are always true: 0 < p, and p < 1 even after both float
-// roundings ((nmeth+pc)/(ntotal+2pc) <= 1 - (pc-2)/(ntotal+2pc-1) with ntotal < 2^24: at least 2^-23 below 1).  The
+// With a pseudo count >= 1 the guards of segmentor.cpp:129,132 are always true: 0 < p, and p < 1 even after all three
+// float roundings: the ABI keeps ntotal <= 255 * 8000 < 2^21, where a float sum is off by at most 2^-4, so
+// fl(nmeth+pc) / fl(ntotal+2pc) <= 1 - (pc - 2^-3) / (ntotal + 2pc) <= 1 - 0.875 / (2^21 + 2) — more than 2^-22 below 1,
+// while the quotient's own rounding moves it by at most 2^-25.  The
 // `0 +` of :131 and the df == 0 exception fall away too: nmeth*log2f(p) is non-zero unless nmeth == 0, and then
 // df = ntotal > 0 makes the second term non-zero, so no sign of zero survives; df == 0 adds -0.0 to a non-zero ll.
 // Three compares, a move and two branch levels fewer per evaluation, same bits (tests: test_02, host twin).
-#define WG_POS_MIN_PC 4.0f
+#define WG_POS_MIN_PC 1.0f
 WG_HD float wg_sample_term_pcpos(float nmeth, float ntotal, float pc, float pc2, const wg_fast_tables* __restrict__ ft,
                                  const wg_log_tables* __restrict__ xt)
 {
@@ -471,7 +473,7 @@ WG_HD float wg_sample_term_pcpos(float nmeth, float ntotal, float pc, float pc2,
     return res;
 }
 
-// What the scoring kernels run for pseudo counts >= 4: the guard-free form WITHOUT the zero-coverage exception — the
+// What the scoring kernels run for pseudo counts >= 1: the guard-free form WITHOUT the zero-coverage exception — the
 // callers ADD the term to a running sum, and with ntotal == 0: p = 1/2, ll = 0 * log2f = -0.0, df = 0, s = -0.0 + 0 * L
 // = -0.0, and adding -0.0 to the running double sum leaves it unchanged, bit for bit: the reference's `continue` (:125)
 // without a branch — on the k-scaled tables (which must hold the rows wg_lookup_rows() names for the longest block
@@ -494,7 +496,7 @@ WG_HD float wg_sample_term_pcpos_ks(float nmeth, float ntotal, float pc, float p
     return res;
 }
 // Rows (exponents k = -(rows-1) .. 0) the two lookup tables need when every block has ntotal <= max_total and the pseudo
-// count is pc >= 4: p and 1 - p are both >= pc / (max_total + 2 pc) (less one float rounding, covered by the margin), and
+// count is pc >= 1: p and 1 - p are both >= pc / (max_total + 2 pc) (less one float rounding, covered by the margin), and
 // an argument v has k = floor(log2(v / 0.6875)) in wg_fast_log2 and floor(log2(v / 0.69921875)) in wg_log2f.
 static inline int wg_lookup_rows(float pc, double max_total)
 {

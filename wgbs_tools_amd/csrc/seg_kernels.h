@@ -649,7 +649,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 {
     constexpr int KS = SPLIT ? WG_WIDE_TK + 1 : TI + WG_NARROW_WMAX + 1;   // entries per sample row of the E array
     constexpr int IS = SPLIT ? WG_WIDE_TS + 1 : 0;                         // entries per sample row of the S array
-    // pseudo count >= 4: both logs on their k-scaled lookup tables, A.rows exponents each (sized by the host to the
+    // pseudo count >= 1: both logs on their k-scaled lookup tables, A.rows exponents each (sized by the host to the
     // longest block of the tile class)
     constexpr bool KY = (FAST == 2);
     extern __shared__ __attribute__((aligned(16))) char smem[];

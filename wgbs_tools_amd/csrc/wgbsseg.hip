@@ -523,7 +523,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const double Favg = (double)total_pairs / (double)std::max<int64_t>(1, J);
     const int WA = std::min(Wmax, WG_NARROW_WMAX);
     const int TKB = WG_WIDE_TK;
-    // exponent rows of the k-scaled log tables (pseudo count >= 4): narrow tiles score blocks of <= WG_NARROW_WMAX sites,
+    // exponent rows of the k-scaled log tables (pseudo count >= 1): narrow tiles score blocks of <= WG_NARROW_WMAX sites,
     // wide tiles blocks up to the job's widest window
     const bool ks = wg_term_mode(P->pseudo_count) == 2;
     const int rowsA = ks ? wg_lookup_rows(P->pseudo_count, 255.0 * WG_NARROW_WMAX) : 0;
