@@ -164,6 +164,28 @@ uint64_t ks_sum_ulp_gap(const float* nmeth, const float* ntotal, int64_t count, 
     }
     return mx;
 }
+// wg_lookup_rows against the arguments the kernels really compute: for every block total T in [t_lo, t_hi] the smallest p
+// (nmeth = 0) and the smallest 1 - p (nmeth = T) — and their neighbours nmeth = 1, T - 1 — must index inside the rows
+// granted for max_total = T.  Returns the number of violations.
+uint64_t lookup_rows_violations(float pc, uint32_t t_lo, uint32_t t_hi)
+{
+    const float pc2 = pc + pc;
+    uint64_t bad = 0;
+    for (uint32_t T = t_lo; T <= t_hi; T++) {
+        const int rows = wg_lookup_rows(pc, (double)T);
+        const float t = (float)T;
+        const float ms[4] = {0.0f, 1.0f, t - 1.0f, t};
+        for (int j = 0; j < 4; j++) {
+            const float m = ms[j];
+            if (m < 0.0f || m > t) continue;
+            const float p = wg_div_f32(m + pc, t + pc2);
+            const double x = 1.0 - (double)p;
+            const int kf = (int32_t)(wg_f2u(p) - 0x3f330000u) >> 23, kd = (int32_t)((uint32_t)(wg_d2u(x) >> 32) - 0x3fe60000u) >> 20;
+            if (kf > 0 || kd > 0 || kf < -(rows - 1) || kd < -(rows - 1) || !(p > 0.0f) || !(p < 1.0f)) bad++;
+        }
+    }
+    return bad;
+}
 void exact_sample_terms(const float* nmeth, const float* ntotal, int64_t count, float pc, float* out)
 {
     float pc2 = pc + pc;

@@ -37,6 +37,8 @@ def load_exact():
         getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
     L.exact_ks_mismatches.restype = C.c_uint64
     L.exact_ks_mismatches.argtypes = [C.c_uint32, C.c_uint64, C.c_int, C.c_void_p]
+    L.lookup_rows_violations.restype = C.c_uint64
+    L.lookup_rows_violations.argtypes = [C.c_float, C.c_uint32, C.c_uint32]
     L.ks_log2_max_ulp.restype = C.c_uint64
     L.ks_log2_max_ulp.argtypes = [C.c_uint32, C.c_uint64, C.c_int]
     L.ks_sum_ulp_gap.restype = C.c_uint64
@@ -124,6 +126,13 @@ def _hdr_const(name):
     import re
     m = re.search(r'#define\s+%s\s+(\d+)' % name, open(HDR).read())
     return int(m.group(1))
+
+
+@pytest.mark.parametrize('pcount', [1.0, 1.0000001, 1.5, 3.3333333, 4.0, 15.0, 15.000001, 100.0, 16777216.0])
+def test_lookup_table_rows_cover_every_computed_argument(exact, pcount):
+    """wg_lookup_rows (how many exponent rows the k-scaled tables get) against the p and 1 - p the kernels compute, for
+    EVERY block total the ABI admits (1 .. 255 * 8000) at the extreme counts: no index outside the rows, 0 < p < 1."""
+    assert exact.lookup_rows_violations(C.c_float(pcount), 1, 255 * 8000) == 0
 
 
 def test_shortened_log2_polynomial_error_and_guard_band(exact):

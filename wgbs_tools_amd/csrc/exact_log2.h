@@ -495,14 +495,20 @@ WG_HD float wg_sample_term_pcpos_ks(float nmeth, float ntotal, float pc, float p
         res = (float)((double)ll + (double)df * wg_log2(1.0 - (double)wg_opaque_f32(p), xt->d_tab, xt->d_tab2));
     return res;
 }
-// Rows (exponents k = -(rows-1) .. 0) the two lookup tables need when every block has ntotal <= max_total and the pseudo
-// count is pc >= 1: p and 1 - p are both >= pc / (max_total + 2 pc) (less one float rounding, covered by the margin), and
-// an argument v has k = floor(log2(v / 0.6875)) in wg_fast_log2 and floor(log2(v / 0.69921875)) in wg_log2f.
+// Rows (exponents k = -(rows-1) .. 0) the two lookup tables need when every block has ntotal <= max_total < 2^21 and the
+// pseudo count is pc >= 1.  In exact arithmetic p and 1 - p are both >= v = pc / (max_total + 2 pc) >= 2^-21.01.  The
+// computed p = fl(fl(nmeth+pc) / fl(ntotal+2pc)) carries three float roundings, a relative error below 3 * 2^-24: the
+// smallest computed p is >= v (1 - 2^-22), and the smallest computed 1 - p (the subtraction is exact in double) is
+// >= v - 3 * 2^-24 > v - 2^-22 — an ABSOLUTE error, a quarter of v at the extreme.  An argument w has exponent
+// k = floor(log2(w / 0.6875)) in wg_fast_log2 and floor(log2(w / 0.69921875)) in wg_log2f: the LARGER base gives the lower
+// exponent, so the rows must reach down to 0.69921875 * 2^-(rows-1) <= w (tests/test_exact_log2_cpu.py walks every block
+// total the ABI admits).
 static inline int wg_lookup_rows(float pc, double max_total)
 {
-    const double vmin = (double)pc / (max_total + 2.0 * (double)pc) * (1.0 - 0x1p-18);
+    const double v = (double)pc / (max_total + 2.0 * (double)pc);
+    const double wmin = v - 0x1p-22;
     int rows = 1;
-    for (double lo = 0.6875; lo > vmin; lo *= 0.5) rows++;       // 0.6875 <= 0.69921875: the smaller base bounds both
+    for (double lo = 0.69921875; !(lo <= wmin) && rows <= 64; lo *= 0.5) rows++;
     return rows;
 }
 
