@@ -128,6 +128,19 @@ def _hdr_const(name):
     return int(m.group(1))
 
 
+@pytest.mark.parametrize('pcount', [15.0, 1.0, 2.5, 0.5, 0.0])
+def test_sample_term_on_the_whole_small_count_lattice(exact, pcount):
+    """Every (nmeth, ntotal) with ntotal <= 2200 (2.4 M blocks — the counts short blocks really have), all forms against
+    the oracle's term."""
+    t = np.repeat(np.arange(0, 2201), np.arange(1, 2202)).astype(np.float32)
+    m = np.concatenate([np.arange(0, k + 1) for k in range(0, 2201)]).astype(np.float32)
+    want = oracle.sample_terms(m, t, pcount)
+    for fn in (exact.exact_sample_terms, exact.exact_sample_terms_plain):
+        got = np.empty_like(t)
+        fn(m.ctypes.data, t.ctypes.data, t.size, C.c_float(pcount), got.ctypes.data)
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), fn
+
+
 @pytest.mark.parametrize('pcount', [1.0, 1.0000001, 1.5, 3.3333333, 4.0, 15.0, 15.000001, 100.0, 16777216.0])
 def test_lookup_table_rows_cover_every_computed_argument(exact, pcount):
     """wg_lookup_rows (how many exponent rows the k-scaled tables get) against the p and 1 - p the kernels compute, for
