@@ -19,14 +19,9 @@ struct ks_tables { wg_d2 iy[(WG_KY_KMIN + 1) * 16], ky[(WG_KY_KMIN + 1) * 64]; }
 static ks_tables make_ks()
 {
     ks_tables t;
-    for (int x = 0; x < (WG_KY_KMIN + 1) * 16; x++) {
-        const int k = (x >> 4) - WG_KY_KMIN;
-        t.iy[x].a = g_tab.f_tab[x & 15].a * (double)(1u << -k); t.iy[x].b = g_tab.f_tab[x & 15].b + (double)k;
-    }
-    for (int x = 0; x < (WG_KY_KMIN + 1) * 64; x++) {
-        const int k = (x >> 6) - WG_KY_KMIN;
-        t.ky[x].a = g_tab.d_fast[x & 63].a * (double)(1u << -k); t.ky[x].b = (double)k + g_tab.d_fast[x & 63].b;
-    }
+    wg_log_tables raw = WG_LOG_TABLES_INIT;                      // (the builders re-centre the fast-log2 interval themselves)
+    for (int x = 0; x < (WG_KY_KMIN + 1) * 16; x++) t.iy[x] = wg_ks_iy_entry(&raw, WG_KY_KMIN + 1, x);
+    for (int x = 0; x < (WG_KY_KMIN + 1) * 64; x++) t.ky[x] = wg_ks_ky_entry(&raw, WG_KY_KMIN + 1, x);
     return t;
 }
 static const ks_tables g_ks = make_ks();

@@ -512,6 +512,29 @@ static inline int wg_lookup_rows(float pc, double max_total)
     return rows;
 }
 
+// Entry x of the two k-scaled tables with `rows` exponents (k = -(rows-1) .. 0), from the constant tables:
+//   iy[(k + rows-1) * 16 + i] = {invc_f[i] * 2^-k, logc_f[i] + k}     ky[(k + rows-1) * 64 + i] = {invc_d[i] * 2^-k, k + logc_d[i]}
+// (interval WG_FAST_CENTRE_ENTRY of the fast log2 centred on 1, as in wg_tables_finish()).  The scaling is exact (a
+// power of two), the second member is the one IEEE addition the unscaled functions perform per call: host and device
+// builds produce the same bits.
+WG_HD wg_d2 wg_ks_iy_entry(const wg_log_tables* __restrict__ tb, int rows, int x)
+{
+    const int k = (x >> 4) - (rows - 1);
+    wg_d2 e;
+    e.a = tb->f_tab[x & 15].a * (double)(1u << -k);
+    e.b = tb->f_tab[x & 15].b + (double)k;                        // logc[i] + k, exactly as wg_log2f_normal adds them
+    return e;
+}
+WG_HD wg_d2 wg_ks_ky_entry(const wg_log_tables* __restrict__ tb, int rows, int x)
+{
+    const int i = x & 63, k = (x >> 6) - (rows - 1);
+    const bool centre = i == WG_FAST_CENTRE_ENTRY;
+    wg_d2 e;
+    e.a = (centre ? 1.0 : tb->d_tab[i].a) * (double)(1u << -k);
+    e.b = (double)k + (centre ? 0.0 : tb->d_tab[i].b);            // (double)k + logc, exactly as wg_fast_log2 adds them
+    return e;
+}
+
 // term mode of a pseudo count: 0 plain exact form, 1 fast form with the guards, 2 fast form without them
 // Above WG_FAST_MAX_PC the plain exact form is used as well: the division core is validated for divisors below 2^26
 // (ntotal + 2 pc with ntotal < 2^24), and a pseudo count whose double overflows makes p == 0, which the guard-free form excludes.

@@ -51,25 +51,18 @@ __device__ __forceinline__ void wg_fast_tables_to_lds(wg_fast_tables* ft, int ti
     }
 }
 
-// The two k-scaled lookup tables of the guard-free scoring kernels (wg_log2f_ks / wg_fast_log2_ks), `rows` exponents
-// each (k = -(rows-1) .. 0), from the constant tables in global memory:
-//   iy[(k + rows-1) * 16 + i] = {invc_f[i] * 2^-k, logc_f[i] + k}     ky[(k + rows-1) * 64 + i] = {invc_d[i] * 2^-k, k + logc_d[i]}
-// (interval WG_FAST_CENTRE_ENTRY of the fast log2 centred on 1, as in wg_tables_finish()).
-__device__ __forceinline__ void wg_lookup_tables_to_lds(wg_d2* iy, wg_d2* ky, int rows, int tid, int nthreads)
+// The two k-scaled lookup tables of the guard-free scoring kernels (wg_log2f_ks / wg_fast_log2_ks; entries:
+// wg_ks_iy_entry / wg_ks_ky_entry), `rows` exponents each, iy then ky back to back.  The host builds them once per
+// call (`src`, global memory): a workgroup just copies 16-byte entries.  src == NULL: build them here (test hook).
+__device__ __forceinline__ void wg_lookup_tables_to_lds(wg_d2* iy, wg_d2* ky, int rows, const wg_d2* __restrict__ src, int tid, int nthreads)
 {
-    const double* f = reinterpret_cast<const double*>(g_wg_tables.f_tab);
-    const double* d = reinterpret_cast<const double*>(g_wg_tables.d_tab);
-    for (int x = tid; x < rows * 16; x += nthreads) {
-        const int k = (x >> 4) - (rows - 1);
-        iy[x].a = f[2 * (x & 15)] * (double)(1u << -k);                           // exact: a power of two
-        iy[x].b = f[2 * (x & 15) + 1] + (double)k;                                // logc[i] + k, exactly as wg_log2f_normal adds them
+    if (src) {
+        wg_d2* dst = iy;                                           // ky == iy + rows * 16
+        for (int x = tid; x < rows * (16 + 64); x += nthreads) dst[x] = src[x];
+        return;
     }
-    for (int x = tid; x < rows * 64; x += nthreads) {
-        const int i = x & 63, k = (x >> 6) - (rows - 1);
-        const bool centre = i == WG_FAST_CENTRE_ENTRY;
-        ky[x].a = (centre ? 1.0 : d[2 * i]) * (double)(1u << -k);
-        ky[x].b = (double)k + (centre ? 0.0 : d[2 * i + 1]);                      // (double)k + logc, exactly as wg_fast_log2 adds them
-    }
+    for (int x = tid; x < rows * 16; x += nthreads) iy[x] = wg_ks_iy_entry(&g_wg_tables, rows, x);
+    for (int x = tid; x < rows * 64; x += nthreads) ky[x] = wg_ks_ky_entry(&g_wg_tables, rows, x);
 }
 
 struct ChunkDesc {
@@ -519,6 +512,7 @@ struct CostArgs {
     float pc, pc2;
     int32_t NS;        // samples per LDS group
     int32_t rows;      // guard-free kernels: exponents held by the two lookup tables (wg_lookup_rows for the longest block of the tile class)
+    const wg_d2* tab;  // those tables, built by the host: rows * 16 log2f entries, then rows * 64 fast-log2 entries
 };
 
 // Stage the exclusive prefixes P[A+x], x = x0 .. x0+cnt-1, of sample row `row` into dst[0..cnt) (one wavefront).
@@ -684,7 +678,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int et_hi = SPLIT ? et_lo + WG_WIDE_TK : (1 << 30);
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
 
-    if (KY) wg_lookup_tables_to_lds(iyt, kyt, A.rows, tid, WG_BLOCK);
+    if (KY) wg_lookup_tables_to_lds(iyt, kyt, A.rows, A.tab, tid, WG_BLOCK);
     else wg_fast_tables_to_lds(tb, tid, WG_BLOCK);
     if (wv == 0) {
         const int k = ka + lane;
@@ -1525,7 +1519,7 @@ __global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, f
     __shared__ wg_fast_tables tb;
     __shared__ wg_d2 iyt[(WG_KY_KMIN + 1) * 16], kyt[(WG_KY_KMIN + 1) * 64];
     wg_fast_tables_to_lds(&tb, threadIdx.x, blockDim.x);
-    if (fast == 2) wg_lookup_tables_to_lds(iyt, kyt, rows, threadIdx.x, blockDim.x);
+    if (fast == 2) wg_lookup_tables_to_lds(iyt, kyt, rows, nullptr, threadIdx.x, blockDim.x);
     __syncthreads();
     const float pc2 = pc + pc;
     if (fast == 2) {

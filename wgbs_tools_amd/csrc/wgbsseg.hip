@@ -115,7 +115,8 @@ struct wgbsseg_ctx {
     DevBuf plan_cbase, plan_cum0, plan_tbase, plan_pairs, plan_tiles, plan_cnt, tilesA, tilesB, umax16;
     std::vector<PinnedBuf> pinned;
     std::vector<PinnedBuf> up_stage;   // two page-locked staging pieces per upload thread (set_betas_host)
-    DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders, dbg_a, dbg_b, dbg_c;
+    DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders, dbg_a, dbg_b, dbg_c, lookup;
+    std::vector<wg_d2> h_lookup;   // host copy of the k-scaled log tables of the call in flight (source of an async upload)
     // events
     hipEvent_t ev[8] = {};
     PinnedBuf h_status;      // page-locked landing area of the status words: D2H copies that really are asynchronous
@@ -260,7 +261,7 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->wtile, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs,
                      &c->status, &c->plan_cbase, &c->plan_cum0, &c->plan_tbase, &c->plan_pairs, &c->plan_tiles, &c->plan_cnt, &c->tilesA, &c->tilesB, &c->umax16,
                      &c->cost[0], &c->cost[1], &c->dpstate, &c->tmp_borders, &c->nb, &c->boff, &c->out_borders,
-                     &c->dbg_a, &c->dbg_b, &c->dbg_c};
+                     &c->dbg_a, &c->dbg_b, &c->dbg_c, &c->lookup};
     for (auto* b : all) b->release();
     for (auto& pb : c->pinned) pb.release();
     for (auto& pb : c->up_stage) pb.release();
@@ -574,6 +575,20 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     caB = caA;
     caA.NS = NSA; caA.rows = rowsA;
     caB.NS = NSB; caB.rows = rowsB;
+    if (ks) {   // the k-scaled tables of both tile classes, built here once per call (same IEEE operations as on the device)
+        static const wg_log_tables host_tabs = WG_LOG_TABLES_INIT;
+        c->h_lookup.resize((size_t)(rowsA + rowsB) * 80);
+        wg_d2* ta = c->h_lookup.data();
+        wg_d2* tb2 = ta + (size_t)rowsA * 80;
+        for (int x = 0; x < rowsA * 16; x++) ta[x] = wg_ks_iy_entry(&host_tabs, rowsA, x);
+        for (int x = 0; x < rowsA * 64; x++) ta[rowsA * 16 + x] = wg_ks_ky_entry(&host_tabs, rowsA, x);
+        for (int x = 0; x < rowsB * 16; x++) tb2[x] = wg_ks_iy_entry(&host_tabs, rowsB, x);
+        for (int x = 0; x < rowsB * 64; x++) tb2[rowsB * 16 + x] = wg_ks_ky_entry(&host_tabs, rowsB, x);
+        HIP_TRY(c->lookup.ensure(c->h_lookup.size() * sizeof(wg_d2)));
+        HIP_TRY(hipMemcpyAsync(c->lookup.p, c->h_lookup.data(), c->h_lookup.size() * sizeof(wg_d2), hipMemcpyHostToDevice, c->sA));   // h_lookup lives in the context
+        caA.tab = c->lookup.as<wg_d2>();
+        caB.tab = caA.tab + (size_t)rowsA * 80;
+    }
     const size_t ldsA = (size_t)round_up((int64_t)lds_for(TI, false, NSA), 16);
     const size_t ldsB = (size_t)round_up((int64_t)lds_for(WG_WIDE_TS, true, NSB), 16);
     const int term_mode = wg_term_mode(P->pseudo_count);
