@@ -82,7 +82,9 @@ void wgbsseg_destroy(wgbsseg_ctx* ctx);
  * Beta data: n_samples arrays of n_sites x 2 uint8 (#meth, #cov) — the `.beta` file format
  * (docs/beta_format.md:3-8; what read_beta_file segmentor.cpp:164-177 reads).  Sample order = argv order of the
  * reference (it fixes the order of the double accumulation, segmentor.cpp:120-136).
- * _host: copies every sample into one device allocation [n_samples][pitch] (pitch = 2*n_sites rounded up to 256 B).
+ * _host: copies every sample into one device allocation [n_samples][pitch] (pitch = 2*n_sites rounded up to 256 B);
+ *        the pointers may be pageable memory (e.g. memory-mapped .beta files): above 32 MB the copy runs on a few host
+ *        threads through page-locked staging pieces (WGBSSEG_UPLOAD_THREADS, default 4).  Blocking.
  * _device: borrows a device buffer with that layout; `base` and `pitch_bytes` must be multiples of 16.
  */
 int wgbsseg_set_betas_host(wgbsseg_ctx* ctx, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites,
