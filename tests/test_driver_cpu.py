@@ -381,3 +381,88 @@ def test_native_stitching_matches_reference_driver(name, speculate, driver_golde
     assert hashlib.sha1(np.ascontiguousarray(table).tobytes()).hexdigest() == g['table_sha1']
     for r, (a, b) in zip(res, regions):
         assert r[0] == a and r[-1] == b and (np.diff(r) > 0).all()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# randomised worlds: the native chunk grid + stitching against a plain sequential walk of the reference's pairwise
+# tree (segment.py:157-165) over stitch_2_dfs, with an adversarial engine — a pure function of (start, end) whose
+# borders depend on where the DP started, so that neighbouring results disagree around many junctions and patches have to
+# double (and sometimes swallow a whole operand)
+# ------------------------------------------------------------------------------------------------------------
+class FickleEngine:
+    """Borders of a range = its ends + the sites x with h(x, flavour) == 0, flavour = a hash of the range's start:
+    two DPs over the same sites agree only where their flavours do.  `agree_from`: beyond that many sites from its own
+    start a DP forgets where it started (like the real one does), so that long enough patches do reconcile."""
+
+    def __init__(self, seed, density, agree_from):
+        self.seed, self.density, self.agree_from = seed, density, agree_from
+        self.calls = []
+
+    def _borders(self, start, end):
+        x = np.arange(start + 1, end, dtype=np.int64)
+        flav = (start * 2654435761 + self.seed) % 3
+        local = (x - start) < self.agree_from
+        h = (x * 0x9E3779B1 + np.where(local, flav, 0) * 0x85EBCA6B + self.seed) % (1 << 32)
+        inner = x[(h >> 7) % self.density == 0]
+        return np.concatenate([[start], inner, [end]]).astype(np.int64)
+
+    def segment_many(self, sites_list, params):
+        self.calls += [tuple(s) for s in sites_list]
+        return [self._borders(int(a), int(b)) for a, b in sites_list]
+
+
+def _tree_merge(chunks, params):
+    lst = list(chunks)
+    while len(lst) > 1:                                  # segment.py:157-165
+        nxt = [S.stitch_2_dfs(lst[i - 1], lst[i], params) for i in range(1, len(lst), 2)]
+        if len(lst) % 2:
+            nxt.append(lst[-1])
+        lst = nxt
+    return lst[0]
+
+
+@pytest.mark.parametrize('seed', range(60))
+def test_native_stitching_on_random_worlds_with_a_fickle_engine(seed, stitch_lib):
+    rng = np.random.default_rng(4242 + seed)
+    chunk = int(rng.choice([40, 60, 97, 128, 333, 1000]))
+    n_regions = int(rng.integers(1, 5))
+    regions, pos = [], 1
+    for _ in range(n_regions):
+        ln = int(rng.integers(1, 9 * chunk))
+        regions.append((pos, pos + ln))
+        pos += ln + int(rng.integers(0, 3))
+    density = int(rng.choice([2, 3, 7, 20]))
+    agree_from = int(rng.choice([5, 30, 80, 170, 400]))
+    want, failed = [], None
+    try:
+        for a, b in regions:
+            eng = FickleEngine(seed, density, agree_from)
+            bords = list(range(a, b, chunk)) + [b]
+            chunks = eng.segment_many(list(zip(bords[:-1], bords[1:])), {})
+            want.append(_tree_merge(chunks, {'engine': eng}))
+    except G.IllegalArgumentError as e:                    # the reference gives up (patch grew past an operand)
+        failed = str(e)
+    for speculate in (0, 1):
+        eng = FickleEngine(seed, density, agree_from)
+        if failed is not None:
+            with pytest.raises(AssertionError, match='Patch stitching Failed'):
+                native_segment_regions(stitch_lib, eng, {}, regions, chunk, speculate)
+            continue
+        got, _ = native_segment_regions(stitch_lib, eng, {}, regions, chunk, speculate)
+        for g, w, (a, b) in zip(got, want, regions):
+            assert g.tolist() == w.tolist(), (seed, speculate, a, b)
+
+
+@pytest.mark.parametrize('speculate', [0, 1])
+def test_native_stitching_gives_up_like_the_reference(speculate, stitch_lib):
+    """A patch that never overlaps its operands grows until it would pass one of them: segment.py:229-232."""
+    class NeverOverlaps:
+        def segment_many(self, sites, params):
+            # chunk results (they start on the grid) are their own two ends; a patch answers with borders from nowhere
+            return [np.array([a, b], dtype=np.int64) + (0 if (a - 1) % 100 == 0 and b - a <= 100 else 1000000) for a, b in sites]
+    with pytest.raises(AssertionError, match='Try increasing chunk size'):
+        native_segment_regions(stitch_lib, NeverOverlaps(), {}, [(1, 451)], 100, speculate)
+    with pytest.raises(G.IllegalArgumentError, match='Try increasing chunk size'):
+        eng = NeverOverlaps()
+        bords = list(range(1, 451, 100)) + [451]
+        _tree_merge(eng.segment_many(list(zip(bords[:-1], bords[1:])), {}), {'engine': eng})
