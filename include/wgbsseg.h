@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define WGBSSEG_VERSION 100            /* 0.1.0 */
+#define WGBSSEG_VERSION 200            /* 0.2.0 */
+#define WGBSSEG_MAX_CPG 8000           /* largest max_cpg accepted (see wgbsseg_segment_chunks) */
 
 #define WGBSSEG_OK              0
 #define WGBSSEG_E_ARG          -1      /* bad argument (message says which) */
@@ -103,7 +104,10 @@ int wgbsseg_set_loci_device(wgbsseg_ctx* ctx, const void* loci, int64_t n_sites,
  * integers the reference prints (segmentor.cpp:30-34) — are borders_out[borders_off[c] .. borders_off[c+1]).
  * borders_off has n_chunks+1 entries; borders_cap >= sum(chunk_len) + n_chunks always suffices.
  * Errors the reference also raises: #meth > #cov inside a requested chunk (message names sample and site).
- * Rejected up front: max_bp == 0, max_cpg < 1, 255*max_cpg >= 2^24 (float-exact block sums), chunk out of range.
+ * Rejected up front: max_bp == 0, max_cpg < 1, max_cpg > WGBSSEG_MAX_CPG, chunk out of range.  The cap on max_cpg
+ * (the reference has none) keeps every block's counts below 2^21, which (a) keeps them exact in the float sums of
+ * segmentor.cpp:122-123 and (b) is what the proof that the guards of segmentor.cpp:129,132 never fire rests on
+ * (csrc/exact_log2.h).  Default max_cpg is 1000; the driver rejects larger values with a message that says so.
  */
 int wgbsseg_segment_chunks(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const int32_t* chunk_len,
                            int64_t n_chunks, const wgbsseg_params* params,
@@ -127,6 +131,68 @@ int wgbsseg_segment_regions(wgbsseg_ctx* ctx, const int64_t* region_start, const
                             int64_t chunk_size, const wgbsseg_params* params,
                             int32_t* borders_out, int64_t borders_cap, int64_t* borders_off, int64_t* stats,
                             char* err, size_t errlen);
+
+/*
+ * The native chunk grid + junction stitching of wgbsseg_segment_regions around a CALLER-SUPPLIED chunk engine: `fn` is
+ * called with batches of 1-based half-open site ranges (chunks and junction patches) and must set, for every range i,
+ * out_ptr[i] / out_cnt[i] to the range's border list RELATIVE to its start (int32, ascending, first 0, last end-start —
+ * what `segmentor` prints, segmentor.cpp:30-34); the lists must stay valid until wgbsseg_stitch_regions returns.
+ * Non-zero return of `fn` aborts.  Used by the multi-process driver (rank 0 stitches what the ranks' GPUs produced) and
+ * by the CPU test-suite (engine = the oracle).  speculate != 0: ask for a junction's possible second attempts together
+ * with the first (fewer, larger batches).  No device is touched by this call itself.
+ */
+typedef int (*wgbsseg_batch_fn)(void* user, const int64_t* starts, const int64_t* ends, int64_t n,
+                                const int32_t** out_ptr, int64_t* out_cnt);
+int wgbsseg_stitch_regions(const int64_t* region_start, const int64_t* region_end, int64_t n_regions, int64_t chunk_size,
+                           wgbsseg_batch_fn fn, void* user, int32_t speculate, int32_t* borders_out, int64_t borders_cap,
+                           int64_t* borders_off, int64_t* stats, char* err, size_t errlen);
+
+/* Absolute 0-based index of resident site 0 (default 0).  Coordinates of every call stay relative to the resident data;
+ * the base only makes error messages ("invalid data ... site N") name absolute sites when a context holds a slice. */
+int wgbsseg_set_site_base(wgbsseg_ctx* ctx, int64_t site_base);
+
+/*
+ * Share groups: the whole `Pool(threads)` of segment.py:144-146 spread over several GPUs from ONE process (the
+ * reference's `-@`).  A group owns one context per share (devices[d]: a device may appear more than once).
+ *   wgbsseg_group_plan     cuts the chunk grid of the regions (segment.py:124-135) into n_shares contiguous runs of chunks
+ *                          balanced by WORK (the number of candidate blocks the chunks hold, counted from the host loci
+ *                          with the window rule of segmentor.cpp:111-117, plus a per-site term), uploads every share's
+ *                          window of the loci, and reports the 0-based site window [win_lo, win_hi) each share must hold:
+ *                          its chunks +- `halo` sites (halo < 0: max(chunk_size, 4096)), lower edge on a multiple of 128.
+ *   wgbsseg_group_load_host        every share uploads ITS window of the beta bytes (samples[s] = whole-genome array of
+ *                          sample s, e.g. a memory-mapped .beta file), all shares side by side.
+ *   wgbsseg_group_share_set_device lends share `share` a device buffer that holds exactly its window: row s at
+ *                          base + s * pitch_bytes, n = win_hi - win_lo sites (base, pitch multiples of 16).
+ *   wgbsseg_group_segment_regions  = wgbsseg_segment_regions over the planned regions: every batch of the stitching loop
+ *                          (chunks + junction patches, then the follow-ups) is routed item by item to the share holding
+ *                          it and runs on one host thread per share; the reference's pairwise tree (segment.py:157-165)
+ *                          runs ONCE on the host over all results, so the borders are those of a one-GPU run whatever
+ *                          the number of shares.  No device-to-device traffic.  A junction patch that outgrows the halo
+ *                          (patch doubling past `halo` sites at a share boundary) fails with WGBSSEG_E_STATE.
+ * share_chunks / share_work (optional, n_shares each): chunks and work units given to each share.
+ */
+typedef struct wgbsseg_group wgbsseg_group;
+/* The planner on its own (host only, no device): own_lo/own_hi = 0-based sites [lo, hi) of the chunks given to each of the
+ * n_shares shares (hi == lo: none), win_* = those +- halo.  The multi-process driver (one rank per GPU) cuts the genome
+ * with it so that every rank computes the same shares. */
+int wgbsseg_plan_shares(const uint32_t* loci, int64_t n_sites, const int64_t* region_start, const int64_t* region_end,
+                        int64_t n_regions, int64_t chunk_size, const wgbsseg_params* params, int32_t n_shares, int64_t halo,
+                        int64_t* own_lo, int64_t* own_hi, int64_t* win_lo, int64_t* win_hi, int64_t* share_chunks,
+                        int64_t* share_work, char* err, size_t errlen);
+int wgbsseg_group_create(const int32_t* devices, int32_t n_shares, wgbsseg_group** out, char* err, size_t errlen);
+void wgbsseg_group_destroy(wgbsseg_group* g);
+int32_t wgbsseg_group_size(const wgbsseg_group* g);
+int wgbsseg_group_plan(wgbsseg_group* g, const uint32_t* loci, int64_t n_sites, const int64_t* region_start,
+                       const int64_t* region_end, int64_t n_regions, int64_t chunk_size, const wgbsseg_params* params,
+                       int64_t halo, int64_t* win_lo, int64_t* win_hi, int64_t* share_chunks, int64_t* share_work,
+                       char* err, size_t errlen);
+int wgbsseg_group_load_host(wgbsseg_group* g, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites,
+                            char* err, size_t errlen);
+int wgbsseg_group_share_set_device(wgbsseg_group* g, int32_t share, const void* base, int64_t n_samples,
+                                   int64_t pitch_bytes, char* err, size_t errlen);
+int wgbsseg_group_segment_regions(wgbsseg_group* g, int32_t* borders_out, int64_t borders_cap, int64_t* borders_off,
+                                  int64_t* stats, char* err, size_t errlen);
+int wgbsseg_group_get_timings(const wgbsseg_group* g, int32_t share, wgbsseg_timings* out);
 
 /*
  * One-shot form (host buffers in, host borders out): creates a context on `device`, uploads, segments, destroys.

@@ -46,6 +46,10 @@ def lib():
         L.oracle_segment_chunks.argtypes = [
             C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
             C.c_float, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+        L.oracle_segment_chunk_mt.restype = C.c_int
+        L.oracle_segment_chunk_mt.argtypes = [
+            C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_uint32, C.c_int,
+            C.c_void_p, C.POINTER(C.c_int)]
         L.oracle_sample_terms.restype = None
         L.oracle_sample_terms.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p]
         L.probe_log2f_fill.restype = None
@@ -97,6 +101,22 @@ def segment_chunk(slices, loci, pcount, max_cpg, max_bp, debug=False):
         raise OracleError(rc, bs.value, bi.value)
     b = borders[:nb.value].copy()
     return (b, M, T, band) if debug else b
+
+
+def segment_chunk_mt(slices, loci, pcount, max_cpg, max_bp, threads=None):
+    """One big chunk on many threads (cost rows in parallel, recurrence sequential): same arithmetic as
+    segment_chunk, for full-size cases (50,000 sites x 512 samples at max_cpg 5000)."""
+    slices = [np.ascontiguousarray(s, dtype=np.uint8) for s in slices]
+    n = slices[0].shape[0]
+    loci = np.ascontiguousarray(loci, dtype=np.uint32)
+    assert loci.shape[0] == n
+    borders = np.empty(n + 1, dtype=np.int32)
+    nb = C.c_int(0)
+    rc = lib().oracle_segment_chunk_mt(_ptr_array(slices), len(slices), n, loci.ctypes.data, C.c_float(pcount), int(max_cpg),
+                                       int(max_bp), int(threads or os.cpu_count() or 1), borders.ctypes.data, C.byref(nb))
+    if rc != ORACLE_OK:
+        raise OracleError(rc)
+    return borders[:nb.value].copy()
 
 
 def segment_chunks(samples, loci, start0, lens, pcount, max_cpg, max_bp, threads=1):

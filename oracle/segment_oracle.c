@@ -249,6 +249,117 @@ int oracle_segment_chunks(const uint8_t *const *samples, int n_samples, const ui
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * One BIG chunk on many threads (full-size parity tests: a 50,000-site chunk x 512 samples at max_cpg 5000 is
+ * 1.3e11 likelihood evaluations).  Same arithmetic as dp_core, statement for statement: a cost row depends only on
+ * its start site (segmentor.cpp:103-138), so rows are filled in parallel, slab by slab, into the reference's ring of
+ * rows (segmentor.cpp:92-95); the recurrence (segmentor.cpp:142-154) then runs over the slab sequentially, exactly as
+ * in dp_core.  tests/test_oracle_golden.py pins this variant to the single-threaded one and to the goldens.
+ * ---------------------------------------------------------------------------------------------- */
+static void cost_row(const oracle_params *pr, float *const *data, const uint32_t *loci, int i, double *row,
+                     float *run_m, float *run_t)
+{
+    const int n = pr->n_sites, N = pr->n_samples, max_cpg = pr->max_cpg;
+    for (int j = 0; j < max_cpg; j++) row[j] = 0.0;                 /* :106 */
+    memset(run_m, 0, sizeof(float) * (size_t)N);                    /* :108-109 */
+    memset(run_t, 0, sizeof(float) * (size_t)N);
+    int window = n - i < max_cpg ? n - i : max_cpg;                 /* :111 */
+    for (int j = 0; j < window; j++) {
+        if ((uint32_t)(loci[i + j] - loci[i]) > pr->max_bp || loci[i + j] < loci[i]) {   /* :114-117 */
+            row[j] = -INFINITY;
+            continue;
+        }
+        double ll_sum = 0;
+        for (int s = 0; s < N; s++) {                               /* :120-136, argv order */
+            run_m[s] += data[s][(size_t)(i + j) * 2];
+            run_t[s] += data[s][(size_t)(i + j) * 2 + 1];
+            float nt = run_t[s], nm = run_m[s];
+            if (!nt) continue;                                      /* :125 */
+            ll_sum += sample_term(nm, nt, pr->pseudo_count);        /* :135 */
+        }
+        if (ll_sum) row[j] = ll_sum;                                /* :137 */
+    }
+}
+
+typedef struct {
+    const oracle_params *pr; float *const *data; const uint32_t *loci;
+    double *rows; int mask; int i0, i1; int next; pthread_mutex_t *mu;
+} slab_t;
+
+static void *slab_worker(void *arg)
+{
+    slab_t *sb = (slab_t *)arg;
+    const int N = sb->pr->n_samples, max_cpg = sb->pr->max_cpg;
+    float *run_m = (float *)malloc(sizeof(float) * (size_t)N), *run_t = (float *)malloc(sizeof(float) * (size_t)N);
+    for (;;) {
+        pthread_mutex_lock(sb->mu);
+        int i = sb->next; sb->next += 8;
+        pthread_mutex_unlock(sb->mu);
+        if (i >= sb->i1) break;
+        for (int q = i; q < i + 8 && q < sb->i1; q++)
+            cost_row(sb->pr, sb->data, sb->loci, q, sb->rows + (size_t)(q & sb->mask) * (size_t)max_cpg, run_m, run_t);
+    }
+    free(run_m); free(run_t);
+    return NULL;
+}
+
+int oracle_segment_chunk_mt(const uint8_t *const *slices, int n_samples, int n_sites,
+                            const uint32_t *loci, float pseudo_count, int max_cpg, uint32_t max_bp, int threads,
+                            int32_t *borders, int *n_borders)
+{
+    if (n_samples < 1 || n_sites < 1 || max_cpg < 1 || !slices || !loci || !borders || !n_borders || max_bp == 0 || threads < 1)
+        return ORACLE_E_ARG;
+    if (threads > 512) threads = 512;
+    const int n = n_sites;
+    int rc = ORACLE_OK;
+    const int SLAB = 2048;
+    int ring = 1;
+    while (ring < max_cpg + SLAB) ring <<= 1;
+    const int mask = ring - 1;
+    float **data = (float **)calloc((size_t)n_samples, sizeof(float *));
+    double *M = (double *)malloc(sizeof(double) * ((size_t)n + 1));
+    int32_t *T = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    double *rows = (double *)malloc(sizeof(double) * (size_t)ring * (size_t)max_cpg);
+    if (!data || !M || !T || !rows) { rc = ORACLE_E_NOMEM; goto done; }
+    for (int s = 0; s < n_samples; s++) {
+        data[s] = (float *)malloc(sizeof(float) * 2 * (size_t)n);
+        if (!data[s]) { rc = ORACLE_E_NOMEM; goto done; }
+        for (size_t b = 0; b < 2 * (size_t)n; b++) data[s][b] = (float)slices[s][b];          /* :179 */
+        for (int i = 0; i < n; i++)
+            if (data[s][2 * (size_t)i] > data[s][2 * (size_t)i + 1]) { rc = ORACLE_E_METH_GT_COV; goto done; }   /* :181-188 */
+    }
+    {
+        oracle_params pr = { n_samples, n, pseudo_count, max_cpg, max_bp };
+        pthread_mutex_t mu;
+        pthread_mutex_init(&mu, NULL);
+        M[0] = 0.0; T[0] = 0;                                         /* :97 */
+        for (int i0 = 0; i0 < n; i0 += SLAB) {
+            const int i1 = i0 + SLAB < n ? i0 + SLAB : n;
+            slab_t sb = { &pr, data, loci, rows, mask, i0, i1, i0, &mu };
+            pthread_t th[512];
+            for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, slab_worker, &sb);
+            for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+            for (int i = i0; i < i1; i++) {                           /* :142-154, first maximum wins */
+                double best = -INFINITY;
+                int best_k = -1;
+                int k0 = i + 1 - max_cpg > 0 ? i + 1 - max_cpg : 0;
+                for (int k = k0; k <= i; k++) {
+                    double v = M[k] + rows[(size_t)(k & mask) * (size_t)max_cpg + (size_t)(i - k)];
+                    if (v > best) { best = v; best_k = k; }
+                }
+                M[i + 1] = best;
+                T[i + 1] = best_k;
+            }
+        }
+        pthread_mutex_destroy(&mu);
+        *n_borders = traceback(T, n, borders);
+    }
+done:
+    if (data) { for (int s = 0; s < n_samples; s++) free(data[s]); free(data); }
+    free(M); free(T); free(rows);
+    return rc;
+}
+
 /* The per-(block,sample) term on its own: lets tests compare the device evaluation point-wise. */
 float oracle_sample_term(float nmeth, float ntotal, float pseudo_count)
 {

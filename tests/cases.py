@@ -89,6 +89,13 @@ CHUNK_CASES = {
     'deep_long':      dict(n=20000, a=300000, samples=[0, 1, 2], pcount=15.0, max_cpg=3000, max_bp=100000000),
     'n33_samples':    dict(n=2000, a=130000, samples=list(range(33)), pcount=15.0, max_cpg=1000, max_bp=2000),
     'default_chunk':  dict(n=60000, a=200000, samples=list(range(8)), pcount=15.0, max_cpg=1000, max_bp=2000),
+    # atlas-scale sample counts (BASELINE.json configs[3], [4]): 7 and 16 LDS sample groups in the scoring kernel
+    'n200_samples':   dict(n=1500, a=140000, samples=list(range(200)), pcount=15.0, max_cpg=1000, max_bp=2000),
+    'n512_samples':   dict(n=800, a=150000, samples=list(range(512)), pcount=15.0, max_cpg=1000, max_bp=2000),
+    'n200_islands':   dict(n=4000, a=0, samples=list(range(200)), pcount=15.0, max_cpg=1000, max_bp=2000, loci='hg19like_islands',
+                           loci_seed=20260927),
+    'n512_deep':      dict(n=1200, a=160000, samples=list(range(512)), pcount=15.0, max_cpg=5000, max_bp=1000000),
+    'n200_pcount0':   dict(n=1000, a=170000, samples=list(range(200)), pcount=0.0, max_cpg=1000, max_bp=2000),
 }
 
 # chr21-shaped multi-chunk case (BASELINE.json configs[1]): 400,000 CpGs x 8 samples in default 60,000-site chunks

@@ -12,15 +12,16 @@ int stitch_segment_regions(const int64_t* rs, const int64_t* re, int64_t n_regio
                            int32_t* borders_out, int64_t cap, int64_t* borders_off, int64_t* stats, char* err, size_t errlen, int speculate)
 {
     wgstitch::BatchFn fn = [&](const std::vector<wgstitch::Sites>& todo, wgstitch::BatchResult& res, std::string& msg) -> int {
-        std::vector<int64_t> s(todo.size()), e(todo.size());
-        res.off.resize(todo.size() + 1);
+        std::vector<int64_t> s(todo.size()), e(todo.size()), off(todo.size() + 1);
         int64_t c = 0;
         for (size_t i = 0; i < todo.size(); i++) { s[i] = todo[i].first; e[i] = todo[i].second; c += e[i] - s[i] + 1; }
         std::vector<int64_t> out((size_t)c);
-        if (cb(s.data(), e.data(), (int64_t)todo.size(), out.data(), c, res.off.data()) != 0) { msg = "engine callback failed"; return -1; }
-        res.owned.reset(new int32_t[(size_t)c]); res.flat = res.owned.get();
+        if (cb(s.data(), e.data(), (int64_t)todo.size(), out.data(), c, off.data()) != 0) { msg = "engine callback failed"; return -1; }
+        res.owned.emplace_back(new int32_t[(size_t)c]);
+        int32_t* flat = res.owned.back().get();
         for (size_t i = 0; i < todo.size(); i++)
-            for (int64_t q = res.off[i]; q < res.off[i + 1]; q++) res.flat[(size_t)q] = (int32_t)(out[(size_t)q] - s[i]);   // relative, as the GPU path returns
+            for (int64_t q = off[i]; q < off[i + 1]; q++) flat[(size_t)q] = (int32_t)(out[(size_t)q] - s[i]);   // relative, as the GPU path returns
+        res.set_csr(flat, off.data(), todo.size());
         return 0;
     };
     std::string msg;

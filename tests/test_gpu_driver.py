@@ -71,6 +71,86 @@ def test_cli_matches_reference_driver(name, driver_golden, world, tmp_path):
         assert int(r[1]) == loci[s - 1] and int(r[2]) == loci[e - 2] + 1
 
 
+@pytest.mark.parametrize('name,gpus', [('wg_c20000', 3), ('wg_pcount0', 2), ('sites_3chunks', 4), ('bed_regions', 3), ('tiny_chunks', 5),
+                                       ('small_chunks', 8)])
+def test_cli_over_a_share_group_matches_reference_driver(name, gpus, driver_golden, world, tmp_path):
+    """`wgbstools segment --gpus N`: one process, N shares (on this 1-GPU box they wrap around device 0), every share
+    holding only its own window of the beta files, one host-side tree: the reference driver's blocks, whatever N."""
+    g = driver_golden['cases'][name]
+    out = str(tmp_path / 'blocks.bed')
+    argv = ['wgbstools', 'segment', '--betas'] + world['paths'] + ['--genome', world['refdir'], '-o', out, '--gpus', str(gpus)]
+    for k, v in g['args'].items():
+        flag = {'chunk_size': '-c', 'min_cpg': '--min_cpg', 'sites': '-s', 'pcount': '-p', 'max_cpg': '--max_cpg', 'max_bp': '--max_bp'}[k]
+        argv += [flag, str(v)]
+    if g['bed_rows'] is not None:
+        bed = str(tmp_path / 'regions.bed')
+        with open(bed, 'w') as f:
+            for s, e in g['bed_rows']:
+                f.write('chrN\t0\t1\t%d\t%d\n' % (s, e))
+        argv += ['-L', bed]
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        rc = wgbs_tools.main(argv)
+    assert rc == 0, err.getvalue()
+    rows = [l.rstrip('\n').split('\t') for l in open(out)]
+    table = np.array([[int(r[3]), int(r[4])] for r in rows], dtype=np.int64).reshape(-1, 2)
+    assert table.shape[0] == g['n_blocks']
+    assert hashlib.sha1(table.tobytes()).hexdigest() == g['table_sha1']
+
+
+def test_share_group_plan_windows_and_errors(world):
+    """The group API directly: windows cover the shares, a share reports #meth > #cov with the ABSOLUTE site, a share
+    without data is refused, the group result equals the one-context result."""
+    from wgbs_tools_amd import _lib
+    sizes, loci = world['sizes'], world['loci']
+    total = int(sum(sizes))
+    regions, pos = [], 1
+    for sz in sizes:
+        regions.append((pos, pos + sz))
+        pos += sz
+    maps = [np.fromfile(p, dtype=np.uint8) for p in world['paths']]
+    with _lib.Segmenter(0) as seg:
+        seg.set_betas([m.reshape(-1, 2) for m in maps])
+        seg.set_loci(loci)
+        st = np.array([r[0] for r in regions]); en = np.array([r[1] for r in regions])
+        want, _ = seg.segment_regions(st, en, 9000, 15.0, 1000, 2000)
+    with _lib.SegmenterGroup([0, 0, 0, 0]) as grp:
+        w = grp.plan(loci, regions, 9000, 15.0, 1000, 2000)
+        assert w['chunks'].sum() == sum(-(-sz // 9000) for sz in sizes) and (w['chunks'] > 0).all()
+        with pytest.raises(_lib.SegmentorError, match='no beta data'):
+            grp.segment_regions()
+        grp.load_host(maps)
+        got, stats = grp.segment_regions()
+        assert stats['chunks'] == w['chunks'].sum()
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        # a bad site inside the third share
+        bad_site = int(w['win_lo'][2]) + 9000 + 77
+        maps2 = [m.copy() for m in maps]
+        maps2[1][2 * bad_site] = maps2[1][2 * bad_site + 1] + 1
+        grp.load_host(maps2)
+        with pytest.raises(_lib.SegmentorError, match=r'sample 1 .*site %d \(0-based\)' % bad_site):
+            grp.segment_regions()
+        # a halo too small for the junction patches between shares is refused, not silently wrong
+        w = grp.plan(loci, regions, 9000, 15.0, 1000, 2000, halo=10)
+        sh = _lib.plan_shares(loci, regions, 9000, 15.0, 1000, 2000, 4, halo=10)
+        assert np.array_equal(sh['win_lo'], w['win_lo']) and np.array_equal(sh['win_hi'], w['win_hi'])
+        ends = set(r[1] - 1 for r in regions)
+        uncovered = False
+        for d in range(3):                                   # first-attempt patch of the junction between shares d and d+1
+            j0 = int(sh['own_hi'][d])
+            if j0 in ends:
+                continue                                     # a chromosome boundary: no junction
+            uncovered = uncovered or not any(sh['win_lo'][q] <= j0 - 50 and j0 + 50 <= sh['win_hi'][q] for q in (d, d + 1))
+        grp.load_host(maps)
+        if uncovered:
+            with pytest.raises(_lib.SegmentorError, match='not resident on any single share'):
+                grp.segment_regions()
+        else:
+            got2, _ = grp.segment_regions()
+            assert all(np.array_equal(a, b) for a, b in zip(got2, want))
+
+
 def test_python_stitching_path_equals_native_path(driver_golden, world, tmp_path):
     """The driver's numpy stitching (mirror of segment.py:199-252) and the native rope stitching must agree when both
     run over the HIP chunk engine."""
@@ -78,7 +158,7 @@ def test_python_stitching_path_equals_native_path(driver_golden, world, tmp_path
     g = driver_golden['cases']['wg_c20000']
     args = argparse.Namespace(sites=None, region=None, array_id=None, bed_file=None, genome=world['refdir'], betas=world['paths'],
                               beta_file=None, chunk_size=20000, pcount=15, min_cpg=1, max_cpg=1000, max_bp=2000,
-                              out_path=str(tmp_path / 'a.bed'), threads=1, device=0)
+                              out_path=str(tmp_path / 'a.bed'), threads=1, device=0, gpus=1)
     gen = G.GenomeRefPaths(world['refdir'])
 
     class PyOnly:                                   # hides segment_regions -> forces the numpy stitching path

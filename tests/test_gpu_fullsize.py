@@ -1,0 +1,282 @@
+"""Parity at the north star's sizes (BASELINE.json configs[2..4]) on the GPU, through the C ABI.
+
+  x32   hg19-shaped 28,217,448 CpGs x 32 betas, whole genome: a spread sample of 256 full-size chunks against the
+        reference binary (oracle/_ref/segmentor), one whole chromosome chunk by chunk AND patch by patch against it,
+        and the STITCHED border lists of four chromosomes against the reference's pairwise tree (segment.py:157-165,
+        199-252; restated in wgbs_tools_amd/segment.py and pinned there by vectors captured from the reference's
+        driver) walked over the same chunk / patch DPs.
+  x200  the same genome x 200 betas (7 LDS sample groups in the scoring kernel): 64 sampled chunks against the
+        reference binary, the stitched result of three chromosomes against the tree, genome-wide properties.
+  x512  one piece of configs[4] (max_cpg 5000, max_bp 1e6, chunk 50000, 512 betas): eight 50,000-site chunks on the
+        GPU; one FULL chunk against the many-thread oracle restatement (1.3e11 evaluations), four reduced chunks
+        against the reference binary, stitched result against the tree.
+
+Bit-exact everywhere.  The genome-wide properties: borders strictly ascending, first/last = the chromosome's ends,
+every block <= max_cpg sites and <= max_bp base pairs (segmentor.cpp:111-117).
+"""
+import os
+import os.path as op
+import shutil
+import subprocess
+import tempfile
+import threading
+
+import ctypes as C
+import numpy as np
+import pytest
+
+from oracle import oracle
+from wgbs_tools_amd import _lib, synth, segment as S
+
+pytestmark = pytest.mark.gpu
+SEED = 20260926
+SITES = synth.HG19_NR_SITES
+
+
+def _device_genome(n_sites, n_samples):
+    import torch
+    dev = torch.device('cuda', 0)
+    pitch = ((2 * n_sites + 255) // 256) * 256 + 256
+    buf = torch.empty((n_samples, pitch), dtype=torch.uint8, device=dev)
+    rc = _lib.load_synth().wgbssynth_fill_betas(C.c_void_p(buf.data_ptr()), pitch, n_sites, 0, n_samples, SEED, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    return buf, pitch
+
+
+def _ref_on_ranges(buf, loci, ranges, pcount, max_cpg, max_bp, procs=None):
+    """The reference binary on 0-based site ranges [(start0, n), ...] of the device-resident betas: every range's
+    bytes are written as per-sample .beta files (what `segmentor` reads, segmentor.cpp:164-177) and one single-threaded
+    process per range runs with the loci on stdin (segment.py:48-55 minus tabix).  -> {(start0, n): int64 borders}"""
+    assert oracle.have_ref(), 'oracle/_ref/segmentor did not travel with the snapshot'
+    procs = procs or (os.cpu_count() or 8)
+    out = {}
+    td = tempfile.mkdtemp(dir='/dev/shm' if op.isdir('/dev/shm') else None)
+    try:
+        for g0 in range(0, len(ranges), procs):
+            jobs = []
+            for st, n in ranges[g0:g0 + procs]:
+                host = buf[:, 2 * st:2 * (st + n)].cpu().numpy()
+                d = op.join(td, 'r%d_%d' % (st, n))
+                os.mkdir(d)
+                paths = []
+                for s in range(host.shape[0]):
+                    p = op.join(d, 's%04d.beta' % s)
+                    host[s].tofile(p)
+                    paths.append(p)
+                cmd = [oracle.REF_BIN] + paths + ['-s', '0', '-n', str(n), '-max_cpg', str(max_cpg), '-ps', repr(float(pcount)),
+                                                 '-max_bp', str(max_bp)]
+                stdin = ('\n'.join(map(str, loci[st:st + n].tolist())) + '\n').encode()
+                jobs.append(((st, n), cmd, stdin, d))
+
+            def run(key, cmd, stdin, d):
+                r = subprocess.run(cmd, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                assert r.returncode == 0, r.stderr.decode()[-500:]
+                out[key] = np.array(r.stdout.split(), dtype=np.int64)
+                shutil.rmtree(d, ignore_errors=True)
+            th = [threading.Thread(target=run, args=j) for j in jobs]
+            [t.start() for t in th]
+            [t.join() for t in th]
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    return out
+
+
+class _Recorder:
+    """chunk engine over the HIP path that remembers every range it was asked for (1-based half-open)."""
+
+    def __init__(self, seg, pcount, max_cpg, max_bp):
+        self.seg, self.p = seg, (pcount, max_cpg, max_bp)
+        self.asked = {}
+
+    def segment_many(self, sites_list, params):
+        st0 = [a - 1 for a, _ in sites_list]
+        ln = [b - a for a, b in sites_list]
+        res = self.seg.segment_chunks(st0, ln, *self.p)
+        outs = []
+        for (a, b), r in zip(sites_list, res):
+            r = r.astype(np.int64) + a
+            self.asked[(a, b)] = r
+            outs.append(r)
+        return outs
+
+
+def _tree(chunks, eng):
+    """segment.py:157-165 over stitch_2_dfs (segment.py:199-232), junction by junction."""
+    lst = list(chunks)
+    while len(lst) > 1:
+        nxt = [S.stitch_2_dfs(lst[i - 1], lst[i], {'engine': eng}) for i in range(1, len(lst), 2)]
+        if len(lst) % 2:
+            nxt.append(lst[-1])
+        lst = nxt
+    return lst[0]
+
+
+def _check_properties(res, regions, loci, max_cpg, max_bp):
+    lo = loci.astype(np.int64)
+    for b, (a, e) in zip(res, regions):
+        b = np.asarray(b, dtype=np.int64)
+        assert b[0] == a and b[-1] == e
+        d = np.diff(b)
+        assert (d > 0).all(), 'borders not strictly ascending'
+        assert d.max() <= max_cpg, 'a block has more than max_cpg sites'
+        bp = lo[b[1:] - 2] - lo[b[:-1] - 1]                 # last site of the block minus its first site
+        assert bp.max() <= max_bp, 'a block spans more than max_bp'
+
+
+def _grid(a, e, chunk):
+    bords = list(range(a, e, chunk)) + [e]
+    return list(zip(bords[:-1], bords[1:]))
+
+
+def _run_whole(seg, regions, chunk, pcount, max_cpg, max_bp):
+    st = np.array([r[0] for r in regions], dtype=np.int64)
+    en = np.array([r[1] for r in regions], dtype=np.int64)
+    res, stats = seg.segment_regions(st, en, chunk, pcount, max_cpg, max_bp)
+    return res, stats
+
+
+def _stitched_vs_tree(seg, res, regions, which, chunk, pcount, max_cpg, max_bp):
+    """stitched result of the regions `which` == the reference's tree over the per-chunk DPs; returns the recorders."""
+    recs = []
+    for ri in which:
+        a, e = regions[ri]
+        eng = _Recorder(seg, pcount, max_cpg, max_bp)
+        chunks = eng.segment_many(_grid(a, e, chunk), {})
+        n_chunks = len(chunks)
+        want = _tree(chunks, eng)
+        assert np.array_equal(np.asarray(res[ri], dtype=np.int64), want), 'stitched borders of region %d differ from the reference tree' % ri
+        recs.append((eng, n_chunks))
+    return recs
+
+
+@pytest.fixture(scope='module')
+def hg19():
+    names, sizes = synth.genome_shape(SITES, 25)
+    sizes = [int(s) for s in sizes]
+    loci = synth.synth_loci(SEED, sizes)
+    regions, pos = [], 1
+    for s in sizes:
+        regions.append((pos, pos + s))
+        pos += s
+    return dict(sizes=sizes, loci=loci, regions=regions)
+
+
+def _spread_chunks(sizes, chunk, count):
+    grid, pos = [], 0
+    for sz in sizes:
+        grid += list(range(pos, pos + sz - chunk + 1, chunk))
+        pos += sz
+    pick = sorted(set(grid[i] for i in np.linspace(0, len(grid) - 1, min(len(grid), count)).astype(int)))
+    return pick
+
+
+def test_hg19_x32_whole_genome(hg19):
+    """BASELINE.json configs[2]."""
+    N, chunk, pc, mc, mb = 32, 60000, 15.0, 1000, 2000
+    buf, pitch = _device_genome(SITES, N)
+    loci, regions, sizes = hg19['loci'], hg19['regions'], hg19['sizes']
+    with _lib.Segmenter(0) as seg:
+        seg.set_betas_device(buf.data_ptr(), N, pitch, SITES, keepalive=buf)
+        seg.set_loci(loci)
+        res, stats = _run_whole(seg, regions, chunk, pc, mc, mb)
+        assert stats['chunks'] == 483
+        _check_properties(res, regions, loci, mc, mb)
+        # (a) 256 full-size chunks spread over the genome against the reference binary
+        pick = _spread_chunks(sizes, chunk, 256)
+        ref = _ref_on_ranges(buf, loci, [(st, chunk) for st in pick], pc, mc, mb)
+        got = seg.segment_chunks(pick, [chunk] * len(pick), pc, mc, mb)
+        for st, g in zip(pick, got):
+            assert np.array_equal(g.astype(np.int64), ref[(st, chunk)]), 'chunk at site %d differs from the reference binary' % st
+        # (b) stitched chromosomes against the reference's pairwise tree: chr1 (41 chunks), chr21, chrX, chrM (one short chunk)
+        which = [0, 20, 22, 24]
+        recs = _stitched_vs_tree(seg, res, regions, which, chunk, pc, mc, mb)
+        # (c) chr21 end to end against the reference binary: every chunk and every patch the tree asked for
+        eng, _ = recs[1]
+        ranges = [(a - 1, b - a) for (a, b) in eng.asked]
+        ref21 = _ref_on_ranges(buf, loci, ranges, pc, mc, mb)
+        for (a, b), r in eng.asked.items():
+            assert np.array_equal(r - a, ref21[(a - 1, b - a)]), 'chr21 range %s differs from the reference binary' % ((a, b),)
+        # and the patches of chr1's 40 junctions
+        eng1, n1 = recs[0]
+        patches = [(a, b) for (a, b) in eng1.asked if b - a < chunk and (a, b) not in _grid(*regions[0], chunk)]
+        assert len(patches) >= n1 - 1
+        refp = _ref_on_ranges(buf, loci, [(a - 1, b - a) for a, b in patches], pc, mc, mb)
+        for a, b in patches:
+            assert np.array_equal(eng1.asked[(a, b)] - a, refp[(a - 1, b - a)])
+    del buf
+
+
+def test_hg19_x200_atlas_scale(hg19):
+    """BASELINE.json configs[3] (one GPU's view: the whole genome fits a single MI355X)."""
+    import torch
+    N, chunk, pc, mc, mb = 200, 60000, 15.0, 1000, 2000
+    torch.cuda.empty_cache()
+    buf, pitch = _device_genome(SITES, N)
+    loci, regions, sizes = hg19['loci'], hg19['regions'], hg19['sizes']
+    with _lib.Segmenter(0) as seg:
+        seg.set_betas_device(buf.data_ptr(), N, pitch, SITES, keepalive=buf)
+        seg.set_loci(loci)
+        res, stats = _run_whole(seg, regions, chunk, pc, mc, mb)
+        assert stats['chunks'] == 483
+        _check_properties(res, regions, loci, mc, mb)
+        pick = _spread_chunks(sizes, chunk, 64)
+        ref = _ref_on_ranges(buf, loci, [(st, chunk) for st in pick], pc, mc, mb)
+        got = seg.segment_chunks(pick, [chunk] * len(pick), pc, mc, mb)
+        for st, g in zip(pick, got):
+            assert np.array_equal(g.astype(np.int64), ref[(st, chunk)]), 'chunk at site %d differs from the reference binary' % st
+        recs = _stitched_vs_tree(seg, res, regions, [1, 21, 24], chunk, pc, mc, mb)
+        # the patches of chr22 against the reference binary
+        eng, _ = recs[1]
+        grid = set(_grid(*regions[21], chunk))
+        patches = [(a, b) for (a, b) in eng.asked if (a, b) not in grid]
+        refp = _ref_on_ranges(buf, loci, [(a - 1, b - a) for a, b in patches], pc, mc, mb)
+        for a, b in patches:
+            assert np.array_equal(eng.asked[(a, b)] - a, refp[(a - 1, b - a)])
+        # sharded == unsharded: the 8-piece split of the chunk grid (one piece per GPU of a node), every piece on its own
+        # context holding only its share of the beta bytes, stitched on the host
+        from wgbs_tools_amd import multi
+        sharded = multi.segment_regions_on_shares(buf.data_ptr(), N, pitch, SITES, loci, regions, chunk, pc, mc, mb,
+                                                  devices=[0] * 8)
+        for r1, r8 in zip(res, sharded):
+            assert np.array_equal(np.asarray(r1), np.asarray(r8)), 'the 8-share run differs from the single-context run'
+    del buf
+    torch.cuda.empty_cache()
+
+
+def test_x512_deep_share():
+    """A piece of BASELINE.json configs[4]: 512 betas, max_cpg 5000, max_bp 1e6, chunk_size 50000 (deep-DP stress)."""
+    import torch
+    N, chunk, pc, max_bp = 512, 50000, 15.0, 1000000
+    mc = min(5000, max_bp // 2)                              # segment.py:65
+    n_sites = 8 * chunk
+    torch.cuda.empty_cache()
+    buf, pitch = _device_genome(n_sites, N)
+    loci = synth.synth_loci(SEED, [n_sites])
+    regions = [(1, n_sites + 1)]
+    with _lib.Segmenter(0) as seg:
+        seg.set_betas_device(buf.data_ptr(), N, pitch, n_sites, keepalive=buf)
+        seg.set_loci(loci)
+        res, stats = _run_whole(seg, regions, chunk, pc, mc, max_bp)
+        assert stats['chunks'] == 8
+        _check_properties(res, regions, loci, mc, max_bp)
+        recs = _stitched_vs_tree(seg, res, regions, [0], chunk, pc, mc, max_bp)
+        eng, _ = recs[0]
+        # one FULL 50,000-site chunk (1.3e11 evaluations) against the many-thread restatement of the reference
+        st = 3 * chunk
+        host = buf[:, 2 * st:2 * (st + chunk)].cpu().numpy()
+        want = oracle.segment_chunk_mt([host[s].reshape(-1, 2) for s in range(N)], loci[st:st + chunk], pc, mc, max_bp)
+        assert np.array_equal(eng.asked[(st + 1, st + chunk + 1)] - (st + 1), want.astype(np.int64)), \
+            'full deep chunk differs from the oracle restatement'
+        # four reduced chunks and the junction patches against the reference binary itself
+        small = [(0, 2000), (123457, 2000), (250001, 1800), (n_sites - 1500, 1500)]
+        grid = set(_grid(1, n_sites + 1, chunk))
+        patches = [(a - 1, b - a) for (a, b) in eng.asked if (a, b) not in grid]
+        ref = _ref_on_ranges(buf, loci, small + patches, pc, mc, max_bp)
+        got = seg.segment_chunks([s for s, _ in small], [n for _, n in small], pc, mc, max_bp)
+        for (s0, n), g in zip(small, got):
+            assert np.array_equal(g.astype(np.int64), ref[(s0, n)]), 'reduced deep chunk at %d differs from the reference binary' % s0
+        for (s0, n) in patches:
+            assert np.array_equal(eng.asked[(s0 + 1, s0 + 1 + n)] - (s0 + 1), ref[(s0, n)])
+    del buf
+    torch.cuda.empty_cache()

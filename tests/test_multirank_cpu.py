@@ -1,6 +1,7 @@
-"""The N>1 path on CPU: two gloo ranks shard the chunk grid, each segments + stitches its own pieces, rank 0 gathers
-and joins across ranks; the result must equal the single-rank run.  The chunk engine here is the oracle (test
-infrastructure) — the sharding, gathering and cross-rank stitching code under test is the product's."""
+"""The N>1 path on CPU: two gloo ranks take the two shares the planner cuts, each runs its own chunk DPs, rank 0 gathers
+the per-chunk border lists and walks the reference's pairwise tree over all of them with the native stitcher; the
+result must equal a plain single-process walk of that tree.  The chunk engines here are test infrastructure (the oracle,
+or an adversarial engine that forces patch doubling) — the planning, gathering and stitching under test is the product's."""
 import os
 import os.path as op
 import subprocess
@@ -16,8 +17,8 @@ WORKER = textwrap.dedent('''
     import numpy as np
     sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
     import torch.distributed as dist
-    from wgbs_tools_amd import synth, parallel, segment as S
-    from test_driver_cpu import OracleEngine
+    from wgbs_tools_amd import synth, parallel, segment as S, _lib
+    from test_driver_cpu import OracleEngine, FickleEngine, _tree_merge
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     dist.init_process_group('gloo')
     sizes = [50017, 30040, 9000, 7]
@@ -25,28 +26,39 @@ WORKER = textwrap.dedent('''
     loci = synth.synth_loci(77, sizes)
     total = sum(sizes)
     betas = [synth.synth_betas(77, s, 0, total) for s in range(3)]
-    eng = OracleEngine(betas, loci)
-    params = dict(pcount=15.0, max_cpg=1000, max_bp=2000, engine=eng)
-
-    def run_pieces(pieces):
-        out = []
-        for ci, s, e in pieces:
-            bords = list(range(s, e, chunk)) + [e]
-            arr = eng.segment_many(list(zip(bords[:-1], bords[1:])), params)
-            sbc = S.SegmentByChunks.__new__(S.SegmentByChunks)
-            sbc.param_dict = params
-            out.append((ci, s, e, sbc.merge_df_list(arr)))
-        return out
-    pieces, nch = parallel.shard_pieces(sizes, chunk, world)
-    assert sum(len(p) for p in pieces) >= len(sizes) and nch == sum(-(-s // chunk) for s in sizes)
-    local = run_pieces(pieces[rank])
-    dist.barrier()
-    gathered = parallel.gather_to_rank0(local, rank, world)
+    regions = parallel.regions_of_sizes(sizes)
+    params = dict(pcount=15.0, max_cpg=1000, max_bp=2000)
+    verdicts = []
+    # engines: the oracle, and fickle engines whose borders depend on where a DP started (patches must double, sometimes
+    # past a whole chunk: the situation in which per-rank trees would differ from the reference's tree)
+    engines = [('oracle', OracleEngine(betas, loci))] + [('fickle%%d' %% k, FickleEngine(k, d, a)) for k, (d, a) in enumerate([(3, 170), (7, 400), (20, 80)])]
+    for name, eng in engines:
+        pr = dict(params, engine=eng)
+        mine = parallel.chunks_of_rank(regions, chunk, world, rank, loci, params)
+        local = list(zip(mine, eng.segment_many(mine, pr)))
+        gathered = parallel.gather_to_rank0(local, rank, world)
+        if rank == 0:
+            assert sorted(k for part in gathered for k, _ in part) == sorted((s, e) for _, s, e in parallel.chunk_grid(regions, chunk))
+            assert all(len(part) > 0 for part in gathered)
+            cache = {tuple(k): np.asarray(v) for part in gathered for k, v in part}
+            asked = []
+            def many(sites):
+                need = [s for s in sites if s not in cache]
+                asked.extend(need)
+                got = dict(zip(need, eng.segment_many(need, pr)))
+                return [cache[s] if s in cache else got[s] for s in sites]
+            merged, _ = _lib.stitch_regions(regions, chunk, many)
+            want = []
+            for a, b in regions:
+                bords = list(range(a, b, chunk)) + [b]
+                want.append(_tree_merge(eng.segment_many(list(zip(bords[:-1], bords[1:])), pr), pr))
+            ok = all(np.array_equal(m, w) for m, w in zip(merged, want))
+            grown = any(b - a > 100 for a, b in asked)
+            verdicts.append((name, ok, grown))
+        dist.barrier()
     if rank == 0:
-        merged = parallel.stitch_across_ranks(gathered, lambda a, b: S.stitch_2_dfs(a, b, params))
-        single = parallel.stitch_across_ranks([run_pieces(parallel.shard_pieces(sizes, chunk, 1)[0][0])], None)
-        ok = all(np.array_equal(merged[c], single[c]) for c in single) and set(merged) == set(single)
-        print('MULTIRANK_OK' if ok else 'MULTIRANK_DIFF', {c: len(v) for c, v in merged.items()}, flush=True)
+        good = all(ok for _, ok, _ in verdicts) and any(g for n, _, g in verdicts if n.startswith('fickle'))
+        print('MULTIRANK_OK' if good else 'MULTIRANK_DIFF', verdicts, flush=True)
     dist.barrier()
     dist.destroy_process_group()
 ''')
@@ -64,23 +76,30 @@ def test_two_gloo_ranks_equal_single_rank(tmp_path):
     assert 'MULTIRANK_OK' in out, out[-3000:]
 
 
-def test_shard_pieces_tile_the_grid():
-    from wgbs_tools_amd import parallel
-    sizes = [249, 1000, 37, 5000, 1]
-    for world in (1, 2, 3, 8):
-        pieces, nch = parallel.shard_pieces(sizes, 100, world)
-        flat = sorted(p for pl in pieces for p in pl)
-        # pieces tile every chromosome, start on the chunk grid, and never cross chromosomes
-        pos = 1
-        for ci, sz in enumerate(sizes):
-            mine = [p for p in flat if p[0] == ci]
-            assert mine[0][1] == pos and mine[-1][2] == pos + sz
-            for a, b in zip(mine, mine[1:]):
-                assert a[2] == b[1]
-            for _, s, e in mine:
-                assert (s - pos) % 100 == 0
-            pos += sz
-        assert nch == sum(-(-s // 100) for s in sizes)
+def test_planned_shares_tile_the_grid_and_balance_work():
+    from wgbs_tools_amd import parallel, synth
+    sizes = [24900, 100000, 3700, 50000, 1]
+    loci = synth.synth_loci(5, sizes, islands=True)
+    regions = parallel.regions_of_sizes(sizes)
+    params = dict(pcount=15.0, max_cpg=1000, max_bp=2000)
+    grid = [(s, e) for _, s, e in parallel.chunk_grid(regions, 1000)]
+    for world in (1, 2, 3, 8, 64):
+        sh = parallel.plan(regions, 1000, world, loci, params)
+        got = []
+        for r in range(world):
+            mine = parallel.chunks_of_rank(regions, 1000, world, r, loci, params, shares=sh)
+            assert len(mine) == sh['chunks'][r]
+            got += mine
+            pieces = parallel.pieces_of_rank(regions, 1000, world, r, loci, params, shares=sh)
+            assert sum(e - s for _, s, e in pieces) == sum(e - s for s, e in mine)
+            for ri, s, e in pieces:                                # pieces start on their region's grid, never cross regions
+                assert (s - regions[ri][0]) % 1000 == 0 and regions[ri][0] <= s < e <= regions[ri][1]
+            if mine:                                               # the resident window covers the share and its halo
+                assert sh['win_lo'][r] <= mine[0][0] - 1 and mine[-1][1] - 1 <= sh['win_hi'][r] and sh['win_lo'][r] % 128 == 0
+        assert got == grid                                         # contiguous, in order, nothing lost
+        assert sh['work'].sum() == parallel.plan(regions, 1000, 1, loci, params)['work'][0]
+        if world <= 8:                                             # 179 chunks over <= 8 shares: within one chunk's work of even
+            assert sh['work'].max() - sh['work'].min() <= 2 * sh['work'].sum() / len(grid) * 3
 
 
 WORKER2 = textwrap.dedent('''
@@ -102,9 +121,10 @@ WORKER2 = textwrap.dedent('''
     parallel.init_host_group().barrier()
     args = argparse.Namespace(sites=None, region=None, array_id=None, bed_file=None, genome=refdir, betas=paths, beta_file=None,
                               chunk_size=7000, pcount=15, min_cpg=1, max_cpg=1000, max_bp=2000,
-                              out_path=os.path.join(d, 'sharded.bed'), threads=1, device=0)
+                              out_path=os.path.join(d, 'sharded.bed'), threads=1, device=0, gpus=1)
     with contextlib.redirect_stderr(io.StringIO()):
-        S.SegmentByChunks(args, paths, engine=None).run_sharded(rank, world, local, engine_factory=lambda sr: OracleEngine(betas, loci))
+        S.SegmentByChunks(args, paths, engine=None).run_sharded(rank, world, local, engine_factory=lambda sr: OracleEngine(betas, loci),
+                                                                patch_engine_factory=lambda: OracleEngine(betas, loci))
         if rank == 0:
             args.out_path = os.path.join(d, 'single.bed')
             os.environ['WORLD_SIZE'] = '1'

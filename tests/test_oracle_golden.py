@@ -45,6 +45,26 @@ def test_live_reference_binary_agrees(name, golden_chunks):
     assert b.tolist() == g['borders']
 
 
+@pytest.mark.parametrize('name', ['tiny', 'max_cpg2', 'pcount0', 'zero_stretch', 'dense_w_gt_64', 'deep', 'n512_deep', 'n200_islands'])
+def test_threaded_restatement_matches_reference_golden(name, golden_chunks):
+    """The many-thread variant the full-size GPU tests use as their checker (rows in parallel slabs, recurrence
+    sequential) is the same function as the single-threaded restatement and the reference binary."""
+    g = golden_chunks[name]
+    spec = g['spec']
+    slices, loci = cases.build_case(spec)
+    for th in (1, 3, 8):
+        b = oracle.segment_chunk_mt(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp'], threads=th)
+        assert b.tolist() == g['borders']
+
+
+def test_threaded_restatement_on_a_default_chunk(golden_chunks):
+    g = golden_chunks['default_chunk']                       # 60,000 sites: 30 slabs, ring wrap-around
+    spec = g['spec']
+    slices, loci = cases.build_case(spec)
+    b = oracle.segment_chunk_mt(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp'], threads=8)
+    assert b.tolist() == g['borders']
+
+
 def test_meth_gt_cov_is_an_error():
     """segmentor.cpp:181-188: a site with #meth > #cov aborts the run."""
     spec = cases.CHUNK_CASES['tiny']

@@ -20,7 +20,10 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_set_betas_host', 'wgbsseg_set_betas_device', 'wgbsseg_set_loci_host', 'wgbsseg_set_loci_device',
            'wgbsseg_segment_chunks', 'wgbsseg_segment_regions', 'wgbsseg_segment_chunks_host', 'wgbsseg_prefix_sums', 'wgbsseg_scan_only',
            'wgbsseg_get_timings', 'wgbsseg_debug_fetch', 'wgbsseg_debug_sample_terms', 'wgbsseg_debug_log2',
-           'wgbsseg_debug_div', 'wgbsseg_add_loci', 'wgbsseg_block_sums', 'wgbsseg_last_block_sums_ms']
+           'wgbsseg_debug_div', 'wgbsseg_add_loci', 'wgbsseg_block_sums', 'wgbsseg_last_block_sums_ms',
+           'wgbsseg_set_site_base', 'wgbsseg_stitch_regions', 'wgbsseg_group_create', 'wgbsseg_group_destroy', 'wgbsseg_group_size',
+           'wgbsseg_group_plan', 'wgbsseg_group_load_host', 'wgbsseg_group_share_set_device', 'wgbsseg_group_segment_regions',
+           'wgbsseg_group_get_timings', 'wgbsseg_plan_shares']
 
 
 class NativeLibraryError(RuntimeError):
@@ -50,6 +53,10 @@ class Timings(C.Structure):
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != 'reserved'}
 
+
+# wgbsseg_batch_fn: (user, starts, ends, n, out_ptr, out_cnt) -> 0 on success
+BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_void_p),
+                       C.POINTER(C.c_int64))
 
 _lib = None
 _synth = None
@@ -134,6 +141,28 @@ def load():
     L.wgbsseg_block_sums.argtypes = [vp, vp, vp, i64, i32, C.c_uint32, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_last_block_sums_ms.restype = C.c_double
     L.wgbsseg_last_block_sums_ms.argtypes = [vp]
+    L.wgbsseg_set_site_base.restype = i32
+    L.wgbsseg_set_site_base.argtypes = [vp, i64]
+    L.wgbsseg_stitch_regions.restype = i32
+    L.wgbsseg_stitch_regions.argtypes = [vp, vp, i64, i64, BATCH_FN, vp, i32, vp, i64, vp, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_plan_shares.restype = i32
+    L.wgbsseg_plan_shares.argtypes = [vp, i64, vp, vp, i64, i64, C.POINTER(Params), i32, i64, vp, vp, vp, vp, vp, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_group_create.restype = i32
+    L.wgbsseg_group_create.argtypes = [vp, i32, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.wgbsseg_group_destroy.restype = None
+    L.wgbsseg_group_destroy.argtypes = [vp]
+    L.wgbsseg_group_size.restype = i32
+    L.wgbsseg_group_size.argtypes = [vp]
+    L.wgbsseg_group_plan.restype = i32
+    L.wgbsseg_group_plan.argtypes = [vp, vp, i64, vp, vp, i64, i64, C.POINTER(Params), i64, vp, vp, vp, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_group_load_host.restype = i32
+    L.wgbsseg_group_load_host.argtypes = [vp, C.POINTER(vp), i64, i64, C.c_char_p, C.c_size_t]
+    L.wgbsseg_group_share_set_device.restype = i32
+    L.wgbsseg_group_share_set_device.argtypes = [vp, i32, vp, i64, i64, C.c_char_p, C.c_size_t]
+    L.wgbsseg_group_segment_regions.restype = i32
+    L.wgbsseg_group_segment_regions.argtypes = [vp, vp, i64, vp, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_group_get_timings.restype = i32
+    L.wgbsseg_group_get_timings.argtypes = [vp, i32, C.POINTER(Timings)]
     L.wgbsseg_add_loci.restype = i32
     L.wgbsseg_add_loci.argtypes = [vp, i64, vp, C.POINTER(C.c_char_p), i32, vp, vp, i64, C.c_char_p, i32, i32, C.c_char_p, C.c_size_t]
     _lib = L
@@ -149,6 +178,8 @@ def load_synth():
         S = C.CDLL(SYNTH_LIB_PATH)
         S.wgbssynth_fill_betas.restype = C.c_int
         S.wgbssynth_fill_betas.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_void_p]
+        S.wgbssynth_fill_betas_range.restype = C.c_int
+        S.wgbssynth_fill_betas_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_int]
         _synth = S
     return _synth
 
@@ -213,6 +244,10 @@ class Segmenter:
         loci = np.ascontiguousarray(loci, dtype=np.uint32)
         _check(self._L.wgbsseg_set_loci_host(self._h, loci.ctypes.data, loci.size, self._err, ERRLEN), self._err)
 
+    def set_site_base(self, base):
+        """absolute 0-based index of resident site 0: error messages then name absolute sites"""
+        self._L.wgbsseg_set_site_base(self._h, int(base))
+
     # ---- hot path -----------------------------------------------------------------------------------------
     def segment_chunks(self, start0, lens, pcount, max_cpg, max_bp):
         """-> list of int32 arrays: borders of each chunk relative to its start (first 0, last len)."""
@@ -250,8 +285,7 @@ class Segmenter:
                                                out.ctypes.data, cap, off.ctypes.data, stats.ctypes.data, self._err, ERRLEN),
                self._err)
         res = [out[off[r]:off[r + 1]].astype(np.int64) if copy else out[off[r]:off[r + 1]] for r in range(n)]
-        return res, dict(chunks=int(stats[0]), patch_dps=int(stats[1]), batches=int(stats[2]), patches_planned=int(stats[3]),
-                         wall_us=int(stats[4]), first_batch_us=int(stats[5]), later_batches_us=int(stats[6]))
+        return res, _stats_dict(stats)
 
     def prefix_sums(self, start0, length):
         out = np.empty((self.n_samples, length + 1, 2), dtype=np.uint32)
@@ -325,6 +359,146 @@ class Segmenter:
         if rc != OK:
             raise SegmentorError(rc, 'debug_log2 failed')
         return (f, d, g) if want_fast else (f, d)
+
+
+def _stats_dict(stats):
+    return dict(chunks=int(stats[0]), patch_dps=int(stats[1]), batches=int(stats[2]), patches_planned=int(stats[3]),
+                wall_us=int(stats[4]), first_batch_us=int(stats[5]), later_batches_us=int(stats[6]))
+
+
+def stitch_regions(regions, chunk_size, engine_many, speculate=True):
+    """wgbsseg_stitch_regions: the native chunk grid + pairwise-tree stitching (segment.py:124-135,157-165,199-252) around a
+    Python chunk engine.  regions: [(startCpG, endCpG)] 1-based half-open; engine_many([(start, end), ...]) -> list of ABSOLUTE
+    border arrays (first start, last end), one per range.  -> (list of int64 border arrays per region, stats dict)."""
+    L = load()
+    rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
+    re_ = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+    n = rs.size
+    cap = int((re_ - rs).sum()) + n
+    out = np.empty(cap, dtype=np.int32)
+    off = np.empty(n + 1, dtype=np.int64)
+    stats = np.zeros(8, dtype=np.int64)
+    keep, failure = [], []
+
+    def cb(user, starts, ends, cnt, out_ptr, out_cnt):
+        try:
+            sites = [(int(starts[i]), int(ends[i])) for i in range(cnt)]
+            res = engine_many(sites)
+            for i, (r, (a, _)) in enumerate(zip(res, sites)):
+                rel = np.ascontiguousarray(np.asarray(r, dtype=np.int64) - a, dtype=np.int32)
+                keep.append(rel)
+                out_ptr[i] = rel.ctypes.data
+                out_cnt[i] = rel.size
+            return 0
+        except BaseException as e:           # never let an exception cross the C frame
+            failure.append(e)
+            return -1
+    err = C.create_string_buffer(ERRLEN)
+    rc = L.wgbsseg_stitch_regions(rs.ctypes.data, re_.ctypes.data, n, int(chunk_size), BATCH_FN(cb), None, 1 if speculate else 0,
+                                  out.ctypes.data, cap, off.ctypes.data, stats.ctypes.data, err, ERRLEN)
+    if failure:
+        raise failure[0]
+    _check(rc, err)
+    return [out[off[r]:off[r + 1]].astype(np.int64) for r in range(n)], _stats_dict(stats)
+
+
+def plan_shares(loci, regions, chunk_size, pcount, max_cpg, max_bp, n_shares, halo=-1):
+    """wgbsseg_plan_shares (host only): contiguous work-balanced runs of chunks.  -> dict of int64 arrays [n_shares]:
+    own_lo/own_hi (0-based sites [lo, hi) of the chunks of each share), win_lo/win_hi (+- halo), chunks, work."""
+    L = load()
+    loci = np.ascontiguousarray(loci, dtype=np.uint32)
+    rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
+    re_ = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+    out = {k: np.zeros(n_shares, dtype=np.int64) for k in ('own_lo', 'own_hi', 'win_lo', 'win_hi', 'chunks', 'work')}
+    err = C.create_string_buffer(ERRLEN)
+    p = Params(float(pcount), int(max_cpg), int(max_bp))
+    _check(L.wgbsseg_plan_shares(loci.ctypes.data, loci.size, rs.ctypes.data, re_.ctypes.data, rs.size, int(chunk_size), C.byref(p),
+                                 int(n_shares), int(halo), out['own_lo'].ctypes.data, out['own_hi'].ctypes.data, out['win_lo'].ctypes.data,
+                                 out['win_hi'].ctypes.data, out['chunks'].ctypes.data, out['work'].ctypes.data, err, ERRLEN), err)
+    return out
+
+
+class SegmenterGroup:
+    """wgbsseg_group: one context per share (GPU), contiguous work-balanced shares of the chunk grid, one host-side tree."""
+
+    def __init__(self, devices):
+        self._L = load()
+        self._h = C.c_void_p()
+        self._err = C.create_string_buffer(ERRLEN)
+        dv = np.ascontiguousarray(devices, dtype=np.int32)
+        _check(self._L.wgbsseg_group_create(dv.ctypes.data, dv.size, C.byref(self._h), self._err, ERRLEN), self._err)
+        self.n_shares = int(dv.size)
+        self.devices = [int(d) for d in dv]
+        self._keep = []
+        self._rbuf = None
+        self._cap = 0
+        self.n_regions = 0
+
+    def close(self):
+        if self._h:
+            self._L.wgbsseg_group_destroy(self._h)
+            self._h = C.c_void_p()
+            self._keep = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def plan(self, loci, regions, chunk_size, pcount, max_cpg, max_bp, halo=-1):
+        """regions: [(startCpG, endCpG)] ABSOLUTE 1-based half-open, ascending; loci: whole-genome uint32.
+        -> dict(win_lo, win_hi, chunks, work): per-share 0-based resident windows and load."""
+        loci = np.ascontiguousarray(loci, dtype=np.uint32)
+        rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
+        re_ = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+        G = self.n_shares
+        lo, hi, ch, wk = (np.zeros(G, dtype=np.int64) for _ in range(4))
+        p = Params(float(pcount), int(max_cpg), int(max_bp))
+        _check(self._L.wgbsseg_group_plan(self._h, loci.ctypes.data, loci.size, rs.ctypes.data, re_.ctypes.data, rs.size, int(chunk_size),
+                                          C.byref(p), int(halo), lo.ctypes.data, hi.ctypes.data, ch.ctypes.data, wk.ctypes.data,
+                                          self._err, ERRLEN), self._err)
+        self.n_regions = int(rs.size)
+        self._cap = int((re_ - rs).sum()) + self.n_regions
+        self.n_sites = int(loci.size)
+        self.windows = dict(win_lo=lo, win_hi=hi, chunks=ch, work=wk)
+        return self.windows
+
+    def load_host(self, samples):
+        """samples: whole-genome uint8 arrays (np.memmap of .beta files work); every share uploads only its window."""
+        arrs = [s if isinstance(s, np.ndarray) and s.dtype == np.uint8 and s.ndim == 1 else np.ascontiguousarray(s, dtype=np.uint8).reshape(-1)
+                for s in samples]
+        assert all(a.size == 2 * self.n_sites for a in arrs), 'every sample must hold 2 bytes per site of the planned genome'
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        _check(self._L.wgbsseg_group_load_host(self._h, ptrs, len(arrs), self.n_sites, self._err, ERRLEN), self._err)
+
+    def share_set_device(self, share, data_ptr, n_samples, pitch_bytes, keepalive=None):
+        _check(self._L.wgbsseg_group_share_set_device(self._h, int(share), C.c_void_p(int(data_ptr)), int(n_samples), int(pitch_bytes),
+                                                      self._err, ERRLEN), self._err)
+        self._keep.append(keepalive)
+
+    def segment_regions(self, copy=True):
+        if self._rbuf is None or self._rbuf.size < self._cap:
+            self._rbuf = np.empty(self._cap, dtype=np.int32)
+        out = self._rbuf
+        n = self.n_regions
+        off = np.empty(n + 1, dtype=np.int64)
+        stats = np.zeros(8, dtype=np.int64)
+        _check(self._L.wgbsseg_group_segment_regions(self._h, out.ctypes.data, out.size, off.ctypes.data, stats.ctypes.data,
+                                                     self._err, ERRLEN), self._err)
+        res = [out[off[r]:off[r + 1]].astype(np.int64) if copy else out[off[r]:off[r + 1]] for r in range(n)]
+        return res, _stats_dict(stats)
+
+    def timings(self, share):
+        t = Timings()
+        self._L.wgbsseg_group_get_timings(self._h, int(share), C.byref(t))
+        return t.as_dict()
 
 
 def segment_chunks_host(samples, loci, start0, lens, pcount, max_cpg, max_bp, device=0):

@@ -205,11 +205,18 @@ inline void junctions_of_region(const std::vector<int64_t>& lens, int64_t first_
 }
 
 typedef std::pair<int64_t, int64_t> Sites;                     // 1-based [start, end)
-// Result of one batch of chunk DPs: CSR of int32 borders RELATIVE to each item's start (first 0, last end-start).
+// Result of one batch of chunk DPs: per item, int32 borders RELATIVE to the item's start (first 0, last end-start).
+// The items of a batch may live in several buffers (one per GPU share); all must stay valid until segment_regions returns.
 struct BatchResult {
-    int32_t* flat = nullptr;                 // must stay valid until segment_regions returns
-    std::unique_ptr<int32_t[]> owned;        // optional owner of `flat`
-    std::vector<int64_t> off;
+    std::vector<const int32_t*> ptr;         // [items]
+    std::vector<int64_t> cnt;                // [items]
+    std::vector<std::unique_ptr<int32_t[]>> owned;   // optional owners of what `ptr` points into
+    // CSR form: item i = flat[off[i] .. off[i+1])
+    void set_csr(const int32_t* flat, const int64_t* off, size_t n)
+    {
+        ptr.resize(n); cnt.resize(n);
+        for (size_t i = 0; i < n; i++) { ptr[i] = flat + off[i]; cnt[i] = off[i + 1] - off[i]; }
+    }
 };
 typedef std::function<int(const std::vector<Sites>&, BatchResult&, std::string&)> BatchFn;
 enum { E_ARG = -1, E_CAPACITY = -6 };
@@ -263,7 +270,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     const int64_t us_first = us_batches;
     if (rc != 0) return rc;
     n_batches++;
-    for (size_t i = (size_t)n_chunks; i < items.size(); i++) { cache[items[i]] = Patch{first.flat + first.off[i], first.off[i + 1] - first.off[i]}; n_patch_dp++; }
+    for (size_t i = (size_t)n_chunks; i < items.size(); i++) { cache[items[i]] = Patch{first.ptr[i], first.cnt[i]}; n_patch_dp++; }
 
     // ---- rehearsal ---------------------------------------------------------------------------------------------------
     // The tree below meets its junctions level by level, and a junction whose cached attempts all fail costs a
@@ -282,8 +289,8 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                 const int64_t llen = items[li].second - items[li].first, rlen = items[ri].second - items[ri].first;
                 Stitch t;
                 Rope a, b;
-                a.runs.push_back(Run{first.flat + first.off[li], first.off[li + 1] - first.off[li], items[li].first});
-                b.runs.push_back(Run{first.flat + first.off[ri], first.off[ri + 1] - first.off[ri], items[ri].first});
+                a.runs.push_back(Run{first.ptr[li], first.cnt[li], items[li].first});
+                b.runs.push_back(Run{first.ptr[ri], first.cnt[ri], items[ri].first});
                 std::string e2;
                 if (!t.init(std::move(a), std::move(b), e2)) continue;
                 t.n1 = jn.n1; t.n2 = jn.n2;
@@ -312,7 +319,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
             rc = timed_batch(need, res);
             if (rc != 0) return rc;
             n_batches++;
-            for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = Patch{res.flat + res.off[i], res.off[i + 1] - res.off[i]}; n_patch_dp++; }
+            for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = Patch{res.ptr[i], res.cnt[i]}; n_patch_dp++; }
             pend.swap(still);
         }
     }
@@ -322,7 +329,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     for (int64_t r = 0; r < n_regions; r++)
         for (int64_t q = region_first_chunk[(size_t)r]; q < region_first_chunk[(size_t)r + 1]; q++) {
             Rope rp;
-            rp.runs.push_back(Run{first.flat + first.off[(size_t)q], first.off[(size_t)q + 1] - first.off[(size_t)q], items[(size_t)q].first});
+            rp.runs.push_back(Run{first.ptr[(size_t)q], first.cnt[(size_t)q], items[(size_t)q].first});
             lists[(size_t)r].push_back(std::move(rp));
         }
     for (;;) {
@@ -368,7 +375,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                 rc = timed_batch(need, res);
                 if (rc != 0) return rc;
                 n_batches++;
-                for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = Patch{res.flat + res.off[i], res.off[i + 1] - res.off[i]}; n_patch_dp++; }
+                for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = Patch{res.ptr[i], res.cnt[i]}; n_patch_dp++; }
             }
             for (auto& s : st) {
                 if (s.done) continue;

@@ -28,10 +28,11 @@ __device__ inline int level_map(int u)
     return 16 + ((u - 208) * 184) / 48;
 }
 
-__global__ void k_block_starts(uint64_t key_block, int64_t n, int32_t* bs)
+__global__ void k_block_starts(uint64_t key_block, int64_t lo, int64_t n, int32_t* bs)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t i = lo + t;                                  // absolute site
     int64_t j = i;
     for (;;) {
         if ((j % FORCE_BLOCK) == 0) break;
@@ -39,15 +40,16 @@ __global__ void k_block_starts(uint64_t key_block, int64_t n, int32_t* bs)
         if ((((h >> 32) * BLOCK_ODDS) >> 32) == 0) break;
         j--;
     }
-    bs[i] = (int32_t)j;
+    bs[t] = (int32_t)j;
 }
 
-__global__ void k_fill_sample(uint64_t key_level, uint64_t key_jit, uint64_t key_cov, uint64_t key_bern, int64_t n,
+__global__ void k_fill_sample(uint64_t key_level, uint64_t key_jit, uint64_t key_cov, uint64_t key_bern, int64_t lo, int64_t n,
                               const int32_t* __restrict__ bs, uint8_t* __restrict__ row)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t b = (uint64_t)bs[i];
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t i = lo + t;                                  // absolute site; row[] starts at site lo
+    const uint64_t b = (uint64_t)bs[t];
     const int base = level_map((int)(hash_at(key_level, b) & 0xFF));
     const uint64_t hs = hash_at(key_jit, b);
     int level;
@@ -69,33 +71,43 @@ __global__ void k_fill_sample(uint64_t key_level, uint64_t key_jit, uint64_t key
             meth += (trial < level && t < cov) ? 1 : 0;
         }
     }
-    reinterpret_cast<uint16_t*>(row)[i] = (uint16_t)(meth | (cov << 8));
+    reinterpret_cast<uint16_t*>(row)[t] = (uint16_t)(meth | (cov << 8));
 }
 
 extern "C" {
 
-// Fill rows [sample_first, sample_first+n_samples) of a device buffer [*][pitch] with synthetic samples
-// number sample_first.. of seed `seed`, sites 0..n_sites-1.  `scratch` = device int32[n_sites] or NULL
-// (then allocated and freed here).  Returns 0 or a hipError_t.
-int wgbssynth_fill_betas(void* d_base, int64_t pitch, int64_t n_sites, int sample_first, int n_samples,
-                         uint64_t seed, void* scratch)
+// Fill rows [sample_first, sample_first+n_samples) of a device buffer [*][pitch] on HIP device `device` (-1: the current
+// one) with sites [site_lo, site_hi) of synthetic samples number sample_first.. of seed `seed`: row byte 0 = site_lo.
+// Returns 0 or a hipError_t.
+int wgbssynth_fill_betas_range(void* d_base, int64_t pitch, int64_t site_lo, int64_t site_hi, int sample_first, int n_samples,
+                               uint64_t seed, int device)
 {
-    int32_t* bs = reinterpret_cast<int32_t*>(scratch);
-    bool own = false;
     hipError_t e;
-    if (!bs) { e = hipMalloc(&bs, (size_t)n_sites * 4); if (e != hipSuccess) return (int)e; own = true; }
-    const unsigned blocks = (unsigned)((n_sites + 255) / 256);
-    hipLaunchKernelGGL(k_block_starts, dim3(blocks), dim3(256), 0, 0, stream_key(seed, S_BLOCK), n_sites, bs);
+    if (device >= 0) { e = hipSetDevice(device); if (e != hipSuccess) return (int)e; }
+    const int64_t n = site_hi - site_lo;
+    if (n <= 0) return 0;
+    int32_t* bs = nullptr;
+    e = hipMalloc(&bs, (size_t)n * 4);
+    if (e != hipSuccess) return (int)e;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_block_starts, dim3(blocks), dim3(256), 0, 0, stream_key(seed, S_BLOCK), site_lo, n, bs);
     for (int s = 0; s < n_samples; s++) {
         const uint64_t st = S_SAMPLE0 + 4ull * (uint64_t)(sample_first + s);
         uint8_t* row = reinterpret_cast<uint8_t*>(d_base) + (int64_t)(sample_first + s) * pitch;
         hipLaunchKernelGGL(k_fill_sample, dim3(blocks), dim3(256), 0, 0, stream_key(seed, S_LEVEL), stream_key(seed, st + 0),
-                           stream_key(seed, st + 1), stream_key(seed, st + 2), n_sites, bs, row);
+                           stream_key(seed, st + 1), stream_key(seed, st + 2), site_lo, n, bs, row);
     }
     e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipGetLastError();
-    if (own) (void)hipFree(bs);
+    (void)hipFree(bs);
     return (int)e;
+}
+
+// Sites 0..n_sites-1 on the current device (`scratch` is ignored; kept for the callers of the first version).
+int wgbssynth_fill_betas(void* d_base, int64_t pitch, int64_t n_sites, int sample_first, int n_samples, uint64_t seed, void* scratch)
+{
+    (void)scratch;
+    return wgbssynth_fill_betas_range(d_base, pitch, 0, n_sites, sample_first, n_samples, seed, -1);
 }
 
 }  // extern "C"

@@ -70,6 +70,7 @@ void set_err(char* err, size_t errlen, const char* fmt, ...)
         }                                                                                          \
     } while (0)
 
+hipError_t set_kernel_attributes();      // defined below, next to the kernel launchers
 inline int ceil_pow2(int v) { int r = 1; while (r < v) r <<= 1; return r; }
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
@@ -107,6 +108,7 @@ struct wgbsseg_ctx {
     DevBuf betas_own, loci_own;
     const uint8_t* betas = nullptr;
     int64_t pitch = 0, n_total = 0;
+    int64_t site_base = 0;   // absolute 0-based index of resident site 0 (messages only; all call coordinates are resident-relative)
     int32_t n_samples = 0;
     const uint32_t* loci = nullptr;
     int64_t n_loci = 0;
@@ -226,6 +228,7 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
         set_err(err, errlen, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
         return WGBSSEG_E_HIP;
     }
+    HIP_TRY(set_kernel_attributes());        // per device, checked: k_dp / k_cost ask for more than 64 KB of dynamic LDS
     wgbsseg_ctx* c = new (std::nothrow) wgbsseg_ctx();
     if (!c) { set_err(err, errlen, "out of host memory"); return WGBSSEG_E_NOMEM; }
     c->device = device;
@@ -411,7 +414,7 @@ int report_bad_site(const wgbsseg_ctx* c, const JobStatus& st, char* err, size_t
     uint8_t mc[2] = {0, 0};
     (void)hipMemcpy(mc, c->betas + s * c->pitch + 2 * site, 2, hipMemcpyDeviceToHost);
     set_err(err, errlen, "invalid data: sample %lld (0-based, argument order), site %lld (0-based): meth %d > cov %d",
-            s, site, (int)mc[0], (int)mc[1]);
+            s, site + (long long)c->site_base, (int)mc[0], (int)mc[1]);
     return WGBSSEG_E_METH_GT_COV;
 }
 
@@ -419,11 +422,6 @@ template <int TI, int FAST, int SPLIT>
 hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
     const int64_t padded = round_up(tiles, 8);
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cost<TI, FAST, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
     hipLaunchKernelGGL((k_cost<TI, FAST, SPLIT>), dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, td, tiles, cost, padded);
     return hipGetLastError();
 }
@@ -436,6 +434,32 @@ hipError_t launch_cost_ti(int TI, bool wide, const JobView& v, const StageView& 
     if (TI == 64) return launch_cost<64, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
     if (TI == 32) return launch_cost<32, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
     return launch_cost<16, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
+}
+
+// Kernels that ask for more than 64 KB of dynamic LDS need the attribute on EVERY device they run on: set once per
+// context, right after hipSetDevice (wgbsseg_create), and checked.
+template <int FAST>
+hipError_t set_cost_attrs()
+{
+    const void* fns[] = {reinterpret_cast<const void*>(&k_cost<64, FAST, 0>), reinterpret_cast<const void*>(&k_cost<32, FAST, 0>),
+                         reinterpret_cast<const void*>(&k_cost<16, FAST, 0>), reinterpret_cast<const void*>(&k_cost<WG_WIDE_TS, FAST, 1>)};
+    for (const void* f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+hipError_t set_kernel_attributes()
+{
+    hipError_t e = set_cost_attrs<0>();
+    if (e == hipSuccess) e = set_cost_attrs<1>();
+    if (e == hipSuccess) e = set_cost_attrs<2>();
+    const void* dps[] = {reinterpret_cast<const void*>(&k_dp<3, 64>), reinterpret_cast<const void*>(&k_dp<7, 64>),
+                         reinterpret_cast<const void*>(&k_dp<7, 32>), reinterpret_cast<const void*>(&k_dp<3, 32>),
+                         reinterpret_cast<const void*>(&k_dp<15, 32>)};
+    for (const void* f : dps)
+        if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
 }
 
 void grow_events(std::vector<hipEvent_t>& v, size_t n)
@@ -458,8 +482,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     if (!P || !borders_off) { set_err(err, errlen, "NULL params/borders pointer"); return WGBSSEG_E_ARG; }
     if (P->max_bp == 0) { set_err(err, errlen, "max_bp must be >= 1 (the reference reads uninitialised loci when it is 0: segmentor.cpp:38,114)"); return WGBSSEG_E_ARG; }
     if (P->max_cpg < 1) { set_err(err, errlen, "max_cpg must be >= 1"); return WGBSSEG_E_ARG; }
-    if (255ull * P->max_cpg >= (1ull << 24) || P->max_cpg > 8000) {
-        set_err(err, errlen, "max_cpg %u unsupported: block sums must stay exact in float (255*max_cpg < 2^24) and the DP's pending ring must fit LDS (max_cpg <= 8000)", P->max_cpg);
+    if (P->max_cpg > WGBSSEG_MAX_CPG) {
+        set_err(err, errlen, "max_cpg %u unsupported: at most %d (a block's counts must stay below 2^21 for the exactness proofs of the likelihood term)", P->max_cpg, WGBSSEG_MAX_CPG);
         return WGBSSEG_E_ARG;
     }
     if (!(P->pseudo_count >= 0.0f)) { set_err(err, errlen, "pseudo_count must be >= 0"); return WGBSSEG_E_ARG; }
@@ -664,15 +688,6 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(c->out_borders.ensure((size_t)(J + nC) * 4));
     grow_events(c->ev_cost0, n_stages); grow_events(c->ev_cost1, n_stages);
     grow_events(c->ev_dp0, n_stages); grow_events(c->ev_dp1, n_stages);
-    static bool dp_attr = false;
-    if (!dp_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<7, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<7, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<3, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dp<15, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        dp_attr = true;
-    }
     StageView sv;
     sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbaseA = tbaseA; sv.tbaseB = tbaseB;
     sv.S = S;
@@ -782,51 +797,388 @@ int wgbsseg_segment_chunks_host(const uint8_t* betas, int64_t n_samples, int64_t
     return rc;
 }
 
+}  // extern "C"
+
+namespace {
+// One GPU batch on one context: 0-based resident-relative site ranges -> CSR of relative borders in page-locked memory
+// that stays alive in the context (buffer `slot` of c->pinned) while ropes point into it.
+int run_ctx_batch(wgbsseg_ctx* c, const std::vector<int64_t>& st0, const std::vector<int32_t>& ln, const wgbsseg_params* P, int64_t slot,
+                  bool accumulate, const int32_t*& flat, std::vector<int64_t>& off, std::unique_ptr<int32_t[]>& owned, std::string& msg)
+{
+    off.resize(st0.size() + 1);
+    int32_t* dst = nullptr;
+    BorderAlloc alloc = [&](int64_t total) -> int32_t* {
+        if (c->pinned.size() <= (size_t)slot) c->pinned.resize((size_t)slot + 1);
+        PinnedBuf& pb = c->pinned[(size_t)slot];
+        dst = pb.ensure((size_t)std::max<int64_t>(total, 1) * 4) ? reinterpret_cast<int32_t*>(pb.p) : nullptr;
+        if (!dst) { owned.reset(new int32_t[(size_t)std::max<int64_t>(total, 1)]); dst = owned.get(); }   // pageable fallback
+        return dst;
+    };
+    char ebuf[512] = {0};
+    const bool acc_before = c->accumulate;
+    c->accumulate = accumulate;
+    const int rc = segment_chunks_impl(c, st0.data(), ln.data(), (int64_t)st0.size(), P, alloc, off.data(), ebuf, sizeof(ebuf));
+    c->accumulate = acc_before;
+    if (rc != WGBSSEG_OK) { msg = ebuf; return rc; }
+    flat = dst;
+    return WGBSSEG_OK;
+}
+
+int map_stitch_rc(int rc, const std::string& msg, char* err, size_t errlen)
+{
+    if (rc == 0) return WGBSSEG_OK;
+    set_err(err, errlen, "%s", msg.c_str());
+    return rc == wgstitch::E_CAPACITY ? WGBSSEG_E_CAPACITY : (rc < -1 ? rc : WGBSSEG_E_ARG);
+}
+bool speculation_on()
+{
+    static const bool on = !(getenv("WGBSSEG_NO_SPECULATION") && atoi(getenv("WGBSSEG_NO_SPECULATION")));
+    return on;
+}
+}  // namespace
+
+extern "C" {
+
 int wgbsseg_segment_regions(wgbsseg_ctx* c, const int64_t* region_start, const int64_t* region_end, int64_t n_regions,
                             int64_t chunk_size, const wgbsseg_params* P, int32_t* borders_out, int64_t borders_cap,
                             int64_t* borders_off, int64_t* stats, char* err, size_t errlen)
 {
     if (!c || !P) { set_err(err, errlen, "bad arguments to segment_regions"); return WGBSSEG_E_ARG; }
-    const bool acc_before = c->accumulate;
     int64_t n_batches = 0;
-    // one GPU batch of 1-based site ranges -> absolute int64 border lists
     wgstitch::BatchFn run_batch = [&](const std::vector<wgstitch::Sites>& todo, wgstitch::BatchResult& res, std::string& msg) -> int {
-        std::vector<int64_t> st0(todo.size());
+        std::vector<int64_t> st0(todo.size()), off;
         std::vector<int32_t> ln(todo.size());
         for (size_t i = 0; i < todo.size(); i++) {
             st0[i] = todo[i].first - 1;
             if (todo[i].second - todo[i].first > 0x7fffffff) { msg = "chunk too long"; return WGBSSEG_E_ARG; }
             ln[i] = (int32_t)(todo[i].second - todo[i].first);
         }
-        res.off.resize(todo.size() + 1);
-        // pinned, grow-only, one buffer per batch of the call (they must all stay alive while the ropes point into them)
-        BorderAlloc alloc = [&](int64_t total) -> int32_t* {
-            if (c->pinned.size() <= (size_t)n_batches) c->pinned.resize((size_t)n_batches + 1);
-            PinnedBuf& pb = c->pinned[(size_t)n_batches];
-            res.flat = pb.ensure((size_t)std::max<int64_t>(total, 1) * 4) ? reinterpret_cast<int32_t*>(pb.p) : nullptr;
-            if (!res.flat) { res.owned.reset(new int32_t[(size_t)std::max<int64_t>(total, 1)]); res.flat = res.owned.get(); }   // pageable fallback
-            return res.flat;
-        };
-        char ebuf[512] = {0};
-        c->accumulate = n_batches > 0;
-        const int rc = segment_chunks_impl(c, st0.data(), ln.data(), (int64_t)todo.size(), P, alloc, res.off.data(), ebuf, sizeof(ebuf));
-        c->accumulate = acc_before;
-        if (rc != WGBSSEG_OK) { msg = ebuf; return rc; }
+        const int32_t* flat = nullptr;
+        std::unique_ptr<int32_t[]> owned;
+        const int rc = run_ctx_batch(c, st0, ln, P, n_batches, n_batches > 0, flat, off, owned, msg);
+        if (rc != WGBSSEG_OK) return rc;
+        if (owned) res.owned.push_back(std::move(owned));
+        res.set_csr(flat, off.data(), todo.size());
         n_batches++;
         return WGBSSEG_OK;
     };
     std::string msg;
-    static const bool speculate = !(getenv("WGBSSEG_NO_SPECULATION") && atoi(getenv("WGBSSEG_NO_SPECULATION")));
     const int rc = wgstitch::segment_regions(region_start, region_end, n_regions, chunk_size, run_batch, borders_out, borders_cap,
-                                             borders_off, stats, msg, speculate);
+                                             borders_off, stats, msg, speculation_on());
     if (profiling()) {
         fprintf(stderr, "[wgbsseg] segment_regions: %lld batches; allocations since the last report: %lld calls, %.1f MB, %.1f ms; "
                 "device ms: scan %.2f window %.2f cost %.2f dp %.2f trace %.2f, time line %.2f\n",
                 (long long)n_batches, g_alloc_calls.exchange(0), (double)g_alloc_bytes.exchange(0) * 1e-6, (double)g_alloc_us.exchange(0) * 1e-3,
                 c->tim.scan_ms, c->tim.window_ms, c->tim.cost_ms, c->tim.dp_ms, c->tim.trace_ms, c->tim.total_ms);
     }
-    if (rc != 0) { set_err(err, errlen, "%s", msg.c_str()); return rc == wgstitch::E_CAPACITY ? WGBSSEG_E_CAPACITY : (rc < -1 ? rc : WGBSSEG_E_ARG); }
+    return map_stitch_rc(rc, msg, err, errlen);
+}
+
+int wgbsseg_set_site_base(wgbsseg_ctx* c, int64_t site_base)
+{
+    if (!c || site_base < 0) return WGBSSEG_E_ARG;
+    c->site_base = site_base;
     return WGBSSEG_OK;
+}
+
+// The native chunk grid + stitching around a caller-supplied chunk engine (see include/wgbsseg.h).
+int wgbsseg_stitch_regions(const int64_t* region_start, const int64_t* region_end, int64_t n_regions, int64_t chunk_size,
+                           wgbsseg_batch_fn fn, void* user, int32_t speculate, int32_t* borders_out, int64_t borders_cap,
+                           int64_t* borders_off, int64_t* stats, char* err, size_t errlen)
+{
+    if (!fn) { set_err(err, errlen, "stitch_regions: no chunk engine"); return WGBSSEG_E_ARG; }
+    wgstitch::BatchFn run_batch = [&](const std::vector<wgstitch::Sites>& todo, wgstitch::BatchResult& res, std::string& msg) -> int {
+        std::vector<int64_t> s(todo.size()), e(todo.size());
+        for (size_t i = 0; i < todo.size(); i++) { s[i] = todo[i].first; e[i] = todo[i].second; }
+        res.ptr.assign(todo.size(), nullptr);
+        res.cnt.assign(todo.size(), 0);
+        const int rc = fn(user, s.data(), e.data(), (int64_t)todo.size(), res.ptr.data(), res.cnt.data());
+        if (rc != 0) { msg = "the chunk engine failed (code " + std::to_string(rc) + ")"; return rc < -1 ? rc : WGBSSEG_E_ARG; }
+        for (size_t i = 0; i < todo.size(); i++)
+            if (!res.ptr[i] || res.cnt[i] < 2 || res.ptr[i][0] != 0 || (int64_t)res.ptr[i][res.cnt[i] - 1] != e[i] - s[i]) {
+                msg = "the chunk engine returned a malformed border list for sites [" + std::to_string(s[i]) + ", " + std::to_string(e[i]) + ")";
+                return WGBSSEG_E_ARG;
+            }
+        return 0;
+    };
+    std::string msg;
+    const int rc = wgstitch::segment_regions(region_start, region_end, n_regions, chunk_size, run_batch, borders_out, borders_cap,
+                                             borders_off, stats, msg, speculate != 0);
+    return map_stitch_rc(rc, msg, err, errlen);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------
+// Share groups: one process, several GPUs (or several contexts on one GPU).  The chunk grid of a region list is cut
+// into contiguous runs of chunks, one per share, balanced by the work the chunks hold (number of scored blocks,
+// from the loci); a share keeps only its own window of the beta bytes.  Every batch of the stitching loop is routed
+// item by item to the share that holds it and runs on one host thread per share; the reference's pairwise tree
+// then runs ONCE, on the host, over all shares' results — the answer does not depend on the number of shares.
+// ------------------------------------------------------------------------------------------------------------
+struct wgbsseg_group {
+    std::vector<wgbsseg_ctx*> shares;
+    std::vector<int64_t> own_lo, own_hi;     // 0-based sites [lo, hi) of the chunks a share owns (hi == lo: none)
+    std::vector<int64_t> win_lo, win_hi;     // resident window of the share: owned sites +- halo, inside [0, n_sites)
+    std::vector<int64_t> rs, re;             // the planned regions (1-based half-open)
+    std::vector<int64_t> share_chunks, share_work;
+    int64_t chunk_size = 0, n_sites = 0, halo = 0;
+    wgbsseg_params P = {};
+    bool planned = false;
+    std::vector<char> loaded;
+};
+
+namespace {
+
+// number of scored blocks of a chunk: sum over its sites k of F_k (segmentor.cpp:111-117), by two pointers
+int64_t chunk_work(const uint32_t* loci, int64_t lo, int64_t hi, uint32_t max_cpg, uint32_t max_bp)
+{
+    int64_t w = 0, e = lo;
+    for (int64_t k = lo; k < hi; k++) {
+        if (e < k + 1) e = k + 1;
+        while (e < hi && e - k < (int64_t)max_cpg && loci[e] >= loci[k] && (uint64_t)loci[e] - loci[k] <= max_bp) e++;
+        w += e - k;
+    }
+    return w;
+}
+
+template <class F>
+void parallel_for(int64_t n, int max_threads, F f)
+{
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(max_threads, (int64_t)std::thread::hardware_concurrency()), n));
+    if (T <= 1) { for (int64_t i = 0; i < n; i++) f(i); return; }
+    std::atomic<int64_t> next(0);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back([&]() { for (int64_t i; (i = next.fetch_add(1)) < n;) f(i); });
+    for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+int wgbsseg_group_create(const int32_t* devices, int32_t n_shares, wgbsseg_group** out, char* err, size_t errlen)
+{
+    if (!out) { set_err(err, errlen, "out is NULL"); return WGBSSEG_E_ARG; }
+    *out = nullptr;
+    if (!devices || n_shares < 1 || n_shares > 1024) { set_err(err, errlen, "group_create: need 1..1024 shares"); return WGBSSEG_E_ARG; }
+    std::unique_ptr<wgbsseg_group> g(new (std::nothrow) wgbsseg_group());
+    if (!g) { set_err(err, errlen, "out of host memory"); return WGBSSEG_E_NOMEM; }
+    for (int32_t d = 0; d < n_shares; d++) {
+        wgbsseg_ctx* c = nullptr;
+        const int rc = wgbsseg_create(devices[d], &c, err, errlen);
+        if (rc != WGBSSEG_OK) { for (auto* x : g->shares) wgbsseg_destroy(x); return rc; }
+        g->shares.push_back(c);
+    }
+    g->loaded.assign((size_t)n_shares, 0);
+    *out = g.release();
+    return WGBSSEG_OK;
+}
+
+void wgbsseg_group_destroy(wgbsseg_group* g)
+{
+    if (!g) return;
+    // releasing gigabytes of device buffers takes milliseconds per context: do the shares side by side
+    parallel_for((int64_t)g->shares.size(), 64, [&](int64_t d) { wgbsseg_destroy(g->shares[(size_t)d]); });
+    delete g;
+}
+
+int32_t wgbsseg_group_size(const wgbsseg_group* g) { return g ? (int32_t)g->shares.size() : 0; }
+
+int wgbsseg_plan_shares(const uint32_t* loci, int64_t n_sites, const int64_t* region_start, const int64_t* region_end, int64_t n_regions,
+                        int64_t chunk_size, const wgbsseg_params* P, int32_t n_shares, int64_t halo, int64_t* own_lo, int64_t* own_hi,
+                        int64_t* win_lo, int64_t* win_hi, int64_t* share_chunks, int64_t* share_work, char* err, size_t errlen)
+{
+    if (!loci || n_sites < 1 || !region_start || !region_end || n_regions < 1 || chunk_size < 1 || !P || n_shares < 1 || !own_lo || !own_hi) {
+        set_err(err, errlen, "bad arguments to plan_shares"); return WGBSSEG_E_ARG;
+    }
+    if (P->max_bp == 0 || P->max_cpg < 1) { set_err(err, errlen, "max_bp and max_cpg must be >= 1"); return WGBSSEG_E_ARG; }
+    const int G = n_shares;
+    struct Ck { int64_t lo, hi, w; };
+    std::vector<Ck> cks;
+    for (int64_t r = 0; r < n_regions; r++) {
+        const int64_t a = region_start[r], b = region_end[r];
+        if (a < 1 || b <= a || b - 1 > n_sites) { set_err(err, errlen, "region %lld = [%lld, %lld) is empty or outside the %lld sites", (long long)r, (long long)a, (long long)b, (long long)n_sites); return WGBSSEG_E_ARG; }
+        if (r && a < region_end[r - 1]) { set_err(err, errlen, "plan_shares: regions must be ascending and disjoint"); return WGBSSEG_E_ARG; }
+        for (int64_t s0 = a; s0 < b; s0 += chunk_size) cks.push_back({s0 - 1, std::min(s0 + chunk_size, b) - 1, 0});
+    }
+    parallel_for((int64_t)cks.size(), 32, [&](int64_t i) {
+        Ck& c = cks[(size_t)i];
+        c.w = chunk_work(loci, c.lo, c.hi, P->max_cpg, P->max_bp) + 4 * (c.hi - c.lo);     // + the per-site passes (scan, windows, recurrence)
+    });
+    int64_t total = 0;
+    for (auto& c : cks) total += c.w;
+    if (halo < 0) halo = std::max<int64_t>(chunk_size, 4096);
+    std::vector<int64_t> nch((size_t)G, 0), wk((size_t)G, 0);
+    std::vector<char> any((size_t)G, 0);
+    {   // contiguous runs of chunks: share d ends where the cumulative work passes (d+1)/G of the total
+        int d = 0;
+        int64_t acc = 0;
+        for (auto& c : cks) {
+            while (d < G - 1 && (double)acc >= (double)total * (d + 1) / G) d++;
+            if (!any[(size_t)d]) { own_lo[d] = c.lo; any[(size_t)d] = 1; }
+            own_hi[d] = c.hi;
+            nch[(size_t)d]++; wk[(size_t)d] += c.w;
+            acc += c.w;
+        }
+    }
+    for (int q = 0; q < G; q++) {
+        if (!any[(size_t)q]) own_lo[q] = own_hi[q] = q ? own_hi[q - 1] : cks.front().lo;
+        // window: owned sites +- halo, the lower edge on a multiple of 128 sites (views into one device buffer stay 256-byte aligned)
+        const bool has = own_hi[q] > own_lo[q];
+        if (win_lo) win_lo[q] = has ? (std::max<int64_t>(0, own_lo[q] - halo) & ~127LL) : 0;
+        if (win_hi) win_hi[q] = has ? std::min<int64_t>(n_sites, own_hi[q] + halo) : 0;
+        if (share_chunks) share_chunks[q] = nch[(size_t)q];
+        if (share_work) share_work[q] = wk[(size_t)q];
+    }
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_group_plan(wgbsseg_group* g, const uint32_t* loci, int64_t n_sites, const int64_t* region_start, const int64_t* region_end,
+                       int64_t n_regions, int64_t chunk_size, const wgbsseg_params* P, int64_t halo, int64_t* win_lo, int64_t* win_hi,
+                       int64_t* share_chunks, int64_t* share_work, char* err, size_t errlen)
+{
+    if (!g) { set_err(err, errlen, "group is NULL"); return WGBSSEG_E_ARG; }
+    const int G = (int)g->shares.size();
+    g->planned = false;
+    std::fill(g->loaded.begin(), g->loaded.end(), 0);
+    g->own_lo.assign((size_t)G, 0); g->own_hi.assign((size_t)G, 0);
+    g->win_lo.assign((size_t)G, 0); g->win_hi.assign((size_t)G, 0);
+    g->share_chunks.assign((size_t)G, 0); g->share_work.assign((size_t)G, 0);
+    if (halo < 0) halo = std::max<int64_t>(chunk_size, 4096);
+    int rc = wgbsseg_plan_shares(loci, n_sites, region_start, region_end, n_regions, chunk_size, P, G, halo, g->own_lo.data(), g->own_hi.data(),
+                                 g->win_lo.data(), g->win_hi.data(), g->share_chunks.data(), g->share_work.data(), err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
+    g->rs.assign(region_start, region_start + n_regions);
+    g->re.assign(region_end, region_end + n_regions);
+    g->chunk_size = chunk_size; g->n_sites = n_sites; g->halo = halo; g->P = *P;
+    // every share's window of the loci goes to its device now (4 bytes per site)
+    std::vector<int> rcs((size_t)G, WGBSSEG_OK);
+    std::vector<std::string> msgs((size_t)G);
+    parallel_for(G, 64, [&](int64_t d) {
+        if (g->win_hi[(size_t)d] <= g->win_lo[(size_t)d]) return;
+        char eb[512] = {0};
+        rcs[(size_t)d] = wgbsseg_set_loci_host(g->shares[(size_t)d], loci + g->win_lo[(size_t)d], g->win_hi[(size_t)d] - g->win_lo[(size_t)d], eb, sizeof(eb));
+        g->shares[(size_t)d]->site_base = g->win_lo[(size_t)d];
+        msgs[(size_t)d] = eb;
+    });
+    for (int d = 0; d < G; d++) if (rcs[(size_t)d] != WGBSSEG_OK) { set_err(err, errlen, "share %d: %s", d, msgs[(size_t)d].c_str()); return rcs[(size_t)d]; }
+    for (int d = 0; d < G; d++) {
+        if (win_lo) win_lo[d] = g->win_lo[(size_t)d];
+        if (win_hi) win_hi[d] = g->win_hi[(size_t)d];
+        if (share_chunks) share_chunks[d] = g->share_chunks[(size_t)d];
+        if (share_work) share_work[d] = g->share_work[(size_t)d];
+    }
+    g->planned = true;
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_group_load_host(wgbsseg_group* g, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites, char* err, size_t errlen)
+{
+    if (!g || !g->planned) { set_err(err, errlen, "group_load_host: call wgbsseg_group_plan first"); return WGBSSEG_E_STATE; }
+    if (!samples || n_samples < 1 || n_sites != g->n_sites) { set_err(err, errlen, "group_load_host: bad arguments (the plan is for %lld sites)", (long long)g->n_sites); return WGBSSEG_E_ARG; }
+    const int G = (int)g->shares.size();
+    std::vector<int> rcs((size_t)G, WGBSSEG_OK);
+    std::vector<std::string> msgs((size_t)G);
+    parallel_for(G, 64, [&](int64_t d) {
+        const int64_t lo = g->win_lo[(size_t)d], hi = g->win_hi[(size_t)d];
+        if (hi <= lo) return;
+        std::vector<const uint8_t*> ptrs((size_t)n_samples);
+        for (int64_t s = 0; s < n_samples; s++) ptrs[(size_t)s] = samples[s] + 2 * lo;
+        char eb[512] = {0};
+        rcs[(size_t)d] = wgbsseg_set_betas_host(g->shares[(size_t)d], ptrs.data(), n_samples, hi - lo, eb, sizeof(eb));
+        msgs[(size_t)d] = eb;
+        if (rcs[(size_t)d] == WGBSSEG_OK) g->loaded[(size_t)d] = 1;
+    });
+    for (int d = 0; d < G; d++) if (rcs[(size_t)d] != WGBSSEG_OK) { set_err(err, errlen, "share %d: %s", d, msgs[(size_t)d].c_str()); return rcs[(size_t)d]; }
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_group_share_set_device(wgbsseg_group* g, int32_t share, const void* base, int64_t n_samples, int64_t pitch_bytes, char* err, size_t errlen)
+{
+    if (!g || !g->planned) { set_err(err, errlen, "group_share_set_device: call wgbsseg_group_plan first"); return WGBSSEG_E_STATE; }
+    if (share < 0 || share >= (int32_t)g->shares.size()) { set_err(err, errlen, "no share %d", (int)share); return WGBSSEG_E_ARG; }
+    const int64_t n = g->win_hi[(size_t)share] - g->win_lo[(size_t)share];
+    if (n <= 0) return WGBSSEG_OK;                          // a share without chunks needs no data
+    const int rc = wgbsseg_set_betas_device(g->shares[(size_t)share], base, n_samples, pitch_bytes, n, err, errlen);
+    if (rc == WGBSSEG_OK) g->loaded[(size_t)share] = 1;
+    return rc;
+}
+
+int wgbsseg_group_segment_regions(wgbsseg_group* g, int32_t* borders_out, int64_t borders_cap, int64_t* borders_off, int64_t* stats,
+                                  char* err, size_t errlen)
+{
+    if (!g || !g->planned) { set_err(err, errlen, "group_segment_regions: call wgbsseg_group_plan first"); return WGBSSEG_E_STATE; }
+    const int G = (int)g->shares.size();
+    for (int d = 0; d < G; d++)
+        if (g->win_hi[(size_t)d] > g->win_lo[(size_t)d] && !g->loaded[(size_t)d]) { set_err(err, errlen, "share %d has no beta data yet", d); return WGBSSEG_E_STATE; }
+    int64_t n_batches = 0;
+    std::vector<char> ran((size_t)G, 0);                     // the share's timings of this call: reset on its first batch, summed after
+    wgstitch::BatchFn run_batch = [&](const std::vector<wgstitch::Sites>& todo, wgstitch::BatchResult& res, std::string& msg) -> int {
+        // route: the share that owns the first site of the range; a junction patch reaches into the next share's first chunk,
+        // which the halo of the window covers
+        std::vector<std::vector<size_t>> items((size_t)G);
+        for (size_t i = 0; i < todo.size(); i++) {
+            const int64_t lo = todo[i].first - 1, hi = todo[i].second - 1;
+            if (hi - lo > 0x7fffffff) { msg = "chunk too long"; return WGBSSEG_E_ARG; }
+            int d = (int)(std::upper_bound(g->own_lo.begin(), g->own_lo.end(), lo) - g->own_lo.begin()) - 1;
+            d = std::max(d, 0);
+            while (d > 0 && g->own_hi[(size_t)d] <= g->own_lo[(size_t)d]) d--;              // shares without chunks own nothing
+            int pick = -1;
+            for (int q : {d, d + 1, d - 1})
+                if (q >= 0 && q < G && g->win_lo[(size_t)q] <= lo && hi <= g->win_hi[(size_t)q] && g->win_hi[(size_t)q] > g->win_lo[(size_t)q]) { pick = q; break; }
+            if (pick < 0) {
+                msg = "sites [" + std::to_string(lo + 1) + ", " + std::to_string(hi + 1) + ") are not resident on any single share (halo " +
+                      std::to_string(g->halo) + " sites): a junction patch outgrew it; rerun on one share";
+                return WGBSSEG_E_STATE;
+            }
+            items[(size_t)pick].push_back(i);
+        }
+        res.ptr.assign(todo.size(), nullptr);
+        res.cnt.assign(todo.size(), 0);
+        std::vector<int> rcs((size_t)G, WGBSSEG_OK);
+        std::vector<std::string> msgs((size_t)G);
+        std::vector<std::unique_ptr<int32_t[]>> owned((size_t)G);
+        auto work = [&](int d) {
+            const std::vector<size_t>& it = items[(size_t)d];
+            if (it.empty()) return;
+            std::vector<int64_t> st0(it.size()), off;
+            std::vector<int32_t> ln(it.size());
+            for (size_t k = 0; k < it.size(); k++) {
+                st0[k] = todo[it[k]].first - 1 - g->win_lo[(size_t)d];
+                ln[k] = (int32_t)(todo[it[k]].second - todo[it[k]].first);
+            }
+            const int32_t* flat = nullptr;
+            rcs[(size_t)d] = run_ctx_batch(g->shares[(size_t)d], st0, ln, &g->P, n_batches, ran[(size_t)d] != 0, flat, off, owned[(size_t)d], msgs[(size_t)d]);
+            if (rcs[(size_t)d] != WGBSSEG_OK) return;
+            ran[(size_t)d] = 1;
+            for (size_t k = 0; k < it.size(); k++) { res.ptr[it[k]] = flat + off[k]; res.cnt[it[k]] = off[k + 1] - off[k]; }
+        };
+        int busy = 0, only = -1;
+        for (int d = 0; d < G; d++) if (!items[(size_t)d].empty()) { busy++; only = d; }
+        if (busy == 1) work(only);
+        else {
+            std::vector<std::thread> th;
+            for (int d = 0; d < G; d++) if (!items[(size_t)d].empty()) th.emplace_back(work, d);
+            for (auto& x : th) x.join();
+        }
+        for (int d = 0; d < G; d++) {
+            if (rcs[(size_t)d] != WGBSSEG_OK) { msg = "share " + std::to_string(d) + ": " + msgs[(size_t)d]; return rcs[(size_t)d]; }
+            if (owned[(size_t)d]) res.owned.push_back(std::move(owned[(size_t)d]));
+        }
+        n_batches++;
+        return WGBSSEG_OK;
+    };
+    std::string msg;
+    const int rc = wgstitch::segment_regions(g->rs.data(), g->re.data(), (int64_t)g->rs.size(), g->chunk_size, run_batch, borders_out,
+                                             borders_cap, borders_off, stats, msg, speculation_on());
+    return map_stitch_rc(rc, msg, err, errlen);
+}
+
+int wgbsseg_group_get_timings(const wgbsseg_group* g, int32_t share, wgbsseg_timings* out)
+{
+    if (!g || share < 0 || share >= (int32_t)g->shares.size()) return WGBSSEG_E_ARG;
+    return wgbsseg_get_timings(g->shares[(size_t)share], out);
 }
 
 int wgbsseg_scan_only(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks, int repeat,
@@ -971,7 +1323,7 @@ int wgbsseg_debug_sample_terms(wgbsseg_ctx* c, const float* nmeth, const float* 
     HIP_TRY(hipMemcpyAsync(c->dbg_b.p, ntotal, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
     const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 8192);
     const int fast = wg_term_mode(pseudo_count);                                         // the library's own dispatch rule
-    const int rows = fast == 2 ? wg_lookup_rows(pseudo_count, 255.0 * 8000.0) : 0;       // the ABI's longest block (max_cpg <= 8000)
+    const int rows = fast == 2 ? wg_lookup_rows(pseudo_count, 255.0 * WGBSSEG_MAX_CPG) : 0;       // the ABI's longest block
     if (rows > WG_KY_KMIN + 1) return WGBSSEG_E_ARG;
     hipLaunchKernelGGL(k_debug_terms, dim3(blocks), dim3(256), 0, c->sA, c->dbg_a.as<float>(), c->dbg_b.as<float>(), count, pseudo_count, c->dbg_c.as<float>(), fast, rows);
     HIP_TRY(hipGetLastError());

@@ -1,0 +1,70 @@
+"""Several GPUs from one process: the `-@` of the reference (segment.py:144-146, a Pool of chunk processes) as a group of
+GPU shares (include/wgbsseg.h, wgbsseg_group_*).
+
+The chunk grid (segment.py:124-135) is cut into contiguous runs of chunks, one per share, balanced by the work the chunks
+hold (scored blocks, counted from the loci); a share uploads only its own window of every beta file; the chunk DPs and
+junction patches of a batch run on all shares side by side (one host thread each, no device-to-device traffic); the
+reference's pairwise stitching tree (segment.py:157-165,199-252) runs once on the host over all shares' results, so
+the borders do not depend on the number of shares.
+"""
+import numpy as np
+
+from . import _lib
+
+
+class GroupEngine:
+    """Chunk engine of SegmentByChunks over a group of shares; same `segment_regions` interface as HipEngine."""
+
+    def __init__(self, betas, genome, devices):
+        self.betas = list(betas)
+        self.genome = genome
+        self.devices = list(devices)
+        self.group = _lib.SegmenterGroup(self.devices)
+        self._maps = None
+        self.base = 0
+        self.last_stats = None
+        self.windows = None
+
+    def segment_regions(self, regions, chunk_size, params):
+        """regions: [(startCpG, endCpG)] 1-based half-open, ascending and disjoint (whole chromosomes, a -s/-r range or the
+        rows of a sorted -L file).  -> merged absolute border list of each region."""
+        loci = self.genome.loci()
+        self.windows = self.group.plan(loci, regions, chunk_size, params['pcount'], params['max_cpg'], params['max_bp'])
+        if self._maps is None:
+            self._maps = [np.memmap(b, dtype=np.uint8, mode='r') for b in self.betas]
+        self.group.load_host(self._maps)
+        res, self.last_stats = self.group.segment_regions()
+        return res
+
+    def timings(self):
+        return [self.group.timings(d) for d in range(self.group.n_shares)]
+
+    def close(self):
+        self.group.close()
+        self._maps = None
+
+
+def regions_fit_a_group(regions):
+    """A group plans over ascending, disjoint regions (every whole-genome / -r / -s run, and sorted -L files)."""
+    return all(b > a for a, b in regions) and all(regions[i][0] >= regions[i - 1][1] for i in range(1, len(regions)))
+
+
+def segment_regions_on_shares(data_ptr, n_samples, pitch, n_sites, loci, regions, chunk_size, pcount, max_cpg, max_bp, devices,
+                              keepalive=None, group=None, want_group=False):
+    """The group path over ONE whole-genome device buffer [n_samples][pitch] that every share can see (all `devices` equal
+    to the buffer's device: tests and the one-GPU bench): share d borrows the view of its window.
+    -> list of border arrays per region (and the group, stats when want_group)."""
+    own = group is None
+    g = group or _lib.SegmenterGroup(devices)
+    try:
+        if own or g.n_regions == 0:
+            w = g.plan(loci, regions, chunk_size, pcount, max_cpg, max_bp)
+            for d in range(g.n_shares):
+                g.share_set_device(d, int(data_ptr) + 2 * int(w['win_lo'][d]), n_samples, pitch, keepalive=keepalive)
+        res, stats = g.segment_regions()
+        if want_group:
+            return res, stats, g
+        return res
+    finally:
+        if own and not want_group:
+            g.close()

@@ -1,12 +1,13 @@
-"""Multi-GPU sharding of the segment path: one process per GPU, no collective on the data path.
+"""Multi-process sharding of the segment path: one process per GPU (python -m torch.distributed.run), no collective on
+the data path.
 
-Chunks are independent DP problems and chromosomes never interact (segment.py:84-86,129-134), so the chunk grid is
-cut into `world` contiguous runs of chunks (balanced by site count, always on the reference's grid so every chunk is
-the very chunk a single-GPU run would segment).  Each rank segments and stitches its own pieces; the per-rank border
-lists are gathered as Python objects on rank 0 (host side), which stitches the at most world-1 junctions that fall
-between two ranks with the reference's own rule (segment.py:199-232) and concatenates.
+Chunks are independent DP problems and chromosomes never interact (segment.py:84-86,129-134).  The chunk grid is cut into
+`world` contiguous runs of chunks by the planner of the share groups (wgbsseg_plan_shares, include/wgbsseg.h: balanced by the
+scored blocks the chunks hold, always on the reference's grid so every chunk is the very chunk a one-GPU run would segment).
+Each rank runs its chunk DPs on its own GPU; the per-chunk border lists are gathered as Python objects on the host of rank
+0, which walks the reference's pairwise tree (segment.py:157-165,199-252) over ALL chunks with the native stitcher
+(wgbsseg_stitch_regions): the answer does not depend on the number of ranks.
 """
-import numpy as np
 
 
 def regions_of_sizes(sizes):
@@ -27,49 +28,37 @@ def chunk_grid(regions, chunk):
     return chunks
 
 
-def shard_regions(regions, chunk, world):
-    """-> (pieces per rank: [[(region idx, start, end), ...], ...], number of chunks).  A piece is a maximal run of
-    consecutive chunks of one region owned by one rank; pieces start on the region's chunk grid."""
-    chunks = chunk_grid(regions, chunk)
-    total = sum(e - s for _, s, e in chunks)
-    out, acc, r = [[] for _ in range(world)], 0, 0
-    for ri, s, e in chunks:
-        while r < world - 1 and acc >= total * (r + 1) / world:
-            r += 1
-        p = out[r]
-        if p and p[-1][2] == s and p[-1][0] == ri:
-            p[-1] = (ri, p[-1][1], e)
+def plan(regions, chunk, world, loci, params):
+    """wgbsseg_plan_shares for `world` shares -> dict of arrays (own_lo, own_hi, win_lo, win_hi, chunks, work)."""
+    from . import _lib
+    return _lib.plan_shares(loci, regions, chunk, params['pcount'], params['max_cpg'], params['max_bp'], world)
+
+
+def chunks_of_rank(regions, chunk, world, rank, loci, params, shares=None):
+    """The chunks (1-based half-open) rank `rank` of `world` segments: a contiguous run of the reference's chunk grid."""
+    sh = shares or plan(regions, chunk, world, loci, params)
+    lo, hi = int(sh['own_lo'][rank]), int(sh['own_hi'][rank])
+    return [(s, e) for _, s, e in chunk_grid(regions, chunk) if hi > lo and lo <= s - 1 and e - 1 <= hi]
+
+
+def pieces_of_rank(regions, chunk, world, rank, loci, params, shares=None):
+    """The same chunks as maximal runs inside one region: [(region idx, start, end)], every piece starting on the
+    region's chunk grid (what a rank hands to wgbsseg_segment_regions when it times its own share: bench.py)."""
+    sh = shares or plan(regions, chunk, world, loci, params)
+    lo, hi = int(sh['own_lo'][rank]), int(sh['own_hi'][rank])
+    out = []
+    for ri, s, e in chunk_grid(regions, chunk):
+        if not (hi > lo and lo <= s - 1 and e - 1 <= hi):
+            continue
+        if out and out[-1][0] == ri and out[-1][2] == s:
+            out[-1] = (ri, out[-1][1], e)
         else:
-            p.append((ri, s, e))
-        acc += e - s
-    return out, len(chunks)
-
-
-def shard_pieces(sizes, chunk, world):
-    """shard_regions over whole chromosomes of the given CpG counts."""
-    return shard_regions(regions_of_sizes(sizes), chunk, world)
-
-
-def stitch_across_ranks(gathered, stitch_fn):
-    """gathered: list over ranks of [(chrom idx, start, end, borders ndarray), ...].  Joins pieces of the same
-    chromosome in order with `stitch_fn(b1, b2)` (= stitch_2_dfs bound to an engine).  -> {chrom idx: borders}."""
-    by_chrom = {}
-    for plist in gathered:
-        for ci, s, e, b in plist:
-            by_chrom.setdefault(ci, []).append((s, e, np.asarray(b)))
-    merged = {}
-    for ci, lst in by_chrom.items():
-        lst.sort(key=lambda x: x[0])
-        cur = lst[0][2]
-        for s, e, b in lst[1:]:
-            assert cur[-1] == s and b[0] == s, 'pieces of a chromosome must tile it'
-            cur = stitch_fn(cur, b)
-        merged[ci] = cur
-    return merged
+            out.append((ri, s, e))
+    return out
 
 
 def gather_to_rank0(local, rank, world):
-    """Host-side gather of per-rank piece results (small int arrays); no-op for world == 1."""
+    """Host-side gather of per-rank chunk results (small int arrays); no-op for world == 1."""
     if world == 1:
         return [local]
     import torch.distributed as dist
@@ -85,7 +74,7 @@ def env_rank_world():
 
 
 def init_host_group():
-    """The only communication of a multi-GPU segment run is the final host-side gather of border lists: a gloo group."""
+    """The only communication of a multi-process segment run is the final host-side gather of border lists: a gloo group."""
     import torch.distributed as dist
     if not dist.is_initialized():
         dist.init_process_group('gloo')

@@ -22,6 +22,7 @@ import numpy as np
 from .genome import (GenomeRefPaths, GenomicRegion, IllegalArgumentError, beta_sanity_check, eprint, write_bed)
 
 DEF_CHUNK = 60000
+MAX_CPG_CAP = 8000            # WGBSSEG_MAX_CPG (include/wgbsseg.h): the one limit the reference does not have
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -39,6 +40,7 @@ class HipEngine:
         maps = [np.memmap(b, dtype=np.uint8, mode='r') for b in betas]
         self._seg.set_betas([m[2 * lo:2 * hi] for m in maps])
         self._seg.set_loci(genome.loci()[lo:hi])
+        self._seg.set_site_base(lo)                              # error messages name absolute sites
 
     def segment_many(self, sites_list, params):
         """sites_list: [(start, end), ...] 1-based half-open; returns [np.int64 array of absolute borders, ...]."""
@@ -77,6 +79,48 @@ class HipEngine:
 
     def timings(self):
         return self._seg.timings()
+
+    def close(self):
+        self._seg.close()
+
+
+class GatherEngine:
+    """Junction patches anywhere in the genome on one GPU without the genome being resident there: the sites of the
+    requested ranges are gathered from the memory-mapped beta files into one compact buffer (a chunk DP reads nothing
+    outside its own range: segmentor.cpp:164-177 seeks to -s and reads -n sites).  Used by rank 0 of a multi-process run for
+    the patches between the ranks' chunk results: a few hundred sites per junction."""
+
+    def __init__(self, betas, genome, device=0):
+        from . import _lib
+        self._seg = _lib.Segmenter(device)
+        self._maps = [np.memmap(b, dtype=np.uint8, mode='r') for b in betas]
+        self._loci = genome.loci()
+
+    def segment_many(self, sites_list, params):
+        out = [None] * len(sites_list)
+        idx = [i for i, (a, b) in enumerate(sites_list) if b - a > 1]
+        for i, (a, b) in enumerate(sites_list):
+            assert b - a > 0, f'trying to segment an empty interval {(a, b)}'
+            if b - a == 1:                                       # segment.py:45-46
+                out[i] = np.array([a, b])
+        if idx:
+            lens = np.array([sites_list[i][1] - sites_list[i][0] for i in idx], dtype=np.int64)
+            offs = np.concatenate([[0], np.cumsum((lens + 7) // 8 * 8)])      # ranges start on 16-byte boundaries
+            total = int(offs[-1])
+            buf = np.zeros((len(self._maps), 2 * total), dtype=np.uint8)
+            loci = np.zeros(total, dtype=np.uint32)
+            for k, i in enumerate(idx):
+                a, b = sites_list[i]
+                o = int(offs[k])
+                for s, m in enumerate(self._maps):
+                    buf[s, 2 * o:2 * (o + b - a)] = m[2 * (a - 1):2 * (b - 1)]
+                loci[o:o + b - a] = self._loci[a - 1:b - 1]
+            self._seg.set_betas(list(buf))
+            self._seg.set_loci(loci)
+            res = self._seg.segment_chunks(offs[:-1], lens, params['pcount'], params['max_cpg'], params['max_bp'])
+            for i, r in zip(idx, res):
+                out[i] = r.astype(np.int64) + sites_list[i][0]
+        return out
 
     def close(self):
         self._seg.close()
@@ -192,6 +236,11 @@ class SegmentByChunks:
         self.betas = betas
         max_cpg = min(args.max_cpg, args.max_bp // 2)            # segment.py:65
         assert max_cpg > 1
+        if max_cpg > MAX_CPG_CAP:
+            # the one limit the reference does not have (include/wgbsseg.h, WGBSSEG_MAX_CPG): say so here, before any upload
+            raise IllegalArgumentError(f'[wt segment] ERROR: blocks of up to min(max_cpg, max_bp/2) = {max_cpg} sites requested; '
+                                       f'this implementation supports at most {MAX_CPG_CAP} (default 1000).')
+        self._regions = None
         self.genome = GenomeRefPaths(args.genome)
         self.param_dict = {'betas': betas,
                            'pcount': args.pcount,
@@ -209,7 +258,14 @@ class SegmentByChunks:
                 raise IllegalArgumentError(msg)
 
     def regions(self):
-        """The (startCpG, endCpG) rows break_to_chunks iterates over (segment.py:95-122)."""
+        """The (startCpG, endCpG) rows break_to_chunks iterates over (segment.py:95-122), read once.  Rows with
+        endCpG == startCpG yield no chunk in the reference (`range(start, end, step) + [end]` has a single element):
+        they are dropped here."""
+        if self._regions is None:
+            self._regions = [(s, e) for s, e in self._read_regions() if e > s]
+        return self._regions
+
+    def _read_regions(self):
         if self.args.bed_file:
             df = load_blocks_file(self.args.bed_file)
             is_nice, msg = is_block_file_nice(df)
@@ -259,19 +315,28 @@ class SegmentByChunks:
         if world > 1:
             return self.run_sharded(rank, world, local)
         prof = [('start', time.perf_counter())] if os.environ.get('WGBSSEG_PROFILE') else None
+        if not starts:                                           # nothing to segment (e.g. an -L file of empty rows)
+            self.dump_result(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+            return
         if own_engine:
-            lo = min(starts) - 1 if starts else 0
-            hi = max(ends) - 1 if ends else 0
-            self.param_dict['engine'] = HipEngine(self.betas, self.genome, device=getattr(self.args, 'device', 0),
-                                                  site_range=(lo, hi))
-            if prof: prof.append(('loci + betas to the device', time.perf_counter()))
+            self.param_dict['engine'] = self.make_engine(starts, ends)
+            if prof: prof.append(('engine (one GPU: loci + betas to the device)', time.perf_counter()))
         try:
             eng = self.param_dict['engine']
             if hasattr(eng, 'segment_regions'):
                 # native chunk grid + batched patches + stitching around the GPU batches (csrc/stitch.h)
                 regs = self.regions()
-                merged = dict(zip([f'{a}-{b}' for a, b in regs],
-                                  eng.segment_regions(regs, self.args.chunk_size, self.param_dict)))
+                try:
+                    res = eng.segment_regions(regs, self.args.chunk_size, self.param_dict)
+                except Exception as e:
+                    if not (own_engine and getattr(e, 'code', 0) == -7 and 'not resident on any single share' in str(e)):
+                        raise
+                    # a junction patch outgrew the halo between two shares (patch doubling past a chunk): one GPU, whole range
+                    eprint('[wt segment] a junction patch outgrew the share halo; rerunning on one GPU')
+                    eng.close()
+                    eng = self.param_dict['engine'] = self.make_engine(starts, ends, gpus=1)
+                    res = eng.segment_regions(regs, self.args.chunk_size, self.param_dict)
+                merged = dict(zip([f'{a}-{b}' for a, b in regs], res))
             else:
                 arr = eng.segment_many(list(zip(starts, ends)), self.param_dict)
                 # merge chunks from the same "tag" group (segment.py:148-154); all groups advance round by round together
@@ -298,46 +363,69 @@ class SegmentByChunks:
             prof.append(('blocks to BED', time.perf_counter()))
             eprint('[wt segment] phases: ' + ', '.join('%s %.3f s' % (n, t - prof[i][1]) for i, (n, t) in enumerate(prof[1:])))
 
-    def run_sharded(self, rank, world, local, engine_factory=None):
+    def make_engine(self, starts, ends, gpus=None):
+        """--gpus N (default: every visible GPU): N > 1 and a region list a group can plan over -> one share per GPU
+        (wgbs_tools_amd/multi.py); else one GPU holding just the site range the run needs."""
+        from . import _lib, multi
+        want = getattr(self.args, 'gpus', 0) if gpus is None else gpus
+        have = max(1, _lib.device_count())
+        n = want or have            # more shares than GPUs is allowed (they wrap around the devices): only useful for tests
+        first = getattr(self.args, 'device', 0)
+        if n > 1 and multi.regions_fit_a_group(self.regions()):
+            return multi.GroupEngine(self.betas, self.genome, [(first + d) % have for d in range(n)])
+        return HipEngine(self.betas, self.genome, device=first, site_range=(min(starts) - 1, max(ends) - 1))
+
+    def run_sharded(self, rank, world, local, engine_factory=None, patch_engine_factory=None):
         """One process per GPU (python -m torch.distributed.run ... wgbstools segment ...): the chunk grid is cut into
-        `world` contiguous pieces, every rank segments and stitches its own pieces on its own GPU, the border lists
-        are gathered on the host of rank 0 (no collective on the data path), which stitches the junctions between
-        ranks with the reference's rule and writes the BED.  The other ranks produce no output."""
-        from . import parallel
+        `world` contiguous, work-balanced runs of chunks (the planner of the share groups, include/wgbsseg.h); every rank
+        uploads its own window of the beta files and runs its chunk DPs on its own GPU; the per-chunk border lists are
+        gathered on the host of rank 0 (no collective on the data path), which walks the reference's pairwise tree
+        (segment.py:157-165) over ALL chunks with the native stitcher — the junction patches, a few hundred sites each,
+        run on rank 0's GPU from a gathered buffer — and writes the BED.  The result is the one-GPU result whatever the
+        number of ranks.  The other ranks produce no output."""
+        from . import parallel, _lib
         regs = self.regions()
-        pieces, _ = parallel.shard_regions(regs, self.args.chunk_size, world)
-        mine = pieces[rank]
+        pd = self.param_dict
         dist = parallel.init_host_group()
         if engine_factory is None:
             def engine_factory(site_range):
-                import torch
-                ndev = max(1, torch.cuda.device_count())
+                ndev = max(1, _lib.device_count())
                 return HipEngine(self.betas, self.genome, device=local % ndev, site_range=site_range)
-        # every rank needs its own pieces; rank 0 also the junction neighbourhoods between ranks: keep it simple, one range
-        lo = min(a for a, _ in regs) - 1
-        hi = max(b for _, b in regs) - 1
-        if mine and rank != 0:
-            lo, hi = min(p[1] for p in mine) - 1, max(p[2] for p in mine) - 1
-        eng = engine_factory((lo, hi)) if (mine or rank == 0) else None
+        if patch_engine_factory is None:
+            def patch_engine_factory():
+                return GatherEngine(self.betas, self.genome, device=local % max(1, _lib.device_count()))
+        if not regs:
+            if rank == 0:
+                self.dump_result(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+            dist.barrier()
+            return
+        mine = parallel.chunks_of_rank(regs, self.args.chunk_size, world, rank, self.genome.loci(), pd)
+        eng = None
         try:
             local_res = []
             if mine:
-                res = eng.segment_regions([(s, e) for _, s, e in mine], self.args.chunk_size, self.param_dict) \
-                    if hasattr(eng, 'segment_regions') else None
-                if res is None:
-                    res = []
-                    for _, s, e in mine:
-                        bords = list(range(s, e, self.args.chunk_size)) + [e]
-                        arr = eng.segment_many(list(zip(bords[:-1], bords[1:])), self.param_dict)
-                        self.param_dict['engine'] = eng
-                        res.append(self.merge_df_list(arr))
-                local_res = [(ri, s, e, np.asarray(b)) for (ri, s, e), b in zip(mine, res)]
+                eng = engine_factory((min(a for a, _ in mine) - 1, max(b for _, b in mine) - 1))
+                local_res = list(zip(mine, eng.segment_many(mine, pd)))
             gathered = parallel.gather_to_rank0(local_res, rank, world)
             if rank == 0:
-                pd = dict(self.param_dict, engine=eng)
-                merged = parallel.stitch_across_ranks(gathered, lambda a, b: stitch_2_dfs(a, b, pd))
-                s_ = np.concatenate([m[:-1] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
-                e_ = np.concatenate([m[1:] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
+                chunk_res = {tuple(k): np.asarray(v) for part in gathered for k, v in part}
+                peng = []
+
+                def engine_many(sites):
+                    need = [s for s in sites if s not in chunk_res]
+                    if need:
+                        if not peng:
+                            peng.append(patch_engine_factory())
+                        got = dict(zip(need, peng[0].segment_many(need, pd)))
+                    return [chunk_res[s] if s in chunk_res else got[s] for s in sites]
+                try:
+                    merged, self.last_stats = _lib.stitch_regions(regs, self.args.chunk_size, engine_many)
+                finally:
+                    for e in peng:
+                        if hasattr(e, 'close'):
+                            e.close()
+                s_ = np.concatenate([m[:-1] for m in merged])
+                e_ = np.concatenate([m[1:] for m in merged])
                 self.dump_result(s_, e_)
         finally:
             if eng is not None and hasattr(eng, 'close'):
@@ -477,13 +565,16 @@ def parse_args(argv=None):
                              'ommited from output (equivalent to set min_cpg to 1 and then filter output by '
                              'length). Default is 1')
     parser.add_argument('--max_cpg', type=int, default=1000,
-                        help='Maximal allowed block size (in #sites). Default is 1000')
+                        help=f'Maximal allowed block size (in #sites). Default is 1000 (at most {MAX_CPG_CAP} here)')
     parser.add_argument('--max_bp', type=int, default=2000,
                         help='Maximal allowed block size (in bp). Default is 2000')
     parser.add_argument('-o', '--out_path', default=sys.stdout,
                         help='output path [stdout]')
     add_multi_thread_args(parser)
-    parser.add_argument('--device', type=int, default=0, help='HIP device index [0]')
+    parser.add_argument('--device', type=int, default=0, help='HIP device index of the (first) GPU [0]')
+    parser.add_argument('--gpus', type=int, default=0,
+                        help='Number of GPUs to spread the chunks over from this one process (the role of -@ in the '
+                             'CPU implementation). Default: all visible GPUs')
     return parser.parse_args(argv)
 
 
