@@ -90,6 +90,10 @@ void wgbsseg_destroy(wgbsseg_ctx* ctx);
  */
 int wgbsseg_set_betas_host(wgbsseg_ctx* ctx, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites,
                            char* err, size_t errlen);
+/* .lbeta rows (uint16 pairs, docs/beta_format.md:41-44; utils_wgbs.py:311-319 reads them as np.uint16) for the block
+ * reduction only: wgbsseg_block_sums accepts them, the segment calls refuse (the reference's segmentor reads uint8 only). */
+int wgbsseg_set_lbetas_host(wgbsseg_ctx* ctx, const uint16_t* const* samples, int64_t n_samples, int64_t n_sites,
+                            char* err, size_t errlen);
 int wgbsseg_set_betas_device(wgbsseg_ctx* ctx, const void* base, int64_t n_samples, int64_t pitch_bytes,
                              int64_t n_sites, char* err, size_t errlen);
 

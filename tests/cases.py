@@ -100,3 +100,11 @@ CHUNK_CASES = {
 
 # chr21-shaped multi-chunk case (BASELINE.json configs[1]): 400,000 CpGs x 8 samples in default 60,000-site chunks
 CHR21 = dict(n=400000, a=0, samples=list(range(8)), pcount=15.0, max_cpg=1000, max_bp=2000, chunk=60000)
+
+
+def lbeta_twin(data):
+    """uint16 [n, 2] twin of a uint8 beta array for the .lbeta-input cases: (meth, cov) of site i times k(i) = 1 + (i * 2654435761 mod 997)
+    (<= 54 * 997 < 65536; keeps meth <= cov)."""
+    i = np.arange(data.shape[0], dtype=np.uint64)
+    k = (1 + (i * np.uint64(2654435761)) % np.uint64(997)).astype(np.uint32)
+    return (data.astype(np.uint32) * k[:, None]).astype(np.uint16)

@@ -67,6 +67,7 @@ def write_blocks(path, rows):
 
 
 def main():
+    import hashlib
     import beta_to_blocks as rb
     import beta_to_table as rt
     rng = np.random.default_rng(20260926)
@@ -79,6 +80,11 @@ def main():
             synth.synth_betas(cases.SEED, s, 0, N_SITES).tofile(p)
             betas.append(p)
         fixture['input_crc32'] = synth.checksum(*[np.fromfile(b, dtype=np.uint8) for b in betas])
+        lbetas = []
+        for s in SAMPLES:                                       # uint16 twins of the samples: (meth, cov) * k(site), k <= 997
+            p = op.join(td, 'smp%d.lbeta' % s)
+            cases.lbeta_twin(synth.synth_betas(cases.SEED, s, 0, N_SITES)).tofile(p)
+            lbetas.append(p)
         gpath = op.join(td, 'groups.csv')
         with open(gpath, 'w') as f:
             f.write('name,group\nsmp0,A\nsmp1,B\nsmp2,A\nsmp3,B\n')
@@ -113,6 +119,26 @@ def main():
                 o = op.join(td, 't.tsv')
                 rt.dump(o, t, True, dg)
                 rec[tag] = text_record(open(o).read())
+            # the same with uint16 .lbeta INPUT files (utils_wgbs.py:311-319): outputs as digests
+            lrec = {'bin_sha1': {}, 'lbeta_sha1': {}}
+            for lb in lbetas:
+                key = op.basename(lb)
+                for lbeta in (False, True):
+                    od = op.join(td, 'lout_%s_%d' % (name, int(lbeta)))
+                    os.makedirs(od, exist_ok=True)
+                    stderr, sys.stderr = sys.stderr, io.StringIO()
+                    try:
+                        rb.collapse_process(lb, df.copy(), is_nice, lbeta, od, False)
+                    finally:
+                        sys.stderr = stderr
+                    stem = op.join(od, op.splitext(key)[0])
+                    data = open(stem + ('.lbeta' if lbeta else '.bin'), 'rb').read()
+                    lrec['lbeta_sha1' if lbeta else 'bin_sha1'][key] = hashlib.sha1(data).hexdigest()
+            t = rt.betas2table(lbetas, bpath, None, 4, threads=2)
+            o = op.join(td, 'tl.tsv')
+            rt.dump(o, t, True, 3)
+            lrec['table_plain'] = text_record(open(o).read())
+            rec['lbeta_inputs'] = lrec
             fixture['tables'][name] = rec
             print(name, 'rows', len(rows), 'nice', is_nice, msg)
     with open(op.join(HERE, 'block_cases.json'), 'w') as f:

@@ -7,10 +7,10 @@ import json
 import os.path as op
 
 import numpy as np
-import pandas as pd
 import pytest
 
 from oracle import block_sums as OB
+import cases
 from wgbs_tools_amd import beta_to_blocks as B2B, beta_to_table as B2T, synth
 
 HERE = op.dirname(op.abspath(__file__))
@@ -34,17 +34,22 @@ def world(tmp_path_factory):
             for c, s, e, a, b in rec['rows']:
                 f.write('%s\t%d\t%d\t%s\t%s\n' % (c, s, e, 'NA' if a is None else a, 'NA' if b is None else b))
         paths[name] = p
+    lbetas = []
+    for s, d in zip(g['samples'], data):
+        p = str(td / ('smp%d.lbeta' % s))
+        cases.lbeta_twin(d).tofile(p)
+        lbetas.append(p)
     gpath = str(td / 'groups.csv')
     with open(gpath, 'w') as f:
         f.write('name,group\nsmp0,A\nsmp1,B\nsmp2,A\nsmp3,B\n')
-    return dict(g=g, td=td, betas=betas, data=data, blocks=paths, groups=gpath)
+    return dict(g=g, td=td, betas=betas, lbetas=lbetas, data=data, blocks=paths, groups=gpath)
 
 
 class OracleBlockEngine:
     """stands in for BlockSumEngine (same reduce() contract), numpy instead of the GPU"""
 
     def __init__(self, data):
-        self.data = data
+        self.data = data                       # uint8 or uint16 [n, 2] arrays
 
     def reduce(self, df, mode=0, min_cov=1):
         s0, e0 = B2B.block_site_ranges(df)
@@ -96,6 +101,46 @@ def test_oracle_and_host_logic_match_reference(world, name, tmp_path):
         text = buf.getvalue()
         assert text[:600] == rec[tag]['head'], (name, tag)
         assert len(text) == rec[tag]['len'] and _sha(text) == rec[tag]['sha1']
+        # in chunks, as the CLI walks the table
+        buf = io.StringIO()
+        for a in range(0, len(df), 257):
+            B2T.dump(buf, B2T.get_table(df.rows(a, a + 257), gf, mc, engine=eng), a == 0, dg)
+        assert buf.getvalue() == text
+    # uint16 .lbeta INPUT files (utils_wgbs.py:311-319): the oracle's sums -> the reference's .bin / .lbeta bytes and table
+    lrec = rec['lbeta_inputs']
+    ldata = [cases.lbeta_twin(d) for d in world['data']]
+    for i, lb in enumerate(world['lbetas']):
+        key = op.basename(lb)
+        sums = OB.block_sums(ldata[i], s0, e0)
+        assert hashlib.sha1(OB.trim(sums, False).tobytes()).hexdigest() == lrec['bin_sha1'][key]
+        assert hashlib.sha1(OB.trim(sums, True).tobytes()).hexdigest() == lrec['lbeta_sha1'][key]
+    gf = B2T.groups_load_wrap(None, world['lbetas'])
+    buf = io.StringIO()
+    B2T.dump(buf, B2T.get_table(df.copy(), gf, 4, engine=OracleBlockEngine(ldata)), True, 3)
+    text = buf.getvalue()
+    assert text[:600] == lrec['table_plain']['head'] and _sha(text) == lrec['table_plain']['sha1']
+
+
+def test_groups_file_rules(tmp_path):
+    """groups csv: comments, `include` column, missing cells, unknown prefixes (dmb.py:24-79)."""
+    for i in range(3):
+        (tmp_path / ('a%d.beta' % i)).write_bytes(b'')
+    betas = [str(tmp_path / ('a%d.beta' % i)) for i in range(3)]
+    g = tmp_path / 'g.csv'
+    g.write_text('# comment\nname,group,include\na0,X,True\na1,Y,False\na2,X,TRUE\n,Z,True\na1,,True\n')
+    gf = B2T.groups_load_wrap(str(g), betas)
+    assert gf.fname == ['a0', 'a2'] and gf.group == ['X', 'X'] and [op.basename(p) for p in gf.full_path] == ['a0.beta', 'a2.beta']
+    g.write_text('name,group,include\na0,X,yes\n')
+    with pytest.raises(B2B.IllegalArgumentError, match='Include column must be boolean'):
+        B2T.groups_load_wrap(str(g), betas)
+    g.write_text('name,grp\na0,X\n')
+    with pytest.raises(B2B.IllegalArgumentError, match='column named "group"'):
+        B2T.groups_load_wrap(str(g), betas)
+    g.write_text('name,group\na0,X\nzz,Y\n')
+    with pytest.raises(B2B.IllegalArgumentError, match='groups file mismatch'):
+        B2T.groups_load_wrap(str(g), betas)
+    gf = B2T.groups_load_wrap(None, betas + betas[:1])
+    assert gf.fname == ['a0', 'a1', 'a2'] and gf.group == gf.fname
 
 
 def test_blocks_file_rules(tmp_path):

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from oracle import block_sums as OB
+import cases
 from wgbs_tools_amd import _lib, synth, wgbs_tools
 from test_blocks_cpu import world          # noqa: F401  (fixture: betas, blocks tables and goldens on disk)
 
@@ -43,6 +44,21 @@ def test_cli_outputs_match_reference(world, name, tmp_path):
         text = open(out).read()
         assert text[:600] == rec[tag]['head'], (name, tag)
         assert len(text) == rec[tag]['len'] and _sha(text) == rec[tag]['sha1']
+    # uint16 .lbeta INPUT files: .bin / .lbeta bytes and the table, against what the reference made of them
+    lrec = rec['lbeta_inputs']
+    for lbeta in (False, True):
+        od = tmp_path / ('lo%d' % lbeta)
+        od.mkdir()
+        argv = ['wgbstools', 'beta_to_blocks'] + world['lbetas'] + ['-b', world['blocks'][name], '-o', str(od)] + (['-l'] if lbeta else [])
+        assert wgbs_tools.main(argv) == 0
+        for b in world['lbetas']:
+            key = op.basename(b)
+            got = open(str(od / op.splitext(key)[0]) + ('.lbeta' if lbeta else '.bin'), 'rb').read()
+            assert hashlib.sha1(got).hexdigest() == lrec['lbeta_sha1' if lbeta else 'bin_sha1'][key], (name, key, lbeta)
+    out = str(tmp_path / 'ltable.tsv')
+    assert wgbs_tools.main(['wgbstools', 'beta_to_table', world['blocks'][name], '--betas'] + world['lbetas'] + ['-o', out, '-c', '4', '--digits', '3']) == 0
+    text = open(out).read()
+    assert text[:600] == lrec['table_plain']['head'] and _sha(text) == lrec['table_plain']['sha1']
     # second run without --force skips existing files (beta_to_blocks.py:168-178)
     od = tmp_path / 'o0'
     before = {f: os.stat(od / f).st_mtime_ns for f in os.listdir(od)}
@@ -83,6 +99,37 @@ def test_block_sums_all_modes_against_oracle():
             sg.block_sums([9], [3])
     finally:
         sg.close()
+
+
+def test_block_sums_of_uint16_rows_against_oracle():
+    """.lbeta rows (uint16 pairs): random tables incl. unsorted, overlapping, empty and tile-crossing blocks; the segment
+    calls refuse such rows."""
+    n, N = 300000, 3
+    data = [cases.lbeta_twin(synth.synth_betas(99, s, 0, n)) for s in range(N)]
+    data[1][1000:3000, :] = 65535                                 # coverage sums far beyond uint16 / uint32-per-tile worries
+    rng = np.random.default_rng(5)
+    s0 = rng.integers(0, n - 1, 40000)
+    ln = np.where(rng.random(40000) < 0.9, rng.integers(0, 30, 40000), rng.integers(30, 9000, 40000))
+    e0 = np.minimum(s0 + ln, n)
+    s0 = np.concatenate([s0, [0, n - 1, n, 1023, 1024, 1025]]); e0 = np.concatenate([e0, [n, n, n, 1025, 2048, 1025]])
+    with _lib.Segmenter(0) as sg:
+        sg.set_lbetas(data)
+        b8 = sg.block_sums(s0, e0, mode=1)
+        b16 = sg.block_sums(s0, e0, mode=2)
+        mean = sg.block_sums(s0, e0, mode=3, min_cov=1000)
+        short = (e0 - s0) <= 65536
+        raw = sg.block_sums(s0[short], e0[short], mode=0)
+        for s in range(N):
+            want = OB.block_sums(data[s], s0, e0)
+            assert (b8[s] == OB.trim(want, False)).all() and (b16[s] == OB.trim(want, True)).all()
+            w3 = OB.beta2vec(want, 1000)
+            assert (np.isnan(mean[s]) == np.isnan(w3)).all() and np.array_equal(mean[s][~np.isnan(w3)], w3[~np.isnan(w3)])
+            assert (raw[s].astype(np.int64) == (want[short] & 0xffffffff)).all()
+        with pytest.raises(_lib.SegmentorError, match='exact up to 65536 sites'):
+            sg.block_sums([0], [70000], mode=0)
+        sg.set_loci(np.arange(n, dtype=np.uint32) * 50)
+        with pytest.raises(_lib.SegmentorError, match='uint16'):
+            sg.segment_chunks([0], [1000], 15.0, 1000, 2000)
 
 
 def test_block_sums_full_size_tiling_property():

@@ -23,7 +23,7 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_debug_div', 'wgbsseg_add_loci', 'wgbsseg_block_sums', 'wgbsseg_last_block_sums_ms',
            'wgbsseg_set_site_base', 'wgbsseg_stitch_regions', 'wgbsseg_group_create', 'wgbsseg_group_destroy', 'wgbsseg_group_size',
            'wgbsseg_group_plan', 'wgbsseg_group_load_host', 'wgbsseg_group_share_set_device', 'wgbsseg_group_segment_regions',
-           'wgbsseg_group_get_timings', 'wgbsseg_plan_shares']
+           'wgbsseg_group_get_timings', 'wgbsseg_plan_shares', 'wgbsseg_set_lbetas_host']
 
 
 class NativeLibraryError(RuntimeError):
@@ -110,6 +110,8 @@ def load():
     L.wgbsseg_destroy.argtypes = [vp]
     L.wgbsseg_set_betas_host.restype = i32
     L.wgbsseg_set_betas_host.argtypes = [vp, C.POINTER(vp), i64, i64, C.c_char_p, C.c_size_t]
+    L.wgbsseg_set_lbetas_host.restype = i32
+    L.wgbsseg_set_lbetas_host.argtypes = [vp, C.POINTER(vp), i64, i64, C.c_char_p, C.c_size_t]
     L.wgbsseg_set_betas_device.restype = i32
     L.wgbsseg_set_betas_device.argtypes = [vp, vp, i64, i64, i64, C.c_char_p, C.c_size_t]
     L.wgbsseg_set_loci_host.restype = i32
@@ -231,6 +233,15 @@ class Segmenter:
         assert all(a.size == n2 for a in arrs) and n2 % 2 == 0
         ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
         _check(self._L.wgbsseg_set_betas_host(self._h, ptrs, len(arrs), n2 // 2, self._err, ERRLEN), self._err)
+        self.n_sites, self.n_samples = n2 // 2, len(arrs)
+
+    def set_lbetas(self, samples):
+        """samples: list of uint16 arrays [n_sites, 2] (.lbeta files); block sums only."""
+        arrs = [np.ascontiguousarray(s, dtype=np.uint16).reshape(-1) for s in samples]
+        n2 = arrs[0].size
+        assert all(a.size == n2 for a in arrs) and n2 % 2 == 0
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        _check(self._L.wgbsseg_set_lbetas_host(self._h, ptrs, len(arrs), n2 // 2, self._err, ERRLEN), self._err)
         self.n_sites, self.n_samples = n2 // 2, len(arrs)
 
     def set_betas_device(self, data_ptr, n_samples, pitch_bytes, n_sites, keepalive=None):

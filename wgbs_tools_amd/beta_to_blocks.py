@@ -1,110 +1,177 @@
 """`wgbstools beta_to_blocks` on the GPU: collapse beta files to a blocks table.
 
-Mirror of the reference's src/python/beta_to_blocks.py — same entry points, flags, file formats and messages:
-    load_blocks_file / is_block_file_nice      beta_to_blocks.py:24-91
-    reduce_data / collapse_process             beta_to_blocks.py:101-139   -> wgbsseg_block_sums (include/wgbsseg.h)
-    dump (.bin / .lbeta / .bedGraph)           beta_to_blocks.py:149-165, utils_wgbs.py:277-290 trim_to_uint8
-The reduction itself — per block, the sums of (#meth, #cov) over its CpGs, for every sample — runs in one kernel launch
-over all the given beta files at once instead of one numpy pass per file in a process pool.  No CPU fallback.
+Drop-in for the reference's src/python/beta_to_blocks.py: same flags, file formats (.bin / .lbeta / .bedGraph), messages
+and entry-point names (load_blocks_file, is_block_file_nice, reduce_data, collapse_process, dump, main), written against
+the FORMATS rather than the reference's pandas code:
+
+    blocks table   tab-separated text, >= 5 columns chr, start, end, startCpG, endCpG (+ optional anno, gene), optional
+                   header line, '#' comment lines, 'NA'/empty CpG fields allowed          (beta_to_blocks.py:52-91)
+    nice table     no NA, no empty block, both CpG columns ascending, no duplicate rows, no overlaps   (:24-49)
+    reduction      per block the sums of (#meth, #cov) over sites [startCpG-1, endCpG-1); NA rows -> (0, 0)   (:101-126)
+    .bin / .lbeta  the sums as uint8 / uint16 pairs; a row whose coverage exceeds the type's maximum M becomes
+                   (trunc(meth / cov * M), M)                                             (utils_wgbs.py:277-290)
+    .bedGraph      chr, start, end, beta = meth/cov of the TRIMMED row (%.2f, -1 when cov == 0), coverage   (:160-165)
+
+The reduction runs in ONE kernel launch over all the given beta files (wgbsseg_block_sums, include/wgbsseg.h) instead of
+one numpy pass per file in a process pool; input files may be uint8 `.beta` / `.bin` or uint16 `.lbeta`
+(utils_wgbs.py:311-319).  No CPU fallback.
 """
 import argparse
 import os.path as op
 import sys
 
 import numpy as np
-import pandas as pd
 
 from .genome import IllegalArgumentError, eprint
 
 COORDS_COLS5 = ['chr', 'start', 'end', 'startCpG', 'endCpG']
+NA_TOKENS = ('', 'NA', 'NaN', 'nan', 'N/A', 'NULL', 'null', '<NA>', 'n/a', '#N/A', 'None')
 
 
 def b2b_log(*args, **kwargs):
     print('[ wt beta_to_blocks ]', *args, file=sys.stderr, **kwargs)
 
 
-def is_block_file_nice(df):
-    """beta_to_blocks.py:24-49: (True, '') when the table has no NAs or empty blocks, is sorted, has no duplicates and no
-    overlaps; else (False, the first reason in the reference's order)."""
-    msg = ''
-    if df[['startCpG', 'endCpG']].isna().values.sum() > 0:
-        msg = 'Some blocks are empty (NA)'
-    elif not (df['endCpG'] - df['startCpG'] > 0).all():
-        msg = 'Some blocks are empty (startCpG==endCpG)'
-    elif not np.all(np.diff(df['startCpG'].values) >= 0):
-        msg = 'startCpG is not monotonically increasing'
-    elif not np.all(np.diff(df['endCpG'].values) >= 0):
-        msg = 'endCpG is not monotonically increasing'
-    elif df.shape[0] != df.drop_duplicates().shape[0]:
-        msg = 'Some blocks are duplicated'
-    elif not (df['startCpG'][1:].values - df['endCpG'][:df.shape[0] - 1].values >= 0).all():
-        msg = 'Some blocks overlap'
-    return (False, msg) if msg else (True, '')
+class BlocksTable:
+    """A blocks table in memory, column-wise.  `chr`, `start`, `end`: the file's own text (they are only ever written back);
+    `startCpG`, `endCpG`: int64 with `na` marking rows whose CpG fields are missing; `extra`: {'anno': [...], 'gene': [...]}."""
+
+    def __init__(self, chrom, start, end, start_cpg, end_cpg, na, extra=None):
+        self.chr, self.start, self.end = list(chrom), list(start), list(end)
+        self.startCpG = np.asarray(start_cpg, dtype=np.int64)
+        self.endCpG = np.asarray(end_cpg, dtype=np.int64)
+        self.na = np.asarray(na, dtype=bool)
+        self.extra = dict(extra or {})
+
+    @property
+    def columns(self):
+        return COORDS_COLS5 + list(self.extra)
+
+    @property
+    def shape(self):
+        return (len(self.chr), len(self.columns))
+
+    def __len__(self):
+        return len(self.chr)
+
+    def rows(self, a, b):
+        """rows [a, b) as a new table (beta_to_table walks the table in chunks)"""
+        return BlocksTable(self.chr[a:b], self.start[a:b], self.end[a:b], self.startCpG[a:b], self.endCpG[a:b], self.na[a:b],
+                           {k: v[a:b] for k, v in self.extra.items()})
+
+    def copy(self):
+        return self.rows(0, len(self))
+
+    def cpg_text(self):
+        """the two CpG columns as they print: integers, NA where missing"""
+        s = ['NA' if n else str(v) for v, n in zip(self.startCpG.tolist(), self.na.tolist())]
+        e = ['NA' if n else str(v) for v, n in zip(self.endCpG.tolist(), self.na.tolist())]
+        return s, e
+
+
+def _opener(path):
+    if path.endswith('.gz'):
+        import gzip
+        return gzip.open(path, 'rt')
+    return open(path, 'r')
 
 
 def load_blocks_file(blocks_path, anno=False, nrows=None):
-    """beta_to_blocks.py:52-91: 5-column (optionally 7 with anno, gene) tab-separated table, header line optional,
-    '#' comments skipped, NA allowed in the CpG columns; empty DataFrame on parser errors."""
+    """Parse a blocks table (format above).  Fewer than 5 columns, or endCpG < startCpG in a complete row, are errors;
+    a file without any row gives an empty table (after the reference's 'Empty blocks file.' note)."""
     if not op.isfile(blocks_path):
         raise IllegalArgumentError(f'Invalid file: {blocks_path}')
-    try:
-        peek_df = pd.read_csv(blocks_path, sep='\t', nrows=1, header=None, comment='#')
-        header = None if str(peek_df.iloc[0, 1]).isdigit() else 0
-        names = COORDS_COLS5.copy()
-        if anno:
-            names += ['anno', 'gene']
-        if len(peek_df.columns) < len(COORDS_COLS5):
-            msg = f'Invalid blocks file: {blocks_path}. less than {len(names)} columns.\n'
-            msg += f'Run wgbstools convert -L {blocks_path} -o OUTPUT_REGION_FILE to add the CpG columns'
-            raise IllegalArgumentError(msg)
-        elif len(peek_df.columns) < len(names):
-            names = COORDS_COLS5
-        dtypes = {'startCpG': 'Int64', 'endCpG': 'Int64'}
-        df = pd.read_csv(blocks_path, sep='\t', usecols=range(len(names)), dtype=dtypes, header=header, names=names,
-                         nrows=nrows, comment='#')
-        dfnona = df.dropna()
-        if not ((dfnona['endCpG'] - dfnona['startCpG']) >= 0).all():
-            raise IllegalArgumentError(f'Invalid CpG columns in blocks file {blocks_path}')
-        if dfnona.shape[0] == df.shape[0]:
-            df['startCpG'] = df['startCpG'].astype(int)
-            df['endCpG'] = df['endCpG'].astype(int)
-    except pd.errors.ParserError as e:
-        eprint(f'Invalid input file.\n{e}')
-        return pd.DataFrame()
-    except pd.errors.EmptyDataError as e:
-        eprint(f'Empty blocks file.\n{e}')
-        return pd.DataFrame()
-    return df
+    want = 7 if anno else 5
+    chrom, start, end, scpg, ecpg, na = [], [], [], [], [], []
+    extra = None
+    first = True
+    with _opener(blocks_path) as f:
+        for line in f:
+            if line.startswith('#') or not line.strip():
+                continue
+            tok = line.rstrip('\n').rstrip('\r').split('\t')
+            if first:
+                first = False
+                if len(tok) < 5:
+                    msg = f'Invalid blocks file: {blocks_path}. less than {want} columns.\n'
+                    msg += f'Run wgbstools convert -L {blocks_path} -o OUTPUT_REGION_FILE to add the CpG columns'
+                    raise IllegalArgumentError(msg)
+                if anno and len(tok) >= 7:
+                    extra = {'anno': [], 'gene': []}
+                if not tok[1].isdigit():                         # a header line: the second field of a data row is a position
+                    continue
+            if len(tok) < 5:
+                eprint(f'Invalid input file.\nrow with {len(tok)} fields: {line.strip()[:80]}')
+                return BlocksTable([], [], [], [], [], [])
+            chrom.append(tok[0]); start.append(tok[1]); end.append(tok[2])
+            miss = tok[3] in NA_TOKENS or tok[4] in NA_TOKENS
+            na.append(miss)
+            scpg.append(0 if miss else int(float(tok[3])))
+            ecpg.append(0 if miss else int(float(tok[4])))
+            if extra is not None:
+                extra['anno'].append(tok[5] if len(tok) > 5 else '')
+                extra['gene'].append(tok[6] if len(tok) > 6 else '')
+            if nrows is not None and len(chrom) >= nrows:
+                break
+    if not chrom:
+        eprint('Empty blocks file.\nNo columns to parse from file')
+        return BlocksTable([], [], [], [], [], [])
+    t = BlocksTable(chrom, start, end, scpg, ecpg, na, extra)
+    ok = ~t.na
+    if (t.endCpG[ok] < t.startCpG[ok]).any():
+        raise IllegalArgumentError(f'Invalid CpG columns in blocks file {blocks_path}')
+    return t
 
 
-def block_site_ranges(df):
-    """0-based half-open site ranges of the table's rows: [startCpG-1, endCpG-1); NA rows -> empty range (sum 0, 0:
-    what the reference's slow_method writes for them, beta_to_blocks.py:112-114)."""
-    s = pd.to_numeric(df['startCpG'], errors='coerce').astype('float64').values
-    e = pd.to_numeric(df['endCpG'], errors='coerce').astype('float64').values
-    na = np.isnan(s) | np.isnan(e)
-    s0 = np.where(na, 0, s - 1).astype(np.int64)
-    e0 = np.where(na, 0, e - 1).astype(np.int64)
+def is_block_file_nice(t):
+    """(True, '') for a nice table (definition above), else (False, reason): the first failing rule in the reference's
+    order of checks (beta_to_blocks.py:24-49)."""
+    n = len(t)
+    s, e = t.startCpG, t.endCpG
+    if t.na.any():
+        return False, 'Some blocks are empty (NA)'
+    if (e <= s).any():
+        return False, 'Some blocks are empty (startCpG==endCpG)'
+    if n > 1 and (s[1:] < s[:-1]).any():
+        return False, 'startCpG is not monotonically increasing'
+    if n > 1 and (e[1:] < e[:-1]).any():
+        return False, 'endCpG is not monotonically increasing'
+    cols = [t.chr, t.start, t.end, s.tolist(), e.tolist()] + [t.extra[k] for k in t.extra]
+    if len(set(zip(*cols))) != n:
+        return False, 'Some blocks are duplicated'
+    if n > 1 and (s[1:] < e[:-1]).any():
+        return False, 'Some blocks overlap'
+    return True, ''
+
+
+def block_site_ranges(t):
+    """0-based half-open site ranges of the rows: [startCpG-1, endCpG-1); NA rows -> the empty range (sums 0, 0)."""
+    s0 = np.where(t.na, 0, t.startCpG - 1).astype(np.int64)
+    e0 = np.where(t.na, 0, t.endCpG - 1).astype(np.int64)
     return s0, e0
 
 
 class BlockSumEngine:
-    """The given beta files resident on one GPU (uint8 .beta / .bin rows; .lbeta is not read by this library)."""
+    """The given beta files resident on one GPU: uint8 `.beta` / `.bin`, or uint16 `.lbeta` (not mixed)."""
 
     def __init__(self, beta_paths, device=0):
         from . import _lib                     # raises NativeLibraryError if libwgbsseg.so is not built
+        suffs = {op.splitext(b)[1] for b in beta_paths}
         for b in beta_paths:
-            if not (op.isfile(b) and op.splitext(b)[1] in ('.beta', '.bin')):
+            if not (op.isfile(b) and op.splitext(b)[1] in ('.beta', '.lbeta', '.bin')):
                 raise IllegalArgumentError(f'Invalid beta file:\n{b}')
+        wide = '.lbeta' in suffs
+        if wide and len(suffs) > 1:
+            raise IllegalArgumentError('uint16 (.lbeta) and uint8 (.beta / .bin) files cannot be reduced together')
         self._seg = _lib.Segmenter(device)
-        maps = [np.memmap(b, dtype=np.uint8, mode='r') for b in beta_paths]
+        maps = [np.memmap(b, dtype=np.uint16 if wide else np.uint8, mode='r') for b in beta_paths]
         if len({m.size for m in maps}) != 1:
             raise IllegalArgumentError('beta files of different sizes')
         self.nr_sites = maps[0].size // 2
-        self._seg.set_betas(maps)
+        (self._seg.set_lbetas if wide else self._seg.set_betas)(maps)
 
-    def reduce(self, df, mode=0, min_cov=1):
-        s0, e0 = block_site_ranges(df)
+    def reduce(self, t, mode=0, min_cov=1):
+        s0, e0 = block_site_ranges(t)
         if s0.size and (e0.max() > self.nr_sites):
             raise IllegalArgumentError('blocks table reaches beyond the beta file')
         return self._seg.block_sums(s0, e0, mode=mode, min_cov=min_cov)
@@ -117,55 +184,56 @@ class BlockSumEngine:
 
 
 def reduce_data(beta_path, df, is_nice=None, engine=None):
-    """beta_to_blocks.py:119-126: int array [n_blocks, 2] of (#meth, #cov) sums of one beta file."""
-    own = engine is None
-    eng = BlockSumEngine([beta_path]) if own else engine
+    """int64 array [n_blocks, 2] of the (#meth, #cov) sums of one beta file (beta_to_blocks.py:119-126)."""
+    eng = engine or BlockSumEngine([beta_path])
     try:
-        return eng.reduce(df.reset_index(drop=True), mode=0)[0].astype(np.int64)
+        return eng.reduce(df, mode=0)[0].astype(np.int64)
     finally:
-        if own:
+        if engine is None:
             eng.close()
 
 
 def trim_to_uint8(data, lbeta=False):
-    """utils_wgbs.py:277-290 (host form, for callers that hold the sums): rows with cov > max become
-    (trunc(meth / cov * max), max).  The device applies the same rule in modes 1 / 2 of wgbsseg_block_sums."""
-    max_val = 65535 if lbeta else 255
-    data = np.array(data, dtype=np.int64)
-    big = data[:, 1] > max_val
-    data[big, 0] = (data[big, 0] / data[big, 1] * max_val).astype(np.int64)
-    data[big, 1] = max_val
-    return data.astype(np.uint16 if lbeta else np.uint8)
+    """Host form of the .bin / .lbeta row rule (format above) for callers that hold the sums; the device applies the same
+    rule in modes 1 / 2 of wgbsseg_block_sums."""
+    top = 65535 if lbeta else 255
+    t = np.array(data, dtype=np.int64)
+    over = t[:, 1] > top
+    t[over, 0] = (t[over, 0] / t[over, 1] * top).astype(np.int64)
+    t[over, 1] = top
+    return t.astype(np.uint16 if lbeta else np.uint8)
+
+
+def write_bedgraph(path, t, bin_table):
+    """chr, start, end, beta (%.2f; -1 for 0/0), coverage — from the trimmed rows, like the reference's in-place trim."""
+    meth = bin_table[:, 0].astype(np.int64)
+    cov = bin_table[:, 1].astype(np.int64)
+    with open(path, 'w') as f:
+        for c, s, e, m, v in zip(t.chr, t.start, t.end, meth.tolist(), cov.tolist()):
+            beta = '%.2f' % (m / v) if v else '-1'               # 0/0 is the table's missing value: -1
+            f.write(f'{c}\t{s}\t{e}\t{beta}\t{v}\n')
 
 
 def dump(df, bin_table, beta_path, lbeta, out_dir, bedGraph):
-    """beta_to_blocks.py:149-165; bin_table = the trimmed table of this beta (what the reference's in-place
-    trim_to_uint8 leaves in reduced_data before the bedGraph is computed from it)."""
-    name = op.splitext(op.basename(beta_path))[0]
-    suff = '.lbeta' if lbeta else '.bin'
-    prefix = op.join(out_dir, name)
-    bin_table.tofile(prefix + suff)
-    b2b_log(prefix + suff)
+    """Write <out_dir>/<beta name>.bin|.lbeta (and .bedGraph) for one beta file; bin_table = its trimmed table."""
+    stem = op.join(out_dir, op.splitext(op.basename(beta_path))[0])
+    target = stem + ('.lbeta' if lbeta else '.bin')
+    np.ascontiguousarray(bin_table).tofile(target)
+    b2b_log(target)
     if bedGraph:
-        df = df.copy()
-        with np.errstate(divide='ignore', invalid='ignore'):
-            df['beta'] = bin_table[:, 0].astype(np.int64) / bin_table[:, 1].astype(np.int64)
-        df['coverage'] = bin_table[:, 1].astype(np.int64)
-        df[['chr', 'start', 'end', 'beta', 'coverage']].to_csv(prefix + '.bedGraph', sep='\t', index=None, header=None,
-                                                             na_rep=-1, float_format='%.2f')
+        write_bedgraph(stem + '.bedGraph', df, bin_table)
 
 
 def collapse_process(beta_path, df, is_nice=None, lbeta=False, out_dir=None, bedGraph=False, engine=None):
-    """beta_to_blocks.py:129-139 for one beta file."""
+    """One beta file: the sums (out_dir None) or its output files; failures are logged, not raised (beta_to_blocks.py:129-139)."""
     try:
         if out_dir is None:
             return reduce_data(beta_path, df, is_nice, engine)
-        own = engine is None
-        eng = BlockSumEngine([beta_path]) if own else engine
+        eng = engine or BlockSumEngine([beta_path])
         try:
-            table = eng.reduce(df.reset_index(drop=True), mode=2 if lbeta else 1)[0]
+            table = eng.reduce(df, mode=2 if lbeta else 1)[0]
         finally:
-            if own:
+            if engine is None:
                 eng.close()
         return dump(df, table, beta_path, lbeta, out_dir, bedGraph)
     except Exception as e:
@@ -173,18 +241,21 @@ def collapse_process(beta_path, df, is_nice=None, lbeta=False, out_dir=None, bed
         b2b_log('Exception:', e)
 
 
+def output_stem(beta, out_dir):
+    base = op.basename(beta)
+    if base.endswith('.gz'):
+        base = base[:-3]
+    return op.join(out_dir, op.splitext(base)[0])
+
+
 def filter_existing_files(files, out_dir, lbeta):
-    files_to_process = []
+    """the input files whose output does not exist yet; the others are named on stderr"""
     suff = '.lbeta' if lbeta else '.bin'
-    for beta in files:
-        base = op.basename(beta)
-        stem = base[:-3] if base.endswith('.gz') else base
-        prefix = op.join(out_dir, op.splitext(stem)[0])
-        if not op.isfile(prefix + suff):
-            files_to_process.append(beta)
-        else:
-            b2b_log(f'Skipping {beta}. Use -f flag to overwrite')
-    return files_to_process
+    todo = [b for b in files if not op.isfile(output_stem(b, out_dir) + suff)]
+    for b in files:
+        if b not in todo:
+            b2b_log(f'Skipping {b}. Use -f flag to overwrite')
+    return todo
 
 
 def parse_args(argv=None):
@@ -206,27 +277,25 @@ def main(argv=None):
     Collapse beta file to blocks binary file, of the same beta format
     """
     args = parse_args(argv)
-    files = args.input_files
-    for f in files:
-        if not op.isfile(f):
-            raise IllegalArgumentError(f'Invalid file: {f}')
+    missing = [f for f in args.input_files if not op.isfile(f)]
+    if missing:
+        raise IllegalArgumentError(f'Invalid file: {missing[0]}')
     if not op.isdir(args.out_dir):
         raise IllegalArgumentError(f'Invalid output dir: {args.out_dir}')
-    if not args.force:
-        files = filter_existing_files(files, args.out_dir, args.lbeta)
-    df = load_blocks_file(args.blocks_file)
-    is_nice, msg = is_block_file_nice(df)
-    if not is_nice:
-        b2b_log(msg)
+    files = args.input_files if args.force else filter_existing_files(args.input_files, args.out_dir, args.lbeta)
+    table = load_blocks_file(args.blocks_file)
+    nice, why = is_block_file_nice(table)
+    if not nice:
+        b2b_log(why)
     if not files:
         return
     eng = BlockSumEngine(files, device=args.device)
     try:
-        tables = eng.reduce(df.reset_index(drop=True), mode=2 if args.lbeta else 1)
+        rows = eng.reduce(table, mode=2 if args.lbeta else 1)
     finally:
         eng.close()
-    for beta, table in zip(files, tables):
-        dump(df, table, beta, args.lbeta, args.out_dir, args.bedGraph)
+    for beta, tbl in zip(files, rows):
+        dump(table, tbl, beta, args.lbeta, args.out_dir, args.bedGraph)
 
 
 if __name__ == '__main__':

@@ -1,27 +1,31 @@
-"""`wgbstools beta_to_table` on the GPU: a text table of per-block average methylation per sample or group.
+"""`wgbstools beta_to_table` on the GPU: a text table of per-block average methylation per sample or per group.
 
-Mirror of the reference's src/python/beta_to_table.py (flags, table layout, NA / rounding rules):
-    groups_load_wrap / load_gfile_helper        beta_to_table.py:39-57, dmb.py:24-38
-    get_table                                   beta_to_table.py:73-106: block sums -> beta2vec -> nanmean per group
-    dump                                        beta_to_table.py:116-128
-The block sums and the meth/cov ratios (NaN below --min_cov, utils_wgbs.py:270-274) of ALL beta files come from one
-wgbsseg_block_sums call per chunk of blocks (mode 3); grouping and text formatting stay on the host.
+Drop-in for the reference's src/python/beta_to_table.py (flags, table layout, NA and rounding rules), written against the
+formats:
+
+    groups file    csv with a header; first column = file name prefix, a column named `group`, optional boolean column
+                   `include`; '#' comment lines; rows with an empty name or group are ignored            (dmb.py:24-38)
+    table          the blocks table's columns, then one column per sample (no groups file) or per group: the mean over the
+                   group's samples of meth/cov per block, samples with coverage < --min_cov counting as missing; missing
+                   values print as NA, floats with --digits decimals; header line once                  (beta_to_table.py:73-128)
+
+The block sums and the meth/cov ratios of ALL beta files come from one wgbsseg_block_sums call per chunk of blocks
+(mode 3: ratios as float64, NaN below min_cov — utils_wgbs.py:270-274); grouping and text formatting stay on the host.
 """
 import argparse
+import csv
 import os.path as op
 import sys
 import warnings
 
 import numpy as np
-import pandas as pd
 
 from .beta_to_blocks import BlockSumEngine, load_blocks_file
 from .genome import IllegalArgumentError, eprint
 
 
 def drop_dup_keep_order(lst):
-    seen = set()
-    return [x for x in lst if not (x in seen or seen.add(x))]
+    return list(dict.fromkeys(lst))
 
 
 def pretty_name(fpath):
@@ -31,35 +35,55 @@ def pretty_name(fpath):
     return op.splitext(base)[0]
 
 
+class Groups:
+    """fname[i] belongs to group[i] and lives in full_path[i]."""
+
+    def __init__(self, fname, group, full_path=None):
+        self.fname, self.group, self.full_path = list(fname), list(group), list(full_path or [])
+
+    def __getitem__(self, key):                                    # gf['fname'] / gf['group'] / gf['full_path']
+        return getattr(self, key)
+
+
 def load_gfile_helper(groups_file):
-    """dmb.py:24-38"""
-    gf = pd.read_csv(groups_file, index_col=False, comment='#')
-    if 'group' not in gf.columns:
+    """Parse a groups file (format above) -> Groups without paths."""
+    with open(groups_file, newline='') as f:
+        rows = [r for r in csv.reader(line for line in f if not line.startswith('#')) if r]
+    if not rows:
         raise IllegalArgumentError('gropus file must have a column named "group"')
-    if 'include' in gf.columns:
-        if gf['include'].dtype != bool:
+    header, body = [h.strip() for h in rows[0]], rows[1:]
+    if 'group' not in header:
+        raise IllegalArgumentError('gropus file must have a column named "group"')
+    gi = header.index('group')
+    keep = [True] * len(body)
+    if 'include' in header:
+        ii = header.index('include')
+        vals = [(r[ii].strip() if ii < len(r) else '') for r in body]
+        if any(v.lower() not in ('true', 'false') for v in vals):
             eprint('Invalid group file')
             raise IllegalArgumentError('Invalid group file. Include column must be boolean')
-        gf = gf[gf['include']]
-    gf = gf.rename(columns={gf.columns[0]: 'fname'})
-    return gf[['fname', 'group']].dropna().reset_index(drop=True)
+        keep = [v.lower() == 'true' for v in vals]
+    fname, group = [], []
+    for r, k in zip(body, keep):
+        name = r[0].strip() if r else ''
+        grp = r[gi].strip() if gi < len(r) else ''
+        if k and name and grp:
+            fname.append(name); group.append(grp)
+    return Groups(fname, group)
 
 
 def match_prefix_to_bin(prefixes, bins, suff):
-    """dmb.py:41-79 (exact-name form): the path of `prefix + suff` among `bins`, for every prefix."""
-    full_paths, missing = [], []
-    for prefix in prefixes:
-        results = [f for f in bins if op.basename(f) == prefix + suff]
-        if not results:
-            missing.append(prefix)
-        else:
-            full_paths.append(results[0])
+    """the path among `bins` whose file name is prefix + suff, for every prefix; all missing ones are reported together"""
+    by_name = {}
+    for f in bins:
+        by_name.setdefault(op.basename(f), f)
+    missing = [p for p in prefixes if p + suff not in by_name]
     if missing:
         eprint(f'Error: {len(missing)} prefixes from groups file were not found in input bins:')
         for p in missing:
             eprint(p)
         raise IllegalArgumentError('groups file mismatch binary files')
-    return full_paths
+    return [by_name[p + suff] for p in prefixes]
 
 
 def groups_load_wrap(groups_file, betas):
@@ -67,40 +91,51 @@ def groups_load_wrap(groups_file, betas):
         if not op.isfile(groups_file):
             raise IllegalArgumentError(f'Invalid file: {groups_file}')
         gf = load_gfile_helper(groups_file)
-    else:
+    else:                                                          # every file its own group, named after the file
         betas = drop_dup_keep_order(list(betas))
-        fnames = [pretty_name(b) for b in betas]
-        gf = pd.DataFrame(columns=['fname'], data=fnames)
-        gf['group'] = gf['fname']
+        names = [pretty_name(b) for b in betas]
+        gf = Groups(names, names)
     suff = '.lbeta' if betas[0].endswith('.lbeta') else '.beta'
-    gf['full_path'] = match_prefix_to_bin(gf['fname'], betas, suff)
+    gf.full_path = match_prefix_to_bin(gf.fname, betas, suff)
     return gf
 
 
+class Table:
+    """blocks + value columns, ready to print"""
+
+    def __init__(self, blocks, names, values):
+        self.blocks, self.names, self.values = blocks, list(names), values       # values: float64 [n_blocks][len(names)]
+
+    @property
+    def shape(self):
+        return (len(self.blocks), self.blocks.shape[1] + len(self.names))
+
+
 def get_table(blocks_df, gf, min_cov, threads=8, verbose=False, group=True, engine=None):
-    """beta_to_table.py:73-106 for one chunk of blocks."""
+    """One chunk of blocks -> Table (per sample when group is False, else per group: nanmean over the group's samples)."""
     if verbose:
-        eprint(f'[wt table] reducing to {blocks_df.shape[0]:,} blocks')
-    betas = drop_dup_keep_order(gf['full_path'])
-    own = engine is None
-    eng = BlockSumEngine(betas) if own else engine
+        eprint(f'[wt table] reducing to {len(blocks_df):,} blocks')
+    betas = drop_dup_keep_order(gf.full_path)
+    eng = engine or BlockSumEngine(betas)
     try:
-        vecs = eng.reduce(blocks_df.reset_index(drop=True), mode=3, min_cov=min_cov)          # [n_betas][n_blocks]
+        vecs = eng.reduce(blocks_df, mode=3, min_cov=min_cov)                     # [n_betas][n_blocks] float64
     finally:
-        if own:
+        if engine is None:
             eng.close()
-    dres = {pretty_name(b): vecs[i] for i, b in enumerate(betas)}
-    blocks_df = blocks_df.reset_index(drop=True)
+    by_name = {pretty_name(b): vecs[i] for i, b in enumerate(betas)}
     if not group:
-        return pd.concat([blocks_df, pd.DataFrame(dres)[gf['fname'].tolist()]], axis=1)
-    ugroups = drop_dup_keep_order(gf['group'])
-    with warnings.catch_warnings():
-        warnings.filterwarnings('ignore', category=RuntimeWarning)
-        cols = {}
-        for ugroup in ugroups:
-            members = gf['fname'][gf['group'] == ugroup]
-            cols[ugroup] = np.nanmean(np.concatenate([dres[k][None, :] for k in members]), axis=0).T
-    return pd.concat([blocks_df, pd.DataFrame(cols, index=blocks_df.index)[ugroups]], axis=1)
+        names = list(gf.fname)
+        cols = [by_name[k] for k in names]
+    else:
+        names = drop_dup_keep_order(gf.group)
+        cols = []
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore', category=RuntimeWarning)             # all-NaN rows: the mean is NaN, printed NA
+            for g in names:
+                members = [f for f, gg in zip(gf.fname, gf.group) if gg == g]
+                cols.append(np.nanmean(np.stack([by_name[k] for k in members]), axis=0))
+    vals = np.stack(cols, axis=1) if cols else np.zeros((len(blocks_df), 0))
+    return Table(blocks_df, names, vals)
 
 
 def betas2table(betas, blocks, groups_file, min_cov, threads=8, verbose=False):
@@ -108,25 +143,40 @@ def betas2table(betas, blocks, groups_file, min_cov, threads=8, verbose=False):
     return get_table(load_blocks_file(blocks), gf, min_cov, threads, verbose)
 
 
-def dump(outpath, df, first=True, digits=3):
-    """beta_to_table.py:116-128"""
-    if outpath is None:
-        outpath = sys.stdout
-    df.to_csv(outpath, na_rep='NA', float_format=f'%.{digits}f', index=None, sep='\t',
-              mode='w' if first else 'a', header=True if first else None)
+def dump(outpath, table, first=True, digits=3):
+    """Append (or start, with the header) the text of a Table: tab-separated, NA for missing, %.<digits>f floats."""
+    own = not hasattr(outpath, 'write') and outpath is not None
+    f = open(outpath, 'w' if first else 'a') if own else (sys.stdout if outpath is None else outpath)
+    try:
+        b = table.blocks
+        if first:
+            f.write('\t'.join(b.columns + table.names) + '\n')
+        s_txt, e_txt = b.cpg_text()
+        fmt = '%%.%df' % digits
+        extra = [b.extra[k] for k in b.extra]
+        vals = table.values
+        lines = []
+        for i in range(len(b)):
+            row = [b.chr[i], b.start[i], b.end[i], s_txt[i], e_txt[i]] + [x[i] for x in extra]
+            row += ['NA' if v != v else fmt % v for v in vals[i].tolist()]
+            lines.append('\t'.join(row))
+        if lines:
+            f.write('\n'.join(lines) + '\n')
+    finally:
+        if own:
+            f.close()
 
 
 def beta2table_generator(betas, blocks, groups_file, min_cov, threads, chunk_size=None, verbose=False, device=0):
     if not op.isfile(blocks):
         raise IllegalArgumentError(f'Invalid file: {blocks}')
     gf = groups_load_wrap(groups_file, betas)
-    blocks_df = load_blocks_file(blocks)
-    if chunk_size is None:
-        chunk_size = blocks_df.shape[0]
-    eng = BlockSumEngine(drop_dup_keep_order(gf['full_path']), device=device)    # the files go to the device once
+    table = load_blocks_file(blocks)
+    step = chunk_size or max(1, len(table))
+    eng = BlockSumEngine(drop_dup_keep_order(gf.full_path), device=device)        # the files go to the device once
     try:
-        for start in range(0, blocks_df.shape[0], chunk_size):
-            yield get_table(blocks_df.iloc[start:start + chunk_size].copy(), gf, min_cov, threads, verbose, engine=eng)
+        for a in range(0, len(table), step):
+            yield get_table(table.rows(a, a + step), gf, min_cov, threads, verbose, engine=eng)
     finally:
         eng.close()
 
@@ -152,11 +202,11 @@ def main(argv=None):
     Optionally collapse samples with groups file
     """
     args = parse_args(argv)
-    first_chunk = True
+    first = True
     for chunk in beta2table_generator(args.betas, args.blocks, args.groups_file, args.min_cov, args.threads,
                                       args.chunk_size, args.verbose, args.device):
-        dump(args.output, chunk, first_chunk, args.digits)
-        first_chunk = False
+        dump(args.output, chunk, first, args.digits)
+        first = False
 
 
 if __name__ == '__main__':

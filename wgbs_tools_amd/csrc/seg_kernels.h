@@ -1448,56 +1448,47 @@ __global__ __launch_bounds__(WG_BLOCK) void k_gather_borders(JobView J, const in
 //   mode 1  uint8  pairs (.bin):   utils_wgbs.py:277-290 trim_to_uint8: cov > 255   -> meth = trunc(meth / cov * 255), cov = 255
 //   mode 2  uint16 pairs (.lbeta): the same with 65535
 //   mode 3  double meth/cov, NaN where cov < min_cov (utils_wgbs.py:270-274 beta2vec)
-// One thread per (block, sample): the block's bytes in 16-byte vectors, SWAR sums, edges masked by site index.
-// HBM-bound: a blocks table that tiles the genome reads every beta byte once (2 N n bytes).
+// HBM-bound: a blocks table that tiles the genome reads every beta byte once (2 N n bytes; 4 N n for uint16 .lbeta input).
+//
+// The blocks arrive SORTED by their first site (the host sorts when the table is not; `perm` then names the row a block
+// came from).  One workgroup takes one tile of WG_BS_TILE consecutive sites and 4 x spw samples: every wavefront streams
+// its sample's bytes of the tile ONCE with 16-byte loads (coalesced: 1 KB per wave instruction), leaves the tile's
+// exclusive prefix sums of (meth, cov) in its own LDS row (two DPP scans per 512 sites), and then every lane takes blocks
+// that START in the tile: a block inside the tile is one subtraction of two LDS entries; the part of a block beyond
+// the tile's end (a few per cent of the blocks of a segmentation) is summed from memory by the lane.  No byte is fetched
+// twice for a table that tiles the genome, whatever the block lengths; a thread per block (the first version of this
+// kernel) fetched 2-3 aligned vectors per 20-byte block.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restrict__ betas, int64_t pitch, int64_t n_total,
-                                                         const int64_t* __restrict__ x0s, const int64_t* __restrict__ x1s, int64_t n_blocks,
-                                                         int mode, uint32_t min_cov, void* __restrict__ out)
+#define WG_BS_TILE 1024
+
+// sums of sites [a, b) of one sample row straight from memory (tails of blocks that leave their tile): 16-byte vectors
+template <int ELEM>
+__device__ __forceinline__ void wg_direct_sum(const uint8_t* __restrict__ row, int64_t a, int64_t b, int64_t n_total, uint64_t& m, uint64_t& c)
 {
-    const int64_t b = (int64_t)blockIdx.x * WG_BLOCK + threadIdx.x;
-    const int s = blockIdx.y;
-    if (b >= n_blocks) return;
-    const int64_t x0 = x0s[b], x1 = x1s[b];
-    const uint8_t* row = betas + (int64_t)s * pitch;
-    uint64_t m = 0, c = 0;
-    if (x1 > x0) {
-        uint32_t sm = 0, sc = 0;
-        int pend = 0;
-        // 8 sites = one 16-byte vector, aligned in the row; the first four vectors of a block (all of a typical block)
-        // are requested before any is used
-        auto fold = [&](const uint4 v, const int64_t site) {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            const bool inner = site >= x0 && site + 8 <= x1;
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                uint32_t x = w[d];
-                if (!inner) {
-                    const int64_t a = site + 2 * d;
-                    const uint32_t k0 = (a >= x0 && a < x1) ? 0x0000ffffu : 0u;
-                    const uint32_t k1 = (a + 1 >= x0 && a + 1 < x1) ? 0xffff0000u : 0u;
-                    x &= k0 | k1;
-                }
-                sm += x & 0x00ff00ffu;
-                sc += (x >> 8) & 0x00ff00ffu;
-            }
-        };
-        const int64_t s0 = x0 & ~7LL;
-        uint4 v4[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) v4[q] = (s0 + 8 * q < x1) ? wg_load16_guarded(row, s0 + 8 * q, n_total) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; q++) if (s0 + 8 * q < x1) fold(v4[q], s0 + 8 * q);
-        for (int64_t site = s0 + 32; site < x1; site += 8) {
-            fold(wg_load16_guarded(row, site, n_total), site);
-            if (++pend == 28) {                                           // 16-bit lanes hold 128 x 255 at most (4 + 28 vectors)
-                m += (sm & 0xffffu) + (sm >> 16); c += (sc & 0xffffu) + (sc >> 16);
-                sm = 0; sc = 0; pend = 0;
+    constexpr int SPV = ELEM == 1 ? 8 : 4;                         // sites per 16-byte vector
+    for (int64_t v0 = a & ~(int64_t)(SPV - 1); v0 < b; v0 += SPV) {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (v0 + SPV <= n_total) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row + (size_t)v0 * 2 * ELEM);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        } else {
+            for (int j = 0; j < SPV; j++) if (v0 + j < n_total) {
+                if (ELEM == 1) w[j >> 1] |= ((uint32_t)row[2 * (v0 + j)] | ((uint32_t)row[2 * (v0 + j) + 1] << 8)) << (16 * (j & 1));
+                else w[j] = (uint32_t)reinterpret_cast<const uint16_t*>(row)[2 * (v0 + j)] | ((uint32_t)reinterpret_cast<const uint16_t*>(row)[2 * (v0 + j) + 1] << 16);
             }
         }
-        m += (sm & 0xffffu) + (sm >> 16); c += (sc & 0xffffu) + (sc >> 16);
+#pragma unroll
+        for (int j = 0; j < SPV; j++) {
+            const int64_t x = v0 + j;
+            if (x < a || x >= b) continue;
+            if (ELEM == 1) { const uint32_t h = w[j >> 1] >> (16 * (j & 1)); m += h & 0xffu; c += (h >> 8) & 0xffu; }
+            else { m += w[j] & 0xffffu; c += w[j] >> 16; }
+        }
     }
-    const int64_t o = (int64_t)s * n_blocks + b;
+}
+
+__device__ __forceinline__ void wg_block_sum_store(void* __restrict__ out, int64_t o, int mode, uint32_t min_cov, uint64_t m, uint64_t c)
+{
     if (mode == 0) {
         reinterpret_cast<uint2*>(out)[o] = make_uint2((uint32_t)m, (uint32_t)c);
     } else if (mode == 1 || mode == 2) {
@@ -1507,6 +1498,83 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
         else           reinterpret_cast<ushort2*>(out)[o] = make_ushort2((unsigned short)m, (unsigned short)c);
     } else {
         reinterpret_cast<double*>(out)[o] = (c >= (uint64_t)min_cov) ? (double)m / (double)c : __builtin_nan("");
+    }
+}
+
+template <int ELEM>           // bytes per count: 1 = .beta / .bin (uint8 pairs), 2 = .lbeta (uint16 pairs)
+__global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restrict__ betas, int64_t pitch, int64_t n_total,
+                                                         const int32_t* __restrict__ x0s, const int32_t* __restrict__ x1s,
+                                                         const int32_t* __restrict__ perm, const int32_t* __restrict__ tile_first,
+                                                         int64_t n_blocks, int n_samples, int spw, int mode, uint32_t min_cov,
+                                                         void* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) uint2 E[WG_BLOCK / 64][WG_BS_TILE + 8];     // per wave: exclusive prefixes of its sample's tile
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    const int b0 = tile_first[tile], b1 = tile_first[tile + 1];
+    if (b0 == b1) return;                                          // no block starts here (the whole workgroup leaves)
+    const int64_t lo = tile * WG_BS_TILE;
+    const int64_t hi = lo + WG_BS_TILE < n_total ? lo + WG_BS_TILE : n_total;
+    const int nt = (int)(hi - lo);
+    constexpr int SPL = ELEM == 1 ? 8 : 4;                         // sites per lane and pass (16 bytes)
+    constexpr int SPP = 64 * SPL;                                  // sites per pass of the wavefront
+    uint2* Ew = E[wv];
+    for (int q = 0; q < spw; q++) {
+        const int s = ((int)blockIdx.y * (WG_BLOCK / 64) + wv) * spw + q;
+        const bool live = s < n_samples;                           // (no early exit: the barriers below are workgroup-wide)
+        const uint8_t* row = betas + (int64_t)(live ? s : 0) * pitch;
+        uint32_t run_m = 0, run_c = 0;
+        for (int base = 0; base < nt; base += SPP) {
+            const int64_t site = lo + base + (int64_t)lane * SPL;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (live && site < hi) {
+                if (site + SPL <= n_total) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(row + (size_t)site * 2 * ELEM);
+                    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+                } else {
+                    for (int j = 0; j < SPL; j++) if (site + j < n_total) {
+                        if (ELEM == 1) w[j >> 1] |= ((uint32_t)row[2 * (site + j)] | ((uint32_t)row[2 * (site + j) + 1] << 8)) << (16 * (j & 1));
+                        else w[j] = (uint32_t)reinterpret_cast<const uint16_t*>(row)[2 * (site + j)] | ((uint32_t)reinterpret_cast<const uint16_t*>(row)[2 * (site + j) + 1] << 16);
+                    }
+                }
+            }
+            uint32_t m[SPL], c[SPL], tm = 0, tc = 0;
+#pragma unroll
+            for (int j = 0; j < SPL; j++) {
+                if (ELEM == 1) { const uint32_t h = w[j >> 1] >> (16 * (j & 1)); m[j] = h & 0xffu; c[j] = (h >> 8) & 0xffu; }
+                else { m[j] = w[j] & 0xffffu; c[j] = w[j] >> 16; }
+                tm += m[j]; tc += c[j];
+            }
+            const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
+            uint32_t em = run_m + (im - tm), ec = run_c + (ic - tc);
+            uint2 e[SPL];
+#pragma unroll
+            for (int j = 0; j < SPL; j++) { e[j] = make_uint2(em, ec); em += m[j]; ec += c[j]; }
+            uint4* dst = reinterpret_cast<uint4*>(Ew + base + lane * SPL);                    // 16-byte stores, lane-contiguous
+#pragma unroll
+            for (int j = 0; j < SPL; j += 2) dst[j >> 1] = make_uint4(e[j].x, e[j].y, e[j + 1].x, e[j + 1].y);
+            run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
+            run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+        }
+        // entries past the tile's last site hold the tile total already (sites beyond `hi` were read as zeros) when the
+        // last pass covered them; make E[nt] right in every case
+        if (lane == 0) Ew[nt] = make_uint2(run_m, run_c);
+        __syncthreads();
+        if (live) {
+            for (int b = b0 + lane; b < b1; b += 64) {
+                const int64_t x0 = x0s[b], x1 = x1s[b];
+                uint64_t m = 0, c = 0;
+                if (x1 > x0) {
+                    const int64_t e = x1 < hi ? x1 : hi;
+                    const uint2 pe = Ew[e - lo], ps = Ew[x0 - lo];
+                    m = pe.x - ps.x; c = pe.y - ps.y;
+                    if (x1 > hi) wg_direct_sum<ELEM>(row, hi, x1, n_total, m, c);
+                }
+                const int64_t r = perm ? (int64_t)perm[b] : (int64_t)b;
+                wg_block_sum_store(out, (int64_t)s * n_blocks + r, mode, min_cov, m, c);
+            }
+        }
+        __syncthreads();
     }
 }
 

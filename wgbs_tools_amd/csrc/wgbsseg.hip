@@ -108,6 +108,7 @@ struct wgbsseg_ctx {
     DevBuf betas_own, loci_own;
     const uint8_t* betas = nullptr;
     int64_t pitch = 0, n_total = 0;
+    int32_t elem = 1;        // bytes per count of the resident rows: 1 = .beta / .bin (uint8 pairs), 2 = .lbeta (uint16 pairs; block sums only)
     int64_t site_base = 0;   // absolute 0-based index of resident site 0 (messages only; all call coordinates are resident-relative)
     int32_t n_samples = 0;
     const uint32_t* loci = nullptr;
@@ -277,21 +278,32 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     if (profiling()) fprintf(stderr, "[wgbsseg] destroy: %.1f ms\n", (wall_s() - t0) * 1e3);
 }
 
-int wgbsseg_set_betas_host(wgbsseg_ctx* c, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites,
-                           char* err, size_t errlen)
+static int set_rows_host(wgbsseg_ctx* c, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites, int elem, char* err, size_t errlen)
 {
     if (!c || !samples || n_samples < 1 || n_sites < 1) { set_err(err, errlen, "bad arguments to set_betas_host"); return WGBSSEG_E_ARG; }
     HIP_TRY(hipSetDevice(c->device));
-    const int64_t pitch = round_up(2 * n_sites, 256) + 256;      // slack: vector loads may run past the last site
+    const int64_t pitch = round_up(2 * elem * n_sites, 256) + 256;      // slack: vector loads may run past the last site
     HIP_TRY(c->betas_own.ensure((size_t)pitch * (size_t)n_samples));
     for (int64_t s = 0; s < n_samples; s++)
         if (!samples[s]) { set_err(err, errlen, "samples[%lld] is NULL", (long long)s); return WGBSSEG_E_ARG; }
-    const int rc = upload_rows(c, c->betas_own.as<uint8_t>(), pitch, samples, n_samples, 2 * n_sites, "betas", err, errlen);
+    const int rc = upload_rows(c, c->betas_own.as<uint8_t>(), pitch, samples, n_samples, 2 * elem * n_sites, "betas", err, errlen);
     if (rc != WGBSSEG_OK) return rc;
     c->betas = c->betas_own.as<uint8_t>();
-    c->pitch = pitch; c->n_total = n_sites; c->n_samples = (int32_t)n_samples;
+    c->pitch = pitch; c->n_total = n_sites; c->n_samples = (int32_t)n_samples; c->elem = elem;
     c->last_valid = false;
     return WGBSSEG_OK;
+}
+
+int wgbsseg_set_betas_host(wgbsseg_ctx* c, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites,
+                           char* err, size_t errlen)
+{
+    return set_rows_host(c, samples, n_samples, n_sites, 1, err, errlen);
+}
+
+int wgbsseg_set_lbetas_host(wgbsseg_ctx* c, const uint16_t* const* samples, int64_t n_samples, int64_t n_sites,
+                            char* err, size_t errlen)
+{
+    return set_rows_host(c, reinterpret_cast<const uint8_t* const*>(samples), n_samples, n_sites, 2, err, errlen);
 }
 
 int wgbsseg_set_betas_device(wgbsseg_ctx* c, const void* base, int64_t n_samples, int64_t pitch_bytes, int64_t n_sites,
@@ -300,7 +312,7 @@ int wgbsseg_set_betas_device(wgbsseg_ctx* c, const void* base, int64_t n_samples
     if (!c || !base || n_samples < 1 || n_sites < 1 || pitch_bytes < 2 * n_sites) { set_err(err, errlen, "bad arguments to set_betas_device"); return WGBSSEG_E_ARG; }
     if (((uintptr_t)base & 15) || (pitch_bytes & 15)) { set_err(err, errlen, "device betas base and pitch must be multiples of 16 bytes"); return WGBSSEG_E_ARG; }
     c->betas = reinterpret_cast<const uint8_t*>(base);
-    c->pitch = pitch_bytes; c->n_total = n_sites; c->n_samples = (int32_t)n_samples;
+    c->pitch = pitch_bytes; c->n_total = n_sites; c->n_samples = (int32_t)n_samples; c->elem = 1;
     c->last_valid = false;
     return WGBSSEG_OK;
 }
@@ -347,6 +359,7 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
 {
     if (!c) { set_err(err, errlen, "ctx is NULL"); return WGBSSEG_E_ARG; }
     if (!c->betas) { set_err(err, errlen, "betas not set"); return WGBSSEG_E_STATE; }
+    if (c->elem != 1) { set_err(err, errlen, "the resident rows are uint16 (.lbeta): segment, scan and prefix sums read uint8 .beta data only (as the reference's segmentor, segmentor.cpp:166-176)"); return WGBSSEG_E_STATE; }
     if (need_loci && (!c->loci || c->n_loci != c->n_total)) { set_err(err, errlen, "loci not set or length differs from the betas (%lld vs %lld)", (long long)c->n_loci, (long long)c->n_total); return WGBSSEG_E_STATE; }
     if (!start0 || !len || n_chunks < 1 || n_chunks > 0x7fffffff) { set_err(err, errlen, "bad chunk list"); return WGBSSEG_E_ARG; }
     job.h.resize((size_t)n_chunks);
@@ -1235,26 +1248,62 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
     if (!c->betas) { set_err(err, errlen, "betas not set"); return WGBSSEG_E_STATE; }
     if (n_blocks < 0 || mode < 0 || mode > 3 || (n_blocks && (!start0 || !end0 || !out))) { set_err(err, errlen, "bad arguments to block_sums"); return WGBSSEG_E_ARG; }
     if (n_blocks == 0) return WGBSSEG_OK;
-    for (int64_t i = 0; i < n_blocks; i++)
+    if (n_blocks > 0x7fffffff || c->n_total > 0x7fffffff) { set_err(err, errlen, "too many blocks / sites for one block_sums call"); return WGBSSEG_E_ARG; }
+    bool sorted = true;
+    for (int64_t i = 0; i < n_blocks; i++) {
         if (start0[i] < 0 || end0[i] < start0[i] || end0[i] > c->n_total) {
             set_err(err, errlen, "block %lld = sites [%lld, %lld) is outside the %lld sites of the beta files or reversed",
                     (long long)i, (long long)start0[i], (long long)end0[i], (long long)c->n_total);
             return WGBSSEG_E_ARG;
         }
+        if (mode == 0 && c->elem == 2 && end0[i] - start0[i] > 65536) { set_err(err, errlen, "block %lld: uint32 sums of uint16 counts are only exact up to 65536 sites per block", (long long)i); return WGBSSEG_E_ARG; }
+        if (i && start0[i] < start0[i - 1]) sorted = false;
+    }
     HIP_TRY(hipSetDevice(c->device));
+    // the kernel wants the blocks in order of their first site (a table a segmentation wrote already is): sort a copy
+    const int64_t n_tiles = (c->n_total + WG_BS_TILE - 1) / WG_BS_TILE;
+    std::vector<int32_t> h((size_t)n_blocks * (sorted ? 2 : 3) + (size_t)n_tiles + 1);
+    int32_t* hx0 = h.data();
+    int32_t* hx1 = hx0 + n_blocks;
+    int32_t* hperm = sorted ? nullptr : hx1 + n_blocks;
+    int32_t* htf = hx1 + n_blocks + (sorted ? 0 : n_blocks);
+    if (sorted) {
+        for (int64_t i = 0; i < n_blocks; i++) { hx0[i] = (int32_t)start0[i]; hx1[i] = (int32_t)end0[i]; }
+    } else {
+        for (int64_t i = 0; i < n_blocks; i++) hperm[i] = (int32_t)i;
+        std::stable_sort(hperm, hperm + n_blocks, [&](int32_t a, int32_t b) { return start0[a] < start0[b]; });
+        for (int64_t i = 0; i < n_blocks; i++) { hx0[i] = (int32_t)start0[hperm[i]]; hx1[i] = (int32_t)end0[hperm[i]]; }
+    }
+    {   // first block that starts at or after every tile's first site (empty blocks ride along with their start site)
+        int64_t b = 0;
+        for (int64_t t = 0; t <= n_tiles; t++) {
+            const int64_t lo = t * WG_BS_TILE;
+            while (b < n_blocks && hx0[b] < lo) b++;
+            htf[t] = (int32_t)b;
+        }
+        htf[n_tiles] = (int32_t)n_blocks;                          // blocks that start at n_total (empty) belong to the last tile
+    }
     const size_t esz = mode == 0 ? 8 : (mode == 1 ? 2 : (mode == 2 ? 4 : 8));
     const size_t obytes = (size_t)c->n_samples * (size_t)n_blocks * esz;
-    HIP_TRY(c->dbg_a.ensure((size_t)n_blocks * 16));
+    HIP_TRY(c->dbg_a.ensure(h.size() * 4));
     HIP_TRY(c->dbg_b.ensure(obytes));
-    int64_t* dx0 = c->dbg_a.as<int64_t>();
-    int64_t* dx1 = dx0 + n_blocks;
-    HIP_TRY(hipMemcpyAsync(dx0, start0, (size_t)n_blocks * 8, hipMemcpyHostToDevice, c->sA));
-    HIP_TRY(hipMemcpyAsync(dx1, end0, (size_t)n_blocks * 8, hipMemcpyHostToDevice, c->sA));
-    const int64_t gx = (n_blocks + WG_BLOCK - 1) / WG_BLOCK;
-    if (gx > 0x7fffffff || c->n_samples > 65535) { set_err(err, errlen, "too many blocks / samples for one block_sums call"); return WGBSSEG_E_ARG; }
+    HIP_TRY(hipMemcpyAsync(c->dbg_a.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, c->sA));
+    const int32_t* dx0 = c->dbg_a.as<int32_t>();
+    const int32_t* dx1 = dx0 + n_blocks;
+    const int32_t* dperm = sorted ? nullptr : dx1 + n_blocks;
+    const int32_t* dtf = dx1 + n_blocks + (sorted ? 0 : n_blocks);
+    // samples per wavefront: enough workgroups to fill the chip, few enough that the block list is re-read rarely
+    int spw = 1;
+    while (spw < 4 && (int64_t)n_tiles * ((c->n_samples + 4 * spw - 1) / (4 * spw)) > 8192 && c->n_samples > 4 * spw) spw *= 2;
+    const unsigned gy = (unsigned)((c->n_samples + 4 * spw - 1) / (4 * spw));
+    if (gy > 65535) { set_err(err, errlen, "too many samples for one block_sums call"); return WGBSSEG_E_ARG; }
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
-    hipLaunchKernelGGL(k_block_sums, dim3((unsigned)gx, (unsigned)c->n_samples), dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total,
-                       dx0, dx1, n_blocks, (int)mode, min_cov, c->dbg_b.p);
+    if (c->elem == 1)
+        hipLaunchKernelGGL(k_block_sums<1>, dim3((unsigned)n_tiles, gy), dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total,
+                           dx0, dx1, dperm, dtf, n_blocks, (int)c->n_samples, spw, (int)mode, min_cov, c->dbg_b.p);
+    else
+        hipLaunchKernelGGL(k_block_sums<2>, dim3((unsigned)n_tiles, gy), dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total,
+                           dx0, dx1, dperm, dtf, n_blocks, (int)c->n_samples, spw, (int)mode, min_cov, c->dbg_b.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
     HIP_TRY(hipMemcpyAsync(out, c->dbg_b.p, obytes, hipMemcpyDeviceToHost, c->sA));
