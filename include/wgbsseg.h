@@ -239,6 +239,22 @@ int wgbsseg_block_sums(wgbsseg_ctx* ctx, const int64_t* start0, const int64_t* e
 double wgbsseg_last_block_sums_ms(const wgbsseg_ctx* ctx);
 
 /*
+ * BED regions -> CpG index ranges: the join of `wgbstools convert -L` (convert.py:147-185 chr_thread, :133-145
+ * slow_conversion + genomic_region.py:126-161), the step users run right before `segment -L` and `beta_to_blocks`; the
+ * inverse direction is wgbsseg_add_loci below.  Against the loci resident in `ctx` (wgbsseg_set_loci_*; no betas
+ * needed).  Region i lies on the chromosome whose CpGs are the 0-based sites [chrom_lo[i], chrom_hi[i]) (equal: unknown
+ * chromosome -> NA) and whose length is chrom_bp[i] base pairs; (start[i], end[i]) is its bp interval.  slow[i] selects the
+ * reference's rule set for the row's chromosome — it uses the as-of joins when the chromosome's regions do not overlap
+ * (slow 0): startCpG = first CpG with locus >= start, endCpG = first CpG with locus >= end (+1 when exactly on `end`; last
+ * CpG of the chromosome + 1 when none); and one GenomicRegion per row when they do (slow 1): CpGs with start <= locus <= end,
+ * endCpG = last + 1 (last itself when its locus == end); end <= start, start < 1, end > chrom_bp: no answer.
+ * Output: 1-based global indexes; (0, 0) where the reference writes NA (no CpG inside).
+ */
+int wgbsseg_convert_regions(wgbsseg_ctx* ctx, const int64_t* chrom_lo, const int64_t* chrom_hi, const int64_t* chrom_bp,
+                            const int64_t* start, const int64_t* end, const uint8_t* slow, int64_t n,
+                            int64_t* start_cpg, int64_t* end_cpg, char* err, size_t errlen);
+
+/*
  * Blocks -> BED rows: the path's last step (segment.py:186-190 -> convert.py:242-248 add_bed_to_cpgs, which pipes the
  * blocks through the reference's `add_loci` binary: src/cpg2bed/add_loci.cpp:22-57, cpg_dict.cpp:40-131).  Host-side,
  * no device involved, no ctx needed.  For every block i (1-based half-open CpG interval) one row

@@ -23,7 +23,8 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_debug_div', 'wgbsseg_add_loci', 'wgbsseg_block_sums', 'wgbsseg_last_block_sums_ms',
            'wgbsseg_set_site_base', 'wgbsseg_stitch_regions', 'wgbsseg_group_create', 'wgbsseg_group_destroy', 'wgbsseg_group_size',
            'wgbsseg_group_plan', 'wgbsseg_group_load_host', 'wgbsseg_group_share_set_device', 'wgbsseg_group_segment_regions',
-           'wgbsseg_group_get_timings', 'wgbsseg_plan_shares', 'wgbsseg_set_lbetas_host']
+           'wgbsseg_group_get_timings', 'wgbsseg_plan_shares', 'wgbsseg_set_lbetas_host',
+           'wgbsseg_convert_regions']
 
 
 class NativeLibraryError(RuntimeError):
@@ -165,6 +166,8 @@ def load():
     L.wgbsseg_group_segment_regions.argtypes = [vp, vp, i64, vp, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_group_get_timings.restype = i32
     L.wgbsseg_group_get_timings.argtypes = [vp, i32, C.POINTER(Timings)]
+    L.wgbsseg_convert_regions.restype = i32
+    L.wgbsseg_convert_regions.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_add_loci.restype = i32
     L.wgbsseg_add_loci.argtypes = [vp, i64, vp, C.POINTER(C.c_char_p), i32, vp, vp, i64, C.c_char_p, i32, i32, C.c_char_p, C.c_size_t]
     _lib = L
@@ -324,6 +327,18 @@ class Segmenter:
         _check(self._L.wgbsseg_block_sums(self._h, s.ctypes.data, e.ctypes.data, n, int(mode), int(min_cov), out.ctypes.data,
                                           self._err, ERRLEN), self._err)
         return out
+
+    def convert_regions(self, chrom_lo, chrom_hi, chrom_bp, start, end, slow):
+        """wgbsseg_convert_regions against the resident loci -> (startCpG, endCpG) int64 arrays, 0 = NA."""
+        a = [np.ascontiguousarray(x, dtype=np.int64) for x in (chrom_lo, chrom_hi, chrom_bp, start, end)]
+        sl = np.ascontiguousarray(slow, dtype=np.uint8)
+        n = a[0].size
+        s = np.zeros(n, dtype=np.int64)
+        e = np.zeros(n, dtype=np.int64)
+        _check(self._L.wgbsseg_convert_regions(self._h, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                                               a[4].ctypes.data, sl.ctypes.data, n, s.ctypes.data, e.ctypes.data, self._err, ERRLEN),
+               self._err)
+        return s, e
 
     def last_block_sums_ms(self):
         return float(self._L.wgbsseg_last_block_sums_ms(self._h))

@@ -31,6 +31,7 @@
 #define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)
 #define WG_TRACE_WIN    32768       // back-pointers staged in LDS by k_trace (64 KiB)
 #define WG_TRACE_SEG    128         // speculative walks per window
+#define WG_NARROW_WMAX  60          // widest window of a narrow scoring tile: TI + 60 + 1 <= 125 entries, + 3 of alignment <= 128 = 32 lanes x 4 sites
 
 // Exact-restatement tables: global (constant) memory, read only by the rare guard-band fallback and by the plain kernel.
 __device__ const wg_log_tables g_wg_tables = WG_LOG_TABLES_INIT;
@@ -96,7 +97,7 @@ struct JobStatus {            // zeroed (first_bad = ~0) before every call
     unsigned int max_window;
     unsigned int loci_disorder;     // 1 + chunk index of a chunk whose loci are not ascending
     unsigned int overflow;          // a chunk's pair count does not fit 32 bits
-    unsigned int wide_units;        // 16-site units with a window > 64 sites
+    unsigned int wide_units;        // 16-site units with a window > WG_NARROW_WMAX sites: they are scored in wide tiles, from the carries of k_scan
 };
 
 struct StageView {            // tables produced by k_stage_plan, row `stage` of each
@@ -170,7 +171,7 @@ __device__ __noinline__ int wg_first_bad_site(uint4 v0, uint4 v1)      // index 
     return bad;
 }
 
-__global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
+__global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int want_carry)
 {
     const int lane = threadIdx.x & 63;
     const int64_t rowid = (int64_t)blockIdx.x * (WG_BLOCK / 64) + (threadIdx.x >> 6);
@@ -194,7 +195,11 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
     const int A6 = (int)(a_abs & (WG_CARRY_G - 1));
     uint32_t run_m = 0, run_t = 0;
     int bad_rel = 0x7fffffff;
-    if (lane == 0) carry[0] = make_uint2(0u, 0u);     // group 0: the chunk start
+    // The carries have ONE consumer: the wide scoring tiles (windows > WG_NARROW_WMAX sites: CpG islands, deep mode), which
+    // k_window_scan has counted on this stream before this kernel starts.  A job without any (every default-parameter
+    // genome) writes none: the pass is then read-only, and the write-back that used to hold it at 4.4 TB/s is gone.
+    const bool keep = want_carry != 0 || __hip_atomic_load(&st->wide_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (keep && lane == 0) carry[0] = make_uint2(0u, 0u);     // group 0: the chunk start
 
     int vi = 2 * lane;                                // this lane's first vector of the current iteration
     uint4 c0 = rv[vi < vlast ? vi : vlast], c1 = rv[vi + 1 < vlast ? vi + 1 : vlast];
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
         // wave-wide inclusive prefix of the lane totals (two 32-bit DPP scans)
         const uint32_t im = wg_wave_incl_scan_dpp_u32(tm);
         const uint32_t it = wg_wave_incl_scan_dpp_u32(tt);
-        if (((A6 + off) & (WG_CARRY_G - 1)) == 0 && rel0 > 0 && rel0 < len)
+        if (keep && ((A6 + off) & (WG_CARRY_G - 1)) == 0 && rel0 > 0 && rel0 < len)
             carry[(A6 + off) >> WG_CARRY_SHIFT] = make_uint2(run_m + (im - tm), run_t + (it - tt));
         run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
         run_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window_scan(JobView J, JobStatus* 
         run += btot;
     }
     uint32_t nwide = 0;
-    for (int u = tid; u < (cd.len + 15) >> 4; u += WG_BLOCK) nwide += J.umax16[cd.unit_off + u] > 64u ? 1u : 0u;
+    for (int u = tid; u < (cd.len + 15) >> 4; u += WG_BLOCK) nwide += J.umax16[cd.unit_off + u] > (uint32_t)WG_NARROW_WMAX ? 1u : 0u;
     for (int o = 32; o > 0; o >>= 1) nwide += (uint32_t)__shfl_down((int)nwide, o);
     if (lane == 0 && nwide) atomicAdd(&st->wide_units, nwide);
     if (tid == 0) {
@@ -629,7 +634,6 @@ __device__ __forceinline__ void wg_stage_local_rows(uint32_t* __restrict__ Et, c
     }
 }
 
-#define WG_NARROW_WMAX  60          // widest window of a narrow tile: TI + 60 + 1 <= 125 entries, + 3 of alignment <= 128 = 32 lanes x 4 sites
 #define WG_WIDE_TK      128         // end sites per wide tile
 #define WG_WIDE_TS      16          // start sites per wide tile
 
@@ -1576,6 +1580,54 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_convert: BED regions -> CpG index ranges against the resident loci (the join of `wgbstools convert -L`,
+// convert.py:147-185 chr_thread / :133-145 slow_conversion + genomic_region.py:126-161).  One thread per region: two
+// binary searches in its chromosome's slice [clo, chi) of the loci.  Region r: bp interval (start, end), chromosome
+// slice, chromosome length in bp, and which of the reference's two rule sets applies (it picks per chromosome: the
+// as-of joins when the chromosome's regions do not overlap, one GenomicRegion per row when they do).
+//   fast: startCpG = first CpG with locus >= start; endCpG = first CpG with locus >= end (+1 when it sits exactly on
+//         `end`; the chromosome's last CpG + 1 when there is none)
+//   slow: CpGs with start <= locus <= end are rows first..last; endCpG = last + 1, or last when the last locus == end;
+//         end <= start, start < 1, end > chromosome length: no answer
+// No CpG inside / start beyond the last CpG: (0, 0) = NA.  Indexes are 1-based and global (init_genome.py:151-157).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t wg_lower_bound_loci(const uint32_t* __restrict__ L, int64_t lo, int64_t hi, int64_t x, bool upper)
+{
+    while (lo < hi) {                                      // first index with L[i] >= x (upper: > x)
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t v = (int64_t)L[mid];
+        if (upper ? v <= x : v < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(WG_BLOCK) void k_convert(const uint32_t* __restrict__ loci, const int64_t* __restrict__ clo, const int64_t* __restrict__ chi,
+                                                      const int64_t* __restrict__ cbp, const int64_t* __restrict__ start, const int64_t* __restrict__ end,
+                                                      const uint8_t* __restrict__ slow, int64_t n, int64_t* __restrict__ s_cpg, int64_t* __restrict__ e_cpg)
+{
+    const int64_t r = (int64_t)blockIdx.x * WG_BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const int64_t lo = clo[r], hi = chi[r], a = start[r], b = end[r];
+    int64_t sc = 0, ec = 0;
+    if (hi > lo) {
+        if (!slow[r]) {
+            const int64_t s = wg_lower_bound_loci(loci, lo, hi, a, false);
+            const int64_t j = wg_lower_bound_loci(loci, lo, hi, b, false);
+            const int64_t hit = (j < hi && (int64_t)loci[j] == b) ? 1 : 0;
+            if (s < hi && j + hit > s) { sc = s + 1; ec = j + 1 + hit; }
+        } else if (b > a && a >= 1 && b <= cbp[r]) {
+            const int64_t i0 = wg_lower_bound_loci(loci, lo, hi, a, false);
+            const int64_t i1 = wg_lower_bound_loci(loci, lo, hi, b, true);
+            if (i1 > i0) {
+                const int64_t e = i1 + ((int64_t)loci[i1 - 1] < b ? 1 : 0);
+                if (e != i0 + 1) { sc = i0 + 1; ec = e; }
+            }
+        }
+    }
+    s_cpg[r] = sc; e_cpg[r] = ec;
 }
 
 // ------------------------------------------------------------------------------------------------------------

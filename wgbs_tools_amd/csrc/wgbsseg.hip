@@ -411,12 +411,12 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
     return WGBSSEG_OK;
 }
 
-int launch_scan(wgbsseg_ctx* c, const Job& job, char* err, size_t errlen)
+int launch_scan(wgbsseg_ctx* c, const Job& job, int want_carry, char* err, size_t errlen)
 {
     const int64_t rows = (int64_t)job.v.n_chunks * job.v.n_samples;
     const int64_t blocks = (rows + (WG_BLOCK / 64) - 1) / (WG_BLOCK / 64);
     if (blocks > 0x7fffffff) { set_err(err, errlen, "too many (chunk, sample) rows"); return WGBSSEG_E_ARG; }
-    hipLaunchKernelGGL(k_scan, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, c->sA, job.v, c->status.as<JobStatus>());
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, c->sA, job.v, c->status.as<JobStatus>(), want_carry);
     HIP_TRY(hipGetLastError());
     return WGBSSEG_OK;
 }
@@ -534,7 +534,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     JobStatus* hst = reinterpret_cast<JobStatus*>(c->h_status.p);
     HIP_TRY(hipMemcpyAsync(&hst[0], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipEventRecord(c->ev[7], c->sA));
-    rc = launch_scan(c, job, err, errlen);
+    rc = launch_scan(c, job, 0, err, errlen);                 // carries only if k_window_scan counted wide units (device-side flag)
     if (rc != WGBSSEG_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], c->sA));
     HIP_TRY(hipEventSynchronize(c->ev[7]));                    // window statistics are here; the scan is still running
@@ -1201,10 +1201,10 @@ int wgbsseg_scan_only(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t
     int rc = build_job(c, chunk_start0, chunk_len, n_chunks, job, false, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
     if (repeat < 1) repeat = 1;
-    rc = launch_scan(c, job, err, errlen);                     // warm-up
+    rc = launch_scan(c, job, 0, err, errlen);                  // warm-up (a fresh status block: no wide units, no carry stores)
     if (rc != WGBSSEG_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
-    for (int r = 0; r < repeat; r++) { rc = launch_scan(c, job, err, errlen); if (rc != WGBSSEG_OK) return rc; }
+    for (int r = 0; r < repeat; r++) { rc = launch_scan(c, job, 0, err, errlen); if (rc != WGBSSEG_OK) return rc; }
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
     float ms = 0;
@@ -1225,7 +1225,7 @@ int wgbsseg_prefix_sums(wgbsseg_ctx* c, int64_t start0, int64_t len, uint32_t* o
     Job job;
     int rc = build_job(c, &start0, &l32, 1, job, false, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
-    rc = launch_scan(c, job, err, errlen);
+    rc = launch_scan(c, job, 1, err, errlen);                  // the carries are what k_prefix_materialise builds on
     if (rc != WGBSSEG_OK) return rc;
     const size_t bytes = (size_t)c->n_samples * (size_t)(len + 1) * 8;
     HIP_TRY(c->dbg_a.ensure(bytes));
@@ -1336,6 +1336,44 @@ int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom
     const int rc = wgadd::add_loci(g, start_cpg, end_cpg, n_blocks, fp, threads, msg);
     if (path) { if (fclose(fp) != 0 && rc == 0) { set_err(err, errlen, "add_loci: write to %s failed", path); return WGBSSEG_E_ARG; } }
     if (rc) { set_err(err, errlen, "%s", msg.c_str()); return WGBSSEG_E_ARG; }
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_convert_regions(wgbsseg_ctx* c, const int64_t* chrom_lo, const int64_t* chrom_hi, const int64_t* chrom_bp, const int64_t* start,
+                            const int64_t* end, const uint8_t* slow, int64_t n, int64_t* start_cpg, int64_t* end_cpg, char* err, size_t errlen)
+{
+    if (!c) { set_err(err, errlen, "ctx is NULL"); return WGBSSEG_E_ARG; }
+    if (!c->loci) { set_err(err, errlen, "loci not set"); return WGBSSEG_E_STATE; }
+    if (n < 0 || (n && (!chrom_lo || !chrom_hi || !chrom_bp || !start || !end || !slow || !start_cpg || !end_cpg))) { set_err(err, errlen, "bad arguments to convert_regions"); return WGBSSEG_E_ARG; }
+    if (n == 0) return WGBSSEG_OK;
+    for (int64_t i = 0; i < n; i++)
+        if (chrom_lo[i] < 0 || chrom_hi[i] < chrom_lo[i] || chrom_hi[i] > c->n_loci) {
+            set_err(err, errlen, "region %lld: chromosome slice [%lld, %lld) is outside the %lld resident loci", (long long)i, (long long)chrom_lo[i], (long long)chrom_hi[i], (long long)c->n_loci);
+            return WGBSSEG_E_ARG;
+        }
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t nb = (size_t)n * 8;
+    HIP_TRY(c->dbg_a.ensure(5 * nb + (size_t)n));
+    HIP_TRY(c->dbg_b.ensure(2 * nb));
+    char* d = c->dbg_a.as<char>();
+    const int64_t* srcs[5] = {chrom_lo, chrom_hi, chrom_bp, start, end};
+    for (int k = 0; k < 5; k++) HIP_TRY(hipMemcpyAsync(d + k * nb, srcs[k], nb, hipMemcpyHostToDevice, c->sA));
+    HIP_TRY(hipMemcpyAsync(d + 5 * nb, slow, (size_t)n, hipMemcpyHostToDevice, c->sA));
+    int64_t* o = c->dbg_b.as<int64_t>();
+    const int64_t gx = (n + WG_BLOCK - 1) / WG_BLOCK;
+    if (gx > 0x7fffffff) { set_err(err, errlen, "too many regions for one convert call"); return WGBSSEG_E_ARG; }
+    HIP_TRY(hipEventRecord(c->ev[0], c->sA));
+    hipLaunchKernelGGL(k_convert, dim3((unsigned)gx), dim3(WG_BLOCK), 0, c->sA, c->loci, reinterpret_cast<const int64_t*>(d),
+                       reinterpret_cast<const int64_t*>(d + nb), reinterpret_cast<const int64_t*>(d + 2 * nb), reinterpret_cast<const int64_t*>(d + 3 * nb),
+                       reinterpret_cast<const int64_t*>(d + 4 * nb), reinterpret_cast<const uint8_t*>(d + 5 * nb), n, o, o + n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[1], c->sA));
+    HIP_TRY(hipMemcpyAsync(start_cpg, o, nb, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipMemcpyAsync(end_cpg, o + n, nb, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->last_block_sums_ms = ms;                            // (shared "last auxiliary kernel" clock: wgbsseg_last_block_sums_ms)
     return WGBSSEG_OK;
 }
 

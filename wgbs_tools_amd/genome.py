@@ -196,6 +196,13 @@ class GenomicRegion:
     def is_whole(self):
         return self.sites is None
 
+    def __str__(self):                                            # genomic_region.py:239-247 (no annotation tracks here)
+        if self.sites is None:
+            return 'Whole genome'
+        s1, s2 = self.sites
+        nr_bp = self.bp_tuple[1] - self.bp_tuple[0] + 1
+        return f'{self.region_str} - {nr_bp:,}bp, {s2 - s1:,}CpGs: {s1}-{s2}'
+
     # genomic_region.py:163-187
     def _sites_str_to_tuple(self, sites_str):
         if not sites_str:
