@@ -269,6 +269,24 @@ int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom
                      int32_t n_chroms, const int64_t* start_cpg, const int64_t* end_cpg, int64_t n_blocks,
                      const char* path, int32_t append, int32_t threads, char* err, size_t errlen);
 
+/*
+ * pat -> beta: the producer of the path's input (`wgbstools pat2beta`: pat2beta.py:17-44 pipes `gunzip -c x.pat.gz` into
+ * the reference's stdin2beta binary, src/pat2beta/stdin2beta.cpp:59-123, and trims the counts with trim_to_uint8,
+ * utils_wgbs.py:277-290).  An accumulator holds (#meth, #cov) of the CpGs [start_cpg, end_cpg) (1-based, half-open; the whole
+ * genome: [1, nr_sites + 1)) on one device.  feed(): a chunk of pat TEXT made of whole lines
+ * "chr \t first CpG index \t pattern over {C,T,H,.} \t count [\t ...]": every site under a C / T / H gains `count`
+ * coverage, under C / H also `count` methylated; reads outside the range are skipped, empty lines too.  Asynchronous (the
+ * text is copied): the caller decompresses the next chunk meanwhile.  finish(): `.beta` rows (uint8 pairs; lbeta != 0:
+ * `.lbeta`, uint16 pairs) into out[2 * (end - start)], coverage above the type's maximum M scaled to (trunc(meth / cov * M), M).
+ * A line with fewer than four fields, or whose site / count is not a number, is an error (the reference prints "failed
+ * calculating beta" and writes nothing): finish() returns WGBSSEG_E_ARG naming the byte offset of the line.
+ */
+typedef struct wgbsseg_patbeta wgbsseg_patbeta;
+int wgbsseg_patbeta_create(int device, int64_t start_cpg, int64_t end_cpg, wgbsseg_patbeta** out, char* err, size_t errlen);
+int wgbsseg_patbeta_feed(wgbsseg_patbeta* pb, const char* text, int64_t n_bytes, char* err, size_t errlen);
+int wgbsseg_patbeta_finish(wgbsseg_patbeta* pb, int32_t lbeta, void* out, char* err, size_t errlen);
+void wgbsseg_patbeta_destroy(wgbsseg_patbeta* pb);
+
 int wgbsseg_get_timings(const wgbsseg_ctx* ctx, wgbsseg_timings* out);
 
 /*

@@ -13,7 +13,13 @@ __global__ __launch_bounds__(256) void k(int iters, float* out, float seed)
     float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3;
     double d0 = a0, d1 = a1, d2 = a2, d3 = a3;
     int i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a1, a2}, p2 = {a2, a3}, p3 = {a3, a0};
     for (int it = 0; it < iters; it++) {
+        if (OP == 12) { REP8(asm volatile("v_pk_fma_f32 %0, %0, %0, %0\n v_pk_fma_f32 %1, %1, %1, %1\n v_pk_fma_f32 %2, %2, %2, %2\n v_pk_fma_f32 %3, %3, %3, %3" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));) }
+        if (OP == 13) { REP8(asm volatile("v_pk_add_f32 %0, %0, %0\n v_pk_add_f32 %1, %1, %1\n v_pk_add_f32 %2, %2, %2\n v_pk_add_f32 %3, %3, %3" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));) }
+        if (OP == 14) { REP8(asm volatile("v_sub_u32 %0, %0, %1\n v_sub_u32 %1, %1, %2\n v_sub_u32 %2, %2, %3\n v_sub_u32 %3, %3, %0" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 15) { REP8(asm volatile("v_bfe_u32 %0, %0, 3, 18\n v_bfe_u32 %1, %1, 3, 18\n v_bfe_u32 %2, %2, 3, 18\n v_bfe_u32 %3, %3, 3, 18" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
         if (OP == 0) { REP8(asm volatile("v_add_f32 %0, %0, %0\n v_add_f32 %1, %1, %1\n v_add_f32 %2, %2, %2\n v_add_f32 %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
         if (OP == 1) { REP8(asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
         if (OP == 2) { REP8(asm volatile("v_fma_f64 %0, %0, %0, %0\n v_fma_f64 %1, %1, %1, %1\n v_fma_f64 %2, %2, %2, %2\n v_fma_f64 %3, %3, %3, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));) }
@@ -27,6 +33,7 @@ __global__ __launch_bounds__(256) void k(int iters, float* out, float seed)
         if (OP == 10) { REP8(asm volatile("v_lshl_add_u32 %0, %0, 3, %0\n v_lshl_add_u32 %1, %1, 3, %1\n v_lshl_add_u32 %2, %2, 3, %2\n v_lshl_add_u32 %3, %3, 3, %3" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
         if (OP == 11) { REP8(asm volatile("v_cvt_f32_u32_sdwa %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %1, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %2, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %3, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
     }
+    a0 += p0.x + p1.y + p2.x + p3.y;
     if (a0 + a1 + a2 + a3 + (float)(d0 + d1 + d2 + d3) + (float)(i0 + i1 + i2 + i3) == 12345.678f) out[0] = a0;
 }
 
@@ -54,6 +61,7 @@ int main()
     run<0>("v_add_f32", out, clock); run<9>("v_fma_f32", out, clock); run<10>("v_lshl_add_u32", out, clock);
     run<1>("v_rcp_f32", out, clock); run<8>("v_cvt_f32_u32", out, clock); run<11>("v_cvt_f32_u32 sdwa", out, clock);
     run<2>("v_fma_f64", out, clock); run<6>("v_add_f64", out, clock); run<7>("v_mul_f64", out, clock);
+    run<12>("v_pk_fma_f32", out, clock); run<13>("v_pk_add_f32", out, clock); run<14>("v_sub_u32", out, clock); run<15>("v_bfe_u32", out, clock);
     run<3>("v_cvt_f64_f32", out, clock); run<4>("v_cvt_f32_f64", out, clock); run<5>("v_cvt_f64_i32", out, clock);
     return 0;
 }

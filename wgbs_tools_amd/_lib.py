@@ -24,7 +24,8 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_set_site_base', 'wgbsseg_stitch_regions', 'wgbsseg_group_create', 'wgbsseg_group_destroy', 'wgbsseg_group_size',
            'wgbsseg_group_plan', 'wgbsseg_group_load_host', 'wgbsseg_group_share_set_device', 'wgbsseg_group_segment_regions',
            'wgbsseg_group_get_timings', 'wgbsseg_plan_shares', 'wgbsseg_set_lbetas_host',
-           'wgbsseg_convert_regions']
+           'wgbsseg_convert_regions', 'wgbsseg_patbeta_create', 'wgbsseg_patbeta_feed', 'wgbsseg_patbeta_finish',
+           'wgbsseg_patbeta_destroy']
 
 
 class NativeLibraryError(RuntimeError):
@@ -168,6 +169,14 @@ def load():
     L.wgbsseg_group_get_timings.argtypes = [vp, i32, C.POINTER(Timings)]
     L.wgbsseg_convert_regions.restype = i32
     L.wgbsseg_convert_regions.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_patbeta_create.restype = i32
+    L.wgbsseg_patbeta_create.argtypes = [i32, i64, i64, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.wgbsseg_patbeta_feed.restype = i32
+    L.wgbsseg_patbeta_feed.argtypes = [vp, C.c_char_p, i64, C.c_char_p, C.c_size_t]
+    L.wgbsseg_patbeta_finish.restype = i32
+    L.wgbsseg_patbeta_finish.argtypes = [vp, i32, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_patbeta_destroy.restype = None
+    L.wgbsseg_patbeta_destroy.argtypes = [vp]
     L.wgbsseg_add_loci.restype = i32
     L.wgbsseg_add_loci.argtypes = [vp, i64, vp, C.POINTER(C.c_char_p), i32, vp, vp, i64, C.c_char_p, i32, i32, C.c_char_p, C.c_size_t]
     _lib = L
@@ -385,6 +394,37 @@ class Segmenter:
         if rc != OK:
             raise SegmentorError(rc, 'debug_log2 failed')
         return (f, d, g) if want_fast else (f, d)
+
+
+class PatBeta:
+    """wgbsseg_patbeta: pat text -> (#meth, #cov) rows of the CpGs [start_cpg, end_cpg) on one GPU."""
+
+    def __init__(self, start_cpg, end_cpg, device=0):
+        self._L = load()
+        self._h = C.c_void_p()
+        self._err = C.create_string_buffer(ERRLEN)
+        self.n = int(end_cpg) - int(start_cpg)
+        _check(self._L.wgbsseg_patbeta_create(int(device), int(start_cpg), int(end_cpg), C.byref(self._h), self._err, ERRLEN), self._err)
+
+    def feed(self, text):
+        """text: bytes made of whole lines (must end with a newline)"""
+        _check(self._L.wgbsseg_patbeta_feed(self._h, text, len(text), self._err, ERRLEN), self._err)
+
+    def finish(self, lbeta=False):
+        out = np.empty((self.n, 2), dtype=np.uint16 if lbeta else np.uint8)
+        _check(self._L.wgbsseg_patbeta_finish(self._h, 1 if lbeta else 0, out.ctypes.data, self._err, ERRLEN), self._err)
+        return out
+
+    def close(self):
+        if self._h:
+            self._L.wgbsseg_patbeta_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def _stats_dict(stats):

@@ -31,6 +31,7 @@
 #define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)
 #define WG_TRACE_WIN    32768       // back-pointers staged in LDS by k_trace (64 KiB)
 #define WG_TRACE_SEG    128         // speculative walks per window
+#define WG_SCAN_PIECES  4           // wave tasks per (chunk, sample) row of k_scan
 #define WG_NARROW_WMAX  60          // widest window of a narrow scoring tile: TI + 60 + 1 <= 125 entries, + 3 of alignment <= 128 = 32 lanes x 4 sites
 
 // Exact-restatement tables: global (constant) memory, read only by the rare guard-band fallback and by the plain kernel.
@@ -174,7 +175,12 @@ __device__ __noinline__ int wg_first_bad_site(uint4 v0, uint4 v1)      // index 
 __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int want_carry)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t rowid = (int64_t)blockIdx.x * (WG_BLOCK / 64) + (threadIdx.x >> 6);
+    // a wave task = one of WG_SCAN_PIECES pieces of one (chunk, sample) row.  With carries wanted the row is one serial
+    // scan (piece 0 runs it, the others leave at once); without, the pass only validates, every piece is independent and
+    // the four-times finer tasks even out the last round of waves on the chip
+    const int64_t task = (int64_t)blockIdx.x * (WG_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t rowid = task / WG_SCAN_PIECES;
+    const int piece = (int)(task - rowid * WG_SCAN_PIECES);
     const int64_t nrows = (int64_t)J.n_chunks * J.n_samples;
     if (rowid >= nrows) return;                       // whole wave leaves together
     const int c = (int)(rowid / J.n_samples);
@@ -199,11 +205,15 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int
     // k_window_scan has counted on this stream before this kernel starts.  A job without any (every default-parameter
     // genome) writes none: the pass is then read-only, and the write-back that used to hold it at 4.4 TB/s is gone.
     const bool keep = want_carry != 0 || __hip_atomic_load(&st->wide_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+    if (keep && piece != 0) return;
     if (keep && lane == 0) carry[0] = make_uint2(0u, 0u);     // group 0: the chunk start
+    const int nit = (span + 1023) >> 10;              // 1024-site iterations of the row
+    const int it0 = keep ? 0 : (int)((int64_t)nit * piece / WG_SCAN_PIECES);
+    const int it1 = keep ? nit : (int)((int64_t)nit * (piece + 1) / WG_SCAN_PIECES);
 
-    int vi = 2 * lane;                                // this lane's first vector of the current iteration
+    int vi = 2 * lane + 128 * it0;                    // this lane's first vector of the current iteration
     uint4 c0 = rv[vi < vlast ? vi : vlast], c1 = rv[vi + 1 < vlast ? vi + 1 : vlast];
-    for (int base = 0; base < span; base += 1024) {
+    for (int base = it0 << 10; base < (it1 << 10); base += 1024) {
         const int vn = vi + 128;                      // one iteration ahead (clamped: never past the row)
         const uint4 m0 = rv[vn < vlast ? vn : vlast], m1 = rv[vn + 1 < vlast ? vn + 1 : vlast];
         uint4 v0 = c0, v1 = c1;
@@ -218,14 +228,16 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int
         wg_sum8(v0, tm0, tt0, bad0);
         wg_sum8(v1, tm1, tt1, bad1);
         if ((bad0 || bad1) && bad_rel == 0x7fffffff) bad_rel = rel0 + wg_first_bad_site(v0, v1);   // rare
-        const uint32_t tm = tm0 + tm1, tt = tt0 + tt1;
-        // wave-wide inclusive prefix of the lane totals (two 32-bit DPP scans)
-        const uint32_t im = wg_wave_incl_scan_dpp_u32(tm);
-        const uint32_t it = wg_wave_incl_scan_dpp_u32(tt);
-        if (keep && ((A6 + off) & (WG_CARRY_G - 1)) == 0 && rel0 > 0 && rel0 < len)
-            carry[(A6 + off) >> WG_CARRY_SHIFT] = make_uint2(run_m + (im - tm), run_t + (it - tt));
-        run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
-        run_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
+        if (keep) {                                   // (wave-uniform)
+            const uint32_t tm = tm0 + tm1, tt = tt0 + tt1;
+            // wave-wide inclusive prefix of the lane totals (two 32-bit DPP scans)
+            const uint32_t im = wg_wave_incl_scan_dpp_u32(tm);
+            const uint32_t it = wg_wave_incl_scan_dpp_u32(tt);
+            if (((A6 + off) & (WG_CARRY_G - 1)) == 0 && rel0 > 0 && rel0 < len)
+                carry[(A6 + off) >> WG_CARRY_SHIFT] = make_uint2(run_m + (im - tm), run_t + (it - tt));
+            run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
+            run_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
+        }
         c0 = m0; c1 = m1; vi = vn;
     }
     if (bad_rel != 0x7fffffff)
@@ -1319,6 +1331,145 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_dp16<NW>: the recurrence of a job whose windows are all <= 64 sites (k_dp<.,64>'s case) in 16-step batches, built to
+// run BESIDE the scoring kernel: 24 KB of LDS instead of 73 KB and 1 + NW = 4 wavefronts, i.e. the footprint of ONE scoring
+// workgroup — when the stages of a many-chunk job are pipelined (scoring of stage s+1 on stream A, recurrence of stage s
+// on stream B) a recurrence workgroup takes the place of a single scoring workgroup on its CU instead of waiting for three
+// of them to retire.  Same push form, same 8-step hand-scheduled groups (wg_dp_group64), same arranged rows
+// (-inf where a lane holds no candidate).  What differs: a barrier every 16 steps, so the workers keep the rows of FOUR
+// batches in flight in registers (a 16-step batch lasts ~0.4 us, a row load under scoring traffic 1-2 us); the batch
+// loop is unrolled by four, which makes the lane of a batch's first step (0, 16, 32, 48) and the register set of the
+// rows in flight compile-time constants; back-pointers are stored once per 64 steps.
+// ------------------------------------------------------------------------------------------------------------
+template <int NW>
+struct Dp16Rows { static constexpr int PER = (16 + NW - 1) / NW; double va[PER]; };
+
+template <int NW>
+__device__ __forceinline__ void wg_dp16_issue(Dp16Rows<NW>& R, const double* __restrict__ cb, const uint16_t* __restrict__ metaW,
+                                              const uint32_t* __restrict__ metaC, int base_rel, int base, int lane, int lw)
+{
+    const int x = (base_rel + lane) & (WG_DP_META_RING - 1);
+    const uint32_t w = lane < 16 ? (uint32_t)metaW[x] : 0u;
+    const uint32_t rel = metaC[x];
+    const int stp0 = base & 63;
+#pragma unroll
+    for (int q = 0; q < Dp16Rows<NW>::PER; q++) {
+        const int sidx = lw + q * NW;
+        R.va[q] = -__builtin_inf();
+        if (sidx < 16) {
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w, sidx);
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rel, sidx);
+            const uint32_t j = (uint32_t)(lane - stp0 - sidx) & 63u;
+            if (j < f) R.va[q] = cb[(int64_t)r + j];
+        }
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void wg_dp16_commit(const Dp16Rows<NW>& R, double* __restrict__ slot, int lane, int lw)
+{
+#pragma unroll
+    for (int q = 0; q < Dp16Rows<NW>::PER; q++) {
+        const int sidx = lw + q * NW;
+        if (sidx < 16) slot[sidx * 64 + lane] = R.va[q];
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * (1 + NW)) void k_dp16(JobView J, StageView SV, const double* __restrict__ cost,
+                                                         double* __restrict__ state, int64_t state_stride)
+{
+    constexpr int BL = 16, D = 4;
+    constexpr int RB = WG_DP_META_REGION / BL;                                // batches per region of the meta ring
+    extern __shared__ __attribute__((aligned(16))) char smem_dp[];
+    double* slots = reinterpret_cast<double*>(smem_dp);                       // [2][16 * 64]
+    uint32_t* metaC = reinterpret_cast<uint32_t*>(slots + 2 * BL * 64);       // [1024] row offsets of the coming steps
+    uint16_t* metaW = reinterpret_cast<uint16_t*>(metaC + WG_DP_META_RING);   // [1024] their windows
+    const int lane = threadIdx.x & 63;
+    const bool worker = threadIdx.x >= 64;
+    const int lw = (int)(threadIdx.x >> 6) - 1;
+    const int c = blockIdx.x;
+    const int nC = J.n_chunks;
+    const ChunkDesc cd = J.chunks[c];
+    const int s0 = SV.stage * SV.S;
+    if (s0 >= cd.len) return;
+    const int s1 = (s0 + SV.S < cd.len) ? s0 + SV.S : cd.len;
+    double* gs = state + (int64_t)c * state_stride;
+    const double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
+    const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
+    const uint16_t* Wp = J.W16 + cd.site_off;
+    const uint32_t* Cp = J.cum32 + cd.site_off;
+    const int nb = (s1 - s0 + BL - 1) / BL;
+
+    if (!worker) __builtin_amdgcn_s_setprio(3);
+    double best = -__builtin_inf();
+    int32_t arg = 0;
+    double Mk = 0.0;                                    // M[0] = 0 (segmentor.cpp:97)
+    Dp16Rows<NW> r0, r1, r2, r3;                        // (workers) the rows of four batches in flight: batch q in set q mod 4
+    DpRefill<NW> refill;
+    if (worker) {
+        wg_dp_refill_issue<NW>(refill, Wp, Cp, cum0, s0, s1, lane, lw);
+        wg_dp_refill_commit<NW>(refill, metaW, metaC, 0, lane, lw);
+        wg_dp_refill_issue<NW>(refill, Wp, Cp, cum0, s0 + WG_DP_META_REGION, s1, lane, lw);
+        wg_dp_refill_commit<NW>(refill, metaW, metaC, WG_DP_META_REGION, lane, lw);
+    } else if (s0 != 0) {
+        Mk = gs[0];
+        best = gs[1 + lane];
+        arg = (int32_t)__double_as_longlong(gs[65 + lane]);
+        asm volatile("" : "+v"(Mk), "+v"(best), "+v"(arg));
+    }
+    __syncthreads();
+    if (worker) {
+        wg_dp16_issue<NW>(r0, cb, metaW, metaC, 0, s0, lane, lw);
+        wg_dp16_commit<NW>(r0, slots, lane, lw);
+        if (1 < nb) wg_dp16_issue<NW>(r1, cb, metaW, metaC, 1 * BL, s0 + 1 * BL, lane, lw);
+        if (2 < nb) wg_dp16_issue<NW>(r2, cb, metaW, metaC, 2 * BL, s0 + 2 * BL, lane, lw);
+        if (3 < nb) wg_dp16_issue<NW>(r3, cb, metaW, metaC, 3 * BL, s0 + 3 * BL, lane, lw);
+        if (4 < nb) wg_dp16_issue<NW>(r0, cb, metaW, metaC, 4 * BL, s0 + 4 * BL, lane, lw);
+    }
+    __syncthreads();
+
+    const uint32_t ninf_hi = 0xfff00000u;
+    uint32_t tbk = 0;
+    // one batch: Q = b mod 4 (compile time): the batch's first step sits on lane 16 Q; the set holding batch b+1 is (Q+1) mod 4
+#define WG_DP16_BATCH(Q, RNEXT)                                                                                            \
+    if (b4 + (Q) < nb) {                                                                                                   \
+        const int b = b4 + (Q);                                                                                            \
+        if (worker) {                                                                                                      \
+            if (b >= RB && b % RB == 0)      wg_dp_refill_issue<NW>(refill, Wp, Cp, cum0, s0 + (b / RB + 1) * WG_DP_META_REGION, s1, lane, lw); \
+            else if (b > RB && b % RB == 1)  wg_dp_refill_commit<NW>(refill, metaW, metaC, (b / RB + 1) * WG_DP_META_REGION, lane, lw); \
+            if (b + 1 < nb) wg_dp16_commit<NW>(RNEXT, slots + (size_t)((b + 1) & 1) * (BL * 64), lane, lw);                   \
+            if (b + 1 + D < nb) wg_dp16_issue<NW>(RNEXT, cb, metaW, metaC, (b + 1 + D) * BL, s0 + (b + 1 + D) * BL, lane, lw); \
+        } else {                                                                                                           \
+            const double* my = slots + (size_t)(b & 1) * (BL * 64) + lane;                                                 \
+            double ra[8], rb[8];                                                                                           \
+            _Pragma("unroll") for (int u = 0; u < 8; u++) { ra[u] = my[u * 64]; rb[u] = my[(8 + u) * 64]; }                \
+            double Ms = wg_readlane_f64(Mk, 0);   /* M[k] is wave-uniform: the asm blocks want it in scalar registers */   \
+            wg_dp_group64<16 * (Q), 0>(best, arg, tbk, Ms, ra, ninf_hi);                                                   \
+            wg_dp_group64<16 * (Q) + 8, 1>(best, arg, tbk, Ms, rb, ninf_hi);                                               \
+            Mk = Ms;                                                                                                       \
+        }                                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                    \
+    }
+    for (int b4 = 0; b4 < nb; b4 += 4) {
+        WG_DP16_BATCH(0, r1) WG_DP16_BATCH(1, r2) WG_DP16_BATCH(2, r3) WG_DP16_BATCH(3, r0)
+        if (!worker) {
+            // the 64 lanes of tbk now hold the source lanes of the steps s0 + 16 b4 + lane (those that ran)
+            const int i = s0 + b4 * BL + lane;
+            const uint32_t len = (((uint32_t)lane - tbk) & 63u) + 1u;
+            if (i < s1) J.back16[cd.site_off + i] = (uint16_t)len;
+            tbk = 0;
+        }
+    }
+#undef WG_DP16_BATCH
+    if (!worker && s1 < cd.len) {
+        if (lane == 0) gs[0] = Mk;
+        gs[1 + lane] = best;
+        gs[65 + lane] = __longlong_as_double((long long)arg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_trace / k_border_offsets / k_gather_borders
 // ------------------------------------------------------------------------------------------------------------
 // k_trace: one workgroup per chunk walks T[] back from the chunk's end (segmentor.cpp:50-58) and leaves the borders in
@@ -1505,80 +1656,164 @@ __device__ __forceinline__ void wg_block_sum_store(void* __restrict__ out, int64
     }
 }
 
+template <int ELEM>
+__device__ __noinline__ uint4 wg_bs_load_tail(const uint8_t* __restrict__ row, int64_t site, int64_t n_total)
+{
+    // the last vector of a row: sites beyond n_total read as zero (rare: once per row)
+    constexpr int SPL = ELEM == 1 ? 8 : 4;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (int j = 0; j < SPL; j++) if (site + j < n_total) {
+        if (ELEM == 1) w[j >> 1] |= ((uint32_t)row[2 * (site + j)] | ((uint32_t)row[2 * (site + j) + 1] << 8)) << (16 * (j & 1));
+        else w[j] = (uint32_t)reinterpret_cast<const uint16_t*>(row)[2 * (site + j)] | ((uint32_t)reinterpret_cast<const uint16_t*>(row)[2 * (site + j) + 1] << 16);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+#define WG_BS_RUN 8            // consecutive tiles streamed by one workgroup
+
+template <int ELEM>
+struct BsTile {                // one tile's inputs in registers: the sample bytes, and the first 128 block descriptors
+    static constexpr int SPL = ELEM == 1 ? 8 : 4;              // sites per lane and pass (16 bytes)
+    static constexpr int SPP = 64 * SPL;                       // sites per pass of the wavefront
+    static constexpr int NPASS = WG_BS_TILE / SPP;
+    static constexpr int MAXQ = ELEM == 1 ? 2 : 1;             // samples per wave
+    uint4 v[MAXQ][NPASS];
+    int32_t b0, b1, xa0, xa1, xb0, xb1, ra, rb;
+};
+
 template <int ELEM>           // bytes per count: 1 = .beta / .bin (uint8 pairs), 2 = .lbeta (uint16 pairs)
 __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restrict__ betas, int64_t pitch, int64_t n_total,
                                                          const int32_t* __restrict__ x0s, const int32_t* __restrict__ x1s,
                                                          const int32_t* __restrict__ perm, const int32_t* __restrict__ tile_first,
-                                                         int64_t n_blocks, int n_samples, int spw, int mode, uint32_t min_cov,
+                                                         int64_t n_tiles, int64_t n_blocks, int n_samples, int spw, int mode, uint32_t min_cov,
                                                          void* __restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) uint2 E[WG_BLOCK / 64][WG_BS_TILE + 8];     // per wave: exclusive prefixes of its sample's tile
+    // per wave: exclusive prefixes of the tile of the sample it is working on.  Waves never touch each other's row and a
+    // wave's LDS instructions execute in program order, so no workgroup barrier is needed anywhere in this kernel.
+    // uint8 rows: a lane's 8 sites are summed IN the lane as packed pairs (meth | cov << 16: 8 x 255 fits 16 bits, one add per
+    // site for both counts) and stored as such (PK), next to the lane's own base (BASE, from two wave scans): a prefix is
+    // BASE[x >> 3] + unpack(PK[x]).  uint16 rows (.lbeta) keep full 32-bit pairs per site (E).
+    constexpr int ROW_BYTES = ELEM == 1 ? (WG_BS_TILE + 8) * 4 + (WG_BS_TILE / 8 + 2) * 8 : (WG_BS_TILE + 8) * 8;
+    __shared__ __attribute__((aligned(16))) char lds[WG_BLOCK / 64][ROW_BYTES];
+    typedef BsTile<ELEM> T;
+    constexpr int SPL = T::SPL, SPP = T::SPP, NPASS = T::NPASS, MAXQ = T::MAXQ;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t tile = blockIdx.x;
-    const int b0 = tile_first[tile], b1 = tile_first[tile + 1];
-    if (b0 == b1) return;                                          // no block starts here (the whole workgroup leaves)
-    const int64_t lo = tile * WG_BS_TILE;
-    const int64_t hi = lo + WG_BS_TILE < n_total ? lo + WG_BS_TILE : n_total;
-    const int nt = (int)(hi - lo);
-    constexpr int SPL = ELEM == 1 ? 8 : 4;                         // sites per lane and pass (16 bytes)
-    constexpr int SPP = 64 * SPL;                                  // sites per pass of the wavefront
-    uint2* Ew = E[wv];
-    for (int q = 0; q < spw; q++) {
-        const int s = ((int)blockIdx.y * (WG_BLOCK / 64) + wv) * spw + q;
-        const bool live = s < n_samples;                           // (no early exit: the barriers below are workgroup-wide)
-        const uint8_t* row = betas + (int64_t)(live ? s : 0) * pitch;
-        uint32_t run_m = 0, run_c = 0;
-        for (int base = 0; base < nt; base += SPP) {
-            const int64_t site = lo + base + (int64_t)lane * SPL;
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-            if (live && site < hi) {
-                if (site + SPL <= n_total) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(row + (size_t)site * 2 * ELEM);
-                    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-                } else {
-                    for (int j = 0; j < SPL; j++) if (site + j < n_total) {
-                        if (ELEM == 1) w[j >> 1] |= ((uint32_t)row[2 * (site + j)] | ((uint32_t)row[2 * (site + j) + 1] << 8)) << (16 * (j & 1));
-                        else w[j] = (uint32_t)reinterpret_cast<const uint16_t*>(row)[2 * (site + j)] | ((uint32_t)reinterpret_cast<const uint16_t*>(row)[2 * (site + j) + 1] << 16);
-                    }
+    uint2* Ew = reinterpret_cast<uint2*>(lds[wv]);                                        // (uint16 rows)
+    uint32_t* PK = reinterpret_cast<uint32_t*>(lds[wv]);                                  // (uint8 rows) [TILE + 8]
+    uint2* BASE = reinterpret_cast<uint2*>(lds[wv] + (WG_BS_TILE + 8) * 4);               // (uint8 rows) [TILE / 8 + 1]
+    const int s_first = ((int)blockIdx.y * (WG_BLOCK / 64) + wv) * spw;
+    if (s_first >= n_samples) return;
+    const int64_t t_first = (int64_t)blockIdx.x * WG_BS_RUN;
+
+    // everything a tile needs, requested in one go (nothing is waited for here)
+    auto issue = [&](T& R, int64_t tile) {
+        R.b0 = R.b1 = 0;
+        if (tile >= n_tiles) return;
+        R.b0 = tile_first[tile]; R.b1 = tile_first[tile + 1];
+        if (R.b0 == R.b1) return;                                  // no block starts in this tile: nothing to read
+        const int64_t lo = tile * WG_BS_TILE;
+        const int64_t hi = lo + WG_BS_TILE < n_total ? lo + WG_BS_TILE : n_total;
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+            const int s = s_first + q;
+            const uint8_t* row = betas + (int64_t)(s < n_samples ? s : 0) * pitch;
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                const int64_t site = lo + p * SPP + (int64_t)lane * SPL;
+                R.v[q][p] = make_uint4(0u, 0u, 0u, 0u);
+                if (q < spw && s < n_samples && site < hi) {
+                    if (site + SPL <= n_total) R.v[q][p] = *reinterpret_cast<const uint4*>(row + (size_t)site * 2 * ELEM);
+                    else R.v[q][p] = wg_bs_load_tail<ELEM>(row, site, n_total);
                 }
             }
-            uint32_t m[SPL], c[SPL], tm = 0, tc = 0;
-#pragma unroll
-            for (int j = 0; j < SPL; j++) {
-                if (ELEM == 1) { const uint32_t h = w[j >> 1] >> (16 * (j & 1)); m[j] = h & 0xffu; c[j] = (h >> 8) & 0xffu; }
-                else { m[j] = w[j] & 0xffffu; c[j] = w[j] >> 16; }
-                tm += m[j]; tc += c[j];
-            }
-            const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
-            uint32_t em = run_m + (im - tm), ec = run_c + (ic - tc);
-            uint2 e[SPL];
-#pragma unroll
-            for (int j = 0; j < SPL; j++) { e[j] = make_uint2(em, ec); em += m[j]; ec += c[j]; }
-            uint4* dst = reinterpret_cast<uint4*>(Ew + base + lane * SPL);                    // 16-byte stores, lane-contiguous
-#pragma unroll
-            for (int j = 0; j < SPL; j += 2) dst[j >> 1] = make_uint4(e[j].x, e[j].y, e[j + 1].x, e[j + 1].y);
-            run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
-            run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
         }
-        // entries past the tile's last site hold the tile total already (sites beyond `hi` were read as zeros) when the
-        // last pass covered them; make E[nt] right in every case
-        if (lane == 0) Ew[nt] = make_uint2(run_m, run_c);
-        __syncthreads();
-        if (live) {
-            for (int b = b0 + lane; b < b1; b += 64) {
-                const int64_t x0 = x0s[b], x1 = x1s[b];
+        const int ba = R.b0 + lane, bb = R.b0 + 64 + lane;
+        R.xa0 = ba < R.b1 ? x0s[ba] : 0; R.xa1 = ba < R.b1 ? x1s[ba] : 0;
+        R.xb0 = bb < R.b1 ? x0s[bb] : 0; R.xb1 = bb < R.b1 ? x1s[bb] : 0;
+        R.ra = ba < R.b1 ? (perm ? perm[ba] : ba) : 0; R.rb = bb < R.b1 ? (perm ? perm[bb] : bb) : 0;
+    };
+    auto compute = [&](const T& R, int64_t tile) {
+        if (R.b0 == R.b1) return;                                  // wave-uniform
+        const int64_t lo = tile * WG_BS_TILE;
+        const int64_t hi = lo + WG_BS_TILE < n_total ? lo + WG_BS_TILE : n_total;
+        const int b0 = R.b0, b1 = R.b1;
+#pragma unroll
+        for (int q = 0; q < MAXQ; q++) {
+            const int s = s_first + q;
+            if (q >= spw || s >= n_samples) break;                 // wave-uniform
+            const uint8_t* row = betas + (int64_t)s * pitch;
+            uint32_t run_m = 0, run_c = 0;
+#pragma unroll
+            for (int p = 0; p < NPASS; p++) {
+                const uint32_t w[4] = {R.v[q][p].x, R.v[q][p].y, R.v[q][p].z, R.v[q][p].w};
+                if (ELEM == 1) {
+                    uint32_t e[8], acc = 0;                        // packed exclusive prefixes inside the lane
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        e[j] = acc;
+                        // site j as (meth | cov << 16): bytes (m, 0, c, 0) picked out of the dword that holds two sites
+                        acc += __builtin_amdgcn_perm(0u, w[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u);
+                    }
+                    const uint32_t tm = acc & 0xffffu, tc = acc >> 16;
+                    const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
+                    BASE[p * 64 + lane] = make_uint2(run_m + (im - tm), run_c + (ic - tc));
+                    uint4* dst = reinterpret_cast<uint4*>(PK + p * SPP + lane * 8);
+                    dst[0] = make_uint4(e[0], e[1], e[2], e[3]);
+                    dst[1] = make_uint4(e[4], e[5], e[6], e[7]);
+                    run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
+                    run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+                } else {
+                    uint32_t m[SPL], c[SPL], tm = 0, tc = 0;
+#pragma unroll
+                    for (int j = 0; j < SPL; j++) { m[j] = w[j] & 0xffffu; c[j] = w[j] >> 16; tm += m[j]; tc += c[j]; }
+                    const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
+                    uint32_t em = run_m + (im - tm), ec = run_c + (ic - tc);
+                    uint2 e[SPL];
+#pragma unroll
+                    for (int j = 0; j < SPL; j++) { e[j] = make_uint2(em, ec); em += m[j]; ec += c[j]; }
+                    uint4* dst = reinterpret_cast<uint4*>(Ew + p * SPP + lane * SPL);          // 16-byte stores, lane-contiguous
+#pragma unroll
+                    for (int j = 0; j < SPL; j += 2) dst[j >> 1] = make_uint4(e[j].x, e[j].y, e[j + 1].x, e[j + 1].y);
+                    run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
+                    run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+                }
+            }
+            if (lane == 0) {                                       // the entry of the tile's end (sites past `hi` were read as zeros)
+                if (ELEM == 1) { BASE[WG_BS_TILE / 8] = make_uint2(run_m, run_c); PK[WG_BS_TILE] = 0u; }
+                else Ew[WG_BS_TILE] = make_uint2(run_m, run_c);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            auto prefix = [&](int x) -> uint2 {                    // sums of the tile's sites before x
+                if (ELEM == 1) { const uint2 b = BASE[x >> 3]; const uint32_t k = PK[x]; return make_uint2(b.x + (k & 0xffffu), b.y + (k >> 16)); }
+                return Ew[x];
+            };
+            auto one = [&](int64_t x0, int64_t x1, int64_t r) {
                 uint64_t m = 0, c = 0;
                 if (x1 > x0) {
                     const int64_t e = x1 < hi ? x1 : hi;
-                    const uint2 pe = Ew[e - lo], ps = Ew[x0 - lo];
+                    const uint2 pe = prefix((int)(e - lo)), ps = prefix((int)(x0 - lo));
                     m = pe.x - ps.x; c = pe.y - ps.y;
                     if (x1 > hi) wg_direct_sum<ELEM>(row, hi, x1, n_total, m, c);
                 }
-                const int64_t r = perm ? (int64_t)perm[b] : (int64_t)b;
                 wg_block_sum_store(out, (int64_t)s * n_blocks + r, mode, min_cov, m, c);
-            }
+            };
+            if (b0 + lane < b1) one(R.xa0, R.xa1, R.ra);
+            if (b0 + 64 + lane < b1) one(R.xb0, R.xb1, R.rb);
+            for (int b = b0 + 128 + lane; b < b1; b += 64) one(x0s[b], x1s[b], perm ? (int64_t)perm[b] : (int64_t)b);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                                                       // reads done before the next row overwrites
         }
-        __syncthreads();
+    };
+    // stream the run of tiles: the next tile's bytes are in flight while this one is reduced
+    T A, B;
+    issue(A, t_first);
+#pragma unroll 1
+    for (int k = 0; k < WG_BS_RUN; k += 2) {
+        issue(B, t_first + k + 1);
+        compute(A, t_first + k);
+        issue(A, t_first + k + 2 < t_first + WG_BS_RUN ? t_first + k + 2 : n_tiles);
+        compute(B, t_first + k + 1);
     }
 }
 
@@ -1628,6 +1863,75 @@ __global__ __launch_bounds__(WG_BLOCK) void k_convert(const uint32_t* __restrict
         }
     }
     s_cpg[r] = sc; e_cpg[r] = ec;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_pat_count / k_pat_trim: a pat file -> (#meth, #cov) per CpG, the producer of the path's input (src/pat2beta/
+// stdin2beta.cpp:59-93 proc_line, :95-123 parse; utils_wgbs.py:277-290 trim_to_uint8).  A pat line is
+//     chr \t first CpG index \t pattern over {C, T, H, .} \t number of reads with that pattern [\t ...]
+// One thread per byte of a chunk of text (whole lines); the threads that sit on the first byte of a line parse it and
+// add `count` to the coverage of every site under a C / T / H and to the methylated count under C / H
+// (atomics on int32: reads overlap).  Reads that end before `start` or begin at or after `end` are skipped, sites outside
+// are ignored, empty lines are skipped (stdin2beta.cpp:75-78,:100).  A line with fewer than four fields or a non-numeric
+// site / count makes the reference give up ("failed calculating beta"): its offset is reported through `bad`.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool wg_parse_int(const char* __restrict__ t, int64_t& i, int64_t n, int64_t& val)
+{
+    // std::stoi: leading white space, an optional sign, at least one digit; anything after the digits is ignored
+    while (i < n && (t[i] == ' ' || (t[i] >= 9 && t[i] <= 13 && t[i] != '\n' && t[i] != '\t'))) i++;
+    bool neg = false;
+    if (i < n && (t[i] == '-' || t[i] == '+')) { neg = t[i] == '-'; i++; }
+    if (!(i < n && t[i] >= '0' && t[i] <= '9')) return false;
+    int64_t v = 0;
+    while (i < n && t[i] >= '0' && t[i] <= '9') { v = v * 10 + (t[i] - '0'); if (v > 0x7fffffffLL) return false; i++; }
+    val = neg ? -v : v;
+    return true;
+}
+
+__global__ __launch_bounds__(WG_BLOCK) void k_pat_count(const char* __restrict__ text, int64_t n, int64_t start, int64_t end,
+                                                        int32_t* __restrict__ meth, int32_t* __restrict__ cov, unsigned long long* bad,
+                                                        unsigned long long chunk_off)
+{
+    const int64_t p = (int64_t)blockIdx.x * WG_BLOCK + threadIdx.x;
+    if (p >= n) return;
+    if (!(p == 0 || text[p - 1] == '\n')) return;              // not the first byte of a line
+    if (text[p] == '\n') return;                                // empty line
+    int64_t i = p;
+    auto fail = [&]() { atomicMin(bad, chunk_off + (unsigned long long)p); };
+    while (i < n && text[i] != '\t' && text[i] != '\n') i++;   // field 1: chromosome
+    if (i >= n || text[i] == '\n') return fail();
+    i++;
+    int64_t site = 0, count = 0;
+    if (!wg_parse_int(text, i, n, site)) return fail();        // field 2: index of the read's first CpG
+    while (i < n && text[i] != '\t' && text[i] != '\n') i++;
+    if (i >= n || text[i] == '\n') return fail();
+    i++;
+    const int64_t ps = i;                                       // field 3: the pattern
+    while (i < n && text[i] != '\t' && text[i] != '\n') i++;
+    if (i >= n || text[i] == '\n') return fail();
+    const int64_t plen = i - ps;
+    i++;
+    if (i >= n || text[i] == '\n' || text[i] == '\t') { if (i >= n || text[i] == '\n') return fail(); }   // an empty fourth field with more behind it: stoi throws
+    if (!wg_parse_int(text, i, n, count)) return fail();       // field 4: how many reads
+    if (site + plen - 1 < start || site >= end) return;        // stdin2beta.cpp:75-78
+    const int64_t nr = end - start;
+    for (int64_t k = 0; k < plen; k++) {
+        const int64_t x = site - start + k;
+        if (x < 0 || x >= nr) continue;
+        const char ch = text[ps + k];
+        if (!(ch == 'T' || ch == 'C' || ch == 'H')) continue;
+        atomicAdd(&cov[x], (int32_t)count);
+        if (ch != 'T') atomicAdd(&meth[x], (int32_t)count);
+    }
+}
+
+// counts -> .beta (uint8 pairs) or .lbeta (uint16 pairs): rows whose coverage exceeds the type's maximum M become
+// (trunc(meth / cov * M), M) (utils_wgbs.py:277-290; the same rule as modes 1 / 2 of the block reduction)
+__global__ __launch_bounds__(WG_BLOCK) void k_pat_trim(const int32_t* __restrict__ meth, const int32_t* __restrict__ cov, int64_t n, int lbeta, void* __restrict__ out)
+{
+    const int64_t x = (int64_t)blockIdx.x * WG_BLOCK + threadIdx.x;
+    if (x >= n) return;
+    wg_block_sum_store(out, x, lbeta ? 2 : 1, 0u, (uint64_t)(uint32_t)meth[x], (uint64_t)(uint32_t)cov[x]);
 }
 
 // ------------------------------------------------------------------------------------------------------------

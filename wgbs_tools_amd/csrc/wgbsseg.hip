@@ -413,7 +413,7 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
 
 int launch_scan(wgbsseg_ctx* c, const Job& job, int want_carry, char* err, size_t errlen)
 {
-    const int64_t rows = (int64_t)job.v.n_chunks * job.v.n_samples;
+    const int64_t rows = (int64_t)job.v.n_chunks * job.v.n_samples * WG_SCAN_PIECES;      // wave tasks
     const int64_t blocks = (rows + (WG_BLOCK / 64) - 1) / (WG_BLOCK / 64);
     if (blocks > 0x7fffffff) { set_err(err, errlen, "too many (chunk, sample) rows"); return WGBSSEG_E_ARG; }
     hipLaunchKernelGGL(k_scan, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, c->sA, job.v, c->status.as<JobStatus>(), want_carry);
@@ -694,7 +694,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     if (c->force_dp_mode > dp_mode) dp_mode = c->force_dp_mode;
     const int ringN = dp_mode ? ceil_pow2(Wmax + 128) : 0;
     const int64_t state_stride = round_up(WG_DP_STATE_HDR + (int64_t)ringN + (ringN + 1) / 2, 2);   // doubles per chunk
-    if (n_stages > 1 || dp_mode) HIP_TRY(c->dpstate.ensure((size_t)nC * (size_t)state_stride * 8));
+    HIP_TRY(c->dpstate.ensure((size_t)nC * (size_t)state_stride * 8));
     HIP_TRY(c->tmp_borders.ensure((size_t)(J + nC) * 4));
     HIP_TRY(c->nb.ensure((size_t)nC * 4));
     HIP_TRY(c->boff.ensure((size_t)(nC + 1) * 8));
@@ -732,7 +732,12 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         // worker waves per chunk, measured: 64-step batches (no window > 64): 7 (whole genome 3 -> 2.14 ms, 7 -> 1.77 ms,
         // 5 / 11 / 15 -> 2.8-3.1 ms); 32-step batches (islands): 3 (4.8 ms; 7 -> 5.8 ms).  WGBSSEG_DP_NW overrides (tests, tuning).
         static const int dp_nw = getenv("WGBSSEG_DP_NW") ? atoi(getenv("WGBSSEG_DP_NW")) : 0;
-        if (dp_mode == 0 && dp_nw == 3)      hipLaunchKernelGGL((k_dp<3, 64>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
+        // 16-step batches at the footprint of one scoring workgroup when the recurrence of a stage runs beside the scoring of
+        // the next one (WGBSSEG_DP16: 0 never, 1 always when windows allow; default: whenever the call is staged)
+        static const int dp16_env = getenv("WGBSSEG_DP16") ? atoi(getenv("WGBSSEG_DP16")) : -1;
+        const bool dp16 = dp_mode == 0 && (dp16_env < 0 ? n_stages > 1 : dp16_env != 0);
+        if (dp16)                            hipLaunchKernelGGL((k_dp16<3>), dim3((unsigned)nC), dim3(64 * 4), (size_t)(2 * 16 * 64 * 8 + WG_DP_META_RING * 6), c->sB, v, sv, cbuf, c->dpstate.as<double>(), state_stride);
+        else if (dp_mode == 0 && dp_nw == 3) hipLaunchKernelGGL((k_dp<3, 64>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else if (dp_mode == 0)               hipLaunchKernelGGL((k_dp<7, 64>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else if (dp_mode == 1 && dp_nw == 7) hipLaunchKernelGGL((k_dp<7, 32>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else if (dp_mode == 1)               hipLaunchKernelGGL((k_dp<3, 32>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
@@ -1293,17 +1298,18 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
     const int32_t* dperm = sorted ? nullptr : dx1 + n_blocks;
     const int32_t* dtf = dx1 + n_blocks + (sorted ? 0 : n_blocks);
     // samples per wavefront: enough workgroups to fill the chip, few enough that the block list is re-read rarely
-    int spw = 1;
-    while (spw < 4 && (int64_t)n_tiles * ((c->n_samples + 4 * spw - 1) / (4 * spw)) > 8192 && c->n_samples > 4 * spw) spw *= 2;
+    // samples per wavefront (the kernel keeps two tiles of each in registers, one being reduced, one in flight)
+    const int spw = (c->elem == 1 && c->n_samples > 4) ? 2 : 1;
+    const int64_t gx = (n_tiles + WG_BS_RUN - 1) / WG_BS_RUN;
     const unsigned gy = (unsigned)((c->n_samples + 4 * spw - 1) / (4 * spw));
     if (gy > 65535) { set_err(err, errlen, "too many samples for one block_sums call"); return WGBSSEG_E_ARG; }
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
     if (c->elem == 1)
-        hipLaunchKernelGGL(k_block_sums<1>, dim3((unsigned)n_tiles, gy), dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total,
-                           dx0, dx1, dperm, dtf, n_blocks, (int)c->n_samples, spw, (int)mode, min_cov, c->dbg_b.p);
+        hipLaunchKernelGGL(k_block_sums<1>, dim3((unsigned)gx, gy), dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total,
+                           dx0, dx1, dperm, dtf, n_tiles, n_blocks, (int)c->n_samples, spw, (int)mode, min_cov, c->dbg_b.p);
     else
-        hipLaunchKernelGGL(k_block_sums<2>, dim3((unsigned)n_tiles, gy), dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total,
-                           dx0, dx1, dperm, dtf, n_blocks, (int)c->n_samples, spw, (int)mode, min_cov, c->dbg_b.p);
+        hipLaunchKernelGGL(k_block_sums<2>, dim3((unsigned)gx, gy), dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total,
+                           dx0, dx1, dperm, dtf, n_tiles, n_blocks, (int)c->n_samples, spw, (int)mode, min_cov, c->dbg_b.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
     HIP_TRY(hipMemcpyAsync(out, c->dbg_b.p, obytes, hipMemcpyDeviceToHost, c->sA));
@@ -1374,6 +1380,111 @@ int wgbsseg_convert_regions(wgbsseg_ctx* c, const int64_t* chrom_lo, const int64
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->last_block_sums_ms = ms;                            // (shared "last auxiliary kernel" clock: wgbsseg_last_block_sums_ms)
+    return WGBSSEG_OK;
+}
+
+}  // extern "C"
+
+// pat -> beta accumulator: counts on one device, text chunks through two page-locked staging buffers so that the caller's
+// decompression of chunk k+1 overlaps the copy and the kernel of chunk k.
+struct wgbsseg_patbeta {
+    int device = 0;
+    hipStream_t st = nullptr;
+    int64_t start = 1, end = 1;
+    DevBuf meth, cov, text[2], outb, bad;
+    PinnedBuf stage[2];
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    int k = 0;
+    unsigned long long fed = 0;
+    double kernel_ms = 0.0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+extern "C" {
+
+int wgbsseg_patbeta_create(int device, int64_t start_cpg, int64_t end_cpg, wgbsseg_patbeta** out, char* err, size_t errlen)
+{
+    if (!out) { set_err(err, errlen, "out is NULL"); return WGBSSEG_E_ARG; }
+    *out = nullptr;
+    if (start_cpg < 1 || end_cpg <= start_cpg || end_cpg - start_cpg > 0x7fffffff) { set_err(err, errlen, "patbeta: bad CpG range [%lld, %lld)", (long long)start_cpg, (long long)end_cpg); return WGBSSEG_E_ARG; }
+    wgbsseg_ctx* probe = nullptr;                                 // device checks (gfx950, index) as for a segment context
+    int rc = wgbsseg_create(device, &probe, err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
+    wgbsseg_destroy(probe);
+    std::unique_ptr<wgbsseg_patbeta> p(new (std::nothrow) wgbsseg_patbeta());
+    if (!p) { set_err(err, errlen, "out of host memory"); return WGBSSEG_E_NOMEM; }
+    p->device = device; p->start = start_cpg; p->end = end_cpg;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
+    for (auto& e : p->ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&p->t0)); HIP_TRY(hipEventCreate(&p->t1));
+    const size_t nb = (size_t)(end_cpg - start_cpg) * 4;
+    HIP_TRY(p->meth.ensure(nb)); HIP_TRY(p->cov.ensure(nb)); HIP_TRY(p->bad.ensure(8));
+    HIP_TRY(hipMemsetAsync(p->meth.p, 0, nb, p->st));            // (the reference leaves its arrays uninitialised: stdin2beta.cpp:48-49)
+    HIP_TRY(hipMemsetAsync(p->cov.p, 0, nb, p->st));
+    HIP_TRY(hipMemsetAsync(p->bad.p, 0xff, 8, p->st));
+    *out = p.release();
+    return WGBSSEG_OK;
+}
+
+void wgbsseg_patbeta_destroy(wgbsseg_patbeta* p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->st) { (void)hipStreamSynchronize(p->st); }
+    for (DevBuf* b : {&p->meth, &p->cov, &p->text[0], &p->text[1], &p->outb, &p->bad}) b->release();
+    for (auto& s : p->stage) s.release();
+    for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
+    if (p->t0) (void)hipEventDestroy(p->t0);
+    if (p->t1) (void)hipEventDestroy(p->t1);
+    if (p->st) (void)hipStreamDestroy(p->st);
+    delete p;
+}
+
+int wgbsseg_patbeta_feed(wgbsseg_patbeta* p, const char* text, int64_t n_bytes, char* err, size_t errlen)
+{
+    if (!p || (n_bytes && !text) || n_bytes < 0) { set_err(err, errlen, "bad arguments to patbeta_feed"); return WGBSSEG_E_ARG; }
+    if (n_bytes == 0) return WGBSSEG_OK;
+    if (text[n_bytes - 1] != '\n') { set_err(err, errlen, "patbeta_feed: a chunk must end with a complete line"); return WGBSSEG_E_ARG; }
+    HIP_TRY(hipSetDevice(p->device));
+    const int k = p->k;
+    if (p->busy[k]) HIP_TRY(hipEventSynchronize(p->ev[k]));      // its previous chunk has been consumed
+    if (!p->stage[k].ensure((size_t)n_bytes)) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
+    HIP_TRY(p->text[k].ensure((size_t)n_bytes));
+    memcpy(p->stage[k].p, text, (size_t)n_bytes);
+    HIP_TRY(hipMemcpyAsync(p->text[k].p, p->stage[k].p, (size_t)n_bytes, hipMemcpyHostToDevice, p->st));
+    const int64_t gx = (n_bytes + WG_BLOCK - 1) / WG_BLOCK;
+    if (gx > 0x7fffffff) { set_err(err, errlen, "patbeta_feed: chunk too large"); return WGBSSEG_E_ARG; }
+    hipLaunchKernelGGL(k_pat_count, dim3((unsigned)gx), dim3(WG_BLOCK), 0, p->st, p->text[k].as<char>(), n_bytes, p->start, p->end,
+                       p->meth.as<int32_t>(), p->cov.as<int32_t>(), p->bad.as<unsigned long long>(), p->fed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(p->ev[k], p->st));
+    p->busy[k] = true;
+    p->k ^= 1;
+    p->fed += (unsigned long long)n_bytes;
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_patbeta_finish(wgbsseg_patbeta* p, int32_t lbeta, void* out, char* err, size_t errlen)
+{
+    if (!p || !out) { set_err(err, errlen, "bad arguments to patbeta_finish"); return WGBSSEG_E_ARG; }
+    HIP_TRY(hipSetDevice(p->device));
+    const int64_t n = p->end - p->start;
+    const size_t ob = (size_t)n * (lbeta ? 4 : 2);
+    HIP_TRY(p->outb.ensure(ob));
+    unsigned long long bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, p->bad.p, 8, hipMemcpyDeviceToHost, p->st));
+    HIP_TRY(hipStreamSynchronize(p->st));
+    if (bad != ~0ULL) {
+        set_err(err, errlen, "failed calculating beta: invalid line at byte offset %llu of the input (too few columns, or a site / count that is not a number)", bad);
+        return WGBSSEG_E_ARG;
+    }
+    hipLaunchKernelGGL(k_pat_trim, dim3((unsigned)((n + WG_BLOCK - 1) / WG_BLOCK)), dim3(WG_BLOCK), 0, p->st, p->meth.as<int32_t>(), p->cov.as<int32_t>(), n,
+                       (int)lbeta, p->outb.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, p->outb.p, ob, hipMemcpyDeviceToHost, p->st));
+    HIP_TRY(hipStreamSynchronize(p->st));
     return WGBSSEG_OK;
 }
 

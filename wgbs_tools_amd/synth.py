@@ -211,3 +211,23 @@ def write_genome(refdir, names, sizes, loci, gz=True):
     os.symlink('CpG.bed.gz', rev)          # init_genome.py:163-168: same file, second index
     np.asarray(loci, dtype=np.uint32).tofile(op.join(refdir, 'loci.u32'))
     return refdir
+
+
+def synth_pat_lines(seed, n_sites, n_reads, names=None, sizes=None):
+    """Lines of a synthetic pat file over CpGs 1..n_sites (pat2beta tests): `chr \t first CpG \t pattern \t count`, reads of 1-12
+    CpGs over {C, T, H, .}, counts 1-40, sorted by start as real pat files are; a few reads hang over the ends of the range."""
+    idx = np.arange(n_reads, dtype=np.int64)
+    h0 = hash_at(seed, 91, idx)
+    start = np.sort((h0 % np.uint64(n_sites + 6)).astype(np.int64) - 2)          # -2 .. n_sites + 3
+    h1 = hash_at(seed, 92, idx)
+    ln = 1 + (h1 & U64(15)).astype(np.int64) % 12
+    cnt = 1 + ((h1 >> U64(8)) % U64(40)).astype(np.int64)
+    cum = None if sizes is None else np.cumsum(sizes)
+    lines = []
+    alphabet = 'CCCTTTH.'
+    for i in range(n_reads):
+        hp = int(hash_at(seed, 93, np.array([i], dtype=np.int64))[0])
+        pat = ''.join(alphabet[(hp >> (3 * k)) & 7] for k in range(int(ln[i])))
+        chrom = 'chr1' if cum is None else names[int(np.searchsorted(cum, max(int(start[i]), 1), 'left').clip(0, len(names) - 1))]
+        lines.append('%s\t%d\t%s\t%d' % (chrom, start[i], pat, cnt[i]))
+    return lines
