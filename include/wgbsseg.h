@@ -192,6 +192,13 @@ int wgbsseg_group_plan(wgbsseg_group* g, const uint32_t* loci, int64_t n_sites, 
                        char* err, size_t errlen);
 int wgbsseg_group_load_host(wgbsseg_group* g, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites,
                             char* err, size_t errlen);
+/* The same upload without waiting for it: returns once the device rows exist; every share's bytes then arrive front to back
+ * on background threads (site-major: piece k of every sample before piece k+1 of any), and wgbsseg_group_segment_regions
+ * segments what is resident while the rest is on its way (the first batch of a share runs as a few sub-batches).  The
+ * sample buffers must stay valid until wgbsseg_group_segment_regions or wgbsseg_group_load_wait has returned. */
+int wgbsseg_group_load_host_async(wgbsseg_group* g, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites,
+                                  char* err, size_t errlen);
+int wgbsseg_group_load_wait(wgbsseg_group* g, char* err, size_t errlen);
 int wgbsseg_group_share_set_device(wgbsseg_group* g, int32_t share, const void* base, int64_t n_samples,
                                    int64_t pitch_bytes, char* err, size_t errlen);
 int wgbsseg_group_segment_regions(wgbsseg_group* g, int32_t* borders_out, int64_t borders_cap, int64_t* borders_off,

@@ -269,6 +269,7 @@ def test_native_add_loci_rows_and_errors(tmp_path):
     cases = [((np.array([3, 9, 8]), np.array([5, 8, 9])), '[wt add_loci] line 1: endCpG < startCpG'),
              ((np.array([3, 0]), np.array([5, 4])), '[wt add_loci] line 1: startCpG < 1'),
              ((np.array([69990]), np.array([70005])), '[wt add_loci] line 0: Cross chromosomes'),
+             ((np.array([n + 1]), np.array([n + 1])), '[ cpg_dict ] Could not find chromosome for site: %d' % (n + 1)),   # a START on nr_sites + 1: the reference reads past its loci here
              ((np.array([n + 2]), np.array([n + 3])), '[ cpg_dict ] Could not find chromosome for site: %d' % (n + 2))]
     for (bs, be), msg in cases:
         with pytest.raises(_lib.SegmentorError) as ei:

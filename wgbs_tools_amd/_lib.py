@@ -25,7 +25,7 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_group_plan', 'wgbsseg_group_load_host', 'wgbsseg_group_share_set_device', 'wgbsseg_group_segment_regions',
            'wgbsseg_group_get_timings', 'wgbsseg_plan_shares', 'wgbsseg_set_lbetas_host',
            'wgbsseg_convert_regions', 'wgbsseg_patbeta_create', 'wgbsseg_patbeta_feed', 'wgbsseg_patbeta_finish',
-           'wgbsseg_patbeta_destroy']
+           'wgbsseg_patbeta_destroy', 'wgbsseg_group_load_host_async', 'wgbsseg_group_load_wait']
 
 
 class NativeLibraryError(RuntimeError):
@@ -161,6 +161,10 @@ def load():
     L.wgbsseg_group_plan.argtypes = [vp, vp, i64, vp, vp, i64, i64, C.POINTER(Params), i64, vp, vp, vp, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_group_load_host.restype = i32
     L.wgbsseg_group_load_host.argtypes = [vp, C.POINTER(vp), i64, i64, C.c_char_p, C.c_size_t]
+    L.wgbsseg_group_load_host_async.restype = i32
+    L.wgbsseg_group_load_host_async.argtypes = [vp, C.POINTER(vp), i64, i64, C.c_char_p, C.c_size_t]
+    L.wgbsseg_group_load_wait.restype = i32
+    L.wgbsseg_group_load_wait.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_group_share_set_device.restype = i32
     L.wgbsseg_group_share_set_device.argtypes = [vp, i32, vp, i64, i64, C.c_char_p, C.c_size_t]
     L.wgbsseg_group_segment_regions.restype = i32
@@ -536,13 +540,23 @@ class SegmenterGroup:
         self.windows = dict(win_lo=lo, win_hi=hi, chunks=ch, work=wk)
         return self.windows
 
-    def load_host(self, samples):
-        """samples: whole-genome uint8 arrays (np.memmap of .beta files work); every share uploads only its window."""
+    def load_host(self, samples, wait=True):
+        """samples: whole-genome uint8 arrays (np.memmap of .beta files work); every share uploads only its window.
+        wait=False: the upload runs in the background and segment_regions() starts on what has arrived (the arrays are kept
+        alive here until then)."""
         arrs = [s if isinstance(s, np.ndarray) and s.dtype == np.uint8 and s.ndim == 1 else np.ascontiguousarray(s, dtype=np.uint8).reshape(-1)
                 for s in samples]
         assert all(a.size == 2 * self.n_sites for a in arrs), 'every sample must hold 2 bytes per site of the planned genome'
         ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
-        _check(self._L.wgbsseg_group_load_host(self._h, ptrs, len(arrs), self.n_sites, self._err, ERRLEN), self._err)
+        if wait:
+            _check(self._L.wgbsseg_group_load_host(self._h, ptrs, len(arrs), self.n_sites, self._err, ERRLEN), self._err)
+        else:
+            self._streaming = arrs
+            _check(self._L.wgbsseg_group_load_host_async(self._h, ptrs, len(arrs), self.n_sites, self._err, ERRLEN), self._err)
+
+    def load_wait(self):
+        _check(self._L.wgbsseg_group_load_wait(self._h, self._err, ERRLEN), self._err)
+        self._streaming = None
 
     def share_set_device(self, share, data_ptr, n_samples, pitch_bytes, keepalive=None):
         _check(self._L.wgbsseg_group_share_set_device(self._h, int(share), C.c_void_p(int(data_ptr)), int(n_samples), int(pitch_bytes),
@@ -556,8 +570,13 @@ class SegmenterGroup:
         n = self.n_regions
         off = np.empty(n + 1, dtype=np.int64)
         stats = np.zeros(8, dtype=np.int64)
-        _check(self._L.wgbsseg_group_segment_regions(self._h, out.ctypes.data, out.size, off.ctypes.data, stats.ctypes.data,
-                                                     self._err, ERRLEN), self._err)
+        try:
+            _check(self._L.wgbsseg_group_segment_regions(self._h, out.ctypes.data, out.size, off.ctypes.data, stats.ctypes.data,
+                                                         self._err, ERRLEN), self._err)
+        finally:
+            if getattr(self, '_streaming', None) is not None:
+                self._L.wgbsseg_group_load_wait(self._h, None, 0)      # (already collected on success; a failed call may have left uploaders running)
+                self._streaming = None
         res = [out[off[r]:off[r + 1]].astype(np.int64) if copy else out[off[r]:off[r + 1]] for r in range(n)]
         return res, _stats_dict(stats)
 

@@ -1670,12 +1670,15 @@ __device__ __noinline__ uint4 wg_bs_load_tail(const uint8_t* __restrict__ row, i
 }
 
 #define WG_BS_RUN 8            // consecutive tiles streamed by one workgroup
+#define WG_BS_OVER 128         // sites behind a tile's end that are staged with it: a block that starts in the tile and ends within
+                               // them (almost every tile's last block) is still two LDS reads; no global load sits in the reduction
+                               // of the common case, where it would have to wait for the NEXT tile's prefetch as well
 
 template <int ELEM>
 struct BsTile {                // one tile's inputs in registers: the sample bytes, and the first 128 block descriptors
     static constexpr int SPL = ELEM == 1 ? 8 : 4;              // sites per lane and pass (16 bytes)
     static constexpr int SPP = 64 * SPL;                       // sites per pass of the wavefront
-    static constexpr int NPASS = WG_BS_TILE / SPP;
+    static constexpr int NPASS = WG_BS_TILE / SPP + 1;         // + one short pass over the WG_BS_OVER sites behind the tile
     static constexpr int MAXQ = ELEM == 1 ? 2 : 1;             // samples per wave
     uint4 v[MAXQ][NPASS];
     int32_t b0, b1, xa0, xa1, xb0, xb1, ra, rb;
@@ -1693,14 +1696,15 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
     // uint8 rows: a lane's 8 sites are summed IN the lane as packed pairs (meth | cov << 16: 8 x 255 fits 16 bits, one add per
     // site for both counts) and stored as such (PK), next to the lane's own base (BASE, from two wave scans): a prefix is
     // BASE[x >> 3] + unpack(PK[x]).  uint16 rows (.lbeta) keep full 32-bit pairs per site (E).
-    constexpr int ROW_BYTES = ELEM == 1 ? (WG_BS_TILE + 8) * 4 + (WG_BS_TILE / 8 + 2) * 8 : (WG_BS_TILE + 8) * 8;
+    constexpr int EXT = WG_BS_TILE + WG_BS_OVER;                   // sites staged per tile
+    constexpr int ROW_BYTES = ELEM == 1 ? (EXT + 8) * 4 + (EXT / 8 + 2) * 8 : (EXT + 8) * 8;
     __shared__ __attribute__((aligned(16))) char lds[WG_BLOCK / 64][ROW_BYTES];
     typedef BsTile<ELEM> T;
     constexpr int SPL = T::SPL, SPP = T::SPP, NPASS = T::NPASS, MAXQ = T::MAXQ;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint2* Ew = reinterpret_cast<uint2*>(lds[wv]);                                        // (uint16 rows)
     uint32_t* PK = reinterpret_cast<uint32_t*>(lds[wv]);                                  // (uint8 rows) [TILE + 8]
-    uint2* BASE = reinterpret_cast<uint2*>(lds[wv] + (WG_BS_TILE + 8) * 4);               // (uint8 rows) [TILE / 8 + 1]
+    uint2* BASE = reinterpret_cast<uint2*>(lds[wv] + (EXT + 8) * 4);                      // (uint8 rows) [EXT / 8 + 1]
     const int s_first = ((int)blockIdx.y * (WG_BLOCK / 64) + wv) * spw;
     if (s_first >= n_samples) return;
     const int64_t t_first = (int64_t)blockIdx.x * WG_BS_RUN;
@@ -1712,7 +1716,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
         R.b0 = tile_first[tile]; R.b1 = tile_first[tile + 1];
         if (R.b0 == R.b1) return;                                  // no block starts in this tile: nothing to read
         const int64_t lo = tile * WG_BS_TILE;
-        const int64_t hi = lo + WG_BS_TILE < n_total ? lo + WG_BS_TILE : n_total;
+        const int64_t hi = lo + EXT < n_total ? lo + EXT : n_total;          // staged sites [lo, hi)
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
             const int s = s_first + q;
@@ -1721,7 +1725,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
             for (int p = 0; p < NPASS; p++) {
                 const int64_t site = lo + p * SPP + (int64_t)lane * SPL;
                 R.v[q][p] = make_uint4(0u, 0u, 0u, 0u);
-                if (q < spw && s < n_samples && site < hi) {
+                if (q < spw && s < n_samples && site < hi && (p < NPASS - 1 || lane * SPL < WG_BS_OVER)) {
                     if (site + SPL <= n_total) R.v[q][p] = *reinterpret_cast<const uint4*>(row + (size_t)site * 2 * ELEM);
                     else R.v[q][p] = wg_bs_load_tail<ELEM>(row, site, n_total);
                 }
@@ -1735,7 +1739,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
     auto compute = [&](const T& R, int64_t tile) {
         if (R.b0 == R.b1) return;                                  // wave-uniform
         const int64_t lo = tile * WG_BS_TILE;
-        const int64_t hi = lo + WG_BS_TILE < n_total ? lo + WG_BS_TILE : n_total;
+        const int64_t hi = lo + EXT < n_total ? lo + EXT : n_total;          // staged sites [lo, hi)
         const int b0 = R.b0, b1 = R.b1;
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
@@ -1756,10 +1760,12 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
                     }
                     const uint32_t tm = acc & 0xffffu, tc = acc >> 16;
                     const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
-                    BASE[p * 64 + lane] = make_uint2(run_m + (im - tm), run_c + (ic - tc));
-                    uint4* dst = reinterpret_cast<uint4*>(PK + p * SPP + lane * 8);
-                    dst[0] = make_uint4(e[0], e[1], e[2], e[3]);
-                    dst[1] = make_uint4(e[4], e[5], e[6], e[7]);
+                    if (p < NPASS - 1 || lane * 8 < WG_BS_OVER) {              // (the short pass: its first lanes only)
+                        BASE[p * 64 + lane] = make_uint2(run_m + (im - tm), run_c + (ic - tc));
+                        uint4* dst = reinterpret_cast<uint4*>(PK + p * SPP + lane * 8);
+                        dst[0] = make_uint4(e[0], e[1], e[2], e[3]);
+                        dst[1] = make_uint4(e[4], e[5], e[6], e[7]);
+                    }
                     run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
                     run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
                 } else {
@@ -1771,16 +1777,18 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
                     uint2 e[SPL];
 #pragma unroll
                     for (int j = 0; j < SPL; j++) { e[j] = make_uint2(em, ec); em += m[j]; ec += c[j]; }
-                    uint4* dst = reinterpret_cast<uint4*>(Ew + p * SPP + lane * SPL);          // 16-byte stores, lane-contiguous
+                    if (p < NPASS - 1 || lane * SPL < WG_BS_OVER) {
+                        uint4* dst = reinterpret_cast<uint4*>(Ew + p * SPP + lane * SPL);      // 16-byte stores, lane-contiguous
 #pragma unroll
-                    for (int j = 0; j < SPL; j += 2) dst[j >> 1] = make_uint4(e[j].x, e[j].y, e[j + 1].x, e[j + 1].y);
+                        for (int j = 0; j < SPL; j += 2) dst[j >> 1] = make_uint4(e[j].x, e[j].y, e[j + 1].x, e[j + 1].y);
+                    }
                     run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
                     run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
                 }
             }
             if (lane == 0) {                                       // the entry of the tile's end (sites past `hi` were read as zeros)
-                if (ELEM == 1) { BASE[WG_BS_TILE / 8] = make_uint2(run_m, run_c); PK[WG_BS_TILE] = 0u; }
-                else Ew[WG_BS_TILE] = make_uint2(run_m, run_c);
+                if (ELEM == 1) { BASE[EXT / 8] = make_uint2(run_m, run_c); PK[EXT] = 0u; }
+                else Ew[EXT] = make_uint2(run_m, run_c);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -944,6 +944,17 @@ struct wgbsseg_group {
     wgbsseg_params P = {};
     bool planned = false;
     std::vector<char> loaded;
+    // streaming upload (wgbsseg_group_load_host_async): one uploader per share; `ready` = sites of the share's window that are
+    // resident for EVERY sample, counted from the window's first site
+    struct Loader {
+        std::thread th;
+        std::atomic<int64_t> ready{0};
+        std::atomic<int> finished{0};
+        int rc = WGBSSEG_OK;
+        std::string msg;
+    };
+    std::vector<std::unique_ptr<Loader>> loaders;
+    bool streaming = false;
 };
 
 namespace {
@@ -973,6 +984,77 @@ void parallel_for(int64_t n, int max_threads, F f)
 
 }  // namespace
 
+namespace {
+
+// Site-major upload of `n_rows` pageable rows: pieces of `piece` bytes go out in the order (piece 0 of every row, piece 1 of
+// every row, ...) on T host threads, each with its own stream and two page-locked staging buffers; `ready_sites` follows
+// the longest prefix of every row that is known to be resident, in sites of 2 bytes (a piece counts once its DMA has completed).
+int upload_rows_streaming(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const uint8_t* const* rows, int64_t n_rows, int64_t row_bytes,
+                          std::atomic<int64_t>& ready_sites, std::string& msg)
+{
+    const double t0 = wall_s();
+    int64_t piece = 2 << 20;
+    { const char* e = getenv("WGBSSEG_UPLOAD_PIECE_KB"); if (e && atoi(e) >= 64) piece = (int64_t)atoi(e) << 10; }
+    const int64_t ppr = (row_bytes + piece - 1) / piece, n_tasks = ppr * n_rows;
+    int T = 4;
+    { const char* e = getenv("WGBSSEG_UPLOAD_THREADS"); if (e && atoi(e) > 0) T = atoi(e); }
+    T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(T, 64), n_tasks));
+    std::vector<std::atomic<int>> rows_done((size_t)ppr);
+    for (auto& x : rows_done) x.store(0);
+    std::atomic<int64_t> next(0), pieces_done(0);
+    std::mutex mu;
+    std::vector<hipError_t> terr((size_t)T, hipSuccess);
+    auto complete = [&](int64_t task) {                          // task = p * n_rows + r: row r's piece p is on the device
+        const int64_t p = task / n_rows;
+        if (rows_done[(size_t)p].fetch_add(1) + 1 == (int)n_rows) {
+            std::lock_guard<std::mutex> lk(mu);
+            int64_t d = pieces_done.load();
+            while (d < ppr && rows_done[(size_t)d].load() == (int)n_rows) d++;
+            pieces_done.store(d);
+            ready_sites.store(std::min<int64_t>(d * piece, row_bytes) / 2);
+        }
+    };
+    auto worker = [&](int t) {
+        hipError_t e = hipSetDevice(c->device);
+        hipStream_t st = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        void* stg[2] = {nullptr, nullptr};
+        int64_t task_of[2] = {-1, -1};
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipHostMalloc(&stg[k], (size_t)piece, hipHostMallocDefault);
+        int k = 0;
+        while (e == hipSuccess) {
+            const int64_t it = next.fetch_add(1);
+            if (it >= n_tasks) break;
+            const int64_t p = it / n_rows, r = it % n_rows, o = p * piece, b = std::min<int64_t>(piece, row_bytes - o);
+            if (task_of[k] >= 0) { e = hipEventSynchronize(ev[k]); if (e != hipSuccess) break; complete(task_of[k]); task_of[k] = -1; }
+            memcpy(stg[k], rows[r] + o, (size_t)b);
+            e = hipMemcpyAsync(dst + r * dst_pitch + o, stg[k], (size_t)b, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipEventRecord(ev[k], st);
+            task_of[k] = it;
+            k ^= 1;
+        }
+        for (int q = 0; q < 2 && e == hipSuccess; q++, k ^= 1)
+            if (task_of[k] >= 0) { e = hipEventSynchronize(ev[k]); if (e == hipSuccess) complete(task_of[k]); task_of[k] = -1; }
+        if (st) (void)hipStreamDestroy(st);
+        for (auto& x : ev) if (x) (void)hipEventDestroy(x);
+        for (auto& x : stg) if (x) (void)hipHostFree(x);
+        terr[(size_t)t] = e;
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++) th.emplace_back(worker, t);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < T; t++)
+        if (terr[(size_t)t] != hipSuccess) { msg = std::string("HIP error during the upload: ") + hipGetErrorString(terr[(size_t)t]); return WGBSSEG_E_HIP; }
+    ready_sites.store(row_bytes / 2);
+    if (profiling()) fprintf(stderr, "[wgbsseg] betas to the device (streaming): %.1f ms, %.1f GB/s (%d upload threads)\n", (wall_s() - t0) * 1e3,
+                             (double)row_bytes * n_rows / (wall_s() - t0) * 1e-9, T);
+    return WGBSSEG_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int wgbsseg_group_create(const int32_t* devices, int32_t n_shares, wgbsseg_group** out, char* err, size_t errlen)
@@ -993,9 +1075,12 @@ int wgbsseg_group_create(const int32_t* devices, int32_t n_shares, wgbsseg_group
     return WGBSSEG_OK;
 }
 
+void group_join_loaders(wgbsseg_group* g);
+
 void wgbsseg_group_destroy(wgbsseg_group* g)
 {
     if (!g) return;
+    group_join_loaders(g);
     // releasing gigabytes of device buffers takes milliseconds per context: do the shares side by side
     parallel_for((int64_t)g->shares.size(), 64, [&](int64_t d) { wgbsseg_destroy(g->shares[(size_t)d]); });
     delete g;
@@ -1020,10 +1105,14 @@ int wgbsseg_plan_shares(const uint32_t* loci, int64_t n_sites, const int64_t* re
         if (r && a < region_end[r - 1]) { set_err(err, errlen, "plan_shares: regions must be ascending and disjoint"); return WGBSSEG_E_ARG; }
         for (int64_t s0 = a; s0 < b; s0 += chunk_size) cks.push_back({s0 - 1, std::min(s0 + chunk_size, b) - 1, 0});
     }
-    parallel_for((int64_t)cks.size(), 32, [&](int64_t i) {
-        Ck& c = cks[(size_t)i];
-        c.w = chunk_work(loci, c.lo, c.hi, P->max_cpg, P->max_bp) + 4 * (c.hi - c.lo);     // + the per-site passes (scan, windows, recurrence)
-    });
+    if (G == 1) {
+        for (auto& c : cks) c.w = c.hi - c.lo;                  // nothing to balance: do not walk the loci
+    } else {
+        parallel_for((int64_t)cks.size(), 32, [&](int64_t i) {
+            Ck& c = cks[(size_t)i];
+            c.w = chunk_work(loci, c.lo, c.hi, P->max_cpg, P->max_bp) + 4 * (c.hi - c.lo);     // + the per-site passes (scan, windows, recurrence)
+        });
+    }
     int64_t total = 0;
     for (auto& c : cks) total += c.w;
     if (halo < 0) halo = std::max<int64_t>(chunk_size, 4096);
@@ -1112,6 +1201,62 @@ int wgbsseg_group_load_host(wgbsseg_group* g, const uint8_t* const* samples, int
     return WGBSSEG_OK;
 }
 
+void group_join_loaders(wgbsseg_group* g)
+{
+    for (auto& l : g->loaders) if (l && l->th.joinable()) l->th.join();
+}
+
+int wgbsseg_group_load_host_async(wgbsseg_group* g, const uint8_t* const* samples, int64_t n_samples, int64_t n_sites, char* err, size_t errlen)
+{
+    if (!g || !g->planned) { set_err(err, errlen, "group_load_host_async: call wgbsseg_group_plan first"); return WGBSSEG_E_STATE; }
+    if (!samples || n_samples < 1 || n_sites != g->n_sites) { set_err(err, errlen, "group_load_host_async: bad arguments (the plan is for %lld sites)", (long long)g->n_sites); return WGBSSEG_E_ARG; }
+    for (int64_t s = 0; s < n_samples; s++) if (!samples[s]) { set_err(err, errlen, "samples[%lld] is NULL", (long long)s); return WGBSSEG_E_ARG; }
+    group_join_loaders(g);
+    const int G = (int)g->shares.size();
+    g->loaders.clear();
+    g->loaders.resize((size_t)G);
+    // the device rows exist (and the contexts point at them) before any byte moves; the uploaders then fill them front to back
+    for (int d = 0; d < G; d++) {
+        const int64_t lo = g->win_lo[(size_t)d], hi = g->win_hi[(size_t)d];
+        if (hi <= lo) continue;
+        wgbsseg_ctx* c = g->shares[(size_t)d];
+        HIP_TRY(hipSetDevice(c->device));
+        const int64_t n = hi - lo, pitch = round_up(2 * n, 256) + 256;
+        HIP_TRY(c->betas_own.ensure((size_t)pitch * (size_t)n_samples));
+        c->betas = c->betas_own.as<uint8_t>();
+        c->pitch = pitch; c->n_total = n; c->n_samples = (int32_t)n_samples; c->elem = 1;
+        c->last_valid = false;
+    }
+    std::vector<const uint8_t*> base(samples, samples + n_samples);
+    for (int d = 0; d < G; d++) {
+        const int64_t lo = g->win_lo[(size_t)d], hi = g->win_hi[(size_t)d];
+        if (hi <= lo) continue;
+        g->loaders[(size_t)d].reset(new wgbsseg_group::Loader());
+        wgbsseg_group::Loader* L = g->loaders[(size_t)d].get();
+        wgbsseg_ctx* c = g->shares[(size_t)d];
+        L->th = std::thread([L, c, base, lo, hi, n_samples]() {
+            std::vector<const uint8_t*> ptrs((size_t)n_samples);
+            for (int64_t s = 0; s < n_samples; s++) ptrs[(size_t)s] = base[(size_t)s] + 2 * lo;
+            L->rc = upload_rows_streaming(c, c->betas_own.as<uint8_t>(), c->pitch, ptrs.data(), n_samples, 2 * (hi - lo), L->ready, L->msg);
+            L->ready.store(L->rc == WGBSSEG_OK ? hi - lo : L->ready.load());
+            L->finished.store(1);
+        });
+        g->loaded[(size_t)d] = 1;
+    }
+    g->streaming = true;
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_group_load_wait(wgbsseg_group* g, char* err, size_t errlen)
+{
+    if (!g) { set_err(err, errlen, "group is NULL"); return WGBSSEG_E_ARG; }
+    group_join_loaders(g);
+    g->streaming = false;
+    for (size_t d = 0; d < g->loaders.size(); d++)
+        if (g->loaders[d] && g->loaders[d]->rc != WGBSSEG_OK) { set_err(err, errlen, "share %d: %s", (int)d, g->loaders[d]->msg.c_str()); return g->loaders[d]->rc; }
+    return WGBSSEG_OK;
+}
+
 int wgbsseg_group_share_set_device(wgbsseg_group* g, int32_t share, const void* base, int64_t n_samples, int64_t pitch_bytes, char* err, size_t errlen)
 {
     if (!g || !g->planned) { set_err(err, errlen, "group_share_set_device: call wgbsseg_group_plan first"); return WGBSSEG_E_STATE; }
@@ -1132,6 +1277,7 @@ int wgbsseg_group_segment_regions(wgbsseg_group* g, int32_t* borders_out, int64_
         if (g->win_hi[(size_t)d] > g->win_lo[(size_t)d] && !g->loaded[(size_t)d]) { set_err(err, errlen, "share %d has no beta data yet", d); return WGBSSEG_E_STATE; }
     int64_t n_batches = 0;
     std::vector<char> ran((size_t)G, 0);                     // the share's timings of this call: reset on its first batch, summed after
+    std::vector<int64_t> slot_next((size_t)G, 0);            // page-locked result buffers of a share used by this call so far
     wgstitch::BatchFn run_batch = [&](const std::vector<wgstitch::Sites>& todo, wgstitch::BatchResult& res, std::string& msg) -> int {
         // route: the share that owns the first site of the range; a junction patch reaches into the next share's first chunk,
         // which the halo of the window covers
@@ -1156,10 +1302,8 @@ int wgbsseg_group_segment_regions(wgbsseg_group* g, int32_t* borders_out, int64_
         res.cnt.assign(todo.size(), 0);
         std::vector<int> rcs((size_t)G, WGBSSEG_OK);
         std::vector<std::string> msgs((size_t)G);
-        std::vector<std::unique_ptr<int32_t[]>> owned((size_t)G);
-        auto work = [&](int d) {
-            const std::vector<size_t>& it = items[(size_t)d];
-            if (it.empty()) return;
+        std::vector<std::vector<std::unique_ptr<int32_t[]>>> owned((size_t)G);
+        auto run_items = [&](int d, const std::vector<size_t>& it) -> bool {
             std::vector<int64_t> st0(it.size()), off;
             std::vector<int32_t> ln(it.size());
             for (size_t k = 0; k < it.size(); k++) {
@@ -1167,10 +1311,45 @@ int wgbsseg_group_segment_regions(wgbsseg_group* g, int32_t* borders_out, int64_
                 ln[k] = (int32_t)(todo[it[k]].second - todo[it[k]].first);
             }
             const int32_t* flat = nullptr;
-            rcs[(size_t)d] = run_ctx_batch(g->shares[(size_t)d], st0, ln, &g->P, n_batches, ran[(size_t)d] != 0, flat, off, owned[(size_t)d], msgs[(size_t)d]);
-            if (rcs[(size_t)d] != WGBSSEG_OK) return;
+            std::unique_ptr<int32_t[]> own;
+            rcs[(size_t)d] = run_ctx_batch(g->shares[(size_t)d], st0, ln, &g->P, slot_next[(size_t)d]++, ran[(size_t)d] != 0, flat, off, own, msgs[(size_t)d]);
+            if (rcs[(size_t)d] != WGBSSEG_OK) return false;
+            if (own) owned[(size_t)d].push_back(std::move(own));
             ran[(size_t)d] = 1;
             for (size_t k = 0; k < it.size(); k++) { res.ptr[it[k]] = flat + off[k]; res.cnt[it[k]] = off[k + 1] - off[k]; }
+            return true;
+        };
+        auto work = [&](int d) {
+            const std::vector<size_t>& it = items[(size_t)d];
+            if (it.empty()) return;
+            wgbsseg_group::Loader* L = (g->streaming && (size_t)d < g->loaders.size()) ? g->loaders[(size_t)d].get() : nullptr;
+            if (!L || L->finished.load()) {
+                if (L && L->rc != WGBSSEG_OK) { rcs[(size_t)d] = L->rc; msgs[(size_t)d] = L->msg; return; }
+                run_items(d, it);
+                return;
+            }
+            // the share's bytes are still arriving (front to back): segment what is resident while the rest is on its way —
+            // items in order of their last site, a sub-batch whenever a fair part of the share has landed
+            std::vector<size_t> order(it);
+            std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return todo[a].second < todo[b].second; });
+            const int64_t wlo = g->win_lo[(size_t)d];
+            const int64_t min_take = std::max<int64_t>(4 * g->chunk_size, (g->win_hi[(size_t)d] - wlo) / 5);
+            size_t pos = 0;
+            while (pos < order.size()) {
+                const int64_t first_end = todo[order[pos]].second - 1 - wlo;          // resident sites the next item needs
+                int64_t r = 0;
+                for (;;) {
+                    const bool fin = L->finished.load() != 0;
+                    r = L->ready.load();
+                    if (fin && L->rc != WGBSSEG_OK) { rcs[(size_t)d] = L->rc; msgs[(size_t)d] = L->msg; return; }
+                    if (fin) { r = g->win_hi[(size_t)d] - wlo; break; }
+                    if (r >= first_end && r - (todo[order[pos]].first - 1 - wlo) >= min_take) break;
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                }
+                std::vector<size_t> take;
+                while (pos < order.size() && todo[order[pos]].second - 1 - wlo <= r) take.push_back(order[pos++]);
+                if (!run_items(d, take)) return;
+            }
         };
         int busy = 0, only = -1;
         for (int d = 0; d < G; d++) if (!items[(size_t)d].empty()) { busy++; only = d; }
@@ -1182,7 +1361,7 @@ int wgbsseg_group_segment_regions(wgbsseg_group* g, int32_t* borders_out, int64_
         }
         for (int d = 0; d < G; d++) {
             if (rcs[(size_t)d] != WGBSSEG_OK) { msg = "share " + std::to_string(d) + ": " + msgs[(size_t)d]; return rcs[(size_t)d]; }
-            if (owned[(size_t)d]) res.owned.push_back(std::move(owned[(size_t)d]));
+            for (auto& o : owned[(size_t)d]) res.owned.push_back(std::move(o));
         }
         n_batches++;
         return WGBSSEG_OK;
@@ -1190,6 +1369,11 @@ int wgbsseg_group_segment_regions(wgbsseg_group* g, int32_t* borders_out, int64_
     std::string msg;
     const int rc = wgstitch::segment_regions(g->rs.data(), g->re.data(), (int64_t)g->rs.size(), g->chunk_size, run_batch, borders_out,
                                              borders_cap, borders_off, stats, msg, speculation_on());
+    if (g->streaming) {                                        // every byte has been consumed by now; collect the uploaders
+        char eb[512] = {0};
+        const int lrc = wgbsseg_group_load_wait(g, eb, sizeof(eb));
+        if (rc == 0 && lrc != WGBSSEG_OK) { set_err(err, errlen, "%s", eb); return lrc; }
+    }
     return map_stitch_rc(rc, msg, err, errlen);
 }
 
@@ -1331,16 +1515,20 @@ int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom
         set_err(err, errlen, "add_loci: bad argument"); return WGBSSEG_E_ARG;
     }
     if (chrom_cum[n_chroms - 1] != n_sites) { set_err(err, errlen, "add_loci: chromosome sizes sum to %lld, loci has %lld sites", (long long)chrom_cum[n_chroms - 1], (long long)n_sites); return WGBSSEG_E_ARG; }
-    FILE* fp = stdout;
-    if (path) {
-        fp = fopen(path, append ? "ab" : "wb");
-        if (!fp) { set_err(err, errlen, "add_loci: cannot open %s", path); return WGBSSEG_E_ARG; }
-        setvbuf(fp, nullptr, _IOFBF, 1 << 22);
-    }
     wgadd::Genome g = {loci, n_sites, chrom_cum, chrom_names, n_chroms};
     std::string msg;
-    const int rc = wgadd::add_loci(g, start_cpg, end_cpg, n_blocks, fp, threads, msg);
-    if (path) { if (fclose(fp) != 0 && rc == 0) { set_err(err, errlen, "add_loci: write to %s failed", path); return WGBSSEG_E_ARG; } }
+    int rc = 0;
+    if (path) {
+        // a regular file: format on all cores, then write the shards side by side at their offsets
+        const int fd = open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0666);
+        if (fd < 0) { set_err(err, errlen, "add_loci: cannot open %s", path); return WGBSSEG_E_ARG; }
+        const off_t base = append ? lseek(fd, 0, SEEK_END) : 0;
+        rc = base < 0 ? 3 : wgadd::add_loci_fd(g, start_cpg, end_cpg, n_blocks, fd, (int64_t)base, threads, msg);
+        if (close(fd) != 0 && rc == 0) { set_err(err, errlen, "add_loci: write to %s failed", path); return WGBSSEG_E_ARG; }
+        if (rc == 3 && msg.empty()) msg = "write failed";
+    } else {
+        rc = wgadd::add_loci(g, start_cpg, end_cpg, n_blocks, stdout, threads, msg);
+    }
     if (rc) { set_err(err, errlen, "%s", msg.c_str()); return WGBSSEG_E_ARG; }
     return WGBSSEG_OK;
 }

@@ -32,7 +32,7 @@ class GroupEngine:
         self.windows = self.group.plan(loci, regions, chunk_size, params['pcount'], params['max_cpg'], params['max_bp'])
         if self._maps is None:
             self._maps = [np.memmap(b, dtype=np.uint8, mode='r') for b in self.betas]
-        self.group.load_host(self._maps)
+        self.group.load_host(self._maps, wait=False)        # the shares segment what has arrived while the rest is uploading
         res, self.last_stats = self.group.segment_regions()
         return res
 

@@ -364,14 +364,16 @@ class SegmentByChunks:
             eprint('[wt segment] phases: ' + ', '.join('%s %.3f s' % (n, t - prof[i][1]) for i, (n, t) in enumerate(prof[1:])))
 
     def make_engine(self, starts, ends, gpus=None):
-        """--gpus N (default: every visible GPU): N > 1 and a region list a group can plan over -> one share per GPU
-        (wgbs_tools_amd/multi.py); else one GPU holding just the site range the run needs."""
+        """--gpus N (default: every visible GPU): a region list a share group can plan over (ascending, disjoint: every
+        whole-genome / -r / -s run and sorted -L files) -> one share per GPU (wgbs_tools_amd/multi.py), each holding only its
+        window; else one GPU holding the site range the run needs."""
         from . import _lib, multi
         want = getattr(self.args, 'gpus', 0) if gpus is None else gpus
         have = max(1, _lib.device_count())
         n = want or have            # more shares than GPUs is allowed (they wrap around the devices): only useful for tests
         first = getattr(self.args, 'device', 0)
-        if n > 1 and multi.regions_fit_a_group(self.regions()):
+        if multi.regions_fit_a_group(self.regions()):
+            # one share per GPU (also for a single GPU: the share group streams the upload and segments what has arrived)
             return multi.GroupEngine(self.betas, self.genome, [(first + d) % have for d in range(n)])
         return HipEngine(self.betas, self.genome, device=first, site_range=(min(starts) - 1, max(ends) - 1))
 
