@@ -601,14 +601,16 @@ __device__ __forceinline__ void wg_stage_local_rows(uint32_t* __restrict__ Et, c
                                                     int s_first, int ns, const ChunkDesc& cd, int64_t n_total, int ka, int cnt,
                                                     int lane, int wv)
 {
-    const int half = lane >> 5, l5 = lane & 31;
+    // rows of more than 128 entries (TI = 128: up to 189 + 3 of alignment): one sample row per wavefront pass, all 64 lanes
+    constexpr bool WHOLE = ROW > 128;
+    const int half = WHOLE ? 0 : lane >> 5, l5 = WHOLE ? lane : lane & 31;
     const int64_t abs0 = cd.start0 + ka;
     const int64_t al = abs0 & ~3LL;                    // 8-byte aligned
     const int hs = (int)(abs0 - al);
     const int sidx = l5 * 4;                           // site offset of this lane from `al`
     const int64_t a = al + sidx;
     const int nsite = cnt - 1;                         // sites ka .. ka+cnt-2 are summed
-    for (int r0 = wv * 2; r0 < ns; r0 += 2 * (WG_BLOCK / 64)) {
+    for (int r0 = WHOLE ? wv : wv * 2; r0 < ns; r0 += (WHOLE ? 1 : 2) * (WG_BLOCK / 64)) {
         const int rr = r0 + half;
         const bool act = rr < ns;
         uint32_t w0 = 0, w1 = 0;
@@ -634,7 +636,8 @@ __device__ __forceinline__ void wg_stage_local_rows(uint32_t* __restrict__ Et, c
             mt[j] = in ? ((h & 0xffu) | ((h & 0xff00u) << 8)) : 0u;
             tot += mt[j];
         }
-        const uint32_t incl = wg_half_incl_scan_dpp_u32(tot);    // <= 32*1020 per field: no carry between the fields
+        // <= 32*1020 (whole wave: 64*1020 = 65280) per field: no carry between the fields
+        const uint32_t incl = WHOLE ? wg_wave_incl_scan_dpp_u32(tot) : wg_half_incl_scan_dpp_u32(tot);
         uint32_t e = incl - tot;
         uint32_t* dst = Et + (size_t)rr * ROW;
 #pragma unroll
@@ -696,9 +699,11 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 
     if (KY) wg_lookup_tables_to_lds(iyt, kyt, A.rows, A.tab, tid, WG_BLOCK);
     else wg_fast_tables_to_lds(tb, tid, WG_BLOCK);
-    if (wv == 0) {
-        const int k = ka + lane;
-        const bool valid = lane < nk;
+    constexpr int PW = (TI + 63) / 64;                   // wavefronts that share the tile's start sites (two for TI = 128)
+    if (wv < PW) {
+        const int kl = wv * 64 + lane;
+        const int k = ka + kl;
+        const bool valid = kl < nk;
         int cnt = 0, is = 0, ie = -1;
         if (valid) {
             const int f = J.W16[cd.site_off + k];
@@ -706,22 +711,28 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             ie = (k + f < et_hi ? k + f : et_hi) - 1;
             cnt = ie - is + 1;
             if (cnt < 0) cnt = 0;
-            if (lane < TI) {
-                radj[lane] = (int64_t)(J.cum32[cd.site_off + k] - cum0) - k;      // row offset of k, minus k: + i addresses (k, i)
-                ist[lane] = is;
+            if (kl < TI) {
+                radj[kl] = (int64_t)(J.cum32[cd.site_off + k] - cum0) - k;      // row offset of k, minus k: + i addresses (k, i)
+                ist[kl] = is;
             }
         }
         const uint32_t incl = wg_wave_incl_scan_dpp_u32((uint32_t)cnt);
-        if (lane < TI) offs[lane + 1] = (int32_t)incl;
-        if (lane == 0) offs[0] = 0;
+        if (kl < TI) offs[kl + 1] = (int32_t)incl;       // (second wavefront: still without the first one's total)
+        if (kl == 0) offs[0] = 0;
         const uint32_t imin = wg_wave_min_u32(cnt > 0 ? (uint32_t)is : 0x7fffffffu);
         const uint32_t imax = wg_wave_max_u32(cnt > 0 ? (uint32_t)ie : 0u);
-        if (lane == 0) { misc[0] = (int32_t)imin; misc[1] = (int32_t)imax; }
+        if (lane == 0) { misc[2 * wv] = (int32_t)imin; misc[2 * wv + 1] = (int32_t)imax; }
+        if (PW > 1 && lane == 63) misc[4 + wv] = (int32_t)incl;
     }
     __syncthreads();
+    if (PW > 1) {
+        if (wv == 1 && 64 + lane < TI) offs[64 + lane + 1] += misc[4];
+        __syncthreads();
+    }
     const int Q = offs[nk];
     if (Q == 0) return;
-    const int imin = misc[0], imax = misc[1];
+    const int imin = PW > 1 ? (misc[0] < misc[2] ? misc[0] : misc[2]) : misc[0];
+    const int imax = PW > 1 ? (misc[1] > misc[3] ? misc[1] : misc[3]) : misc[1];
     // wide: E array = P[x] for x = eA .. imax+1 (ends use P[i+1]), S array = P[k] for k = ka .. kb-1.
     // narrow: one array L[x - ka], x = ka .. imax+1, serves both.
     const int eA = SPLIT ? imin + 1 : ka;
@@ -736,10 +747,12 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     // order of segmentor.cpp:120-136.
     const float pc = A.pc, pc2 = A.pc2;
     double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
-    double accR[WG_PAIR_CAP / WG_BLOCK];                 // partial sums of this thread's blocks across sample groups
+    // TI = 128 tiles (up to 7680 blocks) are only planned when all samples fit LDS at once: one group, no partial sums
+    constexpr bool ONEGROUP = TI > 64;
+    double accR[ONEGROUP ? 1 : WG_PAIR_CAP / WG_BLOCK];  // partial sums of this thread's blocks across sample groups
     for (int g0 = 0; g0 < J.n_samples; g0 += A.NS) {
         const int ns = (J.n_samples - g0 < A.NS) ? J.n_samples - g0 : A.NS;
-        const bool firstg = g0 == 0, lastg = g0 + ns >= J.n_samples;
+        const bool firstg = ONEGROUP || g0 == 0, lastg = ONEGROUP || g0 + ns >= J.n_samples;
         __syncthreads();
         if (SPLIT) {
             for (int rr = wv; rr < ns; rr += WG_BLOCK / 64) {
@@ -1614,7 +1627,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_gather_borders(JobView J, const in
 // twice for a table that tiles the genome, whatever the block lengths; a thread per block (the first version of this
 // kernel) fetched 2-3 aligned vectors per 20-byte block.
 // ------------------------------------------------------------------------------------------------------------
-#define WG_BS_TILE 1024
+#define WG_BS_TILE 896         // tile stride; WG_BS_EXT = 1024 sites are staged per tile (one wavefront pass of 16 sites per lane for uint8 rows)
 
 // sums of sites [a, b) of one sample row straight from memory (tails of blocks that leave their tile): 16-byte vectors
 template <int ELEM>
@@ -1670,17 +1683,17 @@ __device__ __noinline__ uint4 wg_bs_load_tail(const uint8_t* __restrict__ row, i
 }
 
 #define WG_BS_RUN 8            // consecutive tiles streamed by one workgroup
-#define WG_BS_OVER 128         // sites behind a tile's end that are staged with it: a block that starts in the tile and ends within
-                               // them (almost every tile's last block) is still two LDS reads; no global load sits in the reduction
-                               // of the common case, where it would have to wait for the NEXT tile's prefetch as well
+#define WG_BS_EXT 1024         // sites staged per tile = WG_BS_TILE + 128: a block that starts in the tile and ends within 128 sites
+                               // of its end (almost every tile's last block) is still served from LDS; no global load sits in the
+                               // reduction of the common case, where it would have to wait for the NEXT tile's prefetch as well
 
 template <int ELEM>
-struct BsTile {                // one tile's inputs in registers: the sample bytes, and the first 128 block descriptors
-    static constexpr int SPL = ELEM == 1 ? 8 : 4;              // sites per lane and pass (16 bytes)
+struct BsTile {                // one tile's inputs in registers: the sample bytes (32 per lane and pass), and the first 128 block descriptors
+    static constexpr int SPL = ELEM == 1 ? 16 : 8;             // sites per lane and pass (two 16-byte vectors)
     static constexpr int SPP = 64 * SPL;                       // sites per pass of the wavefront
-    static constexpr int NPASS = WG_BS_TILE / SPP + 1;         // + one short pass over the WG_BS_OVER sites behind the tile
+    static constexpr int NPASS = WG_BS_EXT / SPP;              // uint8 rows: ONE pass stages the tile; uint16 rows: two
     static constexpr int MAXQ = ELEM == 1 ? 2 : 1;             // samples per wave
-    uint4 v[MAXQ][NPASS];
+    uint4 v[MAXQ][NPASS][2];
     int32_t b0, b1, xa0, xa1, xb0, xb1, ra, rb;
 };
 
@@ -1691,23 +1704,23 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
                                                          int64_t n_tiles, int64_t n_blocks, int n_samples, int spw, int mode, uint32_t min_cov,
                                                          void* __restrict__ out)
 {
-    // per wave: exclusive prefixes of the tile of the sample it is working on.  Waves never touch each other's row and a
-    // wave's LDS instructions execute in program order, so no workgroup barrier is needed anywhere in this kernel.
-    // uint8 rows: a lane's 8 sites are summed IN the lane as packed pairs (meth | cov << 16: 8 x 255 fits 16 bits, one add per
-    // site for both counts) and stored as such (PK), next to the lane's own base (BASE, from two wave scans): a prefix is
-    // BASE[x >> 3] + unpack(PK[x]).  uint16 rows (.lbeta) keep full 32-bit pairs per site (E).
-    constexpr int EXT = WG_BS_TILE + WG_BS_OVER;                   // sites staged per tile
-    constexpr int ROW_BYTES = ELEM == 1 ? (EXT + 8) * 4 + (EXT / 8 + 2) * 8 : (EXT + 8) * 8;
+    // per wave: exclusive prefixes of the staged sites of the sample it is working on.  Waves never touch each other's row and
+    // a wave's LDS instructions execute in program order, so no workgroup barrier is needed anywhere in this kernel.
+    // uint8 rows: a lane's 16 sites are summed IN the lane as packed pairs (meth | cov << 16: 16 x 255 fits 16 bits, one add
+    // per site for both counts) and stored as such (PK), next to the lane's own base (BASE, from two wave scans per tile): a
+    // prefix is BASE[x >> 4] + unpack(PK[x]).  uint16 rows (.lbeta) keep full 32-bit pairs per site (E).
+    constexpr int ROW_BYTES = ELEM == 1 ? (WG_BS_EXT + 16) * 4 + (WG_BS_EXT / 16 + 2) * 8 : (WG_BS_EXT + 8) * 8;
     __shared__ __attribute__((aligned(16))) char lds[WG_BLOCK / 64][ROW_BYTES];
     typedef BsTile<ELEM> T;
     constexpr int SPL = T::SPL, SPP = T::SPP, NPASS = T::NPASS, MAXQ = T::MAXQ;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint2* Ew = reinterpret_cast<uint2*>(lds[wv]);                                        // (uint16 rows)
-    uint32_t* PK = reinterpret_cast<uint32_t*>(lds[wv]);                                  // (uint8 rows) [TILE + 8]
-    uint2* BASE = reinterpret_cast<uint2*>(lds[wv] + (EXT + 8) * 4);                      // (uint8 rows) [EXT / 8 + 1]
+    uint2* Ew = reinterpret_cast<uint2*>(lds[wv]);                                        // (uint16 rows) [EXT + 1]
+    uint32_t* PK = reinterpret_cast<uint32_t*>(lds[wv]);                                  // (uint8 rows) [EXT + 1]
+    uint2* BASE = reinterpret_cast<uint2*>(lds[wv] + (WG_BS_EXT + 16) * 4);               // (uint8 rows) [EXT / 16 + 1]
     const int s_first = ((int)blockIdx.y * (WG_BLOCK / 64) + wv) * spw;
     if (s_first >= n_samples) return;
     const int64_t t_first = (int64_t)blockIdx.x * WG_BS_RUN;
+    const size_t esz = mode == 0 ? 8 : (mode == 1 ? 2 : (mode == 2 ? 4 : 8));
 
     // everything a tile needs, requested in one go (nothing is waited for here)
     auto issue = [&](T& R, int64_t tile) {
@@ -1716,20 +1729,22 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
         R.b0 = tile_first[tile]; R.b1 = tile_first[tile + 1];
         if (R.b0 == R.b1) return;                                  // no block starts in this tile: nothing to read
         const int64_t lo = tile * WG_BS_TILE;
-        const int64_t hi = lo + EXT < n_total ? lo + EXT : n_total;          // staged sites [lo, hi)
+        const int64_t hi = lo + WG_BS_EXT < n_total ? lo + WG_BS_EXT : n_total;          // staged sites [lo, hi)
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
             const int s = s_first + q;
             const uint8_t* row = betas + (int64_t)(s < n_samples ? s : 0) * pitch;
 #pragma unroll
-            for (int p = 0; p < NPASS; p++) {
-                const int64_t site = lo + p * SPP + (int64_t)lane * SPL;
-                R.v[q][p] = make_uint4(0u, 0u, 0u, 0u);
-                if (q < spw && s < n_samples && site < hi && (p < NPASS - 1 || lane * SPL < WG_BS_OVER)) {
-                    if (site + SPL <= n_total) R.v[q][p] = *reinterpret_cast<const uint4*>(row + (size_t)site * 2 * ELEM);
-                    else R.v[q][p] = wg_bs_load_tail<ELEM>(row, site, n_total);
+            for (int p = 0; p < NPASS; p++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int64_t site = lo + p * SPP + (int64_t)lane * SPL + h * (SPL / 2);
+                    R.v[q][p][h] = make_uint4(0u, 0u, 0u, 0u);
+                    if (q < spw && s < n_samples && site < hi) {
+                        if (site + SPL / 2 <= n_total) R.v[q][p][h] = *reinterpret_cast<const uint4*>(row + (size_t)site * 2 * ELEM);
+                        else R.v[q][p][h] = wg_bs_load_tail<ELEM>(row, site, n_total);
+                    }
                 }
-            }
         }
         const int ba = R.b0 + lane, bb = R.b0 + 64 + lane;
         R.xa0 = ba < R.b1 ? x0s[ba] : 0; R.xa1 = ba < R.b1 ? x1s[ba] : 0;
@@ -1738,36 +1753,36 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
     };
     auto compute = [&](const T& R, int64_t tile) {
         if (R.b0 == R.b1) return;                                  // wave-uniform
-        const int64_t lo = tile * WG_BS_TILE;
-        const int64_t hi = lo + EXT < n_total ? lo + EXT : n_total;          // staged sites [lo, hi)
+        const int lo = (int)(tile * WG_BS_TILE);
+        const int hi = (int64_t)lo + WG_BS_EXT < n_total ? lo + WG_BS_EXT : (int)n_total;   // staged sites [lo, hi)
         const int b0 = R.b0, b1 = R.b1;
 #pragma unroll
         for (int q = 0; q < MAXQ; q++) {
             const int s = s_first + q;
             if (q >= spw || s >= n_samples) break;                 // wave-uniform
             const uint8_t* row = betas + (int64_t)s * pitch;
+            char* orow = reinterpret_cast<char*>(out) + (size_t)s * (size_t)n_blocks * esz;
             uint32_t run_m = 0, run_c = 0;
 #pragma unroll
             for (int p = 0; p < NPASS; p++) {
-                const uint32_t w[4] = {R.v[q][p].x, R.v[q][p].y, R.v[q][p].z, R.v[q][p].w};
+                const uint32_t w[8] = {R.v[q][p][0].x, R.v[q][p][0].y, R.v[q][p][0].z, R.v[q][p][0].w,
+                                       R.v[q][p][1].x, R.v[q][p][1].y, R.v[q][p][1].z, R.v[q][p][1].w};
                 if (ELEM == 1) {
-                    uint32_t e[8], acc = 0;                        // packed exclusive prefixes inside the lane
+                    uint32_t e[16], acc = 0;                       // packed exclusive prefixes inside the lane
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
+                    for (int j = 0; j < 16; j++) {
                         e[j] = acc;
                         // site j as (meth | cov << 16): bytes (m, 0, c, 0) picked out of the dword that holds two sites
                         acc += __builtin_amdgcn_perm(0u, w[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u);
                     }
                     const uint32_t tm = acc & 0xffffu, tc = acc >> 16;
                     const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
-                    if (p < NPASS - 1 || lane * 8 < WG_BS_OVER) {              // (the short pass: its first lanes only)
-                        BASE[p * 64 + lane] = make_uint2(run_m + (im - tm), run_c + (ic - tc));
-                        uint4* dst = reinterpret_cast<uint4*>(PK + p * SPP + lane * 8);
-                        dst[0] = make_uint4(e[0], e[1], e[2], e[3]);
-                        dst[1] = make_uint4(e[4], e[5], e[6], e[7]);
-                    }
-                    run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
-                    run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+                    BASE[lane] = make_uint2(im - tm, ic - tc);
+                    uint4* dst = reinterpret_cast<uint4*>(PK + lane * 16);
+#pragma unroll
+                    for (int j = 0; j < 16; j += 4) dst[j >> 2] = make_uint4(e[j], e[j + 1], e[j + 2], e[j + 3]);
+                    run_m = (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
+                    run_c = (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
                 } else {
                     uint32_t m[SPL], c[SPL], tm = 0, tc = 0;
 #pragma unroll
@@ -1777,38 +1792,41 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
                     uint2 e[SPL];
 #pragma unroll
                     for (int j = 0; j < SPL; j++) { e[j] = make_uint2(em, ec); em += m[j]; ec += c[j]; }
-                    if (p < NPASS - 1 || lane * SPL < WG_BS_OVER) {
-                        uint4* dst = reinterpret_cast<uint4*>(Ew + p * SPP + lane * SPL);      // 16-byte stores, lane-contiguous
+                    uint4* dst = reinterpret_cast<uint4*>(Ew + p * SPP + lane * SPL);          // 16-byte stores, lane-contiguous
 #pragma unroll
-                        for (int j = 0; j < SPL; j += 2) dst[j >> 1] = make_uint4(e[j].x, e[j].y, e[j + 1].x, e[j + 1].y);
-                    }
+                    for (int j = 0; j < SPL; j += 2) dst[j >> 1] = make_uint4(e[j].x, e[j].y, e[j + 1].x, e[j + 1].y);
                     run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
                     run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
                 }
             }
-            if (lane == 0) {                                       // the entry of the tile's end (sites past `hi` were read as zeros)
-                if (ELEM == 1) { BASE[EXT / 8] = make_uint2(run_m, run_c); PK[EXT] = 0u; }
-                else Ew[EXT] = make_uint2(run_m, run_c);
+            if (lane == 0) {                                       // the entry behind the last staged site (sites past `hi` were read as zeros)
+                if (ELEM == 1) { BASE[WG_BS_EXT / 16] = make_uint2(run_m, run_c); PK[WG_BS_EXT] = 0u; }
+                else Ew[WG_BS_EXT] = make_uint2(run_m, run_c);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            auto prefix = [&](int x) -> uint2 {                    // sums of the tile's sites before x
-                if (ELEM == 1) { const uint2 b = BASE[x >> 3]; const uint32_t k = PK[x]; return make_uint2(b.x + (k & 0xffffu), b.y + (k >> 16)); }
+            auto prefix = [&](int x) -> uint2 {                    // sums of the staged sites before x
+                if (ELEM == 1) { const uint2 b = BASE[x >> 4]; const uint32_t k = PK[x]; return make_uint2(b.x + (k & 0xffffu), b.y + (k >> 16)); }
                 return Ew[x];
             };
-            auto one = [&](int64_t x0, int64_t x1, int64_t r) {
-                uint64_t m = 0, c = 0;
+            auto one = [&](int x0, int x1, int r) {
+                uint32_t m32 = 0, c32 = 0;
                 if (x1 > x0) {
-                    const int64_t e = x1 < hi ? x1 : hi;
-                    const uint2 pe = prefix((int)(e - lo)), ps = prefix((int)(x0 - lo));
-                    m = pe.x - ps.x; c = pe.y - ps.y;
-                    if (x1 > hi) wg_direct_sum<ELEM>(row, hi, x1, n_total, m, c);
+                    const int e = x1 < hi ? x1 : hi;
+                    const uint2 pe = prefix(e - lo), ps = prefix(x0 - lo);
+                    m32 = pe.x - ps.x; c32 = pe.y - ps.y;
                 }
-                wg_block_sum_store(out, (int64_t)s * n_blocks + r, mode, min_cov, m, c);
+                if (x1 > hi) {                                     // rare: a block reaching beyond the staged sites
+                    uint64_t m = m32, c = c32;
+                    wg_direct_sum<ELEM>(row, hi, x1, n_total, m, c);
+                    wg_block_sum_store(orow, r, mode, min_cov, m, c);
+                } else {
+                    wg_block_sum_store(orow, r, mode, min_cov, (uint64_t)m32, (uint64_t)c32);
+                }
             };
             if (b0 + lane < b1) one(R.xa0, R.xa1, R.ra);
             if (b0 + 64 + lane < b1) one(R.xb0, R.xb1, R.rb);
-            for (int b = b0 + 128 + lane; b < b1; b += 64) one(x0s[b], x1s[b], perm ? (int64_t)perm[b] : (int64_t)b);
+            for (int b = b0 + 128 + lane; b < b1; b += 64) one(x0s[b], x1s[b], perm ? perm[b] : b);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();                                                       // reads done before the next row overwrites
         }

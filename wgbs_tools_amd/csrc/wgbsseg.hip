@@ -444,6 +444,7 @@ template <int FAST>
 hipError_t launch_cost_ti(int TI, bool wide, const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
     if (wide) return launch_cost<WG_WIDE_TS, FAST, 1>(v, sv, a, td, tiles, cost, lds, s);
+    if (TI == 128) return launch_cost<128, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
     if (TI == 64) return launch_cost<64, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
     if (TI == 32) return launch_cost<32, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
     return launch_cost<16, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
@@ -454,7 +455,8 @@ hipError_t launch_cost_ti(int TI, bool wide, const JobView& v, const StageView& 
 template <int FAST>
 hipError_t set_cost_attrs()
 {
-    const void* fns[] = {reinterpret_cast<const void*>(&k_cost<64, FAST, 0>), reinterpret_cast<const void*>(&k_cost<32, FAST, 0>),
+    const void* fns[] = {reinterpret_cast<const void*>(&k_cost<128, FAST, 0>),
+                         reinterpret_cast<const void*>(&k_cost<64, FAST, 0>), reinterpret_cast<const void*>(&k_cost<32, FAST, 0>),
                          reinterpret_cast<const void*>(&k_cost<16, FAST, 0>), reinterpret_cast<const void*>(&k_cost<WG_WIDE_TS, FAST, 1>)};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -575,13 +577,17 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         return tabs + rows + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 24;
     };
     int TI = 64, NSA = 1, NSB = 1;
+    static const int ti128_max_n = getenv("WGBSSEG_TI128_MAX_N") ? atoi(getenv("WGBSSEG_TI128_MAX_N")) : 16;
     {
         double best = -1;
-        for (int ti = 64; ti >= 16; ti >>= 1) {
+        for (int ti = 128; ti >= 16; ti >>= 1) {
             if (c->force_ti > 0 && ti != c->force_ti) continue;
             const int ns_opts[5] = {Nsmp, 32, 16, 8, 4};
             for (int ns : ns_opts) {
                 if (ns > Nsmp) continue;
+                // 128-start tiles: half the per-tile overhead for small cohorts; only with every sample in LDS at once (one group),
+                // and not by default above WGBSSEG_TI128_MAX_N samples, where their larger rows cost a workgroup per CU
+                if (ti == 128 && (ns != Nsmp || (c->force_ti != 128 && Nsmp > ti128_max_n))) continue;
                 if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
                 const size_t l = lds_for(ti, false, ns);
                 if (l > 64 * 1024) continue;

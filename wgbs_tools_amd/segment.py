@@ -467,10 +467,13 @@ class SegmentByChunks:
             eprint('Empty blocks array')
             return
         nr_blocks = start_cpg.size
-        order = np.argsort(start_cpg, kind='stable')
-        s, e = start_cpg[order], end_cpg[order]
+        s, e = start_cpg, end_cpg
+        if not (s[1:] >= s[:-1]).all():                          # (chromosome by chromosome they already come sorted)
+            order = np.argsort(s, kind='stable')
+            s, e = s[order], e[order]
         keep = (e - s) > self.args.min_cpg - 1
-        s, e = s[keep], e[keep]
+        if not keep.all():
+            s, e = s[keep], e[keep]
         nr_blocks_filt = s.size
         nr_dropped = nr_blocks - nr_blocks_filt
         eprint(f'[wt segment] found {nr_blocks_filt:,} blocks\n'
