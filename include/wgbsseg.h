@@ -242,6 +242,15 @@ int wgbsseg_scan_only(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const int32
  */
 int wgbsseg_block_sums(wgbsseg_ctx* ctx, const int64_t* start0, const int64_t* end0, int64_t n_blocks, int32_t mode,
                        uint32_t min_cov, void* out, char* err, size_t errlen);
+/*
+ * find_markers' per-block group statistics (find_markers.py:188-196, :318-335) over the ratio table the LAST wgbsseg_block_sums
+ * call left on the device (it must have been a mode-3 call over n_blocks blocks): for a target set and a background set of
+ * sample indexes (argument order of the setter; visited in the given order) out[b] = {n_tg, sum_tg, min_tg, max_tg, n_bg, sum_bg,
+ * min_bg, max_bg} as doubles — the number of samples with a value (coverage >= min_cov), their sequential sum (nanmean =
+ * sum / n), smallest and largest value (NaN when none).  out is a HOST buffer of n_blocks * 8 doubles.
+ */
+int wgbsseg_marker_stats(wgbsseg_ctx* ctx, const int32_t* tg, int32_t n_tg, const int32_t* bg, int32_t n_bg, int64_t n_blocks,
+                         double* out, char* err, size_t errlen);
 /* HIP-event time of the kernel of the last wgbsseg_block_sums call (ms) */
 double wgbsseg_last_block_sums_ms(const wgbsseg_ctx* ctx);
 

@@ -108,3 +108,68 @@ def lbeta_twin(data):
     i = np.arange(data.shape[0], dtype=np.uint64)
     k = (1 + (i * np.uint64(2654435761)) % np.uint64(997)).astype(np.uint32)
     return (data.astype(np.uint32) * k[:, None]).astype(np.uint16)
+
+
+MARKER_SPEC = dict(seed=20260929, n_sites=60000, groups=[('Liver', 4), ('Blood', 3), ('Colon', 3), ('Lung', 2), ('Solo', 1)])
+
+
+def marker_world(td, spec=MARKER_SPEC):
+    """Inputs of the find_markers cases, written under `td`: beta files of several groups of samples with group-specific
+    differentially methylated blocks, a blocks table (with blocks of every length, a few uncovered), a groups csv.
+    -> dict(betas, blocks, groups, spec).  Everything from integer hashes of the seed: regenerated, never stored."""
+    import os.path as op
+    seed, n = spec['seed'], spec['n_sites']
+    U64 = np.uint64
+    # blocks: consecutive, 3..40 sites, every 37th gap skipped
+    starts, pos, k = [], 1, 0
+    while pos < n - 50:
+        ln = 3 + int(synth.hash_at(seed, 201, np.array([k]))[0] % U64(38))
+        starts.append((pos, pos + ln))
+        pos += ln + (5 if k % 37 == 36 else 0)
+        k += 1
+    nb = len(starts)
+    bidx = np.arange(nb, dtype=np.int64)
+    hb = synth.hash_at(seed, 202, bidx)
+    base = np.where((hb & U64(1)) == 0, 205, 30).astype(np.int64)              # background level of the block: high or low (of 256)
+    names, groups = [], []
+    for g, cnt in spec['groups']:
+        for i in range(cnt):
+            names.append('%s_%d' % (g, i + 1)); groups.append(g)
+    site_block = np.zeros(n, dtype=np.int64) - 1
+    for b, (a, e) in enumerate(starts):
+        site_block[a - 1:e - 1] = b
+    betas = []
+    gnames = [g for g, _ in spec['groups']]
+    for si, (nm, g) in enumerate(zip(names, groups)):
+        gi = gnames.index(g)
+        special = ((hb >> U64(8)) % U64(9)).astype(np.int64) == gi             # this group's differential blocks
+        lvl_b = np.where(special, 235 - base, base)                            # flipped level
+        jit = (synth.hash_at(seed, 210 + si, bidx) % U64(41)).astype(np.int64) - 20
+        lvl_b = np.clip(lvl_b + jit, 0, 255)
+        idx = np.arange(n, dtype=np.int64)
+        hc = synth.hash_at(seed, 300 + si, idx)
+        cov = (4 + (hc % U64(28))).astype(np.int64)
+        cov = np.where(((hc >> U64(20)) % U64(23)) == 0, 0, cov)               # ~4 % uncovered sites
+        lowcov_block = ((synth.hash_at(seed, 400 + si, bidx) % U64(29)) == 0)  # whole blocks this sample does not cover
+        lvl = np.where(site_block >= 0, lvl_b[np.maximum(site_block, 0)], 128)
+        cov = np.where((site_block >= 0) & lowcov_block[np.maximum(site_block, 0)], 0, cov)
+        meth = np.zeros(n, dtype=np.int64)
+        for t in range(4):                                                     # cov <= 31: four groups of 8 byte-trials
+            hbt = synth.hash_at(seed, 500 + si, idx * 4 + t)
+            for byte in range(8):
+                trial = ((hbt >> U64(8 * byte)) & U64(0xFF)).astype(np.int64)
+                meth += ((trial < lvl) & (t * 8 + byte < cov)).astype(np.int64)
+        arr = np.stack([meth, cov], axis=1).astype(np.uint8)
+        p = op.join(td, nm + '.beta')
+        arr.tofile(p)
+        betas.append(p)
+    bp = op.join(td, 'blocks.bed')
+    with open(bp, 'w') as f:
+        for b, (a, e) in enumerate(starts):
+            f.write('chr1\t%d\t%d\t%d\t%d\n' % (1000 + 50 * a, 1000 + 50 * e + 17 * (b % 5), a, e))
+    gp = op.join(td, 'groups.csv')
+    with open(gp, 'w') as f:
+        f.write('name,group\n')
+        for nm, g in zip(names, groups):
+            f.write('%s,%s\n' % (nm, g))
+    return dict(betas=betas, blocks=bp, groups=gp, spec=spec, n_blocks=nb)

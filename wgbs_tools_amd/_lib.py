@@ -25,7 +25,8 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_group_plan', 'wgbsseg_group_load_host', 'wgbsseg_group_share_set_device', 'wgbsseg_group_segment_regions',
            'wgbsseg_group_get_timings', 'wgbsseg_plan_shares', 'wgbsseg_set_lbetas_host',
            'wgbsseg_convert_regions', 'wgbsseg_patbeta_create', 'wgbsseg_patbeta_feed', 'wgbsseg_patbeta_finish',
-           'wgbsseg_patbeta_destroy', 'wgbsseg_group_load_host_async', 'wgbsseg_group_load_wait']
+           'wgbsseg_patbeta_destroy', 'wgbsseg_group_load_host_async', 'wgbsseg_group_load_wait',
+           'wgbsseg_marker_stats']
 
 
 class NativeLibraryError(RuntimeError):
@@ -181,6 +182,8 @@ def load():
     L.wgbsseg_patbeta_finish.argtypes = [vp, i32, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_patbeta_destroy.restype = None
     L.wgbsseg_patbeta_destroy.argtypes = [vp]
+    L.wgbsseg_marker_stats.restype = i32
+    L.wgbsseg_marker_stats.argtypes = [vp, vp, i32, vp, i32, i64, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_add_loci.restype = i32
     L.wgbsseg_add_loci.argtypes = [vp, i64, vp, C.POINTER(C.c_char_p), i32, vp, vp, i64, C.c_char_p, i32, i32, C.c_char_p, C.c_size_t]
     _lib = L
@@ -352,6 +355,15 @@ class Segmenter:
                                                a[4].ctypes.data, sl.ctypes.data, n, s.ctypes.data, e.ctypes.data, self._err, ERRLEN),
                self._err)
         return s, e
+
+    def marker_stats(self, tg, bg, n_blocks):
+        """wgbsseg_marker_stats over the table of the last mode-3 block_sums call -> float64 [n_blocks, 8]"""
+        tg = np.ascontiguousarray(tg, dtype=np.int32)
+        bg = np.ascontiguousarray(bg, dtype=np.int32)
+        out = np.empty((int(n_blocks), 8), dtype=np.float64)
+        _check(self._L.wgbsseg_marker_stats(self._h, tg.ctypes.data, tg.size, bg.ctypes.data, bg.size, int(n_blocks), out.ctypes.data,
+                                            self._err, ERRLEN), self._err)
+        return out
 
     def last_block_sums_ms(self):
         return float(self._L.wgbsseg_last_block_sums_ms(self._h))

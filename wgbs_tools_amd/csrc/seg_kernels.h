@@ -1961,6 +1961,39 @@ __global__ __launch_bounds__(WG_BLOCK) void k_pat_trim(const int32_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_marker_stats: per block, the statistics of a target and a background set of samples that `wgbstools find_markers` filters
+// on (find_markers.py:188-196 coverage filter, :318-335 find_X_markers: nanmean / min / max per group), from the
+// device-resident table of meth/cov ratios (mode 3 of the block reduction: NaN = below min_cov).  One thread per block;
+// the samples of a set are visited in the order given (the column order of the reference's DataFrame): the sum is the
+// sequential one numpy takes over that axis.  out[b] = {n_tg, sum_tg, min_tg, max_tg, n_bg, sum_bg, min_bg, max_bg}
+// (min / max NaN when the set has no value).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG_BLOCK) void k_marker_stats(const double* __restrict__ V, int64_t n_blocks, const int32_t* __restrict__ tg, int n_tg,
+                                                           const int32_t* __restrict__ bg, int n_bg, double* __restrict__ out)
+{
+    const int64_t b = (int64_t)blockIdx.x * WG_BLOCK + threadIdx.x;
+    if (b >= n_blocks) return;
+    const double nan = __builtin_nan("");
+    for (int set = 0; set < 2; set++) {
+        const int32_t* idx = set ? bg : tg;
+        const int n = set ? n_bg : n_tg;
+        double cnt = 0.0, sum = 0.0, mn = nan, mx = nan;
+        for (int k = 0; k < n; k++) {
+            const double v = V[(int64_t)idx[k] * n_blocks + b];
+            if (v == v) {
+                cnt += 1.0; sum += v;
+                mn = (mn == mn) ? (v < mn ? v : mn) : v;
+                mx = (mx == mx) ? (v > mx ? v : mx) : v;
+            } else {
+                sum += 0.0;                                     // numpy's nanmean adds the zero it put in place of the NaN
+            }
+        }
+        double* o = out + b * 8 + set * 4;
+        o[0] = cnt; o[1] = sum; o[2] = mn; o[3] = mx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // test hooks
 // ------------------------------------------------------------------------------------------------------------
 // fast == 2: `rows` = wg_lookup_rows(pc, the ABI's largest block total), the k-scaled tables the scoring kernels would build

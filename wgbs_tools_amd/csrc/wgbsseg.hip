@@ -136,6 +136,7 @@ struct wgbsseg_ctx {
     int force_ti = 0;
     int min_stages = 0;      // WGBSSEG_MIN_STAGES; 0: decided per call from the number of chunks
     double last_block_sums_ms = 0.0;
+    int64_t table_blocks = 0;  // > 0: dbg_b still holds the [n_samples][table_blocks] ratio table of the last mode-3 block reduction
     bool accumulate = false;   // add to `tim` instead of resetting it (region-level calls span several batches)
 };
 
@@ -1508,6 +1509,34 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     c->last_block_sums_ms = ms;
     c->last_valid = false;
+    c->table_blocks = mode == 3 ? n_blocks : 0;
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_marker_stats(wgbsseg_ctx* c, const int32_t* tg, int32_t n_tg, const int32_t* bg, int32_t n_bg, int64_t n_blocks, double* out,
+                         char* err, size_t errlen)
+{
+    if (!c || !tg || !bg || n_tg < 1 || n_bg < 1 || !out || n_blocks < 1) { set_err(err, errlen, "bad arguments to marker_stats"); return WGBSSEG_E_ARG; }
+    if (c->table_blocks != n_blocks) { set_err(err, errlen, "marker_stats: the last wgbsseg_block_sums call was not a mode-3 reduction over these %lld blocks", (long long)n_blocks); return WGBSSEG_E_STATE; }
+    for (int i = 0; i < n_tg; i++) if (tg[i] < 0 || tg[i] >= c->n_samples) { set_err(err, errlen, "marker_stats: no sample %d", (int)tg[i]); return WGBSSEG_E_ARG; }
+    for (int i = 0; i < n_bg; i++) if (bg[i] < 0 || bg[i] >= c->n_samples) { set_err(err, errlen, "marker_stats: no sample %d", (int)bg[i]); return WGBSSEG_E_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->dbg_c.ensure((size_t)n_blocks * 64 + (size_t)(n_tg + n_bg) * 4));
+    double* dout = c->dbg_c.as<double>();
+    int32_t* dtg = reinterpret_cast<int32_t*>(dout + n_blocks * 8);
+    int32_t* dbg = dtg + n_tg;
+    HIP_TRY(hipMemcpyAsync(dtg, tg, (size_t)n_tg * 4, hipMemcpyHostToDevice, c->sA));
+    HIP_TRY(hipMemcpyAsync(dbg, bg, (size_t)n_bg * 4, hipMemcpyHostToDevice, c->sA));
+    HIP_TRY(hipEventRecord(c->ev[0], c->sA));
+    hipLaunchKernelGGL(k_marker_stats, dim3((unsigned)((n_blocks + WG_BLOCK - 1) / WG_BLOCK)), dim3(WG_BLOCK), 0, c->sA, c->dbg_b.as<double>(), n_blocks,
+                       dtg, (int)n_tg, dbg, (int)n_bg, dout);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[1], c->sA));
+    HIP_TRY(hipMemcpyAsync(out, dout, (size_t)n_blocks * 64, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+    c->last_block_sums_ms = ms;
     return WGBSSEG_OK;
 }
 
@@ -1555,6 +1584,7 @@ int wgbsseg_convert_regions(wgbsseg_ctx* c, const int64_t* chrom_lo, const int64
     const size_t nb = (size_t)n * 8;
     HIP_TRY(c->dbg_a.ensure(5 * nb + (size_t)n));
     HIP_TRY(c->dbg_b.ensure(2 * nb));
+    c->table_blocks = 0;
     char* d = c->dbg_a.as<char>();
     const int64_t* srcs[5] = {chrom_lo, chrom_hi, chrom_bp, start, end};
     for (int k = 0; k < 5; k++) HIP_TRY(hipMemcpyAsync(d + k * nb, srcs[k], nb, hipMemcpyHostToDevice, c->sA));

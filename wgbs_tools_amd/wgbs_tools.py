@@ -1,18 +1,18 @@
 #!/usr/bin/python3 -u
 """`wgbstools <command>` dispatcher (reference: src/python/wgbs_tools.py:50-79).  This build carries `segment` — the
 MI355X-native hot path — and the steps either side of it that work on the same resident data: `convert` (loci <-> CpG
-indexes, what feeds `segment -L`), `pat2beta` (the producer of the beta files), `beta_to_blocks` and `beta_to_table` (the reductions over the blocks it writes);
+indexes, what feeds `segment -L`), `pat2beta` (the producer of the beta files), `beta_to_blocks`, `beta_to_table` and `find_markers` (the reductions over the blocks it writes);
 every other reference subcommand is out of scope and says so."""
 import sys
 
 from .genome import IllegalArgumentError, eprint
 
 VERSION = '0.2.0-mi355x'
-COMMANDS = ['segment', 'convert', 'pat2beta', 'beta_to_blocks', 'beta_to_table']
+COMMANDS = ['segment', 'convert', 'pat2beta', 'beta_to_blocks', 'beta_to_table', 'find_markers']
 # reference command list (wgbs_tools.py:11-48), for the "not in this build" message
 REFERENCE_ONLY = ['view', 'merge', 'cview', 'index', 'beta_cov',
                   'beta2bed', 'beta2bw', 'bam2pat', 'mbias', 'init_genome', 'set_default_ref', 'vis', 'pat_fig',
-                  'find_markers', 'homog', 'test_bimodal', 'compare_betas', 'dmb', 'mix_pat', 'bed2beta',
+                  'homog', 'test_bimodal', 'compare_betas', 'dmb', 'mix_pat', 'bed2beta',
                   'split_by_allele', 'split_by_meth', 'frag_len', 'add_cpg_counts', 'beta_to_450k']
 
 
