@@ -21,7 +21,8 @@ def one_pass(counter):
     d = op.join(OUT, 'pmc_' + counter)
     cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
            sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0']
-    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'))
+    subprocess.run(cmd + ['--e2e', '0'], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'),
+                   timeout=240)
     best = None
     for f in glob.glob(op.join(d, '**', '*counter_collection.csv'), recursive=True):
         with open(f) as fh:
@@ -41,13 +42,17 @@ def main():
     gf, fetch = one_pass('FETCH_SIZE')
     gw, write = one_pass('WRITE_SIZE')
     assert gf == gw
-    n_sites, n_samples = 28217448, 32
-    alg = 2 * n_samples * (n_sites + 1832 * 100 + 0)        # chunks + the upfront patches of the main batch (approx.; bench.py reports the exact figure)
+    # the exact algorithmic bytes of that launch (2 bytes x samples x sites of the main batch: chunks + upfront patches): bench.py reports it
+    r = subprocess.run([sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0'],
+                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=240)
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    alg = int(json.loads(line)['roofline']['algorithmic_bytes_per_launch'])
     rec = {'kernel': 'k_scan', 'workload': 'hg19-shaped 28217448 CpGs x 32 betas, main batch (483 chunks + upfront patches)',
            'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), gfx950, ROCm 7.2; largest k_scan dispatch of `python bench.py --steps 1 --warmup 0 --cpu-seconds 0`',
            'grid_size': gf, 'FETCH_SIZE_KB': fetch, 'WRITE_SIZE_KB': write,
            'correction': 'MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane) -> doubled; WRITE_SIZE taken as is; units KB = 1024 B',
-           'read_bytes': 2 * fetch * 1024, 'write_bytes': write * 1024, 'traffic_bytes': 2 * fetch * 1024 + write * 1024}
+           'read_bytes': 2 * fetch * 1024, 'write_bytes': write * 1024, 'traffic_bytes': 2 * fetch * 1024 + write * 1024,
+           'algorithmic_bytes': alg, 'traffic_over_algorithmic': (2 * fetch * 1024 + write * 1024) / alg}
     json.dump(rec, open(op.join(OUT, 'scan_traffic.json'), 'w'), indent=1)
     print(json.dumps(rec))
 

@@ -176,6 +176,11 @@ class BlockSumEngine:
             raise IllegalArgumentError('blocks table reaches beyond the beta file')
         return self._seg.block_sums(s0, e0, mode=mode, min_cov=min_cov)
 
+    def marker_stats(self, tg, bg, n_blocks):
+        """per-block statistics of two sets of resident samples over the table the last mode-3 reduce() left on the device
+        (find_markers; include/wgbsseg.h wgbsseg_marker_stats)"""
+        return self._seg.marker_stats(tg, bg, n_blocks)
+
     def kernel_ms(self):
         return self._seg.last_block_sums_ms()
 
