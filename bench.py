@@ -13,8 +13,8 @@ only meet at the timing barrier.  `python bench.py --gpus N` WITHOUT the launche
 through a share group (the product's `wgbstools segment --gpus N`: one host thread per GPU, one host-side stitching
 tree).  Total work is fixed as N grows => "scaling": "strong".
 
-The JSON line carries `roofline` for the HBM-bound scan kernel (k_scan; algorithmic bytes = 2 * samples * sites per
-launch) measured with HIP events on the kernel's own stream inside the timed steps, the fp64-VALU
+The JSON line carries `roofline` for the HBM-bound scan pass (k_validate for a job without wide tiles — the default
+genome —, k_scan with carries otherwise; algorithmic bytes = 2 * samples * sites per launch) measured with HIP events on the kernel's own stream inside the timed steps, the fp64-VALU
 bound scoring kernel's rate as `scoring`, and `cpu_baseline`: the reference's own `segmentor` (oracle/_ref, built
 from the reference sources) timed on this host on a bounded sample of the same workload.
 """
@@ -321,6 +321,7 @@ def main():
         scan_gbs = acc['scan_main_bytes'] / (main_ms * 1e-3) / 1e9
         scan_all_gbs = acc['scan_bytes'] / (acc['scan_ms'] * 1e-3) / 1e9
         evals_s = acc['evals'] / (acc['cost_ms'] * 1e-3)
+        stats_wide = acc['max_window'] > 60          # WG_NARROW_WMAX: wide scoring tiles exist, so the scan keeps its carries
         # HBM traffic of that launch from the PMC counters (collected separately with rocprofv3, profiles/): only
         # reported when the committed measurement is for exactly this workload
         traffic, traffic_note = None, 'traffic: PMC pass not available for this workload'
@@ -347,7 +348,8 @@ def main():
                        'share_chunks': None if shares is None else [int(x) for x in shares['chunks']],
                        'share_work': None if shares is None else [int(x) for x in shares['work']],
                        'rank0_sites': my_sites, 'rank0_stats': stats, 'rank0_blocks': n_blocks},
-            'roofline': {'kernel': 'k_scan (per-sample prefix scan + meth<=cov validation)', 'bound': 'hbm',
+            'roofline': {'kernel': ('k_scan (per-sample prefix scan -> 128-site carries + meth<=cov validation: the job has wide tiles)' if stats_wide else
+                                    'k_validate (the scan pass of a job without wide tiles: every beta byte read once, meth<=cov checked; no carries needed)'), 'bound': 'hbm',
                          'achieved': scan_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': scan_gbs / HBM_PEAK_GBS,
                          'traffic': traffic,
                          'algorithmic_bytes_per_launch': acc['scan_main_bytes'], 'avg_launch_ms': main_ms,

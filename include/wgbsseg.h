@@ -327,6 +327,13 @@ int wgbsseg_debug_log2(wgbsseg_ctx* ctx, uint32_t first_bits, int64_t count, uin
 /* wgbsseg_debug_div: the scoring kernel's 8-instruction fp32 division core and the compiler's IEEE `/`, both evaluated
  * on the device for `count` operand pairs (uint32 bit patterns out). */
 int wgbsseg_debug_div(wgbsseg_ctx* ctx, const float* a, const float* b, int64_t count, uint32_t* out_fast, uint32_t* out_ieee);
+/* wgbsseg_debug_check_div: the verdict the library takes once per context and pseudo count before it lets the narrow scoring
+ * tiles use the 4-instruction division core (v_rcp_f32, quotient, one residual correction): the number of operand pairs
+ * a = fl(nmeth + pc), b = fl(ntotal + 2 pc), 0 <= nmeth <= ntotal <= max_total, whose quotient differs from IEEE `/`
+ * (all evaluated on the device).  The library uses the short core only when this is 0 for max_total = 255 * 60. */
+int wgbsseg_debug_check_div(wgbsseg_ctx* ctx, float pseudo_count, int32_t max_total, int64_t* mismatches);
+/* wgbsseg_debug_div_short: the short core itself on arrays of operands (bit patterns of the quotients). */
+int wgbsseg_debug_div_short(wgbsseg_ctx* ctx, const float* a, const float* b, int64_t count, uint32_t* out);
 
 #ifdef __cplusplus
 }

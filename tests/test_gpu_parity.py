@@ -121,6 +121,59 @@ def test_02b_division_core_equals_ieee_division(seg, pcount):
     assert _first_diff(ieee, want) is None
 
 
+@pytest.mark.parametrize('pcount', [15.0, 1.0, 2.0, 100.0, 1000.0, 1.5, 3.25, 1.1, 7.77, 1.0000001, 123.456, 16777216.0])
+def test_02c_short_division_core_is_used_only_where_it_is_exact(seg, pcount):
+    """Narrow scoring tiles divide with a 4-instruction core (v_rcp_f32, quotient, one correction) when k_check_div finds it
+    equal to IEEE `/` on EVERY operand pair such a tile can form with the call's pseudo count.  Here: (1) the verdict
+    kernel counts exactly the mismatches that numpy finds when it compares the core's quotients with IEEE division, on the
+    full lattice up to ntotal 3000 (and so is not blind); (2) integer pseudo counts pass on the whole narrow-tile domain
+    (ntotal <= 255 * 60), as the distance of a / b from a rounding midpoint guarantees."""
+    pc = np.float32(pcount)
+    T = 3000
+    t = np.repeat(np.arange(0, T + 1, dtype=np.int64), np.arange(1, T + 2))
+    m = np.concatenate([np.arange(0, tt + 1) for tt in range(0, T + 1)])
+    a = (m.astype(np.float32) + pc).astype(np.float32)
+    b = (t.astype(np.float32) + (pc + pc)).astype(np.float32)
+    short = seg.debug_div_short(a, b)
+    want = (a / b).astype(np.float32).view(np.uint32)
+    n_bad = int((short != want).sum())
+    assert seg.debug_check_div(pcount, T) == n_bad
+    full = seg.debug_check_div(pcount)
+    print('pseudo count %r: %d of %d pairs differ up to ntotal %d, %d on the narrow-tile domain' % (pcount, n_bad, a.size, T, full))
+    if float(pcount).is_integer() and pcount < 2 ** 23:
+        assert full == 0
+
+
+def test_02d_verdict_kernel_sees_a_wrong_quotient(seg):
+    """The short core is not IEEE division in general: far outside the narrow-tile domain (operands with all 24 bits in
+    play) it does differ now and then, and the verdict kernel must say so."""
+    rng = np.random.default_rng(11)
+    a = rng.uniform(1.0, 2.0, 20000000).astype(np.float32)
+    b = rng.uniform(1.0, 2.0, 20000000).astype(np.float32)
+    short = seg.debug_div_short(a, b)
+    want = (a / b).astype(np.float32).view(np.uint32)
+    print('short core vs IEEE on 2e7 random pairs of full-width floats: %d differ' % int((short != want).sum()))
+    assert int((short != want).sum()) > 0
+
+
+def test_07c_full_division_core_on_every_case(golden_chunks):
+    """WGBSSEG_DIV_SHORT=0 keeps the 8-instruction core in the narrow tiles: same borders on every golden case."""
+    os.environ['WGBSSEG_DIV_SHORT'] = '0'
+    try:
+        sg = _lib.Segmenter(0)
+    finally:
+        del os.environ['WGBSSEG_DIV_SHORT']
+    try:
+        for name in cases.CHUNK_CASES:
+            g = golden_chunks[name]
+            spec = g['spec']
+            _load_case(sg, spec)
+            got = sg.segment_chunks([0], [spec['n']], spec['pcount'], spec['max_cpg'], spec['max_bp'])[0]
+            assert got.tolist() == g['borders'], '%s: %s' % (name, _first_diff(got, np.array(g['borders'])))
+    finally:
+        sg.close()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # 2. scan pass
 # ---------------------------------------------------------------------------------------------------------
@@ -148,6 +201,58 @@ def test_04_meth_gt_cov_is_reported(seg):
     # a bad site OUTSIDE the requested chunks is not an error (the reference only reads the chunk's bytes)
     b = seg.segment_chunks([40], [spec['n'] - 40], spec['pcount'], spec['max_cpg'], spec['max_bp'])[0]
     assert b[0] == 0 and b[-1] == spec['n'] - 40
+
+
+@pytest.mark.parametrize('piece', [0, 1024, 4096])
+def test_04b_validation_pass_sees_every_site_of_every_chunk_and_nothing_else(piece, monkeypatch):
+    """The read-only scan of a job without wide tiles works on the union of the chunks, cut into pieces: a `meth > cov` site is
+    found wherever it sits (first / last site of a chunk, either side of a piece boundary, in a patch-like chunk that overlaps
+    others, in the last vector of the row), the LOWEST (sample, site) is the one named, sites between chunks are never read,
+    and a region-level call (chunks + junction patches in one batch, patches again in the follow-up batch) reports it too."""
+    if piece: monkeypatch.setenv('WGBSSEG_SCAN_PIECE_SITES', str(piece))
+    sg = _lib.Segmenter(0)
+    try:
+        n, N = 40000, 3
+        rng = np.random.default_rng(5)
+        clean = [synth.synth_betas(cases.SEED, s, 0, n) for s in range(N)]
+        loci = np.cumsum(rng.integers(2, 300, n)).astype(np.uint32)
+        sg.set_loci(loci)
+        chunks = [(100, 9000), (9100, 5000), (14100, 3333), (17433, 4096), (21529, 18471 - 100), (8900, 400), (14000, 300)]   # two runs + a gap [39900, n), two overlapping patch-like chunks
+        st0 = [c[0] for c in chunks]; ln = [c[1] for c in chunks]
+        covered = np.zeros(n, dtype=bool)
+        for a, l in chunks: covered[a:a + l] = True
+        def run(bad):
+            sl = [x.copy() for x in clean]
+            for s_, site in bad: sl[s_][site, 0] = sl[s_][site, 1] + 1
+            sg.set_betas(sl)
+            return sg.segment_chunks(st0, ln, 15.0, 1000, 2000)
+        run([])                                                                    # clean: no error
+        for site in [100, 9099, 9100, 14099, 14100, 1023, 1024, 1025, 4095, 4096, 16383, 16384, 16385, 17432, 17433, 21528, 21529, 32768, 39899]:
+            assert covered[site]
+            for s_ in (0, N - 1):
+                with pytest.raises(_lib.SegmentorError) as e:
+                    run([(s_, site)])
+                assert e.value.code == _lib.E_METH_GT_COV and 'sample %d' % s_ in e.value.msg and 'site %d ' % site in e.value.msg, (site, s_, e.value.msg)
+        for site in [0, 99, 39900, 39999]:                                         # outside every chunk: never read
+            assert not covered[site]
+            run([(1, site)])
+        with pytest.raises(_lib.SegmentorError) as e:                              # the lowest (sample, site) wins
+            run([(2, 150), (1, 30000), (1, 9000), (2, 120)])
+        assert 'sample 1' in e.value.msg and 'site 9000 ' in e.value.msg
+        # region level: [1, n] in chunks of 5000 -> chunks + junction patches (+ follow-up batches of patches)
+        sl = [x.copy() for x in clean]
+        sg.set_betas(sl)
+        ok, _ = sg.segment_regions([1], [n + 1], 5000, 15.0, 1000, 2000)
+        assert ok[0][0] == 1 and ok[0][-1] == n + 1
+        for site in [0, 4999, 5000, 5003, 39999]:
+            sl = [x.copy() for x in clean]
+            sl[1][site, 0] = sl[1][site, 1] + 1
+            sg.set_betas(sl)
+            with pytest.raises(_lib.SegmentorError) as e:
+                sg.segment_regions([1], [n + 1], 5000, 15.0, 1000, 2000)
+            assert e.value.code == _lib.E_METH_GT_COV and 'site %d ' % site in e.value.msg, e.value.msg
+    finally:
+        sg.close()
 
 
 # ---------------------------------------------------------------------------------------------------------

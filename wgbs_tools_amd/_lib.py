@@ -20,7 +20,7 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_set_betas_host', 'wgbsseg_set_betas_device', 'wgbsseg_set_loci_host', 'wgbsseg_set_loci_device',
            'wgbsseg_segment_chunks', 'wgbsseg_segment_regions', 'wgbsseg_segment_chunks_host', 'wgbsseg_prefix_sums', 'wgbsseg_scan_only',
            'wgbsseg_get_timings', 'wgbsseg_debug_fetch', 'wgbsseg_debug_sample_terms', 'wgbsseg_debug_log2',
-           'wgbsseg_debug_div', 'wgbsseg_add_loci', 'wgbsseg_block_sums', 'wgbsseg_last_block_sums_ms',
+           'wgbsseg_debug_div', 'wgbsseg_debug_check_div', 'wgbsseg_debug_div_short', 'wgbsseg_add_loci', 'wgbsseg_block_sums', 'wgbsseg_last_block_sums_ms',
            'wgbsseg_set_site_base', 'wgbsseg_stitch_regions', 'wgbsseg_group_create', 'wgbsseg_group_destroy', 'wgbsseg_group_size',
            'wgbsseg_group_plan', 'wgbsseg_group_load_host', 'wgbsseg_group_share_set_device', 'wgbsseg_group_segment_regions',
            'wgbsseg_group_get_timings', 'wgbsseg_plan_shares', 'wgbsseg_set_lbetas_host',
@@ -140,6 +140,10 @@ def load():
     L.wgbsseg_debug_sample_terms.argtypes = [vp, vp, vp, i64, C.c_float, vp]
     L.wgbsseg_debug_log2.restype = i32
     L.wgbsseg_debug_log2.argtypes = [vp, C.c_uint32, i64, vp, vp, vp]
+    L.wgbsseg_debug_div_short.restype = i32
+    L.wgbsseg_debug_div_short.argtypes = [vp, vp, vp, i64, vp]
+    L.wgbsseg_debug_check_div.restype = i32
+    L.wgbsseg_debug_check_div.argtypes = [vp, C.c_float, i32, vp]
     L.wgbsseg_debug_div.restype = i32
     L.wgbsseg_debug_div.argtypes = [vp, vp, vp, i64, vp, vp]
     L.wgbsseg_block_sums.restype = i32
@@ -389,6 +393,23 @@ class Segmenter:
                                                 C.c_float(pcount), out.ctypes.data)
         if rc != OK:
             raise SegmentorError(rc, 'debug_sample_terms failed')
+        return out
+
+    def debug_check_div(self, pseudo_count, max_total=255 * 60):
+        """Operand pairs of a narrow scoring tile for which the short division core is NOT the IEEE quotient (0: usable)."""
+        n = C.c_int64(0)
+        rc = self._L.wgbsseg_debug_check_div(self._h, C.c_float(pseudo_count), int(max_total), C.byref(n))
+        if rc != 0:
+            raise SegmentorError(rc, 'debug_check_div failed')
+        return int(n.value)
+
+    def debug_div_short(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        out = np.empty(a.size, dtype=np.uint32)
+        rc = self._L.wgbsseg_debug_div_short(self._h, a.ctypes.data, b.ctypes.data, a.size, out.ctypes.data)
+        if rc != 0:
+            raise SegmentorError(rc, 'debug_div_short failed')
         return out
 
     def debug_div(self, a, b):

@@ -443,6 +443,26 @@ WG_HD float wg_div_f32(float a, float b)
 #endif
 }
 
+// The short core: v_rcp_f32 (1 ulp), the quotient, ONE residual correction — 4 instructions.  The correction term carries a
+// relative error of about 2^-22 ulp of the quotient, so the result is the correctly rounded quotient unless a / b lies that
+// close to a rounding midpoint.  That cannot be excluded for arbitrary floats, but the operands of a narrow scoring tile are
+// few: a = fl(nmeth + pc), b = fl(ntotal + 2 pc), 0 <= nmeth <= ntotal <= 255 * 60.  The library checks ALL of them on the
+// device against the compiler's IEEE division for the pseudo count of a call (k_check_div: 1.2e8 pairs, ~0.1 ms, once per
+// context and pseudo count) and uses this form only when not one quotient differs; otherwise, and for wide tiles, the
+// 8-instruction core above.  (Integer pseudo counts: a / b of integers below 2^14 stays >= 2^-15 ulp away from every
+// midpoint, far outside the error; the check covers fractional ones.)
+WG_HD float wg_div_f32_short(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    const float res = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(res, r, q);
+#else
+    return a / b;
+#endif
+}
+
 // Preconditions of the fast form (the library dispatches on them; otherwise wg_sample_term_plain is used):
 // pc == 0 or pc >= WG_FAST_MIN_PC.  Then (a) p == 0 exactly or p >= 2^-45: p is a normal float and, when p > 0,
 // x = 1 - p < 1 strictly (wg_fast_log2's domain); (b) every non-zero sum is >= 2^-60 in magnitude, so the float
@@ -481,10 +501,11 @@ WG_HD float wg_sample_term_pcpos(float nmeth, float ntotal, float pc, float pc2,
 // fused multiply-add.  Against the reference's s = fl(ll + fl(df L)):  |df L' - fl(df L)| <= (E 2^-52 + 2^-53) |df L|,
 // |df L| <= |s| (both addends <= 0), one more rounding of at most half an ulp, and ulp(s) >= 2^-53 |s|: |s' - s| <=
 // (2 E + 2) ulp(s) < WG_GUARD_ULPS_KS.  Inside that band around a float rounding midpoint the exact form decides, as ever.
+template <bool DIVS = false>       // DIVS: the short division core (only where k_check_div has verified it for the call's operands)
 WG_HD float wg_sample_term_pcpos_ks(float nmeth, float ntotal, float pc, float pc2, const wg_d2* __restrict__ iys0,
                                     const wg_d2* __restrict__ kys0, const wg_log_tables* __restrict__ xt)
 {
-    const float p = wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
+    const float p = DIVS ? wg_div_f32_short(nmeth + pc, ntotal + pc2) : wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
     const double pd = (double)p;
     const float ll = nmeth * wg_log2f_ks(p, pd, iys0);             // :129-131
     const float df = wg_opaque_f32(ntotal) - nmeth;                // (opaque: or the subtraction moves to the integers the counts came from, one conversion more)

@@ -31,7 +31,6 @@
 #define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)
 #define WG_TRACE_WIN    32768       // back-pointers staged in LDS by k_trace (64 KiB)
 #define WG_TRACE_SEG    128         // speculative walks per window
-#define WG_SCAN_PIECES  4           // wave tasks per (chunk, sample) row of k_scan
 #define WG_NARROW_WMAX  60          // widest window of a narrow scoring tile: TI + 60 + 1 <= 125 entries, + 3 of alignment <= 128 = 32 lanes x 4 sites
 
 // Exact-restatement tables: global (constant) memory, read only by the rare guard-band fallback and by the plain kernel.
@@ -175,12 +174,11 @@ __device__ __noinline__ int wg_first_bad_site(uint4 v0, uint4 v1)      // index 
 __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int want_carry)
 {
     const int lane = threadIdx.x & 63;
-    // a wave task = one of WG_SCAN_PIECES pieces of one (chunk, sample) row.  With carries wanted the row is one serial
-    // scan (piece 0 runs it, the others leave at once); without, the pass only validates, every piece is independent and
-    // the four-times finer tasks even out the last round of waves on the chip
-    const int64_t task = (int64_t)blockIdx.x * (WG_BLOCK / 64) + (threadIdx.x >> 6);
-    const int64_t rowid = task / WG_SCAN_PIECES;
-    const int piece = (int)(task - rowid * WG_SCAN_PIECES);
+    // The carries have ONE consumer: the wide scoring tiles (windows > WG_NARROW_WMAX sites: CpG islands, deep mode), which
+    // k_window_scan has counted on this stream before this kernel starts.  A job without any (every default-parameter
+    // genome) needs none: this launch leaves at once and k_validate (launched beside it) does the read-only pass.
+    if (want_carry == 0 && __hip_atomic_load(&st->wide_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    const int64_t rowid = (int64_t)blockIdx.x * (WG_BLOCK / 64) + (threadIdx.x >> 6);      // a wave task = one (chunk, sample) row
     const int64_t nrows = (int64_t)J.n_chunks * J.n_samples;
     if (rowid >= nrows) return;                       // whole wave leaves together
     const int c = (int)(rowid / J.n_samples);
@@ -201,19 +199,12 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int
     const int A6 = (int)(a_abs & (WG_CARRY_G - 1));
     uint32_t run_m = 0, run_t = 0;
     int bad_rel = 0x7fffffff;
-    // The carries have ONE consumer: the wide scoring tiles (windows > WG_NARROW_WMAX sites: CpG islands, deep mode), which
-    // k_window_scan has counted on this stream before this kernel starts.  A job without any (every default-parameter
-    // genome) writes none: the pass is then read-only, and the write-back that used to hold it at 4.4 TB/s is gone.
-    const bool keep = want_carry != 0 || __hip_atomic_load(&st->wide_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
-    if (keep && piece != 0) return;
-    if (keep && lane == 0) carry[0] = make_uint2(0u, 0u);     // group 0: the chunk start
+    if (lane == 0) carry[0] = make_uint2(0u, 0u);     // group 0: the chunk start
     const int nit = (span + 1023) >> 10;              // 1024-site iterations of the row
-    const int it0 = keep ? 0 : (int)((int64_t)nit * piece / WG_SCAN_PIECES);
-    const int it1 = keep ? nit : (int)((int64_t)nit * (piece + 1) / WG_SCAN_PIECES);
 
-    int vi = 2 * lane + 128 * it0;                    // this lane's first vector of the current iteration
+    int vi = 2 * lane;                                // this lane's first vector of the current iteration
     uint4 c0 = rv[vi < vlast ? vi : vlast], c1 = rv[vi + 1 < vlast ? vi + 1 : vlast];
-    for (int base = it0 << 10; base < (it1 << 10); base += 1024) {
+    for (int base = 0; base < (nit << 10); base += 1024) {
         const int vn = vi + 128;                      // one iteration ahead (clamped: never past the row)
         const uint4 m0 = rv[vn < vlast ? vn : vlast], m1 = rv[vn + 1 < vlast ? vn + 1 : vlast];
         uint4 v0 = c0, v1 = c1;
@@ -228,20 +219,79 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int
         wg_sum8(v0, tm0, tt0, bad0);
         wg_sum8(v1, tm1, tt1, bad1);
         if ((bad0 || bad1) && bad_rel == 0x7fffffff) bad_rel = rel0 + wg_first_bad_site(v0, v1);   // rare
-        if (keep) {                                   // (wave-uniform)
-            const uint32_t tm = tm0 + tm1, tt = tt0 + tt1;
-            // wave-wide inclusive prefix of the lane totals (two 32-bit DPP scans)
-            const uint32_t im = wg_wave_incl_scan_dpp_u32(tm);
-            const uint32_t it = wg_wave_incl_scan_dpp_u32(tt);
-            if (((A6 + off) & (WG_CARRY_G - 1)) == 0 && rel0 > 0 && rel0 < len)
-                carry[(A6 + off) >> WG_CARRY_SHIFT] = make_uint2(run_m + (im - tm), run_t + (it - tt));
-            run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
-            run_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
-        }
+        const uint32_t tm = tm0 + tm1, tt = tt0 + tt1;
+        // wave-wide inclusive prefix of the lane totals (two 32-bit DPP scans)
+        const uint32_t im = wg_wave_incl_scan_dpp_u32(tm);
+        const uint32_t it = wg_wave_incl_scan_dpp_u32(tt);
+        if (((A6 + off) & (WG_CARRY_G - 1)) == 0 && rel0 > 0 && rel0 < len)
+            carry[(A6 + off) >> WG_CARRY_SHIFT] = make_uint2(run_m + (im - tm), run_t + (it - tt));
+        run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
+        run_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
         c0 = m0; c1 = m1; vi = vn;
     }
     if (bad_rel != 0x7fffffff)
         atomicMin(&st->first_bad, ((unsigned long long)s << 40) | (unsigned long long)(cd.start0 + bad_rel));
+}
+
+// k_validate: the scan pass of a job WITHOUT wide tiles — nobody reads carries, what is left of segmentor.cpp:164-190 is the
+// read itself and its `meth > cov` abort.  The host hands over the sites of the batch as disjoint pieces (the chunks of a
+// genome tile their regions; junction patches lie inside chunks the same call has already checked and add nothing), one
+// wave task = one (piece, sample): 64 lanes x 32 B per iteration, the next iteration in flight, loads clamped to the
+// piece so that no byte outside it is fetched; a packed compare per dword, no sums, no scans, no stores.
+// Leaves at once when the job has wide units (k_scan, launched beside it, then validates while it builds the carries).
+struct ScanPiece {
+    int64_t lo;          // first site (0-based, resident-relative)
+    int32_t n;           // sites
+    int32_t pad;
+};
+
+__device__ __forceinline__ uint32_t wg_ok8(const uint4 v, uint32_t ok)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        // a dword = two sites, bytes (m0, c0, m1, c1).  16-bit lanes (c + 0xff00) - m: bit 8 stays set iff cov >= meth (a lane
+        // never borrows from its neighbour: it is >= 0xff00 - 255)
+        const uint32_t c = __builtin_amdgcn_perm(0u, w[d], 0x0d030d01u);           // (c0, 0xff, c1, 0xff)
+        ok &= c - (w[d] & 0x00ff00ffu);
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(WG_BLOCK) void k_validate(JobView J, JobStatus* st, const ScanPiece* __restrict__ pieces, int64_t n_pieces)
+{
+    if (__hip_atomic_load(&st->wide_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t task = (int64_t)blockIdx.x * (WG_BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t pi = task / J.n_samples;
+    if (pi >= n_pieces) return;
+    const int s = (int)(task - pi * J.n_samples);
+    const ScanPiece P = pieces[pi];
+    const int64_t a_abs = P.lo & ~15LL;
+    const int head = (int)(P.lo - a_abs);
+    const int len = P.n;
+    const int span = head + len;
+    const uint4* rv = reinterpret_cast<const uint4*>(J.betas + (int64_t)s * J.pitch) + (a_abs >> 3);
+    const int vlast = (span - 1) >> 3;                // last vector that holds a site of the piece (it starts inside the row)
+    const int nit = (span + 1023) >> 10;
+    int bad_rel = 0x7fffffff;
+    int vi = 2 * lane;
+    uint4 c0 = rv[vi < vlast ? vi : vlast], c1 = rv[vi + 1 < vlast ? vi + 1 : vlast];
+    for (int base = 0; base < (nit << 10); base += 1024) {
+        const int vn = vi + 128;
+        const uint4 m0 = rv[vn < vlast ? vn : vlast], m1 = rv[vn + 1 < vlast ? vn + 1 : vlast];
+        uint4 v0 = c0, v1 = c1;
+        const int rel0 = base + lane * 16 - head;
+        if (rel0 < 0 || rel0 + 16 > len) {
+            v0 = wg_blank_outside(v0, rel0, len);
+            v1 = wg_blank_outside(v1, rel0 + 8, len);
+        }
+        const uint32_t ok = wg_ok8(v1, wg_ok8(v0, 0x01000100u));
+        if ((ok & 0x01000100u) != 0x01000100u && bad_rel == 0x7fffffff) bad_rel = rel0 + wg_first_bad_site(v0, v1);   // rare
+        c0 = m0; c1 = m1; vi = vn;
+    }
+    if (bad_rel != 0x7fffffff)
+        atomicMin(&st->first_bad, ((unsigned long long)s << 40) | (unsigned long long)(P.lo + bad_rel));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -664,7 +714,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     constexpr int IS = SPLIT ? WG_WIDE_TS + 1 : 0;                         // entries per sample row of the S array
     // pseudo count >= 1: both logs on their k-scaled lookup tables, A.rows exponents each (sized by the host to the
     // longest block of the tile class)
-    constexpr bool KY = (FAST == 2);
+    constexpr bool KY = (FAST >= 2);             // 2: k-scaled tables; 3: the same with the short division core (narrow tiles, verified per call)
+    constexpr bool DIVS = (FAST == 3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // KY: only the two lookup tables, A.rows exponents each; otherwise the general fast tables
     const size_t TB = KY ? (size_t)A.rows * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
@@ -784,7 +835,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 auto one = [&](int sl) {
                     const uint2 pi = Ep[sl * KS];
                     const uint2 pk = Sp[sl * IS];
-                    if (KY) acc += (double)wg_sample_term_pcpos_ks((float)(pi.x - pk.x), (float)(pi.y - pk.y), pc, pc2, iy0, ky0, &g_wg_tables);
+                    if (KY) acc += (double)wg_sample_term_pcpos_ks<DIVS>((float)(pi.x - pk.x), (float)(pi.y - pk.y), pc, pc2, iy0, ky0, &g_wg_tables);
                     else acc += term((float)(pi.x - pk.x), (float)(pi.y - pk.y));
                 };
                 int sl = 0;
@@ -795,7 +846,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 const uint32_t* Sp = Lt + lo;              // L[k-ka]
                 auto one = [&](int sl) {
                     const uint32_t d = Ep[sl * KS] - Sp[sl * KS];                // both fields at once: no borrow, L is monotone per field
-                    if (KY) acc += (double)wg_sample_term_pcpos_ks((float)(d & 0xffffu), (float)(d >> 16), pc, pc2, iy0, ky0, &g_wg_tables);
+                    if (KY) acc += (double)wg_sample_term_pcpos_ks<DIVS>((float)(d & 0xffffu), (float)(d >> 16), pc, pc2, iy0, ky0, &g_wg_tables);
                     else acc += term((float)(d & 0xffffu), (float)(d >> 16));
                 };
                 int sl = 0;
@@ -2020,6 +2071,30 @@ __global__ void k_debug_terms(const float* nm, const float* nt, int64_t count, f
     }
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x)
         out[q] = fast == 1 ? wg_sample_term(nm[q], nt[q], pc, pc2, &tb, &g_wg_tables) : wg_sample_term_plain(nm[q], nt[q], pc, pc2, &g_wg_tables);
+}
+
+// k_check_div: does the short division core give the IEEE quotient for EVERY operand pair a narrow scoring tile can form with
+// this pseudo count?  a = fl(nmeth + pc), b = fl(ntotal + pc2), 0 <= nmeth <= ntotal <= max_total.  One workgroup per ntotal.
+// *mismatches counts the pairs that differ (0 = the short core may be used).
+__global__ __launch_bounds__(WG_BLOCK) void k_check_div(float pc, float pc2, int max_total, unsigned int* __restrict__ mismatches)
+{
+    const int nt_i = (int)blockIdx.x;
+    if (nt_i > max_total) return;
+    const float b = (float)nt_i + pc2;
+    unsigned int bad = 0;
+    for (int nm_i = (int)threadIdx.x; nm_i <= nt_i; nm_i += WG_BLOCK) {
+        const float a = (float)nm_i + pc;
+        const float want = wg_opaque_f32(a) / wg_opaque_f32(b);                  // the compiler's full IEEE sequence
+        bad += wg_f2u(wg_div_f32_short(a, b)) != wg_f2u(want) ? 1u : 0u;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// test hook: the short division core on arrays of operands
+__global__ void k_debug_div_short(const float* a, const float* b, int64_t count, uint32_t* out)
+{
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (int64_t)gridDim.x * blockDim.x)
+        out[q] = wg_f2u(wg_div_f32_short(a[q], b[q]));
 }
 
 // test hook: wg_div_f32 vs the compiler's IEEE division, both on the device

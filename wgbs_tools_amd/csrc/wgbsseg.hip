@@ -138,6 +138,16 @@ struct wgbsseg_ctx {
     double last_block_sums_ms = 0.0;
     int64_t table_blocks = 0;  // > 0: dbg_b still holds the [n_samples][table_blocks] ratio table of the last mode-3 block reduction
     bool accumulate = false;   // add to `tim` instead of resetting it (region-level calls span several batches)
+    // site ranges whose `meth <= cov` check has run in the API call in flight (sorted, disjoint): the follow-up batches of a
+    // region-level call hold junction patches only, all inside chunks its first batch has validated.  Never kept across
+    // API calls: device-resident betas handed over by pointer may change between them.
+    std::vector<std::pair<int64_t, int64_t>> validated;
+    DevBuf scan_pieces, divcheck;
+    // the short division core of the narrow scoring tiles: verified on the device per pseudo count (k_check_div)
+    float divs_pc = -1.0f;     // pseudo count the verdict below is for
+    bool divs_ok = false;
+    bool divs_enabled = true;  // WGBSSEG_DIV_SHORT=0: always the 8-instruction core
+    int64_t scan_piece_sites = 16384;   // WGBSSEG_SCAN_PIECE_SITES: sites per wave task of k_validate (multiple of 1024)
 };
 
 namespace {
@@ -253,6 +263,10 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     c->force_ti = ft ? atoi(ft) : 0;
     const char* ms = getenv("WGBSSEG_MIN_STAGES");
     if (ms && atoi(ms) > 0) c->min_stages = atoi(ms);
+    const char* dv = getenv("WGBSSEG_DIV_SHORT");
+    if (dv) c->divs_enabled = atoi(dv) != 0;
+    const char* sp = getenv("WGBSSEG_SCAN_PIECE_SITES");
+    if (sp && atoi(sp) >= 1024) c->scan_piece_sites = (int64_t)(atoi(sp) & ~1023);
     *out = c;
     return WGBSSEG_OK;
 }
@@ -348,6 +362,8 @@ namespace {
 // Host copy of the chunk table + job-wide offsets; uploads it and builds the JobView.
 struct Job {
     std::vector<ChunkDesc> h;
+    std::vector<ScanPiece> pieces;      // what k_validate reads: the batch's sites not yet validated in this API call, cut into wave tasks
+    int64_t val_sites = 0;
     std::vector<int64_t> wtile_off;     // exclusive prefix of 256-site tiles per chunk (+ total), then (as int32 pairs) the chunk of every 256th tile
     int64_t sites = 0, carry_entries = 0, units = 0, n_hint = 0;
     int32_t max_len = 0;
@@ -412,13 +428,72 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
     return WGBSSEG_OK;
 }
 
+bool interval_covered(const std::vector<std::pair<int64_t, int64_t>>& v, int64_t lo, int64_t hi)
+{
+    // v sorted by first site: the last interval that begins at or before lo (false negatives only when intervals overlap)
+    auto it = std::upper_bound(v.begin(), v.end(), lo, [](int64_t x, const std::pair<int64_t, int64_t>& iv) { return x < iv.first; });
+    return it != v.begin() && (--it)->second >= hi;
+}
+
+// The sites of a batch that still need the `meth <= cov` pass in this API call, as wave tasks of k_validate.  Chunks of a
+// genome arrive in order and tile their regions: they fuse into one run per region; junction patches (same batch or a
+// follow-up batch) fall inside runs and drop out.  Arbitrary chunk lists work too (overlaps are validated twice).
+int plan_validation(wgbsseg_ctx* c, Job& job, bool fresh_call, char* err, size_t errlen)
+{
+    if (fresh_call) c->validated.clear();
+    std::vector<std::pair<int64_t, int64_t>> runs;
+    bool sorted = true;
+    for (const ChunkDesc& d : job.h) {
+        const int64_t lo = d.start0, hi = d.start0 + d.len;
+        if (!runs.empty() && lo == runs.back().second) { runs.back().second = hi; continue; }
+        if (interval_covered(c->validated, lo, hi) || (sorted && interval_covered(runs, lo, hi))) continue;
+        if (!runs.empty() && lo < runs.back().first) sorted = false;
+        runs.emplace_back(lo, hi);
+    }
+    const int64_t P = c->scan_piece_sites;
+    job.pieces.clear(); job.val_sites = 0;
+    for (const auto& r : runs) {
+        job.val_sites += r.second - r.first;
+        for (int64_t a = r.first; a < r.second; ) {
+            const int64_t b = std::min(r.second, (a / P + 1) * P);          // cut on absolute multiples of P: aligned streams
+            job.pieces.push_back(ScanPiece{a, (int32_t)(b - a), 0});
+            a = b;
+        }
+    }
+    if (!runs.empty()) {
+        std::vector<std::pair<int64_t, int64_t>>& V = c->validated;
+        V.insert(V.end(), runs.begin(), runs.end());
+        std::sort(V.begin(), V.end());
+        size_t w = 0;
+        for (size_t i = 1; i < V.size(); i++) {
+            if (V[i].first <= V[w].second) V[w].second = std::max(V[w].second, V[i].second);
+            else V[++w] = V[i];
+        }
+        V.resize(w + 1);
+        HIP_TRY(c->scan_pieces.ensure(sizeof(ScanPiece) * job.pieces.size()));
+        HIP_TRY(hipMemcpyAsync(c->scan_pieces.p, job.pieces.data(), sizeof(ScanPiece) * job.pieces.size(), hipMemcpyHostToDevice, c->sA));
+    }
+    return WGBSSEG_OK;
+}
+
+// The scan pass: k_scan (per chunk, with carries; does its work only when the job has wide units or the caller wants the
+// carries) and k_validate (per piece, read-only; only when it has none).  The device-side flag decides, so both can be
+// queued before the host has seen the window statistics.
 int launch_scan(wgbsseg_ctx* c, const Job& job, int want_carry, char* err, size_t errlen)
 {
-    const int64_t rows = (int64_t)job.v.n_chunks * job.v.n_samples * WG_SCAN_PIECES;      // wave tasks
+    const int64_t rows = (int64_t)job.v.n_chunks * job.v.n_samples;      // wave tasks
     const int64_t blocks = (rows + (WG_BLOCK / 64) - 1) / (WG_BLOCK / 64);
     if (blocks > 0x7fffffff) { set_err(err, errlen, "too many (chunk, sample) rows"); return WGBSSEG_E_ARG; }
     hipLaunchKernelGGL(k_scan, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, c->sA, job.v, c->status.as<JobStatus>(), want_carry);
     HIP_TRY(hipGetLastError());
+    if (!want_carry && !job.pieces.empty()) {
+        const int64_t tasks = (int64_t)job.pieces.size() * job.v.n_samples;
+        const int64_t vb = (tasks + (WG_BLOCK / 64) - 1) / (WG_BLOCK / 64);
+        if (vb > 0x7fffffff) { set_err(err, errlen, "too many (piece, sample) rows"); return WGBSSEG_E_ARG; }
+        hipLaunchKernelGGL(k_validate, dim3((unsigned)vb), dim3(WG_BLOCK), 0, c->sA, job.v, c->status.as<JobStatus>(),
+                           c->scan_pieces.as<ScanPiece>(), (int64_t)job.pieces.size());
+        HIP_TRY(hipGetLastError());
+    }
     return WGBSSEG_OK;
 }
 
@@ -444,7 +519,7 @@ hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a,
 template <int FAST>
 hipError_t launch_cost_ti(int TI, bool wide, const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
-    if (wide) return launch_cost<WG_WIDE_TS, FAST, 1>(v, sv, a, td, tiles, cost, lds, s);
+    if (wide) return launch_cost<WG_WIDE_TS, FAST == 3 ? 2 : FAST, 1>(v, sv, a, td, tiles, cost, lds, s);      // (the short division is a narrow-tile form)
     if (TI == 128) return launch_cost<128, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
     if (TI == 64) return launch_cost<64, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
     if (TI == 32) return launch_cost<32, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
@@ -458,7 +533,7 @@ hipError_t set_cost_attrs()
 {
     const void* fns[] = {reinterpret_cast<const void*>(&k_cost<128, FAST, 0>),
                          reinterpret_cast<const void*>(&k_cost<64, FAST, 0>), reinterpret_cast<const void*>(&k_cost<32, FAST, 0>),
-                         reinterpret_cast<const void*>(&k_cost<16, FAST, 0>), reinterpret_cast<const void*>(&k_cost<WG_WIDE_TS, FAST, 1>)};
+                         reinterpret_cast<const void*>(&k_cost<16, FAST, 0>), reinterpret_cast<const void*>(&k_cost<WG_WIDE_TS, FAST == 3 ? 2 : FAST, 1>)};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -470,6 +545,7 @@ hipError_t set_kernel_attributes()
     hipError_t e = set_cost_attrs<0>();
     if (e == hipSuccess) e = set_cost_attrs<1>();
     if (e == hipSuccess) e = set_cost_attrs<2>();
+    if (e == hipSuccess) e = set_cost_attrs<3>();
     const void* dps[] = {reinterpret_cast<const void*>(&k_dp<3, 64>), reinterpret_cast<const void*>(&k_dp<7, 64>),
                          reinterpret_cast<const void*>(&k_dp<7, 32>), reinterpret_cast<const void*>(&k_dp<3, 32>),
                          reinterpret_cast<const void*>(&k_dp<15, 32>)};
@@ -506,6 +582,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     Job job;
     int rc = build_job(c, chunk_start0, chunk_len, n_chunks, job, true, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
+    rc = plan_validation(c, job, !c->accumulate, err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
     c->last_valid = false;
     const int nC = (int)n_chunks;
     const int64_t J = job.sites;
@@ -524,6 +602,19 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // hides behind the scan pass (whose own verdict, meth > cov, is read with the plan totals further down).
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
     if (job.wtile_off[(size_t)nC] > 0x7fffffff) { set_err(err, errlen, "too many sites in one call"); return WGBSSEG_E_ARG; }
+    if (!c->h_status.ensure(4 * sizeof(JobStatus))) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
+    // a pseudo count this context has not scored with yet: may the narrow tiles use the short division core?  Every operand
+    // pair they can form is tried on the device (0.1 ms, once); the verdict arrives with the window statistics.
+    const bool check_div = c->divs_enabled && wg_term_mode(P->pseudo_count) == 2 && c->divs_pc != P->pseudo_count;
+    if (check_div) {
+        HIP_TRY(c->divcheck.ensure(4));
+        HIP_TRY(hipMemsetAsync(c->divcheck.p, 0, 4, c->sA));
+        const int max_total = 255 * WG_NARROW_WMAX;
+        hipLaunchKernelGGL(k_check_div, dim3((unsigned)max_total + 1), dim3(WG_BLOCK), 0, c->sA, P->pseudo_count, P->pseudo_count + P->pseudo_count,
+                           max_total, c->divcheck.as<unsigned int>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(reinterpret_cast<JobStatus*>(c->h_status.p) + 1, c->divcheck.p, 4, hipMemcpyDeviceToHost, c->sA));
+    }
     // loci of a 1024-site tile and of everything its windows can reach, in LDS (<= 48 KB; deeper windows search in L2)
     const int win_cap = (int)std::min<int64_t>((int64_t)WG_WIN_TILE + P->max_cpg - 1, 12288);
     const int win_lds = ((int64_t)WG_WIN_TILE + P->max_cpg - 1 <= 12288) ? win_cap : 0;
@@ -533,7 +624,6 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     hipLaunchKernelGGL(k_window_scan, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, c->status.as<JobStatus>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
-    if (!c->h_status.ensure(4 * sizeof(JobStatus))) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
     JobStatus* hst = reinterpret_cast<JobStatus*>(c->h_status.p);
     HIP_TRY(hipMemcpyAsync(&hst[0], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipEventRecord(c->ev[7], c->sA));
@@ -542,6 +632,11 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipEventRecord(c->ev[2], c->sA));
     HIP_TRY(hipEventSynchronize(c->ev[7]));                    // window statistics are here; the scan is still running
     const JobStatus st = hst[0];
+    if (check_div) {
+        c->divs_ok = *reinterpret_cast<const unsigned int*>(&hst[1]) == 0u;
+        c->divs_pc = P->pseudo_count;
+        if (profiling()) fprintf(stderr, "[wgbsseg] short division core for pseudo count %g: %s\n", (double)P->pseudo_count, c->divs_ok ? "verified on every operand pair of a narrow tile" : "NOT exact, the full core stays");
+    }
     if (st.loci_disorder || st.overflow) {
         JobStatus st2;                                        // the scan's verdict takes precedence, as it always has
         HIP_TRY(hipMemcpyAsync(&st2, c->status.p, sizeof(st2), hipMemcpyDeviceToHost, c->sA));
@@ -721,7 +816,9 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipEventRecord(c->ev_cost0[stg], c->sA));
         if (stage_tiles[2 * (size_t)stg] > 0) {
             const TileDesc* td = c->tilesA.as<TileDesc>() + tileA0[(size_t)stg];
-            hipError_t e = term_mode == 2 ? launch_cost_ti<2>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
+            const bool divs = c->divs_enabled && c->divs_ok && c->divs_pc == P->pseudo_count;
+            hipError_t e = term_mode == 2 ? (divs ? launch_cost_ti<3>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
+                                                  : launch_cost_ti<2>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA))
                          : (term_mode == 1 ? launch_cost_ti<1>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
                                            : launch_cost_ti<0>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA));
             HIP_TRY(e);
@@ -777,7 +874,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     if (!c->accumulate) memset(&T, 0, sizeof(T));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[7], c->ev[2])); T.scan_ms += ms;
-    if (2 * J * c->n_samples > T.scan_main_bytes) { T.scan_main_bytes = 2 * J * c->n_samples; T.scan_main_ms = ms; }
+    // algorithmic bytes of the pass: with wide units k_scan reads every chunk row of the batch; without, k_validate reads the
+    // batch's not-yet-validated sites once
+    const int64_t scan_bytes = 2 * (st.wide_units ? J : job.val_sites) * c->n_samples;
+    if (scan_bytes > T.scan_main_bytes) { T.scan_main_bytes = scan_bytes; T.scan_main_ms = ms; }
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); T.window_ms += ms;
     for (int stg = 0; stg < n_stages; stg++) {
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_cost0[stg], c->ev_cost1[stg])); T.cost_ms += ms;
@@ -786,7 +886,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5])); T.trace_ms += ms;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[6])); T.total_ms += ms;
     T.sites += J; T.pairs += total_pairs; T.evals += total_pairs * c->n_samples;
-    T.scan_bytes += 2 * J * c->n_samples; T.max_window = std::max<int32_t>(T.max_window, Wmax);
+    T.scan_bytes += scan_bytes; T.max_window = std::max<int32_t>(T.max_window, Wmax);
     T.n_stages = std::max<int32_t>(T.n_stages, n_stages); T.scan_launches += 1;
     c->last_sites = J; c->last_pairs = total_pairs; c->last_stages = n_stages; c->last_valid = true;
     return WGBSSEG_OK;
@@ -1396,8 +1496,11 @@ int wgbsseg_scan_only(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t
     Job job;
     int rc = build_job(c, chunk_start0, chunk_len, n_chunks, job, false, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
+    rc = plan_validation(c, job, true, err, errlen);
+    if (rc != WGBSSEG_OK) return rc;
+    c->validated.clear();
     if (repeat < 1) repeat = 1;
-    rc = launch_scan(c, job, 0, err, errlen);                  // warm-up (a fresh status block: no wide units, no carry stores)
+    rc = launch_scan(c, job, 0, err, errlen);                  // warm-up (a fresh status block: no wide units, so the read-only pass)
     if (rc != WGBSSEG_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
     for (int r = 0; r < repeat; r++) { rc = launch_scan(c, job, 0, err, errlen); if (rc != WGBSSEG_OK) return rc; }
@@ -1406,7 +1509,7 @@ int wgbsseg_scan_only(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     if (ms_per_launch) *ms_per_launch = (double)ms / repeat;
-    if (bytes_per_launch) *bytes_per_launch = 2 * job.sites * c->n_samples;
+    if (bytes_per_launch) *bytes_per_launch = 2 * job.val_sites * c->n_samples;
     JobStatus st;
     HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
@@ -1770,6 +1873,40 @@ int wgbsseg_debug_div(wgbsseg_ctx* c, const float* a, const float* b, int64_t co
     HIP_TRY(hipMemcpyAsync(out_fast, o1, (size_t)count * 4, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipMemcpyAsync(out_ieee, o2, (size_t)count * 4, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_debug_div_short(wgbsseg_ctx* c, const float* a, const float* b, int64_t count, uint32_t* out)
+{
+    char* err = nullptr; size_t errlen = 0;
+    if (!c || !a || !b || !out || count < 1) return WGBSSEG_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->dbg_a.ensure((size_t)count * 8)); HIP_TRY(c->dbg_b.ensure((size_t)count * 4));
+    float* da = c->dbg_a.as<float>(); float* db = da + count;
+    HIP_TRY(hipMemcpyAsync(da, a, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
+    HIP_TRY(hipMemcpyAsync(db, b, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
+    const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_debug_div_short, dim3(blocks), dim3(256), 0, c->sA, da, db, count, c->dbg_b.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->dbg_b.p, (size_t)count * 4, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_debug_check_div(wgbsseg_ctx* c, float pseudo_count, int32_t max_total, int64_t* mismatches)
+{
+    char* err = nullptr; size_t errlen = 0;
+    if (!c || !mismatches || max_total < 0 || max_total > (1 << 21)) return WGBSSEG_E_ARG;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->divcheck.ensure(4));
+    HIP_TRY(hipMemsetAsync(c->divcheck.p, 0, 4, c->sA));
+    hipLaunchKernelGGL(k_check_div, dim3((unsigned)max_total + 1), dim3(WG_BLOCK), 0, c->sA, pseudo_count, pseudo_count + pseudo_count,
+                       (int)max_total, c->divcheck.as<unsigned int>());
+    HIP_TRY(hipGetLastError());
+    unsigned int n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, c->divcheck.p, 4, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    *mismatches = (int64_t)n;
     return WGBSSEG_OK;
 }
 
