@@ -144,16 +144,17 @@ def test_02c_short_division_core_is_used_only_where_it_is_exact(seg, pcount):
         assert full == 0
 
 
-def test_02d_verdict_kernel_sees_a_wrong_quotient(seg):
-    """The short core is not IEEE division in general: far outside the narrow-tile domain (operands with all 24 bits in
-    play) it does differ now and then, and the verdict kernel must say so."""
+def test_02d_verdict_kernel_is_not_blind(seg):
+    """Where the short core cannot work — a pseudo count whose double overflows: b = inf, IEEE gives 0, the core's residual is
+    NaN — the verdict kernel must count every pair.  (On full-width random floats the core has not been seen to differ from
+    IEEE division at all — v_rcp_f32 is better than its 1 ulp bound there — which is recorded here, not relied upon.)"""
+    assert seg.debug_check_div(3e38, 100) == 101 * 102 // 2
     rng = np.random.default_rng(11)
     a = rng.uniform(1.0, 2.0, 20000000).astype(np.float32)
     b = rng.uniform(1.0, 2.0, 20000000).astype(np.float32)
     short = seg.debug_div_short(a, b)
     want = (a / b).astype(np.float32).view(np.uint32)
     print('short core vs IEEE on 2e7 random pairs of full-width floats: %d differ' % int((short != want).sum()))
-    assert int((short != want).sum()) > 0
 
 
 def test_07c_full_division_core_on_every_case(golden_chunks):
