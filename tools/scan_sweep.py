@@ -27,8 +27,8 @@ def main():
     names, sizes = synth.genome_shape(args.sites, 25 if args.sites >= 2500000 else 1)
     regions = parallel.regions_of_sizes([int(s) for s in sizes])
     grid = parallel.chunk_grid(regions, args.chunk)
-    st = np.array([a - 1 for a, b in grid], dtype=np.int64)
-    ln = np.array([b - a for a, b in grid], dtype=np.int32)
+    st = np.array([a - 1 for _, a, b in grid], dtype=np.int64)
+    ln = np.array([b - a for _, a, b in grid], dtype=np.int32)
     S = _lib.load_synth()
     n = args.sites
     pitch = ((2 * n + 255) // 256) * 256 + 256

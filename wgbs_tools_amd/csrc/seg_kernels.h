@@ -106,7 +106,7 @@ struct StageView {            // tables produced by k_stage_plan, row `stage` of
     const int64_t* tbaseA;    // [n_stages][n_chunks+1] exclusive prefix of the narrow k_cost tiles
     const int64_t* tbaseB;    // [n_stages][n_chunks+1] exclusive prefix of the wide k_cost tiles
     int32_t stage;
-    int32_t S;                // sites of each chunk per stage (multiple of 64)
+    const int32_t* sb;        // [n_stages + 1] stage s covers the chunk-relative sites [sb[s], sb[s+1]) of every chunk (multiples of 64; the last bound >= the longest chunk)
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window_scan(JobView J, JobStatus* 
 // k_tile_count counts the tiles of each class per (stage, chunk); k_stage_plan turns the counts into per-stage
 // prefixes over the chunks; k_tile_emit writes the tile descriptors in site order.
 // ------------------------------------------------------------------------------------------------------------
-struct PlanArgs { int32_t S, TI, WA, TK, n_stages; };
+struct PlanArgs { const int32_t* sb; int32_t TI, WA, TK, n_stages; };     // sb: stage bounds, as in StageView
 
 struct TileDesc { int32_t chunk, ka, nk, et_lo; };     // start sites [ka, ka+nk); wide tiles: end sites [et_lo, et_lo+TK)
 
@@ -451,10 +451,10 @@ __global__ __launch_bounds__(WG_BLOCK) void k_tile_count(JobView J, PlanArgs P, 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = blockIdx.x, stg = blockIdx.y;
     const ChunkDesc cd = J.chunks[c];
-    const int s0 = stg * P.S;
+    const int s0 = P.sb[stg];
     uint32_t a = 0, b = 0;
     if (s0 < cd.len) {
-        const int s1 = (s0 + P.S < cd.len) ? s0 + P.S : cd.len;
+        const int s1 = (P.sb[stg + 1] < cd.len) ? P.sb[stg + 1] : cd.len;
         const int nU = (s1 - s0 + P.TI - 1) / P.TI;
         for (int u = tid; u < nU; u += WG_BLOCK) {
             uint32_t na, nb;
@@ -490,9 +490,9 @@ __global__ __launch_bounds__(WG_BLOCK) void k_stage_plan(JobView J, PlanArgs P, 
         uint32_t c0 = 0;
         if (c < nC) {
             const ChunkDesc cd = J.chunks[c];
-            const int64_t s0 = (int64_t)stg * P.S;
+            const int64_t s0 = P.sb[stg];
             if (s0 < cd.len) {
-                const int64_t s1 = (s0 + P.S < cd.len) ? s0 + P.S : cd.len;
+                const int64_t s1 = (P.sb[stg + 1] < cd.len) ? P.sb[stg + 1] : cd.len;
                 c0 = J.cum32[cd.site_off + s0];
                 const uint64_t cend = (s1 < cd.len) ? (uint64_t)J.cum32[cd.site_off + s1] : (uint64_t)J.chunk_pairs[c];
                 sz = cend - c0;
@@ -534,9 +534,9 @@ __global__ __launch_bounds__(WG_BLOCK) void k_tile_emit(JobView J, PlanArgs P, i
     const int c = blockIdx.x;
     const int nC = J.n_chunks;
     const ChunkDesc cd = J.chunks[c];
-    const int s0 = stg * P.S;
+    const int s0 = P.sb[stg];
     if (s0 >= cd.len) return;
-    const int s1 = (s0 + P.S < cd.len) ? s0 + P.S : cd.len;
+    const int s1 = (P.sb[stg + 1] < cd.len) ? P.sb[stg + 1] : cd.len;
     const int nU = (s1 - s0 + P.TI - 1) / P.TI;
     int64_t runA = tbaseA[(int64_t)stg * (nC + 1) + c], runB = tbaseB[(int64_t)stg * (nC + 1) + c];
     for (int base = 0; base < nU; base += WG_BLOCK) {
@@ -1225,9 +1225,9 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     const int c = blockIdx.x;
     const int nC = J.n_chunks;
     const ChunkDesc cd = J.chunks[c];
-    const int s0 = SV.stage * SV.S;
+    const int s0 = SV.sb[SV.stage];
     if (s0 >= cd.len) return;
-    const int s1 = (s0 + SV.S < cd.len) ? s0 + SV.S : cd.len;
+    const int s1 = (SV.sb[SV.stage + 1] < cd.len) ? SV.sb[SV.stage + 1] : cd.len;
     const int rmask = A.ringN - 1;
     double* gs = state + (int64_t)c * state_stride;
     double* pendB = gs + WG_DP_STATE_HDR;                                     // [ringN]
@@ -1455,9 +1455,9 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp16(JobView J, StageView SV,
     const int c = blockIdx.x;
     const int nC = J.n_chunks;
     const ChunkDesc cd = J.chunks[c];
-    const int s0 = SV.stage * SV.S;
+    const int s0 = SV.sb[SV.stage];
     if (s0 >= cd.len) return;
-    const int s1 = (s0 + SV.S < cd.len) ? s0 + SV.S : cd.len;
+    const int s1 = (SV.sb[SV.stage + 1] < cd.len) ? SV.sb[SV.stage + 1] : cd.len;
     double* gs = state + (int64_t)c * state_stride;
     const double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];

@@ -142,7 +142,9 @@ struct wgbsseg_ctx {
     // region-level call hold junction patches only, all inside chunks its first batch has validated.  Never kept across
     // API calls: device-resident betas handed over by pointer may change between them.
     std::vector<std::pair<int64_t, int64_t>> validated;
-    DevBuf scan_pieces, divcheck;
+    DevBuf scan_pieces, divcheck, plan_sb;
+    std::vector<int32_t> h_stage_bounds;
+    double tail_frac = -1.0;   // WGBSSEG_TAIL_FRAC: share of every chunk scored in the second of two uneven stages (many-chunk jobs); 0: one stage; < 0: from the call's size
     // the short division core of the narrow scoring tiles: verified on the device per pseudo count (k_check_div)
     float divs_pc = -1.0f;     // pseudo count the verdict below is for
     bool divs_ok = false;
@@ -263,6 +265,8 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     c->force_ti = ft ? atoi(ft) : 0;
     const char* ms = getenv("WGBSSEG_MIN_STAGES");
     if (ms && atoi(ms) > 0) c->min_stages = atoi(ms);
+    const char* tf = getenv("WGBSSEG_TAIL_FRAC");
+    if (tf) c->tail_frac = std::min(0.9, atof(tf));
     const char* dv = getenv("WGBSSEG_DIV_SHORT");
     if (dv) c->divs_enabled = atoi(dv) != 0;
     const char* sp = getenv("WGBSSEG_SCAN_PIECE_SITES");
@@ -734,6 +738,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
 
     // ---- stages: bound the scored-block buffer and overlap scoring (stream A) with the recurrence (stream B) --
     int n_stages = 1;
+    bool tail_split = false;          // two uneven stages: the recurrence of the long first one hides behind the scoring of the short last one
     {
         const long long bytes = total_pairs * 8;
         n_stages = (int)std::max<long long>(1, (bytes + c->cost_budget_bytes - 1) / c->cost_budget_bytes);
@@ -744,18 +749,41 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         int n_long = 0;
         for (const ChunkDesc& d : job.h) n_long += d.len >= 8192;
         if (job.max_len >= 8192) n_stages = std::max(n_stages, c->min_stages > 0 ? c->min_stages : (n_long <= 160 ? 8 : 1));
+        // Many chunks, all windows <= 64: one stage scores and k_dp<7,64> follows alone (1.8 ms exposed).  Instead: score the
+        // first (1 - f) of every chunk, then score the rest while k_dp16 (the footprint of one scoring workgroup) runs the
+        // recurrence of the first part beside it; only the last part's recurrence (k_dp<7,64>, alone again) is exposed.
+        if (n_stages == 1 && c->force_stages <= 0 && c->min_stages <= 0 && job.max_len >= 8192 && Wmax <= 64 && c->tail_frac != 0.0) { n_stages = 2; tail_split = true; }
         if (c->force_stages > 0) n_stages = c->force_stages;
         n_stages = std::min<int>(n_stages, std::max(1, (job.max_len + 63) / 64));
     }
-    const int S = (int)round_up((job.max_len + n_stages - 1) / n_stages, 64);
-    n_stages = (job.max_len + S - 1) / S;
+    std::vector<int32_t>& sb = c->h_stage_bounds;              // (lives in the context: source of an async upload)
+    if (tail_split) {
+        // the second stage must score for as long as k_dp16 needs for the first: ~3.5 ms per 60,000 steps beside the scoring
+        // kernel (measured), against evaluations at ~7.5e11 / s
+        double f = c->tail_frac;
+        if (f < 0.0) {
+            const double t_dp = 3.5e-3 * (double)job.max_len / 60000.0, t_cost = (double)total_pairs * Nsmp / 7.5e11;
+            f = std::min(0.5, 1.25 * t_dp / (t_cost + t_dp));
+        }
+        const int cut = (int)std::max<int64_t>(64, round_up((int64_t)((1.0 - f) * job.max_len), 64));
+        tail_split = cut < job.max_len;
+        sb.assign({0, std::min<int32_t>(cut, job.max_len)});
+        if (tail_split) sb.push_back(job.max_len); else n_stages = 1;
+    } else {
+        const int S = (int)round_up((job.max_len + n_stages - 1) / n_stages, 64);
+        n_stages = (job.max_len + S - 1) / S;
+        sb.resize((size_t)n_stages + 1);
+        for (int q = 0; q <= n_stages; q++) sb[(size_t)q] = (int32_t)std::min<int64_t>((int64_t)q * S, job.max_len);
+    }
+    HIP_TRY(c->plan_sb.ensure(sb.size() * 4));
+    HIP_TRY(hipMemcpyAsync(c->plan_sb.p, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, c->sA));
     HIP_TRY(c->plan_cbase.ensure((size_t)n_stages * nC * 8));
     HIP_TRY(c->plan_cum0.ensure((size_t)n_stages * nC * 4));
     HIP_TRY(c->plan_tbase.ensure((size_t)n_stages * (nC + 1) * 8 * 2));
     HIP_TRY(c->plan_cnt.ensure((size_t)n_stages * nC * 4 * 2));
     HIP_TRY(c->plan_pairs.ensure((size_t)n_stages * 8));
     HIP_TRY(c->plan_tiles.ensure((size_t)n_stages * 8 * 2));
-    PlanArgs pa = {S, TI, WA, TKB, n_stages};
+    PlanArgs pa = {c->plan_sb.as<int32_t>(), TI, WA, TKB, n_stages};
     uint32_t* cntA = c->plan_cnt.as<uint32_t>();
     uint32_t* cntB = cntA + (size_t)n_stages * nC;
     int64_t* tbaseA = c->plan_tbase.as<int64_t>();
@@ -805,7 +833,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     grow_events(c->ev_dp0, n_stages); grow_events(c->ev_dp1, n_stages);
     StageView sv;
     sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbaseA = tbaseA; sv.tbaseB = tbaseB;
-    sv.S = S;
+    sv.sb = c->plan_sb.as<int32_t>();
     // LDS of k_dp: two arranged batches (64 steps x 64 lanes, or 32 steps x 64 lanes x {A, B}) + M ring + fetched ring entries + flags + ring of windows / row offsets
     DpArgs da = {ringN, {0, 0, 0}};
     const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16 + 1024 * 6;
@@ -839,7 +867,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         // 16-step batches at the footprint of one scoring workgroup when the recurrence of a stage runs beside the scoring of
         // the next one (WGBSSEG_DP16: 0 never, 1 always when windows allow; default: whenever the call is staged)
         static const int dp16_env = getenv("WGBSSEG_DP16") ? atoi(getenv("WGBSSEG_DP16")) : -1;
-        const bool dp16 = dp_mode == 0 && (dp16_env < 0 ? n_stages > 1 : dp16_env != 0);
+        // the LAST stage's recurrence has the chip to itself: the 64-step-batch kernel is twice as fast there
+        const bool dp16 = dp_mode == 0 && (dp16_env < 0 ? (n_stages > 1 && stg + 1 < n_stages) : dp16_env != 0);
         if (dp16)                            hipLaunchKernelGGL((k_dp16<3>), dim3((unsigned)nC), dim3(64 * 4), (size_t)(2 * 16 * 64 * 8 + WG_DP_META_RING * 6), c->sB, v, sv, cbuf, c->dpstate.as<double>(), state_stride);
         else if (dp_mode == 0 && dp_nw == 3) hipLaunchKernelGGL((k_dp<3, 64>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else if (dp_mode == 0)               hipLaunchKernelGGL((k_dp<7, 64>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
