@@ -144,12 +144,12 @@ struct wgbsseg_ctx {
     std::vector<std::pair<int64_t, int64_t>> validated;
     DevBuf scan_pieces, divcheck, plan_sb;
     std::vector<int32_t> h_stage_bounds;
-    double tail_frac = -1.0;   // WGBSSEG_TAIL_FRAC: share of every chunk scored in the second of two uneven stages (many-chunk jobs); 0: one stage; < 0: from the call's size
+    double tail_frac = 0.0;   // WGBSSEG_TAIL_FRAC: share of every chunk scored in the second of two uneven stages (many-chunk jobs); 0: one stage; < 0: from the call's size
     // the short division core of the narrow scoring tiles: verified on the device per pseudo count (k_check_div)
     float divs_pc = -1.0f;     // pseudo count the verdict below is for
     bool divs_ok = false;
     bool divs_enabled = true;  // WGBSSEG_DIV_SHORT=0: always the 8-instruction core
-    int64_t scan_piece_sites = 16384;   // WGBSSEG_SCAN_PIECE_SITES: sites per wave task of k_validate (multiple of 1024)
+    int64_t scan_piece_sites = 4096;    // WGBSSEG_SCAN_PIECE_SITES: sites per wave task of k_validate (multiple of 1024)
 };
 
 namespace {
@@ -749,9 +749,12 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         int n_long = 0;
         for (const ChunkDesc& d : job.h) n_long += d.len >= 8192;
         if (job.max_len >= 8192) n_stages = std::max(n_stages, c->min_stages > 0 ? c->min_stages : (n_long <= 160 ? 8 : 1));
-        // Many chunks, all windows <= 64: one stage scores and k_dp<7,64> follows alone (1.8 ms exposed).  Instead: score the
-        // first (1 - f) of every chunk, then score the rest while k_dp16 (the footprint of one scoring workgroup) runs the
-        // recurrence of the first part beside it; only the last part's recurrence (k_dp<7,64>, alone again) is exposed.
+        // Many chunks, all windows <= 64: one stage scores and k_dp<7,64> follows alone (1.8 ms exposed).  The alternative
+        // (WGBSSEG_TAIL_FRAC=f, off by default): score the first (1 - f) of every chunk, then score the rest while k_dp16 runs
+        // the recurrence of the first part beside it; only the last part's recurrence is exposed.  Measured (hg19 x 32, f =
+        // 1/16 .. 3/8): 27.1-27.3 ms against 27.0 — whatever f, the scoring kernel loses the 1.4 ms the recurrence no longer
+        // shows: a recurrence wave issues ~40 of every ~57 cycles on its SIMD at raised priority, and the scoring kernel is
+        // VALU-issue bound, so the chain's instructions are paid either way (x 8: 11.2 -> 11.0).
         if (n_stages == 1 && c->force_stages <= 0 && c->min_stages <= 0 && job.max_len >= 8192 && Wmax <= 64 && c->tail_frac != 0.0) { n_stages = 2; tail_split = true; }
         if (c->force_stages > 0) n_stages = c->force_stages;
         n_stages = std::min<int>(n_stages, std::max(1, (job.max_len + 63) / 64));
@@ -835,7 +838,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbaseA = tbaseA; sv.tbaseB = tbaseB;
     sv.sb = c->plan_sb.as<int32_t>();
     // LDS of k_dp: two arranged batches (64 steps x 64 lanes, or 32 steps x 64 lanes x {A, B}) + M ring + fetched ring entries + flags + ring of windows / row offsets
-    DpArgs da = {ringN, {0, 0, 0}};
+    static const int dp_rot = getenv("WGBSSEG_DP_ROT") ? atoi(getenv("WGBSSEG_DP_ROT")) : 8;     // workgroups per dispatch round = CUs (2^8); 31: no rotation
+    DpArgs da = {ringN, dp_rot, {0, 0}};
     const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16 + 1024 * 6;
     for (int stg = 0; stg < n_stages; stg++) {
         sv.stage = stg;
