@@ -880,7 +880,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 //   Timeline, batch b = steps [base, base+32): sources of batch b are pushed during batch b+1 (targets >= base+128),
 //   the ring entries of batch b+2 are fetched (and reset) during batch b+1 — always disjoint from the pushes.
 // ------------------------------------------------------------------------------------------------------------
-struct DpArgs { int32_t ringN; int32_t rot_shift; int32_t pad[2]; };      // ringN: pending-step ring (pow2 >= max window + 128), 0 if BL == 64; rot_shift: see k_dp
+struct DpArgs { int32_t ringN; int32_t pad[3]; };      // ringN: pending-step ring (pow2 >= max window + 128), 0 if BL == 64
 
 #define WG_DP_STATE_HDR 257   // doubles of per-chunk state ahead of the ring: M[k], bestA[64], argA[64], bestB[64], argB[64]
 
@@ -1220,10 +1220,9 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     uint32_t* metaC = kinds + 4;                                              // [1024] row offsets of the coming steps
     uint16_t* metaW = reinterpret_cast<uint16_t*>(metaC + WG_DP_META_RING);   // [1024] their windows
     const int lane = threadIdx.x & 63;
-    // Wavefront h of a workgroup runs on SIMD h mod 4.  Two workgroups that share a CU (hundreds of chunks on 256 CUs) would
-    // both put their recurrence wave — the one that issues 40 of every ~57 cycles — on SIMD 0; rotating the roles by the
-    // dispatch round (A.rot_shift: log2 of the workgroups per round) spreads them over the SIMDs.
-    const int wvl = (int)((threadIdx.x >> 6) + ((blockIdx.x >> A.rot_shift) & 3u)) & NW;      // logical wave: 0 = recurrence (NW + 1 is a power of two)
+    // (Tried: rotating which wavefront of the workgroup runs the recurrence by dispatch round, so that two workgroups sharing
+    // a CU do not both put theirs on wavefront 0's SIMD — 1.75 -> 2.35 ms for 483 chunks: worse; wavefront 0 it stays.)
+    const int wvl = (int)(threadIdx.x >> 6);          // 0 = recurrence
     const bool worker = wvl != 0;
     const int lw = wvl - 1;                           // worker index (0..NW-1)
     const int c = blockIdx.x;

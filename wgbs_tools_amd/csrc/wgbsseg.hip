@@ -838,8 +838,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbaseA = tbaseA; sv.tbaseB = tbaseB;
     sv.sb = c->plan_sb.as<int32_t>();
     // LDS of k_dp: two arranged batches (64 steps x 64 lanes, or 32 steps x 64 lanes x {A, B}) + M ring + fetched ring entries + flags + ring of windows / row offsets
-    static const int dp_rot = getenv("WGBSSEG_DP_ROT") ? atoi(getenv("WGBSSEG_DP_ROT")) : 8;     // workgroups per dispatch round = CUs (2^8); 31: no rotation
-    DpArgs da = {ringN, dp_rot, {0, 0}};
+    DpArgs da = {ringN, {0, 0, 0}};
     const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16 + 1024 * 6;
     for (int stg = 0; stg < n_stages; stg++) {
         sv.stage = stg;
@@ -903,6 +902,14 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipStreamSynchronize(c->sA));
 
     // ---- timings ---------------------------------------------------------------------------------------------
+    static const bool timeline = getenv("WGBSSEG_PROFILE") && atoi(getenv("WGBSSEG_PROFILE")) >= 2;
+    if (timeline) {       // device time line of the batch, ms after its first event (scoring / recurrence: first and last stage)
+        auto at = [&](hipEvent_t e) { float x = 0; (void)hipEventElapsedTime(&x, c->ev[0], e); return (double)x; };
+        fprintf(stderr, "[wgbsseg] batch of %d chunks, %lld sites: windows done %.3f | stats copied %.3f | scan done %.3f | plan + tiles done %.3f | "
+                "scoring %.3f .. %.3f | recurrence %.3f .. %.3f | trace %.3f .. %.3f | borders on the host %.3f\n", nC, (long long)J,
+                at(c->ev[1]), at(c->ev[7]), at(c->ev[2]), at(c->ev[3]), at(c->ev_cost0[0]), at(c->ev_cost1[n_stages - 1]),
+                at(c->ev_dp0[0]), at(c->ev_dp1[n_stages - 1]), at(c->ev[4]), at(c->ev[5]), at(c->ev[6]));
+    }
     wgbsseg_timings& T = c->tim;
     if (!c->accumulate) memset(&T, 0, sizeof(T));
     float ms = 0;
