@@ -157,6 +157,29 @@ def test_02d_verdict_kernel_is_not_blind(seg):
     print('short core vs IEEE on 2e7 random pairs of full-width floats: %d differ' % int((short != want).sum()))
 
 
+@pytest.mark.parametrize('ti,ns', [(128, 0), (64, 0), (32, 0), (16, 0), (64, 4), (32, 8)])
+def test_07d_every_narrow_tile_shape_on_every_case(ti, ns, golden_chunks):
+    """The launcher picks the narrow tile width (128 / 64 / 32 / 16 start sites; 128 with its block -> start byte map) and the
+    samples per LDS group by cohort size and LDS budget; here every shape is forced onto every golden case (a shape that does
+    not fit a case's LDS budget falls back to the launcher's choice)."""
+    os.environ['WGBSSEG_TI'] = str(ti)
+    if ns: os.environ['WGBSSEG_NS'] = str(ns)
+    try:
+        sg = _lib.Segmenter(0)
+    finally:
+        del os.environ['WGBSSEG_TI']
+        os.environ.pop('WGBSSEG_NS', None)
+    try:
+        for name in cases.CHUNK_CASES:
+            g = golden_chunks[name]
+            spec = g['spec']
+            _load_case(sg, spec)
+            got = sg.segment_chunks([0], [spec['n']], spec['pcount'], spec['max_cpg'], spec['max_bp'])[0]
+            assert got.tolist() == g['borders'], '%s, TI %d NS %d: %s' % (name, ti, ns, _first_diff(got, np.array(g['borders'])))
+    finally:
+        sg.close()
+
+
 def test_07c_full_division_core_on_every_case(golden_chunks):
     """WGBSSEG_DIV_SHORT=0 keeps the 8-instruction core in the narrow tiles: same borders on every golden case."""
     os.environ['WGBSSEG_DIV_SHORT'] = '0'

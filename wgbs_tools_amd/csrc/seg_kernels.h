@@ -732,6 +732,10 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
     int32_t* ist = offs + (TI + 1);                                              // [TI] first end of start kl in this unit
     int32_t* misc = ist + TI;                                                    // [2 (+1 pad)]
+    // 128-start tiles (small cohorts: the per-block overhead is a larger share of the work): the start of every block of the
+    // tile as a byte map, filled once per tile, instead of a 7-step binary search in offs[] per block
+    constexpr bool BMAP = (TI == 128 && !SPLIT);
+    uint8_t* bmap = reinterpret_cast<uint8_t*>(misc + 8);                        // (BMAP) [TI * WG_NARROW_WMAX]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nC = J.n_chunks;
@@ -782,6 +786,10 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     }
     const int Q = offs[nk];
     if (Q == 0) return;
+    if (BMAP && tid < nk) {
+        const int o0 = offs[tid], o1 = offs[tid + 1];
+        for (int o = o0; o < o1; o++) bmap[o] = (uint8_t)tid;                    // (read after the barrier that opens the sample group)
+    }
     const int imin = PW > 1 ? (misc[0] < misc[2] ? misc[0] : misc[2]) : misc[0];
     const int imax = PW > 1 ? (misc[1] > misc[3] ? misc[1] : misc[3]) : misc[1];
     // wide: E array = P[x] for x = eA .. imax+1 (ends use P[i+1]), S array = P[k] for k = ka .. kb-1.
@@ -820,7 +828,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
         int qi = 0;
         for (int q = tid; q < Q; q += WG_BLOCK, qi++) {
             int lo = 0, hi = nk;                           // largest kl with offs[kl] <= q
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
+            if (BMAP) lo = (int)bmap[q];
+            else while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
             const int i = ist[lo] + (q - offs[lo]);
             double acc = firstg ? 0.0 : accR[qi];
             // sample loop, unrolled by four by hand (the optimiser leaves a loop with the rare exact path inside alone):
@@ -1206,7 +1215,7 @@ __device__ __forceinline__ void wg_dp_group64(double& best, int32_t& arg, uint32
 // state kept per chunk in global memory: [0] M[k] of the next step, [1..64] best, [65..128] arg, [129..192] bestB,
 // [193..256] argB (args as doubles' bits) — written only between stages — then the ring: ringN doubles, ringN int32
 template <int NW, int BL>
-__global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
+__global__ __launch_bounds__(64 * (1 + NW), NW == 7 ? 4 : 1) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
                                                       double* __restrict__ state, int64_t state_stride)
 {
     constexpr bool WIDEJOB = BL < 64;
@@ -1247,6 +1256,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     int32_t arg = 0, argB = 0;
     double Mk = 0.0;                                    // M[k] of the step about to run; M[0] = 0 (segmentor.cpp:97)
     DpRows<NW, BL> rows;                                // (workers) rows of the batch after the next, in flight
+    DpRows<NW, BL> rows2;                               // (workers, 64-step batches) a second set: rows are loaded THREE batches ahead there — set `rows` holds even batches, `rows2` odd ones
     DpRefill<NW> refill;                                // (workers) a region of windows / row offsets, in flight
     uint32_t fm_prev = 0, fm_cur = 0, fm_n1 = 0;        // (workers) widest window of batches b-1, b, b+1
     constexpr int RB = WG_DP_META_REGION / BL;          // batches per region of the meta ring
@@ -1284,7 +1294,12 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
         wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, 0, lane), s0, lane, lw);
         wg_dp_rows_commit<NW, BL>(rows, slots, slots + BL * 64, kinds, lane, lw);
         fm_cur = rows.fmax;
-        if (nb > 1) { wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, BL, lane), s0 + BL, lane, lw); fm_n1 = rows.fmax; }
+        if (WIDEJOB) {
+            if (nb > 1) { wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, BL, lane), s0 + BL, lane, lw); fm_n1 = rows.fmax; }
+        } else {
+            if (nb > 1) wg_dp_rows_issue<NW, BL>(rows2, cb, wg_dp_meta_lds<BL>(metaW, metaC, BL, lane), s0 + BL, lane, lw);
+            if (nb > 2) wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, 2 * BL, lane), s0 + 2 * BL, lane, lw);
+        }
     }
     __syncthreads();
 
@@ -1311,6 +1326,17 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
             else if (b > RB && b % RB == 1)  wg_dp_refill_commit<NW>(refill, metaW, metaC, (b / RB + 1) * WG_DP_META_REGION, lane, lw);
             if (WIDEJOB && b >= 1 && fm_prev > 128u)
                 wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, base - BL, s1, Mring, pendB, pendA, rmask, lane, lw);
+            if (!WIDEJOB) {
+                // 64-step batches: the rows of batch b+1 (loaded two batches ago) into the free slot, then the loads of batch b+3
+                // into the register set that just emptied — a row has two batch times (~3.5 us) to arrive, not one
+                if ((b & 1) == 0) {
+                    if (b + 1 < nb) wg_dp_rows_commit<NW, BL>(rows2, slots + (size_t)SLOT, slots + (size_t)SLOT + BL * 64, kinds + 1, lane, lw);
+                    if (b + 3 < nb) wg_dp_rows_issue<NW, BL>(rows2, cb, wg_dp_meta_lds<BL>(metaW, metaC, (b + 3) * BL, lane), base + 3 * BL, lane, lw);
+                } else {
+                    if (b + 1 < nb) wg_dp_rows_commit<NW, BL>(rows, slots, slots + BL * 64, kinds, lane, lw);
+                    if (b + 3 < nb) wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, (b + 3) * BL, lane), base + 3 * BL, lane, lw);
+                }
+            } else {
             if (b + 1 < nb)
                 wg_dp_rows_commit<NW, BL>(rows, slots + (size_t)((b + 1) & 1) * SLOT, slots + (size_t)((b + 1) & 1) * SLOT + BL * 64,
                                           kinds + ((b + 1) & 1), lane, lw);
@@ -1324,6 +1350,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
                 fm_n2 = rows.fmax;
             }
             fm_prev = fm_cur; fm_cur = fm_n1; fm_n1 = fm_n2;
+            }
         } else {
             const double* slot = slots + (size_t)(b & 1) * SLOT;
             const bool wideb = WIDEJOB && kinds[b & 1] != 0u;
