@@ -36,7 +36,8 @@ sys.path.insert(0, ROOT)
 SEED = 20260926
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 FP64_VALU_PEAK = 78.6e12         # flop/s, vector fp64 (FMA counted as 2)
-VALU_PER_EVAL = 44.5             # VALU instructions per evaluation, common path (tools/micro/count_cost_loop.py)
+VALU_PER_EVAL = 44.5             # VALU instructions per evaluation, common path (tools/micro/count_cost_loop.py): 8-instruction division core
+VALU_PER_EVAL_SHORT = 40.5       # the same with the verified 4-instruction division core (narrow tiles, pseudo count >= 1)
 FP64_FLOP_PER_EVAL = 29          # fp64 flops of one evaluation, FMA = 2: log2f 5 FMA + 1 mul, fast log2 7 FMA, fused sum 1 FMA, 1-p, accumulate
 
 
@@ -289,7 +290,7 @@ def main():
             acc = dict(t)
         else:
             for k in t:
-                acc[k] = max(acc[k], t[k]) if k in ('max_window', 'n_stages', 'scan_main_bytes') else acc[k] + t[k]
+                acc[k] = max(acc[k], t[k]) if k in ('max_window', 'n_stages', 'scan_main_bytes', 'div_short') else acc[k] + t[k]
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device='cpu' if oversub else dev)
@@ -321,6 +322,7 @@ def main():
         scan_gbs = acc['scan_main_bytes'] / (main_ms * 1e-3) / 1e9
         scan_all_gbs = acc['scan_bytes'] / (acc['scan_ms'] * 1e-3) / 1e9
         evals_s = acc['evals'] / (acc['cost_ms'] * 1e-3)
+        valu_per_eval = VALU_PER_EVAL_SHORT if acc.get('div_short') else VALU_PER_EVAL
         stats_wide = acc['max_window'] > 60          # WG_NARROW_WMAX: wide scoring tiles exist, so the scan keeps its carries
         # HBM traffic of that launch from the PMC counters (collected separately with rocprofv3, profiles/): only
         # reported when the committed measurement is for exactly this workload
@@ -363,9 +365,10 @@ def main():
             # fp64: FP64_FLOP_PER_EVAL counts the fp64 VALU work of one evaluation with an FMA as 2 against the
             # 78.6 TFLOP/s vector-fp64 peak - informative only, the kernel also spends issue slots on fp32/int/conversions.
             'roofline_cost': {'kernel': 'k_cost (block log-likelihoods)', 'bound': 'valu-issue',
-                              'achieved': evals_s * VALU_PER_EVAL, 'peak': 256 * 4 * 16 * 2.4e9, 'unit': 'lane-ops/s',
-                              'frac': evals_s * VALU_PER_EVAL / (256 * 4 * 16 * 2.4e9),
-                              'evals_per_s': evals_s, 'valu_instr_per_eval': VALU_PER_EVAL,
+                              'achieved': evals_s * valu_per_eval, 'peak': 256 * 4 * 16 * 2.4e9, 'unit': 'lane-ops/s',
+                              'frac': evals_s * valu_per_eval / (256 * 4 * 16 * 2.4e9),
+                              'evals_per_s': evals_s, 'valu_instr_per_eval': valu_per_eval,
+                              'division_core': '4 instructions, verified on the device for this pseudo count' if acc.get('div_short') else '8 instructions',
                               'fp64_flop_per_eval': FP64_FLOP_PER_EVAL, 'fp64_tflops': evals_s * FP64_FLOP_PER_EVAL / 1e12,
                               'fp64_frac_of_peak': evals_s * FP64_FLOP_PER_EVAL / FP64_VALU_PEAK,
                               'evals_per_step': acc['evals'] / args.steps, 'pairs_per_step': acc['pairs'] / args.steps,

@@ -52,7 +52,7 @@ typedef struct wgbsseg_params {
 
 /* HIP-event timings of the last wgbsseg_segment_chunks() call, milliseconds, and its work counters. */
 typedef struct wgbsseg_timings {
-    double scan_ms;          /* prefix-scan + validation pass over the beta bytes (HBM-bound kernel)   */
+    double scan_ms;          /* scan pass over the beta bytes: validation (+ carries when the job has wide tiles)  */
     double window_ms;        /* window extents from loci + CSR offsets                                 */
     double cost_ms;          /* block log-likelihood evaluation, summed over stages                    */
     double dp_ms;            /* changepoint recurrence, summed over stages                             */
@@ -65,7 +65,7 @@ typedef struct wgbsseg_timings {
     int32_t max_window;      /* largest F_k                                                            */
     int32_t n_stages;
     int32_t scan_launches;   /* kernel launches behind scan_ms (1 per batch)                           */
-    int32_t reserved;
+    int32_t div_short;       /* 1: the narrow scoring tiles of the call ran the verified 4-instruction division core */
     double  scan_main_ms;    /* duration of the largest scan launch of the call (the batch holding the chunks) */
     int64_t scan_main_bytes; /* its algorithmic bytes                                                  */
 } wgbsseg_timings;

@@ -50,11 +50,11 @@ class Timings(C.Structure):
     _fields_ = [('scan_ms', C.c_double), ('window_ms', C.c_double), ('cost_ms', C.c_double), ('dp_ms', C.c_double),
                 ('trace_ms', C.c_double), ('total_ms', C.c_double), ('sites', C.c_int64), ('pairs', C.c_int64),
                 ('evals', C.c_int64), ('scan_bytes', C.c_int64), ('max_window', C.c_int32), ('n_stages', C.c_int32),
-                ('scan_launches', C.c_int32), ('reserved', C.c_int32), ('scan_main_ms', C.c_double),
+                ('scan_launches', C.c_int32), ('div_short', C.c_int32), ('scan_main_ms', C.c_double),
                 ('scan_main_bytes', C.c_int64)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != 'reserved'}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 # wgbsseg_batch_fn: (user, starts, ends, n, out_ptr, out_cnt) -> 0 on success

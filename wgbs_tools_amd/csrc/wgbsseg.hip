@@ -928,6 +928,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     T.sites += J; T.pairs += total_pairs; T.evals += total_pairs * c->n_samples;
     T.scan_bytes += scan_bytes; T.max_window = std::max<int32_t>(T.max_window, Wmax);
     T.n_stages = std::max<int32_t>(T.n_stages, n_stages); T.scan_launches += 1;
+    if (term_mode == 2 && c->divs_enabled && c->divs_ok && c->divs_pc == P->pseudo_count) T.div_short = 1;
     c->last_sites = J; c->last_pairs = total_pairs; c->last_stages = n_stages; c->last_valid = true;
     return WGBSSEG_OK;
 }
