@@ -101,6 +101,53 @@ def test_block_sums_all_modes_against_oracle():
         sg.close()
 
 
+@pytest.mark.parametrize('general', [0, 1])
+def test_block_sums_of_ordered_tables_against_oracle(general, monkeypatch):
+    """Tables ordered by first and last site (what a segmentation writes) go through the streaming kernel: tiles of 1024
+    sites, runs of 8 tiles, a two-tile ring of prefixes.  Blocks of one site, empty blocks, blocks across tile and run
+    boundaries, blocks longer than a tile and longer than a run, gaps, overlaps that keep the order, a row length that is no
+    multiple of anything, the rows shuffled (the host sorts; results go back to the caller's rows); all four modes, and the
+    general kernel forced onto the same tables."""
+    if general: monkeypatch.setenv('WGBSSEG_BLOCK_SUMS_GENERAL', '1')
+    n, N = 1000003, 6
+    data = [synth.synth_betas(777, s, 0, n) for s in range(N)]
+    data[2][40000:47000, :] = 255                                  # saturated: the trims of modes 1 and 2
+    data[5][8000:8400, :] = 0
+    rng = np.random.default_rng(8)
+    tables = {}
+    cuts = np.unique(np.concatenate([rng.integers(0, n, 90000), [0, n], np.arange(1024, n, 1024)[::7], np.arange(8192, n, 8192)[::3] + 1]))
+    tables['tiling'] = (cuts[:-1], cuts[1:])
+    st = np.sort(rng.integers(0, n - 3000, 30000))
+    ln = np.where(rng.random(30000) < 0.9, rng.integers(0, 30, 30000), rng.integers(30, 2500, 30000))
+    en = np.maximum.accumulate(np.minimum(st + ln, n))             # ends forced into order: overlaps, nesting never
+    en = np.maximum(en, st)
+    tables['gaps_and_overlaps'] = (st, en)
+    tables['long'] = (np.array([5, 1000, 3000, 20000, 20000, 50000, 700000, n - 1, n]), np.array([1000, 3000, 20000, 20000, 50000, 700000, n, n, n]))
+    edge = np.array([0, 1023, 1024, 1025, 2047, 8191, 8192, 8193, 16383, 16384, n - 17, n - 1])
+    tables['edges'] = (edge[:-1], edge[1:])
+    tables['single_tile_late'] = (np.array([900000, 900010]), np.array([900010, 900500]))
+    with _lib.Segmenter(0) as sg:
+        sg.set_betas(data)
+        for name, (s0, e0) in tables.items():
+            s0 = np.asarray(s0, dtype=np.int64); e0 = np.asarray(e0, dtype=np.int64)
+            for shuffled in (False, True):
+                if shuffled:
+                    o = rng.permutation(s0.size)
+                    s0, e0 = s0[o], e0[o]
+                raw = sg.block_sums(s0, e0, mode=0)
+                b8 = sg.block_sums(s0, e0, mode=1)
+                b16 = sg.block_sums(s0, e0, mode=2)
+                mean = sg.block_sums(s0, e0, mode=3, min_cov=9)
+                for s in range(N):
+                    want = OB.block_sums(data[s], s0, e0)
+                    bad = np.flatnonzero((raw[s].astype(np.int64) != want).any(1))
+                    assert bad.size == 0, '%s (shuffled %s) sample %d: block %d = [%d, %d): got %s want %s' % (
+                        name, shuffled, s, bad[0], s0[bad[0]], e0[bad[0]], raw[s][bad[0]], want[bad[0]])
+                    assert (b8[s] == OB.trim(want, False)).all() and (b16[s] == OB.trim(want, True)).all(), (name, s)
+                    w3 = OB.beta2vec(want, 9)
+                    assert (np.isnan(mean[s]) == np.isnan(w3)).all() and np.array_equal(mean[s][~np.isnan(w3)].view(np.uint64), w3[~np.isnan(w3)].view(np.uint64)), (name, s)
+
+
 def test_block_sums_of_uint16_rows_against_oracle():
     """.lbeta rows (uint16 pairs): random tables incl. unsorted, overlapping, empty and tile-crossing blocks; the segment
     calls refuse such rows."""

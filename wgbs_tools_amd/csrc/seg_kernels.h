@@ -1909,6 +1909,123 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// k_block_sums_run: the block reduction for uint8 rows and a table whose blocks are ordered by first AND by last site (every
+// table a segmentation wrote; every "nice" table of beta_to_blocks.py:45-60) — the common case, streamed:
+// one wavefront takes one sample and a RUN of consecutive 1024-site tiles and walks them in order, keeping running totals,
+// so that the prefixes it leaves in LDS (two tiles: a ring) are prefixes of the whole run; after staging tile t it resolves
+// the blocks whose LAST site lies in tile t: their first site is in tile t or t-1 (blocks up to 1024 sites), so a block is
+// one subtraction of two prefixes whatever tile boundary it crosses.  Every byte is read once (no halo), two tiles are in
+// flight while one is reduced, one sample per wavefront keeps it at 60-odd VGPRs.  Blocks that begin before the run or more
+// than a tile back are summed from memory by their lane (one or two per run; blocks longer than 1024 sites).
+// The general kernel above stays for .lbeta rows and for tables with nested / overlapping blocks.
+// ------------------------------------------------------------------------------------------------------------
+#define WG_BSR_TILE 1024
+#define WG_BSR_RUN 8
+#define WG_BSR_PK (WG_BSR_TILE + 16)          // packed in-lane prefixes of a tile (+ the entry behind its last site)
+
+__device__ __noinline__ void wg_block_sum_store_slow(void* __restrict__ out, int64_t o, int mode, uint32_t min_cov, uint64_t m, uint64_t c)
+{
+    wg_block_sum_store(out, o, mode, min_cov, m, c);
+}
+
+__global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __restrict__ betas, int64_t pitch, int64_t n_total,
+                                                             const int32_t* __restrict__ x0s, const int32_t* __restrict__ x1s,
+                                                             const int32_t* __restrict__ perm, const int32_t* __restrict__ end_first,
+                                                             int64_t n_tiles, int64_t n_blocks, int n_samples, int mode, uint32_t min_cov,
+                                                             void* __restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t PKs[WG_BLOCK / 64][2][WG_BSR_PK];
+    __shared__ uint2 BASEs[WG_BLOCK / 64][2][WG_BSR_TILE / 16 + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int s = (int)blockIdx.y * (WG_BLOCK / 64) + wv;
+    if (s >= n_samples) return;
+    const int64_t t0 = (int64_t)blockIdx.x * WG_BSR_RUN;
+    const int64_t t1 = t0 + WG_BSR_RUN < n_tiles ? t0 + WG_BSR_RUN : n_tiles;
+    if (end_first[t0] == end_first[t1]) return;                    // no block ends in this run: nothing to read
+    const uint8_t* row = betas + (int64_t)s * pitch;
+    const size_t esz = mode == 0 ? 8 : (mode == 1 ? 2 : (mode == 2 ? 4 : 8));
+    char* orow = reinterpret_cast<char*>(out) + (size_t)s * (size_t)n_blocks * esz;
+
+    auto load = [&](int64_t t, uint4& a, uint4& b) {               // this lane's 16 sites of tile t
+        a = b = make_uint4(0u, 0u, 0u, 0u);
+        if (t >= t1) return;
+        const int64_t site = t * WG_BSR_TILE + (int64_t)lane * 16;
+        if (site + 8 <= n_total) a = *reinterpret_cast<const uint4*>(row + (size_t)site * 2);
+        else if (site < n_total) a = wg_bs_load_tail<1>(row, site, n_total);
+        if (site + 16 <= n_total) b = *reinterpret_cast<const uint4*>(row + (size_t)(site + 8) * 2);
+        else if (site + 8 < n_total) b = wg_bs_load_tail<1>(row, site + 8, n_total);
+    };
+    uint4 c0, c1, n0, n1, m0, m1;
+    load(t0, c0, c1);
+    load(t0 + 1, n0, n1);
+    uint32_t run_m = 0, run_c = 0;                                 // totals of the run's sites before the current tile
+    for (int64_t t = t0; t < t1; t++) {
+        load(t + 2, m0, m1);
+        const int h = (int)(t - t0) & 1;
+        uint32_t* PK = PKs[wv][h];
+        uint2* BASE = BASEs[wv][h];
+        {
+            const uint32_t w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            uint32_t e[16], acc = 0;                               // packed exclusive prefixes inside the lane (16 x 255 fits 16 bits)
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                e[j] = acc;
+                acc += __builtin_amdgcn_perm(0u, w[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u);     // site j as (meth | cov << 16)
+            }
+            const uint32_t tm = acc & 0xffffu, tc = acc >> 16;
+            const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
+            BASE[lane] = make_uint2(run_m + (im - tm), run_c + (ic - tc));
+            uint4* dst = reinterpret_cast<uint4*>(PK + lane * 16);
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) dst[j >> 2] = make_uint4(e[j], e[j + 1], e[j + 2], e[j + 3]);
+            run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
+            run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+            if (lane == 0) { BASE[WG_BSR_TILE / 16] = make_uint2(run_m, run_c); PK[WG_BSR_TILE] = 0u; }     // the entry behind the tile's last site
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int lo = (int)(t * WG_BSR_TILE);
+        const int b1 = end_first[t + 1];
+        for (int b = end_first[t] + lane; b < b1; b += 64) {
+            const int x0 = x0s[b], x1 = x1s[b];
+            const int64_t r = perm ? perm[b] : b;
+            const int r1 = x1 - lo, r0 = x0 - lo;                  // r1 in [0, 1024]
+            uint32_t m32 = 0, c32 = 0;
+            bool direct = false;
+            if (x1 > x0) {
+                const uint2 be = BASE[r1 >> 4];
+                const uint32_t ke = PK[r1];
+                uint2 bs;
+                uint32_t ks;
+                if (r0 >= 0) { bs = BASE[r0 >> 4]; ks = PK[r0]; }
+                else if (r0 >= -WG_BSR_TILE && t > t0) { bs = BASEs[wv][h ^ 1][(r0 + WG_BSR_TILE) >> 4]; ks = PKs[wv][h ^ 1][r0 + WG_BSR_TILE]; }
+                else { direct = true; bs = make_uint2(0u, 0u); ks = 0u; }
+                m32 = (be.x + (ke & 0xffffu)) - (bs.x + (ks & 0xffffu));
+                c32 = (be.y + (ke >> 16)) - (bs.y + (ks >> 16));
+            }
+            if (direct) {                                          // rare: begins before the run, or more than a tile back
+                uint64_t m = 0, c = 0;
+                wg_direct_sum<1>(row, x0, x1, n_total, m, c);
+                wg_block_sum_store_slow(orow, r, mode, min_cov, m, c);
+            } else if (mode == 1 && c32 <= 255u) {
+                reinterpret_cast<uchar2*>(orow)[r] = make_uchar2((unsigned char)m32, (unsigned char)c32);
+            } else if (mode == 0) {
+                reinterpret_cast<uint2*>(orow)[r] = make_uint2(m32, c32);
+            } else if (mode == 3) {
+                reinterpret_cast<double*>(orow)[r] = (c32 >= min_cov) ? (double)m32 / (double)c32 : __builtin_nan("");
+            } else if (mode == 2 && c32 <= 65535u) {
+                reinterpret_cast<ushort2*>(orow)[r] = make_ushort2((unsigned short)m32, (unsigned short)c32);
+            } else {
+                wg_block_sum_store_slow(orow, r, mode, min_cov, (uint64_t)m32, (uint64_t)c32);     // counts above the format's maximum: rescaled
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                           // (the half written next is the one last read a tile ago)
+        c0 = n0; c1 = n1; n0 = m0; n1 = m1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_convert: BED regions -> CpG index ranges against the resident loci (the join of `wgbstools convert -L`,
 // convert.py:147-185 chr_thread / :133-145 slow_conversion + genomic_region.py:126-161).  One thread per region: two
 // binary searches in its chromosome's slice [clo, chi) of the loci.  Region r: bp interval (start, end), chromosome

@@ -149,6 +149,7 @@ struct wgbsseg_ctx {
     float divs_pc = -1.0f;     // pseudo count the verdict below is for
     bool divs_ok = false;
     bool divs_enabled = true;  // WGBSSEG_DIV_SHORT=0: always the 8-instruction core
+    bool bs_general = false;   // WGBSSEG_BLOCK_SUMS_GENERAL=1: never the streaming block-sums kernel
     int64_t scan_piece_sites = 4096;    // WGBSSEG_SCAN_PIECE_SITES: sites per wave task of k_validate (multiple of 1024)
 };
 
@@ -267,6 +268,8 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     if (ms && atoi(ms) > 0) c->min_stages = atoi(ms);
     const char* tf = getenv("WGBSSEG_TAIL_FRAC");
     if (tf) c->tail_frac = std::min(0.9, atof(tf));
+    const char* bg = getenv("WGBSSEG_BLOCK_SUMS_GENERAL");
+    if (bg) c->bs_general = atoi(bg) != 0;
     const char* dv = getenv("WGBSSEG_DIV_SHORT");
     if (dv) c->divs_enabled = atoi(dv) != 0;
     const char* sp = getenv("WGBSSEG_SCAN_PIECE_SITES");
@@ -1625,6 +1628,23 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
     }
     const size_t esz = mode == 0 ? 8 : (mode == 1 ? 2 : (mode == 2 ? 4 : 8));
     const size_t obytes = (size_t)c->n_samples * (size_t)n_blocks * esz;
+    // uint8 rows and a table ordered by first AND last site (what a segmentation writes; beta_to_blocks' "nice" tables): the
+    // streaming kernel.  Its tile table: the first block whose last site lies at or behind every 1024-site tile's first site.
+    bool monotone = c->elem == 1;
+    for (int64_t i = 1; i < n_blocks && monotone; i++) monotone = hx1[i] >= hx1[i - 1];
+    if (c->bs_general) monotone = false;                         // WGBSSEG_BLOCK_SUMS_GENERAL=1 (tests): the general kernel for every table
+    const int64_t n_rtiles = (c->n_total + WG_BSR_TILE - 1) / WG_BSR_TILE;
+    if (monotone) {
+        h.resize((size_t)n_blocks * (sorted ? 2 : 3) + (size_t)n_rtiles + 1);
+        hx0 = h.data(); hx1 = hx0 + n_blocks; hperm = sorted ? nullptr : hx1 + n_blocks;
+        htf = hx1 + n_blocks + (sorted ? 0 : n_blocks);
+        int64_t b = 0;
+        for (int64_t t = 0; t <= n_rtiles; t++) {                  // tile of a block: the one holding its last site (empty blocks: their position)
+            while (b < n_blocks && (hx1[b] == 0 ? 0 : ((int64_t)std::max(hx1[b] - 1, hx0[b])) / WG_BSR_TILE) < t) b++;
+            htf[t] = (int32_t)b;
+        }
+        htf[n_rtiles] = (int32_t)n_blocks;
+    }
     HIP_TRY(c->dbg_a.ensure(h.size() * 4));
     HIP_TRY(c->dbg_b.ensure(obytes));
     HIP_TRY(hipMemcpyAsync(c->dbg_a.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, c->sA));
@@ -1639,7 +1659,10 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
     const unsigned gy = (unsigned)((c->n_samples + 4 * spw - 1) / (4 * spw));
     if (gy > 65535) { set_err(err, errlen, "too many samples for one block_sums call"); return WGBSSEG_E_ARG; }
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
-    if (c->elem == 1)
+    if (monotone)
+        hipLaunchKernelGGL(k_block_sums_run, dim3((unsigned)((n_rtiles + WG_BSR_RUN - 1) / WG_BSR_RUN), (unsigned)((c->n_samples + 3) / 4)), dim3(WG_BLOCK), 0, c->sA,
+                           c->betas, c->pitch, c->n_total, dx0, dx1, dperm, dtf, n_rtiles, n_blocks, (int)c->n_samples, (int)mode, min_cov, c->dbg_b.p);
+    else if (c->elem == 1)
         hipLaunchKernelGGL(k_block_sums<1>, dim3((unsigned)gx, gy), dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total,
                            dx0, dx1, dperm, dtf, n_tiles, n_blocks, (int)c->n_samples, spw, (int)mode, min_cov, c->dbg_b.p);
     else
