@@ -1928,6 +1928,17 @@ __device__ __noinline__ void wg_block_sum_store_slow(void* __restrict__ out, int
     wg_block_sum_store(out, o, mode, min_cov, m, c);
 }
 
+__device__ __noinline__ void wg_block_direct_store(const uint8_t* __restrict__ row, int x0, int x1, int64_t n_total, void* __restrict__ out, int64_t o,
+                                                   int mode, uint32_t min_cov)
+{
+    uint64_t m = 0, c = 0;
+    wg_direct_sum<1>(row, x0, x1, n_total, m, c);
+    wg_block_sum_store(out, o, mode, min_cov, m, c);
+}
+
+#define WG_BSR_PRE 3                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
+struct BsrDesc { int32_t x0[WG_BSR_PRE], x1[WG_BSR_PRE], r[WG_BSR_PRE]; };
+
 __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __restrict__ betas, int64_t pitch, int64_t n_total,
                                                              const int32_t* __restrict__ x0s, const int32_t* __restrict__ x1s,
                                                              const int32_t* __restrict__ perm, const int32_t* __restrict__ end_first,
@@ -1940,28 +1951,44 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
     const int s = (int)blockIdx.y * (WG_BLOCK / 64) + wv;
     if (s >= n_samples) return;
     const int64_t t0 = (int64_t)blockIdx.x * WG_BSR_RUN;
-    const int64_t t1 = t0 + WG_BSR_RUN < n_tiles ? t0 + WG_BSR_RUN : n_tiles;
-    if (end_first[t0] == end_first[t1]) return;                    // no block ends in this run: nothing to read
+    const int nt = (int)((t0 + WG_BSR_RUN < n_tiles ? t0 + WG_BSR_RUN : n_tiles) - t0);       // tiles of this run
+    // the run's slice of the tile table in one register (lane i: first block that ends in tile t0 + i or later)
+    const int efv = lane <= nt ? end_first[t0 + lane] : 0;
+    if (__builtin_amdgcn_readlane(efv, 0) == __builtin_amdgcn_readlane(efv, nt)) return;     // no block ends in this run: nothing to read
     const uint8_t* row = betas + (int64_t)s * pitch;
     const size_t esz = mode == 0 ? 8 : (mode == 1 ? 2 : (mode == 2 ? 4 : 8));
     char* orow = reinterpret_cast<char*>(out) + (size_t)s * (size_t)n_blocks * esz;
 
-    auto load = [&](int64_t t, uint4& a, uint4& b) {               // this lane's 16 sites of tile t
+    auto load = [&](int i, uint4& a, uint4& b) {                   // this lane's 16 sites of the run's tile i
         a = b = make_uint4(0u, 0u, 0u, 0u);
-        if (t >= t1) return;
-        const int64_t site = t * WG_BSR_TILE + (int64_t)lane * 16;
+        if (i >= nt) return;
+        const int64_t site = (t0 + i) * WG_BSR_TILE + (int64_t)lane * 16;
         if (site + 8 <= n_total) a = *reinterpret_cast<const uint4*>(row + (size_t)site * 2);
         else if (site < n_total) a = wg_bs_load_tail<1>(row, site, n_total);
         if (site + 16 <= n_total) b = *reinterpret_cast<const uint4*>(row + (size_t)(site + 8) * 2);
         else if (site + 8 < n_total) b = wg_bs_load_tail<1>(row, site + 8, n_total);
     };
+    auto descriptors = [&](int i, BsrDesc& D) {                    // the first 64 x WG_BSR_PRE blocks that end in tile i of the run
+        const int b0 = __builtin_amdgcn_readlane(efv, i), b1 = __builtin_amdgcn_readlane(efv, i + 1);
+#pragma unroll
+        for (int k = 0; k < WG_BSR_PRE; k++) {
+            const int b = b0 + 64 * k + lane;
+            const bool in = b < b1;
+            D.x0[k] = in ? x0s[b] : 0;
+            D.x1[k] = in ? x1s[b] : 0;
+            D.r[k] = in ? (perm ? perm[b] : b) : -1;
+        }
+    };
     uint4 c0, c1, n0, n1, m0, m1;
-    load(t0, c0, c1);
-    load(t0 + 1, n0, n1);
+    BsrDesc dc, dn;
+    load(0, c0, c1);
+    descriptors(0, dc);
+    load(1, n0, n1);
     uint32_t run_m = 0, run_c = 0;                                 // totals of the run's sites before the current tile
-    for (int64_t t = t0; t < t1; t++) {
-        load(t + 2, m0, m1);
-        const int h = (int)(t - t0) & 1;
+    for (int i = 0; i < nt; i++) {
+        load(i + 2, m0, m1);
+        if (i + 1 < nt) descriptors(i + 1, dn);
+        const int h = i & 1;
         uint32_t* PK = PKs[wv][h];
         uint2* BASE = BASEs[wv][h];
         {
@@ -1984,11 +2011,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int lo = (int)(t * WG_BSR_TILE);
-        const int b1 = end_first[t + 1];
-        for (int b = end_first[t] + lane; b < b1; b += 64) {
-            const int x0 = x0s[b], x1 = x1s[b];
-            const int64_t r = perm ? perm[b] : b;
+        const int lo = (int)((t0 + i) * WG_BSR_TILE);
+        auto one = [&](int x0, int x1, int64_t r) {
             const int r1 = x1 - lo, r0 = x0 - lo;                  // r1 in [0, 1024]
             uint32_t m32 = 0, c32 = 0;
             bool direct = false;
@@ -1998,15 +2022,13 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
                 uint2 bs;
                 uint32_t ks;
                 if (r0 >= 0) { bs = BASE[r0 >> 4]; ks = PK[r0]; }
-                else if (r0 >= -WG_BSR_TILE && t > t0) { bs = BASEs[wv][h ^ 1][(r0 + WG_BSR_TILE) >> 4]; ks = PKs[wv][h ^ 1][r0 + WG_BSR_TILE]; }
+                else if (r0 >= -WG_BSR_TILE && i > 0) { bs = BASEs[wv][h ^ 1][(r0 + WG_BSR_TILE) >> 4]; ks = PKs[wv][h ^ 1][r0 + WG_BSR_TILE]; }
                 else { direct = true; bs = make_uint2(0u, 0u); ks = 0u; }
                 m32 = (be.x + (ke & 0xffffu)) - (bs.x + (ks & 0xffffu));
                 c32 = (be.y + (ke >> 16)) - (bs.y + (ks >> 16));
             }
             if (direct) {                                          // rare: begins before the run, or more than a tile back
-                uint64_t m = 0, c = 0;
-                wg_direct_sum<1>(row, x0, x1, n_total, m, c);
-                wg_block_sum_store_slow(orow, r, mode, min_cov, m, c);
+                wg_block_direct_store(row, x0, x1, n_total, orow, r, mode, min_cov);
             } else if (mode == 1 && c32 <= 255u) {
                 reinterpret_cast<uchar2*>(orow)[r] = make_uchar2((unsigned char)m32, (unsigned char)c32);
             } else if (mode == 0) {
@@ -2018,10 +2040,18 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
             } else {
                 wg_block_sum_store_slow(orow, r, mode, min_cov, (uint64_t)m32, (uint64_t)c32);     // counts above the format's maximum: rescaled
             }
+        };
+#pragma unroll
+        for (int k = 0; k < WG_BSR_PRE; k++)
+            if (dc.r[k] >= 0) one(dc.x0[k], dc.x1[k], dc.r[k]);
+        {
+            const int b1 = __builtin_amdgcn_readlane(efv, i + 1);
+            for (int b = __builtin_amdgcn_readlane(efv, i) + 64 * WG_BSR_PRE + lane; b < b1; b += 64) one(x0s[b], x1s[b], perm ? perm[b] : b);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();                           // (the half written next is the one last read a tile ago)
         c0 = n0; c1 = n1; n0 = m0; n1 = m1;
+        dc = dn;
     }
 }
 
