@@ -1936,122 +1936,131 @@ __device__ __noinline__ void wg_block_direct_store(const uint8_t* __restrict__ r
     wg_block_sum_store(out, o, mode, min_cov, m, c);
 }
 
-#define WG_BSR_PRE 3                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
-struct BsrDesc { int32_t x0[WG_BSR_PRE], x1[WG_BSR_PRE], r[WG_BSR_PRE]; };
+#define WG_BSR_PRE 2                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
 
+// Straight-line code on purpose: the tile loop is unrolled (register sets rotate by renaming, not by moves), everything a
+// wavefront shares is forced into scalar registers (its sample's row, its LDS rows, the run's tile table), loads that may
+// fall outside are clamped instead of predicated, the two tiles of prefixes form ONE ring (index (1024 h + rel) mod 2048
+// reaches back into the previous tile without a branch), and the output mode is a template parameter.
+template <int MODE>
 __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __restrict__ betas, int64_t pitch, int64_t n_total,
                                                              const int32_t* __restrict__ x0s, const int32_t* __restrict__ x1s,
                                                              const int32_t* __restrict__ perm, const int32_t* __restrict__ end_first,
-                                                             int64_t n_tiles, int64_t n_blocks, int n_samples, int mode, uint32_t min_cov,
+                                                             int64_t n_tiles, int64_t n_blocks, int n_samples, uint32_t min_cov,
                                                              void* __restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t PKs[WG_BLOCK / 64][2][WG_BSR_PK];
-    __shared__ uint2 BASEs[WG_BLOCK / 64][2][WG_BSR_TILE / 16 + 2];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int RING = 2 * WG_BSR_TILE;
+    __shared__ __attribute__((aligned(16))) uint32_t PKs[WG_BLOCK / 64][RING];      // packed (meth | cov << 16) prefixes inside a lane's 16 sites
+    __shared__ uint2 BASEs[WG_BLOCK / 64][RING / 16];                                // the run's totals before each lane's 16 sites
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int s = (int)blockIdx.y * (WG_BLOCK / 64) + wv;
     if (s >= n_samples) return;
     const int64_t t0 = (int64_t)blockIdx.x * WG_BSR_RUN;
     const int nt = (int)((t0 + WG_BSR_RUN < n_tiles ? t0 + WG_BSR_RUN : n_tiles) - t0);       // tiles of this run
     // the run's slice of the tile table in one register (lane i: first block that ends in tile t0 + i or later)
-    const int efv = lane <= nt ? end_first[t0 + lane] : 0;
+    const int efv = end_first[t0 + (lane <= nt ? lane : nt)];
     if (__builtin_amdgcn_readlane(efv, 0) == __builtin_amdgcn_readlane(efv, nt)) return;     // no block ends in this run: nothing to read
     const uint8_t* row = betas + (int64_t)s * pitch;
-    const size_t esz = mode == 0 ? 8 : (mode == 1 ? 2 : (mode == 2 ? 4 : 8));
-    char* orow = reinterpret_cast<char*>(out) + (size_t)s * (size_t)n_blocks * esz;
+    constexpr uint32_t ESZ = MODE == 0 ? 8u : (MODE == 1 ? 2u : (MODE == 2 ? 4u : 8u));
+    char* orow = reinterpret_cast<char*>(out) + (size_t)s * (size_t)n_blocks * ESZ;      // (the host keeps n_blocks * 8 below 2^32: 32-bit offsets)
+    uint32_t* PK = PKs[wv];
+    uint2* BASE = BASEs[wv];
+    const uint32_t site0 = (uint32_t)(t0 * WG_BSR_TILE);           // first site of the run (n_total < 2^31)
+    const uint32_t last_vec = (uint32_t)(((n_total + 7) >> 3) - 1);                       // last 16-byte vector that holds a site of the row
 
-    auto load = [&](int i, uint4& a, uint4& b) {                   // this lane's 16 sites of the run's tile i
-        a = b = make_uint4(0u, 0u, 0u, 0u);
-        if (i >= nt) return;
-        const int64_t site = (t0 + i) * WG_BSR_TILE + (int64_t)lane * 16;
-        if (site + 8 <= n_total) a = *reinterpret_cast<const uint4*>(row + (size_t)site * 2);
-        else if (site < n_total) a = wg_bs_load_tail<1>(row, site, n_total);
-        if (site + 16 <= n_total) b = *reinterpret_cast<const uint4*>(row + (size_t)(site + 8) * 2);
-        else if (site + 8 < n_total) b = wg_bs_load_tail<1>(row, site + 8, n_total);
+    // this lane's 16 sites of the run's tile i: two 16-byte vectors.  A vector beyond the row is clamped onto the row's last
+    // one (readable: the pitch is a multiple of 16 bytes) — it only feeds prefixes behind every block's last site.  The last
+    // vector itself may hold sites beyond n_total: bytes of the row's padding, which no block reaches either.
+    auto load = [&](int i, uint4& a, uint4& b) {
+        const uint32_t v = ((site0 + (uint32_t)i * WG_BSR_TILE) >> 3) + 2u * (uint32_t)lane;
+        const uint4* rv = reinterpret_cast<const uint4*>(row);
+        a = rv[v < last_vec ? v : last_vec];
+        b = rv[v + 1u < last_vec ? v + 1u : last_vec];
     };
-    auto descriptors = [&](int i, BsrDesc& D) {                    // the first 64 x WG_BSR_PRE blocks that end in tile i of the run
+    struct Desc { int32_t x0[WG_BSR_PRE], x1[WG_BSR_PRE], r[WG_BSR_PRE]; };
+    auto descriptors = [&](int i, Desc& D) {                       // the first 64 x WG_BSR_PRE blocks that end in tile i of the run
         const int b0 = __builtin_amdgcn_readlane(efv, i), b1 = __builtin_amdgcn_readlane(efv, i + 1);
 #pragma unroll
         for (int k = 0; k < WG_BSR_PRE; k++) {
             const int b = b0 + 64 * k + lane;
-            const bool in = b < b1;
-            D.x0[k] = in ? x0s[b] : 0;
-            D.x1[k] = in ? x1s[b] : 0;
-            D.r[k] = in ? (perm ? perm[b] : b) : -1;
+            const int bc = b < b1 ? b : b0;                        // (b0 < n_blocks whenever b1 > b0; an empty tile loads nothing it uses)
+            const int bq = bc < (int)n_blocks ? bc : (int)n_blocks - 1;
+            D.x0[k] = x0s[bq];
+            D.x1[k] = x1s[bq];
+            D.r[k] = b < b1 ? (perm ? perm[bq] : bq) : -1;
         }
     };
-    uint4 c0, c1, n0, n1, m0, m1;
-    BsrDesc dc, dn;
-    load(0, c0, c1);
-    descriptors(0, dc);
-    load(1, n0, n1);
     uint32_t run_m = 0, run_c = 0;                                 // totals of the run's sites before the current tile
-    for (int i = 0; i < nt; i++) {
-        load(i + 2, m0, m1);
-        if (i + 1 < nt) descriptors(i + 1, dn);
-        const int h = i & 1;
-        uint32_t* PK = PKs[wv][h];
-        uint2* BASE = BASEs[wv][h];
-        {
-            const uint32_t w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            uint32_t e[16], acc = 0;                               // packed exclusive prefixes inside the lane (16 x 255 fits 16 bits)
+    auto stage = [&](int h, const uint4& c0, const uint4& c1) {
+        const uint32_t w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        uint32_t e[16], acc = 0;                                   // packed exclusive prefixes inside the lane (16 x 255 fits 16 bits)
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                e[j] = acc;
-                acc += __builtin_amdgcn_perm(0u, w[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u);     // site j as (meth | cov << 16)
-            }
-            const uint32_t tm = acc & 0xffffu, tc = acc >> 16;
-            const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
-            BASE[lane] = make_uint2(run_m + (im - tm), run_c + (ic - tc));
-            uint4* dst = reinterpret_cast<uint4*>(PK + lane * 16);
-#pragma unroll
-            for (int j = 0; j < 16; j += 4) dst[j >> 2] = make_uint4(e[j], e[j + 1], e[j + 2], e[j + 3]);
-            run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
-            run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
-            if (lane == 0) { BASE[WG_BSR_TILE / 16] = make_uint2(run_m, run_c); PK[WG_BSR_TILE] = 0u; }     // the entry behind the tile's last site
+        for (int j = 0; j < 16; j++) {
+            e[j] = acc;
+            acc += __builtin_amdgcn_perm(0u, w[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u);     // site j as (meth | cov << 16)
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int lo = (int)((t0 + i) * WG_BSR_TILE);
-        auto one = [&](int x0, int x1, int64_t r) {
-            const int r1 = x1 - lo, r0 = x0 - lo;                  // r1 in [0, 1024]
-            uint32_t m32 = 0, c32 = 0;
-            bool direct = false;
-            if (x1 > x0) {
-                const uint2 be = BASE[r1 >> 4];
-                const uint32_t ke = PK[r1];
-                uint2 bs;
-                uint32_t ks;
-                if (r0 >= 0) { bs = BASE[r0 >> 4]; ks = PK[r0]; }
-                else if (r0 >= -WG_BSR_TILE && i > 0) { bs = BASEs[wv][h ^ 1][(r0 + WG_BSR_TILE) >> 4]; ks = PKs[wv][h ^ 1][r0 + WG_BSR_TILE]; }
-                else { direct = true; bs = make_uint2(0u, 0u); ks = 0u; }
-                m32 = (be.x + (ke & 0xffffu)) - (bs.x + (ks & 0xffffu));
-                c32 = (be.y + (ke >> 16)) - (bs.y + (ks >> 16));
-            }
-            if (direct) {                                          // rare: begins before the run, or more than a tile back
-                wg_block_direct_store(row, x0, x1, n_total, orow, r, mode, min_cov);
-            } else if (mode == 1 && c32 <= 255u) {
-                reinterpret_cast<uchar2*>(orow)[r] = make_uchar2((unsigned char)m32, (unsigned char)c32);
-            } else if (mode == 0) {
-                reinterpret_cast<uint2*>(orow)[r] = make_uint2(m32, c32);
-            } else if (mode == 3) {
-                reinterpret_cast<double*>(orow)[r] = (c32 >= min_cov) ? (double)m32 / (double)c32 : __builtin_nan("");
-            } else if (mode == 2 && c32 <= 65535u) {
-                reinterpret_cast<ushort2*>(orow)[r] = make_ushort2((unsigned short)m32, (unsigned short)c32);
-            } else {
-                wg_block_sum_store_slow(orow, r, mode, min_cov, (uint64_t)m32, (uint64_t)c32);     // counts above the format's maximum: rescaled
-            }
-        };
+        const uint32_t tm = acc & 0xffffu, tc = acc >> 16;
+        const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
+        BASE[h * (WG_BSR_TILE / 16) + lane] = make_uint2(run_m + (im - tm), run_c + (ic - tc));
+        uint4* dst = reinterpret_cast<uint4*>(PK + h * WG_BSR_TILE + lane * 16);
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) dst[j >> 2] = make_uint4(e[j], e[j + 1], e[j + 2], e[j + 3]);
+        run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
+        run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+    };
+    // one block whose last site lies in tile i (lo = the tile's first site, h = its half of the ring)
+    auto one = [&](int i, int h, uint32_t lo, int x0, int x1, int r) {
+        const int r1 = x1 - (int)lo, r0 = x0 - (int)lo;            // r1 in [1, 1024] for a block with sites
+        const uint32_t q1 = (uint32_t)(h * WG_BSR_TILE + r1) & (RING - 1), q0 = (uint32_t)(h * WG_BSR_TILE + r0) & (RING - 1);
+        const uint2 be = BASE[q1 >> 4], bs = BASE[q0 >> 4];
+        const uint32_t ke = PK[q1], ks = PK[q0];
+        const bool at_end = r1 == WG_BSR_TILE;                     // the prefix behind the tile's last site is the running total
+        const uint32_t pm1 = at_end ? run_m : be.x + (ke & 0xffffu), pc1 = at_end ? run_c : be.y + (ke >> 16);
+        uint32_t m32 = pm1 - (bs.x + (ks & 0xffffu)), c32 = pc1 - (bs.y + (ks >> 16));
+        const bool empty = x1 <= x0;
+        m32 = empty ? 0u : m32; c32 = empty ? 0u : c32;
+        const bool reach = r0 >= (i > 0 ? -WG_BSR_TILE : 0);       // the first site is in this tile or the previous one of the run
+        const uint32_t o = (uint32_t)r * ESZ;
+        if (!reach && !empty) {                                    // rare: begins before the run, or more than a tile back
+            wg_block_direct_store(row, x0, x1, n_total, orow, r, MODE, min_cov);
+        } else if (MODE == 0) {
+            *reinterpret_cast<uint2*>(orow + o) = make_uint2(m32, c32);
+        } else if (MODE == 3) {
+            *reinterpret_cast<double*>(orow + o) = (c32 >= min_cov) ? (double)m32 / (double)c32 : __builtin_nan("");
+        } else if (c32 <= (MODE == 1 ? 255u : 65535u)) {
+            if (MODE == 1) *reinterpret_cast<uchar2*>(orow + o) = make_uchar2((unsigned char)m32, (unsigned char)c32);
+            else           *reinterpret_cast<ushort2*>(orow + o) = make_ushort2((unsigned short)m32, (unsigned short)c32);
+        } else {
+            wg_block_sum_store_slow(orow, r, MODE, min_cov, (uint64_t)m32, (uint64_t)c32);      // counts above the format's maximum: rescaled
+        }
+    };
+    auto resolve = [&](int i, int h, const Desc& D) {
+        const uint32_t lo = site0 + (uint32_t)i * WG_BSR_TILE;
 #pragma unroll
         for (int k = 0; k < WG_BSR_PRE; k++)
-            if (dc.r[k] >= 0) one(dc.x0[k], dc.x1[k], dc.r[k]);
-        {
-            const int b1 = __builtin_amdgcn_readlane(efv, i + 1);
-            for (int b = __builtin_amdgcn_readlane(efv, i) + 64 * WG_BSR_PRE + lane; b < b1; b += 64) one(x0s[b], x1s[b], perm ? perm[b] : b);
+            if (D.r[k] >= 0) one(i, h, lo, D.x0[k], D.x1[k], D.r[k]);
+        const int b1 = __builtin_amdgcn_readlane(efv, i + 1);
+        for (int b = __builtin_amdgcn_readlane(efv, i) + 64 * WG_BSR_PRE + lane; b < b1; b += 64) one(i, h, lo, x0s[b], x1s[b], perm ? perm[b] : b);
+    };
+
+    uint4 va[3], vb[3];                                            // tile i in set i mod 3: one being staged, two in flight
+    Desc D[2];                                                     // descriptors of tile i in set i mod 2
+    load(0, va[0], vb[0]);
+    descriptors(0, D[0]);
+    if (1 < nt) load(1, va[1], vb[1]);
+#pragma unroll
+    for (int i = 0; i < WG_BSR_RUN; i++) {
+        if (i < nt) {                                              // (wave-uniform)
+            if (i + 2 < nt) load(i + 2, va[(i + 2) % 3], vb[(i + 2) % 3]);
+            if (i + 1 < nt) descriptors(i + 1, D[(i + 1) & 1]);
+            stage(i & 1, va[i % 3], vb[i % 3]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            resolve(i, i & 1, D[i & 1]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                       // (the half written next is the one last read a tile ago)
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                           // (the half written next is the one last read a tile ago)
-        c0 = n0; c1 = n1; n0 = m0; n1 = m1;
-        dc = dn;
     }
 }
 

@@ -1630,7 +1630,7 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
     const size_t obytes = (size_t)c->n_samples * (size_t)n_blocks * esz;
     // uint8 rows and a table ordered by first AND last site (what a segmentation writes; beta_to_blocks' "nice" tables): the
     // streaming kernel.  Its tile table: the first block whose last site lies at or behind every 1024-site tile's first site.
-    bool monotone = c->elem == 1;
+    bool monotone = c->elem == 1 && (uint64_t)n_blocks * 8 < (1ull << 32);      // (32-bit output offsets in the streaming kernel)
     for (int64_t i = 1; i < n_blocks && monotone; i++) monotone = hx1[i] >= hx1[i - 1];
     if (c->bs_general) monotone = false;                         // WGBSSEG_BLOCK_SUMS_GENERAL=1 (tests): the general kernel for every table
     const int64_t n_rtiles = (c->n_total + WG_BSR_TILE - 1) / WG_BSR_TILE;
@@ -1659,10 +1659,13 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
     const unsigned gy = (unsigned)((c->n_samples + 4 * spw - 1) / (4 * spw));
     if (gy > 65535) { set_err(err, errlen, "too many samples for one block_sums call"); return WGBSSEG_E_ARG; }
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
-    if (monotone)
-        hipLaunchKernelGGL(k_block_sums_run, dim3((unsigned)((n_rtiles + WG_BSR_RUN - 1) / WG_BSR_RUN), (unsigned)((c->n_samples + 3) / 4)), dim3(WG_BLOCK), 0, c->sA,
-                           c->betas, c->pitch, c->n_total, dx0, dx1, dperm, dtf, n_rtiles, n_blocks, (int)c->n_samples, (int)mode, min_cov, c->dbg_b.p);
-    else if (c->elem == 1)
+    if (monotone) {
+        const dim3 grid((unsigned)((n_rtiles + WG_BSR_RUN - 1) / WG_BSR_RUN), (unsigned)((c->n_samples + 3) / 4));
+#define WG_LAUNCH_BSR(M) hipLaunchKernelGGL(k_block_sums_run<M>, grid, dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total, dx0, dx1, dperm, dtf, \
+                                            n_rtiles, n_blocks, (int)c->n_samples, min_cov, c->dbg_b.p)
+        if (mode == 0) WG_LAUNCH_BSR(0); else if (mode == 1) WG_LAUNCH_BSR(1); else if (mode == 2) WG_LAUNCH_BSR(2); else WG_LAUNCH_BSR(3);
+#undef WG_LAUNCH_BSR
+    } else if (c->elem == 1)
         hipLaunchKernelGGL(k_block_sums<1>, dim3((unsigned)gx, gy), dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total,
                            dx0, dx1, dperm, dtf, n_tiles, n_blocks, (int)c->n_samples, spw, (int)mode, min_cov, c->dbg_b.p);
     else
