@@ -2003,18 +2003,24 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
         const uint32_t tm = acc & 0xffffu, tc = acc >> 16;
         const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
         BASE[h * (WG_BSR_TILE / 16) + lane] = make_uint2(run_m + (im - tm), run_c + (ic - tc));
-        uint4* dst = reinterpret_cast<uint4*>(PK + h * WG_BSR_TILE + lane * 16);
+        // LDS layout of a half: the four sites 4 g .. 4 g + 3 of lane L at dwords (g * 64 + L) * 4: consecutive lanes write
+        // consecutive 16-byte slots (no bank conflicts; lane-major rows of 16 dwords would be 16-way conflicts and were what held
+        // the first version of this kernel — and the general one — at 2-3 TB/s)
+        uint4* dst = reinterpret_cast<uint4*>(PK + h * WG_BSR_TILE) + lane;
 #pragma unroll
-        for (int j = 0; j < 16; j += 4) dst[j >> 2] = make_uint4(e[j], e[j + 1], e[j + 2], e[j + 3]);
+        for (int j = 0; j < 16; j += 4) dst[(j >> 2) * 64] = make_uint4(e[j], e[j + 1], e[j + 2], e[j + 3]);
         run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
         run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+    };
+    auto pk_at = [&](uint32_t q) -> uint32_t {                     // ring position (half, site of the tile) -> the dword it was stored at
+        return (q & ~(uint32_t)(WG_BSR_TILE - 1)) | ((q & 12u) << 6) | ((q >> 2) & 0xfcu) | (q & 3u);
     };
     // one block whose last site lies in tile i (lo = the tile's first site, h = its half of the ring)
     auto one = [&](int i, int h, uint32_t lo, int x0, int x1, int r) {
         const int r1 = x1 - (int)lo, r0 = x0 - (int)lo;            // r1 in [1, 1024] for a block with sites
         const uint32_t q1 = (uint32_t)(h * WG_BSR_TILE + r1) & (RING - 1), q0 = (uint32_t)(h * WG_BSR_TILE + r0) & (RING - 1);
         const uint2 be = BASE[q1 >> 4], bs = BASE[q0 >> 4];
-        const uint32_t ke = PK[q1], ks = PK[q0];
+        const uint32_t ke = PK[pk_at(q1)], ks = PK[pk_at(q0)];
         const bool at_end = r1 == WG_BSR_TILE;                     // the prefix behind the tile's last site is the running total
         const uint32_t pm1 = at_end ? run_m : be.x + (ke & 0xffffu), pc1 = at_end ? run_c : be.y + (ke >> 16);
         uint32_t m32 = pm1 - (bs.x + (ks & 0xffffu)), c32 = pc1 - (bs.y + (ks >> 16));
