@@ -1923,26 +1923,66 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
 #define WG_BSR_RUN 8
 #define WG_BSR_PK (WG_BSR_TILE + 16)          // packed in-lane prefixes of a tile (+ the entry behind its last site)
 
-__device__ __noinline__ void wg_block_sum_store_slow(void* __restrict__ out, int64_t o, int mode, uint32_t min_cov, uint64_t m, uint64_t c)
+// trunc(fl(fl(m / c) * 255)) — utils_wgbs.py:277-290 in float64 — without a float64 division on the common path: with
+// q = 255 m / c NOT an integer, the two roundings (relative 2^-52 each) cannot carry the product across an integer
+// (q is at least 1 / c > 2^-25 away from one), so the result is floor(q), taken in integers from a float estimate corrected
+// by one multiply-back; when q IS an integer the roundings decide whether it is reached, and the reference's own operations
+// are evaluated (a few per cent of the blocks).  m <= c < 2^24 (255 m < 2^32).
+__device__ __forceinline__ uint32_t wg_rescale_255(uint32_t m, uint32_t c)
 {
-    wg_block_sum_store(out, o, mode, min_cov, m, c);
+    const uint32_t P = m * 255u;
+    uint32_t k = (uint32_t)((float)P * __builtin_amdgcn_rcpf((float)c));      // within 1 of floor(P / c): P / c <= 255, relative error < 2^-22
+    int32_t r = (int32_t)(P - k * c);
+    if (r < 0) { k -= 1u; r += (int32_t)c; }
+    if (r >= (int32_t)c) { k += 1u; r -= (int32_t)c; }
+    if (r == 0 || m > c) k = (uint32_t)(uint64_t)((double)m / (double)c * 255.0);
+    return k;
 }
 
-__device__ __noinline__ void wg_block_direct_store(const uint8_t* __restrict__ row, int x0, int x1, int64_t n_total, void* __restrict__ out, int64_t o,
-                                                   int mode, uint32_t min_cov)
+// k_block_sums_direct: the blocks the streaming kernel leaves out — those that begin before their run or more than a tile
+// before the tile they end in (blocks longer than 1024 sites, and one or two per run boundary): one wavefront per (block,
+// sample) reads the block's bytes with 16-byte loads, 512 sites per iteration, and reduces across lanes.  Which blocks these are
+// depends on the table alone: the host lists them.
+__global__ __launch_bounds__(WG_BLOCK) void k_block_sums_direct(const uint8_t* __restrict__ betas, int64_t pitch, int64_t n_total,
+                                                                const int32_t* __restrict__ x0s, const int32_t* __restrict__ x1s,
+                                                                const int32_t* __restrict__ perm, const int32_t* __restrict__ list, int64_t n_list,
+                                                                int64_t n_blocks, int n_samples, int mode, uint32_t min_cov, void* __restrict__ out)
 {
-    uint64_t m = 0, c = 0;
-    wg_direct_sum<1>(row, x0, x1, n_total, m, c);
-    wg_block_sum_store(out, o, mode, min_cov, m, c);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int s = (int)blockIdx.y * (WG_BLOCK / 64) + wv;
+    if (s >= n_samples || (int64_t)blockIdx.x >= n_list) return;
+    const int b = list[blockIdx.x];
+    const int x0 = x0s[b], x1 = x1s[b];
+    const uint8_t* row = betas + (int64_t)s * pitch;
+    const int64_t last_vec = ((n_total + 7) >> 3) - 1;
+    unsigned long long m = 0, c = 0;
+    for (int64_t v0 = (int64_t)(x0 & ~7) + 8 * lane; v0 < x1; v0 += 512) {
+        const int64_t vi = v0 >> 3;
+        const uint4 v = reinterpret_cast<const uint4*>(row)[vi < last_vec ? vi : last_vec];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int64_t x = v0 + j;
+            if (x < x0 || x >= x1) continue;
+            const uint32_t hh = w[j >> 1] >> (16 * (j & 1));
+            m += hh & 0xffu; c += (hh >> 8) & 0xffu;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { m += __shfl_down(m, o); c += __shfl_down(c, o); }
+    if (lane == 0) {
+        const size_t esz = mode == 0 ? 8 : (mode == 1 ? 2 : (mode == 2 ? 4 : 8));
+        char* orow = reinterpret_cast<char*>(out) + (size_t)s * (size_t)n_blocks * esz;
+        wg_block_sum_store(orow, perm ? perm[b] : b, mode, min_cov, (uint64_t)m, (uint64_t)c);
+    }
 }
 
-#define WG_BSR_PRE 2                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
+#define WG_BSR_PRE 3                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
 
 // Straight-line code on purpose: the tile loop is unrolled (register sets rotate by renaming, not by moves), everything a
 // wavefront shares is forced into scalar registers (its sample's row, its LDS rows, the run's tile table), loads that may
 // fall outside are clamped instead of predicated, the two tiles of prefixes form ONE ring (index (1024 h + rel) mod 2048
 // reaches back into the previous tile without a branch), and the output mode is a template parameter.
-template <int MODE>
+template <int MODE, bool PERM>
 __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __restrict__ betas, int64_t pitch, int64_t n_total,
                                                              const int32_t* __restrict__ x0s, const int32_t* __restrict__ x1s,
                                                              const int32_t* __restrict__ perm, const int32_t* __restrict__ end_first,
@@ -1972,8 +2012,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
     // this lane's 16 sites of the run's tile i: two 16-byte vectors.  A vector beyond the row is clamped onto the row's last
     // one (readable: the pitch is a multiple of 16 bytes) — it only feeds prefixes behind every block's last site.  The last
     // vector itself may hold sites beyond n_total: bytes of the row's padding, which no block reaches either.
-    auto load = [&](int i, uint4& a, uint4& b) {
-        const uint32_t v = ((site0 + (uint32_t)i * WG_BSR_TILE) >> 3) + 2u * (uint32_t)lane;
+    auto load = [&](int i, uint4& a, uint4& b) {                   // (a tile behind the run's last: that one again — no branch, nobody uses it)
+        const uint32_t v = ((site0 + (uint32_t)(i < nt ? i : nt - 1) * WG_BSR_TILE) >> 3) + 2u * (uint32_t)lane;
         const uint4* rv = reinterpret_cast<const uint4*>(row);
         a = rv[v < last_vec ? v : last_vec];
         b = rv[v + 1u < last_vec ? v + 1u : last_vec];
@@ -1988,7 +2028,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
             const int bq = bc < (int)n_blocks ? bc : (int)n_blocks - 1;
             D.x0[k] = x0s[bq];
             D.x1[k] = x1s[bq];
-            D.r[k] = b < b1 ? (perm ? perm[bq] : bq) : -1;
+            D.r[k] = b < b1 ? (PERM ? perm[bq] : bq) : -1;
         }
     };
     uint32_t run_m = 0, run_c = 0;                                 // totals of the run's sites before the current tile
@@ -2028,17 +2068,17 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
         m32 = empty ? 0u : m32; c32 = empty ? 0u : c32;
         const bool reach = r0 >= (i > 0 ? -WG_BSR_TILE : 0);       // the first site is in this tile or the previous one of the run
         const uint32_t o = (uint32_t)r * ESZ;
-        if (!reach && !empty) {                                    // rare: begins before the run, or more than a tile back
-            wg_block_direct_store(row, x0, x1, n_total, orow, r, MODE, min_cov);
-        } else if (MODE == 0) {
+        if (!reach && !empty) return;                              // begins before the run or more than a tile back: k_block_sums_direct's
+        if (MODE == 0) {
             *reinterpret_cast<uint2*>(orow + o) = make_uint2(m32, c32);
         } else if (MODE == 3) {
             *reinterpret_cast<double*>(orow + o) = (c32 >= min_cov) ? (double)m32 / (double)c32 : __builtin_nan("");
-        } else if (c32 <= (MODE == 1 ? 255u : 65535u)) {
-            if (MODE == 1) *reinterpret_cast<uchar2*>(orow + o) = make_uchar2((unsigned char)m32, (unsigned char)c32);
-            else           *reinterpret_cast<ushort2*>(orow + o) = make_ushort2((unsigned short)m32, (unsigned short)c32);
+        } else if (MODE == 1) {
+            if (c32 > 255u) { m32 = wg_rescale_255(m32, c32); c32 = 255u; }
+            *reinterpret_cast<uchar2*>(orow + o) = make_uchar2((unsigned char)m32, (unsigned char)c32);
         } else {
-            wg_block_sum_store_slow(orow, r, MODE, min_cov, (uint64_t)m32, (uint64_t)c32);      // counts above the format's maximum: rescaled
+            if (c32 > 65535u) { m32 = (uint32_t)(uint64_t)((double)m32 / (double)c32 * 65535.0); c32 = 65535u; }     // (> 257 saturated sites: rare)
+            *reinterpret_cast<ushort2*>(orow + o) = make_ushort2((unsigned short)m32, (unsigned short)c32);
         }
     };
     auto resolve = [&](int i, int h, const Desc& D) {
@@ -2047,19 +2087,21 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
         for (int k = 0; k < WG_BSR_PRE; k++)
             if (D.r[k] >= 0) one(i, h, lo, D.x0[k], D.x1[k], D.r[k]);
         const int b1 = __builtin_amdgcn_readlane(efv, i + 1);
-        for (int b = __builtin_amdgcn_readlane(efv, i) + 64 * WG_BSR_PRE + lane; b < b1; b += 64) one(i, h, lo, x0s[b], x1s[b], perm ? perm[b] : b);
+        for (int b = __builtin_amdgcn_readlane(efv, i) + 64 * WG_BSR_PRE + lane; b < b1; b += 64) one(i, h, lo, x0s[b], x1s[b], PERM ? perm[b] : b);
     };
 
     uint4 va[3], vb[3];                                            // tile i in set i mod 3: one being staged, two in flight
     Desc D[2];                                                     // descriptors of tile i in set i mod 2
     load(0, va[0], vb[0]);
     descriptors(0, D[0]);
-    if (1 < nt) load(1, va[1], vb[1]);
+    load(1, va[1], vb[1]);
 #pragma unroll
     for (int i = 0; i < WG_BSR_RUN; i++) {
         if (i < nt) {                                              // (wave-uniform)
-            if (i + 2 < nt) load(i + 2, va[(i + 2) % 3], vb[(i + 2) % 3]);
-            if (i + 1 < nt) descriptors(i + 1, D[(i + 1) & 1]);
+            // (vector memory operations of a wave complete in order: the descriptors, needed one tile from now, go first, so that
+            // waiting for them leaves the bytes of tile i + 2 in flight)
+            descriptors(i + 1, D[(i + 1) & 1]);                    // (behind the run's last tile: an empty range)
+            load(i + 2, va[(i + 2) % 3], vb[(i + 2) % 3]);
             stage(i & 1, va[i % 3], vb[i % 3]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -1630,6 +1630,7 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
     const size_t obytes = (size_t)c->n_samples * (size_t)n_blocks * esz;
     // uint8 rows and a table ordered by first AND last site (what a segmentation writes; beta_to_blocks' "nice" tables): the
     // streaming kernel.  Its tile table: the first block whose last site lies at or behind every 1024-site tile's first site.
+    std::vector<int32_t> direct;
     bool monotone = c->elem == 1 && (uint64_t)n_blocks * 8 < (1ull << 32);      // (32-bit output offsets in the streaming kernel)
     for (int64_t i = 1; i < n_blocks && monotone; i++) monotone = hx1[i] >= hx1[i - 1];
     if (c->bs_general) monotone = false;                         // WGBSSEG_BLOCK_SUMS_GENERAL=1 (tests): the general kernel for every table
@@ -1644,6 +1645,16 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
             htf[t] = (int32_t)b;
         }
         htf[n_rtiles] = (int32_t)n_blocks;
+        // blocks the streaming kernel cannot resolve from its two-tile ring (they begin before their run, or more than a tile
+        // before the tile they end in): a matter of the table alone; they get a wavefront per (block, sample) afterwards
+        for (int64_t i = 0; i < n_blocks; i++) {
+            if (hx1[i] <= hx0[i]) continue;
+            const int64_t t = (hx1[i] - 1) / WG_BSR_TILE, run0 = t / WG_BSR_RUN * WG_BSR_RUN;
+            if (hx0[i] < std::max(run0, t - 1) * WG_BSR_TILE) direct.push_back((int32_t)i);
+        }
+        h.insert(h.end(), direct.begin(), direct.end());
+        hx0 = h.data(); hx1 = hx0 + n_blocks; hperm = sorted ? nullptr : hx1 + n_blocks;
+        htf = hx1 + n_blocks + (sorted ? 0 : n_blocks);
     }
     HIP_TRY(c->dbg_a.ensure(h.size() * 4));
     HIP_TRY(c->dbg_b.ensure(obytes));
@@ -1661,10 +1672,18 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
     if (monotone) {
         const dim3 grid((unsigned)((n_rtiles + WG_BSR_RUN - 1) / WG_BSR_RUN), (unsigned)((c->n_samples + 3) / 4));
-#define WG_LAUNCH_BSR(M) hipLaunchKernelGGL(k_block_sums_run<M>, grid, dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total, dx0, dx1, dperm, dtf, \
-                                            n_rtiles, n_blocks, (int)c->n_samples, min_cov, c->dbg_b.p)
+#define WG_LAUNCH_BSR(M) do { if (dperm) hipLaunchKernelGGL((k_block_sums_run<M, true>), grid, dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total, dx0, dx1, dperm, dtf, \
+                                                            n_rtiles, n_blocks, (int)c->n_samples, min_cov, c->dbg_b.p); \
+                              else hipLaunchKernelGGL((k_block_sums_run<M, false>), grid, dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total, dx0, dx1, dperm, dtf, \
+                                                      n_rtiles, n_blocks, (int)c->n_samples, min_cov, c->dbg_b.p); } while (0)
         if (mode == 0) WG_LAUNCH_BSR(0); else if (mode == 1) WG_LAUNCH_BSR(1); else if (mode == 2) WG_LAUNCH_BSR(2); else WG_LAUNCH_BSR(3);
 #undef WG_LAUNCH_BSR
+        if (!direct.empty()) {
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_block_sums_direct, dim3((unsigned)direct.size(), (unsigned)((c->n_samples + 3) / 4)), dim3(WG_BLOCK), 0, c->sA,
+                               c->betas, c->pitch, c->n_total, dx0, dx1, dperm, dtf + n_rtiles + 1, (int64_t)direct.size(), n_blocks,
+                               (int)c->n_samples, (int)mode, min_cov, c->dbg_b.p);
+        }
     } else if (c->elem == 1)
         hipLaunchKernelGGL(k_block_sums<1>, dim3((unsigned)gx, gy), dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total,
                            dx0, dx1, dperm, dtf, n_tiles, n_blocks, (int)c->n_samples, spw, (int)mode, min_cov, c->dbg_b.p);
