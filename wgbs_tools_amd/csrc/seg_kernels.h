@@ -1977,28 +1977,59 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_direct(const uint8_t* _
 }
 
 #define WG_BSR_PRE 3                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
+#define WG_BSR_RING (2 * WG_BSR_TILE)
+
+// LDS layout of the prefix ring: ring position q = (half, site x of the tile); the four sites 4 g .. 4 g + 3 of lane L (x = 16 L +
+// 4 g + k) sit at dwords (g * 64 + L) * 4 + k of their half: consecutive lanes write consecutive 16-byte slots (no bank
+// conflicts; lane-major rows of 16 dwords are 16-way conflicts).
+__host__ __device__ __forceinline__ uint32_t wg_bsr_pk_at(uint32_t q)
+{
+    return (q & ~(uint32_t)(WG_BSR_TILE - 1)) | ((q & 12u) << 6) | ((q >> 2) & 0xfcu) | (q & 3u);
+}
+
+// k_block_sums_prep: what the streaming kernel needs to know about a block depends on the table alone, so it is worked out once
+// per call, not once per sample: the LDS addresses of the two prefixes whose difference is the block's sum — INCLUSIVE
+// prefixes I(x1 - 1) - I(x0 - 1): the last site x1 - 1 lies in the block's tile, x0 - 1 in it or in the previous one, an
+// empty block reads one entry twice, and the position before the run's first site is an entry kept at zero — and the row
+// the result goes to (-1: a block the ring cannot serve, k_block_sums_direct's).
+//   d1[b] / d0[b] = byte offset of the PK entry | byte offset of the BASE entry << 16
+__global__ __launch_bounds__(WG_BLOCK) void k_block_sums_prep(const int32_t* __restrict__ x0s, const int32_t* __restrict__ x1s, const int32_t* __restrict__ perm,
+                                                              int64_t n_blocks, int64_t n_tiles, int32_t* __restrict__ d1, int32_t* __restrict__ d0, int32_t* __restrict__ rr)
+{
+    const int64_t b = (int64_t)blockIdx.x * WG_BLOCK + threadIdx.x;
+    if (b >= n_blocks) return;
+    const int x0 = x0s[b], x1 = x1s[b];
+    int64_t t = (int64_t)(x1 - 1 > x0 ? x1 - 1 : x0) / WG_BSR_TILE;        // the tile the block is resolved in (k_block_sums_run's table uses the same rule)
+    if (t > n_tiles - 1) t = n_tiles - 1;                                   // (an empty block at the very end of the row)
+    const int i = (int)(t % WG_BSR_RUN), h = i & 1;
+    const int lo = (int)(t * WG_BSR_TILE);
+    const uint32_t q1 = (uint32_t)(h * WG_BSR_TILE + (x1 - 1 - lo)) & (WG_BSR_RING - 1), q0 = (uint32_t)(h * WG_BSR_TILE + (x0 - 1 - lo)) & (WG_BSR_RING - 1);
+    const bool reach = x1 <= x0 || (i == 0 ? x0 >= lo : x0 >= lo - (WG_BSR_TILE - 1));
+    d1[b] = (int32_t)((wg_bsr_pk_at(q1) * 4u) | (((q1 >> 4) * 8u) << 16));
+    d0[b] = (int32_t)((wg_bsr_pk_at(q0) * 4u) | (((q0 >> 4) * 8u) << 16));
+    rr[b] = reach ? (perm ? perm[b] : (int32_t)b) : -1;
+}
 
 // Straight-line code on purpose: the tile loop is unrolled (register sets rotate by renaming, not by moves), everything a
 // wavefront shares is forced into scalar registers (its sample's row, its LDS rows, the run's tile table), loads that may
-// fall outside are clamped instead of predicated, the two tiles of prefixes form ONE ring (index (1024 h + rel) mod 2048
-// reaches back into the previous tile without a branch), and the output mode is a template parameter.
-template <int MODE, bool PERM>
+// fall outside are clamped instead of predicated, no calls and no per-block address arithmetic (k_block_sums_prep), and the
+// output mode is a template parameter.
+template <int MODE>
 __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __restrict__ betas, int64_t pitch, int64_t n_total,
-                                                             const int32_t* __restrict__ x0s, const int32_t* __restrict__ x1s,
-                                                             const int32_t* __restrict__ perm, const int32_t* __restrict__ end_first,
+                                                             const int32_t* __restrict__ d1s, const int32_t* __restrict__ d0s,
+                                                             const int32_t* __restrict__ rrs, const int32_t* __restrict__ end_first,
                                                              int64_t n_tiles, int64_t n_blocks, int n_samples, uint32_t min_cov,
                                                              void* __restrict__ out)
 {
-    constexpr int RING = 2 * WG_BSR_TILE;
-    __shared__ __attribute__((aligned(16))) uint32_t PKs[WG_BLOCK / 64][RING];      // packed (meth | cov << 16) prefixes inside a lane's 16 sites
-    __shared__ uint2 BASEs[WG_BLOCK / 64][RING / 16];                                // the run's totals before each lane's 16 sites
+    __shared__ __attribute__((aligned(16))) uint32_t PKs[WG_BLOCK / 64][WG_BSR_RING];      // packed (meth | cov << 16) INCLUSIVE prefixes inside a lane's 16 sites
+    __shared__ uint2 BASEs[WG_BLOCK / 64][WG_BSR_RING / 16];                                // the run's totals before each lane's 16 sites
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int s = (int)blockIdx.y * (WG_BLOCK / 64) + wv;
     if (s >= n_samples) return;
     const int64_t t0 = (int64_t)blockIdx.x * WG_BSR_RUN;
     const int nt = (int)((t0 + WG_BSR_RUN < n_tiles ? t0 + WG_BSR_RUN : n_tiles) - t0);       // tiles of this run
-    // the run's slice of the tile table in one register (lane i: first block that ends in tile t0 + i or later)
+    // the run's slice of the tile table in one register (lane i: first block resolved in tile t0 + i or later)
     const int efv = end_first[t0 + (lane <= nt ? lane : nt)];
     if (__builtin_amdgcn_readlane(efv, 0) == __builtin_amdgcn_readlane(efv, nt)) return;     // no block ends in this run: nothing to read
     const uint8_t* row = betas + (int64_t)s * pitch;
@@ -2006,8 +2037,11 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
     char* orow = reinterpret_cast<char*>(out) + (size_t)s * (size_t)n_blocks * ESZ;      // (the host keeps n_blocks * 8 below 2^32: 32-bit offsets)
     uint32_t* PK = PKs[wv];
     uint2* BASE = BASEs[wv];
+    const char* PKc = reinterpret_cast<const char*>(PK);
+    const char* BASEc = reinterpret_cast<const char*>(BASE);
     const uint32_t site0 = (uint32_t)(t0 * WG_BSR_TILE);           // first site of the run (n_total < 2^31)
     const uint32_t last_vec = (uint32_t)(((n_total + 7) >> 3) - 1);                       // last 16-byte vector that holds a site of the row
+    const int nb_all = (int)n_blocks;
 
     // this lane's 16 sites of the run's tile i: two 16-byte vectors.  A vector beyond the row is clamped onto the row's last
     // one (readable: the pitch is a multiple of 16 bytes) — it only feeds prefixes behind every block's last site.  The last
@@ -2018,57 +2052,43 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
         a = rv[v < last_vec ? v : last_vec];
         b = rv[v + 1u < last_vec ? v + 1u : last_vec];
     };
-    struct Desc { int32_t x0[WG_BSR_PRE], x1[WG_BSR_PRE], r[WG_BSR_PRE]; };
-    auto descriptors = [&](int i, Desc& D) {                       // the first 64 x WG_BSR_PRE blocks that end in tile i of the run
+    struct Desc { int32_t d1[WG_BSR_PRE], d0[WG_BSR_PRE], r[WG_BSR_PRE]; };
+    auto descriptors = [&](int i, Desc& D) {                       // the first 64 x WG_BSR_PRE blocks resolved in tile i of the run
         const int b0 = __builtin_amdgcn_readlane(efv, i), b1 = __builtin_amdgcn_readlane(efv, i + 1);
 #pragma unroll
         for (int k = 0; k < WG_BSR_PRE; k++) {
             const int b = b0 + 64 * k + lane;
-            const int bc = b < b1 ? b : b0;                        // (b0 < n_blocks whenever b1 > b0; an empty tile loads nothing it uses)
-            const int bq = bc < (int)n_blocks ? bc : (int)n_blocks - 1;
-            D.x0[k] = x0s[bq];
-            D.x1[k] = x1s[bq];
-            D.r[k] = b < b1 ? (PERM ? perm[bq] : bq) : -1;
+            const int bq = b < nb_all ? b : nb_all - 1;            // (clamped, not predicated)
+            D.d1[k] = d1s[bq];
+            D.d0[k] = d0s[bq];
+            const int r = rrs[bq];
+            D.r[k] = b < b1 ? r : -1;
         }
     };
     uint32_t run_m = 0, run_c = 0;                                 // totals of the run's sites before the current tile
     auto stage = [&](int h, const uint4& c0, const uint4& c1) {
         const uint32_t w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        uint32_t e[16], acc = 0;                                   // packed exclusive prefixes inside the lane (16 x 255 fits 16 bits)
+        uint32_t e[16], acc = 0;                                   // packed inclusive prefixes inside the lane (16 x 255 fits 16 bits)
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            e[j] = acc;
             acc += __builtin_amdgcn_perm(0u, w[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u);     // site j as (meth | cov << 16)
+            e[j] = acc;
         }
         const uint32_t tm = acc & 0xffffu, tc = acc >> 16;
         const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
         BASE[h * (WG_BSR_TILE / 16) + lane] = make_uint2(run_m + (im - tm), run_c + (ic - tc));
-        // LDS layout of a half: the four sites 4 g .. 4 g + 3 of lane L at dwords (g * 64 + L) * 4: consecutive lanes write
-        // consecutive 16-byte slots (no bank conflicts; lane-major rows of 16 dwords would be 16-way conflicts and were what held
-        // the first version of this kernel — and the general one — at 2-3 TB/s)
         uint4* dst = reinterpret_cast<uint4*>(PK + h * WG_BSR_TILE) + lane;
 #pragma unroll
         for (int j = 0; j < 16; j += 4) dst[(j >> 2) * 64] = make_uint4(e[j], e[j + 1], e[j + 2], e[j + 3]);
         run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
         run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
     };
-    auto pk_at = [&](uint32_t q) -> uint32_t {                     // ring position (half, site of the tile) -> the dword it was stored at
-        return (q & ~(uint32_t)(WG_BSR_TILE - 1)) | ((q & 12u) << 6) | ((q >> 2) & 0xfcu) | (q & 3u);
-    };
-    // one block whose last site lies in tile i (lo = the tile's first site, h = its half of the ring)
-    auto one = [&](int i, int h, uint32_t lo, int x0, int x1, int r) {
-        const int r1 = x1 - (int)lo, r0 = x0 - (int)lo;            // r1 in [1, 1024] for a block with sites
-        const uint32_t q1 = (uint32_t)(h * WG_BSR_TILE + r1) & (RING - 1), q0 = (uint32_t)(h * WG_BSR_TILE + r0) & (RING - 1);
-        const uint2 be = BASE[q1 >> 4], bs = BASE[q0 >> 4];
-        const uint32_t ke = PK[pk_at(q1)], ks = PK[pk_at(q0)];
-        const bool at_end = r1 == WG_BSR_TILE;                     // the prefix behind the tile's last site is the running total
-        const uint32_t pm1 = at_end ? run_m : be.x + (ke & 0xffffu), pc1 = at_end ? run_c : be.y + (ke >> 16);
-        uint32_t m32 = pm1 - (bs.x + (ks & 0xffffu)), c32 = pc1 - (bs.y + (ks >> 16));
-        const bool empty = x1 <= x0;
-        m32 = empty ? 0u : m32; c32 = empty ? 0u : c32;
-        const bool reach = r0 >= (i > 0 ? -WG_BSR_TILE : 0);       // the first site is in this tile or the previous one of the run
+    auto one = [&](int d1, int d0, int r) {
+        const uint2 be = *reinterpret_cast<const uint2*>(BASEc + ((uint32_t)d1 >> 16)), bs = *reinterpret_cast<const uint2*>(BASEc + ((uint32_t)d0 >> 16));
+        const uint32_t ke = *reinterpret_cast<const uint32_t*>(PKc + ((uint32_t)d1 & 0xffffu)), ks = *reinterpret_cast<const uint32_t*>(PKc + ((uint32_t)d0 & 0xffffu));
+        uint32_t m32 = (be.x + (ke & 0xffffu)) - (bs.x + (ks & 0xffffu));
+        uint32_t c32 = (be.y + (ke >> 16)) - (bs.y + (ks >> 16));
         const uint32_t o = (uint32_t)r * ESZ;
-        if (!reach && !empty) return;                              // begins before the run or more than a tile back: k_block_sums_direct's
         if (MODE == 0) {
             *reinterpret_cast<uint2*>(orow + o) = make_uint2(m32, c32);
         } else if (MODE == 3) {
@@ -2081,15 +2101,15 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
             *reinterpret_cast<ushort2*>(orow + o) = make_ushort2((unsigned short)m32, (unsigned short)c32);
         }
     };
-    auto resolve = [&](int i, int h, const Desc& D) {
-        const uint32_t lo = site0 + (uint32_t)i * WG_BSR_TILE;
+    auto resolve = [&](int i, const Desc& D) {
 #pragma unroll
         for (int k = 0; k < WG_BSR_PRE; k++)
-            if (D.r[k] >= 0) one(i, h, lo, D.x0[k], D.x1[k], D.r[k]);
+            if (D.r[k] >= 0) one(D.d1[k], D.d0[k], D.r[k]);
         const int b1 = __builtin_amdgcn_readlane(efv, i + 1);
-        for (int b = __builtin_amdgcn_readlane(efv, i) + 64 * WG_BSR_PRE + lane; b < b1; b += 64) one(i, h, lo, x0s[b], x1s[b], PERM ? perm[b] : b);
+        for (int b = __builtin_amdgcn_readlane(efv, i) + 64 * WG_BSR_PRE + lane; b < b1; b += 64) { const int r = rrs[b]; if (r >= 0) one(d1s[b], d0s[b], r); }
     };
 
+    if (lane == 0) { PK[WG_BSR_RING - 1] = 0u; BASE[WG_BSR_RING / 16 - 1] = make_uint2(0u, 0u); }      // I(-1) of the run: the entry "before" tile 0
     uint4 va[3], vb[3];                                            // tile i in set i mod 3: one being staged, two in flight
     Desc D[2];                                                     // descriptors of tile i in set i mod 2
     load(0, va[0], vb[0]);
@@ -2105,7 +2125,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
             stage(i & 1, va[i % 3], vb[i % 3]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            resolve(i, i & 1, D[i & 1]);
+            resolve(i, D[i & 1]);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             __builtin_amdgcn_wave_barrier();                       // (the half written next is the one last read a tile ago)
         }

@@ -142,7 +142,7 @@ struct wgbsseg_ctx {
     // region-level call hold junction patches only, all inside chunks its first batch has validated.  Never kept across
     // API calls: device-resident betas handed over by pointer may change between them.
     std::vector<std::pair<int64_t, int64_t>> validated;
-    DevBuf scan_pieces, divcheck, plan_sb;
+    DevBuf scan_pieces, divcheck, plan_sb, bs_desc;
     std::vector<int32_t> h_stage_bounds;
     double tail_frac = 0.0;   // WGBSSEG_TAIL_FRAC: share of every chunk scored in the second of two uneven stages (many-chunk jobs); 0: one stage; < 0: from the call's size
     // the short division core of the narrow scoring tiles: verified on the device per pseudo count (k_check_div)
@@ -287,7 +287,7 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->wtile, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs,
                      &c->status, &c->plan_cbase, &c->plan_cum0, &c->plan_tbase, &c->plan_pairs, &c->plan_tiles, &c->plan_cnt, &c->tilesA, &c->tilesB, &c->umax16,
                      &c->cost[0], &c->cost[1], &c->dpstate, &c->tmp_borders, &c->nb, &c->boff, &c->out_borders,
-                     &c->dbg_a, &c->dbg_b, &c->dbg_c, &c->lookup};
+                     &c->dbg_a, &c->dbg_b, &c->dbg_c, &c->lookup, &c->scan_pieces, &c->divcheck, &c->plan_sb, &c->bs_desc};
     for (auto* b : all) b->release();
     for (auto& pb : c->pinned) pb.release();
     for (auto& pb : c->up_stage) pb.release();
@@ -1649,8 +1649,8 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
         // before the tile they end in): a matter of the table alone; they get a wavefront per (block, sample) afterwards
         for (int64_t i = 0; i < n_blocks; i++) {
             if (hx1[i] <= hx0[i]) continue;
-            const int64_t t = (hx1[i] - 1) / WG_BSR_TILE, run0 = t / WG_BSR_RUN * WG_BSR_RUN;
-            if (hx0[i] < std::max(run0, t - 1) * WG_BSR_TILE) direct.push_back((int32_t)i);
+            const int64_t t = (hx1[i] - 1) / WG_BSR_TILE, lo = t * WG_BSR_TILE;                 // (k_block_sums_prep applies the same rule)
+            if (t % WG_BSR_RUN == 0 ? hx0[i] < lo : hx0[i] < lo - (WG_BSR_TILE - 1)) direct.push_back((int32_t)i);
         }
         h.insert(h.end(), direct.begin(), direct.end());
         hx0 = h.data(); hx1 = hx0 + n_blocks; hperm = sorted ? nullptr : hx1 + n_blocks;
@@ -1671,11 +1671,15 @@ int wgbsseg_block_sums(wgbsseg_ctx* c, const int64_t* start0, const int64_t* end
     if (gy > 65535) { set_err(err, errlen, "too many samples for one block_sums call"); return WGBSSEG_E_ARG; }
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
     if (monotone) {
+        HIP_TRY(c->bs_desc.ensure((size_t)n_blocks * 12));
+        int32_t* dd1 = c->bs_desc.as<int32_t>();
+        int32_t* dd0 = dd1 + n_blocks;
+        int32_t* drr = dd0 + n_blocks;
+        hipLaunchKernelGGL(k_block_sums_prep, dim3((unsigned)((n_blocks + WG_BLOCK - 1) / WG_BLOCK)), dim3(WG_BLOCK), 0, c->sA, dx0, dx1, dperm, n_blocks, n_rtiles, dd1, dd0, drr);
+        HIP_TRY(hipGetLastError());
         const dim3 grid((unsigned)((n_rtiles + WG_BSR_RUN - 1) / WG_BSR_RUN), (unsigned)((c->n_samples + 3) / 4));
-#define WG_LAUNCH_BSR(M) do { if (dperm) hipLaunchKernelGGL((k_block_sums_run<M, true>), grid, dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total, dx0, dx1, dperm, dtf, \
-                                                            n_rtiles, n_blocks, (int)c->n_samples, min_cov, c->dbg_b.p); \
-                              else hipLaunchKernelGGL((k_block_sums_run<M, false>), grid, dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total, dx0, dx1, dperm, dtf, \
-                                                      n_rtiles, n_blocks, (int)c->n_samples, min_cov, c->dbg_b.p); } while (0)
+#define WG_LAUNCH_BSR(M) hipLaunchKernelGGL(k_block_sums_run<M>, grid, dim3(WG_BLOCK), 0, c->sA, c->betas, c->pitch, c->n_total, dd1, dd0, drr, dtf, \
+                                            n_rtiles, n_blocks, (int)c->n_samples, min_cov, c->dbg_b.p)
         if (mode == 0) WG_LAUNCH_BSR(0); else if (mode == 1) WG_LAUNCH_BSR(1); else if (mode == 2) WG_LAUNCH_BSR(2); else WG_LAUNCH_BSR(3);
 #undef WG_LAUNCH_BSR
         if (!direct.empty()) {
