@@ -1978,6 +1978,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_direct(const uint8_t* _
 
 #define WG_BSR_PRE 3                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
 #define WG_BSR_RING (2 * WG_BSR_TILE)
+#define WG_BSR_AHEAD 4                         // tiles of sample bytes in flight per wavefront (2 KB each)
 
 // LDS layout of the prefix ring: ring position q = (half, site x of the tile); the four sites 4 g .. 4 g + 3 of lane L (x = 16 L +
 // 4 g + k) sit at dwords (g * 64 + L) * 4 + k of their half: consecutive lanes write consecutive 16-byte slots (no bank
@@ -2110,19 +2111,21 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
     };
 
     if (lane == 0) { PK[WG_BSR_RING - 1] = 0u; BASE[WG_BSR_RING / 16 - 1] = make_uint2(0u, 0u); }      // I(-1) of the run: the entry "before" tile 0
-    uint4 va[3], vb[3];                                            // tile i in set i mod 3: one being staged, two in flight
+    constexpr int AHEAD = WG_BSR_AHEAD;                            // tiles in flight behind the one being staged
+    uint4 va[AHEAD + 1], vb[AHEAD + 1];                            // tile i in set i mod (AHEAD + 1)
     Desc D[2];                                                     // descriptors of tile i in set i mod 2
     load(0, va[0], vb[0]);
     descriptors(0, D[0]);
-    load(1, va[1], vb[1]);
+#pragma unroll
+    for (int a = 1; a < AHEAD; a++) load(a, va[a], vb[a]);
 #pragma unroll
     for (int i = 0; i < WG_BSR_RUN; i++) {
         if (i < nt) {                                              // (wave-uniform)
             // (vector memory operations of a wave complete in order: the descriptors, needed one tile from now, go first, so that
-            // waiting for them leaves the bytes of tile i + 2 in flight)
+            // waiting for them leaves the bytes of the tiles ahead in flight)
             descriptors(i + 1, D[(i + 1) & 1]);                    // (behind the run's last tile: an empty range)
-            load(i + 2, va[(i + 2) % 3], vb[(i + 2) % 3]);
-            stage(i & 1, va[i % 3], vb[i % 3]);
+            load(i + AHEAD, va[(i + AHEAD) % (AHEAD + 1)], vb[(i + AHEAD) % (AHEAD + 1)]);
+            stage(i & 1, va[i % (AHEAD + 1)], vb[i % (AHEAD + 1)]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             resolve(i, D[i & 1]);
