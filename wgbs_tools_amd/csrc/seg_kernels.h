@@ -580,6 +580,8 @@ struct CostArgs {
     int32_t NS;        // samples per LDS group
     int32_t rows;      // guard-free kernels: exponents held by the two lookup tables (wg_lookup_rows for the longest block of the tile class)
     const wg_d2* tab;  // those tables, built by the host: rows * 16 log2f entries, then rows * 64 fast-log2 entries
+    int32_t xcd_group; // consecutive tiles that go to one XCD before the next XCD's group begins (see k_cost)
+    int32_t pad;
 };
 
 // Stage the exclusive prefixes P[A+x], x = x0 .. x0+cnt-1, of sample row `row` into dst[0..cnt) (one wavefront).
@@ -739,9 +741,12 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nC = J.n_chunks;
-    // XCD-aware remap: consecutive tiles (which share halo sites) land on the same XCD's L2
-    const int64_t per = n_tiles_padded >> 3;
-    const int64_t t = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    // XCD-aware remap.  Workgroup i runs on XCD i mod 8, each with its own L2: consecutive tiles (which share halo sites) go to
+    // the same XCD in groups of G; the groups are dealt round-robin, so that every XCD gets an even sample of the genome (tile
+    // costs follow the CpG density: eight contiguous eighths — round 1's mapping — left the densest eighth's XCD working alone
+    // at the end of a small job)
+    const int64_t G = A.xcd_group, jx = (int64_t)(blockIdx.x >> 3);
+    const int64_t t = (jx / G) * (8 * G) + (int64_t)(blockIdx.x & 7) * G + (jx % G);
     if (t >= n_tiles) return;
     const TileDesc td = tiles[t];
     const int c = td.chunk;

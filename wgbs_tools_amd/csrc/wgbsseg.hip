@@ -517,7 +517,7 @@ int report_bad_site(const wgbsseg_ctx* c, const JobStatus& st, char* err, size_t
 template <int TI, int FAST, int SPLIT>
 hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
-    const int64_t padded = round_up(tiles, 8);
+    const int64_t padded = round_up(tiles, 8 * (int64_t)a.xcd_group);      // whole groups for every XCD; workgroups behind the last tile leave at once
     hipLaunchKernelGGL((k_cost<TI, FAST, SPLIT>), dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, td, tiles, cost, padded);
     return hipGetLastError();
 }
@@ -718,6 +718,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     CostArgs caA, caB;
     memset(&caA, 0, sizeof(caA));
     caA.pc = P->pseudo_count; caA.pc2 = P->pseudo_count + P->pseudo_count;
+    static const int xcd_group = getenv("WGBSSEG_XCD_GROUP") ? std::max(1, atoi(getenv("WGBSSEG_XCD_GROUP"))) : 64;
+    caA.xcd_group = xcd_group;
     caB = caA;
     caA.NS = NSA; caA.rows = rowsA;
     caB.NS = NSB; caB.rows = rowsB;
