@@ -121,7 +121,7 @@ struct wgbsseg_ctx {
     DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders, dbg_a, dbg_b, dbg_c, lookup;
     std::vector<wg_d2> h_lookup;   // host copy of the k-scaled log tables of the call in flight (source of an async upload)
     // events
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[9] = {};   // [8]: between the two launches of the scan pass (k_scan | k_validate)
     PinnedBuf h_status;      // page-locked landing area of the status words: D2H copies that really are asynchronous
     std::vector<hipEvent_t> ev_cost0, ev_cost1, ev_dp0, ev_dp1;
     // last-call info
@@ -493,6 +493,7 @@ int launch_scan(wgbsseg_ctx* c, const Job& job, int want_carry, char* err, size_
     if (blocks > 0x7fffffff) { set_err(err, errlen, "too many (chunk, sample) rows"); return WGBSSEG_E_ARG; }
     hipLaunchKernelGGL(k_scan, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, c->sA, job.v, c->status.as<JobStatus>(), want_carry);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[8], c->sA));
     if (!want_carry && !job.pieces.empty()) {
         const int64_t tasks = (int64_t)job.pieces.size() * job.v.n_samples;
         const int64_t vb = (tasks + (WG_BLOCK / 64) - 1) / (WG_BLOCK / 64);
@@ -918,7 +919,9 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     wgbsseg_timings& T = c->tim;
     if (!c->accumulate) memset(&T, 0, sizeof(T));
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, c->ev[7], c->ev[2])); T.scan_ms += ms;
+    // the scan pass = the one of its two launches that did the work (the other left at once): k_scan before ev[8], k_validate after
+    if (st.wide_units) HIP_TRY(hipEventElapsedTime(&ms, c->ev[7], c->ev[8])); else HIP_TRY(hipEventElapsedTime(&ms, c->ev[8], c->ev[2]));
+    T.scan_ms += ms;
     // algorithmic bytes of the pass: with wide units k_scan reads every chunk row of the batch; without, k_validate reads the
     // batch's not-yet-validated sites once
     const int64_t scan_bytes = 2 * (st.wide_units ? J : job.val_sites) * c->n_samples;
