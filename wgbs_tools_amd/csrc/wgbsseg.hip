@@ -1149,7 +1149,7 @@ int upload_rows_streaming(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const
                           std::atomic<int64_t>& ready_sites, std::string& msg)
 {
     const double t0 = wall_s();
-    int64_t piece = 2 << 20;
+    int64_t piece = 1 << 20;      // (measured: 4 threads x 1 MB 33.5 GB/s, x 2 MB 26-29, 8-16 threads 17-30: profiles/r02_upload_sweep.txt)
     { const char* e = getenv("WGBSSEG_UPLOAD_PIECE_KB"); if (e && atoi(e) >= 64) piece = (int64_t)atoi(e) << 10; }
     const int64_t ppr = (row_bytes + piece - 1) / piece, n_tasks = ppr * n_rows;
     int T = 4;
