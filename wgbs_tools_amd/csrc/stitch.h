@@ -13,14 +13,17 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdint>
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
 #include <vector>
+#include <unistd.h>
 
 namespace wgstitch {
 
@@ -204,6 +207,67 @@ inline void junctions_of_region(const std::vector<int64_t>& lens, int64_t first_
     }
 }
 
+// A few persistent host threads for the junction-local work of a call (rehearsal of ~500 junctions, the trees of 25
+// chromosomes, flattening 2.8 M borders): a call lasts a millisecond, so threads spawned per call would cost what they save.
+// Created on first use, never torn down (the process exit takes them); WGBSSEG_STITCH_THREADS=1 keeps everything on the caller.
+class Pool {
+public:
+    static Pool& get() { static Pool* p = new Pool(); return *p; }
+    int threads() const { return (int)workers_.size() + 1; }
+    // f(k) for k = 0 .. n-1 on the pool's threads and the calling one; returns when all are done
+    void run(int64_t n, const std::function<void(int64_t)>& f)
+    {
+        if (n <= 0) return;
+        // one parallel section at a time: a second caller (another context on another thread) does its own work itself, and so
+        // does a forked child, which has inherited the object but not the threads
+        std::unique_lock<std::mutex> turn(run_m_, std::try_to_lock);
+        if (workers_.empty() || n == 1 || !turn.owns_lock() || getpid() != pid_) { for (int64_t k = 0; k < n; k++) f(k); return; }
+        {
+            std::lock_guard<std::mutex> g(m_);
+            job_ = &f; n_ = n; next_.store(0); pending_ = (int)workers_.size(); gen_++;
+        }
+        cv_.notify_all();
+        for (int64_t k; (k = next_.fetch_add(1)) < n;) f(k);
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [&] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+private:
+    Pool()
+    {
+        int t = (int)std::min<unsigned>(8, std::max<unsigned>(1, std::thread::hardware_concurrency() / 2));
+        if (const char* e = getenv("WGBSSEG_STITCH_THREADS")) t = std::max(1, atoi(e));
+        for (int i = 1; i < t; i++) { workers_.emplace_back([this] { loop(); }); workers_.back().detach(); }
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int64_t)>* f;
+            int64_t n;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_ != seen; });
+                seen = gen_; f = job_; n = n_;
+            }
+            for (int64_t k; (k = next_.fetch_add(1)) < n;) (*f)(k);
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--pending_ == 0) done_.notify_one();
+            }
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex m_, run_m_;
+    pid_t pid_ = getpid();
+    std::condition_variable cv_, done_;
+    const std::function<void(int64_t)>* job_ = nullptr;
+    int64_t n_ = 0;
+    std::atomic<int64_t> next_{0};
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+};
+
 typedef std::pair<int64_t, int64_t> Sites;                     // 1-based [start, end)
 // Result of one batch of chunk DPs: per item, int32 borders RELATIVE to the item's start (first 0, last end-start).
 // The items of a batch may live in several buffers (one per GPU share); all must stay valid until segment_regions returns.
@@ -279,12 +343,16 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     // every junction now against those two chunks, collect ALL missing patches, and fetch them in one batch (repeat while
     // something is missing).  Only the cache is filled here; the tree then does the real work and, where the rehearsal
     // could not foresee a request (a patch outgrowing its chunk), still asks for it.
+    Pool& pool = Pool::get();
     if (speculate) {
         std::vector<Junction> pend = junctions;
+        struct Sim { std::vector<Sites> want; bool still = false; };
         for (int pass = 0; pass < 4 && !pend.empty(); pass++) {
-            std::vector<Sites> need;
-            std::vector<Junction> still;
-            for (const Junction& jn : pend) {
+            // every junction against the cache as it stands (read-only: the junctions run on the pool's threads) ...
+            std::vector<Sim> sims(pend.size());
+            pool.run((int64_t)pend.size(), [&](int64_t k) {
+                const Junction& jn = pend[(size_t)k];
+                Sim& out = sims[(size_t)k];
                 const size_t li = (size_t)jn.left_item, ri = (size_t)jn.right_item;
                 const int64_t llen = items[li].second - items[li].first, rlen = items[ri].second - items[ri].first;
                 Stitch t;
@@ -292,7 +360,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                 a.runs.push_back(Run{first.ptr[li], first.cnt[li], items[li].first});
                 b.runs.push_back(Run{first.ptr[ri], first.cnt[ri], items[ri].first});
                 std::string e2;
-                if (!t.init(std::move(a), std::move(b), e2)) continue;
+                if (!t.init(std::move(a), std::move(b), e2)) return;
                 t.n1 = jn.n1; t.n2 = jn.n2;
                 t.p1 = std::min<int64_t>(50, t.n1); t.p2 = std::min<int64_t>(50, t.n2);
                 while (!t.done) {
@@ -300,18 +368,24 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                     if (!t.want(w, e2) || t.p1 > llen || t.p2 > rlen) break;       // the tree will deal with it
                     auto it = cache.find(w);
                     if (it == cache.end() || it->second.p == nullptr) {
-                        if (it == cache.end()) { cache[w] = Patch{nullptr, 0}; need.push_back(w); }
+                        out.want.push_back(w);
                         const int64_t j = t.b1.back();
                         const int64_t q1 = increase_patch(t.p1, t.n1), q2 = increase_patch(t.p2, t.n2);
                         const Sites alt[3] = {{j - q1, j + t.p2}, {j - t.p1, j + q2}, {j - q1, j + q2}};
                         const bool ok[3] = {q1 <= t.n1, q2 <= t.n2, q1 <= t.n1 && q2 <= t.n2};
-                        for (int k = 0; k < 3; k++)
-                            if (ok[k] && !cache.count(alt[k])) { cache[alt[k]] = Patch{nullptr, 0}; need.push_back(alt[k]); }
-                        still.push_back(jn);
+                        for (int q = 0; q < 3; q++) if (ok[q]) out.want.push_back(alt[q]);
+                        out.still = true;
                         break;
                     }
                     t.feed(it->second.p, it->second.n, w.first);
                 }
+            });
+            // ... then, in junction order, what is missing
+            std::vector<Sites> need;
+            std::vector<Junction> still;
+            for (size_t k = 0; k < pend.size(); k++) {
+                for (const Sites& w : sims[k].want) if (!cache.count(w)) { cache[w] = Patch{nullptr, 0}; need.push_back(w); }
+                if (sims[k].still) still.push_back(pend[k]);
             }
             if (need.empty()) break;
             keep.emplace_back(new BatchResult());
@@ -325,13 +399,44 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     }
     mark("rehearsal (incl. its batches)");
     // ---- pairwise-tree stitching (segment.py:157-165), all regions advancing round by round ------------------------
+    // Regions never interact: each region's tree on a pool thread, against the cache as the rehearsal left it (read-only).
+    // A region whose tree asks for a patch that is not there (or fails) is set aside and goes through the batching loop below,
+    // which fetches what is missing round by round and reports errors in the reference's order.
     std::vector<std::vector<Rope>> lists((size_t)n_regions);
-    for (int64_t r = 0; r < n_regions; r++)
+    auto chunk_ropes = [&](int64_t r, std::vector<Rope>& l) {
+        l.clear();
         for (int64_t q = region_first_chunk[(size_t)r]; q < region_first_chunk[(size_t)r + 1]; q++) {
             Rope rp;
             rp.runs.push_back(Run{first.ptr[(size_t)q], first.cnt[(size_t)q], items[(size_t)q].first});
-            lists[(size_t)r].push_back(std::move(rp));
+            l.push_back(std::move(rp));
         }
+    };
+    pool.run(n_regions, [&](int64_t r) {
+        std::vector<Rope> l;
+        chunk_ropes(r, l);
+        std::string e2;
+        bool ok = true;
+        while (ok && l.size() > 1) {
+            std::vector<Rope> nxt;
+            for (size_t i = 1; ok && i < l.size(); i += 2) {
+                Stitch st1;
+                if (!st1.init(std::move(l[i - 1]), std::move(l[i]), e2)) { ok = false; break; }
+                while (!st1.done) {
+                    Sites w;
+                    if (!st1.want(w, e2)) { ok = false; break; }
+                    auto it = cache.find(w);
+                    if (it == cache.end() || it->second.p == nullptr) { ok = false; break; }
+                    st1.feed(it->second.p, it->second.n, w.first);
+                }
+                if (ok) nxt.push_back(std::move(st1.result));
+            }
+            if (!ok) break;
+            if (l.size() % 2) nxt.push_back(std::move(l.back()));
+            l.swap(nxt);
+        }
+        if (ok) lists[(size_t)r] = std::move(l);                 // one rope: done
+        else chunk_ropes(r, lists[(size_t)r]);                   // from scratch in the loop below
+    });
     for (;;) {
         bool any = false;
         for (auto& l : lists) any = any || l.size() > 1;
@@ -396,18 +501,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     for (int64_t r = 0; r < n_regions; r++) { borders_off[r] = total; total += lists[(size_t)r][0].size(); }
     borders_off[n_regions] = total;
     if (total > borders_cap) { err = "borders_out too small: need " + std::to_string(total); return E_CAPACITY; }
-    {   // regions are independent: flatten them on a few threads when there is enough to copy
-        const int nth = (total > (1 << 20) && n_regions > 1) ? (int)std::min<int64_t>(4, n_regions) : 1;
-        if (nth == 1) {
-            for (int64_t r = 0; r < n_regions; r++) lists[(size_t)r][0].flatten(borders_out + borders_off[r]);
-        } else {
-            std::vector<std::thread> th;
-            std::atomic<int64_t> next(0);
-            for (int t = 0; t < nth; t++)
-                th.emplace_back([&]() { for (int64_t r; (r = next.fetch_add(1)) < n_regions;) lists[(size_t)r][0].flatten(borders_out + borders_off[r]); });
-            for (auto& x : th) x.join();
-        }
-    }
+    pool.run(n_regions, [&](int64_t r) { lists[(size_t)r][0].flatten(borders_out + borders_off[r]); });
     mark("flatten");
     if (prof) {
         for (size_t i = 1; i < marks.size(); i++)
