@@ -224,13 +224,23 @@ public:
         if (workers_.empty() || n == 1 || !turn.owns_lock() || getpid() != pid_) { for (int64_t k = 0; k < n; k++) f(k); return; }
         {
             std::lock_guard<std::mutex> g(m_);
-            job_ = &f; n_ = n; next_.store(0); pending_ = (int)workers_.size(); gen_++;
+            job_ = &f; n_ = n; next_.store(0); pending_.store((int)workers_.size());
+            gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
         for (int64_t k; (k = next_.fetch_add(1)) < n;) f(k);
-        std::unique_lock<std::mutex> g(m_);
-        done_.wait(g, [&] { return pending_ == 0; });
+        while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();       // (the stragglers are on their last item)
         job_ = nullptr;
+    }
+    // The threads sleep between calls, and a sleeping core takes ~100 us to come back — as long as the work they are wanted for.
+    // heat() wakes them ahead of time (the library calls it when the recurrence of a batch is done: traceback and the copy of
+    // the borders, ~0.4 ms, are still to come); awake, they poll for work for `us` microseconds before they go back to sleep.
+    void heat(int us = 3000)
+    {
+        if (workers_.empty() || getpid() != pid_) return;
+        hot_until_.store(now_us() + us, std::memory_order_relaxed);
+        { std::lock_guard<std::mutex> g(m_); }
+        cv_.notify_all();
     }
 private:
     Pool()
@@ -239,33 +249,44 @@ private:
         if (const char* e = getenv("WGBSSEG_STITCH_THREADS")) t = std::max(1, atoi(e));
         for (int i = 1; i < t; i++) { workers_.emplace_back([this] { loop(); }); workers_.back().detach(); }
     }
+    static int64_t now_us() { return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    static void cpu_relax()
+    {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
     void loop()
     {
         uint64_t seen = 0;
         for (;;) {
+            // wait for a new job: polling while hot, on the condition variable otherwise
+            while (gen_.load(std::memory_order_acquire) == seen) {
+                if (now_us() < hot_until_.load(std::memory_order_relaxed)) { cpu_relax(); continue; }
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return gen_.load(std::memory_order_acquire) != seen || now_us() < hot_until_.load(std::memory_order_relaxed); });
+            }
             const std::function<void(int64_t)>* f;
             int64_t n;
             {
-                std::unique_lock<std::mutex> g(m_);
-                cv_.wait(g, [&] { return gen_ != seen; });
-                seen = gen_; f = job_; n = n_;
+                std::lock_guard<std::mutex> g(m_);
+                seen = gen_.load(std::memory_order_acquire); f = job_; n = n_;
             }
             for (int64_t k; (k = next_.fetch_add(1)) < n;) (*f)(k);
-            {
-                std::lock_guard<std::mutex> g(m_);
-                if (--pending_ == 0) done_.notify_one();
-            }
+            pending_.fetch_sub(1, std::memory_order_release);
+            hot_until_.store(std::max(hot_until_.load(std::memory_order_relaxed), now_us() + 300), std::memory_order_relaxed);   // the next section usually follows at once
         }
     }
     std::vector<std::thread> workers_;
     std::mutex m_, run_m_;
     pid_t pid_ = getpid();
-    std::condition_variable cv_, done_;
+    std::condition_variable cv_;
     const std::function<void(int64_t)>* job_ = nullptr;
     int64_t n_ = 0;
     std::atomic<int64_t> next_{0};
-    int pending_ = 0;
-    uint64_t gen_ = 0;
+    std::atomic<int> pending_{0};
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int64_t> hot_until_{0};
 };
 
 typedef std::pair<int64_t, int64_t> Sites;                     // 1-based [start, end)
@@ -380,6 +401,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                     t.feed(it->second.p, it->second.n, w.first);
                 }
             });
+            mark("  rehearsal: junctions against the cache");
             // ... then, in junction order, what is missing
             std::vector<Sites> need;
             std::vector<Junction> still;
@@ -387,6 +409,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                 for (const Sites& w : sims[k].want) if (!cache.count(w)) { cache[w] = Patch{nullptr, 0}; need.push_back(w); }
                 if (sims[k].still) still.push_back(pend[k]);
             }
+            mark("  rehearsal: list of missing patches");
             if (need.empty()) break;
             keep.emplace_back(new BatchResult());
             BatchResult& res = *keep.back();
@@ -395,6 +418,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
             n_batches++;
             for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = Patch{res.ptr[i], res.cnt[i]}; n_patch_dp++; }
             pend.swap(still);
+            mark("  rehearsal: follow-up batch");
         }
     }
     mark("rehearsal (incl. its batches)");

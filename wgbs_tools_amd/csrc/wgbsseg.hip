@@ -898,6 +898,12 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[5], c->sB));
     HIP_TRY(hipMemcpyAsync(borders_off, c->boff.p, (size_t)(nC + 1) * 8, hipMemcpyDeviceToHost, c->sB));
+    if (J >= (1 << 20)) {
+        // a large batch: when its recurrence is done, ~0.4 ms of traceback and copies remain — just the time the host threads
+        // of the junction stitching need to wake up (stitch.h)
+        HIP_TRY(hipEventSynchronize(c->ev_dp1[n_stages - 1]));
+        wgstitch::Pool::get().heat();
+    }
     HIP_TRY(hipStreamSynchronize(c->sB));
     const int64_t total_b = borders_off[nC];
     int32_t* borders_out = alloc(total_b);
