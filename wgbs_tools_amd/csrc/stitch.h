@@ -225,10 +225,11 @@ public:
         {
             std::lock_guard<std::mutex> g(m_);
             job_ = &f; n_ = n; next_.store(0); pending_.store((int)workers_.size());
+            grab_ = std::max<int64_t>(1, n / (4 * ((int64_t)workers_.size() + 1)));      // items per visit to the shared counter
             gen_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
-        for (int64_t k; (k = next_.fetch_add(1)) < n;) f(k);
+        for (int64_t k; (k = next_.fetch_add(grab_)) < n;) for (int64_t q = k; q < std::min(n, k + grab_); q++) f(q);
         while (pending_.load(std::memory_order_acquire) != 0) cpu_relax();       // (the stragglers are on their last item)
         job_ = nullptr;
     }
@@ -267,12 +268,12 @@ private:
                 cv_.wait(g, [&] { return gen_.load(std::memory_order_acquire) != seen || now_us() < hot_until_.load(std::memory_order_relaxed); });
             }
             const std::function<void(int64_t)>* f;
-            int64_t n;
+            int64_t n, grab;
             {
                 std::lock_guard<std::mutex> g(m_);
-                seen = gen_.load(std::memory_order_acquire); f = job_; n = n_;
+                seen = gen_.load(std::memory_order_acquire); f = job_; n = n_; grab = grab_;
             }
-            for (int64_t k; (k = next_.fetch_add(1)) < n;) (*f)(k);
+            for (int64_t k; (k = next_.fetch_add(grab)) < n;) for (int64_t q = k; q < std::min(n, k + grab); q++) (*f)(q);
             pending_.fetch_sub(1, std::memory_order_release);
             hot_until_.store(std::max(hot_until_.load(std::memory_order_relaxed), now_us() + 300), std::memory_order_relaxed);   // the next section usually follows at once
         }
@@ -282,7 +283,7 @@ private:
     pid_t pid_ = getpid();
     std::condition_variable cv_;
     const std::function<void(int64_t)>* job_ = nullptr;
-    int64_t n_ = 0;
+    int64_t n_ = 0, grab_ = 1;
     std::atomic<int64_t> next_{0};
     std::atomic<int> pending_{0};
     std::atomic<uint64_t> gen_{0};
