@@ -379,16 +379,17 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, c
     }
 }
 
-__global__ __launch_bounds__(WG_BLOCK) void k_window_scan(JobView J, JobStatus* st)
+#define WG_WSCAN_BLOCK 1024      // one workgroup per chunk: 16 wavefronts x 8 sites per thread = 8192 sites per step (a 60,000-site chunk: 8 steps)
+__global__ __launch_bounds__(WG_WSCAN_BLOCK) void k_window_scan(JobView J, JobStatus* st)
 {
-    __shared__ uint32_t wsum[WG_BLOCK / 64];
+    __shared__ uint32_t wsum[WG_WSCAN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = blockIdx.x;
     const ChunkDesc cd = J.chunks[c];
     const uint16_t* W = J.W16 + cd.site_off;
     uint32_t* C = J.cum32 + cd.site_off;
     uint64_t run = 0;
-    for (int base = 0; base < cd.len; base += WG_BLOCK * 8) {         // 8 consecutive sites per thread
+    for (int base = 0; base < cd.len; base += WG_WSCAN_BLOCK * 8) {   // 8 consecutive sites per thread
         const int k0 = base + tid * 8;
         uint32_t w[8], tot = 0;
 #pragma unroll
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window_scan(JobView J, JobStatus* 
         __syncthreads();
         uint32_t woff = 0, btot = 0;
 #pragma unroll
-        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) woff += wsum[q]; btot += wsum[q]; }
+        for (int q = 0; q < WG_WSCAN_BLOCK / 64; q++) { if (q < wv) woff += wsum[q]; btot += wsum[q]; }
         __syncthreads();
         uint32_t e = (uint32_t)(run + woff + (incl - tot));
 #pragma unroll
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window_scan(JobView J, JobStatus* 
         run += btot;
     }
     uint32_t nwide = 0;
-    for (int u = tid; u < (cd.len + 15) >> 4; u += WG_BLOCK) nwide += J.umax16[cd.unit_off + u] > (uint32_t)WG_NARROW_WMAX ? 1u : 0u;
+    for (int u = tid; u < (cd.len + 15) >> 4; u += WG_WSCAN_BLOCK) nwide += J.umax16[cd.unit_off + u] > (uint32_t)WG_NARROW_WMAX ? 1u : 0u;
     for (int o = 32; o > 0; o >>= 1) nwide += (uint32_t)__shfl_down((int)nwide, o);
     if (lane == 0 && nwide) atomicAdd(&st->wide_units, nwide);
     if (tid == 0) {

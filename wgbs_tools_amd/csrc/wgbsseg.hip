@@ -103,7 +103,8 @@ struct PinnedBuf {          // grow-only page-locked host buffer (fast, truly as
 
 struct wgbsseg_ctx {
     int device = 0;
-    hipStream_t sA = nullptr, sB = nullptr;
+    hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;     // scoring (+ everything else) | recurrence, traceback | the scan pass
+    bool scan_stream = true;   // WGBSSEG_SCAN_STREAM=0: the scan pass on the scoring stream, ahead of the scoring kernel
     // inputs
     DevBuf betas_own, loci_own;
     const uint8_t* betas = nullptr;
@@ -254,6 +255,8 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
         (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
         HIP_TRY(hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, hi_p));
     }
+    HIP_TRY(hipStreamCreateWithFlags(&c->sC, hipStreamNonBlocking));
+    { const char* e = getenv("WGBSSEG_SCAN_STREAM"); if (e) c->scan_stream = atoi(e) != 0; }
     for (auto& v : c->ev) HIP_TRY(hipEventCreate(&v));
     const char* b = getenv("WGBSSEG_COST_BUDGET_MB");
     c->cost_budget_bytes = (b && atoll(b) > 0 ? atoll(b) : 6144LL) << 20;
@@ -296,6 +299,7 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     for (auto* vec : {&c->ev_cost0, &c->ev_cost1, &c->ev_dp0, &c->ev_dp1}) for (auto v : *vec) (void)hipEventDestroy(v);
     if (c->sA) (void)hipStreamDestroy(c->sA);
     if (c->sB) (void)hipStreamDestroy(c->sB);
+    if (c->sC) (void)hipStreamDestroy(c->sC);
     delete c;
     if (profiling()) fprintf(stderr, "[wgbsseg] destroy: %.1f ms\n", (wall_s() - t0) * 1e3);
 }
@@ -486,19 +490,19 @@ int plan_validation(wgbsseg_ctx* c, Job& job, bool fresh_call, char* err, size_t
 // The scan pass: k_scan (per chunk, with carries; does its work only when the job has wide units or the caller wants the
 // carries) and k_validate (per piece, read-only; only when it has none).  The device-side flag decides, so both can be
 // queued before the host has seen the window statistics.
-int launch_scan(wgbsseg_ctx* c, const Job& job, int want_carry, char* err, size_t errlen)
+int launch_scan(wgbsseg_ctx* c, const Job& job, int want_carry, hipStream_t s, char* err, size_t errlen)
 {
     const int64_t rows = (int64_t)job.v.n_chunks * job.v.n_samples;      // wave tasks
     const int64_t blocks = (rows + (WG_BLOCK / 64) - 1) / (WG_BLOCK / 64);
     if (blocks > 0x7fffffff) { set_err(err, errlen, "too many (chunk, sample) rows"); return WGBSSEG_E_ARG; }
-    hipLaunchKernelGGL(k_scan, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, c->sA, job.v, c->status.as<JobStatus>(), want_carry);
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, s, job.v, c->status.as<JobStatus>(), want_carry);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev[8], c->sA));
+    HIP_TRY(hipEventRecord(c->ev[8], s));
     if (!want_carry && !job.pieces.empty()) {
         const int64_t tasks = (int64_t)job.pieces.size() * job.v.n_samples;
         const int64_t vb = (tasks + (WG_BLOCK / 64) - 1) / (WG_BLOCK / 64);
         if (vb > 0x7fffffff) { set_err(err, errlen, "too many (piece, sample) rows"); return WGBSSEG_E_ARG; }
-        hipLaunchKernelGGL(k_validate, dim3((unsigned)vb), dim3(WG_BLOCK), 0, c->sA, job.v, c->status.as<JobStatus>(),
+        hipLaunchKernelGGL(k_validate, dim3((unsigned)vb), dim3(WG_BLOCK), 0, s, job.v, c->status.as<JobStatus>(),
                            c->scan_pieces.as<ScanPiece>(), (int64_t)job.pieces.size());
         HIP_TRY(hipGetLastError());
     }
@@ -587,6 +591,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         return WGBSSEG_E_ARG;
     }
     if (!(P->pseudo_count >= 0.0f)) { set_err(err, errlen, "pseudo_count must be >= 0"); return WGBSSEG_E_ARG; }
+    if (c && c->sC) HIP_TRY(hipStreamSynchronize(c->sC));      // (a call that failed half way may have left its scan pass running)
     Job job;
     int rc = build_job(c, chunk_start0, chunk_len, n_chunks, job, true, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
@@ -629,17 +634,24 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     hipLaunchKernelGGL(k_window, dim3((unsigned)job.wtile_off[(size_t)nC]), dim3(WG_BLOCK), (size_t)win_lds * 4, c->sA, v, c->status.as<JobStatus>(),
                        c->wtile.as<int64_t>(), reinterpret_cast<const int32_t*>(c->wtile.as<int64_t>() + nC + 1), P->max_cpg, P->max_bp, win_lds);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_window_scan, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, c->status.as<JobStatus>());
+    hipLaunchKernelGGL(k_window_scan, dim3((unsigned)nC), dim3(WG_WSCAN_BLOCK), 0, c->sA, v, c->status.as<JobStatus>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
     JobStatus* hst = reinterpret_cast<JobStatus*>(c->h_status.p);
     HIP_TRY(hipMemcpyAsync(&hst[0], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipEventRecord(c->ev[7], c->sA));
-    rc = launch_scan(c, job, 0, err, errlen);                 // carries only if k_window_scan counted wide units (device-side flag)
+    // The scan pass on its own stream.  It needs the windows' verdict (wide units or not: device-side flag), nothing else; the
+    // narrow scoring tiles need nothing from it, so for a job without wide units the HBM-bound scan and its host round trips run
+    // beside the tile plan and the VALU-bound scoring kernel; wide tiles (carries) make the scoring stream wait for it.
+    hipStream_t sS = c->scan_stream ? c->sC : c->sA;
+    if (c->scan_stream) HIP_TRY(hipStreamWaitEvent(c->sC, c->ev[1], 0));
+    rc = launch_scan(c, job, 0, sS, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
-    HIP_TRY(hipEventRecord(c->ev[2], c->sA));
+    HIP_TRY(hipEventRecord(c->ev[2], sS));
+    HIP_TRY(hipMemcpyAsync(&hst[2], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, sS));      // the scan's verdict, read at the end of the batch
     HIP_TRY(hipEventSynchronize(c->ev[7]));                    // window statistics are here; the scan is still running
     const JobStatus st = hst[0];
+    if (c->scan_stream && st.wide_units) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));
     if (check_div) {
         c->divs_ok = *reinterpret_cast<const unsigned int*>(&hst[1]) == 0u;
         c->divs_pc = P->pseudo_count;
@@ -647,6 +659,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     }
     if (st.loci_disorder || st.overflow) {
         JobStatus st2;                                        // the scan's verdict takes precedence, as it always has
+        HIP_TRY(hipStreamSynchronize(sS));
         HIP_TRY(hipMemcpyAsync(&st2, c->status.p, sizeof(st2), hipMemcpyDeviceToHost, c->sA));
         HIP_TRY(hipStreamSynchronize(c->sA));
         if (st2.first_bad != ~0ULL) return report_bad_site(c, st2, err, errlen);
@@ -805,10 +818,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     std::vector<int64_t> stage_pairs((size_t)n_stages), stage_tiles((size_t)n_stages * 2);
     HIP_TRY(hipMemcpyAsync(stage_pairs.data(), c->plan_pairs.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipMemcpyAsync(stage_tiles.data(), c->plan_tiles.p, (size_t)n_stages * 16, hipMemcpyDeviceToHost, c->sA));
-    JobStatus st_scan;
-    HIP_TRY(hipMemcpyAsync(&st_scan, c->status.p, sizeof(st_scan), hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
-    if (st_scan.first_bad != ~0ULL) return report_bad_site(c, st_scan, err, errlen);
+    if (!c->scan_stream && hst[2].first_bad != ~0ULL) return report_bad_site(c, hst[2], err, errlen);     // (scan on this stream: its verdict is here already)
     std::vector<int64_t> tileA0((size_t)n_stages + 1, 0), tileB0((size_t)n_stages + 1, 0);
     for (int stg = 0; stg < n_stages; stg++) {
         tileA0[(size_t)stg + 1] = tileA0[(size_t)stg] + stage_tiles[2 * (size_t)stg];
@@ -912,6 +923,11 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipEventRecord(c->ev[6], c->sB));
     HIP_TRY(hipStreamSynchronize(c->sB));
     HIP_TRY(hipStreamSynchronize(c->sA));
+    HIP_TRY(hipStreamSynchronize(sS));
+    // the scan's verdict (segmentor.cpp:186-189).  With the scan beside the scoring kernel an invalid file is found out at the end
+    // of the batch; every kernel downstream of the counts is safe on such data (LDS indices out of a table's range read zeros,
+    // the traceback bounds its steps) and what it produced is dropped here.
+    if (hst[2].first_bad != ~0ULL) return report_bad_site(c, hst[2], err, errlen);
 
     // ---- timings ---------------------------------------------------------------------------------------------
     static const bool timeline = getenv("WGBSSEG_PROFILE") && atoi(getenv("WGBSSEG_PROFILE")) >= 2;
@@ -1555,10 +1571,10 @@ int wgbsseg_scan_only(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t
     if (rc != WGBSSEG_OK) return rc;
     c->validated.clear();
     if (repeat < 1) repeat = 1;
-    rc = launch_scan(c, job, 0, err, errlen);                  // warm-up (a fresh status block: no wide units, so the read-only pass)
+    rc = launch_scan(c, job, 0, c->sA, err, errlen);           // warm-up (a fresh status block: no wide units, so the read-only pass)
     if (rc != WGBSSEG_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
-    for (int r = 0; r < repeat; r++) { rc = launch_scan(c, job, 0, err, errlen); if (rc != WGBSSEG_OK) return rc; }
+    for (int r = 0; r < repeat; r++) { rc = launch_scan(c, job, 0, c->sA, err, errlen); if (rc != WGBSSEG_OK) return rc; }
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
     float ms = 0;
@@ -1579,7 +1595,7 @@ int wgbsseg_prefix_sums(wgbsseg_ctx* c, int64_t start0, int64_t len, uint32_t* o
     Job job;
     int rc = build_job(c, &start0, &l32, 1, job, false, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
-    rc = launch_scan(c, job, 1, err, errlen);                  // the carries are what k_prefix_materialise builds on
+    rc = launch_scan(c, job, 1, c->sA, err, errlen);           // the carries are what k_prefix_materialise builds on
     if (rc != WGBSSEG_OK) return rc;
     const size_t bytes = (size_t)c->n_samples * (size_t)(len + 1) * 8;
     HIP_TRY(c->dbg_a.ensure(bytes));
