@@ -104,7 +104,7 @@ struct PinnedBuf {          // grow-only page-locked host buffer (fast, truly as
 struct wgbsseg_ctx {
     int device = 0;
     hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;     // scoring (+ everything else) | recurrence, traceback | the scan pass
-    bool scan_stream = true;   // WGBSSEG_SCAN_STREAM=0: the scan pass on the scoring stream, ahead of the scoring kernel
+    int scan_stream = 1;       // WGBSSEG_SCAN_STREAM: 0 the scan pass on the scoring stream, ahead of the scoring kernel; 1 on its own stream for small jobs; 2 always
     // inputs
     DevBuf betas_own, loci_own;
     const uint8_t* betas = nullptr;
@@ -256,7 +256,7 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
         HIP_TRY(hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, hi_p));
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->sC, hipStreamNonBlocking));
-    { const char* e = getenv("WGBSSEG_SCAN_STREAM"); if (e) c->scan_stream = atoi(e) != 0; }
+    { const char* e = getenv("WGBSSEG_SCAN_STREAM"); if (e) c->scan_stream = std::min(2, std::max(0, atoi(e))); }
     for (auto& v : c->ev) HIP_TRY(hipEventCreate(&v));
     const char* b = getenv("WGBSSEG_COST_BUDGET_MB");
     c->cost_budget_bytes = (b && atoll(b) > 0 ? atoll(b) : 6144LL) << 20;
@@ -643,15 +643,19 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // The scan pass on its own stream.  It needs the windows' verdict (wide units or not: device-side flag), nothing else; the
     // narrow scoring tiles need nothing from it, so for a job without wide units the HBM-bound scan and its host round trips run
     // beside the tile plan and the VALU-bound scoring kernel; wide tiles (carries) make the scoring stream wait for it.
-    hipStream_t sS = c->scan_stream ? c->sC : c->sA;
-    if (c->scan_stream) HIP_TRY(hipStreamWaitEvent(c->sC, c->ev[1], 0));
+    // Measured (WGBSSEG_SCAN_STREAM=1 / 0, ms per step): hg19 x 8 10.24 / 10.61, one eighth x 32 4.42 / 4.52, x 32 26.90 / 26.88,
+    // x 200 141.3 / 142.1: it pays where the scan and the round trips are a visible share of the step; a large job keeps the scan
+    // alone on the chip (WGBSSEG_SCAN_STREAM=2: always beside).
+    const bool beside = c->scan_stream == 2 || (c->scan_stream == 1 && (double)J * c->n_samples < 5e8);
+    hipStream_t sS = beside ? c->sC : c->sA;
+    if (beside) HIP_TRY(hipStreamWaitEvent(c->sC, c->ev[1], 0));
     rc = launch_scan(c, job, 0, sS, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], sS));
     HIP_TRY(hipMemcpyAsync(&hst[2], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, sS));      // the scan's verdict, read at the end of the batch
     HIP_TRY(hipEventSynchronize(c->ev[7]));                    // window statistics are here; the scan is still running
     const JobStatus st = hst[0];
-    if (c->scan_stream && st.wide_units) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));
+    if (beside && st.wide_units) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));
     if (check_div) {
         c->divs_ok = *reinterpret_cast<const unsigned int*>(&hst[1]) == 0u;
         c->divs_pc = P->pseudo_count;
@@ -819,7 +823,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipMemcpyAsync(stage_pairs.data(), c->plan_pairs.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipMemcpyAsync(stage_tiles.data(), c->plan_tiles.p, (size_t)n_stages * 16, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
-    if (!c->scan_stream && hst[2].first_bad != ~0ULL) return report_bad_site(c, hst[2], err, errlen);     // (scan on this stream: its verdict is here already)
+    if (!beside && hst[2].first_bad != ~0ULL) return report_bad_site(c, hst[2], err, errlen);     // (scan on this stream: its verdict is here already)
     std::vector<int64_t> tileA0((size_t)n_stages + 1, 0), tileB0((size_t)n_stages + 1, 0);
     for (int stg = 0; stg < n_stages; stg++) {
         tileA0[(size_t)stg + 1] = tileA0[(size_t)stg] + stage_tiles[2 * (size_t)stg];
