@@ -646,16 +646,17 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // Measured (WGBSSEG_SCAN_STREAM=1 / 0, ms per step): hg19 x 8 10.24 / 10.61, one eighth x 32 4.42 / 4.52, x 32 26.90 / 26.88,
     // x 200 141.3 / 142.1: it pays where the scan and the round trips are a visible share of the step; a large job keeps the scan
     // alone on the chip (WGBSSEG_SCAN_STREAM=2: always beside).
+    // Either way the tile plan (which needs the windows only) runs while the scan does.
     const bool beside = c->scan_stream == 2 || (c->scan_stream == 1 && (double)J * c->n_samples < 5e8);
-    hipStream_t sS = beside ? c->sC : c->sA;
-    if (beside) HIP_TRY(hipStreamWaitEvent(c->sC, c->ev[1], 0));
+    const bool own_stream = c->scan_stream != 0;
+    hipStream_t sS = own_stream ? c->sC : c->sA;
+    if (own_stream) HIP_TRY(hipStreamWaitEvent(c->sC, c->ev[1], 0));
     rc = launch_scan(c, job, 0, sS, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[2], sS));
     HIP_TRY(hipMemcpyAsync(&hst[2], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, sS));      // the scan's verdict, read at the end of the batch
     HIP_TRY(hipEventSynchronize(c->ev[7]));                    // window statistics are here; the scan is still running
     const JobStatus st = hst[0];
-    if (beside && st.wide_units) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));
     if (check_div) {
         c->divs_ok = *reinterpret_cast<const unsigned int*>(&hst[1]) == 0u;
         c->divs_pc = P->pseudo_count;
@@ -823,7 +824,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipMemcpyAsync(stage_pairs.data(), c->plan_pairs.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipMemcpyAsync(stage_tiles.data(), c->plan_tiles.p, (size_t)n_stages * 16, hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
-    if (!beside && hst[2].first_bad != ~0ULL) return report_bad_site(c, hst[2], err, errlen);     // (scan on this stream: its verdict is here already)
+    if (!own_stream && hst[2].first_bad != ~0ULL) return report_bad_site(c, hst[2], err, errlen);     // (scan on this stream: its verdict is here already)
     std::vector<int64_t> tileA0((size_t)n_stages + 1, 0), tileB0((size_t)n_stages + 1, 0);
     for (int stg = 0; stg < n_stages; stg++) {
         tileA0[(size_t)stg + 1] = tileA0[(size_t)stg] + stage_tiles[2 * (size_t)stg];
@@ -861,6 +862,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // LDS of k_dp: two arranged batches (64 steps x 64 lanes, or 32 steps x 64 lanes x {A, B}) + M ring + fetched ring entries + flags + ring of windows / row offsets
     DpArgs da = {ringN, {0, 0, 0}};
     const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16 + 1024 * 6;
+    if (own_stream && (!beside || st.wide_units)) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));      // scoring after the scan (always when it reads carries)
     for (int stg = 0; stg < n_stages; stg++) {
         sv.stage = stg;
         double* cbuf = c->cost[stg % nbuf].as<double>();
