@@ -646,9 +646,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // Measured (WGBSSEG_SCAN_STREAM=1 / 0, ms per step): hg19 x 8 10.24 / 10.61, one eighth x 32 4.42 / 4.52, x 32 26.90 / 26.88,
     // x 200 141.3 / 142.1: it pays where the scan and the round trips are a visible share of the step; a large job keeps the scan
     // alone on the chip (WGBSSEG_SCAN_STREAM=2: always beside).
-    // Either way the tile plan (which needs the windows only) runs while the scan does.
+    // (The tile plan beside the scan of a large job, scoring behind both: measured neutral in time, and the plan kernels cost the
+    // scan 3 % of its rate; not done.)
     const bool beside = c->scan_stream == 2 || (c->scan_stream == 1 && (double)J * c->n_samples < 5e8);
-    const bool own_stream = c->scan_stream != 0;
+    const bool own_stream = beside;
     hipStream_t sS = own_stream ? c->sC : c->sA;
     if (own_stream) HIP_TRY(hipStreamWaitEvent(c->sC, c->ev[1], 0));
     rc = launch_scan(c, job, 0, sS, err, errlen);
