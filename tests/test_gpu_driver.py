@@ -195,3 +195,42 @@ def test_two_ranks_one_process_per_gpu_cli(driver_golden, world, tmp_path):
     table = np.array([[int(r[3]), int(r[4])] for r in rows], dtype=np.int64).reshape(-1, 2)
     assert table.shape[0] == g['n_blocks']
     assert hashlib.sha1(table.tobytes()).hexdigest() == g['table_sha1']
+
+
+def test_two_contexts_on_two_host_threads_share_the_stitching_pool():
+    """The junction stitching uses one process-wide pool of host threads; a second caller does its own work itself.  Two contexts
+    segmenting different genomes at the same time from two Python threads (ctypes releases the GIL) must each get the answer they
+    get alone."""
+    import threading
+    from wgbs_tools_amd import _lib
+    worlds = []
+    for seed, n_chr in ((5, 6), (6, 9)):
+        sizes = [int(x) for x in np.random.default_rng(seed).integers(30000, 90000, n_chr)]
+        loci = synth.synth_loci(seed, sizes)
+        total = int(sum(sizes))
+        betas = [synth.synth_betas(seed, i, 0, total) for i in range(4)]
+        cum = np.concatenate([[0], np.cumsum(sizes)])
+        worlds.append((loci, betas, cum[:-1] + 1, cum[1:] + 1))
+    segs = []
+    for loci, betas, st, en in worlds:
+        sg = _lib.Segmenter(0)
+        sg.set_betas(betas)
+        sg.set_loci(loci)
+        segs.append(sg)
+    try:
+        alone = [sg.segment_regions(st, en, 7000, 15.0, 1000, 2000)[0] for sg, (_, _, st, en) in zip(segs, worlds)]
+        for _ in range(5):
+            got = [None, None]
+
+            def work(i):
+                got[i] = segs[i].segment_regions(worlds[i][2], worlds[i][3], 7000, 15.0, 1000, 2000)[0]
+            ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            for i in range(2):
+                assert len(got[i]) == len(alone[i])
+                for a, b in zip(got[i], alone[i]):
+                    assert np.array_equal(a, b)
+    finally:
+        for sg in segs:
+            sg.close()

@@ -236,7 +236,7 @@ def test_04b_validation_pass_sees_every_site_of_every_chunk_and_nothing_else(pie
     if piece: monkeypatch.setenv('WGBSSEG_SCAN_PIECE_SITES', str(piece))
     sg = _lib.Segmenter(0)
     try:
-        n, N = 40000, 3
+        n, N = 40003, 3                                                    # (no multiple of the 8 sites of a 16-byte vector)
         rng = np.random.default_rng(5)
         clean = [synth.synth_betas(cases.SEED, s, 0, n) for s in range(N)]
         loci = np.cumsum(rng.integers(2, 300, n)).astype(np.uint32)
@@ -257,7 +257,7 @@ def test_04b_validation_pass_sees_every_site_of_every_chunk_and_nothing_else(pie
                 with pytest.raises(_lib.SegmentorError) as e:
                     run([(s_, site)])
                 assert e.value.code == _lib.E_METH_GT_COV and 'sample %d' % s_ in e.value.msg and 'site %d ' % site in e.value.msg, (site, s_, e.value.msg)
-        for site in [0, 99, 39900, 39999]:                                         # outside every chunk: never read
+        for site in [0, 99, 39900, 39999, 40002]:                                  # outside every chunk: never read
             assert not covered[site]
             run([(1, site)])
         with pytest.raises(_lib.SegmentorError) as e:                              # the lowest (sample, site) wins
@@ -268,7 +268,7 @@ def test_04b_validation_pass_sees_every_site_of_every_chunk_and_nothing_else(pie
         sg.set_betas(sl)
         ok, _ = sg.segment_regions([1], [n + 1], 5000, 15.0, 1000, 2000)
         assert ok[0][0] == 1 and ok[0][-1] == n + 1
-        for site in [0, 4999, 5000, 5003, 39999]:
+        for site in [0, 4999, 5000, 5003, 39999, 40000, 40002]:
             sl = [x.copy() for x in clean]
             sl[1][site, 0] = sl[1][site, 1] + 1
             sg.set_betas(sl)
