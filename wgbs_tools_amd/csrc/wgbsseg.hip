@@ -741,6 +741,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     caA.pc = P->pseudo_count; caA.pc2 = P->pseudo_count + P->pseudo_count;
     static const int xcd_group = getenv("WGBSSEG_XCD_GROUP") ? std::max(1, atoi(getenv("WGBSSEG_XCD_GROUP"))) : 64;
     caA.xcd_group = xcd_group;
+    static const int use_cmap = !(getenv("WGBSSEG_NO_CMAP") && atoi(getenv("WGBSSEG_NO_CMAP")));
+    caA.cmap = use_cmap;
     caB = caA;
     caA.NS = NSA; caA.rows = rowsA;
     caB.NS = NSB; caB.rows = rowsB;
