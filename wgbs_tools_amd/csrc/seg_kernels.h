@@ -739,11 +739,11 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     // tile as a byte map, filled once per tile, instead of a 7-step binary search in offs[] per block
     constexpr bool BMAP = (TI == 128 && !SPLIT);
     uint8_t* bmap = reinterpret_cast<uint8_t*>(misc + 8);                        // (BMAP) [TI * WG_NARROW_WMAX]
-    // narrow tiles of 64 starts or fewer have no LDS to spare for a byte per block (a fifth workgroup per CU is worth more): a byte
-    // per FOUR blocks — the start of block 4 g — and a step or two forward from there (a start has ~20 blocks) instead of the
-    // 6-step binary search: 1 KB for a 64-start tile
+    // narrow tiles of 64 starts or fewer have no LDS to spare for a byte per block (31.1 KB per workgroup: 25 LDS granules of
+    // 1280 bytes, five workgroups per CU; one granule more and it is four): a byte per EIGHT blocks — the start of block 8 g —
+    // and a step forward from there when needed (a start has ~20 blocks) instead of the 6-step binary search: 488 bytes
     constexpr bool CMAP = (!SPLIT && TI <= 64);
-    uint8_t* cmap = bmap;                                                        // (CMAP) [TI * WG_NARROW_WMAX / 4 + 1]
+    uint8_t* cmap = bmap;                                                        // (CMAP) [TI * WG_NARROW_WMAX / 8 + 1]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nC = J.n_chunks;
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     }
     if (CMAP && tid < nk) {
         const int o0 = offs[tid], o1 = offs[tid + 1];
-        for (int g = (o0 + 3) >> 2; 4 * g < o1; g++) cmap[g] = (uint8_t)tid;
+        for (int g = (o0 + 7) >> 3; 8 * g < o1; g++) cmap[g] = (uint8_t)tid;
     }
     const int imin = PW > 1 ? (misc[0] < misc[2] ? misc[0] : misc[2]) : misc[0];
     const int imax = PW > 1 ? (misc[1] > misc[3] ? misc[1] : misc[3]) : misc[1];
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
         for (int q = tid; q < Q; q += WG_BLOCK, qi++) {
             int lo = 0, hi = nk;                           // largest kl with offs[kl] <= q
             if (BMAP) lo = (int)bmap[q];
-            else if (CMAP && A.cmap) { lo = (int)cmap[q >> 2]; while (lo + 1 < nk && offs[lo + 1] <= q) lo++; }
+            else if (CMAP && A.cmap) { lo = (int)cmap[q >> 3]; while (lo + 1 < nk && offs[lo + 1] <= q) lo++; }
             else while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
             const int i = ist[lo] + (q - offs[lo]);
             double acc = firstg ? 0.0 : accR[qi];

@@ -698,7 +698,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         // guard-free kernels: just the two lookup tables, sized to the pseudo count and the tile class; otherwise the general fast tables
         const size_t tabs = ks ? (size_t)(split ? rowsB : rowsA) * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
         return tabs + rows + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 32 +
-               (split ? 0 : (ti == 128 ? (size_t)ti * WG_NARROW_WMAX : (size_t)ti * WG_NARROW_WMAX / 4 + 16));      // (+ the block -> start map: a byte per block / per four blocks)
+               (split ? 0 : (ti == 128 ? (size_t)ti * WG_NARROW_WMAX : (size_t)ti * WG_NARROW_WMAX / 8 + 8));      // (+ the block -> start map: a byte per block / per eight blocks)
     };
     int TI = 64, NSA = 1, NSB = 1;
     static const int ti128_max_n = getenv("WGBSSEG_TI128_MAX_N") ? atoi(getenv("WGBSSEG_TI128_MAX_N")) : 16;
