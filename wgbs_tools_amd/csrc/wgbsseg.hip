@@ -715,7 +715,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
                 if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
                 const size_t l = lds_for(ti, false, ns);
                 if (l > 64 * 1024) continue;
-                const int wgs = (int)std::min<size_t>(5, (160 * 1024) / l);          // registers allow 5 workgroups per CU
+                const int wgs = (int)std::min<size_t>(5, (160 * 1024) / (size_t)round_up((int64_t)l, 1280));   // registers allow 5 workgroups per CU; LDS is handed out in granules of 1280 bytes
                 const double q = ti * std::min<double>(Favg, WA), eff = q / (256.0 * std::ceil(q / 256.0));
                 const double groups = std::ceil((double)Nsmp / ns);
                 const double score = wgs * eff / (1.0 + 0.02 * (groups - 1)) * (1.0 + 0.04 * (ti / 16));   // bias to big tiles (less staging)
@@ -730,7 +730,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
             if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
             const size_t l = lds_for(WG_WIDE_TS, true, ns);
             if (l > 64 * 1024) continue;
-            const int wgs = (int)std::min<size_t>(4, (160 * 1024) / l);      // 103 VGPRs: 4 workgroups per CU at most
+            const int wgs = (int)std::min<size_t>(4, (160 * 1024) / (size_t)round_up((int64_t)l, 1280));      // 103 VGPRs: 4 workgroups per CU at most
             const double groups = std::ceil((double)Nsmp / ns);
             const double score = wgs / (1.0 + 0.02 * (groups - 1));
             if (score > best) { best = score; NSB = ns; }
