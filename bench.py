@@ -55,7 +55,7 @@ def parse():
     ap.add_argument('--islands', action='store_true', help='add CpG islands to the synthetic loci (windows of several hundred sites; not the BASELINE workload)')
     ap.add_argument('--block-sums', action='store_true', help='also time the block reduction (beta_to_blocks / beta_to_table kernel) over the blocks just found')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target wall time of the CPU baseline sample (0: skip)')
-    ap.add_argument('--e2e', type=int, default=1, help='also time the CLI end to end on tmpfs files (1 GPU only; 0: skip)')
+    ap.add_argument('--e2e', type=int, default=1, help='also time the CLI end to end on page-cached files (1 GPU only; 0: skip)')
     return ap.parse_args()
 
 

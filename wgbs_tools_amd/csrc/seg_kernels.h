@@ -735,14 +735,15 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
     int32_t* ist = offs + (TI + 1);                                              // [TI] first end of start kl in this unit
     int32_t* misc = ist + TI;                                                    // [2 (+1 pad)]
-    // 128-start tiles (small cohorts: the per-block overhead is a larger share of the work): the start of every block of the
-    // tile as a byte map, filled once per tile, instead of a 7-step binary search in offs[] per block
-    constexpr bool BMAP = (TI == 128 && !SPLIT);
-    uint8_t* bmap = reinterpret_cast<uint8_t*>(misc + 8);                        // (BMAP) [TI * WG_NARROW_WMAX]
-    // narrow tiles of 64 starts or fewer have no LDS to spare for a byte per block (31.1 KB per workgroup: 25 LDS granules of
-    // 1280 bytes, five workgroups per CU; one granule more and it is four): a byte per EIGHT blocks — the start of block 8 g —
-    // and a step forward from there when needed (a start has ~20 blocks) instead of the 6-step binary search: 488 bytes
-    constexpr bool CMAP = (!SPLIT && TI <= 64);
+    // The start site of a block: a byte per EIGHT blocks — the start of block 8 g — and a step forward from there when needed (a
+    // start has ~20 blocks), instead of a 6-7-step binary search in offs[] per block.  Why not a byte per block (tried for the
+    // 128-start tiles: 7.7 KB) or per four: LDS is handed out in granules of 1280 bytes and a 64-start tile at 32 samples sits at
+    // 31.6 KB = 25 granules = five workgroups per CU; one granule more and it is four (-5 %).  For the 128-start tiles of small
+    // cohorts the coarse map frees a workgroup slot per CU (x 16: scoring 13.1 -> 12.0 ms).
+    constexpr bool BMAP = false;
+    uint8_t* bmap = reinterpret_cast<uint8_t*>(misc + 8);
+    uint8_t* cmap = bmap;                                                        // [TI * WG_NARROW_WMAX / 8 + 1]
+    constexpr bool CMAP = !SPLIT;
     uint8_t* cmap = bmap;                                                        // (CMAP) [TI * WG_NARROW_WMAX / 8 + 1]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;

@@ -698,7 +698,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         // guard-free kernels: just the two lookup tables, sized to the pseudo count and the tile class; otherwise the general fast tables
         const size_t tabs = ks ? (size_t)(split ? rowsB : rowsA) * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
         return tabs + rows + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 32 +
-               (split ? 0 : (ti == 128 ? (size_t)ti * WG_NARROW_WMAX : (size_t)ti * WG_NARROW_WMAX / 8 + 8));      // (+ the block -> start map: a byte per block / per eight blocks)
+               (split ? 0 : (size_t)ti * WG_NARROW_WMAX / 8 + 8);      // (+ the block -> start map: a byte per block / per eight blocks)
     };
     int TI = 64, NSA = 1, NSB = 1;
     static const int ti128_max_n = getenv("WGBSSEG_TI128_MAX_N") ? atoi(getenv("WGBSSEG_TI128_MAX_N")) : 16;
@@ -715,7 +715,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
                 if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
                 const size_t l = lds_for(ti, false, ns);
                 if (l > 64 * 1024) continue;
-                const int wgs = (int)std::min<size_t>(5, (160 * 1024) / (size_t)round_up((int64_t)l, 1280));   // registers allow 5 workgroups per CU; LDS is handed out in granules of 1280 bytes
+                const int wgs = (int)std::min<size_t>(ti == 128 ? 8 : 5, (160 * 1024) / (size_t)round_up((int64_t)l, 1280));   // registers allow 5 workgroups per CU; LDS is handed out in granules of 1280 bytes
                 const double q = ti * std::min<double>(Favg, WA), eff = q / (256.0 * std::ceil(q / 256.0));
                 const double groups = std::ceil((double)Nsmp / ns);
                 const double score = wgs * eff / (1.0 + 0.02 * (groups - 1)) * (1.0 + 0.04 * (ti / 16));   // bias to big tiles (less staging)
