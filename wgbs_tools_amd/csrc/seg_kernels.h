@@ -744,7 +744,6 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     uint8_t* bmap = reinterpret_cast<uint8_t*>(misc + 8);
     uint8_t* cmap = bmap;                                                        // [TI * WG_NARROW_WMAX / 8 + 1]
     constexpr bool CMAP = !SPLIT;
-    uint8_t* cmap = bmap;                                                        // (CMAP) [TI * WG_NARROW_WMAX / 8 + 1]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nC = J.n_chunks;
