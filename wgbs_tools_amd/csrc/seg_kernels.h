@@ -582,7 +582,7 @@ struct CostArgs {
     int32_t rows;      // guard-free kernels: exponents held by the two lookup tables (wg_lookup_rows for the longest block of the tile class)
     const wg_d2* tab;  // those tables, built by the host: rows * 16 log2f entries, then rows * 64 fast-log2 entries
     int32_t xcd_group; // consecutive tiles that go to one XCD before the next XCD's group begins (see k_cost)
-    int32_t cmap;      // 0: binary search for the start of a block even where the coarse map exists (WGBSSEG_NO_CMAP=1: A/B measurements)
+    int32_t cmap;      // log2 of the blocks per entry of the coarse block -> start map (3 or 4); 0: binary search instead (WGBSSEG_NO_CMAP=1: A/B measurements)
 };
 
 // Stage the exclusive prefixes P[A+x], x = x0 .. x0+cnt-1, of sample row `row` into dst[0..cnt) (one wavefront).
@@ -803,7 +803,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     }
     if (CMAP && tid < nk) {
         const int o0 = offs[tid], o1 = offs[tid + 1];
-        for (int g = (o0 + 7) >> 3; 8 * g < o1; g++) cmap[g] = (uint8_t)tid;
+        const int sh = A.cmap ? A.cmap : 3;
+        for (int g = (o0 + (1 << sh) - 1) >> sh; (g << sh) < o1; g++) cmap[g] = (uint8_t)tid;
     }
     const int imin = PW > 1 ? (misc[0] < misc[2] ? misc[0] : misc[2]) : misc[0];
     const int imax = PW > 1 ? (misc[1] > misc[3] ? misc[1] : misc[3]) : misc[1];
@@ -844,7 +845,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
         for (int q = tid; q < Q; q += WG_BLOCK, qi++) {
             int lo = 0, hi = nk;                           // largest kl with offs[kl] <= q
             if (BMAP) lo = (int)bmap[q];
-            else if (CMAP && A.cmap) { lo = (int)cmap[q >> 3]; while (lo + 1 < nk && offs[lo + 1] <= q) lo++; }
+            else if (CMAP && A.cmap) { lo = (int)cmap[q >> A.cmap]; while (lo + 1 < nk && offs[lo + 1] <= q) lo++; }
             else while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
             const int i = ist[lo] + (q - offs[lo]);
             double acc = firstg ? 0.0 : accR[qi];
