@@ -698,7 +698,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         // guard-free kernels: just the two lookup tables, sized to the pseudo count and the tile class; otherwise the general fast tables
         const size_t tabs = ks ? (size_t)(split ? rowsB : rowsA) * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
         return tabs + rows + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 32 +
-               (split ? 0 : (size_t)ti * WG_NARROW_WMAX / (ti == 128 ? 16 : 8) + 8);      // (128-start tiles: an entry per 16 blocks — at 8 samples that is the 144 bytes between six and seven workgroups per CU)      // (+ the block -> start map: a byte per block / per eight blocks)
+               (split ? 0 : (size_t)ti * WG_NARROW_WMAX / 8 + 8);      // (+ the coarse block -> start map; an entry per 16 blocks for the 128-start tiles would let a seventh workgroup onto the CU at 8 samples: measured, no gain)      // (+ the block -> start map: a byte per block / per eight blocks)
     };
     int TI = 64, NSA = 1, NSB = 1;
     static const int ti128_max_n = getenv("WGBSSEG_TI128_MAX_N") ? atoi(getenv("WGBSSEG_TI128_MAX_N")) : 16;
@@ -745,7 +745,6 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     caA.cmap = use_cmap ? 3 : 0;
     caB = caA;
     caA.NS = NSA; caA.rows = rowsA;
-    if (caA.cmap && TI == 128) caA.cmap = 4;
     caB.NS = NSB; caB.rows = rowsB;
     if (ks) {   // the k-scaled tables of both tile classes, built here once per call (same IEEE operations as on the device)
         static const wg_log_tables host_tabs = WG_LOG_TABLES_INIT;
