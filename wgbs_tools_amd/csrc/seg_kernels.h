@@ -1936,8 +1936,9 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
 // than a tile back are summed from memory by their lane (one or two per run; blocks longer than 1024 sites).
 // The general kernel above stays for .lbeta rows and for tables with nested / overlapping blocks.
 // ------------------------------------------------------------------------------------------------------------
-#define WG_BSR_TILE 1024
-#define WG_BSR_RUN 8
+#define WG_BSR_SPL 8                           // sites per lane of a tile: one 16-byte vector
+#define WG_BSR_TILE (64 * WG_BSR_SPL)
+#define WG_BSR_RUN 16
 #define WG_BSR_PK (WG_BSR_TILE + 16)          // packed in-lane prefixes of a tile (+ the entry behind its last site)
 
 // trunc(fl(fl(m / c) * 255)) — utils_wgbs.py:277-290 in float64 — without a float64 division on the common path: with
@@ -1993,16 +1994,19 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_direct(const uint8_t* _
     }
 }
 
-#define WG_BSR_PRE 3                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
+#define WG_BSR_PRE 2                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
 #define WG_BSR_RING (2 * WG_BSR_TILE)
-#define WG_BSR_AHEAD 4                         // tiles of sample bytes in flight per wavefront (2 KB each)
+#define WG_BSR_AHEAD 6                         // tiles of sample bytes in flight per wavefront (1 KB each)
 
 // LDS layout of the prefix ring: ring position q = (half, site x of the tile); the four sites 4 g .. 4 g + 3 of lane L (x = 16 L +
 // 4 g + k) sit at dwords (g * 64 + L) * 4 + k of their half: consecutive lanes write consecutive 16-byte slots (no bank
 // conflicts; lane-major rows of 16 dwords are 16-way conflicts).
 __host__ __device__ __forceinline__ uint32_t wg_bsr_pk_at(uint32_t q)
 {
-    return (q & ~(uint32_t)(WG_BSR_TILE - 1)) | ((q & 12u) << 6) | ((q >> 2) & 0xfcu) | (q & 3u);
+    // x = SPL L + 4 g + k  ->  (g * 64 + L) * 4 + k
+    constexpr uint32_t GM = (WG_BSR_SPL / 4 - 1) << 2;           // the bits of g in x
+    constexpr int LS = WG_BSR_SPL == 16 ? 4 : 3;                  // log2(SPL)
+    return (q & ~(uint32_t)(WG_BSR_TILE - 1)) | ((q & GM) << 6) | (((q & (WG_BSR_TILE - 1)) >> LS) << 2) | (q & 3u);
 }
 
 // k_block_sums_prep: what the streaming kernel needs to know about a block depends on the table alone, so it is worked out once
@@ -2023,8 +2027,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_prep(const int32_t* __r
     const int lo = (int)(t * WG_BSR_TILE);
     const uint32_t q1 = (uint32_t)(h * WG_BSR_TILE + (x1 - 1 - lo)) & (WG_BSR_RING - 1), q0 = (uint32_t)(h * WG_BSR_TILE + (x0 - 1 - lo)) & (WG_BSR_RING - 1);
     const bool reach = x1 <= x0 || (i == 0 ? x0 >= lo : x0 >= lo - (WG_BSR_TILE - 1));
-    d1[b] = (int32_t)((wg_bsr_pk_at(q1) * 4u) | (((q1 >> 4) * 8u) << 16));
-    d0[b] = (int32_t)((wg_bsr_pk_at(q0) * 4u) | (((q0 >> 4) * 8u) << 16));
+    d1[b] = (int32_t)((wg_bsr_pk_at(q1) * 4u) | (((q1 / WG_BSR_SPL) * 8u) << 16));
+    d0[b] = (int32_t)((wg_bsr_pk_at(q0) * 4u) | (((q0 / WG_BSR_SPL) * 8u) << 16));
     rr[b] = reach ? (perm ? perm[b] : (int32_t)b) : -1;
 }
 
@@ -2040,7 +2044,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
                                                              void* __restrict__ out)
 {
     __shared__ __attribute__((aligned(16))) uint32_t PKs[WG_BLOCK / 64][WG_BSR_RING];      // packed (meth | cov << 16) INCLUSIVE prefixes inside a lane's 16 sites
-    __shared__ uint2 BASEs[WG_BLOCK / 64][WG_BSR_RING / 16];                                // the run's totals before each lane's 16 sites
+    __shared__ uint2 BASEs[WG_BLOCK / 64][WG_BSR_RING / WG_BSR_SPL];                        // the run's totals before each lane's sites
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int s = (int)blockIdx.y * (WG_BLOCK / 64) + wv;
@@ -2065,10 +2069,11 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
     // one (readable: the pitch is a multiple of 16 bytes) — it only feeds prefixes behind every block's last site.  The last
     // vector itself may hold sites beyond n_total: bytes of the row's padding, which no block reaches either.
     auto load = [&](int i, uint4& a, uint4& b) {                   // (a tile behind the run's last: that one again — no branch, nobody uses it)
-        const uint32_t v = ((site0 + (uint32_t)(i < nt ? i : nt - 1) * WG_BSR_TILE) >> 3) + 2u * (uint32_t)lane;
+        constexpr uint32_t VPL = WG_BSR_SPL / 8;                   // 16-byte vectors per lane
+        const uint32_t v = ((site0 + (uint32_t)(i < nt ? i : nt - 1) * WG_BSR_TILE) >> 3) + VPL * (uint32_t)lane;
         const uint4* rv = reinterpret_cast<const uint4*>(row);
         a = rv[v < last_vec ? v : last_vec];
-        b = rv[v + 1u < last_vec ? v + 1u : last_vec];
+        if (VPL > 1) b = rv[v + 1u < last_vec ? v + 1u : last_vec]; else b = a;
     };
     struct Desc { int32_t d1[WG_BSR_PRE], d0[WG_BSR_PRE], r[WG_BSR_PRE]; };
     auto descriptors = [&](int i, Desc& D) {                       // the first 64 x WG_BSR_PRE blocks resolved in tile i of the run
@@ -2086,18 +2091,18 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
     uint32_t run_m = 0, run_c = 0;                                 // totals of the run's sites before the current tile
     auto stage = [&](int h, const uint4& c0, const uint4& c1) {
         const uint32_t w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        uint32_t e[16], acc = 0;                                   // packed inclusive prefixes inside the lane (16 x 255 fits 16 bits)
+        uint32_t e[WG_BSR_SPL], acc = 0;                          // packed inclusive prefixes inside the lane (16 x 255 fits 16 bits)
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < WG_BSR_SPL; j++) {
             acc += __builtin_amdgcn_perm(0u, w[j >> 1], (j & 1) ? 0x0c030c02u : 0x0c010c00u);     // site j as (meth | cov << 16)
             e[j] = acc;
         }
         const uint32_t tm = acc & 0xffffu, tc = acc >> 16;
         const uint32_t im = wg_wave_incl_scan_dpp_u32(tm), ic = wg_wave_incl_scan_dpp_u32(tc);
-        BASE[h * (WG_BSR_TILE / 16) + lane] = make_uint2(run_m + (im - tm), run_c + (ic - tc));
+        BASE[h * 64 + lane] = make_uint2(run_m + (im - tm), run_c + (ic - tc));
         uint4* dst = reinterpret_cast<uint4*>(PK + h * WG_BSR_TILE) + lane;
 #pragma unroll
-        for (int j = 0; j < 16; j += 4) dst[(j >> 2) * 64] = make_uint4(e[j], e[j + 1], e[j + 2], e[j + 3]);
+        for (int j = 0; j < WG_BSR_SPL; j += 4) dst[(j >> 2) * 64] = make_uint4(e[j], e[j + 1], e[j + 2], e[j + 3]);
         run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
         run_c += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
     };
@@ -2127,7 +2132,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
         for (int b = __builtin_amdgcn_readlane(efv, i) + 64 * WG_BSR_PRE + lane; b < b1; b += 64) { const int r = rrs[b]; if (r >= 0) one(d1s[b], d0s[b], r); }
     };
 
-    if (lane == 0) { PK[WG_BSR_RING - 1] = 0u; BASE[WG_BSR_RING / 16 - 1] = make_uint2(0u, 0u); }      // I(-1) of the run: the entry "before" tile 0
+    if (lane == 0) { PK[WG_BSR_RING - 1] = 0u; BASE[WG_BSR_RING / WG_BSR_SPL - 1] = make_uint2(0u, 0u); }      // I(-1) of the run: the entry "before" tile 0
     constexpr int AHEAD = WG_BSR_AHEAD;                            // tiles in flight behind the one being staged
     uint4 va[AHEAD + 1], vb[AHEAD + 1];                            // tile i in set i mod (AHEAD + 1)
     Desc D[2];                                                     // descriptors of tile i in set i mod 2
