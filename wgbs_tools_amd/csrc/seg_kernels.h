@@ -1936,9 +1936,11 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
 // than a tile back are summed from memory by their lane (one or two per run; blocks longer than 1024 sites).
 // The general kernel above stays for .lbeta rows and for tables with nested / overlapping blocks.
 // ------------------------------------------------------------------------------------------------------------
-#define WG_BSR_SPL 8                           // sites per lane of a tile: one 16-byte vector
+#define WG_BSR_SPL 16                          // sites per lane of a tile: two 16-byte vectors.  (8 = 512-site tiles, runs of 16: 68 VGPRs and 20 KB of
+                                               // LDS per workgroup, i.e. 28 instead of 16 resident wavefronts per CU — measured 0.467 vs 0.434-0.455 ms: the
+                                               // pass is instruction-bound, and the per-tile work is spread over half the sites)
 #define WG_BSR_TILE (64 * WG_BSR_SPL)
-#define WG_BSR_RUN 16
+#define WG_BSR_RUN 8
 #define WG_BSR_PK (WG_BSR_TILE + 16)          // packed in-lane prefixes of a tile (+ the entry behind its last site)
 
 // trunc(fl(fl(m / c) * 255)) — utils_wgbs.py:277-290 in float64 — without a float64 division on the common path: with
@@ -1994,9 +1996,9 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_direct(const uint8_t* _
     }
 }
 
-#define WG_BSR_PRE 2                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
+#define WG_BSR_PRE 3                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
 #define WG_BSR_RING (2 * WG_BSR_TILE)
-#define WG_BSR_AHEAD 6                         // tiles of sample bytes in flight per wavefront (1 KB each)
+#define WG_BSR_AHEAD 4                         // tiles of sample bytes in flight per wavefront (2 KB each)
 
 // LDS layout of the prefix ring: ring position q = (half, site x of the tile); the four sites 4 g .. 4 g + 3 of lane L (x = 16 L +
 // 4 g + k) sit at dwords (g * 64 + L) * 4 + k of their half: consecutive lanes write consecutive 16-byte slots (no bank
