@@ -202,6 +202,33 @@ def test_region_and_sites_parsing(synth_world):
     assert whole.sites == (s3 + 1, s3 + synth_world['sizes'][2] + 1)
 
 
+def test_array_id_parsing(synth_world, tmp_path):
+    """--array_id cgNNNN -> the CpG index in the genome's ilmn2CpG.tsv.gz (genomic_region.py:212-232): whole-word match like
+    `grep -w`, second column, exactly one hit; the reference's messages otherwise."""
+    import argparse
+    import gzip
+    import shutil
+    ref = tmp_path / 'references' / 'synth_ilmn'
+    shutil.copytree(synth_world['refdir'], ref)
+    gen = G.GenomeRefPaths(str(ref))
+    with pytest.raises(G.IllegalArgumentError, match='Could not find Illumina map file'):
+        G.GenomicRegion(args=argparse.Namespace(genome=str(ref), sites=None, region=None, array_id='cg00000029'), genome=gen)
+    with gzip.open(ref / 'ilmn2CpG.tsv.gz', 'wt') as f:
+        f.write('cg00000029\t1234\t450K\ncg000000290\t77\t850K\ncg00000108\t5\t450K\ncg00000108\t6\t850K\nch.1.1\t9\t450K\ncg99999999\tNA\t450K\n')
+    gen = G.GenomeRefPaths(str(ref))
+    assert gen.ilmn2cpg_dict == str(ref / 'ilmn2CpG.tsv.gz')
+    ns = lambda i: argparse.Namespace(genome=str(ref), sites=None, region=None, array_id=i)
+    gr = G.GenomicRegion(args=ns('cg00000029'), genome=gen)                     # not cg000000290
+    assert gr.sites == (1234, 1235) and gr.chrom == 'chr1'
+    assert gr.sites == G.GenomicRegion(sites='1234', genome=gen).sites and gr.region_str == G.GenomicRegion(sites='1234', genome=gen).region_str
+    for bad in ('ch.1.1', 'cg', 'cgx12', '00000029'):
+        with pytest.raises(G.IllegalArgumentError, match='Invalid Illumina array ID'):
+            G.GenomicRegion(args=ns(bad), genome=gen)
+    for bad in ('cg00000108', 'cg12345678', 'cg99999999'):                      # two hits, none, not a number
+        with pytest.raises(G.IllegalArgumentError, match='Failed retrieving locus for site ' + bad):
+            G.GenomicRegion(args=ns(bad), genome=gen)
+
+
 def test_bed_writer_reproduces_reference_fixture(tmp_path):
     """Byte-identity with the reference's own golden BED (tests/data/segment/chr19_100k_500k.blocks.bed) given a
     loci table consistent with it: pins the add_loci formula and the text format."""

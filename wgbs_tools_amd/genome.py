@@ -48,6 +48,7 @@ class GenomeRefPaths:
         self.chrom_cpg_sizes = self.join('CpG.chrome.size')
         self.chrom_sizes = self.join('chrome.size')
         self.revdict_path = self.join('rev.CpG.bed.gz', validate=False)
+        self.ilmn2cpg_dict = self.join('ilmn2CpG.tsv.gz', validate=False)        # utils_wgbs.py:67
         self._names = None
         self._sizes = None
         self._bp_sizes = None
@@ -167,8 +168,7 @@ def beta_sanity_check(beta_path, genome):
 
 
 class GenomicRegion:
-    """The subset of genomic_region.py:23-247 that `segment` uses: -s/--sites and -r/--region (no --array_id:
-    it needs the Illumina map file and is outside the segment hot path)."""
+    """The subset of genomic_region.py:23-247 that `segment` / `convert` use: -s/--sites, -r/--region and --array_id."""
 
     def __init__(self, args=None, region=None, sites=None, genome=None):
         self.chrom = None
@@ -182,7 +182,7 @@ class GenomicRegion:
             elif getattr(args, 'region', None):
                 self.parse_region(args.region)
             elif getattr(args, 'array_id', None):
-                raise IllegalArgumentError('--array_id is not supported by this implementation of segment')
+                self.parse_array_id(args.array_id)
         else:
             self.genome = genome
             if region is not None:
@@ -195,6 +195,30 @@ class GenomicRegion:
 
     def is_whole(self):
         return self.sites is None
+
+    def parse_array_id(self, array_id):
+        """--array_id cg00001755: the CpG index of an Illumina array probe, from the genome's map file (genomic_region.py:212-232:
+        `gunzip -c ilmn2CpG.tsv.gz | grep -w <id> | cut -f2`, which must come out as ONE integer)."""
+        import gzip
+        if not (array_id.startswith('cg') and len(array_id) > 2 and array_id[2:].isdigit()):
+            eprint(f'ERROR: Invalid Illumina array id: {array_id}')
+            raise IllegalArgumentError('Invalid Illumina array ID')
+        idict = self.genome.ilmn2cpg_dict
+        if idict is None or not op.isfile(idict):
+            raise IllegalArgumentError(f'Could not find Illumina map file: {idict}')
+        word = re.compile(r'(?<![A-Za-z0-9_])' + re.escape(array_id) + r'(?![A-Za-z0-9_])')      # grep -w
+        hits = []
+        with gzip.open(idict, 'rt') as f:
+            for line in f:
+                if word.search(line):
+                    fields = line.rstrip('\n').split('\t')
+                    hits.append(fields[1] if len(fields) > 1 else line.rstrip('\n'))       # cut -f2 (a line without a tab passes whole)
+        try:
+            cpg_ind = int('\n'.join(hits).strip())
+        except ValueError as e:
+            cmd = f'gunzip -c {idict} | grep -w {array_id} | cut -f2'
+            raise IllegalArgumentError(f'Failed retrieving locus for site {array_id} with command:\n{cmd}\n{e}')
+        self.parse_sites(str(cpg_ind))
 
     def __str__(self):                                            # genomic_region.py:239-247 (no annotation tracks here)
         if self.sites is None:
