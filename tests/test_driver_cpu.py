@@ -126,6 +126,26 @@ def test_driver_matches_reference_driver(name, driver_golden, synth_world, tmp_p
         assert int(r[1]) == loci[s - 1] and int(r[2]) == loci[e - 2] + 1 and int(r[1]) < int(r[2]) and s < e
 
 
+def test_stats_report(driver_golden, synth_world, tmp_path):
+    """--stats PATH: a JSON report of the run (the reference only has its stderr lines); the stderr text is unchanged by it."""
+    import json
+    g = driver_golden['cases']['wg_c60000_min3']
+    out_path, stats_path = str(tmp_path / 'out.bed'), str(tmp_path / 'run.json')
+    args = make_args(synth_world, out_path, stats=stats_path, **dict(g['args']))
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        sbc = S.SegmentByChunks(args, synth_world['paths'], engine=OracleEngine(synth_world['betas'], synth_world['loci']))
+        sbc.break_to_chunks()
+        sbc.run()
+    assert err.getvalue() == g['stderr']
+    rep = json.load(open(stats_path))
+    n_rows = sum(1 for _ in open(out_path))
+    assert rep['tool'] == 'wgbstools segment' and rep['blocks_found'] == g['n_blocks'] == n_rows and rep['blocks_dropped'] >= 0
+    assert rep['chunks'] == len(g['chunks']['starts']) and rep['sites'] == sum(e - s for s, e in zip(g['chunks']['starts'], g['chunks']['ends']))
+    assert rep['parameters']['min_cpg'] == 3 and rep['parameters']['betas'] == len(synth_world['paths']) and rep['out_path'] == out_path
+    assert rep['wall_s'] > 0 and set(rep['phases_s']) >= {'segmentation (device + stitching)', 'blocks to BED'}
+
+
 def test_stitch_helpers_match_reference(driver_golden):
     for rec in driver_golden['funcs']:
         b1, b2 = np.array(rec['b1']), np.array(rec['b2'])

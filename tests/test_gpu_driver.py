@@ -234,3 +234,21 @@ def test_two_contexts_on_two_host_threads_share_the_stitching_pool():
     finally:
         for sg in segs:
             sg.close()
+
+
+@pytest.mark.parametrize('gpus', [1, 3])
+def test_cli_stats_report(gpus, driver_golden, world, tmp_path):
+    """--stats: the JSON report of a run on the device (engine, chunks, junction patches, batches, blocks, phases, device timings of
+    every share)."""
+    g = driver_golden['cases']['wg_c20000']
+    out, rep_path = str(tmp_path / 'blocks.bed'), str(tmp_path / 'run.json')
+    argv = ['wgbstools', 'segment', '--betas'] + world['paths'] + ['--genome', world['refdir'], '-o', out, '-c', str(g['args']['chunk_size']),
+                                                                     '--gpus', str(gpus), '--stats', rep_path]
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        assert wgbs_tools.main(argv) == 0, err.getvalue()
+    rep = json.load(open(rep_path))
+    assert rep['engine'] in ('HipEngine', 'GroupEngine') and rep['blocks_found'] == g['n_blocks'] == sum(1 for _ in open(out))
+    assert rep['chunks'] == len(g['chunks']['starts']) == rep['stitching']['chunks'] and rep['stitching']['batches'] >= 1
+    assert len(rep['device']) in (1, gpus) and all(d['cost_ms'] >= 0 and d['sites'] >= 0 for d in rep['device'])
+    assert sum(d['evals'] for d in rep['device']) > 0 and rep['wall_s'] > 0

@@ -314,9 +314,12 @@ class SegmentByChunks:
         own_engine = self.param_dict['engine'] is None
         if world > 1:
             return self.run_sharded(rank, world, local)
-        prof = [('start', time.perf_counter())] if os.environ.get('WGBSSEG_PROFILE') else None
+        want_stats = bool(getattr(self.args, 'stats', None))
+        prof = [('start', time.perf_counter())] if (os.environ.get('WGBSSEG_PROFILE') or want_stats) else None
+        self.report = {'regions': len(self.regions()), 'chunks': len(starts), 'sites': int(sum(e - s for s, e in zip(starts, ends)))}
         if not starts:                                           # nothing to segment (e.g. an -L file of empty rows)
             self.dump_result(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+            self.write_stats(prof)
             return
         if own_engine:
             self.param_dict['engine'] = self.make_engine(starts, ends)
@@ -337,6 +340,11 @@ class SegmentByChunks:
                     eng = self.param_dict['engine'] = self.make_engine(starts, ends, gpus=1)
                     res = eng.segment_regions(regs, self.args.chunk_size, self.param_dict)
                 merged = dict(zip([f'{a}-{b}' for a, b in regs], res))
+                if want_stats:                                   # (before the engine goes away)
+                    self.report['engine'] = type(eng).__name__
+                    self.report['stitching'] = getattr(eng, 'last_stats', None)
+                    tm = eng.timings() if hasattr(eng, 'timings') else None
+                    self.report['device'] = tm if isinstance(tm, list) else ([tm] if tm else None)
             else:
                 arr = eng.segment_many(list(zip(starts, ends)), self.param_dict)
                 # merge chunks from the same "tag" group (segment.py:148-154); all groups advance round by round together
@@ -361,7 +369,30 @@ class SegmentByChunks:
                 closer.join()
         if prof:
             prof.append(('blocks to BED', time.perf_counter()))
-            eprint('[wt segment] phases: ' + ', '.join('%s %.3f s' % (n, t - prof[i][1]) for i, (n, t) in enumerate(prof[1:])))
+            if os.environ.get('WGBSSEG_PROFILE'):
+                eprint('[wt segment] phases: ' + ', '.join('%s %.3f s' % (n, t - prof[i][1]) for i, (n, t) in enumerate(prof[1:])))
+        self.write_stats(prof)
+
+    def write_stats(self, prof):
+        """--stats PATH: one JSON object about the run (the reference only has its stderr lines)."""
+        path = getattr(self.args, 'stats', None)
+        if not path:
+            return
+        import json
+        from . import wgbs_tools
+        a = self.args
+        rep = {'tool': 'wgbstools segment', 'version': wgbs_tools.VERSION,
+               'parameters': {'betas': len(self.betas), 'genome': self.genome.genome, 'chunk_size': a.chunk_size, 'pcount': a.pcount,
+                              'min_cpg': a.min_cpg, 'max_cpg': self.param_dict['max_cpg'], 'max_bp': a.max_bp,
+                              'region': a.region, 'sites': a.sites, 'bed_file': a.bed_file},
+               'out_path': None if a.out_path is sys.stdout else str(a.out_path)}
+        rep.update(getattr(self, 'report', {}))
+        if prof and len(prof) > 1:
+            rep['phases_s'] = {n: round(t - prof[i][1], 6) for i, (n, t) in enumerate(prof[1:])}
+            rep['wall_s'] = round(prof[-1][1] - prof[0][1], 6)
+        with open(path, 'w') as f:
+            json.dump(rep, f, indent=1, default=lambda o: int(o) if isinstance(o, np.integer) else float(o) if isinstance(o, np.floating) else str(o))
+            f.write('\n')
 
     def make_engine(self, starts, ends, gpus=None):
         """--gpus N (default: every visible GPU): a region list a share group can plan over (ascending, disjoint: every
@@ -478,6 +509,8 @@ class SegmentByChunks:
         nr_dropped = nr_blocks - nr_blocks_filt
         eprint(f'[wt segment] found {nr_blocks_filt:,} blocks\n'
                f'             (dropped {nr_dropped:,} short blocks)')
+        if hasattr(self, 'report'):
+            self.report.update(blocks_found=int(nr_blocks_filt), blocks_dropped=int(nr_dropped))
         write_bed(self.genome, s, e, self.args.out_path)
 
 
@@ -580,6 +613,9 @@ def parse_args(argv=None):
     parser.add_argument('--gpus', type=int, default=0,
                         help='Number of GPUs to spread the chunks over from this one process (the role of -@ in the '
                              'CPU implementation). Default: all visible GPUs')
+    parser.add_argument('--stats', metavar='JSON_PATH',
+                        help='Write a JSON report of the run: parameters, regions, chunks, junction patches, GPU batches, '
+                             'blocks found / dropped, wall-clock phases and device timings')
     return parser.parse_args(argv)
 
 
