@@ -1229,9 +1229,61 @@ __device__ __forceinline__ void wg_dp_group64(double& best, int32_t& arg, uint32
             : "v6", "v7", "s22", "vcc");
 }
 
+// The same eight steps for a job whose windows are all <= 60 sites (WG_NARROW_WMAX: every default-parameter genome): 6.75
+// instead of 10 VALU instructions per step.  A row k then reaches at most step k + 59, so the lane a step has finished in
+// sees no candidate for the next FIVE steps, and the bookkeeping of a finished lane need not follow it step by step: the four
+// lanes of steps g .. g+3 hand their arg to tbk with ONE v_cndmask after step g+3 and are re-armed with -inf by two more during
+// step g+4 (their next candidate can arrive with step g+5 at the earliest; until then their rows hold -inf, which neither
+// max nor the strict compare lets through).  Per step: A C X D Rlo Rhi; the two instruction slots the wait-state rule puts
+// between Rhi and the next A (VALU-written SGPR -> VALU reading it: 2 apart) carry the batched work, the scalar moves of the
+// lane masks, or an s_nop.  Registers as above, plus the lane mask of the last four finished lanes in s[24:25] (carried from
+// block to block: the re-arm of a block's last four lanes is the first thing the next block does; the batch's last four are
+// re-armed by the caller) and -inf's high word in every lane of v40.
+#define WG_DP64L_CORE(CV, P)                            \
+    "v_add_f64 v[6:7], s[20:21], " CV "\n"              \
+    "v_cmp_gt_f64 vcc, v[6:7], v[2:3]\n"                \
+    "v_max_f64 v[2:3], v[2:3], v[6:7]\n"                \
+    "v_cndmask_b32_e64 v4, v4, %[" P "], vcc\n"         \
+    "v_readlane_b32 s20, v2, %[" P "]\n"                \
+    "v_readlane_b32 s21, v3, %[" P "]\n"
+#define WG_DP64L_REARM "v_cndmask_b32_e64 v2, v2, 0, s[24:25]\n" "v_cndmask_b32_e64 v3, v3, v40, s[24:25]\n"
+#define WG_DP64L_CAPT  "v_cndmask_b32_e64 v5, v5, v4, s[24:25]\n" "s_nop 0\n"
+#define WG_DP64L_MASK(LO, HI) "s_mov_b32 s24, %[" LO "]\n" "s_mov_b32 s25, %[" HI "]\n"
+#define WG_DP64L_BLOCK(R0, R1, R2, R3, R4, R5, R6, R7, FIRST)                                             \
+            WG_DP64L_CORE(R0, "p0") FIRST                                                                  \
+            WG_DP64L_CORE(R1, "p1") "s_nop 1\n"                                                            \
+            WG_DP64L_CORE(R2, "p2") WG_DP64L_MASK("ml0", "mh0")                                            \
+            WG_DP64L_CORE(R3, "p3") WG_DP64L_CAPT                                                          \
+            WG_DP64L_CORE(R4, "p4") WG_DP64L_REARM                                                         \
+            WG_DP64L_CORE(R5, "p5") "s_nop 1\n"                                                            \
+            WG_DP64L_CORE(R6, "p6") WG_DP64L_MASK("ml1", "mh1")                                            \
+            WG_DP64L_CORE(R7, "p7") WG_DP64L_CAPT
+#define WG_DP64L_OPERANDS(V0, V1, V2, V3, V4, V5, V6, V7)                                                  \
+            : "+{v[2:3]}"(best), "+{v4}"(arg), "+{v5}"(tbk), "+{s[20:21]}"(Mk), "+{s[24:25]}"(mask)        \
+            : V0(cur[0]), V1(cur[1]), V2(cur[2]), V3(cur[3]), V4(cur[4]), V5(cur[5]), V6(cur[6]), V7(cur[7]), "{v40}"(ninf_splat), \
+              [p0] "n"(G + 0), [p1] "n"(G + 1), [p2] "n"(G + 2), [p3] "n"(G + 3), [p4] "n"(G + 4), [p5] "n"(G + 5), [p6] "n"(G + 6), [p7] "n"(G + 7), \
+              [ml0] "n"((int)(uint32_t)(0xfull << G)), [mh0] "n"((int)(uint32_t)((0xfull << G) >> 32)),   \
+              [ml1] "n"((int)(uint32_t)(0xfull << (G + 4))), [mh1] "n"((int)(uint32_t)((0xfull << (G + 4)) >> 32)) \
+            : "v6", "v7", "vcc"
+
+template <int G, int SET>
+__device__ __forceinline__ void wg_dp_group64_lean(double& best, int32_t& arg, uint32_t& tbk, double& Mk, uint64_t& mask, const double (&cur)[8],
+                                                   const uint32_t ninf_splat)
+{
+    if (SET == 0) {
+        if (G == 0) asm volatile(WG_DP64L_BLOCK("v[8:9]", "v[10:11]", "v[12:13]", "v[14:15]", "v[16:17]", "v[18:19]", "v[20:21]", "v[22:23]", "s_nop 1\n")
+                                 WG_DP64L_OPERANDS("{v[8:9]}", "{v[10:11]}", "{v[12:13]}", "{v[14:15]}", "{v[16:17]}", "{v[18:19]}", "{v[20:21]}", "{v[22:23]}"));
+        else        asm volatile(WG_DP64L_BLOCK("v[8:9]", "v[10:11]", "v[12:13]", "v[14:15]", "v[16:17]", "v[18:19]", "v[20:21]", "v[22:23]", WG_DP64L_REARM)
+                                 WG_DP64L_OPERANDS("{v[8:9]}", "{v[10:11]}", "{v[12:13]}", "{v[14:15]}", "{v[16:17]}", "{v[18:19]}", "{v[20:21]}", "{v[22:23]}"));
+    } else {
+        asm volatile(WG_DP64L_BLOCK("v[24:25]", "v[26:27]", "v[28:29]", "v[30:31]", "v[32:33]", "v[34:35]", "v[36:37]", "v[38:39]", WG_DP64L_REARM)
+                     WG_DP64L_OPERANDS("{v[24:25]}", "{v[26:27]}", "{v[28:29]}", "{v[30:31]}", "{v[32:33]}", "{v[34:35]}", "{v[36:37]}", "{v[38:39]}"));
+    }
+}
+
 // state kept per chunk in global memory: [0] M[k] of the next step, [1..64] best, [65..128] arg, [129..192] bestB,
 // [193..256] argB (args as doubles' bits) — written only between stages — then the ring: ringN doubles, ringN int32
-template <int NW, int BL>
+template <int NW, int BL, bool LEAN = false>      // LEAN (BL == 64 only): every window of the job is <= WG_NARROW_WMAX sites
 __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
                                                       double* __restrict__ state, int64_t state_stride)
 {
@@ -1376,15 +1428,19 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
                     double ra[8], rb[8];                  // the rows of two consecutive groups of 8 steps (register sets 0 and 1)
 #pragma unroll
                     for (int u = 0; u < 8; u++) ra[u] = my[u * 64];
+                    uint64_t lmask = 0;                   // (LEAN) lane mask of the last four finished lanes, carried between the blocks
 #define WG_DP_PAIR64(G)                                                                                   \
                     _Pragma("unroll") for (int u = 0; u < 8; u++) rb[u] = my[((G) + 8 + u) * 64];         \
-                    wg_dp_group64<(G), 0>(best, arg, tbk, Ms, ra, ninf_hi);                               \
+                    if (LEAN) wg_dp_group64_lean<(G), 0>(best, arg, tbk, Ms, lmask, ra, ninf_hi);         \
+                    else wg_dp_group64<(G), 0>(best, arg, tbk, Ms, ra, ninf_hi);                          \
                     if ((G) + 16 < 64) {                                                                  \
                         _Pragma("unroll") for (int u = 0; u < 8; u++) ra[u] = my[((G) + 16 + u) * 64];    \
                     }                                                                                     \
-                    wg_dp_group64<(G) + 8, 1>(best, arg, tbk, Ms, rb, ninf_hi);
+                    if (LEAN) wg_dp_group64_lean<(G) + 8, 1>(best, arg, tbk, Ms, lmask, rb, ninf_hi);     \
+                    else wg_dp_group64<(G) + 8, 1>(best, arg, tbk, Ms, rb, ninf_hi);
                     WG_DP_PAIR64(0) WG_DP_PAIR64(16) WG_DP_PAIR64(32) WG_DP_PAIR64(48)
 #undef WG_DP_PAIR64
+                    if (LEAN) best = lane >= 60 ? NEG_INF : best;     // the batch's last four finished lanes (the blocks re-arm the others)
                     Mk = Ms;
                     tbk = (((uint32_t)lane - tbk) & 63u) + 1u;        // source lane -> length of the best block ending here
                 } else if (stp0 == 0) {
