@@ -1390,7 +1390,9 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
             if (WIDEJOB && b >= 1 && fm_prev > 128u)
                 wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, base - BL, s1, Mring, pendB, pendA, rmask, lane, lw);
             // (Tried for the 64-step batches: a second register set so that rows are loaded THREE batches ahead — two batch times to
-            // land instead of one.  137 VGPRs, i.e. one workgroup per CU instead of two, or 128 with spills: 1.75 -> 3.0 ms.)
+            // land instead of one.  Seven workers: 137 VGPRs, i.e. one workgroup per CU instead of two, or 128 with spills: 1.75 -> 3.0 ms.
+            // Eight workers (8 rows each, 119 VGPRs): nine wavefronts per workgroup put three on one SIMD, and two such workgroups
+            // no longer fit a CU's register files: 1.64 -> 2.9 ms.)
             if (b + 1 < nb)
                 wg_dp_rows_commit<NW, BL>(rows, slots + (size_t)((b + 1) & 1) * SLOT, slots + (size_t)((b + 1) & 1) * SLOT + BL * 64,
                                           kinds + ((b + 1) & 1), lane, lw);
