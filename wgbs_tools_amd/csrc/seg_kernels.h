@@ -1366,9 +1366,17 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     }
     __syncthreads();
 
-    for (int b = 0; b < nb; b++) {
+    // Two loops, one per role, with the same barriers: inside ONE loop with a branch the register allocator has to keep the workers'
+    // rows and the recurrence's state alive side by side (a wavefront only ever runs one side, but that is not visible to it).
+    // LDS is all that must be settled at a barrier.  Global memory: nobody in the workgroup reads what the recurrence wave stores; a
+    // ring entry is only ever updated by its owner wave, and fetched (by worker 0) no sooner than two barriers after its last update
+    // — by then the updating wave has waited for loads it issued after that store (the row loads that end every batch), and vector
+    // memory operations of a wave complete in order.  Waiting for store latency there, every 32 steps, would cost more than the steps.
+#define WG_DP_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    if (worker) {
+      for (int b = 0; b < nb; b++) {
         const int base = s0 + b * BL;
-        if (worker) {
+        {
             // Everything a worker loads it consumes a full batch later.  Order of the batch: (1) ring entries of the next
             // batch's steps: loads, and the reset store right behind them (the memory pipeline keeps a wave's accesses
             // to one address in order); (2) meta ring refill; (3) pushes of the blocks > 128 sites of batch b-1;
@@ -1406,7 +1414,13 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
                 fm_n2 = rows.fmax;
             }
             fm_prev = fm_cur; fm_cur = fm_n1; fm_n1 = fm_n2;
-        } else {
+        }
+        WG_DP_BARRIER;
+      }
+    } else {
+      for (int b = 0; b < nb; b++) {
+        const int base = s0 + b * BL;
+        {
             const double* slot = slots + (size_t)(b & 1) * SLOT;
             const bool wideb = WIDEJOB && kinds[b & 1] != 0u;
             const int stp0 = WIDEJOB ? (base & 63) : 0;          // lane of the batch's first step
@@ -1463,13 +1477,10 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
             }
             if (fin && base + d < s1) J.back16[cd.site_off + base + d] = (uint16_t)tbk;
         }
-        // LDS is all that must be settled at the barrier.  Global memory: nobody in the workgroup reads what the
-        // recurrence wave stores; a ring entry is only ever updated by its owner wave, and fetched (by worker 0) no
-        // sooner than two barriers after its last update — by then the updating wave has waited for loads it issued
-        // after that store (the row loads that end every batch), and vector memory operations of a wave complete in
-        // order.  Waiting for store latency here, every 32 steps, would cost more than the steps themselves.
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        WG_DP_BARRIER;
+      }
     }
+#undef WG_DP_BARRIER
     if (WIDEJOB && worker && fm_prev > 128u)
         wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, s0 + (nb - 1) * BL, s1, Mring, pendB, pendA, rmask, lane, lw);
     if (!worker && s1 < cd.len) {
