@@ -1283,7 +1283,7 @@ __device__ __forceinline__ void wg_dp_group64_lean(double& best, int32_t& arg, u
 
 // state kept per chunk in global memory: [0] M[k] of the next step, [1..64] best, [65..128] arg, [129..192] bestB,
 // [193..256] argB (args as doubles' bits) — written only between stages — then the ring: ringN doubles, ringN int32
-template <int NW, int BL, bool LEAN = false>      // LEAN (BL == 64 only): every window of the job is <= WG_NARROW_WMAX sites
+template <int NW, int BL, bool LEAN = false, bool DEEP = false>      // LEAN (BL == 64 only): every window of the job is <= WG_NARROW_WMAX sites; DEEP (BL == 64): rows loaded three batches ahead
 __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
                                                       double* __restrict__ state, int64_t state_stride)
 {
@@ -1325,6 +1325,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     int32_t arg = 0, argB = 0;
     double Mk = 0.0;                                    // M[k] of the step about to run; M[0] = 0 (segmentor.cpp:97)
     DpRows<NW, BL> rows;                                // (workers) rows of the batch after the next, in flight
+    DpRows<NW, BL> rows2;                               // (workers, DEEP) a second set: `rows` holds even batches, `rows2` odd ones, each loaded three batches ahead
     DpRefill<NW> refill;                                // (workers) a region of windows / row offsets, in flight
     uint32_t fm_prev = 0, fm_cur = 0, fm_n1 = 0;        // (workers) widest window of batches b-1, b, b+1
     constexpr int RB = WG_DP_META_REGION / BL;          // batches per region of the meta ring
@@ -1362,7 +1363,12 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
         wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, 0, lane), s0, lane, lw);
         wg_dp_rows_commit<NW, BL>(rows, slots, slots + BL * 64, kinds, lane, lw);
         fm_cur = rows.fmax;
-        if (nb > 1) { wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, BL, lane), s0 + BL, lane, lw); fm_n1 = rows.fmax; }
+        if (!DEEP) {
+            if (nb > 1) { wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, BL, lane), s0 + BL, lane, lw); fm_n1 = rows.fmax; }
+        } else {
+            if (nb > 1) wg_dp_rows_issue<NW, BL>(rows2, cb, wg_dp_meta_lds<BL>(metaW, metaC, BL, lane), s0 + BL, lane, lw);
+            if (nb > 2) wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, 2 * BL, lane), s0 + 2 * BL, lane, lw);
+        }
     }
     __syncthreads();
 
@@ -1397,10 +1403,18 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
             else if (b > RB && b % RB == 1)  wg_dp_refill_commit<NW>(refill, metaW, metaC, (b / RB + 1) * WG_DP_META_REGION, lane, lw);
             if (WIDEJOB && b >= 1 && fm_prev > 128u)
                 wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, base - BL, s1, Mring, pendB, pendA, rmask, lane, lw);
-            // (Tried for the 64-step batches: a second register set so that rows are loaded THREE batches ahead — two batch times to
-            // land instead of one.  Seven workers: 137 VGPRs, i.e. one workgroup per CU instead of two, or 128 with spills: 1.75 -> 3.0 ms.
-            // Eight workers (8 rows each, 119 VGPRs): nine wavefronts per workgroup put three on one SIMD, and two such workgroups
-            // no longer fit a CU's register files: 1.64 -> 2.9 ms.)
+            // DEEP (64-step batches): a second register set, so that a row has two batch times (~3.5 us) to arrive instead of one.
+            // (Before the loop was split by role this did not fit: 137 VGPRs with seven workers, or nine wavefronts per workgroup
+            // with eight — either way one workgroup per CU, 1.75 -> 2.9-3.0 ms.)
+            if (DEEP) {
+                if ((b & 1) == 0) {
+                    if (b + 1 < nb) wg_dp_rows_commit<NW, BL>(rows2, slots + (size_t)SLOT, slots + (size_t)SLOT + BL * 64, kinds + 1, lane, lw);
+                    if (b + 3 < nb) wg_dp_rows_issue<NW, BL>(rows2, cb, wg_dp_meta_lds<BL>(metaW, metaC, (b + 3) * BL, lane), base + 3 * BL, lane, lw);
+                } else {
+                    if (b + 1 < nb) wg_dp_rows_commit<NW, BL>(rows, slots, slots + BL * 64, kinds, lane, lw);
+                    if (b + 3 < nb) wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, (b + 3) * BL, lane), base + 3 * BL, lane, lw);
+                }
+            } else {
             if (b + 1 < nb)
                 wg_dp_rows_commit<NW, BL>(rows, slots + (size_t)((b + 1) & 1) * SLOT, slots + (size_t)((b + 1) & 1) * SLOT + BL * 64,
                                           kinds + ((b + 1) & 1), lane, lw);
@@ -1414,6 +1428,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
                 fm_n2 = rows.fmax;
             }
             fm_prev = fm_cur; fm_cur = fm_n1; fm_n1 = fm_n2;
+            }
         }
         WG_DP_BARRIER;
       }
