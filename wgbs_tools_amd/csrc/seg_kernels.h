@@ -1021,48 +1021,6 @@ __device__ __forceinline__ void wg_dp_rows_commit(const DpRows<NW, BL>& R, doubl
 // Worker waves: blocks longer than 128 sites that START in the batch at `base` (whose M[k] the recurrence has left in
 // Mring), folded target-major into the ring.  A ring entry is always updated by the same wave (64-target tile t>>6
 // belongs to worker (t>>6) mod NW), so its read-modify-write sequence is one wave's program order.
-// The same two phases for the DEEP variant of the 64-step batches (rows loaded three batches ahead), written without a branch around
-// any load: a lane without a candidate loads the row's first entry instead (same cache line as its neighbours) and is blanked at
-// commit time from a predicate bit, the worker's tenth row is clamped onto row 63 and simply not stored by the workers that have
-// none.  Straight-line code lets the compiler see the order of the outstanding loads: the wait in front of a commit then leaves the
-// younger set in flight (with predicated loads it waits for everything).
-template <int NW>
-struct DpRowsU {
-    static constexpr int PER = (64 + NW - 1) / NW;
-    double va[PER];
-    uint32_t pred;                                       // bit q: this lane holds a candidate of the worker's q-th row
-};
-
-template <int NW>
-__device__ __forceinline__ void wg_dp_rows_issue_u(DpRowsU<NW>& R, const double* __restrict__ cb, const DpMeta M, int lane, int lw)
-{
-    const uint32_t w = M.w, rel = M.rel;
-    uint32_t pred = 0;
-#pragma unroll
-    for (int q = 0; q < DpRowsU<NW>::PER; q++) {
-        const int sraw = lw + q * NW, sidx = sraw < 64 ? sraw : 63;
-        const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w, sidx);
-        const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)rel, sidx);
-        const uint32_t j = (uint32_t)(lane - sidx) & 63u;
-        const bool p = j < f;
-        R.va[q] = cb[(int64_t)r + (p ? j : 0u)];
-        pred |= (p ? 1u : 0u) << q;
-    }
-    R.pred = pred;
-}
-
-template <int NW>
-__device__ __forceinline__ void wg_dp_rows_commit_u(const DpRowsU<NW>& R, double* __restrict__ slotA, int lane, int lw)
-{
-    const double NEG_INF = -__builtin_inf();
-#pragma unroll
-    for (int q = 0; q < DpRowsU<NW>::PER; q++) {
-        const int sidx = lw + q * NW;
-        const double v = ((R.pred >> q) & 1u) ? R.va[q] : NEG_INF;
-        if (sidx < 64) slotA[sidx * 64 + lane] = v;               // (wave-uniform)
-    }
-}
-
 template <int NW, int BL>
 __device__ __forceinline__ void wg_dp_far(const double* __restrict__ cb, const uint16_t* __restrict__ Wp, const uint32_t* __restrict__ Cp,
                                           uint32_t cum0, int base, int s1, const double* __restrict__ Mring,
@@ -1325,7 +1283,7 @@ __device__ __forceinline__ void wg_dp_group64_lean(double& best, int32_t& arg, u
 
 // state kept per chunk in global memory: [0] M[k] of the next step, [1..64] best, [65..128] arg, [129..192] bestB,
 // [193..256] argB (args as doubles' bits) — written only between stages — then the ring: ringN doubles, ringN int32
-template <int NW, int BL, bool LEAN = false, bool DEEP = false>      // LEAN (BL == 64 only): every window of the job is <= WG_NARROW_WMAX sites; DEEP (BL == 64): rows loaded three batches ahead
+template <int NW, int BL, bool LEAN = false>      // LEAN (BL == 64 only): every window of the job is <= WG_NARROW_WMAX sites
 __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
                                                       double* __restrict__ state, int64_t state_stride)
 {
@@ -1404,7 +1362,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
         wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, 0, lane), s0, lane, lw);
         wg_dp_rows_commit<NW, BL>(rows, slots, slots + BL * 64, kinds, lane, lw);
         fm_cur = rows.fmax;
-        if (!DEEP && nb > 1) { wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, BL, lane), s0 + BL, lane, lw); fm_n1 = rows.fmax; }
+        if (nb > 1) { wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, BL, lane), s0 + BL, lane, lw); fm_n1 = rows.fmax; }
     }
     __syncthreads();
 
@@ -1415,31 +1373,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     // — by then the updating wave has waited for loads it issued after that store (the row loads that end every batch), and vector
     // memory operations of a wave complete in order.  Waiting for store latency there, every 32 steps, would cost more than the steps.
 #define WG_DP_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    if (worker && DEEP) {
-      // DEEP (64-step batches, no wide windows): a second register set, so that a row has TWO batch times (~3.5 us) to arrive instead
-      // of one.  Batches in pairs: set A holds even batches, set B odd ones; no load sits under a branch (wg_dp_rows_issue_u; the
-      // batch index is clamped at the stage's last batch, whose rows are then loaded again and never stored).
-      DpRowsU<NW> setA, setB;
-      auto do_refill = [&](int bb) {
-          if (bb >= RB && bb % RB == 0)      wg_dp_refill_issue<NW>(refill, Wp, Cp, cum0, s0 + (bb / RB + 1) * WG_DP_META_REGION, s1, lane, lw);
-          else if (bb > RB && bb % RB == 1)  wg_dp_refill_commit<NW>(refill, metaW, metaC, (bb / RB + 1) * WG_DP_META_REGION, lane, lw);
-      };
-      auto clampb = [&](int bb) { return bb < nb ? bb : nb - 1; };
-      wg_dp_rows_issue_u<NW>(setB, cb, wg_dp_meta_lds<BL>(metaW, metaC, clampb(1) * BL, lane), lane, lw);      // batch 1
-      wg_dp_rows_issue_u<NW>(setA, cb, wg_dp_meta_lds<BL>(metaW, metaC, clampb(2) * BL, lane), lane, lw);      // batch 2
-      for (int b = 0; b < nb; b += 2) {
-        do_refill(b);                                             // (even batch b: batch b+1 into slot 1, then the loads of batch b+3)
-        if (b + 1 < nb) wg_dp_rows_commit_u<NW>(setB, slots + (size_t)SLOT, lane, lw);
-        wg_dp_rows_issue_u<NW>(setB, cb, wg_dp_meta_lds<BL>(metaW, metaC, clampb(b + 3) * BL, lane), lane, lw);
-        WG_DP_BARRIER;
-        if (b + 1 < nb) {
-            do_refill(b + 1);                                     // (odd batch b+1: batch b+2 into slot 0, then the loads of batch b+4)
-            if (b + 2 < nb) wg_dp_rows_commit_u<NW>(setA, slots, lane, lw);
-            wg_dp_rows_issue_u<NW>(setA, cb, wg_dp_meta_lds<BL>(metaW, metaC, clampb(b + 4) * BL, lane), lane, lw);
-            WG_DP_BARRIER;
-        }
-      }
-    } else if (worker) {
+    if (worker) {
       for (int b = 0; b < nb; b++) {
         const int base = s0 + b * BL;
         {
@@ -1463,6 +1397,11 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
             else if (b > RB && b % RB == 1)  wg_dp_refill_commit<NW>(refill, metaW, metaC, (b / RB + 1) * WG_DP_META_REGION, lane, lw);
             if (WIDEJOB && b >= 1 && fm_prev > 128u)
                 wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, base - BL, s1, Mring, pendB, pendA, rmask, lane, lw);
+            // (Tried three times for the 64-step batches: a second register set so that rows are loaded THREE batches ahead.  Before the
+            // loop was split by role it did not fit the registers (137 VGPRs with seven workers; nine wavefronts per workgroup with
+            // eight: one workgroup per CU, 1.75 -> 2.9-3.0 ms); after the split it fits (84-114 VGPRs) and, with every load out of its
+            // branch so that the waits leave the younger set in flight, measures 1.79 against 1.61 ms: the rows are not what the
+            // recurrence waits for.)
             if (b + 1 < nb)
                 wg_dp_rows_commit<NW, BL>(rows, slots + (size_t)((b + 1) & 1) * SLOT, slots + (size_t)((b + 1) & 1) * SLOT + BL * 64,
                                           kinds + ((b + 1) & 1), lane, lw);

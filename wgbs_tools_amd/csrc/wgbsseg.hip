@@ -558,7 +558,7 @@ hipError_t set_kernel_attributes()
     if (e == hipSuccess) e = set_cost_attrs<1>();
     if (e == hipSuccess) e = set_cost_attrs<2>();
     if (e == hipSuccess) e = set_cost_attrs<3>();
-    const void* dps[] = {reinterpret_cast<const void*>(&k_dp<3, 64>), reinterpret_cast<const void*>(&k_dp<7, 64>), reinterpret_cast<const void*>(&k_dp<7, 64, true>), reinterpret_cast<const void*>(&k_dp<7, 64, true, true>),
+    const void* dps[] = {reinterpret_cast<const void*>(&k_dp<3, 64>), reinterpret_cast<const void*>(&k_dp<7, 64>), reinterpret_cast<const void*>(&k_dp<7, 64, true>),
                          reinterpret_cast<const void*>(&k_dp<7, 32>), reinterpret_cast<const void*>(&k_dp<3, 32>),
                          reinterpret_cast<const void*>(&k_dp<15, 32>)};
     for (const void* f : dps)
@@ -899,13 +899,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         static const int dp16_env = getenv("WGBSSEG_DP16") ? atoi(getenv("WGBSSEG_DP16")) : -1;
         // windows <= 60 (no wide tile in the job): the step with the batched bookkeeping, 6.75 instead of 10 VALU instructions (WGBSSEG_DP_LEAN=0: never)
         static const bool dp_lean = !(getenv("WGBSSEG_DP_LEAN") && atoi(getenv("WGBSSEG_DP_LEAN")) == 0);
-        static const bool dp_deep = getenv("WGBSSEG_DP_DEEP") && atoi(getenv("WGBSSEG_DP_DEEP")) != 0;      // rows three batches ahead (second register set)
         // the LAST stage's recurrence has the chip to itself: the 64-step-batch kernel is twice as fast there
         const bool dp16 = dp_mode == 0 && (dp16_env < 0 ? (n_stages > 1 && stg + 1 < n_stages) : dp16_env != 0);
         if (dp16)                            hipLaunchKernelGGL((k_dp16<3>), dim3((unsigned)nC), dim3(64 * 4), (size_t)(2 * 16 * 64 * 8 + WG_DP_META_RING * 6), c->sB, v, sv, cbuf, c->dpstate.as<double>(), state_stride);
         else if (dp_mode == 0 && dp_nw == 3) hipLaunchKernelGGL((k_dp<3, 64>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
-        else if (dp_mode == 0 && dp_lean && Wmax <= WG_NARROW_WMAX && dp_deep)
-                                             hipLaunchKernelGGL((k_dp<7, 64, true, true>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else if (dp_mode == 0 && dp_lean && Wmax <= WG_NARROW_WMAX)
                                              hipLaunchKernelGGL((k_dp<7, 64, true>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else if (dp_mode == 0)               hipLaunchKernelGGL((k_dp<7, 64>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
