@@ -1597,28 +1597,33 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp16(JobView J, StageView SV,
     const uint32_t ninf_hi = 0xfff00000u;
     uint32_t tbk = 0;
     // one batch: Q = b mod 4 (compile time): the batch's first step sits on lane 16 Q; the set holding batch b+1 is (Q+1) mod 4
-#define WG_DP16_BATCH(Q, RNEXT)                                                                                            \
+    // (two loops, one per role, with the same barriers: see k_dp)
+#define WG_DP16_WORKER(Q, RNEXT)                                                                                           \
     if (b4 + (Q) < nb) {                                                                                                   \
         const int b = b4 + (Q);                                                                                            \
-        if (worker) {                                                                                                      \
-            if (b >= RB && b % RB == 0)      wg_dp_refill_issue<NW>(refill, Wp, Cp, cum0, s0 + (b / RB + 1) * WG_DP_META_REGION, s1, lane, lw); \
-            else if (b > RB && b % RB == 1)  wg_dp_refill_commit<NW>(refill, metaW, metaC, (b / RB + 1) * WG_DP_META_REGION, lane, lw); \
-            if (b + 1 < nb) wg_dp16_commit<NW>(RNEXT, slots + (size_t)((b + 1) & 1) * (BL * 64), lane, lw);                   \
-            if (b + 1 + D < nb) wg_dp16_issue<NW>(RNEXT, cb, metaW, metaC, (b + 1 + D) * BL, s0 + (b + 1 + D) * BL, lane, lw); \
-        } else {                                                                                                           \
-            const double* my = slots + (size_t)(b & 1) * (BL * 64) + lane;                                                 \
-            double ra[8], rb[8];                                                                                           \
-            _Pragma("unroll") for (int u = 0; u < 8; u++) { ra[u] = my[u * 64]; rb[u] = my[(8 + u) * 64]; }                \
-            double Ms = wg_readlane_f64(Mk, 0);   /* M[k] is wave-uniform: the asm blocks want it in scalar registers */   \
-            wg_dp_group64<16 * (Q), 0>(best, arg, tbk, Ms, ra, ninf_hi);                                                   \
-            wg_dp_group64<16 * (Q) + 8, 1>(best, arg, tbk, Ms, rb, ninf_hi);                                               \
-            Mk = Ms;                                                                                                       \
-        }                                                                                                                  \
+        if (b >= RB && b % RB == 0)      wg_dp_refill_issue<NW>(refill, Wp, Cp, cum0, s0 + (b / RB + 1) * WG_DP_META_REGION, s1, lane, lw); \
+        else if (b > RB && b % RB == 1)  wg_dp_refill_commit<NW>(refill, metaW, metaC, (b / RB + 1) * WG_DP_META_REGION, lane, lw); \
+        if (b + 1 < nb) wg_dp16_commit<NW>(RNEXT, slots + (size_t)((b + 1) & 1) * (BL * 64), lane, lw);                       \
+        if (b + 1 + D < nb) wg_dp16_issue<NW>(RNEXT, cb, metaW, metaC, (b + 1 + D) * BL, s0 + (b + 1 + D) * BL, lane, lw);     \
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                    \
     }
-    for (int b4 = 0; b4 < nb; b4 += 4) {
-        WG_DP16_BATCH(0, r1) WG_DP16_BATCH(1, r2) WG_DP16_BATCH(2, r3) WG_DP16_BATCH(3, r0)
-        if (!worker) {
+#define WG_DP16_REC(Q)                                                                                                     \
+    if (b4 + (Q) < nb) {                                                                                                   \
+        const int b = b4 + (Q);                                                                                            \
+        const double* my = slots + (size_t)(b & 1) * (BL * 64) + lane;                                                     \
+        double ra[8], rb[8];                                                                                               \
+        _Pragma("unroll") for (int u = 0; u < 8; u++) { ra[u] = my[u * 64]; rb[u] = my[(8 + u) * 64]; }                    \
+        double Ms = wg_readlane_f64(Mk, 0);   /* M[k] is wave-uniform: the asm blocks want it in scalar registers */       \
+        wg_dp_group64<16 * (Q), 0>(best, arg, tbk, Ms, ra, ninf_hi);                                                       \
+        wg_dp_group64<16 * (Q) + 8, 1>(best, arg, tbk, Ms, rb, ninf_hi);                                                   \
+        Mk = Ms;                                                                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                                    \
+    }
+    if (worker) {
+        for (int b4 = 0; b4 < nb; b4 += 4) { WG_DP16_WORKER(0, r1) WG_DP16_WORKER(1, r2) WG_DP16_WORKER(2, r3) WG_DP16_WORKER(3, r0) }
+    } else {
+        for (int b4 = 0; b4 < nb; b4 += 4) {
+            WG_DP16_REC(0) WG_DP16_REC(1) WG_DP16_REC(2) WG_DP16_REC(3)
             // the 64 lanes of tbk now hold the source lanes of the steps s0 + 16 b4 + lane (those that ran)
             const int i = s0 + b4 * BL + lane;
             const uint32_t len = (((uint32_t)lane - tbk) & 63u) + 1u;
@@ -1626,7 +1631,8 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp16(JobView J, StageView SV,
             tbk = 0;
         }
     }
-#undef WG_DP16_BATCH
+#undef WG_DP16_WORKER
+#undef WG_DP16_REC
     if (!worker && s1 < cd.len) {
         if (lane == 0) gs[0] = Mk;
         gs[1 + lane] = best;
