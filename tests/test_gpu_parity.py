@@ -520,6 +520,45 @@ def test_13_random_parameters_and_adversarial_inputs_match_oracle(seg, seed):
                 seed, pcount, max_cpg, max_bp, starts[c], lens[c], _first_diff(a, b))
 
 
+@pytest.mark.parametrize('n_samples', [1, 3])
+def test_13b_chunk_ending_on_a_carry_boundary_with_a_wide_last_tile(n_samples):
+    """Found by tools/extra_fuzz.py (seed 5751): a WIDE scoring tile whose first end site is the chunk's last site wants the prefix
+    P[len] alone; when start0 + len is a multiple of 64 that position is a carry group of its own, one past the groups the scan
+    pass wrote for the chunk.  Needs: len = 1 (mod 16) (a last unit of one start) in a group of start sites that holds a window
+    > 60 (or an end tile that begins on the last site: len = 16 m + 129), and the end on a multiple of 64.  The carries are left
+    holding another job's numbers first, so a stale entry cannot pass for the right one."""
+    rng = np.random.default_rng(77 + n_samples)
+    n = 7000
+    loci = (np.cumsum(rng.integers(1, 6, n)) + 500).astype(np.uint32)                  # dense: windows are bounded by max_cpg
+    slices = []
+    for _ in range(n_samples):
+        cov = rng.integers(0, 256, n)
+        cov[rng.random(n) < 0.3] = 0
+        meth = np.minimum(cov, rng.integers(0, 256, n))
+        slices.append(np.stack([meth, cov], axis=1).astype(np.uint8))
+    chunks = []
+    for end in (64 * 20, 64 * 47, 64 * 72, 64 * 100):
+        for ln in (1, 17, 65, 129, 193, 145, 16 * 7 + 129, 1345, 1281):
+            if ln <= end:
+                chunks.append((end - ln, ln))
+    with _lib.Segmenter(0) as sg:
+        sg.set_betas(slices)
+        sg.set_loci(loci)
+        for pcount, max_cpg, max_bp in [(3.9999998, 129, 100000), (1.0, 65, 100000), (15.0, 300, 100000), (0.25, 130, 100000), (0.0, 1000, 5000)]:
+            sg.segment_chunks([5, 2001, 4099], [1900, 2000, 2500], 100.0, 200, 100000)        # other numbers into the carries
+            for st, ln in chunks:                                                           # alone: the chunk's carries end the array
+                got = sg.segment_chunks([st], [ln], pcount, max_cpg, max_bp)[0]
+                want = oracle.segment_chunks(slices, loci, [st], [ln], pcount, max_cpg, max_bp)[0]
+                assert got.tolist() == want.tolist(), 'pcount %r max_cpg %d chunk [%d,+%d): %s' % (pcount, max_cpg, st, ln, _first_diff(got, want))
+            sg.segment_chunks([5, 2001, 4099], [1900, 2000, 2500], 100.0, 200, 100000)
+            starts = [c[0] for c in chunks]
+            lens = [c[1] for c in chunks]
+            got = sg.segment_chunks(starts, lens, pcount, max_cpg, max_bp)                      # together: the next chunk's carries follow
+            want = oracle.segment_chunks(slices, loci, starts, lens, pcount, max_cpg, max_bp, threads=os.cpu_count() or 1)
+            for c, (a, b) in enumerate(zip(got, want)):
+                assert a.tolist() == b.tolist(), 'pcount %r max_cpg %d chunk [%d,+%d) of the batch: %s' % (pcount, max_cpg, starts[c], lens[c], _first_diff(a, b))
+
+
 def test_14_threaded_upload_places_every_byte(monkeypatch):
     """wgbsseg_set_betas_host above 32 MB goes through several threads and page-locked staging pieces: odd row length,
     small pieces, a sample count that does not divide by the threads; every byte must land (checked through the scan)."""
