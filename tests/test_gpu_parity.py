@@ -523,9 +523,9 @@ def test_13_random_parameters_and_adversarial_inputs_match_oracle(seg, seed):
 @pytest.mark.parametrize('n_samples', [1, 3])
 def test_13b_chunk_ending_on_a_carry_boundary_with_a_wide_last_tile(n_samples):
     """Found by tools/extra_fuzz.py (seed 5751): a WIDE scoring tile whose first end site is the chunk's last site wants the prefix
-    P[len] alone; when start0 + len is a multiple of 64 that position is a carry group of its own, one past the groups the scan
+    P[len] alone; when start0 + len is a multiple of 128 (WG_CARRY_G) that position is a carry group of its own, one past the groups the scan
     pass wrote for the chunk.  Needs: len = 1 (mod 16) (a last unit of one start) in a group of start sites that holds a window
-    > 60 (or an end tile that begins on the last site: len = 16 m + 129), and the end on a multiple of 64.  The carries are left
+    > 60 (or an end tile that begins on the last site: len = 16 m + 129), and the end on a multiple of 128.  The carries are left
     holding another job's numbers first, so a stale entry cannot pass for the right one."""
     rng = np.random.default_rng(77 + n_samples)
     n = 7000

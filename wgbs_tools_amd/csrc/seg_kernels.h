@@ -587,7 +587,7 @@ struct CostArgs {
 
 // Stage the exclusive prefixes P[A+x], x = x0 .. x0+cnt-1, of sample row `row` into dst[0..cnt) (one wavefront).
 // A is chunk-relative; start0+A is either the chunk start or a multiple of WG_CARRY_G (wg_group_start), so a carry of
-// k_scan seeds the scan; the up to 64 sites between A and A+x0 are summed but not stored.
+// k_scan seeds the scan; the up to WG_CARRY_G sites between A and A+x0 are summed but not stored.
 __device__ __forceinline__ void wg_stage_prefix_row(uint2* __restrict__ dst, const uint8_t* __restrict__ row,
                                                     const uint2* __restrict__ carry, const ChunkDesc& cd,
                                                     int64_t n_total, int A, int x0, int cnt0, int lane)
@@ -813,7 +813,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int eA = SPLIT ? imin + 1 : ka;
     // carry position the scan of a wide row starts from.  eA == cd.len when the tile's first end is the chunk's last site (P[len]
     // alone is wanted): when start0 + len is a multiple of WG_CARRY_G that position is a group of its own, one past the cd.nG
-    // carries k_scan wrote for the chunk — the scan starts from the last group INSIDE the chunk instead (up to 64 sites summed).
+    // carries k_scan wrote for the chunk — the scan starts from the last group INSIDE the chunk instead (up to WG_CARRY_G sites summed).
     const int eG = wg_group_start(cd, eA < cd.len ? eA : cd.len - 1);
     const int Ecnt = imax + 2 - eA;
     const int sG = wg_group_start(cd, ka);
