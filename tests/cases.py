@@ -98,6 +98,25 @@ CHUNK_CASES = {
     'n200_pcount0':   dict(n=1000, a=170000, samples=list(range(200)), pcount=0.0, max_cpg=1000, max_bp=2000),
 }
 
+# Chunks INSIDE a larger resident world (the way the driver calls the library: `-s start0 -n len` on whole-genome files), placed on the
+# kernels' boundaries: carries of the scan pass sit at every 128th ABSOLUTE site, scoring tiles and units begin at chunk-relative
+# multiples of 16 / 64 / 128.  `ends` are absolute end sites, `lens` chunk lengths: every (end - len, len) with len <= end is a chunk.
+# (Found necessary by tools/extra_fuzz.py seed 5751: len = 1 mod 16 ending on a multiple of 128 with windows > 60.)
+OFFSET_CASES = {
+    'dense_1sample':  dict(n=7000, a=0, samples=[0], pcount=3.9999998, max_cpg=129, max_bp=100000, loci='dense',
+                           zero_ranges=[(0, 2555, 2560), (0, 4606, 4608)],
+                           ends=[2560, 3008, 4608, 6400, 6401, 7000], lens=[1, 17, 65, 129, 145, 193, 241, 1281, 1345]),
+    'dense_3samples': dict(n=5000, a=7000, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=2000, loci='dense',
+                           ends=[1280, 2561, 3840, 4992], lens=[1, 65, 129, 257, 449, 1217]),
+    'islands_8':      dict(n=9000, a=0, samples=list(range(8)), pcount=15.0, max_cpg=1000, max_bp=2000, loci='hg19like_islands',
+                           ends=[3072, 5888, 6016, 8960], lens=[65, 385, 1025, 2945]),
+}
+
+
+def offset_chunks(spec):
+    return [(e - ln, ln) for e in spec['ends'] for ln in spec['lens'] if ln <= e]
+
+
 # chr21-shaped multi-chunk case (BASELINE.json configs[1]): 400,000 CpGs x 8 samples in default 60,000-site chunks
 CHR21 = dict(n=400000, a=0, samples=list(range(8)), pcount=15.0, max_cpg=1000, max_bp=2000, chunk=60000)
 

@@ -20,3 +20,10 @@ def golden_chunks():
     import json
     with open(op.join(ROOT, 'tests', 'golden', 'chunk_cases.json')) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope='session')
+def golden_offsets():
+    import json
+    with open(op.join(ROOT, 'tests', 'golden', 'offset_cases.json')) as f:
+        return json.load(f)

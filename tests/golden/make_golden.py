@@ -10,7 +10,10 @@ container (needs /root/reference); the fixtures it writes are data (specs, input
                      increase_patch, SegmentByChunks.run with its chunk subprocess replaced by the binary above
                      fed from our loci array instead of tabix).
 
-Usage:  python tests/golden/make_golden.py [chunks] [driver]
+  offset_cases.json  the same binary with `-s start0 -n len` on whole-world files: chunks placed on the kernels' boundaries
+                     (tests/cases.py OFFSET_CASES).
+
+Usage:  python tests/golden/make_golden.py [chunks] [driver] [offsets]
 """
 import json
 import os
@@ -76,6 +79,29 @@ def gen_chunk_cases():
     print('wrote chunk_cases.json')
 
 
+def gen_offset_cases():
+    """offset_cases.json: chunks inside a larger world, `segmentor ... -s start0 -n len` on the whole-world .beta files."""
+    oracle.build(ref=True)
+    assert oracle.have_ref(), 'reference binary not built'
+    out = {}
+    for name, spec in cases.OFFSET_CASES.items():
+        slices, loci = cases.build_case(spec)
+        chunks = cases.offset_chunks(spec)
+        with tempfile.TemporaryDirectory() as td:
+            paths = []
+            for i, s in enumerate(slices):
+                p = op.join(td, 's%02d.beta' % i)
+                s.tofile(p)
+                paths.append(p)
+            borders = [oracle.ref_segment_chunk(paths, st, ln, loci[st:st + ln], spec['pcount'], spec['max_cpg'], spec['max_bp']).tolist()
+                       for st, ln in chunks]
+        out[name] = dict(spec=spec, input_crc32=cases.case_checksum(slices, loci), chunks=chunks, borders=borders)
+        print('%-16s world %d x %d, %d chunks, %d borders' % (name, spec['n'], len(spec['samples']), len(chunks), sum(map(len, borders))), flush=True)
+    with open(op.join(HERE, 'offset_cases.json'), 'w') as f:
+        json.dump(out, f, separators=(',', ':'))
+    print('wrote offset_cases.json')
+
+
 if __name__ == '__main__':
     what = [a for a in sys.argv[1:] if not a.startswith('case=')] or ['chunks', 'driver']
     if 'chunks' in what:
@@ -83,3 +109,5 @@ if __name__ == '__main__':
     if 'driver' in what:
         import make_golden_driver
         make_golden_driver.gen_driver_cases()
+    if 'offsets' in what:
+        gen_offset_cases()

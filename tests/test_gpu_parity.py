@@ -341,6 +341,28 @@ def test_06_borders_match_reference_golden(seg, name, golden_chunks):
     assert got.tolist() == g['borders'], _first_diff(got, np.array(g['borders']))
 
 
+@pytest.mark.parametrize('name', list(cases.OFFSET_CASES))
+def test_06b_chunks_inside_a_world_match_reference_golden(name, golden_offsets):
+    """Chunks of a larger resident world, on and next to the boundaries of carries (every 128th absolute site), units, tiles and
+    batches, against the reference binary's `-s start0 -n len` output: every chunk alone, then all in one batch; another job's
+    numbers are left in the device buffers first."""
+    g = golden_offsets[name]
+    spec = g['spec']
+    with _lib.Segmenter(0) as sg:
+        slices, loci = _load_case(sg, spec)
+        assert cases.case_checksum(slices, loci) == g['input_crc32']
+        n = spec['n']
+        poison = ([3, n // 3 + 1, 2 * (n // 3) + 2], [n // 3 - 7, n // 3 - 1, n - 2 * (n // 3) - 2])
+        sg.segment_chunks(poison[0], poison[1], 100.0, 200, 100000)
+        for (st, ln), want in zip(g['chunks'], g['borders']):
+            got = sg.segment_chunks([st], [ln], spec['pcount'], spec['max_cpg'], spec['max_bp'])[0]
+            assert got.tolist() == want, 'chunk [%d,+%d) alone: %s' % (st, ln, _first_diff(got, np.array(want)))
+        sg.segment_chunks(poison[0], poison[1], 100.0, 200, 100000)
+        res = sg.segment_chunks([c[0] for c in g['chunks']], [c[1] for c in g['chunks']], spec['pcount'], spec['max_cpg'], spec['max_bp'])
+        for (st, ln), got, want in zip(g['chunks'], res, g['borders']):
+            assert got.tolist() == want, 'chunk [%d,+%d) of the batch: %s' % (st, ln, _first_diff(got, np.array(want)))
+
+
 @pytest.mark.parametrize('stages', [2, 3, 7, 64])
 def test_07_staging_does_not_change_borders(stages, golden_chunks):
     os.environ['WGBSSEG_FORCE_STAGES'] = str(stages)

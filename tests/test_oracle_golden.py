@@ -35,6 +35,22 @@ def test_chr21_multichunk_matches_reference_golden(golden_chunks):
         assert got.tolist() == want
 
 
+@pytest.mark.parametrize('name', list(cases.OFFSET_CASES))
+def test_chunks_inside_a_world_match_reference_golden(name, golden_offsets):
+    """`segmentor -s start0 -n len` on whole-world files (tests/golden/offset_cases.json): chunks that begin and end on the
+    device kernels' boundaries.  The restatement has no such boundaries: this pins the expected values the GPU test uses."""
+    g = golden_offsets[name]
+    spec = g['spec']
+    slices, loci = cases.build_case(spec)
+    assert cases.case_checksum(slices, loci) == g['input_crc32'], 'synthetic input generator drifted'
+    assert [list(c) for c in cases.offset_chunks(spec)] == g['chunks']
+    starts = [c[0] for c in g['chunks']]
+    lens = [c[1] for c in g['chunks']]
+    res = oracle.segment_chunks(slices, loci, starts, lens, spec['pcount'], spec['max_cpg'], spec['max_bp'], threads=8)
+    for (st, ln), got, want in zip(g['chunks'], res, g['borders']):
+        assert got.tolist() == want, 'chunk [%d,+%d)' % (st, ln)
+
+
 @pytest.mark.skipif(not oracle.have_ref(), reason='oracle/_ref/segmentor not built here')
 @pytest.mark.parametrize('name', ['tiny', 'pcount0', 'zero_stretch', 'dense_w_gt_64'])
 def test_live_reference_binary_agrees(name, golden_chunks):
