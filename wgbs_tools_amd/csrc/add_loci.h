@@ -31,19 +31,31 @@ struct Genome {
     int n_chroms;
 };
 
+// Decimal text of v, two digits per division (a row carries ~34 digits: the divisions are what formatting costs).
 inline char* put_u64(char* p, uint64_t v)
 {
+    static const char D2[201] =
+        "00010203040506070809101112131415161718192021222324252627282930313233343536373839404142434445464748495051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
     char tmp[24];
     int n = 0;
-    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    if (v <= 0xffffffffu) {                                       // loci and CpG indices: 32-bit divisions
+        uint32_t w = (uint32_t)v;
+        while (w >= 100) { const uint32_t q = w / 100, r = w - q * 100; tmp[n++] = D2[2 * r + 1]; tmp[n++] = D2[2 * r]; w = q; }
+        if (w >= 10) { tmp[n++] = D2[2 * w + 1]; tmp[n++] = D2[2 * w]; } else tmp[n++] = (char)('0' + w);
+    } else {
+        while (v >= 100) { const uint64_t q = v / 100, r = v - q * 100; tmp[n++] = D2[2 * r + 1]; tmp[n++] = D2[2 * r]; v = q; }
+        if (v >= 10) { tmp[n++] = D2[2 * v + 1]; tmp[n++] = D2[2 * v]; } else tmp[n++] = (char)('0' + v);
+    }
     while (n) *p++ = tmp[--n];
     return p;
 }
 
 // chromosome index of a 1-based CpG index (cpg_dict.cpp:118-131): the first chromosome whose cumulative count is >= loc;
 // nr_sites+1 (a non-inclusive end) belongs to the last chromosome; anything else is an error (-1)
-inline int loc2chrom(const Genome& g, int64_t loc)
+inline int loc2chrom(const Genome& g, int64_t loc, int hint = -1)
 {
+    // (tables come sorted: the chromosome of the previous site is almost always the answer)
+    if (hint >= 0 && hint < g.n_chroms && loc <= g.cum[hint] && (hint == 0 || loc > g.cum[hint - 1]) && loc >= 1) return hint;
     const int64_t* e = g.cum + g.n_chroms;
     const int64_t* it = std::lower_bound(g.cum, e, loc);
     if (it != e) return (int)(it - g.cum);
@@ -52,16 +64,16 @@ inline int loc2chrom(const Genome& g, int64_t loc)
 }
 
 // Validates like add_loci.cpp:38-49.  Returns 0, or the 1-based position of the failing check with `line` / `msg` set.
-inline int check_row(const Genome& g, int64_t s, int64_t e, int& c1, std::string& msg)
+inline int check_row(const Genome& g, int64_t s, int64_t e, int& c1, std::string& msg, int hint = -1)
 {
     if (e < s) { msg = "endCpG < startCpG"; return 1; }
     if (s < 1) { msg = "startCpG < 1"; return 1; }
     if (e < 1) { msg = "endCpG < 1"; return 1; }
     // (loc2chrom admits nr_sites + 1 because an END may sit there; a block cannot START there: the reference reads one
     // element past its loci vector in that case — refused here, with the message of an unknown site)
-    c1 = s > g.n_sites ? -1 : loc2chrom(g, s);
+    c1 = s > g.n_sites ? -1 : loc2chrom(g, s, hint);
     if (c1 < 0) { msg = "[ cpg_dict ] Could not find chromosome for site: " + std::to_string(s); return 2; }
-    const int c2 = loc2chrom(g, e);
+    const int c2 = loc2chrom(g, e, c1);
     if (c2 < 0) { msg = "[ cpg_dict ] Could not find chromosome for site: " + std::to_string(e); return 2; }
     if (c1 != c2 && e - 1 != g.cum[c1]) { msg = "Cross chromosomes"; return 1; }
     return 0;
@@ -84,9 +96,11 @@ inline void format_range(const Genome& g, const int64_t* s, const int64_t* e, in
     out.buf = static_cast<char*>(malloc((size_t)(hi - lo) * row_cap + 1));
     if (!out.buf) { out.bad_line = lo; out.bad_kind = 3; out.msg = "out of memory"; return; }
     char* p = out.buf;
+    int hint = -1;
     for (int64_t r = lo; r < hi; r++) {
         int c1 = 0;
-        const int kind = check_row(g, s[r], e[r], c1, out.msg);
+        const int kind = check_row(g, s[r], e[r], c1, out.msg, hint);
+        hint = c1;
         if (kind) { out.bad_line = r; out.bad_kind = kind; break; }
         const char* nm = g.names[c1];
         const size_t nl = strlen(nm);
