@@ -286,6 +286,36 @@ int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom
                      const char* path, int32_t append, int32_t threads, char* err, size_t errlen);
 
 /*
+ * The text either side of the block reduction (`wgbstools beta_to_table`: beta_to_table.py:59-127, `beta_to_blocks --bedGraph`:
+ * beta_to_blocks.py:112-126; the reference reads the blocks table with pandas.read_csv and prints with DataFrame.to_csv).  Host
+ * side, no device, no ctx.
+ *
+ * wgbsseg_blocks_parse: the bytes of a blocks table (tab-separated chr, start, end, startCpG, endCpG [, more]; '#' comments,
+ * blank lines and a header line are skipped) -> per row the offset of its first byte (line_off), the length of its
+ * "chr \t start \t end" text (len3), the two CpG columns and na = 1 where one of them is missing (NA, empty, ...).  A FAST PATH:
+ * returns WGBSSEG_OK with *n_rows rows (at most max_rows when max_rows >= 0), or 1 when the text is not a plain table — a row
+ * with fewer than five fields, a CpG field that is neither digits nor a missing-value spelling, carriage returns, non-ASCII
+ * bytes, no row at all — and the caller then parses it line by line (the Python host owns those cases and their messages).
+ * WGBSSEG_E_ARG: more than `cap` rows (cap = number of '\n' + 1 always suffices).
+ *
+ * wgbsseg_blocks_write_table: one output row per parsed row r: its "chr \t start \t end" bytes, startCpG, endCpG (NA where
+ * na[r]), then values[r * stride + c], c < n_cols, as printf("%.<digits>f") (NaN: NA), tab-separated, '\n'; appended to `path`
+ * (append 0: the file is truncated first; path NULL: written to the process's standard output).  The digits are those of the exact binary value rounded half to even, as glibc's
+ * printf and Python's % operator print them.  wgbsseg_blocks_write_bedgraph: chr, start, end, meth / cov as %.2f (-1 for
+ * 0 / 0), cov — from rows of uint8 (wide 0) or uint16 (wide 1) pairs.  threads <= 0: all host cores (at most 32).
+ * wgbsseg_format_fixed: the number formatter alone, one value per line into `out` (test hook); returns the bytes written, -1
+ * when out_cap is too small.
+ */
+int wgbsseg_blocks_parse(const char* text, int64_t len, int64_t max_rows, int64_t cap, int64_t* line_off, int32_t* len3,
+                         int64_t* start_cpg, int64_t* end_cpg, uint8_t* na, int64_t* n_rows);
+int wgbsseg_blocks_write_table(const char* path, int32_t append, const char* text, const int64_t* line_off, const int32_t* len3,
+                               const int64_t* start_cpg, const int64_t* end_cpg, const uint8_t* na, int64_t n_rows,
+                               const double* values, int64_t n_cols, int64_t stride, int32_t digits, int32_t threads, char* err, size_t errlen);
+int wgbsseg_blocks_write_bedgraph(const char* path, const char* text, const int64_t* line_off, const int32_t* len3, int64_t n_rows,
+                                  const void* rows, int32_t wide, int32_t threads, char* err, size_t errlen);
+int64_t wgbsseg_format_fixed(const double* v, int64_t n, int32_t digits, char* out, int64_t out_cap);
+
+/*
  * pat -> beta: the producer of the path's input (`wgbstools pat2beta`: pat2beta.py:17-44 pipes `gunzip -c x.pat.gz` into
  * the reference's stdin2beta binary, src/pat2beta/stdin2beta.cpp:59-123, and trims the counts with trim_to_uint8,
  * utils_wgbs.py:277-290).  An accumulator holds (#meth, #cov) of the CpGs [start_cpg, end_cpg) (1-based, half-open; the whole

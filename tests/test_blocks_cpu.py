@@ -166,3 +166,128 @@ def test_blocks_file_rules(tmp_path):
         B2B.load_blocks_file(table([('chr1', 10, 20)]))                       # fewer than 5 columns
     with pytest.raises(B2B.IllegalArgumentError):
         B2B.load_blocks_file(table([('chr1', 10, 20, 9, 3), ('chr1', 10, 20, 9, 13)]))    # endCpG < startCpG
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the library's text paths (csrc/table_io.h) against the line-by-line Python they stand in for
+# ---------------------------------------------------------------------------------------------------------
+def _py_load(path, monkeypatch, **kw):
+    monkeypatch.setenv('WGBSSEG_PY_TABLES', '1')
+    try:
+        return B2B.load_blocks_file(path, **kw)
+    finally:
+        monkeypatch.delenv('WGBSSEG_PY_TABLES')
+
+
+def _same_table(a, b):
+    assert len(a) == len(b) and a.chr == b.chr and a.start == b.start and a.end == b.end
+    assert a.startCpG.tolist() == b.startCpG.tolist() and a.endCpG.tolist() == b.endCpG.tolist() and a.na.tolist() == b.na.tolist()
+    assert a.columns == b.columns and a.cpg_text() == b.cpg_text()
+
+
+def test_number_formatter_is_printf(monkeypatch):
+    """wgbsseg_format_fixed == Python's '%.Nf' % v (== glibc printf): the exact binary value rounded half to even — random values,
+    every k / 1000 and k / 256, exact ties at every digit count, the neighbours of ties, subnormals, and what falls outside the
+    integer path (negative, > 1, infinities, -0.0, many digits)."""
+    from wgbs_tools_amd import _lib
+    rng = np.random.default_rng(3)
+    ties = [k / 2.0 ** j for j in range(1, 12) for k in range(1, 2 ** j, 2)]
+    near = [np.nextafter(t, 0) for t in ties[:200]] + [np.nextafter(t, 1) for t in ties[:200]]
+    special = [0.0, 1.0, 0.005, 0.015, 0.995, 0.9949999999999999, 0.9950000000000001, 1e-300, 5e-324, 0.49999999999999994,
+               float('nan'), -0.0, -0.5, 1.5, 1e22, float('inf'), float('-inf'), 2.675, 1.005, 123456.789, -1e-9]
+    v = np.concatenate([rng.random(200000), rng.random(20000) * 1e-6, np.arange(1001) / 1000.0, np.arange(257) / 256.0, ties, near, special])
+    for d in (0, 1, 2, 3, 4, 6, 9, 12):
+        got = _lib.format_fixed(v, d)
+        fmt = '%%.%df' % d
+        want = ['NA' if x != x else fmt % x for x in v.tolist()]
+        bad = [(x, g, w) for x, g, w in zip(v.tolist(), got, want) if g != w]
+        assert not bad, (d, bad[:5])
+
+
+def test_native_blocks_parser_and_writers_match_the_python_paths(world, tmp_path, monkeypatch, capfd):
+    from wgbs_tools_amd import _lib
+    # 1. plain tables: every fixture, and files with a header, comments, blank lines, NA spellings, more columns, no last newline
+    files = dict(world['blocks'])
+    extra = tmp_path / 'mixed.bed'
+    extra.write_text('chr\tstart\tend\tstartCpG\tendCpG\n# c\n\n   \t \nchr1\t10\t20\t1\t3\nchr1\t20\t40\tNA\t7\nchr2\t5\t6\t\t\n'
+                     'chr2\t7\t9\t10\tnan\tanno\tgene\nchrUn_gl000220\t000100\t200\t0012\t15\tx\nchr3\t1\t2\t100000000000000\t100000000000001')
+    files['mixed'] = str(extra)
+    import gzip
+    gz = tmp_path / 'nice.bed.gz'
+    gz.write_bytes(gzip.compress(open(world['blocks']['nice'], 'rb').read()))
+    files['gz'] = str(gz)
+    for name, p in files.items():
+        a = B2B.load_blocks_file(p)
+        assert a.parsed is not None, name                                     # the fast path took it
+        b = _py_load(p, monkeypatch)
+        assert b.parsed is None
+        _same_table(a, b)
+        assert B2B.is_block_file_nice(a) == B2B.is_block_file_nice(b)
+        for nrows in (1, 3, 10 ** 9):
+            _same_table(B2B.load_blocks_file(p, nrows=nrows), _py_load(p, monkeypatch, nrows=nrows))
+        _same_table(a.rows(1, 4), b.rows(1, 4))
+    # 2. what the fast path must decline (the Python parser then answers, with its messages)
+    odd = {'crlf': 'chr1\t1\t2\t3\t4\r\nchr1\t2\t3\t4\t5\r\n', 'float': 'chr1\t1\t2\t3.0\t4\n', 'space': 'chr1\t1\t2\t 3\t4\n',
+           'short_later': 'chr1\t1\t2\t3\t4\nchr1\t5\n', 'short_first': 'chr1\t1\t2\n', 'empty': '', 'only_comments': '# a\n# b\n',
+           'utf8': 'chré\t1\t2\t3\t4\n', 'sci': 'chr1\t1\t2\t1e3\t2e3\n', 'neg': 'chr1\t1\t2\t-3\t4\n', 'long': 'chr1\t1\t2\t1234567890123456\t1234567890123457\n',
+           'header_only': 'chr\tstart\tend\tstartCpG\tendCpG\n'}
+    for name, text in odd.items():
+        p = tmp_path / (name + '.bed')
+        p.write_bytes(text.encode('utf-8'))
+        assert _lib.blocks_parse(text.encode('utf-8')) is None, name
+        res = []
+        for py in (False, True):
+            try:
+                t = _py_load(str(p), monkeypatch) if py else B2B.load_blocks_file(str(p))
+                res.append(('ok', t.chr, t.startCpG.tolist(), t.endCpG.tolist(), t.na.tolist()))
+            except Exception as e:
+                res.append((type(e).__name__, str(e)))
+        assert res[0] == res[1], name
+    capfd.readouterr()
+    # 3. the table writer: file, chunks appended, standard output — against the Python loop (which the goldens pin above)
+    df = B2B.load_blocks_file(str(extra))
+    dfp = _py_load(str(extra), monkeypatch)
+    rng = np.random.default_rng(1)
+    for digits in (0, 2, 3, 5):
+        vals = rng.random((len(df), 7))
+        vals[rng.random(vals.shape) < 0.2] = np.nan
+        vals[0, :4] = [0.0, 1.0, 0.125, 0.375]
+        names = ['s%d' % i for i in range(7)]
+        buf = io.StringIO()
+        B2T.dump(buf, B2T.Table(dfp, names, vals), True, digits)
+        want = buf.getvalue()
+        out = str(tmp_path / ('t%d.tsv' % digits))
+        B2T.dump(out, B2T.Table(df, names, vals), True, digits)
+        assert open(out).read() == want
+        for a in range(0, len(df), 2):                                        # in chunks, appended
+            B2T.dump(out, B2T.Table(df.rows(a, a + 2), names, vals[a:a + 2]), a == 0, digits)
+        assert open(out).read() == want
+        B2T.dump(None, B2T.Table(df, names, vals), True, digits)              # standard output
+        assert capfd.readouterr().out == want
+    # a table large enough for several shards and threads
+    n = 70001
+    big = tmp_path / 'big.bed'
+    with open(big, 'w') as f:
+        for i in range(n):
+            f.write('chr%d\t%d\t%d\t%d\t%d\n' % (1 + i % 22, 10 * i, 10 * i + 7, 1 + 2 * i, 3 + 2 * i))
+    df = B2B.load_blocks_file(str(big))
+    dfp = _py_load(str(big), monkeypatch)
+    assert df.parsed is not None and B2B.is_block_file_nice(df) == B2B.is_block_file_nice(dfp) == (True, '')
+    vals = np.round(rng.random((n, 3)), 3)
+    vals[rng.random(vals.shape) < 0.1] = np.nan
+    buf = io.StringIO()
+    B2T.dump(buf, B2T.Table(dfp, ['a', 'b', 'c'], vals), True, 2)
+    out = str(tmp_path / 'big.tsv')
+    B2T.dump(out, B2T.Table(df, ['a', 'b', 'c'], vals), True, 2)
+    assert open(out).read() == buf.getvalue()
+    # 4. bedGraph rows from uint8 and uint16 pairs
+    for dt in (np.uint8, np.uint16):
+        top = np.iinfo(dt).max
+        cov = rng.integers(0, top + 1, n)
+        cov[rng.random(n) < 0.1] = 0
+        meth = (cov * rng.random(n)).astype(np.int64)
+        rows = np.stack([meth, cov], axis=1).astype(dt)
+        pa, pb = str(tmp_path / 'a.bedGraph'), str(tmp_path / 'b.bedGraph')
+        B2B.write_bedgraph(pa, df, rows)
+        B2B.write_bedgraph(pb, dfp, rows)
+        assert open(pa, 'rb').read() == open(pb, 'rb').read()

@@ -26,7 +26,8 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_group_get_timings', 'wgbsseg_plan_shares', 'wgbsseg_set_lbetas_host',
            'wgbsseg_convert_regions', 'wgbsseg_patbeta_create', 'wgbsseg_patbeta_feed', 'wgbsseg_patbeta_finish',
            'wgbsseg_patbeta_destroy', 'wgbsseg_group_load_host_async', 'wgbsseg_group_load_wait',
-           'wgbsseg_marker_stats']
+           'wgbsseg_marker_stats', 'wgbsseg_blocks_parse', 'wgbsseg_blocks_write_table', 'wgbsseg_blocks_write_bedgraph',
+           'wgbsseg_format_fixed']
 
 
 class NativeLibraryError(RuntimeError):
@@ -190,6 +191,14 @@ def load():
     L.wgbsseg_marker_stats.argtypes = [vp, vp, i32, vp, i32, i64, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_add_loci.restype = i32
     L.wgbsseg_add_loci.argtypes = [vp, i64, vp, C.POINTER(C.c_char_p), i32, vp, vp, i64, C.c_char_p, i32, i32, C.c_char_p, C.c_size_t]
+    L.wgbsseg_blocks_parse.restype = i32
+    L.wgbsseg_blocks_parse.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    L.wgbsseg_blocks_write_table.restype = i32
+    L.wgbsseg_blocks_write_table.argtypes = [C.c_char_p, i32, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i32, i32, C.c_char_p, C.c_size_t]
+    L.wgbsseg_blocks_write_bedgraph.restype = i32
+    L.wgbsseg_blocks_write_bedgraph.argtypes = [C.c_char_p, vp, vp, vp, i64, vp, i32, i32, C.c_char_p, C.c_size_t]
+    L.wgbsseg_format_fixed.restype = i64
+    L.wgbsseg_format_fixed.argtypes = [vp, i64, i32, vp, i64]
     _lib = L
     return L
 
@@ -651,3 +660,97 @@ def add_loci(loci, chrom_names, chrom_cum, start_cpg, end_cpg, path=None, append
     rc = L.wgbsseg_add_loci(loci.ctypes.data, loci.size, cum.ctypes.data, names, len(chrom_names), s.ctypes.data, e.ctypes.data,
                             s.size, None if path is None else os.fsencode(path), 1 if append else 0, int(threads), err, ERRLEN)
     _check(rc, err)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# text of the block tools (include/wgbsseg.h: wgbsseg_blocks_*; host side, no device)
+# ------------------------------------------------------------------------------------------------------------
+class ParsedBlocks:
+    """What wgbsseg_blocks_parse leaves: the table's bytes and, per row, where it begins, how long its `chr \\t start \\t end`
+    text is, the two CpG columns (int64, 0 where missing) and the missing flags."""
+
+    def __init__(self, text, line_off, len3, start_cpg, end_cpg, na):
+        self.text, self.line_off, self.len3, self.start_cpg, self.end_cpg, self.na = text, line_off, len3, start_cpg, end_cpg, na
+
+    def __len__(self):
+        return self.line_off.size
+
+    def rows(self, a, b):
+        return ParsedBlocks(self.text, self.line_off[a:b], self.len3[a:b], self.start_cpg[a:b], self.end_cpg[a:b], self.na[a:b])
+
+    def coords(self):
+        """-> (chr, start, end) lists of str: the first three fields of every row, as the file has them"""
+        t = self.text
+        parts = [bytes(t[o:o + l]).decode('ascii').split('\t') for o, l in zip(self.line_off.tolist(), self.len3.tolist())]
+        return [p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts]
+
+    def _ptrs(self):
+        self.line_off = np.ascontiguousarray(self.line_off, dtype=np.int64)
+        self.len3 = np.ascontiguousarray(self.len3, dtype=np.int32)
+        self.start_cpg = np.ascontiguousarray(self.start_cpg, dtype=np.int64)
+        self.end_cpg = np.ascontiguousarray(self.end_cpg, dtype=np.int64)
+        self.na = np.ascontiguousarray(self.na, dtype=np.uint8)
+        return (self.text.ctypes.data, self.line_off.ctypes.data, self.len3.ctypes.data, self.start_cpg.ctypes.data,
+                self.end_cpg.ctypes.data, self.na.ctypes.data)
+
+
+def blocks_parse(data, max_rows=None):
+    """wgbsseg_blocks_parse on the bytes of a blocks table -> ParsedBlocks, or None when the text is not a plain table (the
+    caller then parses it line by line)."""
+    L = load()
+    text = np.frombuffer(data, dtype=np.uint8)
+    if text.size == 0:
+        return None
+    cap = (data.count(b'\n') if isinstance(data, (bytes, bytearray)) else int(np.count_nonzero(text == 10))) + 1
+    if max_rows is not None:
+        cap = min(cap, max(int(max_rows), 0) + 1)
+    line_off = np.empty(cap, dtype=np.int64)
+    len3 = np.empty(cap, dtype=np.int32)
+    s = np.empty(cap, dtype=np.int64)
+    e = np.empty(cap, dtype=np.int64)
+    na = np.empty(cap, dtype=np.uint8)
+    n = C.c_int64(0)
+    rc = L.wgbsseg_blocks_parse(text.ctypes.data, text.size, -1 if max_rows is None else int(max_rows), cap, line_off.ctypes.data,
+                                len3.ctypes.data, s.ctypes.data, e.ctypes.data, na.ctypes.data, C.byref(n))
+    if rc != OK:
+        return None
+    k = int(n.value)
+    return ParsedBlocks(text, line_off[:k], len3[:k], s[:k], e[:k], na[:k])
+
+
+def blocks_write_table(path, parsed, values, digits, append=True, threads=0):
+    """wgbsseg_blocks_write_table: the rows of `parsed` with values[r][c] as %.<digits>f (NaN: NA), appended to `path` (None: the
+    process's standard output; flush sys.stdout first)."""
+    L = load()
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    if v.ndim != 2 or v.shape[0] != len(parsed):
+        raise ValueError('values must be [rows][columns]')
+    t, lo, l3, s, e, na = parsed._ptrs()
+    err = C.create_string_buffer(ERRLEN)
+    rc = L.wgbsseg_blocks_write_table(None if path is None else os.fsencode(path), 1 if append else 0, t, lo, l3, s, e, na, len(parsed), v.ctypes.data,
+                                      v.shape[1], v.shape[1], int(digits), int(threads), err, ERRLEN)
+    _check(rc, err)
+
+
+def blocks_write_bedgraph(path, parsed, rows, threads=0):
+    """wgbsseg_blocks_write_bedgraph: chr, start, end, meth / cov (%.2f, -1 for 0 / 0), cov from uint8 / uint16 pairs."""
+    L = load()
+    rows = np.ascontiguousarray(rows)
+    if rows.dtype not in (np.uint8, np.uint16) or rows.shape != (len(parsed), 2):
+        raise ValueError('rows must be uint8 / uint16 [n][2]')
+    t, lo, l3, _, _, _ = parsed._ptrs()
+    err = C.create_string_buffer(ERRLEN)
+    rc = L.wgbsseg_blocks_write_bedgraph(os.fsencode(path), t, lo, l3, len(parsed), rows.ctypes.data, 1 if rows.dtype == np.uint16 else 0,
+                                         int(threads), err, ERRLEN)
+    _check(rc, err)
+
+
+def format_fixed(values, digits):
+    """wgbsseg_format_fixed -> list of str: printf('%.<digits>f') of every value (NaN: 'NA')"""
+    L = load()
+    v = np.ascontiguousarray(values, dtype=np.float64).ravel()
+    out = np.empty(v.size * 24 + 1024 + 420 * int(np.count_nonzero(~((v >= 0) & (v <= 1)))), dtype=np.uint8)
+    n = L.wgbsseg_format_fixed(v.ctypes.data, v.size, int(digits), out.ctypes.data, out.size)
+    if n < 0:
+        raise ValueError('format_fixed: buffer too small')
+    return out[:n].tobytes().decode('ascii').split('\n')[:-1]

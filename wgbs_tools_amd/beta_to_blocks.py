@@ -17,6 +17,7 @@ one numpy pass per file in a process pool; input files may be uint8 `.beta` / `.
 (utils_wgbs.py:311-319).  No CPU fallback.
 """
 import argparse
+import os
 import os.path as op
 import sys
 
@@ -34,14 +35,35 @@ def b2b_log(*args, **kwargs):
 
 class BlocksTable:
     """A blocks table in memory, column-wise.  `chr`, `start`, `end`: the file's own text (they are only ever written back);
-    `startCpG`, `endCpG`: int64 with `na` marking rows whose CpG fields are missing; `extra`: {'anno': [...], 'gene': [...]}."""
+    `startCpG`, `endCpG`: int64 with `na` marking rows whose CpG fields are missing; `extra`: {'anno': [...], 'gene': [...]}.
+    A table read by the library's parser (`parsed`: _lib.ParsedBlocks) keeps the file's bytes and row offsets instead of three
+    lists of strings: the writers in the library print straight from them; `chr` / `start` / `end` are cut out on first use."""
 
-    def __init__(self, chrom, start, end, start_cpg, end_cpg, na, extra=None):
-        self.chr, self.start, self.end = list(chrom), list(start), list(end)
+    def __init__(self, chrom, start, end, start_cpg, end_cpg, na, extra=None, parsed=None):
+        self.parsed = parsed
+        self._coords = None if parsed is not None else (list(chrom), list(start), list(end))
         self.startCpG = np.asarray(start_cpg, dtype=np.int64)
         self.endCpG = np.asarray(end_cpg, dtype=np.int64)
         self.na = np.asarray(na, dtype=bool)
         self.extra = dict(extra or {})
+
+    def _text_columns(self):
+        if self._coords is None:
+            self._coords = self.parsed.coords()
+        return self._coords
+
+    chr = property(lambda self: self._text_columns()[0])
+    start = property(lambda self: self._text_columns()[1])
+    end = property(lambda self: self._text_columns()[2])
+
+    def coords_of(self, idx):
+        """[(chr, start, end) text of row i for i in idx] without cutting out the whole table"""
+        if self._coords is None:
+            p = self.parsed
+            return [tuple(bytes(p.text[o:o + l]).decode('ascii').split('\t'))
+                    for o, l in zip(p.line_off[idx].tolist(), p.len3[idx].tolist())]
+        c, s, e = self._coords
+        return [(c[i], s[i], e[i]) for i in idx]
 
     @property
     def columns(self):
@@ -49,13 +71,15 @@ class BlocksTable:
 
     @property
     def shape(self):
-        return (len(self.chr), len(self.columns))
+        return (len(self), len(self.columns))
 
     def __len__(self):
-        return len(self.chr)
+        return int(self.startCpG.size)
 
     def rows(self, a, b):
         """rows [a, b) as a new table (beta_to_table walks the table in chunks)"""
+        if self.parsed is not None and not self.extra:
+            return BlocksTable(None, None, None, self.startCpG[a:b], self.endCpG[a:b], self.na[a:b], parsed=self.parsed.rows(a, b))
         return BlocksTable(self.chr[a:b], self.start[a:b], self.end[a:b], self.startCpG[a:b], self.endCpG[a:b], self.na[a:b],
                            {k: v[a:b] for k, v in self.extra.items()})
 
@@ -76,11 +100,42 @@ def _opener(path):
     return open(path, 'r')
 
 
+def _load_blocks_native(blocks_path, nrows):
+    """The library's one-pass parser (include/wgbsseg.h: wgbsseg_blocks_parse) on the file's bytes -> BlocksTable, or None when
+    the library is not built or the file is not a plain table (the line-by-line parser below then handles it and owns the
+    messages).  WGBSSEG_PY_TABLES=1 turns it off (A/B tests)."""
+    if os.environ.get('WGBSSEG_PY_TABLES', '0') not in ('', '0'):
+        return None
+    try:
+        from . import _lib
+        _lib.load()
+    except Exception:
+        return None
+    if blocks_path.endswith('.gz'):
+        import gzip
+        with gzip.open(blocks_path, 'rb') as f:
+            data = f.read()
+    else:
+        with open(blocks_path, 'rb') as f:
+            data = f.read()
+    p = _lib.blocks_parse(data, nrows)
+    if p is None:
+        return None
+    return BlocksTable(None, None, None, p.start_cpg, p.end_cpg, p.na, parsed=p)
+
+
 def load_blocks_file(blocks_path, anno=False, nrows=None):
     """Parse a blocks table (format above).  Fewer than 5 columns, or endCpG < startCpG in a complete row, are errors;
     a file without any row gives an empty table (after the reference's 'Empty blocks file.' note)."""
     if not op.isfile(blocks_path):
         raise IllegalArgumentError(f'Invalid file: {blocks_path}')
+    if not anno:
+        t = _load_blocks_native(blocks_path, nrows)
+        if t is not None:
+            ok = ~t.na
+            if (t.endCpG[ok] < t.startCpG[ok]).any():
+                raise IllegalArgumentError(f'Invalid CpG columns in blocks file {blocks_path}')
+            return t
     want = 7 if anno else 5
     chrom, start, end, scpg, ecpg, na = [], [], [], [], [], []
     extra = None
@@ -136,9 +191,15 @@ def is_block_file_nice(t):
         return False, 'startCpG is not monotonically increasing'
     if n > 1 and (e[1:] < e[:-1]).any():
         return False, 'endCpG is not monotonically increasing'
-    cols = [t.chr, t.start, t.end, s.tolist(), e.tolist()] + [t.extra[k] for k in t.extra]
-    if len(set(zip(*cols))) != n:
-        return False, 'Some blocks are duplicated'
+    # (both CpG columns are in order here: rows that repeat each other have equal CpG columns and stand next to each other)
+    same = np.flatnonzero((s[1:] == s[:-1]) & (e[1:] == e[:-1])) if n > 1 else np.zeros(0, dtype=np.int64)
+    if same.size:
+        idx = np.unique(np.concatenate([same, same + 1]))
+        txt = t.coords_of(idx)
+        ext = [t.extra[k] for k in t.extra]
+        rows = [txt[j] + (int(s[i]), int(e[i])) + tuple(x[i] for x in ext) for j, i in enumerate(idx.tolist())]
+        if len(set(rows)) != len(rows):
+            return False, 'Some blocks are duplicated'
     if n > 1 and (s[1:] < e[:-1]).any():
         return False, 'Some blocks overlap'
     return True, ''
@@ -211,6 +272,10 @@ def trim_to_uint8(data, lbeta=False):
 
 def write_bedgraph(path, t, bin_table):
     """chr, start, end, beta (%.2f; -1 for 0/0), coverage — from the trimmed rows, like the reference's in-place trim."""
+    if t.parsed is not None and bin_table.dtype in (np.uint8, np.uint16) and len(t):
+        from . import _lib
+        _lib.blocks_write_bedgraph(path, t.parsed, bin_table)
+        return
     meth = bin_table[:, 0].astype(np.int64)
     cov = bin_table[:, 1].astype(np.int64)
     with open(path, 'w') as f:

@@ -146,6 +146,20 @@ def betas2table(betas, blocks, groups_file, min_cov, threads=8, verbose=False):
 def dump(outpath, table, first=True, digits=3):
     """Append (or start, with the header) the text of a Table: tab-separated, NA for missing, %.<digits>f floats."""
     own = not hasattr(outpath, 'write') and outpath is not None
+    b = table.blocks
+    if b.parsed is not None and not b.extra and len(b) and (own or outpath is None):
+        # the library prints the rows (include/wgbsseg.h: wgbsseg_blocks_write_table): same bytes as the loop below
+        from . import _lib
+        if own:
+            if first:
+                with open(outpath, 'w') as f:
+                    f.write('\t'.join(b.columns + table.names) + '\n')
+        else:
+            if first:
+                sys.stdout.write('\t'.join(b.columns + table.names) + '\n')
+            sys.stdout.flush()
+        _lib.blocks_write_table(outpath if own else None, b.parsed, table.values, digits, append=True)
+        return
     f = open(outpath, 'w' if first else 'a') if own else (sys.stdout if outpath is None else outpath)
     try:
         b = table.blocks

@@ -24,6 +24,7 @@
 #include "seg_kernels.h"
 #include "stitch.h"
 #include "add_loci.h"
+#include "table_io.h"
 
 namespace {
 
@@ -1800,6 +1801,74 @@ int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom
     }
     if (rc) { set_err(err, errlen, "%s", msg.c_str()); return WGBSSEG_E_ARG; }
     return WGBSSEG_OK;
+}
+
+int wgbsseg_blocks_parse(const char* text, int64_t len, int64_t max_rows, int64_t cap, int64_t* line_off, int32_t* len3,
+                         int64_t* start_cpg, int64_t* end_cpg, uint8_t* na, int64_t* n_rows)
+{
+    if (!n_rows) return WGBSSEG_E_ARG;
+    *n_rows = 0;
+    if (!text || len < 0 || cap < 0 || (cap && (!line_off || !len3 || !start_cpg || !end_cpg || !na))) return WGBSSEG_E_ARG;
+    const int rc = wgtab::parse_blocks(text, len, max_rows, cap, line_off, len3, start_cpg, end_cpg, na, n_rows);
+    return rc == 0 ? WGBSSEG_OK : (rc == 1 ? 1 : WGBSSEG_E_ARG);
+}
+
+namespace {
+int open_for_rows(const char* path, int append, int64_t* base, char* err, size_t errlen)
+{
+    const int fd = open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0666);
+    if (fd < 0) { set_err(err, errlen, "cannot open %s", path); return -1; }
+    const off_t b = append ? lseek(fd, 0, SEEK_END) : 0;
+    if (b < 0) { close(fd); set_err(err, errlen, "cannot seek in %s", path); return -1; }
+    *base = (int64_t)b;
+    return fd;
+}
+}  // namespace
+
+int wgbsseg_blocks_write_table(const char* path, int32_t append, const char* text, const int64_t* line_off, const int32_t* len3,
+                               const int64_t* start_cpg, const int64_t* end_cpg, const uint8_t* na, int64_t n_rows,
+                               const double* values, int64_t n_cols, int64_t stride, int32_t digits, int32_t threads, char* err, size_t errlen)
+{
+    if (n_rows < 0 || n_cols < 0 || stride < n_cols || (n_rows && (!text || !line_off || !len3 || !start_cpg || !end_cpg || !na || (n_cols && !values)))) {
+        set_err(err, errlen, "write_table: bad argument"); return WGBSSEG_E_ARG;
+    }
+    int64_t base = -1;                                   // path NULL: standard output, whatever it is — shards in order
+    const int fd = path ? open_for_rows(path, append, &base, err, errlen) : 1;
+    if (fd < 0) return WGBSSEG_E_ARG;
+    const wgtab::Rows R = {text, line_off, len3, start_cpg, end_cpg, na};
+    std::string msg;
+    const int rc = wgtab::write_table(fd, base, R, n_rows, values, n_cols, stride, digits, threads, msg);
+    if (path && close(fd) != 0 && rc == 0) { set_err(err, errlen, "write to %s failed", path); return WGBSSEG_E_ARG; }
+    if (rc) { set_err(err, errlen, "%s", msg.c_str()); return WGBSSEG_E_ARG; }
+    return WGBSSEG_OK;
+}
+
+int wgbsseg_blocks_write_bedgraph(const char* path, const char* text, const int64_t* line_off, const int32_t* len3, int64_t n_rows,
+                                  const void* rows, int32_t wide, int32_t threads, char* err, size_t errlen)
+{
+    if (!path || n_rows < 0 || (n_rows && (!text || !line_off || !len3 || !rows))) { set_err(err, errlen, "write_bedgraph: bad argument"); return WGBSSEG_E_ARG; }
+    int64_t base = 0;
+    const int fd = open_for_rows(path, 0, &base, err, errlen);
+    if (fd < 0) return WGBSSEG_E_ARG;
+    const wgtab::Rows R = {text, line_off, len3, nullptr, nullptr, nullptr};
+    std::string msg;
+    const int rc = wide ? wgtab::write_bedgraph<uint16_t>(fd, base, R, n_rows, static_cast<const uint16_t*>(rows), threads, msg)
+                        : wgtab::write_bedgraph<uint8_t>(fd, base, R, n_rows, static_cast<const uint8_t*>(rows), threads, msg);
+    if (close(fd) != 0 && rc == 0) { set_err(err, errlen, "write to %s failed", path); return WGBSSEG_E_ARG; }
+    if (rc) { set_err(err, errlen, "%s", msg.c_str()); return WGBSSEG_E_ARG; }
+    return WGBSSEG_OK;
+}
+
+int64_t wgbsseg_format_fixed(const double* v, int64_t n, int32_t digits, char* out, int64_t out_cap)
+{
+    if (n < 0 || (n && (!v || !out))) return -1;
+    char* p = out;
+    for (int64_t i = 0; i < n; i++) {
+        if (out_cap - (p - out) < 420) return -1;
+        p = wgtab::put_fixed(p, v[i], digits);
+        *p++ = '\n';
+    }
+    return (int64_t)(p - out);
 }
 
 int wgbsseg_convert_regions(wgbsseg_ctx* c, const int64_t* chrom_lo, const int64_t* chrom_hi, const int64_t* chrom_bp, const int64_t* start,
