@@ -9,8 +9,12 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <fcntl.h>
+#include <unistd.h>
+#include <cmath>
 #include "stitch.h"
 #include "add_loci.h"
+#include "table_io.h"
 
 static uint64_t mix(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
 
@@ -103,6 +107,58 @@ int main(int argc, char** argv)
         const int r2 = wgadd::add_loci(g, bad_s + i, bad_e + i, 1, nul, 1, m);
         fclose(nul);
         printf("add_loci bad row %d: rc %d %s\n", i, r2, m.c_str());
+    }
+    // the block tools' text paths (table_io.h): a table with a header, comments, NA fields and no last newline through the parser,
+    // the sharded writers (file: pwrite side by side; a pipe-like descriptor: in order) and the number formatter
+    {
+        std::string text = "chr\tstart\tend\tstartCpG\tendCpG\n# c\n\n";
+        const int64_t n_rows = 40000;
+        for (int64_t i = 0; i < n_rows; i++) {
+            char row[96];
+            if (i % 97 == 5) snprintf(row, sizeof row, "chr%d\t%lld\t%lld\tNA\t\n", (int)(1 + i % 22), (long long)(10 * i), (long long)(10 * i + 7));
+            else snprintf(row, sizeof row, "chr%d\t%lld\t%lld\t%lld\t%lld\textra\n", (int)(1 + i % 22), (long long)(10 * i), (long long)(10 * i + 7), (long long)(1 + 2 * i), (long long)(3 + 2 * i));
+            text += row;
+        }
+        text.pop_back();
+        std::vector<int64_t> lo((size_t)n_rows + 8), sc((size_t)n_rows + 8), ec((size_t)n_rows + 8);
+        std::vector<int32_t> l3((size_t)n_rows + 8);
+        std::vector<uint8_t> na((size_t)n_rows + 8);
+        int64_t got = 0;
+        const int prc = wgtab::parse_blocks(text.data(), (int64_t)text.size(), -1, n_rows + 8, lo.data(), l3.data(), sc.data(), ec.data(), na.data(), &got);
+        int64_t n_na = 0;
+        for (int64_t i = 0; i < got; i++) n_na += na[(size_t)i];
+        printf("parse_blocks: rc %d rows %lld na %lld, row 1 = [%lld, %lld)\n", prc, (long long)got, (long long)n_na, (long long)sc[1], (long long)ec[1]);
+        const std::string bad = "chr1\t1\t2\t3.5\t4\n";
+        printf("parse_blocks on a float field: rc %d\n", wgtab::parse_blocks(bad.data(), (int64_t)bad.size(), -1, 4, lo.data(), l3.data(), sc.data(), ec.data(), na.data(), &got));
+        wgtab::parse_blocks(text.data(), (int64_t)text.size(), -1, n_rows + 8, lo.data(), l3.data(), sc.data(), ec.data(), na.data(), &got);
+        const int64_t n_cols = 5;
+        std::vector<double> vals((size_t)(got * n_cols));
+        for (size_t i = 0; i < vals.size(); i++) vals[i] = (mix(i) % 13 == 0) ? std::nan("") : (mix(i) % 11 == 0 ? 1.5e300 : (double)(mix(i) % 100001) / 100000.0);
+        const wgtab::Rows R = {text.data(), lo.data(), l3.data(), sc.data(), ec.data(), na.data()};
+        std::string tpath = std::string(argv[2]) + ".table";
+        uint64_t h = 1469598103934665603ULL;
+        for (int pass = 0; pass < 2; pass++) {                                // 0: regular file, 1: in order (the way a pipe is written)
+            const int fd = open(tpath.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+            std::string m;
+            const int wrc = wgtab::write_table(fd, pass ? -1 : 0, R, got, vals.data(), n_cols, n_cols, 3, atoi(argv[1]), m);
+            close(fd);
+            FILE* f = fopen(tpath.c_str(), "rb");
+            uint64_t hh = 1469598103934665603ULL;
+            int ch;
+            long bytes = 0;
+            while ((ch = fgetc(f)) != EOF) { hh = (hh ^ (uint64_t)ch) * 1099511628211ULL; bytes++; }
+            fclose(f);
+            printf("write_table pass %d: rc %d %s, %ld bytes, checksum %016llx%s\n", pass, wrc, m.c_str(), bytes, (unsigned long long)hh, pass && hh != h ? " DIFFERS" : "");
+            h = hh;
+        }
+        std::vector<uint16_t> mc((size_t)got * 2);
+        for (int64_t i = 0; i < got; i++) { mc[(size_t)(2 * i + 1)] = (uint16_t)(mix((uint64_t)i) % 65536); mc[(size_t)(2 * i)] = (uint16_t)(mc[(size_t)(2 * i + 1)] * (mix((uint64_t)i + 7) % 101) / 100); }
+        const int fd = open(tpath.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        std::string m;
+        const int brc = wgtab::write_bedgraph<uint16_t>(fd, 0, R, got, mc.data(), atoi(argv[1]), m);
+        close(fd);
+        printf("write_bedgraph: rc %d %s\n", brc, m.c_str());
+        unlink(tpath.c_str());
     }
     return 0;
 }
