@@ -171,12 +171,17 @@ def end_to_end(args, buf, sizes, names, loci):
             err = io.StringIO()
             t0 = time.perf_counter()
             with contextlib.redirect_stderr(err):
-                rc = wgbs_tools.main(['wgbstools', 'segment', '--betas'] + paths + ['--genome', ref, '-o', out, '--gpus', '1'])
+                rc = wgbs_tools.main(['wgbstools', 'segment', '--betas'] + paths + ['--genome', ref, '-o', out, '--gpus', '1',
+                                     '--stats', op.join(d, 'run.json')])
             dt = time.perf_counter() - t0
             assert rc == 0, err.getvalue()[-500:]
             if best is None or dt < best:
                 best = dt
-                phases = [l.strip() for l in err.getvalue().splitlines() if 'phases:' in l][-1:]
+                try:
+                    with open(op.join(d, 'run.json')) as f:
+                        phases = [json.load(f).get('phases_s')]
+                except Exception:
+                    phases = []
         rows = sum(1 for _ in open(out))
         return {'wall_s': best, 'value': args.sites / best, 'unit': 'CpG-sites/s', 'bed_rows': rows, 'bed_MB': op.getsize(out) / 1e6,
                 'phases_of_best_run': phases[0] if phases else None,
