@@ -110,6 +110,25 @@ def test_sample_term_forms_match_oracle(exact, pcount):
         assert (got.view(np.uint32) == want.view(np.uint32)).all(), fn
 
 
+def test_sample_term_forms_on_random_pseudo_counts(exact):
+    """The same comparison for pseudo counts nobody chose: 160 floats, log-uniform over 2^-24 .. 2^24, plus the neighbours of
+    every power of two in between (where the exponent of nmeth + pc changes: the k-scaled tables' row index) — all three term
+    modes (plain, fast with guards, guard-free on the k-scaled tables) against the oracle's libm arithmetic."""
+    rng = np.random.default_rng(2024)
+    pcs = list(np.exp2(rng.uniform(-24, 24, 160)).astype(np.float32))
+    for k in range(-6, 22, 3):
+        x = np.float32(2.0 ** k)
+        pcs += [np.nextafter(x, np.float32(0)), x, np.nextafter(x, np.float32(np.inf))]
+    m, t = _term_inputs(12, 60000)
+    for pc in pcs:
+        want = oracle.sample_terms(m, t, float(pc))
+        for fn in (exact.exact_sample_terms, exact.exact_sample_terms_plain):
+            got = np.empty_like(t)
+            fn(m.ctypes.data, t.ctypes.data, t.size, C.c_float(float(pc)), got.ctypes.data)
+            bad = np.flatnonzero(got.view(np.uint32) != want.view(np.uint32))
+            assert bad.size == 0, (float(pc), fn, m[bad[0]], t[bad[0]], got[bad[0]], want[bad[0]])
+
+
 def test_k_scaled_table_forms_are_the_same_functions(exact):
     """wg_fast_log2_ks / wg_log2f_ks (normalisation and exponent term folded into per-(k, i) tables; the narrow scoring
     tiles) against wg_fast_log2(1 - p) and the libm restatement wg_log2f(p) for EVERY float p in [2^-53, 1) whose

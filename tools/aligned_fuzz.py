@@ -39,6 +39,8 @@ for seed in range(first, first + count):
     seg.set_betas(slices); seg.set_loci(loci)
     for draw in range(4):
         pcount = float(rng.choice([0.0, 0.25, 1.0, 3.9999998, 15.0, 100.0, 1e-3]))
+        if rng.random() < 0.3:                                         # a pseudo count nobody chose (its own short-division check, its own table rows)
+            pcount = float(np.float32(np.exp2(rng.uniform(-12, 12))))
         max_cpg = int(rng.choice([2, 17, 59, 60, 61, 64, 65, 127, 128, 129, 130, 193, 300, 1000]))
         max_bp = int(rng.choice([50, 700, 2000, 100000, 100000]))
         starts, lens = [], []
