@@ -316,6 +316,22 @@ int wgbsseg_blocks_write_bedgraph(const char* path, const char* text, const int6
 int64_t wgbsseg_format_fixed(const double* v, int64_t n, int32_t digits, char* out, int64_t out_cap);
 
 /*
+ * The text of `wgbstools convert -L` (convert.py:44-89: pandas.read_csv of a BED table, the two CpG columns inserted after the
+ * third, DataFrame.to_csv).  Host side.  wgbsseg_bed_parse: rows of a BED table whose text can go back out VERBATIM around the
+ * new columns -> per row its offset, the length of "chr \t start \t end" (len3) and of the whole row (row_len), the index of
+ * its chromosome in chrom_names (-1: none of them), start and end.  A FAST PATH like wgbsseg_blocks_parse: returns 1 — and the
+ * caller's own parser takes over — for anything a round trip through pandas would re-print: '#' comments, a header line, rows
+ * of different widths, starts / ends that are not plain integers, columns that read as numbers (they come back as floats) or
+ * hold missing-value spellings other than NA, carriage returns, non-ASCII bytes, an empty table.  *width = fields per row.
+ * wgbsseg_bed_write_annotated: row r as its first len3 bytes, \t startCpG \t endCpG (NA for 0), the rest of the row, \n — to
+ * `path` (truncated first; NULL: standard output).
+ */
+int wgbsseg_bed_parse(const char* text, int64_t len, int64_t cap, const char* const* chrom_names, int32_t n_chroms, int64_t* line_off,
+                      int32_t* len3, int32_t* row_len, int32_t* chrom, int64_t* start, int64_t* end, int64_t* n_rows, int32_t* width);
+int wgbsseg_bed_write_annotated(const char* path, const char* text, const int64_t* line_off, const int32_t* len3, const int32_t* row_len,
+                                const int64_t* start_cpg, const int64_t* end_cpg, int64_t n_rows, int32_t threads, char* err, size_t errlen);
+
+/*
  * pat -> beta: the producer of the path's input (`wgbstools pat2beta`: pat2beta.py:17-44 pipes `gunzip -c x.pat.gz` into
  * the reference's stdin2beta binary, src/pat2beta/stdin2beta.cpp:59-123, and trims the counts with trim_to_uint8,
  * utils_wgbs.py:277-290).  An accumulator holds (#meth, #cov) of the CpGs [start_cpg, end_cpg) (1-based, half-open; the whole

@@ -147,3 +147,98 @@ def test_column_round_trip_and_file_rules(tmp_path, cworld):
 def _write(p, text):
     p.write_text(text)
     return p
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the library's text path for `convert -L` (csrc/table_io.h: wgbsseg_bed_parse / _write_annotated) against the Python path
+# ---------------------------------------------------------------------------------------------------------
+def _python_text(path, cworld, drop):
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        lines = CV.add_cpgs_to_bed(path, cworld['ref'], drop, engine=OracleLociEngine(cworld['loci']))
+    return '\n'.join(lines) + ('\n' if lines else ''), err.getvalue()
+
+
+def _fast_text(path, cworld, drop, out):
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        done = CV.annotate_bed_fast(path, G.GenomeRefPaths(cworld['ref']), drop, out, engine=OracleLociEngine(cworld['loci']))
+    return done, (open(out).read() if done is True else None), err.getvalue()
+
+
+def test_fast_text_path_matches_python_path(cworld, tmp_path, capfd):
+    g = cworld['g']
+    names, sizes, loci = cworld['names'], cworld['sizes'], cworld['loci'].astype(np.int64)
+    cum = np.concatenate([[0], np.cumsum(sizes)])
+    out = str(tmp_path / 'o.bed')
+    taken = 0
+    # the reference's fixtures: the fast path either declines (header ...) or writes the golden text
+    for name, p in cworld['beds'].items():
+        for drop in (False, True):
+            done, text, err = _fast_text(p, cworld, drop, out)
+            want, werr = _python_text(p, cworld, drop)
+            if done is True:
+                taken += 1
+                assert text == want and err == werr, (name, drop)
+                assert text == g['bed'][name]['drop_empty' if drop else 'keep']['text']
+            else:
+                assert done is False
+    assert taken >= 2
+    # tables made here: text columns, integer columns, NA in a text column, unknown chromosomes, regions without CpGs, overlaps
+    # in one chromosome (the per-row rule set), no last newline, blank lines, gzip
+    rng = np.random.default_rng(4)
+    rows = []
+    for i in range(4000):
+        ci = int(rng.integers(0, len(names)))
+        lo = int(loci[cum[ci]]); hi = int(loci[cum[ci + 1] - 1])
+        a = int(rng.integers(max(1, lo - 500), hi + 500))
+        b = a + int(rng.integers(1, 3000))
+        chrom = names[ci] if rng.random() > 0.02 else 'chrUn_%d' % i
+        rows.append([chrom, str(a), str(b), 'name%d' % i if i % 7 else 'NA', str(int(rng.integers(0, 1000))), '+-'[i % 2]])
+    rows.append([names[0], '1', '2', 'tiny', '0', '+'])
+    def write(path, rs, tail='\n', sep_blank=False):
+        with open(path, 'w') as f:
+            f.write(('\n\n' if sep_blank else '') + '\n'.join('\t'.join(r) for r in rs) + tail)
+        return path
+    files = {'six_columns': write(str(tmp_path / 'a.bed'), rows),
+             'three_columns': write(str(tmp_path / 'b.bed'), [r[:3] for r in rows], tail=''),
+             'sorted_no_overlap': write(str(tmp_path / 'c.bed'), sorted([r[:4] for r in rows if r[0] == names[1]][::25], key=lambda r: int(r[1])), sep_blank=True)}
+    import gzip
+    gz = str(tmp_path / 'a.bed.gz')
+    with gzip.open(gz, 'wb') as f:
+        f.write(open(files['six_columns'], 'rb').read())
+    files['gz'] = gz
+    for name, p in files.items():
+        for drop in (False, True):
+            done, text, err = _fast_text(p, cworld, drop, out)
+            want, werr = _python_text(p, cworld, drop)
+            assert done is True, name
+            assert text == want and err == werr, (name, drop)
+    # standard output
+    capfd.readouterr()
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        assert CV.annotate_bed_fast(files['three_columns'], G.GenomeRefPaths(cworld['ref']), False, None, engine=OracleLociEngine(cworld['loci'])) is True
+    assert capfd.readouterr().out == _python_text(files['three_columns'], cworld, False)[0]
+    # what the fast path must decline: whatever a round trip through pandas re-prints, and the malformed
+    base = [names[0], '100', '900']
+    odd = {'header': 'chr\tstart\tend\n' + '\t'.join(base) + '\n', 'comment': '\t'.join(base) + ' # c\n', 'comment_line': '# c\n' + '\t'.join(base) + '\n',
+           'ragged_short': '\t'.join(base + ['x']) + '\n' + '\t'.join(base) + '\n', 'ragged_long': '\t'.join(base) + '\n' + '\t'.join(base + ['x']) + '\n',
+           'float_column': '\t'.join(base + ['0.50']) + '\n' + '\t'.join(base + ['1']) + '\n', 'int_with_na': '\t'.join(base + ['5']) + '\n' + '\t'.join(base + ['NA']) + '\n',
+           'plus_int': '\t'.join(base + ['+5']) + '\n', 'leading_zero_start': names[0] + '\t0100\t900\n', 'spaced_start': names[0] + '\t 100\t900\n',
+           'empty_field_in_text': '\t'.join(base + ['abc']) + '\n' + '\t'.join(base + ['']) + '\n', 'nan_in_text': '\t'.join(base + ['abc']) + '\n' + '\t'.join(base + ['nan']) + '\n',
+           'crlf': '\t'.join(base) + '\r\n', 'two_columns': names[0] + '\t5\n', 'empty': '', 'utf8': 'chré\t1\t2\n', 'inf_column': '\t'.join(base + ['inf']) + '\n',
+           'form_feed': '\t'.join(base + ['a\x0cb']) + '\n', 'float_start': names[0] + '\t100.0\t900\n', 'big_start': names[0] + '\t1234567890123456\t1234567890123457\n'}
+    from wgbs_tools_amd import _lib
+    for name, text in odd.items():
+        assert _lib.bed_parse(text.encode('utf-8'), names) is None, name
+    # ... while their neighbours are taken
+    for name, text in {'na_in_text': '\t'.join(base + ['abc']) + '\n' + '\t'.join(base + ['NA']) + '\n', 'int_column': '\t'.join(base + ['5']) + '\n' + '\t'.join(base + ['0']) + '\n',
+                       'numbers_in_text': '\t'.join(base + ['0.50']) + '\n' + '\t'.join(base + ['x']) + '\n', 'numeric_chrom': '1\t100\t900\n2\t5\t9\n',
+                       'zero_start': names[0] + '\t0\t900\n'}.items():
+        p = str(tmp_path / (name + '.bed'))
+        open(p, 'w').write(text)
+        assert _lib.bed_parse(text.encode('utf-8'), names) is not None, name
+        done, got, err = _fast_text(p, cworld, False, out)
+        want, werr = _python_text(p, cworld, False)
+        assert done is True and got == want and err == werr, name

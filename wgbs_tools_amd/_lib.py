@@ -27,7 +27,7 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_convert_regions', 'wgbsseg_patbeta_create', 'wgbsseg_patbeta_feed', 'wgbsseg_patbeta_finish',
            'wgbsseg_patbeta_destroy', 'wgbsseg_group_load_host_async', 'wgbsseg_group_load_wait',
            'wgbsseg_marker_stats', 'wgbsseg_blocks_parse', 'wgbsseg_blocks_write_table', 'wgbsseg_blocks_write_bedgraph',
-           'wgbsseg_format_fixed']
+           'wgbsseg_format_fixed', 'wgbsseg_bed_parse', 'wgbsseg_bed_write_annotated']
 
 
 class NativeLibraryError(RuntimeError):
@@ -199,6 +199,10 @@ def load():
     L.wgbsseg_blocks_write_bedgraph.argtypes = [C.c_char_p, vp, vp, vp, i64, vp, i32, i32, C.c_char_p, C.c_size_t]
     L.wgbsseg_format_fixed.restype = i64
     L.wgbsseg_format_fixed.argtypes = [vp, i64, i32, vp, i64]
+    L.wgbsseg_bed_parse.restype = i32
+    L.wgbsseg_bed_parse.argtypes = [vp, i64, i64, C.POINTER(C.c_char_p), i32, vp, vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i32)]
+    L.wgbsseg_bed_write_annotated.restype = i32
+    L.wgbsseg_bed_write_annotated.argtypes = [C.c_char_p, vp, vp, vp, vp, vp, vp, i64, i32, C.c_char_p, C.c_size_t]
     _lib = L
     return L
 
@@ -754,3 +758,52 @@ def format_fixed(values, digits):
     if n < 0:
         raise ValueError('format_fixed: buffer too small')
     return out[:n].tobytes().decode('ascii').split('\n')[:-1]
+
+
+class ParsedBed:
+    """What wgbsseg_bed_parse leaves: the table's bytes and, per row, its offset, the length of `chr \\t start \\t end` and of the
+    whole row, the chromosome's index in the names given (-1: unknown), start and end."""
+
+    def __init__(self, text, line_off, len3, row_len, chrom_idx, start, end, width):
+        self.text, self.line_off, self.len3, self.row_len = text, line_off, len3, row_len
+        self.chrom_idx, self.start, self.end, self.width = chrom_idx, start, end, width
+
+    def __len__(self):
+        return self.line_off.size
+
+
+def bed_parse(data, chrom_names):
+    """wgbsseg_bed_parse -> ParsedBed, or None when the table is not one whose rows can be written back verbatim."""
+    L = load()
+    text = np.frombuffer(data, dtype=np.uint8)
+    if text.size == 0:
+        return None
+    cap = (data.count(b'\n') if isinstance(data, (bytes, bytearray)) else int(np.count_nonzero(text == 10))) + 1
+    line_off = np.empty(cap, dtype=np.int64)
+    len3 = np.empty(cap, dtype=np.int32)
+    row_len = np.empty(cap, dtype=np.int32)
+    chrom = np.empty(cap, dtype=np.int32)
+    start = np.empty(cap, dtype=np.int64)
+    end = np.empty(cap, dtype=np.int64)
+    names = (C.c_char_p * len(chrom_names))(*[str(n).encode() for n in chrom_names])
+    n = C.c_int64(0)
+    w = C.c_int32(0)
+    rc = L.wgbsseg_bed_parse(text.ctypes.data, text.size, cap, names, len(chrom_names), line_off.ctypes.data, len3.ctypes.data,
+                             row_len.ctypes.data, chrom.ctypes.data, start.ctypes.data, end.ctypes.data, C.byref(n), C.byref(w))
+    if rc != OK:
+        return None
+    k = int(n.value)
+    return ParsedBed(text, line_off[:k], len3[:k], row_len[:k], chrom[:k], start[:k], end[:k], int(w.value))
+
+
+def bed_write_annotated(path, parsed, start_cpg, end_cpg, keep=None, threads=0):
+    """wgbsseg_bed_write_annotated: the rows of `parsed` (those with keep[r], when given) with the two CpG columns, to `path` (None:
+    the process's standard output; flush sys.stdout first)."""
+    L = load()
+    sel = (lambda a, dt: np.ascontiguousarray(a if keep is None else a[keep], dtype=dt))
+    lo, l3, rl = sel(parsed.line_off, np.int64), sel(parsed.len3, np.int32), sel(parsed.row_len, np.int32)
+    s, e = sel(start_cpg, np.int64), sel(end_cpg, np.int64)
+    err = C.create_string_buffer(ERRLEN)
+    rc = L.wgbsseg_bed_write_annotated(None if path is None else os.fsencode(path), parsed.text.ctypes.data, lo.ctypes.data, l3.ctypes.data,
+                                       rl.ctypes.data, s.ctypes.data, e.ctypes.data, lo.size, int(threads), err, ERRLEN)
+    _check(rc, err)

@@ -149,15 +149,24 @@ def regions_to_cpgs(table, genome, engine=None, device=0):
     names, sizes = genome.get_chrom_cpg_sizes()
     cum = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     index = {c: i for i, c in enumerate(names)}
-    ci = np.array([index.get(c, -1) for c in table.chr], dtype=np.int64)
+    if getattr(table, 'chrom_idx', None) is not None:          # (the library's parser has looked the names up already)
+        ci = np.asarray(table.chrom_idx, dtype=np.int64)
+        present = sorted(names[i] for i in np.unique(ci[ci >= 0]).tolist())
+    else:
+        ci = np.array([index.get(c, -1) for c in table.chr], dtype=np.int64)
+        present = sorted(set(table.chr) & set(names))
     known = ci >= 0
     slow = np.zeros(len(table), dtype=np.uint8)
-    for c in sorted(set(table.chr) & set(names)):              # the reference walks the chromosomes in sorted order (its warnings too)
+    for c in present:                                          # the reference walks the chromosomes in sorted order (its warnings too)
         rows = np.flatnonzero(ci == index[c])
-        uniq = np.unique(np.stack([table.start[rows], table.end[rows]], axis=1), axis=0)     # duplicates do not count as overlaps
-        o = np.argsort(uniq[:, 0], kind='stable')
-        if (uniq[o, 0][1:] - uniq[o, 1][:-1] < 0).any():
-            if uniq.shape[0] > 30:
+        st, en = table.start[rows], table.end[rows]
+        o = np.lexsort((en, st))                               # by start, then end; duplicates do not count as overlaps
+        st, en = st[o], en[o]
+        first = np.ones(st.size, dtype=bool)
+        first[1:] = (st[1:] != st[:-1]) | (en[1:] != en[:-1])
+        st, en = st[first], en[first]
+        if (st[1:] - en[:-1] < 0).any():
+            if st.size > 30:
                 eprint(f'[wt convert] [{c}] WARNING: Found overlaps in the input bed file. Conversion may be slow.\n'
                        '             Install bedtools for better performance')
             slow[rows] = 1
@@ -186,12 +195,76 @@ def add_cpgs_to_bed(bed_file, genome, drop_empty, threads=1, add_anno=False, eng
     return ['\t'.join(c[i] for c in cols) for i in np.flatnonzero(keep).tolist()]
 
 
+class FastBedTable:
+    """A BED table the library's parser has read (include/wgbsseg.h: wgbsseg_bed_parse): start, end and the chromosome index of
+    every row as arrays, the text left where it is — the annotated rows are written from it by wgbsseg_bed_write_annotated."""
+
+    def __init__(self, parsed):
+        self.parsed, self.start, self.end, self.chrom_idx = parsed, parsed.start, parsed.end, parsed.chrom_idx
+
+    def __len__(self):
+        return len(self.parsed)
+
+
+def load_bed_fast(bed_file, genome):
+    """-> FastBedTable, or None when the table needs the line-by-line parser (see wgbsseg_bed_parse for what qualifies), the
+    library is not built, or WGBSSEG_PY_TABLES=1 asks for the Python path (A/B tests)."""
+    if os.environ.get('WGBSSEG_PY_TABLES', '0') not in ('', '0'):
+        return None
+    try:
+        from . import _lib
+        _lib.load()
+    except Exception:
+        return None
+    if hasattr(bed_file, 'read'):
+        raw = getattr(bed_file, 'buffer', None)
+        if raw is None:
+            return None                                          # a text stream without its bytes (tests): the Python parser
+        data = raw.read()
+    elif str(bed_file).endswith('.gz'):
+        import gzip
+        with gzip.open(bed_file, 'rb') as f:
+            data = f.read()
+    else:
+        with open(bed_file, 'rb') as f:
+            data = f.read()
+    names, _ = genome.get_chrom_cpg_sizes()
+    p = _lib.bed_parse(data, list(names))
+    if p is None:
+        return None if not hasattr(bed_file, 'read') else data   # (standard input cannot be read twice: hand the bytes back)
+    return FastBedTable(p)
+
+
+def annotate_bed_fast(bed_file, genome, drop_empty, out_path, engine=None, device=0):
+    """`convert -L` without a Python object per row: the library parses the table, the device joins, the library prints (same
+    bytes as add_cpgs_to_bed's lines: tests/test_convert_cpu.py).  -> True when done; False (or the bytes read from a stream)
+    when the table needs the line-by-line path."""
+    fast = load_bed_fast(bed_file, genome)
+    if not isinstance(fast, FastBedTable):
+        return fast if isinstance(fast, (bytes, bytearray)) else False
+    from . import _lib
+    s, e = regions_to_cpgs(fast, genome, engine, device)
+    keep = (s != 0) if drop_empty else None
+    to_stdout = out_path is None or out_path is sys.stdout
+    if to_stdout:
+        sys.stdout.flush()
+    _lib.bed_write_annotated(None if to_stdout else out_path, fast.parsed, s, e, keep)
+    return True
+
+
 def convert_bed_file(args):
     """convert.py:44-74"""
     out_path = sys.stdout if args.out_path is None else args.out_path
     if not delete_or_skip(out_path, args.force):
         return
     bed_file = sys.stdin if args.bed_file == '-' else args.bed_file
+    g = args.genome if isinstance(args.genome, GenomeRefPaths) else GenomeRefPaths(args.genome)
+    done = annotate_bed_fast(bed_file, g, args.drop_empty, out_path, device=args.device)
+    if done is True:
+        return
+    if isinstance(done, (bytes, bytearray)):                     # standard input, already consumed: its bytes for the parser below
+        import io
+        bed_file = io.StringIO(done.decode('utf-8'))
     lines = add_cpgs_to_bed(bed_file, args.genome, args.drop_empty, args.threads, device=args.device)
     text = '\n'.join(lines) + ('\n' if lines else '')
     if out_path is sys.stdout:

@@ -1859,6 +1859,30 @@ int wgbsseg_blocks_write_bedgraph(const char* path, const char* text, const int6
     return WGBSSEG_OK;
 }
 
+int wgbsseg_bed_parse(const char* text, int64_t len, int64_t cap, const char* const* chrom_names, int32_t n_chroms, int64_t* line_off,
+                      int32_t* len3, int32_t* row_len, int32_t* chrom, int64_t* start, int64_t* end, int64_t* n_rows, int32_t* width)
+{
+    if (!n_rows || !width) return WGBSSEG_E_ARG;
+    *n_rows = 0; *width = 0;
+    if (!text || len < 0 || cap < 0 || n_chroms < 0 || (n_chroms && !chrom_names) || (cap && (!line_off || !len3 || !row_len || !chrom || !start || !end))) return WGBSSEG_E_ARG;
+    const int rc = wgtab::parse_bed(text, len, cap, chrom_names, n_chroms, line_off, len3, row_len, chrom, start, end, n_rows, width);
+    return rc == 0 ? WGBSSEG_OK : (rc == 1 ? 1 : WGBSSEG_E_ARG);
+}
+
+int wgbsseg_bed_write_annotated(const char* path, const char* text, const int64_t* line_off, const int32_t* len3, const int32_t* row_len,
+                                const int64_t* start_cpg, const int64_t* end_cpg, int64_t n_rows, int32_t threads, char* err, size_t errlen)
+{
+    if (n_rows < 0 || (n_rows && (!text || !line_off || !len3 || !row_len || !start_cpg || !end_cpg))) { set_err(err, errlen, "bed_write_annotated: bad argument"); return WGBSSEG_E_ARG; }
+    int64_t base = -1;                                   // path NULL: standard output
+    const int fd = path ? open_for_rows(path, 0, &base, err, errlen) : 1;
+    if (fd < 0) return WGBSSEG_E_ARG;
+    std::string msg;
+    const int rc = wgtab::write_annotated_bed(fd, base, text, line_off, len3, row_len, start_cpg, end_cpg, n_rows, threads, msg);
+    if (path && close(fd) != 0 && rc == 0) { set_err(err, errlen, "write to %s failed", path); return WGBSSEG_E_ARG; }
+    if (rc) { set_err(err, errlen, "%s", msg.c_str()); return WGBSSEG_E_ARG; }
+    return WGBSSEG_OK;
+}
+
 int64_t wgbsseg_format_fixed(const double* v, int64_t n, int32_t digits, char* out, int64_t out_cap)
 {
     if (n < 0 || (n && (!v || !out))) return -1;
