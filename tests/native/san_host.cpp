@@ -158,6 +158,39 @@ int main(int argc, char** argv)
         const int brc = wgtab::write_bedgraph<uint16_t>(fd, 0, R, got, mc.data(), atoi(argv[1]), m);
         close(fd);
         printf("write_bedgraph: rc %d %s\n", brc, m.c_str());
+        // `convert -L`: a BED table with a text, an integer and a strand column, unknown chromosomes, blank lines
+        std::string bed = "\n";
+        const char* cn[3] = {"chr1", "chr2", "chrX"};
+        const int64_t nb = 50000;
+        for (int64_t i = 0; i < nb; i++) {
+            char row[128];
+            snprintf(row, sizeof row, "%s\t%lld\t%lld\t%s%lld\t%lld\t%c\n", i % 211 == 3 ? "chrUn" : cn[i % 3], (long long)(100 + 7 * i), (long long)(300 + 7 * i),
+                     i % 5 ? "n" : "NA", (long long)(i % 5 ? i : 0), (long long)(i % 1000), i % 2 ? '+' : '-');
+            if (i % 5 == 0) { std::string r2 = row; const size_t k = r2.find("NA0"); r2.replace(k, 3, "NA"); bed += r2; } else bed += row;
+        }
+        std::vector<int64_t> blo((size_t)nb + 4), bs((size_t)nb + 4), be((size_t)nb + 4);
+        std::vector<int32_t> bl3((size_t)nb + 4), brl((size_t)nb + 4), bci((size_t)nb + 4);
+        int64_t bn = 0;
+        int32_t bw = 0;
+        const int brc2 = wgtab::parse_bed(bed.data(), (int64_t)bed.size(), nb + 4, cn, 3, blo.data(), bl3.data(), brl.data(), bci.data(), bs.data(), be.data(), &bn, &bw);
+        int64_t unknown = 0;
+        for (int64_t i = 0; i < bn; i++) unknown += bci[(size_t)i] < 0;
+        printf("parse_bed: rc %d rows %lld width %d unknown %lld\n", brc2, (long long)bn, (int)bw, (long long)unknown);
+        const std::string fl = "chr1\t1\t2\t0.5\n";
+        printf("parse_bed on a float column: rc %d\n", wgtab::parse_bed(fl.data(), (int64_t)fl.size(), 4, cn, 3, blo.data(), bl3.data(), brl.data(), bci.data(), bs.data(), be.data(), &bn, &bw));
+        wgtab::parse_bed(bed.data(), (int64_t)bed.size(), nb + 4, cn, 3, blo.data(), bl3.data(), brl.data(), bci.data(), bs.data(), be.data(), &bn, &bw);
+        std::vector<int64_t> cs((size_t)bn), ce((size_t)bn);
+        for (int64_t i = 0; i < bn; i++) { cs[(size_t)i] = bci[(size_t)i] < 0 ? 0 : 1 + i; ce[(size_t)i] = bci[(size_t)i] < 0 ? 0 : 4 + i; }
+        const int fd2 = open(tpath.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        const int arc = wgtab::write_annotated_bed(fd2, 0, bed.data(), blo.data(), bl3.data(), brl.data(), cs.data(), ce.data(), bn, atoi(argv[1]), m);
+        close(fd2);
+        FILE* f2 = fopen(tpath.c_str(), "rb");
+        uint64_t h2 = 1469598103934665603ULL;
+        int ch2;
+        long bytes2 = 0;
+        while ((ch2 = fgetc(f2)) != EOF) { h2 = (h2 ^ (uint64_t)ch2) * 1099511628211ULL; bytes2++; }
+        fclose(f2);
+        printf("write_annotated_bed: rc %d %s, %ld bytes, checksum %016llx\n", arc, m.c_str(), bytes2, (unsigned long long)h2);
         unlink(tpath.c_str());
     }
     return 0;

@@ -228,13 +228,13 @@ def test_fast_text_path_matches_python_path(cworld, tmp_path, capfd):
            'plus_int': '\t'.join(base + ['+5']) + '\n', 'leading_zero_start': names[0] + '\t0100\t900\n', 'spaced_start': names[0] + '\t 100\t900\n',
            'empty_field_in_text': '\t'.join(base + ['abc']) + '\n' + '\t'.join(base + ['']) + '\n', 'nan_in_text': '\t'.join(base + ['abc']) + '\n' + '\t'.join(base + ['nan']) + '\n',
            'crlf': '\t'.join(base) + '\r\n', 'two_columns': names[0] + '\t5\n', 'empty': '', 'utf8': 'chré\t1\t2\n', 'inf_column': '\t'.join(base + ['inf']) + '\n',
-           'form_feed': '\t'.join(base + ['a\x0cb']) + '\n', 'float_start': names[0] + '\t100.0\t900\n', 'big_start': names[0] + '\t1234567890123456\t1234567890123457\n'}
+           'form_feed': '\t'.join(base + ['a\x0cb']) + '\n', 'float_start': names[0] + '\t100.0\t900\n', 'exponent_like': '\t'.join(base + ['1e5']) + '\n' + '\t'.join(base + ['e10']) + '\n', 'underscore_number': '\t'.join(base + ['1_000']) + '\n', 'big_start': names[0] + '\t1234567890123456\t1234567890123457\n'}
     from wgbs_tools_amd import _lib
     for name, text in odd.items():
         assert _lib.bed_parse(text.encode('utf-8'), names) is None, name
     # ... while their neighbours are taken
     for name, text in {'na_in_text': '\t'.join(base + ['abc']) + '\n' + '\t'.join(base + ['NA']) + '\n', 'int_column': '\t'.join(base + ['5']) + '\n' + '\t'.join(base + ['0']) + '\n',
-                       'numbers_in_text': '\t'.join(base + ['0.50']) + '\n' + '\t'.join(base + ['x']) + '\n', 'numeric_chrom': '1\t100\t900\n2\t5\t9\n',
+                       'numbers_in_text': '\t'.join(base + ['0.50']) + '\n' + '\t'.join(base + ['x']) + '\n', 'numeric_chrom': '1\t100\t900\n2\t5\t9\n', 'letters_and_digits': '\t'.join(base + ['n1', 'a2', '+']) + '\n' + '\t'.join(base + ['f3', 'NA', '-']) + '\n',
                        'zero_start': names[0] + '\t0\t900\n'}.items():
         p = str(tmp_path / (name + '.bed'))
         open(p, 'w').write(text)

@@ -307,18 +307,19 @@ inline bool canonical_uint(const char* a, size_t n, size_t max_digits)     // di
 }
 
 // A token that float() surely cannot parse: it has a character no float literal has (digits, sign, point, underscore, exponent,
-// white space, the letters of "infinity" / "nan"), or it has no digit and is not one of those words.
+// white space, the letters of "infinity" / "nan"), or it mixes digits with those letters, or it has no digit and is not one of
+// those words.  (False for everything else, numbers or not: the caller only needs certainty in one direction.)
 inline bool surely_text(const char* a, size_t n)
 {
-    bool digit = false;
+    bool digit = false, word = false;
     for (size_t i = 0; i < n; i++) {
         const char c = a[i];
         if (c >= '0' && c <= '9') { digit = true; continue; }
-        const bool ok = c == '+' || c == '-' || c == '.' || c == '_' || c == 'e' || c == 'E' || c == ' ' || (c >= 9 && c <= 13) ||
-                        c == 'i' || c == 'I' || c == 'n' || c == 'N' || c == 'f' || c == 'F' || c == 't' || c == 'T' || c == 'y' || c == 'Y' || c == 'a' || c == 'A';
-        if (!ok) return true;
+        if (c == '+' || c == '-' || c == '.' || c == '_' || c == 'e' || c == 'E' || c == ' ' || (c >= 9 && c <= 13)) continue;
+        if (c == 'i' || c == 'I' || c == 'n' || c == 'N' || c == 'f' || c == 'F' || c == 't' || c == 'T' || c == 'y' || c == 'Y' || c == 'a' || c == 'A') { word = true; continue; }
+        return true;
     }
-    if (digit) return false;                                       // looks numeric: not this function's call
+    if (digit) return word;                                        // digits and a letter of inf / nan: neither a number nor a word; digits alone: maybe a number
     size_t lo = 0, hi = n;
     while (lo < hi && (a[lo] == ' ' || (a[lo] >= 9 && a[lo] <= 13))) lo++;
     while (hi > lo && (a[hi - 1] == ' ' || (a[hi - 1] >= 9 && a[hi - 1] <= 13))) hi--;
