@@ -297,6 +297,9 @@ int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom
  * with fewer than five fields, a CpG field that is neither digits nor a missing-value spelling, carriage returns, non-ASCII
  * bytes, no row at all — and the caller then parses it line by line (the Python host owns those cases and their messages).
  * WGBSSEG_E_ARG: more than `cap` rows (cap = number of '\n' + 1 always suffices).
+ * Optional outputs (NULL: not wanted): bp_start / bp_end = the rows' second and third fields as integers, valid when *bp_ok = 1
+ * (every row's are plain digits) — `find_markers` filters blocks by their length in base pairs; *first_fields = fields (at most
+ * 7) of the first line that is neither a comment nor blank: a table has the two annotation columns when that line has 7.
  *
  * wgbsseg_blocks_write_table: one output row per parsed row r: its "chr \t start \t end" bytes, startCpG, endCpG (NA where
  * na[r]), then values[r * stride + c], c < n_cols, as printf("%.<digits>f") (NaN: NA), tab-separated, '\n'; appended to `path`
@@ -307,7 +310,8 @@ int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom
  * when out_cap is too small.
  */
 int wgbsseg_blocks_parse(const char* text, int64_t len, int64_t max_rows, int64_t cap, int64_t* line_off, int32_t* len3,
-                         int64_t* start_cpg, int64_t* end_cpg, uint8_t* na, int64_t* n_rows);
+                         int64_t* start_cpg, int64_t* end_cpg, uint8_t* na, int64_t* n_rows,
+                         int64_t* bp_start, int64_t* bp_end, int32_t* bp_ok, int32_t* first_fields);
 int wgbsseg_blocks_write_table(const char* path, int32_t append, const char* text, const int64_t* line_off, const int32_t* len3,
                                const int64_t* start_cpg, const int64_t* end_cpg, const uint8_t* na, int64_t n_rows,
                                const double* values, int64_t n_cols, int64_t stride, int32_t digits, int32_t threads, char* err, size_t errlen);

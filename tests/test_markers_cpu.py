@@ -101,3 +101,48 @@ def test_parameters_and_errors(mworld, tmp_path):
         FM.MarkerFinder(FM.MFParams(FM.parse_args(base + ['--targets', 'Livr'])))
     assert 'Invalid group: Livr' in err.getvalue() and 'Did you mean Liver?' in err.getvalue()
     assert FM.descending_order([3.0, np.nan, 5.0, 1.0]).tolist() == [2, 0, 3, 1]
+
+
+def test_library_parsed_table_is_the_python_parsed_table(mworld, tmp_path, monkeypatch):
+    """find_markers on the blocks table the library parsed (bytes + row offsets; bp columns as integers; annotation columns cut out
+    for the markers' rows only) against the line-by-line Python table: same filters, same rows, same output files — with and
+    without the two annotation columns, with a header, and for the sub-tables take() makes."""
+    fast = B2B.load_blocks_file(mworld['blocks'], anno=True)
+    assert fast.parsed is not None and fast.parsed.bp_start is not None
+    monkeypatch.setenv('WGBSSEG_PY_TABLES', '1')
+    slow = B2B.load_blocks_file(mworld['blocks'], anno=True)
+    monkeypatch.delenv('WGBSSEG_PY_TABLES')
+    assert slow.parsed is None and list(fast.extra) == list(slow.extra) and fast.columns == slow.columns
+    assert fast.parsed.bp_start.tolist() == [int(x) for x in slow.start] and fast.parsed.bp_end.tolist() == [int(x) for x in slow.end]
+    idx = np.array([0, 5, 17, len(slow) - 1, 3])
+    sub_f, sub_s = fast.take(idx), slow.take(idx)
+    assert sub_f.coords_of(np.arange(5)) == sub_s.coords_of(np.arange(5)) == [(slow.chr[i], slow.start[i], slow.end[i]) for i in idx]
+    assert sub_f.extras_of([1, 4]) == sub_s.extras_of([1, 4])
+    assert sub_f.chr == sub_s.chr and sub_f.startCpG.tolist() == sub_s.startCpG.tolist()
+    for k in slow.extra:
+        assert fast.extra[k] == slow.extra[k]
+    # an annotated table (7 columns, a header, an NA row, a short row) through both parsers and through find_markers
+    rows = open(mworld['blocks']).read().splitlines()
+    anno = tmp_path / 'anno.bed'
+    with open(anno, 'w') as f:
+        f.write('chr\tstart\tend\tstartCpG\tendCpG\tanno\tgene\n')
+        for i, r in enumerate(rows):
+            tok = r.split('\t')[:5]
+            f.write('\t'.join(tok + (['exon' if i % 3 else '', 'GENE%d' % i] if i % 11 else ['intron'])) + '\n')
+        f.write('chr1\t5\t9\tNA\tNA\tx\ty')
+    a = B2B.load_blocks_file(str(anno), anno=True)
+    monkeypatch.setenv('WGBSSEG_PY_TABLES', '1')
+    b = B2B.load_blocks_file(str(anno), anno=True)
+    monkeypatch.delenv('WGBSSEG_PY_TABLES')
+    assert a.parsed is not None and b.parsed is None and list(a.extra) == ['anno', 'gene'] == list(b.extra)
+    assert a.extras_of(np.arange(len(a))) == {k: list(v) for k, v in b.extra.items()} and a.chr == b.chr and a.na.tolist() == b.na.tolist()
+    outs = {}
+    for mode in ('fast', 'python'):
+        if mode == 'python':
+            monkeypatch.setenv('WGBSSEG_PY_TABLES', '1')
+        od = str(tmp_path / mode)
+        w = dict(mworld, blocks=str(anno))
+        run_case(w, ['--min_cpg', '1'], od, OracleMarkerEngine)
+        outs[mode] = {f: open(op.join(od, f)).read() for f in sorted(__import__('os').listdir(od)) if f.startswith('Markers.')}
+    monkeypatch.delenv('WGBSSEG_PY_TABLES')
+    assert outs['fast'] == outs['python'] and outs['fast'] and any('GENE' in t for t in outs['fast'].values())

@@ -192,7 +192,7 @@ def load():
     L.wgbsseg_add_loci.restype = i32
     L.wgbsseg_add_loci.argtypes = [vp, i64, vp, C.POINTER(C.c_char_p), i32, vp, vp, i64, C.c_char_p, i32, i32, C.c_char_p, C.c_size_t]
     L.wgbsseg_blocks_parse.restype = i32
-    L.wgbsseg_blocks_parse.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, C.POINTER(i64)]
+    L.wgbsseg_blocks_parse.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, C.POINTER(i64), vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.wgbsseg_blocks_write_table.restype = i32
     L.wgbsseg_blocks_write_table.argtypes = [C.c_char_p, i32, vp, vp, vp, vp, vp, vp, i64, vp, i64, i64, i32, i32, C.c_char_p, C.c_size_t]
     L.wgbsseg_blocks_write_bedgraph.restype = i32
@@ -671,22 +671,42 @@ def add_loci(loci, chrom_names, chrom_cum, start_cpg, end_cpg, path=None, append
 # ------------------------------------------------------------------------------------------------------------
 class ParsedBlocks:
     """What wgbsseg_blocks_parse leaves: the table's bytes and, per row, where it begins, how long its `chr \\t start \\t end`
-    text is, the two CpG columns (int64, 0 where missing) and the missing flags."""
+    text is, the two CpG columns (int64, 0 where missing) and the missing flags; bp_start / bp_end (the second and third fields as
+    integers) when every row's are plain digits, else None; first_fields = fields of the first non-comment line (at most 7)."""
 
-    def __init__(self, text, line_off, len3, start_cpg, end_cpg, na):
+    def __init__(self, text, line_off, len3, start_cpg, end_cpg, na, bp_start=None, bp_end=None, first_fields=0, data=None):
         self.text, self.line_off, self.len3, self.start_cpg, self.end_cpg, self.na = text, line_off, len3, start_cpg, end_cpg, na
+        self.bp_start, self.bp_end, self.first_fields, self.data = bp_start, bp_end, first_fields, data
 
     def __len__(self):
         return self.line_off.size
 
-    def rows(self, a, b):
-        return ParsedBlocks(self.text, self.line_off[a:b], self.len3[a:b], self.start_cpg[a:b], self.end_cpg[a:b], self.na[a:b])
+    def take(self, idx):
+        """rows idx (a slice or an index array) as a new ParsedBlocks over the same bytes"""
+        cut = (lambda a: None if a is None else a[idx])
+        return ParsedBlocks(self.text, self.line_off[idx], self.len3[idx], self.start_cpg[idx], self.end_cpg[idx], self.na[idx],
+                            cut(self.bp_start), cut(self.bp_end), self.first_fields, self.data)
 
-    def coords(self):
-        """-> (chr, start, end) lists of str: the first three fields of every row, as the file has them"""
+    def rows(self, a, b):
+        return self.take(slice(a, b))
+
+    def coords(self, idx=None):
+        """-> (chr, start, end) lists of str: the first three fields of every row (of the rows idx), as the file has them"""
         t = self.text
-        parts = [bytes(t[o:o + l]).decode('ascii').split('\t') for o, l in zip(self.line_off.tolist(), self.len3.tolist())]
+        lo, l3 = (self.line_off, self.len3) if idx is None else (self.line_off[idx], self.len3[idx])
+        parts = [bytes(t[o:o + l]).decode('ascii').split('\t') for o, l in zip(lo.tolist(), l3.tolist())]
         return [p[0] for p in parts], [p[1] for p in parts], [p[2] for p in parts]
+
+    def fields(self, idx, first, count):
+        """-> `count` lists of str: fields first .. first+count-1 of the rows idx ('' where a row has fewer)"""
+        data = self.data if self.data is not None else self.text.tobytes()
+        cols = [[] for _ in range(count)]
+        for o in (self.line_off if idx is None else self.line_off[idx]).tolist():
+            e = data.find(b'\n', o)
+            tok = data[o:(len(data) if e < 0 else e)].decode('ascii').split('\t')
+            for c in range(count):
+                cols[c].append(tok[first + c] if len(tok) > first + c else '')
+        return cols
 
     def _ptrs(self):
         self.line_off = np.ascontiguousarray(self.line_off, dtype=np.int64)
@@ -713,13 +733,19 @@ def blocks_parse(data, max_rows=None):
     s = np.empty(cap, dtype=np.int64)
     e = np.empty(cap, dtype=np.int64)
     na = np.empty(cap, dtype=np.uint8)
+    b0 = np.empty(cap, dtype=np.int64)
+    b1 = np.empty(cap, dtype=np.int64)
     n = C.c_int64(0)
+    ok = C.c_int32(0)
+    ff = C.c_int32(0)
     rc = L.wgbsseg_blocks_parse(text.ctypes.data, text.size, -1 if max_rows is None else int(max_rows), cap, line_off.ctypes.data,
-                                len3.ctypes.data, s.ctypes.data, e.ctypes.data, na.ctypes.data, C.byref(n))
+                                len3.ctypes.data, s.ctypes.data, e.ctypes.data, na.ctypes.data, C.byref(n), b0.ctypes.data, b1.ctypes.data,
+                                C.byref(ok), C.byref(ff))
     if rc != OK:
         return None
     k = int(n.value)
-    return ParsedBlocks(text, line_off[:k], len3[:k], s[:k], e[:k], na[:k])
+    return ParsedBlocks(text, line_off[:k], len3[:k], s[:k], e[:k], na[:k], b0[:k] if ok.value else None, b1[:k] if ok.value else None,
+                        int(ff.value), data if isinstance(data, bytes) else None)
 
 
 def blocks_write_table(path, parsed, values, digits, append=True, threads=0):

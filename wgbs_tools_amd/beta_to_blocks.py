@@ -33,11 +33,51 @@ def b2b_log(*args, **kwargs):
     print('[ wt beta_to_blocks ]', *args, file=sys.stderr, **kwargs)
 
 
+class _LazyExtra(dict):
+    """The extra columns ('anno', 'gene') of a table the library parsed: the names are known, the lists of strings are cut out of
+    the file's text the first time somebody asks for one (find_markers only ever prints them for the markers it found)."""
+
+    def __init__(self, parsed, names):
+        super().__init__()
+        self._parsed, self._names, self._cut = parsed, list(names), False
+
+    def _fill(self):
+        if not self._cut:
+            for k, col in zip(self._names, self._parsed.fields(None, 5, len(self._names))):
+                dict.__setitem__(self, k, col)
+            self._cut = True
+
+    def __getitem__(self, k):
+        self._fill()
+        return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+    def __contains__(self, k):
+        return k in self._names
+
+    def keys(self):
+        return list(self._names)
+
+    def values(self):
+        self._fill()
+        return [dict.__getitem__(self, k) for k in self._names]
+
+    def items(self):
+        self._fill()
+        return [(k, dict.__getitem__(self, k)) for k in self._names]
+
+
 class BlocksTable:
     """A blocks table in memory, column-wise.  `chr`, `start`, `end`: the file's own text (they are only ever written back);
     `startCpG`, `endCpG`: int64 with `na` marking rows whose CpG fields are missing; `extra`: {'anno': [...], 'gene': [...]}.
-    A table read by the library's parser (`parsed`: _lib.ParsedBlocks) keeps the file's bytes and row offsets instead of three
-    lists of strings: the writers in the library print straight from them; `chr` / `start` / `end` are cut out on first use."""
+    A table read by the library's parser (`parsed`: _lib.ParsedBlocks) keeps the file's bytes and row offsets instead of lists
+    of strings: the writers in the library print straight from them; `chr` / `start` / `end` / the extra columns are cut out on
+    first use (coords_of / extras_of: for a few rows only)."""
 
     def __init__(self, chrom, start, end, start_cpg, end_cpg, na, extra=None, parsed=None):
         self.parsed = parsed
@@ -45,7 +85,7 @@ class BlocksTable:
         self.startCpG = np.asarray(start_cpg, dtype=np.int64)
         self.endCpG = np.asarray(end_cpg, dtype=np.int64)
         self.na = np.asarray(na, dtype=bool)
-        self.extra = dict(extra or {})
+        self.extra = extra if isinstance(extra, _LazyExtra) else dict(extra or {})
 
     def _text_columns(self):
         if self._coords is None:
@@ -58,12 +98,20 @@ class BlocksTable:
 
     def coords_of(self, idx):
         """[(chr, start, end) text of row i for i in idx] without cutting out the whole table"""
+        idx = np.asarray(idx, dtype=np.int64)
         if self._coords is None:
-            p = self.parsed
-            return [tuple(bytes(p.text[o:o + l]).decode('ascii').split('\t'))
-                    for o, l in zip(p.line_off[idx].tolist(), p.len3[idx].tolist())]
+            c, s, e = self.parsed.coords(idx)
+            return list(zip(c, s, e))
         c, s, e = self._coords
-        return [(c[i], s[i], e[i]) for i in idx]
+        return [(c[i], s[i], e[i]) for i in idx.tolist()]
+
+    def extras_of(self, idx):
+        """{name: [text of row i for i in idx]} for the extra columns"""
+        idx = np.asarray(idx, dtype=np.int64)
+        if isinstance(self.extra, _LazyExtra) and not self.extra._cut:
+            names = list(self.extra)
+            return dict(zip(names, self.parsed.fields(idx, 5, len(names))))
+        return {k: [v[i] for i in idx.tolist()] for k, v in self.extra.items()}
 
     @property
     def columns(self):
@@ -76,12 +124,20 @@ class BlocksTable:
     def __len__(self):
         return int(self.startCpG.size)
 
+    def take(self, idx):
+        """rows idx (a slice or an index array) as a new table"""
+        if self.parsed is not None:
+            p = self.parsed.take(idx)
+            return BlocksTable(None, None, None, self.startCpG[idx], self.endCpG[idx], self.na[idx],
+                               _LazyExtra(p, list(self.extra)) if len(self.extra) else None, parsed=p)
+        rows = range(*idx.indices(len(self))) if isinstance(idx, slice) else np.asarray(idx).tolist()
+        c, s, e = self._coords
+        return BlocksTable([c[i] for i in rows], [s[i] for i in rows], [e[i] for i in rows], self.startCpG[idx], self.endCpG[idx],
+                           self.na[idx], {k: [v[i] for i in rows] for k, v in self.extra.items()})
+
     def rows(self, a, b):
         """rows [a, b) as a new table (beta_to_table walks the table in chunks)"""
-        if self.parsed is not None and not self.extra:
-            return BlocksTable(None, None, None, self.startCpG[a:b], self.endCpG[a:b], self.na[a:b], parsed=self.parsed.rows(a, b))
-        return BlocksTable(self.chr[a:b], self.start[a:b], self.end[a:b], self.startCpG[a:b], self.endCpG[a:b], self.na[a:b],
-                           {k: v[a:b] for k, v in self.extra.items()})
+        return self.take(slice(a, b))
 
     def copy(self):
         return self.rows(0, len(self))
@@ -100,7 +156,7 @@ def _opener(path):
     return open(path, 'r')
 
 
-def _load_blocks_native(blocks_path, nrows):
+def _load_blocks_native(blocks_path, nrows, anno=False):
     """The library's one-pass parser (include/wgbsseg.h: wgbsseg_blocks_parse) on the file's bytes -> BlocksTable, or None when
     the library is not built or the file is not a plain table (the line-by-line parser below then handles it and owns the
     messages).  WGBSSEG_PY_TABLES=1 turns it off (A/B tests)."""
@@ -121,7 +177,8 @@ def _load_blocks_native(blocks_path, nrows):
     p = _lib.blocks_parse(data, nrows)
     if p is None:
         return None
-    return BlocksTable(None, None, None, p.start_cpg, p.end_cpg, p.na, parsed=p)
+    extra = _LazyExtra(p, ['anno', 'gene']) if (anno and p.first_fields >= 7) else None
+    return BlocksTable(None, None, None, p.start_cpg, p.end_cpg, p.na, extra, parsed=p)
 
 
 def load_blocks_file(blocks_path, anno=False, nrows=None):
@@ -129,8 +186,8 @@ def load_blocks_file(blocks_path, anno=False, nrows=None):
     a file without any row gives an empty table (after the reference's 'Empty blocks file.' note)."""
     if not op.isfile(blocks_path):
         raise IllegalArgumentError(f'Invalid file: {blocks_path}')
-    if not anno:
-        t = _load_blocks_native(blocks_path, nrows)
+    if True:
+        t = _load_blocks_native(blocks_path, nrows, anno)
         if t is not None:
             ok = ~t.na
             if (t.endCpG[ok] < t.startCpG[ok]).any():

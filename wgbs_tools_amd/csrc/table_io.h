@@ -111,10 +111,18 @@ inline bool blank_line(const char* a, size_t n)                    // Python: no
 
 // Returns 0 with *n_rows rows filled; 1: irregular — use the line-by-line parser; 2: more than `cap` rows.
 // Row i: line_off[i] = offset of its first byte, len3[i] = bytes of "chr \t start \t end", start_cpg / end_cpg (0 where na[i]).
+// Optional (NULL: not wanted): bp_start / bp_end = the row's second and third field as integers, *bp_ok = 1 when every row's are
+// plain digits (else the arrays are not to be used: find_markers then converts the text itself, as int() would);
+// *first_fields = fields of the first line that is neither a comment nor blank (the header, when there is one), at most 7 —
+// what decides whether the table has the two annotation columns.
 inline int parse_blocks(const char* t, int64_t len, int64_t max_rows, int64_t cap, int64_t* line_off, int32_t* len3,
-                        int64_t* start_cpg, int64_t* end_cpg, uint8_t* na, int64_t* n_rows)
+                        int64_t* start_cpg, int64_t* end_cpg, uint8_t* na, int64_t* n_rows,
+                        int64_t* bp_start = nullptr, int64_t* bp_end = nullptr, int32_t* bp_ok = nullptr, int32_t* first_fields = nullptr)
 {
     *n_rows = 0;
+    bool bp_good = bp_start && bp_end;
+    if (bp_ok) *bp_ok = 0;
+    if (first_fields) *first_fields = 0;
     if (len < 0 || !t) return 1;
     for (int64_t i = 0; i < len; i++) if ((unsigned char)t[i] >= 0x80 || t[i] == '\r' || t[i] == '\0') return 1;
     bool first = true;
@@ -135,6 +143,11 @@ inline int parse_blocks(const char* t, int64_t len, int64_t max_rows, int64_t ca
         const size_t f1a = tab[0] + 1, f1b = tab[1];
         if (first) {
             first = false;
+            if (first_fields) {
+                int nf = 1;
+                for (size_t i = 0; i < ln && nf < 7; i++) if (L[i] == '\t') nf++;
+                *first_fields = nf;
+            }
             if (!all_digits(L + f1a, f1b - f1a)) { a = next; continue; }     // a header line
         }
         const size_t f3a = tab[2] + 1, f3b = tab[3], f4a = tab[3] + 1, f4b = nt == 5 ? tab[4] : ln;
@@ -150,11 +163,21 @@ inline int parse_blocks(const char* t, int64_t len, int64_t max_rows, int64_t ca
         if (tab[2] > 0x7fffffffu) return 1;
         line_off[n] = a; len3[n] = (int32_t)tab[2];
         start_cpg[n] = s; end_cpg[n] = e; na[n] = miss ? 1 : 0;
+        if (bp_good) {
+            const size_t f2a = tab[1] + 1, f2b = tab[2];
+            if (all_digits(L + f1a, f1b - f1a) && all_digits(L + f2a, f2b - f2a) && f1b - f1a <= 15 && f2b - f2a <= 15) {
+                int64_t x = 0, y = 0;
+                for (size_t i = f1a; i < f1b; i++) x = x * 10 + (L[i] - '0');
+                for (size_t i = f2a; i < f2b; i++) y = y * 10 + (L[i] - '0');
+                bp_start[n] = x; bp_end[n] = y;
+            } else bp_good = false;
+        }
         n++;
         if (max_rows >= 0 && n >= max_rows) break;
         a = next;
     }
     *n_rows = n;
+    if (bp_ok) *bp_ok = bp_good ? 1 : 0;
     return n == 0 ? 1 : 0;                                         // an empty table: the slow path prints the reference's note
 }
 

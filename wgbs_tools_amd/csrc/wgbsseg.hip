@@ -1804,12 +1804,13 @@ int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom
 }
 
 int wgbsseg_blocks_parse(const char* text, int64_t len, int64_t max_rows, int64_t cap, int64_t* line_off, int32_t* len3,
-                         int64_t* start_cpg, int64_t* end_cpg, uint8_t* na, int64_t* n_rows)
+                         int64_t* start_cpg, int64_t* end_cpg, uint8_t* na, int64_t* n_rows,
+                         int64_t* bp_start, int64_t* bp_end, int32_t* bp_ok, int32_t* first_fields)
 {
     if (!n_rows) return WGBSSEG_E_ARG;
     *n_rows = 0;
     if (!text || len < 0 || cap < 0 || (cap && (!line_off || !len3 || !start_cpg || !end_cpg || !na))) return WGBSSEG_E_ARG;
-    const int rc = wgtab::parse_blocks(text, len, max_rows, cap, line_off, len3, start_cpg, end_cpg, na, n_rows);
+    const int rc = wgtab::parse_blocks(text, len, max_rows, cap, line_off, len3, start_cpg, end_cpg, na, n_rows, bp_start, bp_end, bp_ok, first_fields);
     return rc == 0 ? WGBSSEG_OK : (rc == 1 ? 1 : WGBSSEG_E_ARG);
 }
 

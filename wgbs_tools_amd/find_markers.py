@@ -279,15 +279,17 @@ class MarkerFinder:
         if not len(t):
             return t
         n0 = len(t)
-        start = np.array([int(x) for x in t.start], dtype=np.int64)
-        end = np.array([int(x) for x in t.end], dtype=np.int64)
+        if t.parsed is not None and t.parsed.bp_start is not None:      # (the library's parser has the two columns as integers)
+            start, end = t.parsed.bp_start, t.parsed.bp_end
+        else:
+            start = np.array([int(x) for x in t.start], dtype=np.int64)
+            end = np.array([int(x) for x in t.end], dtype=np.int64)
         ln_cpg = t.endCpG - t.startCpG
         ln = end - start
         a = self.args
         keep = (~t.na) & (ln_cpg >= a.min_cpg) & (ln_cpg <= a.max_cpg) & (ln >= a.min_bp) & (ln <= a.max_bp)
         idx = np.flatnonzero(keep)
-        t = BlocksTable([t.chr[i] for i in idx], [t.start[i] for i in idx], [t.end[i] for i in idx], t.startCpG[idx], t.endCpG[idx],
-                        t.na[idx], {k: [v[i] for i in idx] for k, v in t.extra.items()})
+        t = t.take(idx)
         if self.verbose:
             eprint(f'loaded {n0:,} blocks')
             if len(t) != n0:
@@ -480,12 +482,14 @@ class MarkerFinder:
                     f.write(f'#< {s}\n')
             f.write('\t'.join(cols) + '\n')
             stat = [m.cols[k].tolist() for k in STAT_COLS]
+            coords = b.coords_of(m.row)                                        # the text of the markers' rows only
+            extras = b.extras_of(m.row) if with_anno else {}
             for j, r in enumerate(m.row.tolist()):
-                s, e = int(b.start[r]), int(b.end[r])
-                row = [b.chr[r], str(s), str(e), str(int(b.startCpG[r])), str(int(b.endCpG[r])), target, f'{b.chr[r]}:{s}-{e}',
+                chrom, s, e = coords[j][0], int(coords[j][1]), int(coords[j][2])
+                row = [chrom, str(s), str(e), str(int(b.startCpG[r])), str(int(b.endCpG[r])), target, f'{chrom}:{s}-{e}',
                        f'{int(b.endCpG[r] - b.startCpG[r])}CpGs', f'{e - s}bp'] + [g3(x[j]) for x in stat] + [m.direction[j]]
                 if with_anno:
-                    row += [b.extra['anno'][r] or 'NA', b.extra['gene'][r] or 'NA']
+                    row += [extras['anno'][j] or 'NA', extras['gene'][j] or 'NA']
                 f.write('\t'.join(row) + '\n')
 
     def dump_params(self):
