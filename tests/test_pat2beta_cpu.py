@@ -51,3 +51,51 @@ def test_chunks_end_on_lines_and_names(tmp_path):
         f.write(text + b'\n')
     assert b''.join(P2B.pat_chunks(str(g), chunk_bytes=5000)) == text + b'\n'
     assert P2B.splitextgz('a/b/s1.pat.gz') == ('a/b/s1', '.pat.gz') and P2B.splitextgz('s2.pat') == ('s2', '.pat')
+
+
+def _bgzf_bytes(text, block=65280, level=6):
+    """what `bgzip` writes (SAM specification 4.1): independent gzip members with a 'BC' extra subfield, and the empty EOF block"""
+    import struct
+    import zlib
+    out = []
+    for a in list(range(0, len(text), block)) + [None]:
+        piece = b'' if a is None else text[a:a + block]
+        c = zlib.compressobj(level, zlib.DEFLATED, -15)
+        payload = c.compress(piece) + c.flush()
+        bsize = 12 + 6 + len(payload) + 8
+        out.append(b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff' + struct.pack('<H', 6) + b'BC' + struct.pack('<HH', 2, bsize - 1) + payload +
+                   struct.pack('<II', zlib.crc32(piece) & 0xffffffff, len(piece)))
+    return b''.join(out)
+
+
+def test_bgzf_pat_files_are_inflated_block_by_block(tmp_path, monkeypatch):
+    """.pat.gz files are BGZF (bgzip): the blocks are inflated on a pool of threads; same text, in line-aligned chunks, as one gzip
+    stream gives — small blocks, blocks that straddle the reader's buffer, an empty file, plain gzip and multi-member gzip (not
+    BGZF: the gzip module's path), and a truncated file."""
+    lines = synth.synth_pat_lines(7, 500, 40000)
+    text = ('\n'.join(lines) + '\n').encode()
+    assert len(text) > 600000
+    for name, data in (('full', _bgzf_bytes(text)), ('small_blocks', _bgzf_bytes(text, block=1500)), ('empty', _bgzf_bytes(b''))):
+        p = tmp_path / (name + '.pat.gz')
+        p.write_bytes(data)
+        assert gzip.open(p, 'rb').read() == (text if name != 'empty' else b'')            # it IS a gzip file
+        for rb in (1 << 20, 70000, 4096 + 13):                                            # reader buffers smaller than a block too
+            got = b''.join(b for b in P2B.bgzf_pieces(str(p), read_bytes=rb, threads=4))
+            assert got == (text if name != 'empty' else b''), (name, rb)
+        chunks = list(P2B.pat_chunks(str(p), chunk_bytes=100000))
+        assert b''.join(chunks) == (text if name != 'empty' else b'') and all(c.endswith(b'\n') for c in chunks)
+        monkeypatch.setenv('WGBSSEG_PY_GUNZIP', '1')
+        assert b''.join(P2B.pat_chunks(str(p), chunk_bytes=100000)) == b''.join(chunks)
+        monkeypatch.delenv('WGBSSEG_PY_GUNZIP')
+    notail = tmp_path / 'notail.pat.gz'
+    notail.write_bytes(_bgzf_bytes(text[:-1]))
+    assert b''.join(P2B.pat_chunks(str(notail))) == text
+    plain = tmp_path / 'plain.pat.gz'
+    plain.write_bytes(gzip.compress(text[:300000]) + gzip.compress(text[300000:]))      # two ordinary members
+    assert list(P2B.bgzf_pieces(str(plain))) == []
+    assert b''.join(P2B.pat_chunks(str(plain), chunk_bytes=50000)) == text
+    cut = tmp_path / 'cut.pat.gz'
+    whole = _bgzf_bytes(text)
+    cut.write_bytes(whole[:len(whole) // 2 + 7])
+    with pytest.raises(Exception):
+        b''.join(P2B.pat_chunks(str(cut)))

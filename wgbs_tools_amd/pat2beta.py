@@ -14,6 +14,7 @@ counted on the GPU (wgbsseg_patbeta_*, include/wgbsseg.h) while the next chunk i
 """
 import argparse
 import gzip
+import os
 import os.path as op
 
 from .convert import delete_or_skip
@@ -31,22 +32,87 @@ def splitextgz(path):
     return op.splitext(path)
 
 
+def _bgzf_block_size(buf, pos):
+    """Total size of the BGZF block that begins at buf[pos] (the SAM specification, section 4.1: a gzip member whose extra field
+    holds the subfield 'BC' with the block's size - 1), or None when the bytes there are not such a header."""
+    if len(buf) - pos < 18 or buf[pos:pos + 4] != b'\x1f\x8b\x08\x04':
+        return None
+    xlen = buf[pos + 10] | (buf[pos + 11] << 8)
+    q, end = pos + 12, pos + 12 + xlen
+    if end > len(buf):
+        return None
+    while q + 4 <= end:
+        slen = buf[q + 2] | (buf[q + 3] << 8)
+        if buf[q] == 66 and buf[q + 1] == 67 and slen == 2 and q + 6 <= end:
+            return (buf[q + 4] | (buf[q + 5] << 8)) + 1
+        q += 4 + slen
+    return None
+
+
+def _inflate_block(block):
+    import zlib
+    xlen = block[10] | (block[11] << 8)
+    return zlib.decompress(block[12 + xlen:-8], -15)                 # raw deflate between the header and CRC32 + ISIZE
+
+
+def bgzf_pieces(path, read_bytes=16 << 20, threads=None):
+    """The text of a BGZF file (what `bgzip` writes and wgbstools' .pat.gz are: independent gzip blocks of <= 64 KB) in pieces,
+    the blocks of every piece inflated on a pool of threads (zlib releases the interpreter lock) — a .pat.gz of a deep sample is
+    gigabytes of text behind ONE `gunzip -c` in the reference (pat2beta.py:30).  Yields nothing and returns False when the file
+    does not begin with a BGZF header (plain gzip: the caller's gzip.open path)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with open(path, 'rb') as f:
+        buf = f.read(read_bytes)
+        if _bgzf_block_size(buf, 0) is None:
+            return False
+        n_thr = threads or min(32, os.cpu_count() or 1)
+        with ThreadPoolExecutor(n_thr) as pool:
+            while buf:
+                blocks, pos = [], 0
+                while True:
+                    size = _bgzf_block_size(buf, pos)
+                    if size is None or pos + size > len(buf):
+                        break
+                    blocks.append(buf[pos:pos + size])
+                    pos += size
+                if not blocks:
+                    more = f.read(read_bytes)
+                    if not more:
+                        raise IllegalArgumentError(f'Invalid gzip data in {path}: truncated or not BGZF after the first block')
+                    buf = buf[pos:] + more
+                    continue
+                yield b''.join(pool.map(_inflate_block, blocks, chunksize=64))
+                buf = buf[pos:] + f.read(read_bytes)
+    return True
+
+
 def pat_chunks(pat_path, chunk_bytes=CHUNK_BYTES):
     """the text of a .pat / .pat.gz file in pieces that end on line boundaries"""
-    opener = gzip.open if pat_path.endswith('.gz') else open
+    def pieces():
+        if pat_path.endswith('.gz') and os.environ.get('WGBSSEG_PY_GUNZIP', '0') in ('', '0'):
+            gen = bgzf_pieces(pat_path)
+            bgzf = yield from gen
+            if bgzf:
+                return
+        opener = gzip.open if pat_path.endswith('.gz') else open
+        with opener(pat_path, 'rb') as f:
+            while True:
+                buf = f.read(chunk_bytes)
+                if not buf:
+                    return
+                yield buf
     rest = b''
-    with opener(pat_path, 'rb') as f:
-        while True:
-            buf = f.read(chunk_bytes)
-            if not buf:
-                break
-            buf = rest + buf
-            cut = buf.rfind(b'\n') + 1
-            rest = buf[cut:]
-            if cut:
-                yield buf[:cut]
+    for buf in pieces():
+        buf = rest + buf
+        if len(buf) < chunk_bytes and not buf.endswith(b'\n'):      # keep collecting: pieces of a BGZF file are smaller than a chunk
+            rest = buf
+            continue
+        cut = buf.rfind(b'\n') + 1
+        rest = buf[cut:]
+        if cut:
+            yield buf[:cut]
     if rest:
-        yield rest + b'\n'
+        yield rest if rest.endswith(b'\n') else rest + b'\n'
 
 
 def pat2beta(pat_path, out_dir, args, force=True):
