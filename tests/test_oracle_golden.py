@@ -61,6 +61,44 @@ def test_live_reference_binary_agrees(name, golden_chunks):
     assert b.tolist() == g['borders']
 
 
+@pytest.mark.skipif(not oracle.have_ref(), reason='oracle/_ref/segmentor not built here')
+@pytest.mark.parametrize('seed', range(24))
+def test_restatement_against_the_live_reference_on_random_worlds(seed):
+    """Beyond the committed vectors: random worlds (dense runs, equal positions, long gaps; zero, saturated and meth == cov counts),
+    random sample counts, pseudo counts nobody chose (any float in 2^-12 .. 2^12, besides 0 and the usual ones), random window
+    limits — the C restatement against the reference binary run on the spot, chunk by chunk with `-s start0 -n len`."""
+    import os
+    import tempfile
+    rng = np.random.default_rng(31000 + seed)
+    n = int(rng.integers(300, 2500))
+    n_samples = int(rng.choice([1, 2, 3, 5, 9]))
+    kind = rng.integers(0, 4, n)
+    gap = np.where(kind == 0, 0, np.where(kind == 1, rng.integers(1, 12, n), np.where(kind == 2, rng.integers(2, 300, n), rng.integers(300, 9000, n))))
+    loci = (np.cumsum(gap) + 1000).astype(np.uint32)
+    slices = []
+    for _ in range(n_samples):
+        cov = rng.integers(0, 256, n)
+        mode = rng.integers(0, 6, n)
+        cov = np.where(mode == 0, 0, np.where(mode == 1, 255, cov))
+        meth = np.minimum(cov, np.where(mode == 2, cov, np.where(mode == 3, 0, rng.integers(0, 256, n))))
+        slices.append(np.stack([meth, cov], axis=1).astype(np.uint8))
+    pcount = float(np.float32(rng.choice([0.0, 0.5, 1.0, 15.0, float(np.exp2(rng.uniform(-12, 12))), float(np.exp2(rng.uniform(-12, 12)))])))
+    max_cpg = int(rng.choice([2, 7, 60, 61, 129, 500, 1000]))
+    max_bp = int(rng.choice([1, 40, 700, 2000, 100000]))
+    with tempfile.TemporaryDirectory() as td:
+        paths = []
+        for i, s in enumerate(slices):
+            p = os.path.join(td, 's%02d.beta' % i)
+            s.tofile(p)
+            paths.append(p)
+        for _ in range(3):
+            ln = int(rng.integers(1, n + 1))
+            st = int(rng.integers(0, n - ln + 1))
+            want = oracle.ref_segment_chunk(paths, st, ln, loci[st:st + ln], pcount, max_cpg, max_bp)
+            got = oracle.segment_chunks(slices, loci, [st], [ln], pcount, max_cpg, max_bp)[0]
+            assert got.tolist() == want.tolist(), (seed, pcount, max_cpg, max_bp, st, ln)
+
+
 @pytest.mark.parametrize('name', ['tiny', 'max_cpg2', 'pcount0', 'zero_stretch', 'dense_w_gt_64', 'deep', 'n512_deep', 'n200_islands'])
 def test_threaded_restatement_matches_reference_golden(name, golden_chunks):
     """The many-thread variant the full-size GPU tests use as their checker (rows in parallel slabs, recurrence
