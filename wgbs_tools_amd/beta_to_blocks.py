@@ -186,13 +186,12 @@ def load_blocks_file(blocks_path, anno=False, nrows=None):
     a file without any row gives an empty table (after the reference's 'Empty blocks file.' note)."""
     if not op.isfile(blocks_path):
         raise IllegalArgumentError(f'Invalid file: {blocks_path}')
-    if True:
-        t = _load_blocks_native(blocks_path, nrows, anno)
-        if t is not None:
-            ok = ~t.na
-            if (t.endCpG[ok] < t.startCpG[ok]).any():
-                raise IllegalArgumentError(f'Invalid CpG columns in blocks file {blocks_path}')
-            return t
+    t = _load_blocks_native(blocks_path, nrows, anno)
+    if t is not None:
+        ok = ~t.na
+        if (t.endCpG[ok] < t.startCpG[ok]).any():
+            raise IllegalArgumentError(f'Invalid CpG columns in blocks file {blocks_path}')
+        return t
     want = 7 if anno else 5
     chrom, start, end, scpg, ecpg, na = [], [], [], [], [], []
     extra = None
