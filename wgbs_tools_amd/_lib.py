@@ -200,7 +200,7 @@ def load():
     L.wgbsseg_format_fixed.restype = i64
     L.wgbsseg_format_fixed.argtypes = [vp, i64, i32, vp, i64]
     L.wgbsseg_bed_parse.restype = i32
-    L.wgbsseg_bed_parse.argtypes = [vp, i64, i64, C.POINTER(C.c_char_p), i32, vp, vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i32)]
+    L.wgbsseg_bed_parse.argtypes = [vp, i64, i64, C.POINTER(C.c_char_p), i32, vp, vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
     L.wgbsseg_bed_write_annotated.restype = i32
     L.wgbsseg_bed_write_annotated.argtypes = [C.c_char_p, vp, vp, vp, vp, vp, vp, i64, i32, C.c_char_p, C.c_size_t]
     _lib = L
@@ -790,9 +790,9 @@ class ParsedBed:
     """What wgbsseg_bed_parse leaves: the table's bytes and, per row, its offset, the length of `chr \\t start \\t end` and of the
     whole row, the chromosome's index in the names given (-1: unknown), start and end."""
 
-    def __init__(self, text, line_off, len3, row_len, chrom_idx, start, end, width):
+    def __init__(self, text, line_off, len3, row_len, chrom_idx, start, end, width, header=False):
         self.text, self.line_off, self.len3, self.row_len = text, line_off, len3, row_len
-        self.chrom_idx, self.start, self.end, self.width = chrom_idx, start, end, width
+        self.chrom_idx, self.start, self.end, self.width, self.header = chrom_idx, start, end, width, header
 
     def __len__(self):
         return self.line_off.size
@@ -814,12 +814,13 @@ def bed_parse(data, chrom_names):
     names = (C.c_char_p * len(chrom_names))(*[str(n).encode() for n in chrom_names])
     n = C.c_int64(0)
     w = C.c_int32(0)
+    h = C.c_int32(0)
     rc = L.wgbsseg_bed_parse(text.ctypes.data, text.size, cap, names, len(chrom_names), line_off.ctypes.data, len3.ctypes.data,
-                             row_len.ctypes.data, chrom.ctypes.data, start.ctypes.data, end.ctypes.data, C.byref(n), C.byref(w))
+                             row_len.ctypes.data, chrom.ctypes.data, start.ctypes.data, end.ctypes.data, C.byref(n), C.byref(w), C.byref(h))
     if rc != OK:
         return None
     k = int(n.value)
-    return ParsedBed(text, line_off[:k], len3[:k], row_len[:k], chrom[:k], start[:k], end[:k], int(w.value))
+    return ParsedBed(text, line_off[:k], len3[:k], row_len[:k], chrom[:k], start[:k], end[:k], int(w.value), bool(h.value))
 
 
 def bed_write_annotated(path, parsed, start_cpg, end_cpg, keep=None, threads=0):

@@ -232,6 +232,8 @@ def load_bed_fast(bed_file, genome):
     p = _lib.bed_parse(data, list(names))
     if p is None:
         return None if not hasattr(bed_file, 'read') else data   # (standard input cannot be read twice: hand the bytes back)
+    if p.header:
+        eprint('[wt convert] Header line detected. Ignoring first line of input')
     return FastBedTable(p)
 
 

@@ -358,13 +358,16 @@ inline bool surely_text(const char* a, size_t n)
 // what a round trip through pandas does to a column: integers are re-printed, numeric columns become floats, missing values NA):
 // that is the case when every row has the same number (>= 3) of fields, start and end are plain integers as they print, and every
 // other column either holds a token no number parser accepts (a text column: written back as it came) or nothing but plain
-// integers.  Returns 0 with the rows; 1: not such a table (comments, a header, ragged rows, numeric or missing-value columns,
-// carriage returns, non-ASCII bytes ...) — the caller's Python handles it; 2: more than cap rows.
+// integers.  A header line (first line whose second and third fields are not numbers) is skipped and reported in *header_out when
+// that is given: every column is text then.  Returns 0 with the rows; 1: not such a table (comments, ragged rows, numeric or
+// missing-value columns, carriage returns, non-ASCII bytes ...) — the caller's Python handles it; 2: more than cap rows.
 // chrom[i] = index of the row's first field in names[0..n_names), -1 when it is none of them.
 inline int parse_bed(const char* t, int64_t len, int64_t cap, const char* const* names, int n_names, int64_t* line_off, int32_t* len3,
-                     int32_t* row_len, int32_t* chrom, int64_t* start, int64_t* end, int64_t* n_rows, int32_t* width_out)
+                     int32_t* row_len, int32_t* chrom, int64_t* start, int64_t* end, int64_t* n_rows, int32_t* width_out, int32_t* header_out = nullptr)
 {
     *n_rows = 0; *width_out = 0;
+    if (header_out) *header_out = 0;
+    bool raw = false;                                              // a header line was skipped: pandas then reads every column as text
     if (len < 0 || !t) return 1;
     for (int64_t i = 0; i < len; i++) {
         const unsigned char c = (unsigned char)t[i];
@@ -387,12 +390,23 @@ inline int parse_bed(const char* t, int64_t len, int64_t cap, const char* const*
         tabs.clear();
         for (size_t i = 0; i < ln; i++) if (L[i] == '\t') tabs.push_back(i);
         const int w = (int)tabs.size() + 1;
-        if (width == 0) {
+        const bool first_row = width == 0;
+        if (first_row) {
             width = w;
             if (width < 3) return 1;
             has_text.assign((size_t)width, 0); all_int.assign((size_t)width, 1); other_na.assign((size_t)width, 0);
         } else if (w != width) return 1;
         tabs.push_back(ln);
+        if (first_row && header_out) {
+            // convert.py:77-89: a first line whose second and third fields are not numbers (after strip()) is a header: ignored, and
+            // every column of the table is then text — written back as it came
+            auto stripped_digits = [&](size_t a0, size_t b0) {
+                while (a0 < b0 && (L[a0] == ' ' || (L[a0] >= 9 && L[a0] <= 13) || (L[a0] >= 28 && L[a0] <= 31))) a0++;
+                while (b0 > a0 && (L[b0 - 1] == ' ' || (L[b0 - 1] >= 9 && L[b0 - 1] <= 13) || (L[b0 - 1] >= 28 && L[b0 - 1] <= 31))) b0--;
+                return all_digits(L + a0, b0 - a0);
+            };
+            if (!(stripped_digits(tabs[0] + 1, tabs[1]) && stripped_digits(tabs[1] + 1, tabs[2]))) { raw = true; *header_out = 1; a = next; continue; }
+        }
         // start, end: plain integers that print as they read (<= 15 digits)
         const size_t s_a = tabs[0] + 1, s_b = tabs[1], e_a = tabs[1] + 1, e_b = tabs[2];
         if (!canonical_uint(L + s_a, s_b - s_a, 15) || !canonical_uint(L + e_a, e_b - e_a, 15)) return 1;
@@ -427,8 +441,8 @@ inline int parse_bed(const char* t, int64_t len, int64_t cap, const char* const*
     if (n == 0) return 1;
     for (int c = 0; c < width; c++) {
         if (c == 1 || c == 2) continue;
-        const bool text_col = has_text[(size_t)c] && !other_na[(size_t)c];
-        if (!text_col && !all_int[(size_t)c]) return 1;
+        const bool text_col = (raw || has_text[(size_t)c]) && !other_na[(size_t)c];
+        if (!text_col && !(all_int[(size_t)c] && !raw)) return 1;
     }
     *n_rows = n; *width_out = width;
     return 0;

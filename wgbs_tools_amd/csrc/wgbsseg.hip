@@ -1861,12 +1861,12 @@ int wgbsseg_blocks_write_bedgraph(const char* path, const char* text, const int6
 }
 
 int wgbsseg_bed_parse(const char* text, int64_t len, int64_t cap, const char* const* chrom_names, int32_t n_chroms, int64_t* line_off,
-                      int32_t* len3, int32_t* row_len, int32_t* chrom, int64_t* start, int64_t* end, int64_t* n_rows, int32_t* width)
+                      int32_t* len3, int32_t* row_len, int32_t* chrom, int64_t* start, int64_t* end, int64_t* n_rows, int32_t* width, int32_t* header)
 {
-    if (!n_rows || !width) return WGBSSEG_E_ARG;
-    *n_rows = 0; *width = 0;
+    if (!n_rows || !width || !header) return WGBSSEG_E_ARG;
+    *n_rows = 0; *width = 0; *header = 0;
     if (!text || len < 0 || cap < 0 || n_chroms < 0 || (n_chroms && !chrom_names) || (cap && (!line_off || !len3 || !row_len || !chrom || !start || !end))) return WGBSSEG_E_ARG;
-    const int rc = wgtab::parse_bed(text, len, cap, chrom_names, n_chroms, line_off, len3, row_len, chrom, start, end, n_rows, width);
+    const int rc = wgtab::parse_bed(text, len, cap, chrom_names, n_chroms, line_off, len3, row_len, chrom, start, end, n_rows, width, header);
     return rc == 0 ? WGBSSEG_OK : (rc == 1 ? 1 : WGBSSEG_E_ARG);
 }
 
