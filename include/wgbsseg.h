@@ -325,7 +325,8 @@ int64_t wgbsseg_format_fixed(const double* v, int64_t n, int32_t digits, char* o
  * new columns -> per row its offset, the length of "chr \t start \t end" (len3) and of the whole row (row_len), the index of
  * its chromosome in chrom_names (-1: none of them), start and end.  A FAST PATH like wgbsseg_blocks_parse: returns 1 — and the
  * caller's own parser takes over — for anything a round trip through pandas would re-print: '#' comments, rows
- * of different widths, starts / ends that are not plain integers, columns that read as numbers (they come back as floats) or
+ * of different widths, starts / ends that are not plain integers, columns that read as numbers and would print differently
+ * (integers with gaps come back as floats, 0.50 as 0.5, +5 as 5; plain integers and decimals in their shortest form pass) or
  * hold missing-value spellings other than NA, carriage returns, non-ASCII bytes, an empty table.  *width = fields per row;
  * *header = 1 when the first line was a header (second and third fields not numbers): it is skipped, the caller prints the
  * reference's note, and every column of such a table is text.
@@ -334,6 +335,9 @@ int64_t wgbsseg_format_fixed(const double* v, int64_t n, int32_t digits, char* o
  */
 int wgbsseg_bed_parse(const char* text, int64_t len, int64_t cap, const char* const* chrom_names, int32_t n_chroms, int64_t* line_off,
                       int32_t* len3, int32_t* row_len, int32_t* chrom, int64_t* start, int64_t* end, int64_t* n_rows, int32_t* width, int32_t* header);
+/* test hook: out[i] = 1 when the i-th newline-separated token is a decimal number that prints as it reads after a round trip
+ * through a float (csrc/table_io.h: canonical_float); returns the number of tokens, -1 when out_cap is too small */
+int64_t wgbsseg_debug_canonical_float(const char* tokens, int64_t len, uint8_t* out, int64_t out_cap);
 int wgbsseg_bed_write_annotated(const char* path, const char* text, const int64_t* line_off, const int32_t* len3, const int32_t* row_len,
                                 const int64_t* start_cpg, const int64_t* end_cpg, int64_t n_rows, int32_t threads, char* err, size_t errlen);
 

@@ -183,7 +183,7 @@ def test_fast_text_path_matches_python_path(cworld, tmp_path, capfd):
                 assert text == g['bed'][name]['drop_empty' if drop else 'keep']['text']
             else:
                 assert done is False
-    assert taken == 6                                           # all but the one with a float column; the one with a header line too
+    assert taken == 6                                           # the one with a header line too; not the one whose scores read 0.10, 1.00 (0.1, 1.0 on the way out)
     # tables made here: text columns, integer columns, NA in a text column, unknown chromosomes, regions without CpGs, overlaps
     # in one chromosome (the per-row rule set), no last newline, blank lines, gzip
     rng = np.random.default_rng(4)
@@ -243,3 +243,63 @@ def test_fast_text_path_matches_python_path(cworld, tmp_path, capfd):
         done, got, err = _fast_text(p, cworld, False, out)
         want, werr = _python_text(p, cworld, False)
         assert done is True and got == want and err == werr, name
+
+
+def test_decimal_tokens_that_print_as_they_read():
+    """canonical_float (the rule that lets a column of scores go back out verbatim): accepted => Python's repr(float(token)) is the
+    token itself — on reprs of random doubles over the whole positional range, on their perturbations (a digit changed, zeros
+    added, digits dropped, signs, exponents), and on hand-picked edges; and the reprs themselves are accepted wherever the rule's
+    shape admits them (digits.digits, 1e-4 <= |v| < 1e16)."""
+    from wgbs_tools_amd import _lib
+    rng = np.random.default_rng(9)
+    vals = np.concatenate([rng.random(60000), rng.random(20000) * 1000, np.exp(rng.uniform(np.log(1e-6), np.log(1e17), 60000)),
+                           np.round(rng.random(20000), 2), np.round(rng.random(20000) * 100, 3), -rng.random(5000) * 50])
+    toks = [repr(float(v)) for v in vals]
+    extra = []
+    for t in toks[:40000]:
+        k = int(rng.integers(0, 6))
+        if k == 0: extra.append(t + '0')
+        elif k == 1: extra.append('0' + t)
+        elif k == 2 and len(t) > 4: extra.append(t[:-1])
+        elif k == 3 and len(t) > 4: extra.append(t[:-2] + str((int(t[-2]) + 1) % 10 if t[-2].isdigit() else 0) + t[-1])
+        elif k == 4: extra.append('+' + t)
+        else: extra.append(t + '1')
+    hand = ['0.0', '-0.0', '0.5', '5.0', '5', '5.', '.5', '0.50', '00.5', '1e3', '1e-3', '0.0001', '0.00001', '0.00009999999999999999', '9999999999999998.0',
+            '10000000000000000.0', '1000000000000000.5', '0.1', '0.30000000000000004', '0.3000000000000000444', '123456789.123456789', '-7.25', '--1.0', '1.0.0',
+            '1_0.5', ' 1.5', '1.5 ', 'nan', 'inf', '', '.', '-', '-.5', '1.', '17.0', '0.1000000000000000055511151231257827', '4.35', '2.675', '1.005', '100.0']
+    allt = toks + extra + hand
+    ok = _lib.debug_canonical_float(allt)
+    import re
+    shape = re.compile(r'^-?\d+\.\d+$')
+    n_ok = 0
+    for t, a in zip(allt, ok.tolist()):
+        try:
+            same = repr(float(t)) == t
+        except ValueError:
+            same = False
+        if a:
+            n_ok += 1
+            assert same, t                                             # never accept what would be re-printed
+        elif same and shape.match(t):
+            v = abs(float(t))
+            assert not (v == 0.0 or 1e-4 <= v < 1e16), t                 # and do not turn down what fits the rule
+    assert n_ok > 120000 and ok[len(toks) + len(extra)] and not ok[len(toks) + len(extra) + 4]
+
+
+def test_score_columns_go_through_the_fast_path(cworld, tmp_path):
+    """columns of decimals in their shortest form (what repr / to_csv print) pass, with gaps too; the reference's fixture, whose
+    scores read 0.10 and 1.00, does not"""
+    out = str(tmp_path / 'o.bed')
+    assert _fast_text(cworld['beds']['clean_shuffled'], cworld, False, out)[0] is False
+    names = cworld['names']
+    rows = [[names[i % len(names)], str(1000 + 37 * i), str(1500 + 37 * i), 'r%d' % i, repr(round(i / 7.0, 3)) if i % 5 else 'NA'] for i in range(300)]
+    p = str(tmp_path / 'scores.bed')
+    open(p, 'w').write('\n'.join('\t'.join(r) for r in rows) + '\n')
+    done, text, err = _fast_text(p, cworld, False, out)
+    assert done is True and (text, err) == _python_text(p, cworld, False)
+    rows[17][4] = '0.50'                                                   # one value that pandas would print as 0.5: the whole table to the Python path
+    open(p, 'w').write('\n'.join('\t'.join(r) for r in rows) + '\n')
+    assert _fast_text(p, cworld, False, out)[0] is False
+    rows[17][4] = '3'                                                      # an integer among decimals: 3.0 in the output
+    open(p, 'w').write('\n'.join('\t'.join(r) for r in rows) + '\n')
+    assert _fast_text(p, cworld, False, out)[0] is False

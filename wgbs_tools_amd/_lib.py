@@ -27,7 +27,7 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_convert_regions', 'wgbsseg_patbeta_create', 'wgbsseg_patbeta_feed', 'wgbsseg_patbeta_finish',
            'wgbsseg_patbeta_destroy', 'wgbsseg_group_load_host_async', 'wgbsseg_group_load_wait',
            'wgbsseg_marker_stats', 'wgbsseg_blocks_parse', 'wgbsseg_blocks_write_table', 'wgbsseg_blocks_write_bedgraph',
-           'wgbsseg_format_fixed', 'wgbsseg_bed_parse', 'wgbsseg_bed_write_annotated']
+           'wgbsseg_format_fixed', 'wgbsseg_bed_parse', 'wgbsseg_bed_write_annotated', 'wgbsseg_debug_canonical_float']
 
 
 class NativeLibraryError(RuntimeError):
@@ -201,6 +201,8 @@ def load():
     L.wgbsseg_format_fixed.argtypes = [vp, i64, i32, vp, i64]
     L.wgbsseg_bed_parse.restype = i32
     L.wgbsseg_bed_parse.argtypes = [vp, i64, i64, C.POINTER(C.c_char_p), i32, vp, vp, vp, vp, vp, vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
+    L.wgbsseg_debug_canonical_float.restype = i64
+    L.wgbsseg_debug_canonical_float.argtypes = [C.c_char_p, i64, vp, i64]
     L.wgbsseg_bed_write_annotated.restype = i32
     L.wgbsseg_bed_write_annotated.argtypes = [C.c_char_p, vp, vp, vp, vp, vp, vp, i64, i32, C.c_char_p, C.c_size_t]
     _lib = L
@@ -834,3 +836,14 @@ def bed_write_annotated(path, parsed, start_cpg, end_cpg, keep=None, threads=0):
     rc = L.wgbsseg_bed_write_annotated(None if path is None else os.fsencode(path), parsed.text.ctypes.data, lo.ctypes.data, l3.ctypes.data,
                                        rl.ctypes.data, s.ctypes.data, e.ctypes.data, lo.size, int(threads), err, ERRLEN)
     _check(rc, err)
+
+
+def debug_canonical_float(tokens):
+    """wgbsseg_debug_canonical_float -> bool array: which tokens are decimals that print as they read through a float"""
+    L = load()
+    data = '\n'.join(tokens).encode('ascii')
+    out = np.zeros(len(tokens) + 1, dtype=np.uint8)
+    n = L.wgbsseg_debug_canonical_float(data, len(data), out.ctypes.data, out.size)
+    if n < 0:
+        raise ValueError('debug_canonical_float failed')
+    return out[:len(tokens)].astype(bool)

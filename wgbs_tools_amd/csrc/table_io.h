@@ -13,6 +13,7 @@
 // messages and the odd cases.  tests/test_blocks_cpu.py compares the two on every fixture and on adversarial files.
 #pragma once
 #include <atomic>
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -329,6 +330,34 @@ inline bool canonical_uint(const char* a, size_t n, size_t max_digits)     // di
     return n == 1 || a[0] != '0';
 }
 
+// A decimal number that prints as it reads after a round trip through a float (pandas: read_csv types the column float64, to_csv
+// prints repr(v)): digits '.' digits with an optional '-', no needless zeros, between 1e-4 and 1e16 in magnitude (or zero) — the
+// range where Python's repr uses positional notation — and already the SHORTEST text that names its double (std::to_chars and
+// repr both print that one).  "0.50", "7", "+1.5", "1e-3", ".5" are not: they come back as 0.5, 7.0, 1.5, 0.001, 0.5.
+inline bool canonical_float(const char* a, size_t n)
+{
+    if (n < 3 || n > 26) return false;
+    size_t i = a[0] == '-' ? 1 : 0;
+    const size_t i0 = i;
+    while (i < n && a[i] >= '0' && a[i] <= '9') i++;
+    if (i == i0 || i >= n || a[i] != '.') return false;
+    if (i - i0 > 1 && a[i0] == '0') return false;                  // 007.5
+    const size_t f0 = ++i;
+    while (i < n && a[i] >= '0' && a[i] <= '9') i++;
+    if (i != n || i == f0) return false;
+    char tmp[32];
+    memcpy(tmp, a, n); tmp[n] = 0;
+    const double v = strtod(tmp, nullptr);
+    const double m = std::fabs(v);
+    if (!(m == 0.0 || (m >= 1e-4 && m < 1e16))) return false;
+    char out[48];
+    const auto r = std::to_chars(out, out + 40, v, std::chars_format::fixed);
+    if (r.ec != std::errc()) return false;
+    size_t len = (size_t)(r.ptr - out);
+    if (!memchr(out, '.', len)) { out[len++] = '.'; out[len++] = '0'; }
+    return len == n && memcmp(out, a, n) == 0;
+}
+
 // A token that float() surely cannot parse: it has a character no float literal has (digits, sign, point, underscore, exponent,
 // white space, the letters of "infinity" / "nan"), or it mixes digits with those letters, or it has no digit and is not one of
 // those words.  (False for everything else, numbers or not: the caller only needs certainty in one direction.)
@@ -357,8 +386,8 @@ inline bool surely_text(const char* a, size_t n)
 // The rows of a BED table whose text can go back out VERBATIM around the two new columns (wgbs_tools_amd/convert.py restates
 // what a round trip through pandas does to a column: integers are re-printed, numeric columns become floats, missing values NA):
 // that is the case when every row has the same number (>= 3) of fields, start and end are plain integers as they print, and every
-// other column either holds a token no number parser accepts (a text column: written back as it came) or nothing but plain
-// integers.  A header line (first line whose second and third fields are not numbers) is skipped and reported in *header_out when
+// other column either holds a token no number parser accepts (a text column: written back as it came), or nothing but plain
+// integers, or nothing but decimal numbers that print as they read (canonical_float; gaps spelled NA).  A header line (first line whose second and third fields are not numbers) is skipped and reported in *header_out when
 // that is given: every column is text then.  Returns 0 with the rows; 1: not such a table (comments, ragged rows, numeric or
 // missing-value columns, carriage returns, non-ASCII bytes ...) — the caller's Python handles it; 2: more than cap rows.
 // chrom[i] = index of the row's first field in names[0..n_names), -1 when it is none of them.
@@ -376,7 +405,7 @@ inline int parse_bed(const char* t, int64_t len, int64_t cap, const char* const*
     std::vector<size_t> nlen((size_t)n_names);
     for (int i = 0; i < n_names; i++) nlen[(size_t)i] = strlen(names[i]);
     int width = 0;
-    std::vector<uint8_t> has_text, all_int, other_na;
+    std::vector<uint8_t> has_text, all_int, all_float, other_na;      // per column
     std::vector<size_t> tabs;
     int64_t n = 0;
     int last_chrom = -1;
@@ -394,7 +423,7 @@ inline int parse_bed(const char* t, int64_t len, int64_t cap, const char* const*
         if (first_row) {
             width = w;
             if (width < 3) return 1;
-            has_text.assign((size_t)width, 0); all_int.assign((size_t)width, 1); other_na.assign((size_t)width, 0);
+            has_text.assign((size_t)width, 0); all_int.assign((size_t)width, 1); all_float.assign((size_t)width, 1); other_na.assign((size_t)width, 0);
         } else if (w != width) return 1;
         tabs.push_back(ln);
         if (first_row && header_out) {
@@ -426,6 +455,7 @@ inline int parse_bed(const char* t, int64_t len, int64_t cap, const char* const*
             }
             if (surely_text(f, fn)) has_text[(size_t)c] = 1;
             if (!canonical_uint(f, fn, 18)) all_int[(size_t)c] = 0;
+            if (all_float[(size_t)c] && !canonical_float(f, fn)) all_float[(size_t)c] = 0;
         }
         if (n >= cap) return 2;
         if (ln > 0x7fffffffu) return 1;
@@ -442,7 +472,9 @@ inline int parse_bed(const char* t, int64_t len, int64_t cap, const char* const*
     for (int c = 0; c < width; c++) {
         if (c == 1 || c == 2) continue;
         const bool text_col = (raw || has_text[(size_t)c]) && !other_na[(size_t)c];
-        if (!text_col && !(all_int[(size_t)c] && !raw)) return 1;
+        // (a float column may have gaps: they print NA)
+        const bool float_col = !raw && all_float[(size_t)c] && !all_int[(size_t)c] && !other_na[(size_t)c] && !has_text[(size_t)c];
+        if (!text_col && !(all_int[(size_t)c] && !raw) && !float_col) return 1;
     }
     *n_rows = n; *width_out = width;
     return 0;

@@ -1870,6 +1870,20 @@ int wgbsseg_bed_parse(const char* text, int64_t len, int64_t cap, const char* co
     return rc == 0 ? WGBSSEG_OK : (rc == 1 ? 1 : WGBSSEG_E_ARG);
 }
 
+int64_t wgbsseg_debug_canonical_float(const char* tokens, int64_t len, uint8_t* out, int64_t out_cap)
+{
+    if (!tokens || len < 0 || !out) return -1;
+    int64_t n = 0;
+    for (int64_t a = 0; a < len;) {
+        const char* nl = static_cast<const char*>(memchr(tokens + a, '\n', (size_t)(len - a)));
+        const int64_t b = nl ? (int64_t)(nl - tokens) : len;
+        if (n >= out_cap) return -1;
+        out[n++] = wgtab::canonical_float(tokens + a, (size_t)(b - a)) ? 1 : 0;
+        a = b + 1;
+    }
+    return n;
+}
+
 int wgbsseg_bed_write_annotated(const char* path, const char* text, const int64_t* line_off, const int32_t* len3, const int32_t* row_len,
                                 const int64_t* start_cpg, const int64_t* end_cpg, int64_t n_rows, int32_t threads, char* err, size_t errlen)
 {
