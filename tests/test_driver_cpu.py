@@ -514,3 +514,29 @@ def test_native_stitching_gives_up_like_the_reference(speculate, stitch_lib):
         eng = NeverOverlaps()
         bords = list(range(1, 451, 100)) + [451]
         _tree_merge(eng.segment_many(list(zip(bords[:-1], bords[1:])), {}), {'engine': eng})
+
+
+def test_blocks_file_loader_of_dash_L_both_parsers(tmp_path, monkeypatch):
+    """segment.py:94-103 (-L): the library's one-pass parser for plain, complete tables and the line-by-line parser for the rest
+    give the same rows and the same errors."""
+    from wgbs_tools_amd import segment as S
+    cases_ok = {'plain': 'chr1\t10\t20\t1\t3\nchr1\t20\t40\t3\t7\n', 'header': 'chr\tstart\tend\tstartCpG\tendCpG\nchr1\t10\t20\t1\t3\n',
+                'na': 'chr1\t10\t20\t1\t3\nchr1\t20\t40\tNA\tNA\nchr1\t50\t60\t9\t12\n', 'empty_field': 'chr1\t10\t20\t1\t3\nchr1\t20\t40\t\t\n',
+                'comments': '# c\nchr1\t10\t20\t1\t3\n\nchr1\t20\t40\t3\t7', 'bad_order': 'chr1\t10\t20\t5\t3\n', 'short': 'chr1\t10\t20\n',
+                'nan': 'chr1\t1\t2\tNaN\t4\n', 'float': 'chr1\t1\t2\t3.0\t4\n'}
+    for name, text in cases_ok.items():
+        p = tmp_path / (name + '.bed')
+        p.write_text(text)
+        res = []
+        for py in (False, True):
+            if py:
+                monkeypatch.setenv('WGBSSEG_PY_TABLES', '1')
+            try:
+                res.append(('ok', S.load_blocks_file(str(p)).tolist()))
+            except Exception as e:
+                res.append((type(e).__name__, str(e)))
+            if py:
+                monkeypatch.delenv('WGBSSEG_PY_TABLES')
+        assert res[0] == res[1], name
+        if name == 'plain':
+            assert res[0] == ('ok', [[1, 3], [3, 7]])

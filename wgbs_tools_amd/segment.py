@@ -523,6 +523,14 @@ def load_blocks_file(blocks_path):
     import gzip
     if not os.path.isfile(blocks_path):
         raise IllegalArgumentError(f'No such file: {blocks_path}')
+    # the library's one-pass parser when the table is plain and complete (no missing CpG fields: their spellings are this
+    # function's business); anything else line by line below
+    from .beta_to_blocks import _load_blocks_native
+    t = _load_blocks_native(blocks_path, None)
+    if t is not None and not t.na.any():
+        if (t.endCpG < t.startCpG).any():
+            raise IllegalArgumentError(f'Invalid CpG columns in blocks file {blocks_path}')
+        return np.stack([t.startCpG, t.endCpG], axis=1)
     opener = gzip.open if blocks_path.endswith('.gz') else open
     rows = []
     first = True
