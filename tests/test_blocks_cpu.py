@@ -291,3 +291,52 @@ def test_native_blocks_parser_and_writers_match_the_python_paths(world, tmp_path
         B2B.write_bedgraph(pa, df, rows)
         B2B.write_bedgraph(pb, dfp, rows)
         assert open(pa, 'rb').read() == open(pb, 'rb').read()
+
+
+def test_random_block_tables_fast_path_never_disagrees(tmp_path, monkeypatch):
+    """4,000 small random blocks tables over an alphabet of tricky fields: whatever the library's parser takes, it reads as the
+    line-by-line parser does (rows, CpG columns, missing flags, annotation columns, the nice-table verdict, nrows); what it
+    declines, the Python parser answers either way — same table or same exception from load_blocks_file."""
+    rng = np.random.default_rng(12)
+    cpg = ['1', '3', '7', '12', '007', '+5', '-3', '3.0', '1e1', ' 4', '4 ', 'NA', '', 'NaN', 'nan', 'N/A', 'NULL', 'None', 'x', '1234567890123456', '0']
+    taken = 0
+    for it in range(4000):
+        n_rows = int(rng.integers(0, 6))
+        rows = []
+        s0 = 1
+        for r in range(n_rows):
+            w = int(rng.choice([5, 5, 5, 5, 6, 7, 7, 3, 8]))
+            row = ['chr%d' % rng.integers(1, 4), str(int(rng.integers(1, 9999))), str(int(rng.integers(1, 9999)))]
+            if rng.random() < 0.7:
+                e0 = s0 + int(rng.integers(0, 5))
+                row += [str(s0), str(e0)]
+                s0 = e0 if rng.random() < 0.8 else e0 - 1
+            else:
+                row += [str(rng.choice(cpg)), str(rng.choice(cpg))]
+            row += ['anno%d' % r, 'GENE', 'more'][:max(0, w - 5)]
+            rows.append(row[:w])
+        text = '\n'.join('\t'.join(r) for r in rows) + ('\n' if rng.random() > 0.2 else '')
+        if rng.random() < 0.1:
+            text = '# comment\n\n' + text
+        if rng.random() < 0.1:
+            text = 'chr\tstart\tend\tstartCpG\tendCpG' + ('\tanno\tgene' if rng.random() < 0.5 else '') + '\n' + text
+        p = str(tmp_path / 't.bed')
+        with open(p, 'w') as f:
+            f.write(text)
+        for anno in (False, True):
+            res = []
+            for py in (False, True):
+                if py:
+                    monkeypatch.setenv('WGBSSEG_PY_TABLES', '1')
+                try:
+                    t = B2B.load_blocks_file(p, anno=anno, nrows=None if it % 3 else 2)
+                    res.append(('ok', t.chr, t.start, t.end, t.startCpG.tolist(), t.endCpG.tolist(), t.na.tolist(), t.columns,
+                                {k: list(t.extra[k]) for k in t.extra}, B2B.is_block_file_nice(t) if len(t) else None))
+                    if not py and t.parsed is not None:
+                        taken += 1
+                except Exception as e:
+                    res.append((type(e).__name__, str(e)))
+                if py:
+                    monkeypatch.delenv('WGBSSEG_PY_TABLES')
+            assert res[0] == res[1], (it, anno, text)
+    assert taken > 1000, taken

@@ -303,3 +303,52 @@ def test_score_columns_go_through_the_fast_path(cworld, tmp_path):
     rows[17][4] = '3'                                                      # an integer among decimals: 3.0 in the output
     open(p, 'w').write('\n'.join('\t'.join(r) for r in rows) + '\n')
     assert _fast_text(p, cworld, False, out)[0] is False
+
+
+def test_random_tables_fast_path_never_disagrees(cworld, tmp_path):
+    """3,000 small random BED tables over an alphabet of tricky tokens (numbers in every spelling, missing-value spellings, signs,
+    names that look like numbers, blanks): whenever the library's parser takes a table, the text it writes is the Python path's."""
+    from wgbs_tools_amd import _lib
+    names = cworld['names']
+    gen = G.GenomeRefPaths(cworld['ref'])
+    rng = np.random.default_rng(77)
+    alphabet = ['a', 'x1', 'n1', 'NA', '', 'nan', 'NaN', 'N/A', '0', '1', '7', '007', '+5', '-3', '0.5', '0.50', '1.0', '1.', '.5', '1e3', '1E-2', 'inf', '-inf',
+                'Infinity', '+', '-', '.', 'e', 'e5', '1_0', ' 1', '1 ', 'chr1', '12345678901234567890', '0.1', '0.30000000000000004', '2.5', '100.25', '-0.0',
+                '1,5', 'a b', 'None', 'null', '#', 'x#y', '3.0', '0.0001', '0.00001']
+    starts = ['100', '0', '1', '12', '012', '+3', '1.0', ' 4', '', 'NA', 'x', '99999', '1e2']
+    out = str(tmp_path / 'o.bed')
+    taken = 0
+    for it in range(3000):
+        width = int(rng.integers(3, 7))
+        n_rows = int(rng.integers(1, 6))
+        cols = [rng.choice(alphabet, size=int(rng.integers(1, 4)), replace=False).tolist() for _ in range(width)]
+        rows = []
+        for r in range(n_rows):
+            w = width if rng.random() > 0.03 else int(rng.integers(1, 8))
+            row = []
+            for c in range(w):
+                if c == 0:
+                    row.append(str(rng.choice(names + ['chrZ', '1'])) if rng.random() > 0.1 else str(rng.choice(alphabet)))
+                elif c in (1, 2):
+                    row.append(str(rng.choice(starts)) if rng.random() < 0.15 else str(int(rng.integers(0, 30000))))
+                else:
+                    row.append(str(rng.choice(cols[c % width])))
+            rows.append(row)
+        text = '\n'.join('\t'.join(r) for r in rows) + ('\n' if rng.random() > 0.2 else '')
+        if rng.random() < 0.05:
+            text = 'chrom\tstart\tend' + '\tc' * (width - 3) + '\n' + text
+        p = str(tmp_path / 't.bed')
+        with open(p, 'w') as f:
+            f.write(text)
+        err = io.StringIO()
+        with contextlib.redirect_stderr(err):
+            done = CV.annotate_bed_fast(p, gen, False, out, engine=OracleLociEngine(cworld['loci']))
+        if done is not True:
+            continue
+        taken += 1
+        werr = io.StringIO()
+        with contextlib.redirect_stderr(werr):
+            lines = CV.add_cpgs_to_bed(p, cworld['ref'], False, engine=OracleLociEngine(cworld['loci']))
+        want = '\n'.join(lines) + ('\n' if lines else '')
+        assert open(out).read() == want and err.getvalue() == werr.getvalue(), (it, text)
+    assert taken > 300, taken
