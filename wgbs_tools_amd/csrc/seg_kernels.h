@@ -2022,20 +2022,15 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
 #define WG_BSR_RUN 8
 #define WG_BSR_PK (WG_BSR_TILE + 16)          // packed in-lane prefixes of a tile (+ the entry behind its last site)
 
-// trunc(fl(fl(m / c) * 255)) — utils_wgbs.py:277-290 in float64 — without a float64 division on the common path: with
-// q = 255 m / c NOT an integer, the two roundings (relative 2^-52 each) cannot carry the product across an integer
-// (q is at least 1 / c > 2^-25 away from one), so the result is floor(q), taken in integers from a float estimate corrected
-// by one multiply-back; when q IS an integer the roundings decide whether it is reached, and the reference's own operations
-// are evaluated (a few per cent of the blocks).  m <= c < 2^24 (255 m < 2^32).
+// trunc(fl(fl(m / c) * 255)) — utils_wgbs.py:277-290 — with the reference's own float64 operations (division, product,
+// truncation; no contraction): 15 fp64 instructions, straight-line.  (Until the end of round 2 the common case — 255 m / c not an
+// integer, where the two roundings cannot carry the product across one — was taken in integers from a float estimate, 12
+// instructions, and only integer quotients went through float64.  But m = 0 and m = c ARE integer quotients, and with a few per
+// cent of such blocks per lane nearly every wavefront took both paths: 40 instructions per block and sample, a quarter of the
+// kernel's static instruction count — tools/micro/count_block_sums.py: 315 -> 231 VALU per tile and wavefront in mode 1.)
 __device__ __forceinline__ uint32_t wg_rescale_255(uint32_t m, uint32_t c)
 {
-    const uint32_t P = m * 255u;
-    uint32_t k = (uint32_t)((float)P * __builtin_amdgcn_rcpf((float)c));      // within 1 of floor(P / c): P / c <= 255, relative error < 2^-22
-    int32_t r = (int32_t)(P - k * c);
-    if (r < 0) { k -= 1u; r += (int32_t)c; }
-    if (r >= (int32_t)c) { k += 1u; r -= (int32_t)c; }
-    if (r == 0 || m > c) k = (uint32_t)(uint64_t)((double)m / (double)c * 255.0);
-    return k;
+    return (uint32_t)((double)m / (double)c * 255.0);
 }
 
 // k_block_sums_direct: the blocks the streaming kernel leaves out — those that begin before their run or more than a tile
