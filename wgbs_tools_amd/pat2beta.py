@@ -55,7 +55,7 @@ def _inflate_block(block):
     return zlib.decompress(block[12 + xlen:-8], -15)                 # raw deflate between the header and CRC32 + ISIZE
 
 
-def bgzf_pieces(path, read_bytes=16 << 20, threads=None):
+def bgzf_pieces(path, read_bytes=8 << 20, threads=None):
     """The text of a BGZF file (what `bgzip` writes and wgbstools' .pat.gz are: independent gzip blocks of <= 64 KB) in pieces,
     the blocks of every piece inflated on a pool of threads (zlib releases the interpreter lock) — a .pat.gz of a deep sample is
     gigabytes of text behind ONE `gunzip -c` in the reference (pat2beta.py:30).  Yields nothing and returns False when the file
