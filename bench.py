@@ -4,19 +4,32 @@
     python bench.py [--gpus N --steps K --warmup W] [--samples 32] [--sites 28217448]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one whole `segment` job over the resident beta bytes: scan/validate pass, window extents, block
-scoring, changepoint DP, traceback, junction patches and stitching (wgbsseg_segment_regions), borders back on the
-host.  Inputs are synthetic (seeded; wgbs_tools_amd/synth.py) and already in HBM when the timed region starts.
-N > 1 under torch.distributed.run: the chunk grid is cut into N contiguous runs of chunks (one per rank, balanced by the
-scored blocks they hold); every rank generates and holds only its own window; no collective on the data path, ranks
-only meet at the timing barrier.  `python bench.py --gpus N` WITHOUT the launcher drives N GPUs from this one process
-through a share group (the product's `wgbstools segment --gpus N`: one host thread per GPU, one host-side stitching
-tree).  Total work is fixed as N grows => "scaling": "strong".
+One "step" = one whole `segment` job over the resident beta bytes: scan/validate pass, window extents, block scoring,
+changepoint DP, traceback, junction patches and the reference's stitching tree, borders back on the host.  Inputs are
+synthetic (seeded; wgbs_tools_amd/synth.py) and already in HBM when the timed region starts.
 
-The JSON line carries `roofline` for the HBM-bound scan pass (k_validate for a job without wide tiles — the default
-genome —, k_scan with carries otherwise; algorithmic bytes = 2 * samples * sites per launch) measured with HIP events on the kernel's own stream inside the timed steps, the fp64-VALU
-bound scoring kernel's rate as `scoring`, and `cpu_baseline`: the reference's own `segmentor` (oracle/_ref, built
-from the reference sources) timed on this host on a bounded sample of the same workload.
+N = 1: wgbsseg_segment_regions on one context.
+N > 1 under torch.distributed.run (one process per GPU): the product's multi-process path, wgbs_tools_amd/parallel.py
+    ShardedRun — every rank computes the chunks and up-front junction patches it owns (work-balanced contiguous runs of
+    chunks; it generates and holds only its own window of the genome), hands its border lists to rank 0 through a slot in
+    /dev/shm, and rank 0 runs the ONE stitching tree over all chunks inside the timed step (follow-up patches on its own
+    GPU).  No collective on the data path; the ranks meet at the hand-over barrier of each step.
+N > 1 WITHOUT the launcher: one process drives N GPUs through a share group (`wgbstools segment --gpus N`).
+Total work is fixed as N grows => "scaling": "strong".
+
+The JSON line carries
+  roofline        the dominant kernel, k_cost (block log-likelihoods: ~85 % of a step).  Neither HBM- nor MFMA-bound: integer
+                  scan + scalar fp32/fp64 cost on the vector ALUs.  achieved = algorithmic flops (~55
+                  fp64-equivalent flops per (block, sample) evaluation) x evaluations per launch / the launch's duration (HIP
+                  events on the kernel's stream inside the timed steps), against the 78.6 TFLOP/s vector-fp64 peak; `issue` gives
+                  the instruction-issue bound of the kernel's actual instruction mix (profiles/*cost_isa_mix.json x the guide's
+                  cycle table).
+  roofline_scan   the HBM-bound scan pass (k_validate / k_scan): algorithmic bytes = 2 x samples x sites per launch.
+  block_sums      the block reduction (beta_to_blocks / beta_to_table kernel) over the blocks just found.
+  matrix          the same step at the other sample counts of the metric (x8, x200, x512), a few steps each.
+  cpu_baseline    the reference's own `segmentor` (oracle/_ref) on this host: 1 core, one process per physical core, one per
+                  logical CPU; bounded sample of the same workload.
+  end_to_end      the CLI on page-cached files (PCIe and file I/O included; never `value`).
 """
 import argparse
 import ctypes as C
@@ -35,10 +48,12 @@ sys.path.insert(0, ROOT)
 
 SEED = 20260926
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-FP64_VALU_PEAK = 78.6e12         # flop/s, vector fp64 (FMA counted as 2)
-VALU_PER_EVAL = 44.5             # VALU instructions per evaluation, common path (tools/micro/count_cost_loop.py): 8-instruction division core
-VALU_PER_EVAL_SHORT = 40.5       # the same with the verified 4-instruction division core (narrow tiles, pseudo count >= 1)
-FP64_FLOP_PER_EVAL = 29          # fp64 flops of one evaluation, FMA = 2: log2f 5 FMA + 1 mul, fast log2 7 FMA, fused sum 1 FMA, 1-p, accumulate
+FP64_VALU_PEAK = 78.6e12         # flop/s, vector fp64 (FMA counted as 2): 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz
+FLOP_PER_EVAL = 55               # one (block, sample) evaluation ~ 50-60 fp64-equivalent flops (2 int sub, 2 cvt, 2 fadd,
+                                 # fdiv, log2f, fmul, dsub, log2, dmul, 2 dadd, cvt)
+FP64_FLOP_EXECUTED = 29          # fp64 flops the kernel actually executes per evaluation (FMA = 2), informative
+N_SIMD, CLOCK_HZ = 256 * 4, 2.4e9
+MATRIX_SAMPLES = (8, 200, 512)   # the other sample counts of BASELINE.json's metric
 
 
 def parse():
@@ -53,89 +68,124 @@ def parse():
     ap.add_argument('--max-bp', type=int, default=2000)
     ap.add_argument('--pcount', type=float, default=15.0)
     ap.add_argument('--islands', action='store_true', help='add CpG islands to the synthetic loci (windows of several hundred sites; not the BASELINE workload)')
-    ap.add_argument('--block-sums', action='store_true', help='also time the block reduction (beta_to_blocks / beta_to_table kernel) over the blocks just found')
-    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='target wall time of the CPU baseline sample (0: skip)')
+    ap.add_argument('--block-sums', type=int, default=1, help='also time the block reduction over the blocks just found (0: skip)')
+    ap.add_argument('--matrix', type=int, default=1, help='also run a few steps at x8, x200 and x512 (1 GPU only; 0: skip)')
+    ap.add_argument('--cpu-seconds', type=float, default=25.0, help='wall-time budget of the CPU baseline runs (0: skip)')
     ap.add_argument('--e2e', type=int, default=1, help='also time the CLI end to end on page-cached files (1 GPU only; 0: skip)')
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference binary on this host
+# ------------------------------------------------------------------------------------------------------------
+def physical_cores():
+    """One logical CPU of every physical core this process may run on (thread_siblings_list), and all allowed logical CPUs."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, firsts = set(), []
+    for c in allowed:
+        try:
+            sib = open('/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % c).read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            firsts.append(c)
+    return firsts, allowed
+
+
 def cpu_baseline(args, buf, sizes, loci, seg, params):
-    """The reference `segmentor` (oracle/_ref, built from the reference's own sources) on this host's cores over a
-    bounded sample of the same workload: rounds of `cores` default-size chunks taken evenly from the genome's chunk
-    grid, one single-threaded process per core — the reference's own parallel shape (segment.py:144-146, a Pool of
-    chunk processes).  Falls back to the oracle's C port (threads) when the reference binary is absent.  Also
-    checks the GPU's borders for exactly those chunks against what the CPU produced."""
-    import threading
+    """The reference `segmentor` (oracle/_ref, built from the reference's own sources; the oracle's C port when it is absent) on
+    default-size chunks spread evenly over the genome's chunk grid, one single-threaded process per chunk — the reference's own
+    parallel shape (segment.py:144-146) — three ways: ONE process on one core, one process pinned to each PHYSICAL core, one per
+    LOGICAL CPU (every round of a run starts all its processes together).  `value` is the best of them.  The GPU's borders of the
+    sampled chunks are compared with the CPU's."""
     from oracle import oracle
-    cores = os.cpu_count() or 1
-    n = args.chunk
     kind = 'reference' if oracle.have_ref() else 'port'
+    phys, logical = physical_cores()
+    n = args.chunk
     grid, pos = [], 0
     for sz in sizes:                                       # full-size chunks only (0-based starts)
-        grid += [s for s in range(pos, pos + sz - n + 1, n)]
+        grid += list(range(pos, pos + sz - n + 1, n))
         pos += sz
     if not grid:
         grid, n = [0], min(n, sizes[0])
-    pick = [grid[i] for i in np.linspace(0, len(grid) - 1, min(len(grid), cores * 8)).astype(int)]
-    pick = sorted(set(pick))
-    done, wall, borders = 0, 0.0, {}
+    want = min(len(grid), len(logical))
+    pick = sorted(set(grid[i] for i in np.linspace(0, len(grid) - 1, want).astype(int)))
     td = tempfile.mkdtemp(dir='/dev/shm' if op.isdir('/dev/shm') else None)
-    try:
-        t_end = time.time() + args.cpu_seconds
-        while done < len(pick) and (done == 0 or time.time() < t_end):
-            todo = pick[done:done + cores]
-            host = {st: buf[:, 2 * st:2 * (st + n)].cpu().numpy() for st in todo}
+    borders, runs = {}, []
+    t_begin = time.time()
+
+    def prepare(st):
+        d = op.join(td, 'c%d' % st)
+        if op.isdir(d):
+            return
+        os.mkdir(d)
+        host = buf[:, 2 * st:2 * (st + n)].cpu().numpy()
+        for s in range(host.shape[0]):
+            host[s].tofile(op.join(d, 's%04d.beta' % s))
+        with open(op.join(d, 'loci.txt'), 'w') as f:
+            f.write('\n'.join(map(str, loci[st:st + n].tolist())) + '\n')
+
+    def run_round(chunks, cpus):
+        """all `chunks` at once, chunk i pinned to cpus[i] (None: wherever the scheduler puts it) -> wall seconds"""
+        for st in chunks:
+            prepare(st)
+        procs = []
+        t0 = time.time()
+        for i, st in enumerate(chunks):
+            d = op.join(td, 'c%d' % st)
             if kind == 'reference':
-                jobs = []
-                for st in todo:
-                    d = op.join(td, 'c%d' % st)
-                    os.mkdir(d)
-                    paths = []
-                    for s in range(host[st].shape[0]):
-                        pth = op.join(d, 's%04d.beta' % s)
-                        host[st][s].tofile(pth)
-                        paths.append(pth)
-                    cmd = [oracle.REF_BIN] + paths + ['-s', '0', '-n', str(n), '-max_cpg', str(params['max_cpg']),
-                                                     '-ps', repr(float(args.pcount)), '-max_bp', str(args.max_bp)]
-                    stdin = ('\n'.join(map(str, loci[st:st + n].tolist())) + '\n').encode()
-                    jobs.append((st, cmd, stdin))
-                outs = {}
+                cmd = [oracle.REF_BIN] + [op.join(d, 's%04d.beta' % s) for s in range(args.samples)] + \
+                      ['-s', '0', '-n', str(n), '-max_cpg', str(params['max_cpg']), '-ps', repr(float(args.pcount)), '-max_bp', str(args.max_bp)]
+            else:                                          # the oracle's C port through a tiny driver process
+                cmd = [sys.executable, '-c', 'import sys,numpy as np;sys.path.insert(0,%r);from oracle import oracle;'
+                       'd=%r;n=%d;sl=[np.fromfile(d+"/s%%04d.beta"%%s,dtype=np.uint8).reshape(-1,2) for s in range(%d)];'
+                       'print(*oracle.segment_chunk(sl,np.loadtxt(d+"/loci.txt",dtype=np.uint32),%r,%d,%d).tolist())'
+                       % (ROOT, d, n, args.samples, float(args.pcount), params['max_cpg'], args.max_bp)]
+            cpu = cpus[i] if cpus else None
+            procs.append(subprocess.Popen(cmd, stdin=open(op.join(d, 'loci.txt')), stdout=open(op.join(d, 'out.txt'), 'w'),
+                                          preexec_fn=(lambda c=cpu: os.sched_setaffinity(0, {c})) if cpu is not None else None))
+        for p in procs:
+            if p.wait() != 0:
+                raise RuntimeError('CPU baseline process failed')
+        wall = time.time() - t0
+        for st in chunks:
+            borders[st] = np.array(open(op.join(td, 'c%d' % st, 'out.txt')).read().split(), dtype=np.int64)
+        return wall
 
-                def run(st, cmd, stdin):
-                    outs[st] = subprocess.run(cmd, input=stdin, stdout=subprocess.PIPE, check=True).stdout
-                th = [threading.Thread(target=run, args=j) for j in jobs]
-                t0 = time.time()
-                [t.start() for t in th]
-                [t.join() for t in th]
-                wall += time.time() - t0
-                for st in todo:
-                    borders[st] = np.array(outs[st].split(), dtype=np.int64)
-            else:
-                t0 = time.time()
-
-                def runp(st):                              # ctypes drops the GIL: one chunk per thread
-                    sl = [host[st][s].reshape(-1, 2) for s in range(host[st].shape[0])]
-                    borders[st] = oracle.segment_chunk(sl, loci[st:st + n], args.pcount, params['max_cpg'], args.max_bp).astype(np.int64)
-                thr = [threading.Thread(target=runp, args=(st,)) for st in todo]
-                [t.start() for t in thr]
-                [t.join() for t in thr]
-                wall += time.time() - t0
-            done += len(todo)
+    try:
+        plans = [('1 core', [pick[len(pick) // 2]], [phys[0]])]
+        if len(phys) > 1:
+            sub = [pick[i] for i in np.linspace(0, len(pick) - 1, min(len(pick), len(phys))).astype(int)]
+            plans.append(('%d physical cores, one pinned process each' % len(sub), sub, phys[:len(sub)]))
+        if len(logical) > len(phys):
+            plans.append(('%d logical CPUs, one process each (unpinned)' % len(pick), pick, None))
+        for what, chunks, cpus in plans:
+            if runs and time.time() - t_begin > args.cpu_seconds:
+                runs.append({'what': what, 'skipped': 'time budget (--cpu-seconds %g) spent' % args.cpu_seconds})
+                continue
+            wall = run_round(chunks, cpus)
+            runs.append({'what': what, 'cores': len(chunks), 'chunks': len(chunks), 'wall_s': wall, 'value': len(chunks) * n / wall,
+                         'per_core': n / wall})
     finally:
         import shutil
         shutil.rmtree(td, ignore_errors=True)
     sts = sorted(borders)
     got = seg.segment_chunks(sts, [n] * len(sts), args.pcount, params['max_cpg'], args.max_bp)
     same = all(np.array_equal(g.astype(np.int64), borders[st]) for g, st in zip(got, sts))
-    used = min(cores, len(sts))
-    return {'value': len(sts) * n / wall, 'unit': 'CpG-sites/s', 'cores': used, 'kind': kind,
-            'sample': '%d chunks of %d CpGs x %d betas spread over the genome, %d concurrent single-threaded %s, %.1f s wall '
-                      '(host has %d logical CPUs)' % (len(sts), n, args.samples, used,
-                                                      'reference segmentor processes' if kind == 'reference' else 'oracle-port threads',
-                                                      wall, cores),
+    done = [r for r in runs if 'value' in r]
+    best = max(done, key=lambda r: r['value'])
+    return {'value': best['value'], 'unit': 'CpG-sites/s', 'cores': best['cores'], 'kind': kind,
+            'sample': 'default-size chunks (%d CpGs x %d betas) spread over the genome, single-threaded %s; best of the runs below: %s, %.1f s wall '
+                      '(host: %d physical cores, %d logical CPUs)' % (n, args.samples, 'reference segmentor processes' if kind == 'reference' else 'oracle-port processes',
+                                                                      best['what'], best['wall_s'], len(phys), len(logical)),
+            'single_core_value': done[0]['value'], 'runs': runs, 'chunks_compared_with_gpu': len(sts),
             'gpu_borders_identical_on_sample': bool(same)}
 
 
+# ------------------------------------------------------------------------------------------------------------
+# end to end through the CLI
+# ------------------------------------------------------------------------------------------------------------
 def end_to_end(args, buf, sizes, names, loci):
     """`wgbstools segment` as a user runs it: .beta files (just written: in the page cache) -> BED, through the CLI entry point in
     this process.  SURVEY.md 8(d)(ii); PCIe- and file-I/O-inclusive, never `value`."""
@@ -191,11 +241,37 @@ def end_to_end(args, buf, sizes, names, loci):
         shutil.rmtree(d, ignore_errors=True)
 
 
+# ------------------------------------------------------------------------------------------------------------
+# profiles keyed on the library's sources
+# ------------------------------------------------------------------------------------------------------------
+def keyed_profile(pattern, sha, **match):
+    """Newest profiles/<pattern> whose `csrc_sha` is this library's and whose other fields match; None otherwise (a profile of
+    another source state is not evidence for this one)."""
+    import glob
+    for f in sorted(glob.glob(op.join(ROOT, 'profiles', pattern)), reverse=True):
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            continue
+        if rec.get('csrc_sha') == sha and all(rec.get(k) == v for k, v in match.items()):
+            rec['_file'] = op.basename(f)
+            return rec
+    return None
+
+
+def accumulate(acc, t):
+    if acc is None:
+        return dict(t)
+    for k in t:
+        acc[k] = max(acc[k], t[k]) if k in ('max_window', 'n_stages', 'scan_main_bytes', 'div_short') else acc[k] + t[k]
+    return acc
+
+
 def main():
     args = parse()
     import torch
     import torch.distributed as dist
-    from wgbs_tools_amd import _lib, synth, parallel
+    from wgbs_tools_amd import _lib, synth, parallel, build as nbuild
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -206,9 +282,11 @@ def main():
     local = local % max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    host_group = None
     if world > 1:
         if oversub:
             dist.init_process_group('gloo')          # RCCL refuses two ranks on one device; the barrier is all we need
+            host_group = dist
         else:
             dist.init_process_group('nccl', device_id=dev)
 
@@ -219,17 +297,19 @@ def main():
     params = dict(max_cpg=max_cpg, pcount=args.pcount, max_bp=args.max_bp)
     regions = parallel.regions_of_sizes(sizes)
     S = _lib.load_synth()
+    sha = nbuild.source_hash()
 
-    def device_rows(lo, hi, device):
+    def device_rows(lo, hi, device, samples=None):
         """synthetic sites [lo, hi) of every sample, straight into the HBM of `device`"""
+        samples = samples or args.samples
         n = hi - lo
         pitch = ((2 * n + 255) // 256) * 256 + 256
-        b = torch.empty((args.samples, pitch), dtype=torch.uint8, device=torch.device('cuda', device))
-        rc = S.wgbssynth_fill_betas_range(C.c_void_p(b.data_ptr()), pitch, lo, hi, 0, args.samples, SEED, device)
+        b = torch.empty((samples, pitch), dtype=torch.uint8, device=torch.device('cuda', device))
+        rc = S.wgbssynth_fill_betas_range(C.c_void_p(b.data_ptr()), pitch, lo, hi, 0, samples, SEED, device)
         assert rc == 0, 'synthetic fill failed (hip error %d)' % rc
         return b, pitch
 
-    seg = grp = buf = None
+    seg = grp = buf = run = None
     shares = None
     if group_mode:
         devices = [d % max(1, ndev) for d in range(args.gpus)]
@@ -249,29 +329,68 @@ def main():
 
         def timings():
             return grp.timings(0)
-    else:
-        if world > 1:
-            # one process per GPU: this rank holds (and generates) only its own window of the genome
-            shares = parallel.plan(regions, args.chunk, world, loci, params)
-            lo, hi = int(shares['win_lo'][rank]), int(shares['win_hi'][rank])
-            mine = parallel.pieces_of_rank(regions, args.chunk, world, rank, loci, params, shares=shares)
-            n_chunks_total = int(shares['chunks'].sum())
-        else:
-            lo, hi = 0, args.sites
-            mine = [(i, a, b) for i, (a, b) in enumerate(regions)]
-            n_chunks_total = len(parallel.chunk_grid(regions, args.chunk))
+    elif world > 1:
+        # one process per GPU: the product's multi-process path (wgbs_tools_amd/parallel.py ShardedRun).  A rank generates and
+        # holds only its own window; rank 0, which also serves the follow-up patches of the tree, holds the genome.
+        if host_group is None:
+            host_group = dist.new_group(backend='gloo')      # the hand-over barrier of a step is a host-side one
+
+        class _G:                                            # the slice of torch.distributed ShardedRun uses, on the gloo group
+            @staticmethod
+            def barrier():
+                dist.barrier(group=host_group) if host_group is not dist else dist.barrier()
+
+            @staticmethod
+            def all_gather_object(out, obj):
+                dist.all_gather_object(out, obj, group=host_group) if host_group is not dist else dist.all_gather_object(out, obj)
+
+            @staticmethod
+            def broadcast_object_list(lst, src=0):
+                dist.broadcast_object_list(lst, src=src, group=host_group) if host_group is not dist else dist.broadcast_object_list(lst, src=src)
+
+            @staticmethod
+            def gather_object(obj, out, dst=0):
+                dist.gather_object(obj, out, dst=dst, group=host_group) if host_group is not dist else dist.gather_object(obj, out, dst=dst)
+        run = parallel.ShardedRun(_G, regions, args.chunk, loci, params, rank, world)
+        shares = run.shares
+        lo, hi = (0, args.sites) if rank == 0 else run.window()
+        n_chunks_total = int(shares['chunks'].sum())
         buf, pitch = device_rows(lo, max(hi, lo + 1), local)
         seg = _lib.Segmenter(local)
         seg.set_betas_device(buf.data_ptr(), args.samples, pitch, max(hi - lo, 1), keepalive=buf)
         seg.set_loci(loci[lo:max(hi, lo + 1)])
         seg.set_site_base(lo)
-        st = np.array([p[1] for p in mine], dtype=np.int64) - lo
-        en = np.array([p[2] for p in mine], dtype=np.int64) - lo
-        my_sites = int((en - st).sum())
+        my_sites = int((run.ends[run.idx[rank]] - run.starts[run.idx[rank]])[run.idx[rank] < run.n_chunks].sum())
+        own_acc = [None]
+
+        def compute(starts, ends, off=None, out=None):
+            flat, off = seg.segment_chunks_csr(starts - 1 - lo, (ends - starts).astype(np.int32), args.pcount, max_cpg, args.max_bp, out=out, off=off)
+            own_acc[0] = seg.timings()                       # (of the rank's own items: rank 0's follow-up patches are not in it)
+            return off, flat
+
+        def patches(starts, ends):                            # rank 0: what the tree's rehearsal still misses (a hundred ~100-site patches)
+            flat, off = seg.segment_chunks_csr(starts - 1 - lo, (ends - starts).astype(np.int32), args.pcount, max_cpg, args.max_bp)
+            return off, flat
 
         def step():
-            if not len(st):
-                return [], {}
+            merged = run.step(compute, patches, copy=False)
+            return merged, (run.last_stats or {})
+
+        def timings():
+            return own_acc[0]
+    else:
+        lo, hi = 0, args.sites
+        n_chunks_total = len(parallel.chunk_grid(regions, args.chunk))
+        buf, pitch = device_rows(lo, hi, local)
+        seg = _lib.Segmenter(local)
+        seg.set_betas_device(buf.data_ptr(), args.samples, pitch, hi - lo, keepalive=buf)
+        seg.set_loci(loci)
+        seg.set_site_base(0)
+        st = np.array([a for a, _ in regions], dtype=np.int64)
+        en = np.array([b for _, b in regions], dtype=np.int64)
+        my_sites = args.sites
+
+        def step():
             return seg.segment_regions(st, en, args.chunk, args.pcount, max_cpg, args.max_bp, copy=False)
 
         def timings():
@@ -293,58 +412,69 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res, stats = step()
-        t = timings()
-        if acc is None:
-            acc = dict(t)
-        else:
-            for k in t:
-                acc[k] = max(acc[k], t[k]) if k in ('max_window', 'n_stages', 'scan_main_bytes', 'div_short') else acc[k] + t[k]
+        acc = accumulate(acc, timings())
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device='cpu' if oversub else dev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    n_blocks = int(sum(len(r) - 1 for r in res))
-    block_sums = None
-    if args.block_sums and rank == 0 and seg is not None:
-        # the immediate consumer of the borders: (#meth, #cov) of every block in every sample.
-        # Algorithmic bytes = 2 * N * (sites covered); the D2H copy of the table is outside the kernel time.
-        bs = np.concatenate([np.asarray(r[:-1], dtype=np.int64) for r in res]) - 1
-        be = np.concatenate([np.asarray(r[1:], dtype=np.int64) for r in res]) - 1
-        times = []
-        for mode in (1, 1, 1, 3):
-            seg.block_sums(bs, be, mode=mode, min_cov=4)
-            times.append(seg.last_block_sums_ms())
-        covered = int((be - bs).sum())
-        block_sums = {'kernel': 'k_block_sums (per block, per sample sums of meth/cov; .bin rows or means)', 'blocks': int(bs.size),
-                      'ms_bin_rows': min(times[:3]), 'ms_means': times[3], 'algorithmic_bytes': 2 * covered * args.samples,
-                      'GB_per_s': 2 * covered * args.samples / (min(times[:3]) * 1e-3) / 1e9, 'frac_of_hbm_peak': 2 * covered * args.samples / (min(times[:3]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0:
+        n_blocks = int(sum(len(r) - 1 for r in res))
+        block_sums = None
+        if args.block_sums and seg is not None:
+            # the immediate consumer of the borders: (#meth, #cov) of every block in every sample.
+            # Algorithmic bytes = 2 * N * (sites covered); the D2H copy of the table is outside the kernel time.
+            bs = np.concatenate([np.asarray(r[:-1], dtype=np.int64) for r in res]) - 1
+            be = np.concatenate([np.asarray(r[1:], dtype=np.int64) for r in res]) - 1
+            times = []
+            for mode in (1, 1, 1, 1, 1, 3, 3, 0, 0):
+                seg.block_sums(bs, be, mode=mode, min_cov=4)
+                times.append(seg.last_block_sums_ms())
+            covered = int((be - bs).sum())
+            alg = 2 * covered * args.samples
+            t_bin = min(times[:5])
+            block_sums = {'kernel': 'k_block_sums_prep + k_block_sums_run + k_block_sums_direct (per block, per sample sums of meth/cov -> .bin rows; HIP events around the launches)',
+                          'blocks': int(bs.size), 'ms_bin_rows': t_bin, 'ms_bin_rows_all': times[:5], 'ms_means': min(times[5:7]), 'ms_raw_sums': min(times[7:9]),
+                          'algorithmic_bytes': alg, 'GB_per_s': alg / (t_bin * 1e-3) / 1e9, 'frac_of_hbm_peak': alg / (t_bin * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
+
         ms_step = dt / args.steps * 1e3
         value = args.sites / (dt / args.steps)
-        # dominant kernel launch = the scan of the batch that holds the chunks (one per step); the follow-up batches
-        # (a few hundred ~100-site patches) launch it on kilobytes and are reported separately
+        # the scan pass: the launch of the batch that holds the chunks (one per step); the follow-up batches (a few hundred
+        # ~100-site patches) launch it on kilobytes and are reported separately
         main_ms = acc['scan_main_ms'] / args.steps
         scan_gbs = acc['scan_main_bytes'] / (main_ms * 1e-3) / 1e9
         scan_all_gbs = acc['scan_bytes'] / (acc['scan_ms'] * 1e-3) / 1e9
         evals_s = acc['evals'] / (acc['cost_ms'] * 1e-3)
-        valu_per_eval = VALU_PER_EVAL_SHORT if acc.get('div_short') else VALU_PER_EVAL
         stats_wide = acc['max_window'] > 60          # WG_NARROW_WMAX: wide scoring tiles exist, so the scan keeps its carries
-        # HBM traffic of that launch from the PMC counters (collected separately with rocprofv3, profiles/): only
-        # reported when the committed measurement is for exactly this workload
-        traffic, traffic_note = None, 'traffic: PMC pass not available for this workload'
-        for tj in (op.join(ROOT, 'profiles', 'r02_scan_traffic.json'), op.join(ROOT, 'profiles', 'r01_scan_traffic.json')):
-            if op.isfile(tj) and world == 1 and not group_mode:
-                tr = json.load(open(tj))
-                if abs(tr['algorithmic_bytes'] - acc['scan_main_bytes']) <= 0.001 * acc['scan_main_bytes']:
-                    traffic = tr['traffic_bytes']
-                    traffic_note = ('traffic (bytes per launch) = 2 x FETCH_SIZE + WRITE_SIZE from profiles/%s '
-                                    '(rocprofv3 PMC passes of this same command; gfx950 FETCH_SIZE x2 correction)' % op.basename(tj))
-                    break
+        scan_kernel = 'k_scan' if stats_wide else 'k_validate'
+        # HBM traffic of the scan launch from the PMC counters (separate rocprofv3 passes, tools/pmc_scan_traffic.py): only a file
+        # made from THIS source state, for this kernel and these algorithmic bytes, is reported
+        tr = keyed_profile('*scan_traffic*.json', sha, kernel=scan_kernel) if (world == 1 and not group_mode) else None
+        traffic, traffic_note = None, 'traffic: no PMC pass of this source state (csrc_sha %s) for %s on this workload under profiles/' % (sha, scan_kernel)
+        if tr and abs(tr['algorithmic_bytes'] - acc['scan_main_bytes']) <= 0.001 * acc['scan_main_bytes']:
+            traffic = tr['traffic_bytes']
+            traffic_note = ('traffic (bytes per launch) = 2 x FETCH_SIZE + WRITE_SIZE from profiles/%s (rocprofv3 PMC passes of this command on this '
+                            'source state; gfx950 FETCH_SIZE x2 correction)' % tr['_file'])
+        # instruction mix of the scoring kernel's evaluation (tools/micro/count_cost_loop.py --json), same keying
+        mixes = {k: keyed_profile('*cost_isa_mix_%s.json' % k, sha) for k in ('narrow', 'narrow128', 'wide')}
+        main_mix = mixes['narrow128' if args.samples <= 16 else 'narrow']
+        issue = None
+        if main_mix:
+            cyc = main_mix['issue_cycles_per_eval']
+            issue = {'cycles_per_eval_per_wavefront': cyc, 'valu_instr_per_eval': main_mix['valu_per_eval'], 'mix_per_eval': main_mix['mix_per_eval'],
+                     'cycles_per_class': main_mix['cycles_per_class'], 'peak_evals_per_s': N_SIMD * 64 * CLOCK_HZ / cyc,
+                     'frac': evals_s / (N_SIMD * 64 * CLOCK_HZ / cyc), 'file': main_mix['_file'],
+                     'note': 'issue bound of the narrow-tile kernel\'s common path: sum over instruction classes of count x issue cycles per wavefront '
+                             'instruction (fp32 2, fp64 / conversions / 3-operand integer 4, v_rcp_f32 8) on %d SIMDs at %.1f GHz; wide tiles (when the job '
+                             'has any) run a longer evaluation: %s VALU' % (N_SIMD, CLOCK_HZ * 1e-9, mixes['wide']['valu_per_eval'] if mixes['wide'] else '?')}
         mode = ('one process, %d GPUs: a share group (work-balanced contiguous chunk runs, one host thread per GPU, one host-side tree)' % args.gpus
-                if group_mode else 'one process per GPU: work-balanced contiguous chunk runs per rank, no collective' if world > 1 else 'one GPU')
+                if group_mode else
+                'one process per GPU (parallel.ShardedRun): work-balanced contiguous chunk runs per rank, border lists handed to rank 0 through /dev/shm, '
+                'ONE stitching tree on rank 0 inside the timed step; no collective' if world > 1 else 'one GPU')
+        cost_ms = acc['cost_ms'] / args.steps
         out = {
             'metric': 'CpG-sites/sec segmented',
             'value': value, 'unit': 'CpG-sites/s', 'n_gpus': args.gpus if group_mode else world, 'steps': args.steps, 'warmup': args.warmup,
@@ -357,46 +487,82 @@ def main():
                        'chunks': n_chunks_total, 'chromosomes': len(sizes), 'sharding': mode,
                        'share_chunks': None if shares is None else [int(x) for x in shares['chunks']],
                        'share_work': None if shares is None else [int(x) for x in shares['work']],
-                       'rank0_sites': my_sites, 'rank0_stats': stats, 'rank0_blocks': n_blocks},
-            'roofline': {'kernel': ('k_scan (per-sample prefix scan -> 128-site carries + meth<=cov validation: the job has wide tiles)' if stats_wide else
-                                    'k_validate (the scan pass of a job without wide tiles: every beta byte read once, meth<=cov checked; no carries needed)'), 'bound': 'hbm',
-                         'achieved': scan_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': scan_gbs / HBM_PEAK_GBS,
-                         'traffic': traffic,
-                         'algorithmic_bytes_per_launch': acc['scan_main_bytes'], 'avg_launch_ms': main_ms,
-                         'launches_timed': args.steps,
-                         'all_launches': {'count': acc['scan_launches'], 'bytes': acc['scan_bytes'], 'ms': acc['scan_ms'],
-                                          'GB/s': scan_all_gbs},
-                         'note': 'rank 0 / share 0, HIP events on the kernel stream inside the timed steps; ' + traffic_note},
-            # the kernel that IS the step (k_cost: ~85 %): neither HBM- nor MFMA-bound, the bound is VALU issue.
-            # VALU_PER_EVAL = VALU instructions per (block, sample) evaluation on the common path of the guard-free form in the
-            # gfx950 ISA (tools/micro/count_cost_loop.py); issue peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.
-            # fp64: FP64_FLOP_PER_EVAL counts the fp64 VALU work of one evaluation with an FMA as 2 against the
-            # 78.6 TFLOP/s vector-fp64 peak - informative only, the kernel also spends issue slots on fp32/int/conversions.
-            'roofline_cost': {'kernel': 'k_cost (block log-likelihoods)', 'bound': 'valu-issue',
-                              'achieved': evals_s * valu_per_eval, 'peak': 256 * 4 * 16 * 2.4e9, 'unit': 'lane-ops/s',
-                              'frac': evals_s * valu_per_eval / (256 * 4 * 16 * 2.4e9),
-                              'evals_per_s': evals_s, 'valu_instr_per_eval': valu_per_eval,
-                              'division_core': '4 instructions, verified on the device for this pseudo count' if acc.get('div_short') else '8 instructions',
-                              'fp64_flop_per_eval': FP64_FLOP_PER_EVAL, 'fp64_tflops': evals_s * FP64_FLOP_PER_EVAL / 1e12,
-                              'fp64_frac_of_peak': evals_s * FP64_FLOP_PER_EVAL / FP64_VALU_PEAK,
-                              'evals_per_step': acc['evals'] / args.steps, 'pairs_per_step': acc['pairs'] / args.steps,
-                              'max_window': acc['max_window'], 'stages': acc['n_stages'],
-                              'avg_ms_per_step': acc['cost_ms'] / args.steps},
+                       'rank0_sites': my_sites, 'rank0_stats': stats, 'rank0_blocks': n_blocks, 'csrc_sha': sha},
+            # the kernel that IS the step.  Not HBM- and not MFMA-bound (integer scan + scalar cost on the vector ALUs): priced in
+            # algorithmic flops against the vector-fp64 peak, with the instruction-issue bound of its real mix beside it.
+            'roofline': {'kernel': 'k_cost (block log-likelihoods: %.0f %% of the step)' % (100 * cost_ms / ms_step), 'bound': 'valu (vector fp64 peak; no MFMA: not a contraction)',
+                         'achieved': evals_s * FLOP_PER_EVAL / 1e12, 'peak': FP64_VALU_PEAK / 1e12, 'unit': 'TFLOP/s',
+                         'frac': evals_s * FLOP_PER_EVAL / FP64_VALU_PEAK, 'traffic': None,
+                         'algorithmic_flop_per_eval': FLOP_PER_EVAL, 'evals_per_launch': acc['evals'] / args.steps, 'avg_launch_ms': cost_ms,
+                         'launches_timed': args.steps, 'evals_per_s': evals_s,
+                         'fp64_flop_executed_per_eval': FP64_FLOP_EXECUTED, 'fp64_executed_frac_of_peak': evals_s * FP64_FLOP_EXECUTED / FP64_VALU_PEAK,
+                         'issue': issue, 'division_core': '4 instructions, verified on the device for this pseudo count' if acc.get('div_short') else '8 instructions',
+                         'pairs_per_step': acc['pairs'] / args.steps, 'max_window': acc['max_window'], 'stages': acc['n_stages'],
+                         'note': 'rank 0 / share 0; HIP events on the scoring stream inside the timed steps; traffic: the kernel reads the beta bytes of its '
+                                 'tiles through L2 (HBM-side traffic is that of the scan pass, not a bound here)'},
+            'roofline_scan': {'kernel': ('k_scan (per-sample prefix scan -> 128-site carries + meth<=cov validation: the job has wide tiles)' if stats_wide else
+                                         'k_validate (the scan pass of a job without wide tiles: every beta byte read once, meth<=cov checked; no carries needed)'), 'bound': 'hbm',
+                              'achieved': scan_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': scan_gbs / HBM_PEAK_GBS,
+                              'traffic': traffic,
+                              'algorithmic_bytes_per_launch': acc['scan_main_bytes'], 'avg_launch_ms': main_ms,
+                              'launches_timed': args.steps,
+                              'all_launches': {'count': acc['scan_launches'], 'bytes': acc['scan_bytes'], 'ms': acc['scan_ms'],
+                                               'GB/s': scan_all_gbs},
+                              'note': 'rank 0 / share 0, HIP events on the kernel stream inside the timed steps; ' + traffic_note},
             'block_sums': block_sums,
             'device_ms_per_step': {k: acc[k] / args.steps for k in ('scan_ms', 'window_ms', 'cost_ms', 'dp_ms', 'trace_ms', 'total_ms')},
         }
-        if world == 1 and not group_mode and args.e2e:
+        single = world == 1 and not group_mode
+        if single and args.e2e:
             try:
                 out['end_to_end'] = end_to_end(args, buf, sizes, names, loci)
             except Exception as e:
                 out['end_to_end'] = {'value': None, 'what': 'failed: %r' % (e,)}
-        if world == 1 and not group_mode and args.cpu_seconds > 0:
+        if single and args.cpu_seconds > 0:
             try:
                 out['cpu_baseline'] = cpu_baseline(args, buf, sizes, loci, seg, params)
                 out['cpu_baseline']['gpu_over_cpu'] = value / out['cpu_baseline']['value']
             except Exception as e:                       # the baseline must never break the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'CpG-sites/s', 'cores': os.cpu_count(), 'kind': 'reference',
                                        'sample': 'failed: %r' % (e,)}
+        if single and args.matrix:
+            # the other sample counts of the metric, same genome and parameters, a few steps each (timed like the main run)
+            rows = []
+            seg.close()
+            seg, buf = None, None
+            torch.cuda.empty_cache()
+            for ns in MATRIX_SAMPLES:
+                if ns == args.samples:
+                    continue
+                try:
+                    b2, pitch2 = device_rows(0, args.sites, local, samples=ns)
+                    s2 = _lib.Segmenter(local)
+                    s2.set_betas_device(b2.data_ptr(), ns, pitch2, args.sites, keepalive=b2)
+                    s2.set_loci(loci)
+                    k = 5 if ns <= 32 else 3 if ns <= 200 else 2
+                    s2.segment_regions(st, en, args.chunk, args.pcount, max_cpg, args.max_bp, copy=False)
+                    torch.cuda.synchronize()
+                    a2, t1 = None, time.perf_counter()
+                    for _ in range(k):
+                        r2, _st = s2.segment_regions(st, en, args.chunk, args.pcount, max_cpg, args.max_bp, copy=False)
+                        a2 = accumulate(a2, s2.timings())
+                    torch.cuda.synchronize()
+                    d2 = (time.perf_counter() - t1) / k
+                    ev2 = a2['evals'] / (a2['cost_ms'] * 1e-3)
+                    rows.append({'samples': ns, 'steps': k, 'ms_per_step': d2 * 1e3, 'value': args.sites / d2, 'unit': 'CpG-sites/s',
+                                 'blocks': int(sum(len(r) - 1 for r in r2)),
+                                 'cost_ms': a2['cost_ms'] / k, 'dp_ms': a2['dp_ms'] / k, 'scan_ms': a2['scan_main_ms'] / k,
+                                 'evals_per_s': ev2, 'roofline_frac': ev2 * FLOP_PER_EVAL / FP64_VALU_PEAK,
+                                 'scan_GB_per_s': a2['scan_main_bytes'] / (a2['scan_main_ms'] / k * 1e-3) / 1e9,
+                                 'scan_frac_of_hbm_peak': a2['scan_main_bytes'] / (a2['scan_main_ms'] / k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 'beta_GB_resident': ns * pitch2 / 1e9})
+                    s2.close()
+                    del b2, s2
+                    torch.cuda.empty_cache()
+                except Exception as e:
+                    rows.append({'samples': ns, 'failed': repr(e)})
+            out['matrix'] = {'what': 'the same whole-genome step at the other sample counts of the metric (inputs resident, 1 warm-up, timed with '
+                                     'synchronize + perf_counter around the steps like the main run)', 'rows': rows}
         print(json.dumps(out), flush=True)
     if seg is not None:
         seg.close()
@@ -404,6 +570,8 @@ def main():
         grp.close()
     if world > 1:
         dist.barrier() if oversub else dist.barrier(device_ids=[local])
+        if run is not None:
+            run.close()
         dist.destroy_process_group()
 
 

@@ -151,6 +151,18 @@ int wgbsseg_stitch_regions(const int64_t* region_start, const int64_t* region_en
                            wgbsseg_batch_fn fn, void* user, int32_t speculate, int32_t* borders_out, int64_t borders_cap,
                            int64_t* borders_off, int64_t* stats, char* err, size_t errlen);
 
+/*
+ * The site ranges of the FIRST batch wgbsseg_segment_regions / wgbsseg_stitch_regions hand to their chunk engine for these
+ * regions: the chunks of the grid (segment.py:124-135; *n_chunks of them, region by region), then the junction patches
+ * planned up front (first attempts, and with speculate != 0 the three possible second attempts: segment.py:209-227), 1-based
+ * half-open, no repeats.  A pure function of the arguments: the ranks of a multi-process run (one process per GPU) each
+ * work out this list, compute the items whose first site they hold, and rank 0 hands the gathered lists to
+ * wgbsseg_stitch_regions as its first batch.  starts / ends may be NULL to ask for *n_items only.
+ */
+int wgbsseg_first_batch_items(const int64_t* region_start, const int64_t* region_end, int64_t n_regions, int64_t chunk_size,
+                              int32_t speculate, int64_t* starts, int64_t* ends, int64_t cap, int64_t* n_items, int64_t* n_chunks,
+                              char* err, size_t errlen);
+
 /* Absolute 0-based index of resident site 0 (default 0).  Coordinates of every call stay relative to the resident data;
  * the base only makes error messages ("invalid data ... site N") name absolute sites when a context holds a slice. */
 int wgbsseg_set_site_base(wgbsseg_ctx* ctx, int64_t site_base);

@@ -280,3 +280,56 @@ def test_x512_deep_share():
             assert np.array_equal(eng.asked[(s0 + 1, s0 + 1 + n)] - (s0 + 1), ref[(s0, n)])
     del buf
     torch.cuda.empty_cache()
+
+
+def test_x512_deep_full_genome(hg19):
+    """BASELINE.json configs[4] at FULL size on one GPU: 28,217,448 CpGs x 512 betas (28.9 GB resident), max_cpg 5000, max_bp 1e6,
+    chunk_size 50000 — 576 chunks, every window 5000 sites wide: 1.4e11 scored blocks x 512 samples = 7.2e13 evaluations through
+    the staged scored-block buffer (WGBSSEG_COST_BUDGET_MB), the wide scoring tiles, the <15,32> recurrence and its L2 ring.
+    Checked: the genome-wide properties; full 50,000-site chunks spread over the genome (WGBSSEG_DEEP_ORACLE_CHUNKS, default 4;
+    1.3e11 evaluations each on all host threads) against the oracle's many-thread restatement; the stitched trees of chr21 and chr22
+    against the reference's pairwise tree walked over the same DPs.  The run's timing goes to gpurun_out/deep_full_timing.json."""
+    import json
+    import time
+    import torch
+    N, chunk, pc, max_bp = 512, 50000, 15.0, 1000000
+    mc = min(5000, max_bp // 2)                              # segment.py:65
+    torch.cuda.empty_cache()
+    buf, pitch = _device_genome(SITES, N)
+    loci, regions, sizes = hg19['loci'], hg19['regions'], hg19['sizes']
+    with _lib.Segmenter(0) as seg:
+        seg.set_betas_device(buf.data_ptr(), N, pitch, SITES, keepalive=buf)
+        seg.set_loci(loci)
+        t0 = time.perf_counter()
+        res, stats = _run_whole(seg, regions, chunk, pc, mc, max_bp)
+        wall = time.perf_counter() - t0
+        tm = seg.timings()
+        n_chunks = sum(len(_grid(a, e, chunk)) for a, e in regions)
+        assert stats['chunks'] == n_chunks == 576
+        _check_properties(res, regions, loci, mc, max_bp)
+        rec = {'workload': 'hg19-shaped %d CpGs x %d betas, max_cpg %d, max_bp %d, chunk_size %d, pcount %g (BASELINE.json configs[4], whole genome, ONE MI355X)' % (SITES, N, mc, max_bp, chunk, pc),
+               'wall_s': wall, 'value_CpG_sites_per_s': SITES / wall, 'chunks': int(stats['chunks']), 'stitch_stats': {k: int(v) for k, v in stats.items()},
+               'device_ms': {k: tm[k] for k in ('scan_ms', 'window_ms', 'cost_ms', 'dp_ms', 'trace_ms', 'total_ms')},
+               'evals': int(tm['evals']), 'pairs': int(tm['pairs']), 'stages': int(tm['n_stages']), 'max_window': int(tm['max_window']),
+               'evals_per_s_in_k_cost': tm['evals'] / (tm['cost_ms'] * 1e-3),
+               # the recurrence's row traffic: every scored block (8 B) is read once by the workers of k_dp<15,32> and pushed
+               'dp_row_bytes': int(tm['pairs']) * 8, 'dp_row_GB_per_s': tm['pairs'] * 8 / (tm['dp_ms'] * 1e-3) / 1e9,
+               'dp_row_frac_of_hbm_peak': tm['pairs'] * 8 / (tm['dp_ms'] * 1e-3) / 1e9 / 8000.0,
+               'blocks': int(sum(len(r) - 1 for r in res))}
+        os.makedirs('gpurun_out', exist_ok=True)
+        with open(op.join('gpurun_out', 'deep_full_timing.json'), 'w') as f:
+            json.dump(rec, f, indent=1)
+        print('deep full genome: %.1f s, %s' % (wall, json.dumps(rec['device_ms'])))
+        # full chunks spread over the genome against the oracle restatement
+        k = int(os.environ.get('WGBSSEG_DEEP_ORACLE_CHUNKS', '4'))
+        pick = _spread_chunks(sizes, chunk, k)
+        got = seg.segment_chunks(pick, [chunk] * len(pick), pc, mc, max_bp)
+        for st, g in zip(pick, got):
+            host = buf[:, 2 * st:2 * (st + chunk)].cpu().numpy()
+            want = oracle.segment_chunk_mt([host[s].reshape(-1, 2) for s in range(N)], loci[st:st + chunk], pc, mc, max_bp)
+            assert np.array_equal(g.astype(np.int64), want.astype(np.int64)), 'full deep chunk at site %d differs from the oracle restatement' % st
+            del host
+        # the stitched trees of chr21 and chr22 (9 and 10 chunks) against the reference's pairwise tree over the same DPs
+        _stitched_vs_tree(seg, res, regions, [20, 21], chunk, pc, mc, max_bp)
+    del buf
+    torch.cuda.empty_cache()

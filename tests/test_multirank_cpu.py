@@ -37,6 +37,7 @@ WORKER = textwrap.dedent('''
         mine = parallel.chunks_of_rank(regions, chunk, world, rank, loci, params)
         local = list(zip(mine, eng.segment_many(mine, pr)))
         gathered = parallel.gather_to_rank0(local, rank, world)
+        want = None
         if rank == 0:
             assert sorted(k for part in gathered for k, _ in part) == sorted((s, e) for _, s, e in parallel.chunk_grid(regions, chunk))
             assert all(len(part) > 0 for part in gathered)
@@ -56,6 +57,27 @@ WORKER = textwrap.dedent('''
             grown = any(b - a > 100 for a, b in asked)
             verdicts.append((name, ok, grown))
         dist.barrier()
+        # the product's form (parallel.ShardedRun: every rank computes the items of the stitcher's first batch that it owns,
+        # slots in /dev/shm or - second pass - a gather of objects), three steps each so that the two slots alternate
+        for no_shm in ('', '1'):
+            os.environ['WGBSSEG_NO_SHM'] = no_shm
+            run = parallel.ShardedRun(dist, regions, chunk, loci, params, rank, world)
+            assert run.slots.shared == (no_shm == '')
+            late = []
+            def patches(st, en, _e=parallel.csr_engine(eng, pr)):
+                late.extend((en - st).tolist())
+                return _e(st, en)
+            for step in range(3):
+                merged = run.step(parallel.csr_engine(eng, pr), patches)
+                if rank == 0:
+                    ok = all(np.array_equal(m, w) for m, w in zip(merged, want))
+                    verdicts.append((name + ' sharded' + (' objects' if no_shm else ' shm') + ' step %%d' %% step, ok, any(x > 100 for x in late)))
+                else:
+                    assert merged is None
+            assert sum(i.size for i in run.idx) == run.starts.size and all(i.size for i in run.idx)
+            run.close()
+            dist.barrier()
+        os.environ.pop('WGBSSEG_NO_SHM', None)
     if rank == 0:
         good = all(ok for _, ok, _ in verdicts) and any(g for n, _, g in verdicts if n.startswith('fickle'))
         print('MULTIRANK_OK' if good else 'MULTIRANK_DIFF', verdicts, flush=True)

@@ -31,6 +31,25 @@ __global__ __launch_bounds__(256) void k(int iters, float* out, float seed)
         if (OP == 8) { REP8(asm volatile("v_cvt_f32_u32 %0, %4\n v_cvt_f32_u32 %1, %5\n v_cvt_f32_u32 %2, %6\n v_cvt_f32_u32 %3, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
         if (OP == 9) { REP8(asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
         if (OP == 10) { REP8(asm volatile("v_lshl_add_u32 %0, %0, 3, %0\n v_lshl_add_u32 %1, %1, 3, %1\n v_lshl_add_u32 %2, %2, 3, %2\n v_lshl_add_u32 %3, %3, 3, %3" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 16) { REP8(asm volatile("v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %1, 3, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 3, %3" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 17) { REP8(asm volatile("v_and_b32 %0, 0xfffffff0, %0\n v_and_b32 %1, 0xfffffff0, %1\n v_and_b32 %2, 0xfffffff0, %2\n v_and_b32 %3, 0xfffffff0, %3" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 18) { REP8(asm volatile("v_ashrrev_i32 %0, 3, %0\n v_ashrrev_i32 %1, 3, %1\n v_ashrrev_i32 %2, 3, %2\n v_ashrrev_i32 %3, 3, %3" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 19) { REP8(asm volatile("v_and_or_b32 %0, %0, 63, %1\n v_and_or_b32 %1, %1, 63, %2\n v_and_or_b32 %2, %2, 63, %3\n v_and_or_b32 %3, %3, 63, %0" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 20) { REP8(asm volatile("v_add3_u32 %0, %0, %1, %2\n v_add3_u32 %1, %1, %2, %3\n v_add3_u32 %2, %2, %3, %0\n v_add3_u32 %3, %3, %0, %1" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 21) { REP8(asm volatile("v_perm_b32 %0, %0, %1, %2\n v_perm_b32 %1, %1, %2, %3\n v_perm_b32 %2, %2, %3, %0\n v_perm_b32 %3, %3, %0, %1" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 22) { REP8(asm volatile("v_cvt_f32_ubyte0 %0, %4\n v_cvt_f32_ubyte1 %1, %5\n v_cvt_f32_ubyte2 %2, %6\n v_cvt_f32_ubyte3 %3, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
+        if (OP == 23) { REP8(asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %0" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 24) { REP8(asm volatile("v_mul_f32 %0, %0, %0\n v_mul_f32 %1, %1, %1\n v_mul_f32 %2, %2, %2\n v_mul_f32 %3, %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));) }
+        if (OP == 25) { REP8(asm volatile("v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %2\n v_add_u32 %2, %2, %3\n v_add_u32 %3, %3, %0" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 26) { REP8(asm volatile("v_cmp_gt_u32 vcc, %0, %1\n v_cmp_gt_u32 vcc, %1, %2\n v_cmp_gt_u32 vcc, %2, %3\n v_cmp_gt_u32 vcc, %3, %0" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : : "vcc");) }
+        if (OP == 27) { REP8(asm volatile("v_max_f64 %0, %0, %1\n v_max_f64 %1, %1, %2\n v_max_f64 %2, %2, %3\n v_max_f64 %3, %3, %0" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));) }
+        if (OP == 28) { REP8(asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f64 %4, %4, %4, %4\n v_fma_f32 %1, %1, %1, %1\n v_fma_f64 %5, %5, %5, %5" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(d0), "+v"(d1));) }   // 2 fp32 + 2 fp64 alternating
+        if (OP == 29) { REP8(asm volatile("v_fma_f64 %0, %0, %0, %0\n v_lshl_add_u32 %4, %4, 3, %4\n v_fma_f64 %1, %1, %1, %1\n v_cvt_f32_u32 %5, %6" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(i0), "+v"(a1) : "v"(i1));) }   // fp64 / int3 / fp64 / cvt
+        if (OP == 30) { REP8(asm volatile("v_rcp_f32 %0, %0\n v_fma_f64 %4, %4, %4, %4\n v_fma_f64 %5, %5, %5, %5\n v_fma_f64 %6, %6, %6, %6" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(d0), "+v"(d1), "+v"(d2));) }   // 1 rcp + 3 fp64: does the transcendental unit overlap?
+        if (OP == 31) { REP8(asm volatile("v_mad_u32_u24 %0, %0, %1, %2\n v_mad_u32_u24 %1, %1, %2, %3\n v_mad_u32_u24 %2, %2, %3, %0\n v_mad_u32_u24 %3, %3, %0, %1" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }
+        if (OP == 32) { REP8(asm volatile("v_fmac_f64 %0, %1, %2\n v_fmac_f64 %1, %2, %3\n v_fmac_f64 %2, %3, %0\n v_fmac_f64 %3, %0, %1" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));) }
+        if (OP == 33) { REP8(asm volatile("v_bfe_u32 %0, %0, 3, 18\n s_nop 0\n v_bfe_u32 %1, %1, 3, 18\n s_nop 0\n v_bfe_u32 %2, %2, 3, 18\n s_nop 0\n v_bfe_u32 %3, %3, 3, 18\n s_nop 0" : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));) }   // s_nop between VALU: free?
+        if (OP == 34) { REP8(asm volatile("v_cvt_f32_f64 %0, %4\n v_cvt_f64_f32 %5, %0\n v_cvt_f32_f64 %1, %6\n v_cvt_f64_f32 %7, %1" : "+v"(a0), "+v"(a1), "+v"(d0), "+v"(d1) : "v"(d2), "v"(d0), "v"(d3), "v"(d1));) }
         if (OP == 11) { REP8(asm volatile("v_cvt_f32_u32_sdwa %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %1, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_u32_sdwa %2, %6 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_u32_sdwa %3, %7 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(i0), "v"(i1), "v"(i2), "v"(i3));) }
     }
     a0 += p0.x + p1.y + p2.x + p3.y;
@@ -63,5 +82,12 @@ int main()
     run<2>("v_fma_f64", out, clock); run<6>("v_add_f64", out, clock); run<7>("v_mul_f64", out, clock);
     run<12>("v_pk_fma_f32", out, clock); run<13>("v_pk_add_f32", out, clock); run<14>("v_sub_u32", out, clock); run<15>("v_bfe_u32", out, clock);
     run<3>("v_cvt_f64_f32", out, clock); run<4>("v_cvt_f32_f64", out, clock); run<5>("v_cvt_f64_i32", out, clock);
+    // round 3: the rest of the scoring kernel's vocabulary and a few candidates for cheaper index arithmetic
+    run<16>("v_lshrrev_b32", out, clock); run<17>("v_and_b32", out, clock); run<18>("v_ashrrev_i32", out, clock); run<19>("v_and_or_b32", out, clock);
+    run<20>("v_add3_u32", out, clock); run<21>("v_perm_b32", out, clock); run<22>("v_cvt_f32_ubyteN", out, clock); run<23>("v_mov_b32", out, clock);
+    run<24>("v_mul_f32", out, clock); run<25>("v_add_u32", out, clock); run<26>("v_cmp_gt_u32 vcc", out, clock); run<27>("v_max_f64", out, clock);
+    run<31>("v_mad_u32_u24", out, clock); run<32>("v_fmac_f64", out, clock);
+    run<28>("mix 2 fma_f32 + 2 fma_f64", out, clock); run<29>("mix fp64/lshl_add/fp64/cvt", out, clock); run<30>("mix 1 rcp + 3 fma_f64", out, clock);
+    run<33>("v_bfe_u32 + s_nop each", out, clock); run<34>("cvt_f32_f64 -> cvt_f64_f32 (dependent pairs)", out, clock);
     return 0;
 }

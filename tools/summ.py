@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""one compact line per bench.py JSON line found in the given log files"""
+"""one compact line per bench.py JSON line found in the given log files (round-3 layout: roofline = k_cost, roofline_scan)"""
 import json
 import sys
 
@@ -11,7 +11,15 @@ for f in sys.argv[1:]:
         d = json.loads(line)
         dm = d['device_ms_per_step']
         bs = d.get('block_sums')
+        rc = d.get('roofline_cost') or d['roofline']
+        rs = d.get('roofline_scan') or d['roofline']
         print('%-34s %7.3f ms/step | scan %.3f (%.2f of peak) win %.3f cost %.3f (%.3g ev/s) dp %.3f trace %.3f line %.3f | stages %s%s' % (
-            f.split('/')[-1], d['ms_per_step'], dm['scan_ms'], d['roofline']['frac'], dm['window_ms'], dm['cost_ms'],
-            d['roofline_cost']['evals_per_s'], dm['dp_ms'], dm['trace_ms'], dm['total_ms'], d['roofline_cost']['stages'],
+            f.split('/')[-1], d['ms_per_step'], dm['scan_ms'], rs['frac'], dm['window_ms'], dm['cost_ms'],
+            rc['evals_per_s'], dm['dp_ms'], dm['trace_ms'], dm['total_ms'], rc['stages'],
             '' if not bs else ' | block_sums %.3f ms %.2f of peak' % (bs['ms_bin_rows'], bs['frac_of_hbm_peak'])))
+        for r in (d.get('matrix') or {}).get('rows', []):
+            if 'failed' in r:
+                print('    x%-4d failed: %s' % (r['samples'], r['failed']))
+            else:
+                print('    x%-4d %8.3f ms/step  %.3g sites/s | cost %.3f (%.3g ev/s) dp %.3f scan %.3f (%.2f of peak)' % (
+                    r['samples'], r['ms_per_step'], r['value'], r['cost_ms'], r['evals_per_s'], r['dp_ms'], r['scan_ms'], r['scan_frac_of_hbm_peak']))

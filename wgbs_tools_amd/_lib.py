@@ -10,7 +10,9 @@ import os.path as op
 import numpy as np
 
 HERE = op.dirname(op.abspath(__file__))
-LIB_PATH = op.join(HERE, 'csrc', 'libwgbsseg.so')
+# WGBSSEG_LIB: another build of the same ABI (tests only: e.g. tools/build_carrybug_lib.sh, the library with a fixed defect put back,
+# to show that the suite's fuzz catches it)
+LIB_PATH = os.environ.get('WGBSSEG_LIB') or op.join(HERE, 'csrc', 'libwgbsseg.so')
 SYNTH_LIB_PATH = op.join(HERE, 'csrc', 'libwgbssynth.so')
 
 OK, E_ARG, E_METH_GT_COV, E_NOMEM, E_HIP, E_LOCI_ORDER, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
@@ -27,7 +29,8 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_convert_regions', 'wgbsseg_patbeta_create', 'wgbsseg_patbeta_feed', 'wgbsseg_patbeta_finish',
            'wgbsseg_patbeta_destroy', 'wgbsseg_group_load_host_async', 'wgbsseg_group_load_wait',
            'wgbsseg_marker_stats', 'wgbsseg_blocks_parse', 'wgbsseg_blocks_write_table', 'wgbsseg_blocks_write_bedgraph',
-           'wgbsseg_format_fixed', 'wgbsseg_bed_parse', 'wgbsseg_bed_write_annotated', 'wgbsseg_debug_canonical_float']
+           'wgbsseg_format_fixed', 'wgbsseg_bed_parse', 'wgbsseg_bed_write_annotated', 'wgbsseg_debug_canonical_float',
+           'wgbsseg_first_batch_items']
 
 
 class NativeLibraryError(RuntimeError):
@@ -155,6 +158,8 @@ def load():
     L.wgbsseg_set_site_base.argtypes = [vp, i64]
     L.wgbsseg_stitch_regions.restype = i32
     L.wgbsseg_stitch_regions.argtypes = [vp, vp, i64, i64, BATCH_FN, vp, i32, vp, i64, vp, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_first_batch_items.restype = i32
+    L.wgbsseg_first_batch_items.argtypes = [vp, vp, i64, i64, i32, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.c_char_p, C.c_size_t]
     L.wgbsseg_plan_shares.restype = i32
     L.wgbsseg_plan_shares.argtypes = [vp, i64, vp, vp, i64, i64, C.POINTER(Params), i32, i64, vp, vp, vp, vp, vp, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_group_create.restype = i32
@@ -303,14 +308,19 @@ class Segmenter:
         flat, off = self.segment_chunks_csr(start0, lens, pcount, max_cpg, max_bp)
         return [flat[off[c]:off[c + 1]] for c in range(len(off) - 1)]
 
-    def segment_chunks_csr(self, start0, lens, pcount, max_cpg, max_bp):
+    def segment_chunks_csr(self, start0, lens, pcount, max_cpg, max_bp, out=None, off=None):
+        """CSR form: (flat int32 borders relative to each chunk's start, int64 offsets [n + 1]).  `out` / `off`: caller's buffers
+        (e.g. views into a shared-memory slot of a multi-process run) of at least sum(lens) + n int32 / n + 1 int64."""
         start0 = np.ascontiguousarray(start0, dtype=np.int64)
         lens = np.ascontiguousarray(lens, dtype=np.int32)
         n = start0.size
         assert lens.size == n and n >= 1
         cap = int(lens.astype(np.int64).sum()) + n
-        out = np.empty(cap, dtype=np.int32)
-        off = np.empty(n + 1, dtype=np.int64)
+        if out is None:
+            out = np.empty(cap, dtype=np.int32)
+        if off is None:
+            off = np.empty(n + 1, dtype=np.int64)
+        assert out.dtype == np.int32 and out.size >= cap and out.flags.c_contiguous and off.dtype == np.int64 and off.size >= n + 1
         p = Params(float(pcount), int(max_cpg), int(max_bp))
         _check(self._L.wgbsseg_segment_chunks(self._h, start0.ctypes.data, lens.ctypes.data, n, C.byref(p),
                                               out.ctypes.data, cap, off.ctypes.data, self._err, ERRLEN), self._err)
@@ -518,6 +528,57 @@ def stitch_regions(regions, chunk_size, engine_many, speculate=True):
         raise failure[0]
     _check(rc, err)
     return [out[off[r]:off[r + 1]].astype(np.int64) for r in range(n)], _stats_dict(stats)
+
+
+def first_batch_items(regions, chunk_size, speculate=True):
+    """wgbsseg_first_batch_items: the site ranges (1-based half-open) wgbsseg_stitch_regions asks its chunk engine for FIRST over
+    these regions — the chunks of the grid, then the junction patches planned up front.  -> (starts, ends int64 arrays, n_chunks)."""
+    L = load()
+    rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
+    re_ = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+    err = C.create_string_buffer(ERRLEN)
+    n, nch = C.c_int64(0), C.c_int64(0)
+    _check(L.wgbsseg_first_batch_items(rs.ctypes.data, re_.ctypes.data, rs.size, int(chunk_size), 1 if speculate else 0, None, None, 0,
+                                       C.byref(n), C.byref(nch), err, ERRLEN), err)
+    st, en = np.empty(n.value, dtype=np.int64), np.empty(n.value, dtype=np.int64)
+    _check(L.wgbsseg_first_batch_items(rs.ctypes.data, re_.ctypes.data, rs.size, int(chunk_size), 1 if speculate else 0, st.ctypes.data,
+                                       en.ctypes.data, st.size, C.byref(n), C.byref(nch), err, ERRLEN), err)
+    return st, en, int(nch.value)
+
+
+def stitch_regions_csr(regions, chunk_size, batch_csr, speculate=True, copy=True):
+    """wgbsseg_stitch_regions around an array-level chunk engine (no per-item Python work: the multi-process driver's form).
+    batch_csr(starts, ends) — int64 arrays of 1-based half-open ranges — returns (ptr, cnt): uint64 addresses and int64 lengths of
+    each range's int32 border list RELATIVE to its start; whatever owns that memory must live until this call returns.
+    -> (list of border arrays per region, stats dict)."""
+    L = load()
+    rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
+    re_ = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+    n = rs.size
+    cap = int((re_ - rs).sum()) + n
+    out = np.empty(cap, dtype=np.int32)
+    off = np.empty(n + 1, dtype=np.int64)
+    stats = np.zeros(8, dtype=np.int64)
+    failure = []
+
+    def cb(user, starts, ends, cnt, out_ptr, out_cnt):
+        try:
+            st = np.ctypeslib.as_array(starts, shape=(cnt,))
+            en = np.ctypeslib.as_array(ends, shape=(cnt,))
+            ptr, num = batch_csr(st, en)
+            C.memmove(out_ptr, np.ascontiguousarray(ptr, dtype=np.uint64).ctypes.data, 8 * cnt)
+            C.memmove(out_cnt, np.ascontiguousarray(num, dtype=np.int64).ctypes.data, 8 * cnt)
+            return 0
+        except BaseException as e:           # never let an exception cross the C frame
+            failure.append(e)
+            return -1
+    err = C.create_string_buffer(ERRLEN)
+    rc = L.wgbsseg_stitch_regions(rs.ctypes.data, re_.ctypes.data, n, int(chunk_size), BATCH_FN(cb), None, 1 if speculate else 0,
+                                  out.ctypes.data, cap, off.ctypes.data, stats.ctypes.data, err, ERRLEN)
+    if failure:
+        raise failure[0]
+    _check(rc, err)
+    return [out[off[r]:off[r + 1]].astype(np.int64) if copy else out[off[r]:off[r + 1]] for r in range(n)], _stats_dict(stats)
 
 
 def plan_shares(loci, regions, chunk_size, pcount, max_cpg, max_bp, n_shares, halo=-1):

@@ -23,6 +23,18 @@ TARGETS = {
 }
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the sources of libwgbsseg.so: what a profile under profiles/ is keyed on — a PMC or
+    instruction-mix file describes the kernels of exactly one source state (bench.py reports such a file only on a match)."""
+    import hashlib
+    srcs, hdrs = TARGETS['libwgbsseg.so']
+    h = hashlib.sha256()
+    for f in sorted(op.normpath(op.join(CSRC, x)) for x in srcs + hdrs):
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def hipcc():
     for cand in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
         if cand and op.isfile(cand):

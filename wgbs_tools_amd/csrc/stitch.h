@@ -307,6 +307,36 @@ struct BatchResult {
 typedef std::function<int(const std::vector<Sites>&, BatchResult&, std::string&)> BatchFn;
 enum { E_ARG = -1, E_CAPACITY = -6 };
 
+// The items of the FIRST batch of segment_regions — every chunk of the grid (segment.py:124-135), then every junction's
+// first-attempt patch and (speculate) its three possible second attempts, without repeats — a pure function of the regions and
+// the chunk size: a multi-process run lets every rank work out the same list and compute the items it holds.
+struct FirstBatch {
+    std::vector<Sites> items;                                  // chunks first, then patches
+    std::vector<int64_t> region_first_chunk;                   // [n_regions + 1]
+    std::vector<Sites> patches;                                // as planned (with repeats)
+    std::vector<Junction> junctions;
+    int64_t n_chunks = 0;
+};
+inline int first_batch(const int64_t* region_start, const int64_t* region_end, int64_t n_regions, int64_t chunk_size, bool speculate,
+                       FirstBatch& fb, std::string& err)
+{
+    fb.region_first_chunk.assign((size_t)n_regions + 1, 0);
+    for (int64_t r = 0; r < n_regions; r++) {
+        const int64_t a = region_start[r], b = region_end[r];
+        if (a < 1 || b <= a || b > 0x7fffffff) { err = "region " + std::to_string(r) + " is empty, starts before site 1 or ends beyond 2^31"; return E_ARG; }
+        fb.region_first_chunk[(size_t)r] = (int64_t)fb.items.size();
+        std::vector<int64_t> lens;
+        for (int64_t s = a; s < b; s += chunk_size) { const int64_t e = std::min(s + chunk_size, b); fb.items.push_back({s, e}); lens.push_back(e - s); }
+        upfront_patches(a, lens, speculate, fb.patches);
+        junctions_of_region(lens, fb.region_first_chunk[(size_t)r], fb.junctions);
+    }
+    fb.region_first_chunk[(size_t)n_regions] = (int64_t)fb.items.size();
+    fb.n_chunks = (int64_t)fb.items.size();
+    std::map<Sites, char> seen;
+    for (auto& p : fb.patches) if (!seen.count(p)) { seen[p] = 1; fb.items.push_back(p); }
+    return 0;
+}
+
 // The whole driver loop of segment.py:137-165 over `n_regions` regions; see include/wgbsseg.h wgbsseg_segment_regions.
 inline int segment_regions(const int64_t* region_start, const int64_t* region_end, int64_t n_regions, int64_t chunk_size,
                            const BatchFn& run_batch, int32_t* borders_out, int64_t borders_cap, int64_t* borders_off,
@@ -327,24 +357,17 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
         return r;
     };
     // ---- chunk grid (segment.py:124-135) and first-attempt patches ---------------------------------------------
-    std::vector<Sites> items;                                  // chunks first, then patches
-    std::vector<int64_t> region_first_chunk((size_t)n_regions + 1);
-    std::vector<Sites> patches;
-    std::vector<Junction> junctions;
-    for (int64_t r = 0; r < n_regions; r++) {
-        const int64_t a = region_start[r], b = region_end[r];
-        if (a < 1 || b <= a || b > 0x7fffffff) { err = "region " + std::to_string(r) + " is empty, starts before site 1 or ends beyond 2^31"; return E_ARG; }
-        region_first_chunk[(size_t)r] = (int64_t)items.size();
-        std::vector<int64_t> lens;
-        for (int64_t s = a; s < b; s += chunk_size) { const int64_t e = std::min(s + chunk_size, b); items.push_back({s, e}); lens.push_back(e - s); }
-        upfront_patches(a, lens, speculate, patches);
-        junctions_of_region(lens, region_first_chunk[(size_t)r], junctions);
-    }
-    region_first_chunk[(size_t)n_regions] = (int64_t)items.size();
-    const int64_t n_chunks = (int64_t)items.size();
+    FirstBatch fb;
+    const int grid_rc = first_batch(region_start, region_end, n_regions, chunk_size, speculate, fb, err);
+    if (grid_rc != 0) return grid_rc;
+    std::vector<Sites>& items = fb.items;                      // chunks first, then patches
+    std::vector<int64_t>& region_first_chunk = fb.region_first_chunk;
+    std::vector<Sites>& patches = fb.patches;
+    std::vector<Junction>& junctions = fb.junctions;
+    const int64_t n_chunks = fb.n_chunks;
     struct Patch { const int32_t* p; int64_t n; };             // into a BatchResult kept alive in `keep`
     std::map<Sites, Patch> cache;
-    for (auto& p : patches) if (!cache.count(p)) { cache[p] = Patch{nullptr, 0}; items.push_back(p); }
+    for (size_t i = (size_t)n_chunks; i < items.size(); i++) cache[items[i]] = Patch{nullptr, 0};
     int64_t n_batches = 0, n_patch_dp = 0;
     std::vector<std::unique_ptr<BatchResult>> keep;
 

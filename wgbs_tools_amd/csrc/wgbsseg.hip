@@ -1118,6 +1118,25 @@ int wgbsseg_stitch_regions(const int64_t* region_start, const int64_t* region_en
     return map_stitch_rc(rc, msg, err, errlen);
 }
 
+// The items of the first batch of wgbsseg_segment_regions / wgbsseg_stitch_regions over these regions (see include/wgbsseg.h).
+int wgbsseg_first_batch_items(const int64_t* region_start, const int64_t* region_end, int64_t n_regions, int64_t chunk_size,
+                              int32_t speculate, int64_t* starts, int64_t* ends, int64_t cap, int64_t* n_items, int64_t* n_chunks,
+                              char* err, size_t errlen)
+{
+    if (!region_start || !region_end || n_regions < 1 || chunk_size < 1 || !n_items) { set_err(err, errlen, "bad arguments to first_batch_items"); return WGBSSEG_E_ARG; }
+    wgstitch::FirstBatch fb;
+    std::string msg;
+    const int rc = wgstitch::first_batch(region_start, region_end, n_regions, chunk_size, speculate != 0, fb, msg);
+    if (rc != 0) return map_stitch_rc(rc, msg, err, errlen);
+    *n_items = (int64_t)fb.items.size();
+    if (n_chunks) *n_chunks = fb.n_chunks;
+    if (starts && ends) {
+        if (cap < (int64_t)fb.items.size()) { set_err(err, errlen, "first_batch_items: %lld items, room for %lld", (long long)fb.items.size(), (long long)cap); return WGBSSEG_E_CAPACITY; }
+        for (size_t i = 0; i < fb.items.size(); i++) { starts[i] = fb.items[i].first; ends[i] = fb.items[i].second; }
+    }
+    return WGBSSEG_OK;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------------------

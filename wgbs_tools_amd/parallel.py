@@ -79,3 +79,177 @@ def init_host_group():
     if not dist.is_initialized():
         dist.init_process_group('gloo')
     return dist
+
+
+# ------------------------------------------------------------------------------------------------------------
+# One process per GPU, the fast way: the first batch of the native stitcher is cut by owner
+# ------------------------------------------------------------------------------------------------------------
+def item_owners(starts, n_chunks, shares):
+    """Owner rank of every item of the stitcher's first batch (wgbsseg_first_batch_items: chunks, then junction patches): a
+    chunk belongs to the share that the planner gave it to, a patch to the owner of the chunk its first site lies in (its
+    other end stays inside that share's halo: patches planned up front span at most 200 sites)."""
+    import numpy as np
+    lo, hi = np.asarray(shares['own_lo']), np.asarray(shares['own_hi'])
+    cs = np.asarray(starts[:n_chunks]) - 1                      # 0-based first sites of the chunks, ascending
+    holders = np.flatnonzero(hi > lo)
+    rank_of_chunk = holders[np.searchsorted(lo[holders], cs, side='right') - 1]
+    owner = np.empty(len(starts), dtype=np.int64)
+    owner[:n_chunks] = rank_of_chunk
+    owner[n_chunks:] = rank_of_chunk[np.searchsorted(cs, np.asarray(starts[n_chunks:]) - 1, side='right') - 1]
+    return owner
+
+
+class NodeSlots:
+    """Hand-over of the ranks' border lists to rank 0.  On one node: every rank owns two slots (files under /dev/shm mapped by
+    rank 0 as well; steps alternate between them, so that a rank may fill the next step's slot while rank 0 still reads this
+    one's) and the only communication is the barrier that says "written".  Ranks on several hosts fall back to a gather of
+    Python objects.  Slot layout: int64 offsets [items + 1], then int32 borders [cap]."""
+
+    def __init__(self, dist, rank, world, n_items, caps):
+        import os
+        import socket
+        import uuid
+        import numpy as np
+        self.dist, self.rank, self.world = dist, rank, world
+        hosts = [None] * world
+        dist.all_gather_object(hosts, socket.gethostname())
+        tag = [uuid.uuid4().hex[:12] if rank == 0 else None]
+        dist.broadcast_object_list(tag, src=0)
+        self.shared = len(set(hosts)) == 1 and os.path.isdir('/dev/shm') and not os.environ.get('WGBSSEG_NO_SHM')
+        self.n_items, self.caps = [int(x) for x in n_items], [int(x) for x in caps]
+        self.paths, self.maps, self.step_no = [], {}, 0
+        self._pickled = None
+        if self.shared:
+            def path(r, k):
+                return '/dev/shm/wgbsseg_%s_r%d_%d.bin' % (tag[0], r, k)
+            for k in range(2):
+                pth = path(rank, k)
+                np.memmap(pth, dtype=np.uint8, mode='w+', shape=(self._bytes(rank),)).flush()
+                self.paths.append(pth)
+            dist.barrier()
+            for r in (range(world) if rank == 0 else [rank]):
+                for k in range(2):
+                    self.maps[(r, k)] = np.memmap(path(r, k), dtype=np.uint8, mode='r+', shape=(self._bytes(r),))
+
+    def _bytes(self, r):
+        return 8 * (self.n_items[r] + 1) + 4 * max(1, self.caps[r]) + 8
+
+    def _views(self, r, k):
+        import numpy as np
+        m = self.maps[(r, k)]
+        n = self.n_items[r]
+        return m[:8 * (n + 1)].view(np.int64), m[8 * (n + 1):8 * (n + 1) + 4 * max(1, self.caps[r])].view(np.int32)
+
+    def mine(self):
+        """(off, borders) views of this rank's slot of the current step, to be filled in place (None, None without /dev/shm)."""
+        return self._views(self.rank, self.step_no & 1) if self.shared else (None, None)
+
+    def publish(self, off, flat):
+        """This rank's CSR of the current step is complete.  -> on rank 0: [(off, flat)] of every rank; else None."""
+        k = self.step_no & 1
+        self.step_no += 1
+        if self.shared:
+            self.dist.barrier()
+            return [self._views(r, k) for r in range(self.world)] if self.rank == 0 else None
+        out = [None] * self.world if self.rank == 0 else None
+        self.dist.gather_object((off, flat), out, dst=0)
+        return out
+
+    def close(self):
+        import os
+        self.maps = {}
+        for pth in self.paths:
+            try:
+                os.unlink(pth)
+            except OSError:
+                pass
+        self.paths = []
+
+
+class ShardedRun:
+    """The N-process form of wgbsseg_segment_regions: every rank computes the items of the native stitcher's FIRST batch that it
+    owns (chunks and the junction patches planned up front: a patch DP is a pure function of its site range), rank 0 collects
+    them and runs the one tree (wgbsseg_stitch_regions) over all chunks; only the few patches the rehearsal still misses are
+    computed afterwards, by rank 0's `patch_csr`.  No collective on the data path; the borders do not depend on `world`."""
+
+    def __init__(self, dist, regions, chunk_size, loci, params, rank, world, speculate=True):
+        import numpy as np
+        from . import _lib
+        self.dist, self.rank, self.world = dist, rank, world
+        self.regions, self.chunk_size, self.speculate = list(regions), int(chunk_size), speculate
+        self.starts, self.ends, self.n_chunks = _lib.first_batch_items(self.regions, chunk_size, speculate)
+        self.shares = plan(self.regions, chunk_size, world, loci, params)
+        self.owner = item_owners(self.starts, self.n_chunks, self.shares)
+        self.idx = [np.flatnonzero(self.owner == r) for r in range(world)]
+        lens = self.ends - self.starts
+        caps = [int(lens[i].sum()) + int(i.size) for i in self.idx]
+        self.slots = NodeSlots(dist, rank, world, [i.size for i in self.idx], caps)
+        self.my_starts, self.my_ends = self.starts[self.idx[rank]], self.ends[self.idx[rank]]
+        self.last_stats = None
+
+    def window(self):
+        """0-based resident window [lo, hi) this rank needs (own chunks + halo); (0, 0) when it owns nothing."""
+        return int(self.shares['win_lo'][self.rank]), int(self.shares['win_hi'][self.rank])
+
+    def step(self, compute_csr, patch_csr, copy=True):
+        """compute_csr(starts, ends, off, out) -> (off, flat): relative border CSR of this rank's items (into the given slot views
+        when they are not None); patch_csr(starts, ends) -> (off, flat) for follow-up patches anywhere (rank 0 only).
+        -> merged absolute border list per region on rank 0, None elsewhere."""
+        import numpy as np
+        from . import _lib
+        off_v, out_v = self.slots.mine()
+        if self.my_starts.size:
+            off, flat = compute_csr(self.my_starts, self.my_ends, off_v, out_v)
+        else:
+            off, flat = (off_v, out_v) if off_v is not None else (np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.int32))
+            off[0] = 0
+        parts = self.slots.publish(off, flat)
+        if self.rank != 0:
+            return None
+        n = self.starts.size
+        keep, calls = [parts], [0]
+
+        def batch(st, en):
+            calls[0] += 1
+            if calls[0] == 1:
+                if st.size != n or not (np.array_equal(st, self.starts) and np.array_equal(en, self.ends)):
+                    raise RuntimeError('the stitcher asked for a different first batch than wgbsseg_first_batch_items listed')
+                ptr, cnt = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.int64)
+                for r, (o, f) in enumerate(parts):
+                    i = self.idx[r]
+                    if i.size:
+                        o = np.asarray(o[:i.size + 1])
+                        ptr[i] = np.uint64(f.ctypes.data) + (4 * o[:-1]).astype(np.uint64)
+                        cnt[i] = np.diff(o)
+                return ptr, cnt
+            o, f = patch_csr(st, en)
+            keep.append((o, f))
+            o = np.asarray(o[:st.size + 1])
+            return np.uint64(f.ctypes.data) + (4 * o[:-1]).astype(np.uint64), np.diff(o)
+        merged, self.last_stats = _lib.stitch_regions_csr(self.regions, self.chunk_size, batch, speculate=self.speculate, copy=copy)
+        return merged
+
+    def close(self):
+        self.slots.close()
+
+
+def csr_engine(engine, params):
+    """compute_csr / patch_csr of ShardedRun.step over a chunk engine: its own `segment_csr` when it has one (HipEngine,
+    GatherEngine: straight into the slot), else built from `segment_many` (the CPU engines of the test-suite)."""
+    import numpy as np
+
+    def run(starts, ends, off=None, out=None):
+        if hasattr(engine, 'segment_csr'):
+            return engine.segment_csr(starts, ends, params, off=off, out=out)
+        res = engine.segment_many(list(zip(np.asarray(starts).tolist(), np.asarray(ends).tolist())), params)
+        n = len(res)
+        if off is None:
+            off = np.empty(n + 1, dtype=np.int64)
+        off[0] = 0
+        np.cumsum([len(r) for r in res], out=off[1:n + 1])
+        if out is None:
+            out = np.empty(max(1, int(off[n])), dtype=np.int32)
+        for i, r in enumerate(res):
+            out[off[i]:off[i + 1]] = np.asarray(r, dtype=np.int64) - int(starts[i])
+        return off, out
+    return run

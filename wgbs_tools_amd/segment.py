@@ -64,6 +64,14 @@ class HipEngine:
                 out[i] = r.astype(np.int64) + sites_list[i][0]
         return out
 
+    def segment_csr(self, starts, ends, params, off=None, out=None):
+        """Array form of segment_many: 1-based half-open ranges -> (offsets int64 [n + 1], int32 borders RELATIVE to each start),
+        written into `off` / `out` when given (a slot of parallel.NodeSlots)."""
+        st0 = np.asarray(starts, dtype=np.int64) - 1 - self.base
+        ln = (np.asarray(ends, dtype=np.int64) - np.asarray(starts, dtype=np.int64)).astype(np.int32)
+        flat, off = self._seg.segment_chunks_csr(st0, ln, params['pcount'], params['max_cpg'], params['max_bp'], out=out, off=off)
+        return off, flat
+
     def segment_regions(self, regions, chunk_size, params):
         """The whole of SegmentByChunks.run's chunk fan-out + merge_df_list, native (wgbsseg_segment_regions):
         regions = [(startCpG, endCpG), ...] 1-based half-open; returns the merged absolute border list of each."""
@@ -121,6 +129,17 @@ class GatherEngine:
             for i, r in zip(idx, res):
                 out[i] = r.astype(np.int64) + sites_list[i][0]
         return out
+
+    def segment_csr(self, starts, ends, params, off=None, out=None):
+        res = self.segment_many(list(zip(np.asarray(starts).tolist(), np.asarray(ends).tolist())), params)
+        n = len(res)
+        off = np.empty(n + 1, dtype=np.int64) if off is None else off
+        off[0] = 0
+        np.cumsum([len(r) for r in res], out=off[1:n + 1])
+        out = np.empty(max(1, int(off[n])), dtype=np.int32) if out is None else out
+        for i, r in enumerate(res):
+            out[off[i]:off[i + 1]] = r - int(starts[i])
+        return off, out
 
     def close(self):
         self._seg.close()
@@ -432,39 +451,29 @@ class SegmentByChunks:
                 self.dump_result(np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
             dist.barrier()
             return
-        mine = parallel.chunks_of_rank(regs, self.args.chunk_size, world, rank, self.genome.loci(), pd)
-        eng = None
+        run = parallel.ShardedRun(dist, regs, self.args.chunk_size, self.genome.loci(), pd, rank, world)
+        eng, peng = None, []
         try:
-            local_res = []
-            if mine:
-                eng = engine_factory((min(a for a, _ in mine) - 1, max(b for _, b in mine) - 1))
-                local_res = list(zip(mine, eng.segment_many(mine, pd)))
-            gathered = parallel.gather_to_rank0(local_res, rank, world)
-            if rank == 0:
-                chunk_res = {tuple(k): np.asarray(v) for part in gathered for k, v in part}
-                peng = []
+            if run.my_starts.size:
+                eng = engine_factory(run.window())
 
-                def engine_many(sites):
-                    need = [s for s in sites if s not in chunk_res]
-                    if need:
-                        if not peng:
-                            peng.append(patch_engine_factory())
-                        got = dict(zip(need, peng[0].segment_many(need, pd)))
-                    return [chunk_res[s] if s in chunk_res else got[s] for s in sites]
-                try:
-                    merged, self.last_stats = _lib.stitch_regions(regs, self.args.chunk_size, engine_many)
-                finally:
-                    for e in peng:
-                        if hasattr(e, 'close'):
-                            e.close()
+            def patches(starts, ends):                           # the few patches the rehearsal still misses: rank 0's GPU
+                if not peng:
+                    peng.append(patch_engine_factory())
+                return parallel.csr_engine(peng[0], pd)(starts, ends)
+            merged = run.step(parallel.csr_engine(eng, pd), patches)
+            self.last_stats = run.last_stats
+            if rank == 0:
                 s_ = np.concatenate([m[:-1] for m in merged])
                 e_ = np.concatenate([m[1:] for m in merged])
                 self.dump_result(s_, e_)
         finally:
-            if eng is not None and hasattr(eng, 'close'):
-                eng.close()
+            for e in [eng] + peng:
+                if e is not None and hasattr(e, 'close'):
+                    e.close()
             self.param_dict['engine'] = None
             dist.barrier()
+            run.close()
 
     def merge_groups(self, groups):
         """merge_df_list (segment.py:157-165) for every tag at once: the pairing order inside a tag is the
