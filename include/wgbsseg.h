@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 #define WGBSSEG_VERSION 200            /* 0.2.0 */
-#define WGBSSEG_MAX_CPG 8000           /* largest max_cpg accepted (see wgbsseg_segment_chunks) */
+#define WGBSSEG_MAX_CPG 65535          /* longest block, in sites (min(max_cpg, longest chunk)): see wgbsseg_segment_chunks */
 
 #define WGBSSEG_OK              0
 #define WGBSSEG_E_ARG          -1      /* bad argument (message says which) */
@@ -108,10 +108,13 @@ int wgbsseg_set_loci_device(wgbsseg_ctx* ctx, const void* loci, int64_t n_sites,
  * integers the reference prints (segmentor.cpp:30-34) — are borders_out[borders_off[c] .. borders_off[c+1]).
  * borders_off has n_chunks+1 entries; borders_cap >= sum(chunk_len) + n_chunks always suffices.
  * Errors the reference also raises: #meth > #cov inside a requested chunk (message names sample and site).
- * Rejected up front: max_bp == 0, max_cpg < 1, max_cpg > WGBSSEG_MAX_CPG, chunk out of range.  The cap on max_cpg
- * (the reference has none) keeps every block's counts below 2^21, which (a) keeps them exact in the float sums of
- * segmentor.cpp:122-123 and (b) is what the proof that the guards of segmentor.cpp:129,132 never fire rests on
- * (csrc/exact_log2.h).  Default max_cpg is 1000; the driver rejects larger values with a message that says so.
+ * Rejected up front: max_bp == 0 (reference UB), max_cpg < 1, chunk out of range, and blocks of more than WGBSSEG_MAX_CPG =
+ * 65535 sites — i.e. min(max_cpg, longest chunk of the call) > 65535 (a window never exceeds its chunk, segmentor.cpp:110).
+ * The reference sizes its ring to any max_cpg (segmentor.cpp:92-95); but with 255 * block sites >= 2^24 (65,794 sites) its own
+ * float sums of the counts (segmentor.cpp:122-123) stop being exact, so nothing above that is reproducible from prefix sums
+ * (SURVEY.md 8b grants this rejection), and windows are stored in 16 bits here, which moves the line from 65,793 to 65,535.
+ * Up to round 2 the limit was 8000 (block totals < 2^21, which the guard-free form of the likelihood term rests on,
+ * csrc/exact_log2.h); windows beyond that now score with the general guarded form (same bits, ~45 % more instructions).
  */
 int wgbsseg_segment_chunks(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const int32_t* chunk_len,
                            int64_t n_chunks, const wgbsseg_params* params,

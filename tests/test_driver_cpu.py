@@ -146,27 +146,30 @@ def test_stats_report(driver_golden, synth_world, tmp_path):
     assert rep['wall_s'] > 0 and set(rep['phases_s']) >= {'segmentation (device + stitching)', 'blocks to BED'}
 
 
-def test_stitch_helpers_match_reference(driver_golden):
+def test_reference_tree_restatement_matches_reference(driver_golden):
+    """tests/reftree.py (the suite's checker of the native stitcher) against vectors captured from the reference's own helpers."""
+    import reftree as R
     for rec in driver_golden['funcs']:
         b1, b2 = np.array(rec['b1']), np.array(rec['b2'])
-        assert S.find_dups(b1, b2).astype(int).tolist() == rec['find_dups']
-        assert int(S.is_2_overlap(b1, b2)) == rec['overlap']
+        assert R.repeated(b1, b2).astype(int).tolist() == rec['find_dups']
+        assert R.shared(b1, b2) == rec['overlap']
         if rec['overlap']:
-            assert S.merge2(b1, b2).tolist() == rec['merge2']
+            assert R.splice(b1, b2).tolist() == rec['merge2']
     for p, m, want in driver_golden['increase_patch']:
-        assert S.increase_patch(p, m) == want
+        assert R.next_patch(p, m) == want
 
 
-def test_stitch_failure_raises_like_reference():
+def test_stitch_failure_raises_like_reference(stitch_lib):
+    import reftree as R
     # b2 does not continue b1 (segment.py:202-205)
-    with pytest.raises(G.IllegalArgumentError, match='not supposed to be merged'):
-        S.stitch_2_dfs(np.array([1, 5, 9]), np.array([10, 12]), {})
+    with pytest.raises(R.StitchError, match='not supposed to be merged'):
+        R.join(np.array([1, 5, 9]), np.array([10, 12]), None)
 
     class NeverOverlaps:
         def segment_many(self, sites, params):
-            return [np.array([s[0], s[1]]) + 1000000 for s in sites]
-    with pytest.raises(G.IllegalArgumentError, match='Try increasing chunk size'):
-        S.stitch_2_dfs(np.array([1, 5, 9]), np.array([9, 12, 20]), {'engine': NeverOverlaps()})
+            return [np.array([s[0], s[1]]) + (0 if (s[0] - 1) % 4 == 0 and s[1] - s[0] <= 4 else 1000000) for s in sites]
+    with pytest.raises(R.StitchError, match='Try increasing chunk size'):
+        R.join(np.array([1, 5, 9]), np.array([9, 12, 20]), lambda sites: NeverOverlaps().segment_many(sites, {}))
 
 
 def test_genome_validation_and_args(synth_world, tmp_path):
@@ -460,13 +463,9 @@ class FickleEngine:
 
 
 def _tree_merge(chunks, params):
-    lst = list(chunks)
-    while len(lst) > 1:                                  # segment.py:157-165
-        nxt = [S.stitch_2_dfs(lst[i - 1], lst[i], params) for i in range(1, len(lst), 2)]
-        if len(lst) % 2:
-            nxt.append(lst[-1])
-        lst = nxt
-    return lst[0]
+    """the reference's pairwise tree (segment.py:157-165,199-252) as restated in tests/reftree.py, patches from params['engine']"""
+    import reftree
+    return reftree.tree(chunks, lambda sites: params['engine'].segment_many(sites, params), error=G.IllegalArgumentError)
 
 
 @pytest.mark.parametrize('seed', range(60))

@@ -151,9 +151,10 @@ def test_share_group_plan_windows_and_errors(world):
             assert all(np.array_equal(a, b) for a, b in zip(got2, want))
 
 
-def test_python_stitching_path_equals_native_path(driver_golden, world, tmp_path):
-    """The driver's numpy stitching (mirror of segment.py:199-252) and the native rope stitching must agree when both
-    run over the HIP chunk engine."""
+def test_stitcher_around_segment_many_equals_the_native_driver_loop(driver_golden, world, tmp_path):
+    """An engine that only offers segment_many goes through wgbsseg_stitch_regions (the library's tree around a caller's chunk engine,
+    no speculation: the reference's own patch requests); one that offers segment_regions through wgbsseg_segment_regions (batched,
+    speculative).  Same BED over the HIP chunk engine."""
     import argparse
     g = driver_golden['cases']['wg_c20000']
     args = argparse.Namespace(sites=None, region=None, array_id=None, bed_file=None, genome=world['refdir'], betas=world['paths'],
@@ -161,7 +162,7 @@ def test_python_stitching_path_equals_native_path(driver_golden, world, tmp_path
                               out_path=str(tmp_path / 'a.bed'), threads=1, device=0, gpus=1)
     gen = G.GenomeRefPaths(world['refdir'])
 
-    class PyOnly:                                   # hides segment_regions -> forces the numpy stitching path
+    class PyOnly:                                   # hides segment_regions -> wgbsseg_stitch_regions around segment_many
         def __init__(self, eng):
             self.eng = eng
 

@@ -3,7 +3,7 @@
   x32   hg19-shaped 28,217,448 CpGs x 32 betas, whole genome: a spread sample of 256 full-size chunks against the
         reference binary (oracle/_ref/segmentor), one whole chromosome chunk by chunk AND patch by patch against it,
         and the STITCHED border lists of four chromosomes against the reference's pairwise tree (segment.py:157-165,
-        199-252; restated in wgbs_tools_amd/segment.py and pinned there by vectors captured from the reference's
+        199-252; restated in tests/reftree.py and pinned there by vectors captured from the reference's
         driver) walked over the same chunk / patch DPs.
   x200  the same genome x 200 betas (7 LDS sample groups in the scoring kernel): 64 sampled chunks against the
         reference binary, the stitched result of three chromosomes against the tree, genome-wide properties.
@@ -102,14 +102,10 @@ class _Recorder:
 
 
 def _tree(chunks, eng):
-    """segment.py:157-165 over stitch_2_dfs (segment.py:199-232), junction by junction."""
-    lst = list(chunks)
-    while len(lst) > 1:
-        nxt = [S.stitch_2_dfs(lst[i - 1], lst[i], {'engine': eng}) for i in range(1, len(lst), 2)]
-        if len(lst) % 2:
-            nxt.append(lst[-1])
-        lst = nxt
-    return lst[0]
+    """segment.py:157-165 over stitch_2_dfs (segment.py:199-232), junction by junction (tests/reftree.py: the suite's restatement,
+    pinned by vectors from the reference's own Python)."""
+    import reftree
+    return reftree.tree(chunks, lambda sites: eng.segment_many(sites, {}))
 
 
 def _check_properties(res, regions, loci, max_cpg, max_bp):

@@ -26,7 +26,7 @@ import sys
 import numpy as np
 
 from .genome import GenomeRefPaths, GenomicRegion, IllegalArgumentError, eprint, write_bed
-from .segment import add_GR_args, add_multi_thread_args
+from .cliutil import add_threads_option, add_where_options
 
 # what pandas.read_csv treats as missing by default (the reference reads every table with it)
 NA_TOKENS = frozenset(['', '#N/A', '#N/A N/A', '#NA', '-1.#IND', '-1.#QNAN', '-NaN', '-nan', '1.#IND', '1.#QNAN', '<NA>',
@@ -321,7 +321,7 @@ def convert_single_region(args):
 
 def parse_args(argv=None):
     parser = argparse.ArgumentParser(description=main.__doc__)
-    region_or_sites = add_GR_args(parser, bed_file=True)
+    region_or_sites = add_where_options(parser, bed_file=True)
     parser.add_argument('--no_anno', help='Do not print genomic annotations', action='store_true')
     region_or_sites.add_argument('--site_file',
                                  help='text file with a single CpG indexes column, or <startCpG, endCpG> columns.\n'
@@ -331,7 +331,7 @@ def parse_args(argv=None):
     parser.add_argument('-p', '--parsable', action='store_true', help='Output a parsing friendly format')
     parser.add_argument('--drop_empty', action='store_true', help='Drop empty regions (without CpGs)')
     parser.add_argument('-f', '--force', action='store_true', help='Overwrite existing files if existed')
-    add_multi_thread_args(parser)
+    add_threads_option(parser)
     parser.add_argument('--device', type=int, default=0, help='HIP device index [0]')
     return parser.parse_args(argv)
 

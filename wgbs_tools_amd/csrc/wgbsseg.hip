@@ -587,10 +587,20 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     if (!P || !borders_off) { set_err(err, errlen, "NULL params/borders pointer"); return WGBSSEG_E_ARG; }
     if (P->max_bp == 0) { set_err(err, errlen, "max_bp must be >= 1 (the reference reads uninitialised loci when it is 0: segmentor.cpp:38,114)"); return WGBSSEG_E_ARG; }
     if (P->max_cpg < 1) { set_err(err, errlen, "max_cpg must be >= 1"); return WGBSSEG_E_ARG; }
-    if (P->max_cpg > WGBSSEG_MAX_CPG) {
-        set_err(err, errlen, "max_cpg %u unsupported: at most %d (a block's counts must stay below 2^21 for the exactness proofs of the likelihood term)", P->max_cpg, WGBSSEG_MAX_CPG);
+    // The reference sizes its ring to any max_cpg (segmentor.cpp:92-95).  What bounds it here: a block's counts must stay exact in
+    // the float sums of segmentor.cpp:122-123 (255 * max_cpg < 2^24: beyond that the REFERENCE's own sums round),
+    // and a window is stored in 16 bits.  A window never exceeds its chunk (segmentor.cpp:110: j < n - i), so max_cpg counts
+    // only up to the longest chunk of the call.
+    int32_t longest = 1;
+    if (chunk_len) for (int64_t i = 0; i < n_chunks; i++) longest = std::max(longest, chunk_len[i]);
+    wgbsseg_params Peff = *P;
+    Peff.max_cpg = std::min<uint32_t>(P->max_cpg, (uint32_t)longest);
+    if ((uint64_t)Peff.max_cpg * 255u >= (1u << 24) || Peff.max_cpg > WGBSSEG_MAX_CPG) {
+        set_err(err, errlen, "max_cpg %u with chunks of up to %d sites unsupported: blocks of more than %d sites (255 * sites >= 2^24) do not keep their counts exact "
+                "in the float sums of the reference itself (segmentor.cpp:122-123), and windows are stored in 16 bits", P->max_cpg, (int)longest, WGBSSEG_MAX_CPG);
         return WGBSSEG_E_ARG;
     }
+    P = &Peff;
     if (!(P->pseudo_count >= 0.0f)) { set_err(err, errlen, "pseudo_count must be >= 0"); return WGBSSEG_E_ARG; }
     if (c && c->sC) HIP_TRY(hipStreamSynchronize(c->sC));      // (a call that failed half way may have left its scan pass running)
     Job job;
@@ -670,7 +680,13 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipMemcpyAsync(&st2, c->status.p, sizeof(st2), hipMemcpyDeviceToHost, c->sA));
         HIP_TRY(hipStreamSynchronize(c->sA));
         if (st2.first_bad != ~0ULL) return report_bad_site(c, st2, err, errlen);
-        if (st.loci_disorder) { set_err(err, errlen, "loci are not ascending inside chunk %u (a chunk must not cross chromosomes)", st.loci_disorder - 1); return WGBSSEG_E_LOCI_ORDER; }
+        if (st.loci_disorder) {
+            set_err(err, errlen, "loci are not ascending inside chunk %u (0-based sites [%lld, +%d)): the reference's segmentor bars such an extension and leaves the site out of "
+                    "its running sums (segmentor.cpp:114-117), which this implementation does not reproduce — it refuses instead.  A chunk must not cross chromosomes; "
+                    "check the genome's CpG.bed.gz (positions ascending within a chromosome) or the regions of -L / -s",
+                    st.loci_disorder - 1, (long long)(job.h[st.loci_disorder - 1].start0 + c->site_base), (int)job.h[st.loci_disorder - 1].len);
+            return WGBSSEG_E_LOCI_ORDER;
+        }
         set_err(err, errlen, "a chunk scores more than 2^32 blocks; use a smaller chunk_size"); return WGBSSEG_E_ARG;
     }
     const int Wmax = (int)st.max_window;
@@ -689,15 +705,21 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const int TKB = WG_WIDE_TK;
     // exponent rows of the k-scaled log tables (pseudo count >= 1): narrow tiles score blocks of <= WG_NARROW_WMAX sites,
     // wide tiles blocks up to the job's widest window
-    const bool ks = wg_term_mode(P->pseudo_count) == 2;
+    // The guard-free form of the term (pseudo count >= 1) rests on block totals below 2^21 (csrc/exact_log2.h: p < 1 after the
+    // three float roundings, table rows down to 2^-23): the narrow tiles (blocks of <= 60 sites) always have them, the wide
+    // tiles only while 255 * (the job's widest window) < 2^21 — windows beyond 8224 sites (max_cpg > 8000: round 3) score with
+    // the general guarded form, which assumes nothing about the totals.
+    const int term_modeA = wg_term_mode(P->pseudo_count);
+    const int term_modeB = (term_modeA == 2 && 255.0 * std::max(Wmax, 1) >= 0x1p21) ? 1 : term_modeA;
+    const bool ks = term_modeA == 2, ksB = term_modeB == 2;
     const int rowsA = ks ? wg_lookup_rows(P->pseudo_count, 255.0 * WG_NARROW_WMAX) : 0;
-    const int rowsB = ks ? wg_lookup_rows(P->pseudo_count, 255.0 * std::max(Wmax, 1)) : 0;
+    const int rowsB = ksB ? wg_lookup_rows(P->pseudo_count, 255.0 * std::max(Wmax, 1)) : 0;
     if (rowsA > WG_KY_KMIN + 1 || rowsB > WG_KY_KMIN + 1) { set_err(err, errlen, "internal: %d / %d lookup rows", rowsA, rowsB); return WGBSSEG_E_ARG; }
     auto lds_for = [&](int ti, bool split, int ns) -> size_t {
         const size_t rows = split ? (size_t)ns * (WG_WIDE_TK + 1 + WG_WIDE_TS + 1) * 8                      // P of the ends + P of the starts, (meth, cov) as two dwords
                                   : ((((size_t)ns * (ti + WG_NARROW_WMAX + 1) + 1) & ~(size_t)1) * 4);     // tile-local prefixes, packed in one dword
         // guard-free kernels: just the two lookup tables, sized to the pseudo count and the tile class; otherwise the general fast tables
-        const size_t tabs = ks ? (size_t)(split ? rowsB : rowsA) * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
+        const size_t tabs = (split ? ksB : ks) ? (size_t)(split ? rowsB : rowsA) * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
         return tabs + rows + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 32 +
                (split ? 0 : (size_t)ti * WG_NARROW_WMAX / 8 + 8);      // (+ the coarse block -> start map; an entry per 16 blocks for the 128-start tiles would let a seventh workgroup onto the CU at 8 samples: measured, no gain)      // (+ the block -> start map: a byte per block / per eight blocks)
     };
@@ -763,7 +785,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     }
     const size_t ldsA = (size_t)round_up((int64_t)lds_for(TI, false, NSA), 16);
     const size_t ldsB = (size_t)round_up((int64_t)lds_for(WG_WIDE_TS, true, NSB), 16);
-    const int term_mode = wg_term_mode(P->pseudo_count);
+    const int term_mode = term_modeA;
 
     // ---- stages: bound the scored-block buffer and overlap scoring (stream A) with the recurrence (stream B) --
     int n_stages = 1;
@@ -884,8 +906,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         }
         if (stage_tiles[2 * (size_t)stg + 1] > 0) {
             const TileDesc* td = c->tilesB.as<TileDesc>() + tileB0[(size_t)stg];
-            hipError_t e = term_mode == 2 ? launch_cost_ti<2>(TI, true, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
-                         : (term_mode == 1 ? launch_cost_ti<1>(TI, true, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
+            hipError_t e = term_modeB == 2 ? launch_cost_ti<2>(TI, true, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
+                         : (term_modeB == 1 ? launch_cost_ti<1>(TI, true, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
                                            : launch_cost_ti<0>(TI, true, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA));
             HIP_TRY(e);
         }
@@ -2106,7 +2128,7 @@ int wgbsseg_debug_sample_terms(wgbsseg_ctx* c, const float* nmeth, const float* 
     HIP_TRY(hipMemcpyAsync(c->dbg_b.p, ntotal, (size_t)count * 4, hipMemcpyHostToDevice, c->sA));
     const unsigned blocks = (unsigned)std::min<int64_t>((count + 255) / 256, 8192);
     const int fast = wg_term_mode(pseudo_count);                                         // the library's own dispatch rule
-    const int rows = fast == 2 ? wg_lookup_rows(pseudo_count, 255.0 * WGBSSEG_MAX_CPG) : 0;       // the ABI's longest block
+    const int rows = fast == 2 ? wg_lookup_rows(pseudo_count, 255.0 * 8000) : 0;       // block totals up to 255 * 8000 < 2^21: the longest the guard-free form serves
     if (rows > WG_KY_KMIN + 1) return WGBSSEG_E_ARG;
     hipLaunchKernelGGL(k_debug_terms, dim3(blocks), dim3(256), 0, c->sA, c->dbg_a.as<float>(), c->dbg_b.as<float>(), count, pseudo_count, c->dbg_c.as<float>(), fast, rows);
     HIP_TRY(hipGetLastError());

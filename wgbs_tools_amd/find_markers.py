@@ -35,7 +35,7 @@ import numpy as np
 from .beta_to_blocks import BlockSumEngine, BlocksTable, load_blocks_file
 from .beta_to_table import drop_dup_keep_order, load_gfile_helper, match_prefix_to_bin
 from .genome import IllegalArgumentError, eprint
-from .segment import add_multi_thread_args, validate_file_list, validate_single_file
+from .cliutil import add_threads_option, require_file, require_files
 
 # supplemental/find_markers_defaults.txt of the reference (key:value lines), as data
 DEFAULTS = dict(blocks_path=None, groups_file=None, targets=None, background=None, beta_list_file=None, betas=None, min_bp=0,
@@ -60,7 +60,7 @@ def load_param_file(path):
     """key:value lines, '#' comments; NA / empty -> None, True / False, numbers, `targets` as a list"""
     if not path:
         return {}
-    validate_single_file(path)
+    require_file(path)
     d = {}
     with open(path) as f:
         for line in f:
@@ -80,110 +80,109 @@ def load_param_file(path):
     return d
 
 
+# ---- parameter rules, as data --------------------------------------------------------------------------------------
+# (the reference checks them one `if` after another, fm_load_params.py:79-136; the messages, and which of them go to stderr
+# ahead of an exception without text, are its own)
+_AT_LEAST = (('min_cpg', 0, 'min_cpg must be non negative'), ('max_cpg', 1, 'max_cpg must larger than 0'),
+             ('min_bp', 0, 'min_bp must be non negative'), ('max_bp', 2, 'max_bp must be larger than 1'),
+             ('chunk_size', 1, 'chunk_size must be larger than 1'))
+_WITHIN = ((0, 1, ('na_rate_tg', 'na_rate_bg', 'tg_quant', 'bg_quant', 'unmeth_quant_thresh', 'meth_quant_thresh', 'unmeth_mean_thresh',
+                   'meth_mean_thresh', 'pval')),
+           (-1, 1, ('delta_means', 'delta_quants', 'delta_maxmin')))
+_ONE_OF = (('sort_by', ('delta_means', 'delta_quants', 'delta_maxmin', 'startCpG', 'tg_quant', 'tg_mean'), True),    # True: None is allowed
+           ('test_type', ('t', 'mw', 'm_t'), False))
+_INPUT_FILES = ('blocks_path', 'groups_file')
+
+
+def _refuse(text):
+    """the reference's pattern for most parameter errors: the text on stderr, then an exception without one"""
+    eprint(text)
+    raise IllegalArgumentError()
+
+
 class MFParams:
-    """defaults <- config file <- command line (fm_load_params.py:14-40), validated (:73-136)"""
+    """defaults <- config file <- command line (fm_load_params.py:14-40), then the rules above."""
 
     def __init__(self, args):
-        for k, v in DEFAULTS.items():
-            setattr(self, k, v)
-        for k, v in load_param_file(args.config_file).items():
-            setattr(self, k, v)
-        for k, v in vars(args).items():                            # flags that were not given leave the file values alone
-            if (isinstance(v, bool) and not v) or v is None:
-                continue
-            setattr(self, k, v)
-        self.validate_args()
+        layers = (DEFAULTS, load_param_file(args.config_file),
+                  {k: v for k, v in vars(args).items() if v is not None and v is not False})      # flags that were not given leave the file's values alone
+        for layer in layers:
+            self.__dict__.update(layer)
+        self.check()
 
-    def validate_args(self):
-        if self.min_cpg < 0:
-            raise IllegalArgumentError('min_cpg must be non negative')
-        if self.max_cpg < 1:
-            raise IllegalArgumentError('max_cpg must larger than 0')
-        if self.min_bp < 0:
-            raise IllegalArgumentError('min_bp must be non negative')
-        if self.max_bp < 2:
-            raise IllegalArgumentError('max_bp must be larger than 1')
-        if self.chunk_size < 1:
-            raise IllegalArgumentError('chunk_size must be larger than 1')
-
-        def in_range(key, low, high):
-            val = float(getattr(self, key))
-            if not high >= val >= low:
-                eprint(f'Invalid value for {key} ({val}): must be in [{low}, {high}]')
-                raise IllegalArgumentError()
-        for key in ('na_rate_tg', 'na_rate_bg', 'tg_quant', 'bg_quant', 'unmeth_quant_thresh', 'meth_quant_thresh',
-                    'unmeth_mean_thresh', 'meth_mean_thresh', 'pval'):
-            in_range(key, 0, 1)
-        for key in ('delta_means', 'delta_quants', 'delta_maxmin'):
-            in_range(key, -1, 1)
+    def check(self):
+        for key, low, text in _AT_LEAST:
+            if getattr(self, key) < low:
+                raise IllegalArgumentError(text)
+        for low, high, keys in _WITHIN:
+            for key in keys:
+                val = float(getattr(self, key))
+                if not (high >= val >= low):
+                    _refuse(f'Invalid value for {key} ({val}): must be in [{low}, {high}]')
         if self.only_hyper and self.only_hypo:
-            eprint('at most one of (only_hyper, only_hypo) can be specified')
-            raise IllegalArgumentError()
-        if self.sort_by is not None:
-            ops = ('delta_means', 'delta_quants', 'delta_maxmin', 'startCpG', 'tg_quant', 'tg_mean')
-            if self.sort_by not in ops:
-                eprint(f'sort_by argument must be in: {", ".join(ops)}')
-                raise IllegalArgumentError()
-        tests = ('t', 'mw', 'm_t')
-        if self.test_type not in tests:
-            eprint(f'test_type argument must be in: {", ".join(tests)}')
-            raise IllegalArgumentError()
-        for key in ('blocks_path', 'groups_file'):
+            _refuse('at most one of (only_hyper, only_hypo) can be specified')
+        for key, allowed, optional in _ONE_OF:
             val = getattr(self, key)
-            if val is None:
-                eprint(f'[wt fm] missing required parameter: {key}')
-                raise IllegalArgumentError()
-            validate_single_file(val)
-            setattr(self, key, op.abspath(val))
+            if not (val in allowed or (optional and val is None)):
+                _refuse(f'{key} argument must be in: {", ".join(allowed)}')
+        for key in _INPUT_FILES:
+            if getattr(self, key) is None:
+                _refuse(f'[wt fm] missing required parameter: {key}')
+            setattr(self, key, op.abspath(require_file(getattr(self, key))))
         if (self.betas is None) == (self.beta_list_file is None):
-            eprint('[wt fm] Exactly one of the following must be specified: betas, beta_list_file')
-            raise IllegalArgumentError()
+            _refuse('[wt fm] Exactly one of the following must be specified: betas, beta_list_file')
         if self.beta_list_file:
-            validate_single_file(self.beta_list_file)
+            require_file(self.beta_list_file)
             with open(self.beta_list_file) as f:
-                self.betas = [l.strip() for l in f if l.strip()]
+                self.betas = [ln.strip() for ln in f if ln.strip()]
         elif isinstance(self.betas, str):
             self.betas = self.betas.split()
-        validate_file_list(self.betas)
+        require_files(self.betas)
+
+    validate_args = check                                         # the reference's name for it
+
+
+# ---- command line, as data: (flags, type or action, help); every option defaults to None / False = "not given" ------------------
+_OPTIONS = (
+    (('--config_file', '-p'), str, 'find_markers config file (key:value lines)'),
+    (('--blocks_path', '-b'), str, 'Blocks bed path.'),
+    (('--groups_file', '-g'), str, 'csv file of groups'),
+    (('--targets',), '+', 'find markers only for these groups (OR relation)'),
+    (('--background',), '+', 'find markers only against these groups (AND relation)'),
+    (('-o', '--out_dir'), str, 'Output directory'),
+    (('--min_bp',), int, None), (('--max_bp',), int, None), (('--min_cpg',), int, None), (('--max_cpg',), int, None),
+    (('--delta_means',), float, 'Filter markers by beta values delta_means. range: [0.0, 1.0]. Default [0.3].'),
+    (('--delta_quants',), float, 'Filter markers by beta values delta_quants. range: [0.0, 1.0]. Default [0.0]'),
+    (('-c', '--min_cov'), int, 'Minimal number of binary observations in block coverage to be considered. [5]'),
+    (('--only_hyper',), True, 'Only consider hyper-methylated markers'),
+    (('--only_hypo',), True, 'Only consider hypo-methylated markers'),
+    (('--top',), int, 'Output only the top TOP markers, under the constraints. [All]'),
+    (('--header',), True, 'add header to output files'),
+    (('--tg_quant',), float, 'quantile of target samples to ignore. [0.25]'),
+    (('--bg_quant',), float, 'quantile of background samples to ignore. [0.025]'),
+    (('--unmeth_mean_thresh',), float, 'average beta value for the unmethylated group'),
+    (('--meth_mean_thresh',), float, 'average beta value for the methylated group'),
+    (('--unmeth_quant_thresh',), float, 'quantlie beta value for the unmethylated group'),
+    (('--meth_quant_thresh',), float, 'quantlie beta value for the methylated group'),
+    (('--na_rate_tg',), float, 'rate of samples with insufficient coverage allowed in target samples. [.334]'),
+    (('--na_rate_bg',), float, 'rate of samples with insufficient coverage allowed in background samples. [.334]'),
+    (('--pval',), float, 'p-value threshold. DMRs with larger p-value are dropped. [0.05]'),
+    (('--test_type',), str, 'The statistical test used for p-value filtering: t (two-sample t-test), mw (Mann-Whitney U), m_t (t-test on M-values). [t]'),
+    (('--sort_by',), str, 'sort output markers by this column.'),
+    (('--chunk_size',), int, 'Number of blocks to load on each step'),
+    (('--verbose', '-v'), True, None),
+)
 
 
 def parse_args(argv=None):
     parser = argparse.ArgumentParser(description='Find differentially methylated blocks')
-    parser.add_argument('--config_file', '-p', help='find_markers config file (key:value lines)')
-    parser.add_argument('--blocks_path', '-b', help='Blocks bed path.')
-    parser.add_argument('--groups_file', '-g', help='csv file of groups')
-    parser.add_argument('--targets', nargs='+', help='find markers only for these groups (OR relation)')
-    parser.add_argument('--background', nargs='+', help='find markers only against these groups (AND relation)')
-    betas_group = parser.add_mutually_exclusive_group()
-    betas_group.add_argument('--betas', nargs='+', help='beta file paths. files not in the group files are ignored')
-    betas_group.add_argument('--beta_list_file', help='file with a list of beta file paths.')
-    parser.add_argument('-o', '--out_dir', help='Output directory')
-    parser.add_argument('--min_bp', type=int)
-    parser.add_argument('--max_bp', type=int)
-    parser.add_argument('--min_cpg', type=int)
-    parser.add_argument('--max_cpg', type=int)
-    parser.add_argument('--delta_means', type=float, help='Filter markers by beta values delta_means. range: [0.0, 1.0]. Default [0.3].')
-    parser.add_argument('--delta_quants', type=float, help='Filter markers by beta values delta_quants. range: [0.0, 1.0]. Default [0.0]')
-    parser.add_argument('-c', '--min_cov', type=int, help='Minimal number of binary observations in block coverage to be considered. [5]')
-    parser.add_argument('--only_hyper', action='store_true', help='Only consider hyper-methylated markers')
-    parser.add_argument('--only_hypo', action='store_true', help='Only consider hypo-methylated markers')
-    parser.add_argument('--top', type=int, help='Output only the top TOP markers, under the constraints. [All]')
-    parser.add_argument('--header', action='store_true', help='add header to output files')
-    parser.add_argument('--tg_quant', type=float, help='quantile of target samples to ignore. [0.25]')
-    parser.add_argument('--bg_quant', type=float, help='quantile of background samples to ignore. [0.025]')
-    parser.add_argument('--unmeth_mean_thresh', type=float, help='average beta value for the unmethylated group')
-    parser.add_argument('--meth_mean_thresh', type=float, help='average beta value for the methylated group')
-    parser.add_argument('--unmeth_quant_thresh', type=float, help='quantlie beta value for the unmethylated group')
-    parser.add_argument('--meth_quant_thresh', type=float, help='quantlie beta value for the methylated group')
-    parser.add_argument('--na_rate_tg', type=float, help='rate of samples with insufficient coverage allowed in target samples. [.334]')
-    parser.add_argument('--na_rate_bg', type=float, help='rate of samples with insufficient coverage allowed in background samples. [.334]')
-    parser.add_argument('--pval', type=float, help='p-value threshold. DMRs with larger p-value are dropped. [0.05]')
-    parser.add_argument('--test_type', help='The statistical test used for p-value filtering: t (two-sample t-test), mw (Mann-Whitney U), '
-                                            'm_t (t-test on M-values). [t]')
-    parser.add_argument('--sort_by', help='sort output markers by this column.')
-    parser.add_argument('--chunk_size', type=int, help='Number of blocks to load on each step')
-    parser.add_argument('--verbose', '-v', action='store_true')
-    add_multi_thread_args(parser)
+    betas = parser.add_mutually_exclusive_group()
+    betas.add_argument('--betas', nargs='+', help='beta file paths. files not in the group files are ignored')
+    betas.add_argument('--beta_list_file', help='file with a list of beta file paths.')
+    for flags, kind, text in _OPTIONS:
+        kw = dict(action='store_true') if kind is True else dict(nargs='+') if kind == '+' else dict(type=kind)
+        parser.add_argument(*flags, help=text, **kw)
+    add_threads_option(parser)
     parser.add_argument('--device', type=int, default=0, help='HIP device index [0]')
     return parser.parse_args(argv)
 
@@ -250,8 +249,8 @@ class MarkerFinder:
         self.engine = engine
         if args.out_dir:
             os.makedirs(args.out_dir, exist_ok=True)
-        validate_single_file(args.groups_file)
-        validate_file_list(args.betas)
+        require_file(args.groups_file)
+        require_files(args.betas)
         gf = load_gfile_helper(args.groups_file)
         gf.full_path = match_prefix_to_bin(gf.fname, args.betas, '.beta')
         groups = sorted(set(gf.group))

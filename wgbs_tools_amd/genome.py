@@ -167,161 +167,186 @@ def beta_sanity_check(beta_path, genome):
     return True
 
 
+# ------------------------------------------------------------------------------------------------------------
+# -s / -r / --array_id: one resolver per input kind, all table-driven
+#
+# The ACCEPTED spellings, the order of the checks and every message are the reference's (genomic_region.py:70-232: they are what
+# a user of the CLI sees); how they are organised is not: the reference walks a chain of methods that mutate one object and ask
+# `tabix` per locus, here each kind of input is a pure function (text, genome) -> Span over the in-memory tables, driven by the
+# small tables below, and GenomicRegion only carries the answer.
+# ------------------------------------------------------------------------------------------------------------
+_CHROM = r'(chr)?([\d]+|[XYM]|(MT))'
+# region spellings (commas removed first), tried in this order; `kind` says what the numeric groups mean
+_REGION_FORMS = (
+    ('chrom', re.compile(r'^' + _CHROM + r'$')),                                  # a whole chromosome: 1 .. its length
+    ('point', re.compile(r'^(?P<chrom>' + _CHROM + r'):(?P<a>[\d]+)$')),           # chr:pos  ==  chr:pos-(pos+1)
+    ('range', re.compile(r'^(?P<chrom>' + _CHROM + r'):(?P<a>[\d]+)-(?P<b>[\d]+)$')),
+)
+# site spellings (commas removed first).  The range pattern is a PREFIX match, as upstream (re.match without '$').
+_SITE_FORMS = (
+    ('range', re.compile(r'([\d]+)-([\d]+)')),
+    ('single', re.compile(r'^[0-9]+$')),
+)
+
+
+class Span:
+    """What every resolver returns: chromosome, 1-based CpG range [s1, s2), and the base-pair range it prints."""
+    __slots__ = ('chrom', 'sites', 'bp')
+
+    def __init__(self, chrom, sites, bp):
+        self.chrom, self.sites, self.bp = chrom, sites, bp
+
+    @property
+    def text(self):
+        return f'{self.chrom}:{self.bp[0]}-{self.bp[1]}'
+
+
+def _site_pair(genome, text):
+    """'a-b' | 'a' (commas allowed) -> (s1, s2) with the reference's range rule and its message."""
+    if not text:
+        raise IllegalArgumentError(f'Empty sites string: {text}')
+    plain = text.replace(',', '')
+    pair = None
+    for kind, rx in _SITE_FORMS:
+        m = rx.match(plain)
+        if m and kind == 'range':
+            pair = (int(m.group(1)), int(m.group(2)))
+        elif m and '-' not in plain:
+            pair = (int(plain), int(plain) + 1)
+        if pair:
+            break
+    if pair is None:
+        raise IllegalArgumentError(f'sites must be of format: "start-end" or "site" .\nGot: {plain}')
+    s1, s2 = pair
+    top = genome.get_nr_sites() + 1
+    if not (top >= s2 >= s1 >= 1):
+        raise IllegalArgumentError(f'sites violate the constraints: {top} >= {s2} > {s1} >= 1')
+    return (s1, s2 + 1) if s1 == s2 else (s1, s2)
+
+
+def locus_of_site(genome, index):
+    """(chromosome, bp position) of 1-based CpG `index` — the `tabix rev.CpG.bed.gz` lookup of the reference, from the loci array."""
+    index = int(index)
+    if not (genome.get_nr_sites() + 1 >= index >= 1):
+        eprint('Invalid site index:', index)
+        raise IllegalArgumentError('Out of range site index:', index)
+    loci = genome.loci()
+    if index > loci.size:
+        raise IllegalArgumentError(f'Failed retrieving locus for site {index}')
+    return genome.index2chrom(index), int(loci[index - 1])
+
+
+def span_of_sites(genome, text):
+    s1, s2 = _site_pair(genome, text)
+    (c1, first), (c2, last) = locus_of_site(genome, s1), locus_of_site(genome, s2 - 1)
+    if c1 != c2:
+        eprint(f'ERROR: sites range cross chromosomes! ({s1}, {s2})')
+        raise IllegalArgumentError('Invalid sites input')
+    return Span(c1, (s1, s2), (first, last + 1))
+
+
+def _bp_request(genome, text):
+    """A region spelling -> (chromosome, printable region, from, to), unknown chromosomes refused with the reference's text."""
+    plain = text.replace(',', '')
+    known = genome.get_chroms()
+    for kind, rx in _REGION_FORMS:
+        m = rx.match(plain)
+        if not m:
+            continue
+        if kind == 'chrom':
+            if plain not in known:
+                raise IllegalArgumentError(f'Unknown chromosome: {plain}')
+            return plain, plain, 1, genome.get_chrom_size(plain)
+        a = int(m.group('a'))
+        shown = plain if kind == 'range' else f'{plain}-{a + 1}'
+        if m.group('chrom') not in known:
+            raise IllegalArgumentError(f'Unknown chromosome: {shown}')
+        return m.group('chrom'), shown, a, int(m.group('b')) if kind == 'range' else a + 1
+    raise IllegalArgumentError(f'Invalid genomic region: {plain}')
+
+
+def sites_in_bp_range(genome, chrom, a, b, shown):
+    """CpGs with a <= locus <= b on `chrom`, as the 1-based range the reference derives from `tabix CpG.bed.gz chr:a-b`
+    (genomic_region.py:140-161): first row's index .. last row's index, plus one unless the last CpG sits exactly on b."""
+    names, sizes = genome.get_chrom_cpg_sizes()
+    ci = names.index(chrom)
+    lo = int(sizes[:ci].sum())
+    loci = genome.loci()[lo:lo + int(sizes[ci])]
+    i0, i1 = int(np.searchsorted(loci, a, 'left')), int(np.searchsorted(loci, b, 'right'))     # rows i0 .. i1-1
+    first = lo + i0 + 1
+    end = lo + i1 + (1 if i1 > i0 and int(loci[i1 - 1]) < b else 0)
+    if i1 <= i0 or first == end:
+        raise IllegalArgumentError(f'Invalid genomic region: {shown}. No CpGs in range')
+    return _site_pair(genome, f'{first}-{end}')
+
+
+def span_of_region(genome, text):
+    chrom, shown, a, b = _bp_request(genome, text)
+    for bad, why in ((b <= a, 'end before start'), (b > genome.get_chrom_size(chrom) or a < 1, 'Out of range')):
+        if bad:
+            raise IllegalArgumentError(f'Invalid genomic region: {text}. {why}')
+    sp = Span(chrom, sites_in_bp_range(genome, chrom, a, b, shown), (a, b))
+    return sp, shown
+
+
+def site_of_array_id(genome, array_id):
+    """--array_id cg00001755: the CpG index of an Illumina array probe, from the genome's map file (genomic_region.py:212-232:
+    `gunzip -c ilmn2CpG.tsv.gz | grep -w <id> | cut -f2`, which must come out as ONE integer)."""
+    if not (array_id.startswith('cg') and len(array_id) > 2 and array_id[2:].isdigit()):
+        eprint(f'ERROR: Invalid Illumina array id: {array_id}')
+        raise IllegalArgumentError('Invalid Illumina array ID')
+    idict = genome.ilmn2cpg_dict
+    if idict is None or not op.isfile(idict):
+        raise IllegalArgumentError(f'Could not find Illumina map file: {idict}')
+    word = re.compile(r'(?<![A-Za-z0-9_])' + re.escape(array_id) + r'(?![A-Za-z0-9_])')      # grep -w
+    with gzip.open(idict, 'rt') as f:
+        hits = [line.rstrip('\n') for line in f if word.search(line)]
+    second = [h.split('\t')[1] if '\t' in h else h for h in hits]                              # cut -f2 (a line without a tab passes whole)
+    try:
+        return int('\n'.join(second).strip())
+    except ValueError as e:
+        cmd = f'gunzip -c {idict} | grep -w {array_id} | cut -f2'
+        raise IllegalArgumentError(f'Failed retrieving locus for site {array_id} with command:\n{cmd}\n{e}')
+
+
 class GenomicRegion:
-    """The subset of genomic_region.py:23-247 that `segment` / `convert` use: -s/--sites, -r/--region and --array_id."""
+    """What `segment` / `convert` read off genomic_region.py:23-247: .sites (None = whole genome), .chrom, .region_str, .bp_tuple,
+    .nr_sites, is_whole(), str().  Built from parsed CLI arguments (-s / -r / --array_id, in that order of precedence) or from one
+    explicit `region=` / `sites=` text."""
 
     def __init__(self, args=None, region=None, sites=None, genome=None):
-        self.chrom = None
-        self.sites = None
-        self.region_str = None
-        self.bp_tuple = None
-        if args is not None:
+        self.chrom = self.sites = self.region_str = self.bp_tuple = None
+        if args is not None:                                      # the CLI: an empty option is no option
             self.genome = genome if genome is not None else GenomeRefPaths(args.genome)
-            if getattr(args, 'sites', None):
-                self.parse_sites(args.sites)
-            elif getattr(args, 'region', None):
-                self.parse_region(args.region)
-            elif getattr(args, 'array_id', None):
-                self.parse_array_id(args.array_id)
-        else:
+            sites, region = getattr(args, 'sites', None) or None, getattr(args, 'region', None) or None
+            if sites is None and region is None and getattr(args, 'array_id', None):
+                sites = str(site_of_array_id(self.genome, args.array_id))
+            if sites is not None:
+                region = None
+        else:                                                     # one explicit text: whatever it holds is parsed (and may be refused)
             self.genome = genome
-            if region is not None:
-                self.parse_region(region)
-            elif sites is not None:
-                self.parse_sites(sites)
-            else:
+            if region is None and sites is None:
                 raise IllegalArgumentError(f'Invalid GR init {region}')
+            if region is not None:
+                sites = None
+        if sites is not None:
+            sp = span_of_sites(self.genome, sites)
+            self._take(sp, sp.text)
+        elif region is not None:
+            self._take(*span_of_region(self.genome, region))
         self.nr_sites = None if self.sites is None else self.sites[1] - self.sites[0]
+
+    def _take(self, span, shown):
+        self.chrom, self.sites, self.bp_tuple, self.region_str = span.chrom, span.sites, span.bp, shown
 
     def is_whole(self):
         return self.sites is None
-
-    def parse_array_id(self, array_id):
-        """--array_id cg00001755: the CpG index of an Illumina array probe, from the genome's map file (genomic_region.py:212-232:
-        `gunzip -c ilmn2CpG.tsv.gz | grep -w <id> | cut -f2`, which must come out as ONE integer)."""
-        import gzip
-        if not (array_id.startswith('cg') and len(array_id) > 2 and array_id[2:].isdigit()):
-            eprint(f'ERROR: Invalid Illumina array id: {array_id}')
-            raise IllegalArgumentError('Invalid Illumina array ID')
-        idict = self.genome.ilmn2cpg_dict
-        if idict is None or not op.isfile(idict):
-            raise IllegalArgumentError(f'Could not find Illumina map file: {idict}')
-        word = re.compile(r'(?<![A-Za-z0-9_])' + re.escape(array_id) + r'(?![A-Za-z0-9_])')      # grep -w
-        hits = []
-        with gzip.open(idict, 'rt') as f:
-            for line in f:
-                if word.search(line):
-                    fields = line.rstrip('\n').split('\t')
-                    hits.append(fields[1] if len(fields) > 1 else line.rstrip('\n'))       # cut -f2 (a line without a tab passes whole)
-        try:
-            cpg_ind = int('\n'.join(hits).strip())
-        except ValueError as e:
-            cmd = f'gunzip -c {idict} | grep -w {array_id} | cut -f2'
-            raise IllegalArgumentError(f'Failed retrieving locus for site {array_id} with command:\n{cmd}\n{e}')
-        self.parse_sites(str(cpg_ind))
 
     def __str__(self):                                            # genomic_region.py:239-247 (no annotation tracks here)
         if self.sites is None:
             return 'Whole genome'
         s1, s2 = self.sites
-        nr_bp = self.bp_tuple[1] - self.bp_tuple[0] + 1
-        return f'{self.region_str} - {nr_bp:,}bp, {s2 - s1:,}CpGs: {s1}-{s2}'
-
-    # genomic_region.py:163-187
-    def _sites_str_to_tuple(self, sites_str):
-        if not sites_str:
-            raise IllegalArgumentError(f'Empty sites string: {sites_str}')
-        sites_str = sites_str.replace(',', '')
-        m = re.match(r'([\d]+)-([\d]+)', sites_str)
-        if m:
-            site1, site2 = int(m.group(1)), int(m.group(2))
-        elif '-' not in sites_str and sites_str.isdigit():
-            site1 = int(sites_str)
-            site2 = site1 + 1
-        else:
-            raise IllegalArgumentError(f'sites must be of format: "start-end" or "site" .\nGot: {sites_str}')
-        nr = self.genome.get_nr_sites()
-        if not nr + 1 >= site2 >= site1 >= 1:
-            msg = 'sites violate the constraints: '
-            msg += f'{nr + 1} >= {site2} > {site1} >= 1'
-            raise IllegalArgumentError(msg)
-        if site1 == site2:
-            site2 += 1
-        return site1, site2
-
-    # genomic_region.py:189-208
-    def index2locus(self, index):
-        index = int(index)
-        if not self.genome.get_nr_sites() + 1 >= index >= 1:
-            eprint('Invalid site index:', index)
-            raise IllegalArgumentError('Out of range site index:', index)
-        chrom = self.genome.index2chrom(index)
-        loci = self.genome.loci()
-        if index > loci.size:
-            raise IllegalArgumentError(f'Failed retrieving locus for site {index}')
-        return chrom, int(loci[index - 1])
-
-    # genomic_region.py:70-88
-    def parse_sites(self, sites_str):
-        s1, s2 = self._sites_str_to_tuple(sites_str)
-        self.chrom, region_from = self.index2locus(s1)
-        chrom2, region_to = self.index2locus(s2 - 1)
-        region_to += 1
-        if self.chrom != chrom2:
-            eprint(f'ERROR: sites range cross chromosomes! ({s1}, {s2})')
-            raise IllegalArgumentError('Invalid sites input')
-        self.sites = (s1, s2)
-        self.region_str = f'{self.chrom}:{region_from}-{region_to}'
-        self.bp_tuple = (region_from, region_to)
-
-    # genomic_region.py:94-123
-    def find_region_format(self, region):
-        region = region.replace(',', '')
-        if re.match(r'^(chr)?([\d]+|[XYM]|(MT))$', region):
-            if region not in self.genome.get_chroms():
-                raise IllegalArgumentError(f'Unknown chromosome: {region}')
-            self.chrom = region
-            return region, 1, self.genome.get_chrom_size(region)
-        uni = re.match(r'^(chr)?([\d]+|[XYM]|(MT)):([\d]+)$', region)
-        if uni:
-            region += f'-{int(uni.group(4)) + 1}'
-        m = re.match(r'^((chr)?([\d]+|[XYM]|(MT))):([\d]+)-([\d]+)$', region)
-        if not m:
-            raise IllegalArgumentError(f'Invalid genomic region: {region}')
-        self.chrom = m.group(1)
-        if self.chrom not in self.genome.get_chroms():
-            raise IllegalArgumentError(f'Unknown chromosome: {region}')
-        return region, int(m.group(5)), int(m.group(6))
-
-    # genomic_region.py:126-161
-    def parse_region(self, region):
-        self.region_str, region_from, region_to = self.find_region_format(region)
-        if region_to <= region_from:
-            raise IllegalArgumentError(f'Invalid genomic region: {region}. end before start')
-        if region_to > self.genome.get_chrom_size(self.chrom) or region_from < 1:
-            raise IllegalArgumentError(f'Invalid genomic region: {region}. Out of range')
-        self.bp_tuple = (region_from, region_to)
-        self.sites = self._region_str2sites()
-
-    def _region_str2sites(self):
-        """`tabix CpG.bed.gz chr:from-to | awk ...` (genomic_region.py:140-161): rows with from <= locus <= to; the
-        range is first_index .. last_index(+1 unless the last CpG sits exactly on `to`)."""
-        names, sizes = self.genome.get_chrom_cpg_sizes()
-        ci = names.index(self.chrom)
-        cum = np.concatenate([[0], np.cumsum(sizes)])
-        lo, hi = int(cum[ci]), int(cum[ci + 1])               # 0-based [lo, hi) of this chromosome
-        loci = self.genome.loci()[lo:hi]
-        a, b = self.bp_tuple
-        i0 = int(np.searchsorted(loci, a, 'left'))
-        i1 = int(np.searchsorted(loci, b, 'right'))            # rows i0 .. i1-1
-        if i1 <= i0:
-            raise IllegalArgumentError(f'Invalid genomic region: {self.region_str}. No CpGs in range')
-        first = lo + i0 + 1
-        last = lo + i1                                          # 1-based index of the last row
-        end = last + (1 if int(loci[i1 - 1]) < b else 0)
-        if first == end:
-            raise IllegalArgumentError(f'Invalid genomic region: {self.region_str}. No CpGs in range')
-        return self._sites_str_to_tuple(f'{first}-{end}')
+        return f'{self.region_str} - {self.bp_tuple[1] - self.bp_tuple[0] + 1:,}bp, {s2 - s1:,}CpGs: {s1}-{s2}'
 
 
 def blocks_to_bed_lines(genome, start_cpg, end_cpg):

@@ -19,7 +19,7 @@ import os.path as op
 
 from .convert import delete_or_skip
 from .genome import GenomeRefPaths, IllegalArgumentError
-from .segment import add_multi_thread_args, validate_single_file
+from .cliutil import add_threads_option, require_file
 
 CHUNK_BYTES = 64 << 20
 
@@ -117,7 +117,7 @@ def pat_chunks(pat_path, chunk_bytes=CHUNK_BYTES):
 
 def pat2beta(pat_path, out_dir, args, force=True):
     """pat2beta.py:17-44 for one file; returns the path written (None when skipped)."""
-    validate_single_file(pat_path)
+    require_file(pat_path)
     if not (pat_path.endswith('.pat.gz') or pat_path.endswith('.pat')):
         raise IllegalArgumentError(f'Invalid pat suffix: {pat_path}')
     suff = '.lbeta' if args.lbeta else '.beta'
@@ -144,7 +144,7 @@ def parse_args(argv=None):
     parser.add_argument('-o', '--out_dir', help='Output directory for the beta file. [.]', default='.')
     parser.add_argument('-l', '--lbeta', action='store_true', help='Use lbeta file (uint16) instead of beta (uint8)')
     parser.add_argument('--genome', help='Genome reference name.')
-    add_multi_thread_args(parser)
+    add_threads_option(parser)
     parser.add_argument('--device', type=int, default=0, help='HIP device index [0]')
     return parser.parse_args(argv)
 

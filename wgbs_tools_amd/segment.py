@@ -11,7 +11,6 @@ exactly, because the running double sums of the DP make the chunk grid part of t
 There is no CPU fallback: without the HIP library and a gfx950 device `segment` fails.
 """
 import argparse
-import multiprocessing
 import os
 import sys
 import threading
@@ -19,10 +18,11 @@ import time
 
 import numpy as np
 
+from .cliutil import add_threads_option, add_where_options, lines_of, require_files
 from .genome import (GenomeRefPaths, GenomicRegion, IllegalArgumentError, beta_sanity_check, eprint, write_bed)
 
 DEF_CHUNK = 60000
-MAX_CPG_CAP = 8000            # WGBSSEG_MAX_CPG (include/wgbsseg.h): the one limit the reference does not have
+MAX_BLOCK_SITES = 65535       # WGBSSEG_MAX_CPG (include/wgbsseg.h): longest block; min(max_cpg, chunk_size) above it is refused by the library
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -145,109 +145,16 @@ class GatherEngine:
         self._seg.close()
 
 
-def segment_process(params):
-    """segment.py:41-59 for a single chunk (kept for interface parity; the driver itself batches)."""
-    return params['engine'].segment_many([params['sites']], params)[0]
+SMALL_CHUNK_WARNING = ('[wt segment] WARNING: chunk_size is small compared to max_cpg and/or max_bp.\n'
+                       '                      It may cause wt segment to fail. It\'s best setting\n'
+                       '                      chunk_size > min{max_cpg, max_bp/2}')
+STITCH_FAILED = 'Patch stitching Failed'      # segment.py:202-205,229-232: the reference raises IllegalArgumentError with this text
 
 
-# ------------------------------------------------------------------------------------------------------------
-# stitching (segment.py:199-252), restated with numpy set operations instead of pandas
-# ------------------------------------------------------------------------------------------------------------
-def find_dups(b1, b2):
-    """segment.py:239-240: mask over concatenate([b1, b2]) of the values that occur more than once."""
-    cat = np.concatenate([b1, b2])
-    _, inv, cnt = np.unique(cat, return_inverse=True, return_counts=True)
-    return cnt[inv] > 1
-
-
-def is_2_overlap(b1, b2):
-    return np.sum(find_dups(b1, b2))
-
-
-def merge2(b1, b2):
-    """segment.py:243-246"""
-    nr_from_df1 = np.argmax(find_dups(b1, b2))
-    skip_from_df2 = np.searchsorted(b2, b1[nr_from_df1])
-    return np.concatenate([b1[:nr_from_df1 + 1], b2[skip_from_df2 + 1:]]).copy()
-
-
-def increase_patch(pre_size, maxval):
-    """segment.py:249-252"""
-    if pre_size == maxval:
-        return maxval + 1
-    return int(min(pre_size * 2, maxval))
-
-
-STITCH_FAIL_MSG = '[wt segment] Patch stitching Failed! ' \
-                  '             Try increasing chunk size (--chunk_size flag)'
-
-
-class _Stitch:
-    """State machine of one stitch_2_dfs call (segment.py:199-232): `want()` names the patch it needs next,
-    `feed(patch)` consumes it; lets many junctions share one GPU batch per attempt."""
-
-    def __init__(self, b1, b2):
-        if b1[-1] != b2[0]:
-            msg = '[wt segment] Patch stitching Failed! ' \
-                  '             patches are not supposed to be merged'
-            raise IllegalArgumentError(msg)
-        self.b1, self.b2 = b1, b2
-        self.n1 = b1[-1] - b1[0]
-        self.n2 = b2[-1] - b2[0]
-        self.p1 = min(50, self.n1)
-        self.p2 = min(50, self.n2)
-        self.result = None
-
-    def want(self):
-        if self.result is not None:
-            return None
-        if not (self.p1 <= self.n1 and self.p2 <= self.n2):
-            raise IllegalArgumentError(STITCH_FAIL_MSG)
-        return (int(self.b1[-1] - self.p1), int(self.b1[-1] + self.p2))
-
-    def feed(self, patch):
-        o1 = is_2_overlap(self.b1, patch)
-        o2 = is_2_overlap(patch, self.b2)
-        if o1 and o2:
-            self.result = merge2(merge2(self.b1, patch), self.b2)
-        else:
-            if not o1:
-                self.p1 = increase_patch(self.p1, self.n1)
-            if not o2:
-                self.p2 = increase_patch(self.p2, self.n2)
-
-
-def stitch_2_dfs(b1, b2, params):
-    """segment.py:199-232 (one junction; patches come from params['engine'])."""
-    st = _Stitch(b1, b2)
-    while st.result is None:
-        sites = st.want()
-        st.feed(params['engine'].segment_many([sites], params)[0])
-    return st.result
-
-
-def stitch_round(pairs, params, cache):
-    """All junctions of one pairwise-reduce round (segment.py:159-161) together: every attempt's patches go to
-    the GPU as one batch.  The patch DP is a pure function of (start, end), so results are cached."""
-    states = [_Stitch(b1, b2) for b1, b2 in pairs]
-    while True:
-        need = {}
-        for st in states:
-            w = st.want()
-            if w is not None and w not in cache:
-                need[w] = None
-        if need:
-            keys = list(need)
-            for k, r in zip(keys, params['engine'].segment_many(keys, params)):
-                cache[k] = r
-        pending = False
-        for st in states:
-            w = st.want()
-            if w is not None:
-                st.feed(cache[w])
-                pending = pending or st.result is None
-        if not pending:
-            return [st.result for st in states]
+def _as_reference_error(e):
+    """A failed stitch surfaces from the library as SegmentorError; the reference's driver raises IllegalArgumentError with the same text."""
+    msg = getattr(e, 'msg', str(e))
+    return IllegalArgumentError(msg) if STITCH_FAILED in msg else e
 
 
 class SegmentByChunks:
@@ -255,10 +162,11 @@ class SegmentByChunks:
         self.betas = betas
         max_cpg = min(args.max_cpg, args.max_bp // 2)            # segment.py:65
         assert max_cpg > 1
-        if max_cpg > MAX_CPG_CAP:
-            # the one limit the reference does not have (include/wgbsseg.h, WGBSSEG_MAX_CPG): say so here, before any upload
-            raise IllegalArgumentError(f'[wt segment] ERROR: blocks of up to min(max_cpg, max_bp/2) = {max_cpg} sites requested; '
-                                       f'this implementation supports at most {MAX_CPG_CAP} (default 1000).')
+        if min(max_cpg, args.chunk_size) > MAX_BLOCK_SITES:
+            # include/wgbsseg.h, WGBSSEG_MAX_CPG: above 65,793 sites per block the reference's own float sums stop being exact; windows
+            # are stored in 16 bits here.  Said before any upload.
+            raise IllegalArgumentError(f'[wt segment] ERROR: blocks of up to min(max_cpg, max_bp/2, chunk_size) = {min(max_cpg, args.chunk_size)} sites '
+                                       f'requested; at most {MAX_BLOCK_SITES} are supported (default max_cpg 1000).')
         self._regions = None
         self.genome = GenomeRefPaths(args.genome)
         self.param_dict = {'betas': betas,
@@ -310,21 +218,16 @@ class SegmentByChunks:
         return [tuple(int(x) for x in gr.sites)]
 
     def break_to_chunks(self):
-        """ Break range of sites to chunks of size 'step',
-            while keeping chromosomes separated  (segment.py:84-135)"""
-        step = self.args.chunk_size
-        if step < self.args.max_cpg:
-            msg = '[wt segment] WARNING: chunk_size is small compared to max_cpg and/or max_bp.\n' \
-                  '                      It may cause wt segment to fail. It\'s best setting\n' \
-                  '                      chunk_size > min{max_cpg, max_bp/2}'
-            eprint(msg)
-        tags, starts, ends = [], [], []
-        for start, end in self.regions():
-            bords = list(range(start, end, step)) + [end]
-            tags += [f'{start}-{end}'] * (len(bords) - 1)
-            starts += bords[:-1]
-            ends += bords[1:]
-        return tags, starts, ends
+        """(tags, starts, ends) of the chunk grid — every region cut every chunk_size sites from its own start, regions never share a
+        chunk (segment.py:84-135) — with the reference's warning when a chunk is shorter than the longest block allowed.  The grid the
+        library walks is the same one (wgbsseg_first_batch_items / csrc/stitch.h); this list feeds the report and the tests."""
+        size = self.args.chunk_size
+        if size < self.args.max_cpg:
+            eprint(SMALL_CHUNK_WARNING)
+        from . import parallel
+        regs = self.regions()
+        grid = parallel.chunk_grid(regs, size)
+        return ['%d-%d' % regs[ri] for ri, _, _ in grid], [a for _, a, _ in grid], [b for _, _, b in grid]
 
     def run(self):
         tags, starts, ends = self.break_to_chunks()
@@ -352,7 +255,7 @@ class SegmentByChunks:
                     res = eng.segment_regions(regs, self.args.chunk_size, self.param_dict)
                 except Exception as e:
                     if not (own_engine and getattr(e, 'code', 0) == -7 and 'not resident on any single share' in str(e)):
-                        raise
+                        raise _as_reference_error(e)
                     # a junction patch outgrew the halo between two shares (patch doubling past a chunk): one GPU, whole range
                     eprint('[wt segment] a junction patch outgrew the share halo; rerunning on one GPU')
                     eng.close()
@@ -365,12 +268,17 @@ class SegmentByChunks:
                     tm = eng.timings() if hasattr(eng, 'timings') else None
                     self.report['device'] = tm if isinstance(tm, list) else ([tm] if tm else None)
             else:
-                arr = eng.segment_many(list(zip(starts, ends)), self.param_dict)
-                # merge chunks from the same "tag" group (segment.py:148-154); all groups advance round by round together
-                groups = {}
-                for i, t in enumerate(tags):
-                    groups.setdefault(t, []).append(arr[i])
-                merged = self.merge_groups(groups)
+                # a chunk engine without the library's driver loop (the CPU engines of the test-suite): the library's chunk grid and
+                # stitching tree (wgbsseg_stitch_regions, csrc/stitch.h) around its segment_many, asking for exactly the patches the
+                # reference would (no speculation)
+                from . import _lib
+                regs = self.regions()
+                try:
+                    res, self.last_stats = _lib.stitch_regions(regs, self.args.chunk_size, lambda sites: eng.segment_many(sites, self.param_dict),
+                                                               speculate=False)
+                except _lib.SegmentorError as e:
+                    raise _as_reference_error(e)
+                merged = dict(zip([f'{a}-{b}' for a, b in regs], res))
         finally:
             closer = None
             if own_engine:
@@ -420,7 +328,10 @@ class SegmentByChunks:
         from . import _lib, multi
         want = getattr(self.args, 'gpus', 0) if gpus is None else gpus
         have = max(1, _lib.device_count())
-        n = want or have            # more shares than GPUs is allowed (they wrap around the devices): only useful for tests
+        # default: as many GPUs as the job has work for — a share of fewer than four chunks is all launch latency, and a one-chunk
+        # -r / -s run should not create contexts, streams and loader threads on every device of a shared node.
+        # An explicit --gpus N is taken as given (more shares than GPUs wrap around the devices: only useful for tests).
+        n = want or min(have, max(1, -(-len(starts) // 4)))
         first = getattr(self.args, 'device', 0)
         if multi.regions_fit_a_group(self.regions()):
             # one share per GPU (also for a single GPU: the share group streams the upload and segments what has arrived)
@@ -474,32 +385,6 @@ class SegmentByChunks:
             self.param_dict['engine'] = None
             dist.barrier()
             run.close()
-
-    def merge_groups(self, groups):
-        """merge_df_list (segment.py:157-165) for every tag at once: the pairing order inside a tag is the
-        reference's ((0,1),(2,3),.. then again on the merged list); rounds of different tags share GPU batches."""
-        lists = {t: list(v) for t, v in groups.items()}
-        cache = {}
-        while any(len(v) > 1 for v in lists.values()):
-            pairs, owner = [], []
-            for t, dflist in lists.items():
-                if len(dflist) > 1:
-                    for i in range(1, len(dflist), 2):
-                        pairs.append((dflist[i - 1], dflist[i]))
-                        owner.append(t)
-            res = stitch_round(pairs, self.param_dict, cache)
-            new = {t: [] for t in lists}
-            for t, r in zip(owner, res):
-                new[t].append(r)
-            for t, dflist in lists.items():
-                if len(dflist) > 1:
-                    last = [dflist[-1]] if len(dflist) % 2 else []
-                    lists[t] = new[t] + last
-        return {t: v[0] for t, v in lists.items()}
-
-    def merge_df_list(self, dflist, pool=None):
-        """segment.py:157-165 for one tag."""
-        return self.merge_groups({'x': dflist})['x']
 
     def dump_result(self, start_cpg, end_cpg):
         """segment.py:167-190"""
@@ -578,102 +463,50 @@ def is_block_file_nice(df):
 # ------------------------------------------------------------------------------------------------------------
 # Main (segment.py:261-313)
 # ------------------------------------------------------------------------------------------------------------
-def add_GR_args(parser, required=False, bed_file=False):
-    """utils_wgbs.py:233-247"""
-    region_or_sites = parser.add_mutually_exclusive_group(required=required)
-    region_or_sites.add_argument('-s', '--sites', help='a CpG index range, of the form: "450000-450050"')
-    region_or_sites.add_argument('-r', '--region', help='genomic region of the form "chr1:10,000-10,500"')
-    region_or_sites.add_argument('--array_id', help='Illumina array id, e.g. cg00001755')
-    if bed_file:
-        region_or_sites.add_argument('-L', '--bed_file', help='Bed file. Columns <chr, start, end>. '
-                                     'For some features columns 4-5 should be <startCpG, endCpG> (run wgbstools convert -L BED_PATH)')
-    parser.add_argument('--genome', help='Genome reference name. Default is "default".', default='default')
-    return region_or_sites
-
-
-def add_multi_thread_args(parser):
-    """utils_wgbs.py:250-260 (kept for command-line compatibility; the GPU path does not fork workers)."""
-    try:
-        cpu_env = 'SLURM_JOB_CPUS_PER_NODE'
-        if cpu_env in os.environ.keys():
-            def_cpus = int(os.environ[cpu_env])
-        else:
-            def_cpus = multiprocessing.cpu_count()
-    except Exception:
-        def_cpus = 8
-    parser.add_argument('-@', '--threads', type=int, default=def_cpus,
-                        help='Number of threads to use (default: all available CPUs)')
+# the tool's own options: (flags, type, default, help).  Flags, defaults and help texts are the reference's (segment.py:261-282) up to
+# --device / --gpus / --stats, which exist only here.
+_OPTIONS = (
+    (('-c', '--chunk_size'), int, DEF_CHUNK, f'Chunk size. Default {DEF_CHUNK} sites'),
+    (('-p', '--pcount'), float, 15, 'Pseudo counts of C\'s and T\'s in each block. Default 15'),
+    (('--min_cpg',), int, 1, 'Minimal block size (in #sites) to output. Shorter blocks will simply be ommited from output (equivalent to set '
+                             'min_cpg to 1 and then filter output by length). Default is 1'),
+    (('--max_cpg',), int, 1000, 'Maximal allowed block size (in #sites). Default is 1000'),
+    (('--max_bp',), int, 2000, 'Maximal allowed block size (in bp). Default is 2000'),
+    (('-o', '--out_path'), None, sys.stdout, 'output path [stdout]'),
+    (('--device',), int, 0, 'HIP device index of the (first) GPU [0]'),
+    (('--gpus',), int, 0, 'Number of GPUs to spread the chunks over from this one process (the role of -@ in the CPU implementation). '
+                          'Default: one GPU for jobs of a few chunks, else all visible GPUs'),
+    (('--stats',), None, None, 'Write a JSON report of the run to this path: parameters, regions, chunks, junction patches, GPU batches, blocks '
+                               'found / dropped, wall-clock phases and device timings'),
+)
 
 
 def parse_args(argv=None):
     parser = argparse.ArgumentParser(description=main.__doc__)
-    add_GR_args(parser, bed_file=True)
-    betas_or_file = parser.add_mutually_exclusive_group(required=True)
-    betas_or_file.add_argument('--betas', nargs='+')
-    betas_or_file.add_argument('--beta_file', '-F')
-    parser.add_argument('-c', '--chunk_size', type=int, default=DEF_CHUNK,
-                        help=f'Chunk size. Default {DEF_CHUNK} sites')
-    parser.add_argument('-p', '--pcount', type=float, default=15,
-                        help='Pseudo counts of C\'s and T\'s in each block. Default 15')
-    parser.add_argument('--min_cpg', type=int, default=1,
-                        help='Minimal block size (in #sites) to output. Shorter blocks will simply be '
-                             'ommited from output (equivalent to set min_cpg to 1 and then filter output by '
-                             'length). Default is 1')
-    parser.add_argument('--max_cpg', type=int, default=1000,
-                        help=f'Maximal allowed block size (in #sites). Default is 1000 (at most {MAX_CPG_CAP} here)')
-    parser.add_argument('--max_bp', type=int, default=2000,
-                        help='Maximal allowed block size (in bp). Default is 2000')
-    parser.add_argument('-o', '--out_path', default=sys.stdout,
-                        help='output path [stdout]')
-    add_multi_thread_args(parser)
-    parser.add_argument('--device', type=int, default=0, help='HIP device index of the (first) GPU [0]')
-    parser.add_argument('--gpus', type=int, default=0,
-                        help='Number of GPUs to spread the chunks over from this one process (the role of -@ in the '
-                             'CPU implementation). Default: all visible GPUs')
-    parser.add_argument('--stats', metavar='JSON_PATH',
-                        help='Write a JSON report of the run: parameters, regions, chunks, junction patches, GPU batches, '
-                             'blocks found / dropped, wall-clock phases and device timings')
+    add_where_options(parser, bed_file=True)
+    source = parser.add_mutually_exclusive_group(required=True)
+    source.add_argument('--betas', nargs='+')
+    source.add_argument('--beta_file', '-F')
+    for flags, kind, default, text in _OPTIONS:
+        parser.add_argument(*flags, default=default, help=text, **({'type': kind} if kind else {}))
+    add_threads_option(parser)
     return parser.parse_args(argv)
 
 
-def validate_single_file(fpath, suff=None):
-    """utils_wgbs.py:383-406"""
-    if fpath is None:
-        raise IllegalArgumentError("Input file is None")
-    if not os.path.isfile(fpath):
-        raise IllegalArgumentError(f'No such file: {fpath}')
-    if suff is not None and not fpath.endswith(suff):
-        raise IllegalArgumentError(f'file {fpath} must end with {suff}')
-    return fpath
+def beta_paths_of(args):
+    """The input list of `--betas A B ...` or `-F list.txt` (one path per line; blank lines and lines starting with '#' skipped),
+    checked before any work starts with the reference's messages (segment.py:285-301, utils_wgbs.py:355-406).  On top of that every
+    file must be a uint8 `.beta`: the reference's segmentor silently ignores argv tokens that do not end in ".beta"
+    (main.cpp:101-107), which would segment fewer samples than were asked for."""
+    paths = list(args.betas) if args.betas else lines_of(args.beta_file)
+    if not paths:
+        raise IllegalArgumentError(f'no beta files found in file {args.beta_file}')
+    if require_files(paths) != '.beta':
+        raise IllegalArgumentError(f'segment reads uint8 .beta files; got {paths[0]}')
+    return paths
 
 
-def validate_file_list(files, min_len=1):
-    """utils_wgbs.py:355-380"""
-    if len(files) < min_len:
-        raise IllegalArgumentError(f'Input error: at least {min_len} input files must be given')
-    first = files[0]
-    if len(first) == 1:
-        raise IllegalArgumentError(f'Input is not a list of files: {files}')
-    suff = os.path.splitext(first)[1]
-    for fpath in files:
-        validate_single_file(fpath, suff)
-    if suff != '.beta':
-        # the reference's segmentor silently ignores argv tokens that do not end in ".beta" (main.cpp:101-107)
-        raise IllegalArgumentError(f'segment reads uint8 .beta files; got {first}')
-
-
-def parse_betas_input(args):
-    """segment.py:285-301"""
-    if args.betas:
-        betas = args.betas
-    elif args.beta_file:
-        validate_single_file(args.beta_file)
-        with open(args.beta_file, 'r') as f:
-            betas = [b.strip() for b in f.readlines() if b.strip() and not b.startswith('#')]
-        if not betas:
-            raise IllegalArgumentError(f'no beta files found in file {args.beta_file}')
-    validate_file_list(betas)
-    return betas
+parse_betas_input = beta_paths_of        # the reference's name for it (segment.py:285)
 
 
 def main(argv=None):
@@ -683,7 +516,7 @@ def main(argv=None):
     Output: blocks file (BED format + startCpG, endCpG columns)
     """
     args = parse_args(argv)
-    betas = parse_betas_input(args)
+    betas = beta_paths_of(args)
     SegmentByChunks(args, betas).run()
 
 
