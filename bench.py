@@ -448,7 +448,7 @@ def main():
         scan_gbs = acc['scan_main_bytes'] / (main_ms * 1e-3) / 1e9
         scan_all_gbs = acc['scan_bytes'] / (acc['scan_ms'] * 1e-3) / 1e9
         evals_s = acc['evals'] / (acc['cost_ms'] * 1e-3)
-        stats_wide = acc['max_window'] > 60          # WG_NARROW_WMAX: wide scoring tiles exist, so the scan keeps its carries
+        stats_wide = acc['max_window'] > 252         # WG_MEDIUM_WMAX: wide scoring tiles exist, so the scan keeps its carries
         scan_kernel = 'k_scan' if stats_wide else 'k_validate'
         # HBM traffic of the scan launch from the PMC counters (separate rocprofv3 passes, tools/pmc_scan_traffic.py): only a file
         # made from THIS source state, for this kernel and these algorithmic bytes, is reported
@@ -470,6 +470,20 @@ def main():
                      'note': 'issue bound of the narrow-tile kernel\'s common path: sum over instruction classes of count x issue cycles per wavefront '
                              'instruction (fp32 2, fp64 / conversions / 3-operand integer 4, v_rcp_f32 8) on %d SIMDs at %.1f GHz; wide tiles (when the job '
                              'has any) run a longer evaluation: %s VALU' % (N_SIMD, CLOCK_HZ * 1e-9, mixes['wide']['valu_per_eval'] if mixes['wide'] else '?')}
+        # the same bound with the issue rates MEASURED on this chip for a mixed stream (profiles/r03_valu_rates.json): in a stream that
+        # alternates cheap (fp32 / simple integer) and fp64-class instructions every instruction issues at the fp64 rate, so the
+        # evaluation costs (VALU instructions + the extra slots of v_rcp_f32) x the measured fp64 time per wavefront instruction
+        if issue:
+            try:
+                vr = json.load(open(op.join(ROOT, 'profiles', 'r03_valu_rates.json')))['ns_per_wave_instr']
+                t64, trcp = vr['v_fma_f64'] * 1e-9, vr['v_rcp_f32'] * 1e-9
+                slots = main_mix['valu_per_eval'] + main_mix['mix_per_eval'].get('trans', 0) * (trcp / t64 - 1.0)
+                issue['measured_mixed_stream'] = {'slots_per_eval': slots, 'ns_per_slot': t64 * 1e9, 'peak_evals_per_s': N_SIMD * 64 / (slots * t64),
+                                                  'frac': evals_s / (N_SIMD * 64 / (slots * t64)), 'file': 'r03_valu_rates.json',
+                                                  'note': 'every instruction of a mixed fp32 / fp64 stream issues at the fp64 rate measured on this chip (a stream alternating '
+                                                          'v_fma_f32 and v_fma_f64 runs at 0.95 of the pure fp64 time per instruction); v_rcp_f32 at its own measured time'}
+            except Exception:
+                pass
         mode = ('one process, %d GPUs: a share group (work-balanced contiguous chunk runs, one host thread per GPU, one host-side tree)' % args.gpus
                 if group_mode else
                 'one process per GPU (parallel.ShardedRun): work-balanced contiguous chunk runs per rank, border lists handed to rank 0 through /dev/shm, '

@@ -282,8 +282,8 @@ def test_x512_deep_full_genome(hg19):
     """BASELINE.json configs[4] at FULL size on one GPU: 28,217,448 CpGs x 512 betas (28.9 GB resident), max_cpg 5000, max_bp 1e6,
     chunk_size 50000 — 576 chunks, every window 5000 sites wide: 1.4e11 scored blocks x 512 samples = 7.2e13 evaluations through
     the staged scored-block buffer (WGBSSEG_COST_BUDGET_MB), the wide scoring tiles, the <15,32> recurrence and its L2 ring.
-    Checked: the genome-wide properties; full 50,000-site chunks spread over the genome (WGBSSEG_DEEP_ORACLE_CHUNKS, default 4;
-    1.3e11 evaluations each on all host threads) against the oracle's many-thread restatement; the stitched trees of chr21 and chr22
+    Checked: the genome-wide properties; full 50,000-site chunks spread over the genome (WGBSSEG_DEEP_ORACLE_CHUNKS, default 1 —
+    1.3e11 evaluations and two minutes on all host threads each; 8 of them in profiles/r03_deep_full_genome.log) against the oracle's many-thread restatement; the stitched trees of chr21 and chr22
     against the reference's pairwise tree walked over the same DPs.  The run's timing goes to gpurun_out/deep_full_timing.json."""
     import json
     import time
@@ -317,7 +317,7 @@ def test_x512_deep_full_genome(hg19):
             json.dump(rec, f, indent=1)
         print('deep full genome: %.1f s, %s' % (wall, json.dumps(rec['device_ms'])))
         # full chunks spread over the genome against the oracle restatement
-        k = int(os.environ.get('WGBSSEG_DEEP_ORACLE_CHUNKS', '4'))
+        k = int(os.environ.get('WGBSSEG_DEEP_ORACLE_CHUNKS', '1'))
         pick = _spread_chunks(sizes, chunk, k)
         got = seg.segment_chunks(pick, [chunk] * len(pick), pc, mc, max_bp)
         for st, g in zip(pick, got):

@@ -671,3 +671,42 @@ def test_15b_windows_between_8000_and_65535_match_the_oracle():
         with pytest.raises(_lib.SegmentorError) as e:
             sg.segment_chunks([0], [n], 15.0, 65536, 2000)
         assert e.value.code == _lib.E_ARG and '2^24' in str(e.value)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 16. medium scoring tiles (round 3): units with windows of 61 .. 252 sites, tile-local packed prefixes
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n_samples,cov_mode', [(1, 'sat'), (3, 'mix'), (40, 'mix')])
+def test_16_medium_tiles_match_oracle_and_wide_tiles(monkeypatch, n_samples, cov_mode):
+    """Dense worlds whose windows sit on both sides of the class boundaries (60 | 61 and 252 | 253 sites) and of the packed fields'
+    capacity: with every count saturated (meth = cov = 255) the prefixes of a 269-entry row run past 2^16 in both fields (carry from
+    the #meth into the #cov field, wrap at 2^32) while a block's own counts (<= 252 * 255) still fit — the case the medium tiles'
+    difference-of-dwords rests on.  Chunks start off the 8-site vector grid, end inside a unit, and (40 samples) take two LDS sample
+    groups.  Borders == oracle, with the medium class on, off (the wide tiles take those units), and cut at 124."""
+    rng = np.random.default_rng(1600 + n_samples)
+    n = 9000
+    loci = (np.cumsum(rng.integers(1, 4, n)) + 5000).astype(np.uint32)              # ~2 bp apart: max_bp decides nothing below
+    slices = []
+    for _ in range(n_samples):
+        if cov_mode == 'sat':
+            cov = np.full(n, 255)
+            meth = np.where(rng.random(n) < 0.5, 255, 0)
+            meth[2000:2600] = 255                                               # 600 saturated sites in a row
+        else:
+            cov = rng.integers(0, 256, n)
+            cov[rng.random(n) < 0.1] = 0
+            meth = np.minimum(cov, rng.integers(0, 256, n))
+        slices.append(np.stack([meth, cov], axis=1).astype(np.uint8))
+    chunks = [(0, 3000), (1999, 1203), (2005, 700), (4103, 1531), (8000, 1000), (8737, 263), (5, 253)]
+    starts, lens = [c[0] for c in chunks], [c[1] for c in chunks]
+    with _lib.Segmenter(0) as sg:
+        sg.set_betas(slices)
+        sg.set_loci(loci)
+        for pcount, max_cpg in [(15.0, 252), (15.0, 253), (15.0, 61), (1.0, 130), (0.25, 200), (0.0, 252), (7.77, 189), (15.0, 1000)]:
+            want = oracle.segment_chunks(slices, loci, starts, lens, pcount, max_cpg, 10**6, threads=os.cpu_count() or 1)
+            for wm in ('252', '0', '124'):
+                monkeypatch.setenv('WGBSSEG_MEDIUM_WMAX', wm)
+                got = sg.segment_chunks(starts, lens, pcount, max_cpg, 10**6)
+                for c, (a, b) in enumerate(zip(got, want)):
+                    assert a.tolist() == b.tolist(), 'pcount %r max_cpg %d medium<=%s chunk [%d,+%d): %s' % (pcount, max_cpg, wm, starts[c], lens[c], _first_diff(a, b))
+        monkeypatch.delenv('WGBSSEG_MEDIUM_WMAX')

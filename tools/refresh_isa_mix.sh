@@ -7,3 +7,4 @@ cd "$(dirname "$0")/.."
 python tools/micro/count_cost_loop.py 64 3 0 --json profiles/${R}_cost_isa_mix_narrow.json | tail -1
 python tools/micro/count_cost_loop.py 128 3 0 --json profiles/${R}_cost_isa_mix_narrow128.json | tail -1
 python tools/micro/count_cost_loop.py 16 2 1 --json profiles/${R}_cost_isa_mix_wide.json | tail -1
+python tools/micro/count_cost_loop.py 16 3 2 --json profiles/${R}_cost_isa_mix_medium.json | tail -1

@@ -32,6 +32,9 @@
 #define WG_TRACE_WIN    32768       // back-pointers staged in LDS by k_trace (64 KiB)
 #define WG_TRACE_SEG    128         // speculative walks per window
 #define WG_NARROW_WMAX  60          // widest window of a narrow scoring tile: TI + 60 + 1 <= 125 entries, + 3 of alignment <= 128 = 32 lanes x 4 sites
+#define WG_MEDIUM_WMAX  252         // widest window of a medium scoring tile (16 starts, every end): block counts <= 255 * 252 < 2^16 still fit the packed
+                                    // tile-local prefixes of the narrow tiles (a block's counts are ONE difference of two dwords), no carries of k_scan
+#define WG_MEDIUM_TS    16          // start sites of a medium tile = one 16-site unit
 
 // Exact-restatement tables: global (constant) memory, read only by the rare guard-band fallback and by the plain kernel.
 __device__ const wg_log_tables g_wg_tables = WG_LOG_TABLES_INIT;
@@ -97,7 +100,7 @@ struct JobStatus {            // zeroed (first_bad = ~0) before every call
     unsigned int max_window;
     unsigned int loci_disorder;     // 1 + chunk index of a chunk whose loci are not ascending
     unsigned int overflow;          // a chunk's pair count does not fit 32 bits
-    unsigned int wide_units;        // 16-site units with a window > WG_NARROW_WMAX sites: they are scored in wide tiles, from the carries of k_scan
+    unsigned int wide_units;        // 16-site units with a window beyond the medium tiles' (> WG_MEDIUM_WMAX sites by default): they are scored in wide tiles, from the carries of k_scan
 };
 
 struct StageView {            // tables produced by k_stage_plan, row `stage` of each
@@ -174,7 +177,7 @@ __device__ __noinline__ int wg_first_bad_site(uint4 v0, uint4 v1)      // index 
 __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int want_carry)
 {
     const int lane = threadIdx.x & 63;
-    // The carries have ONE consumer: the wide scoring tiles (windows > WG_NARROW_WMAX sites: CpG islands, deep mode), which
+    // The carries have ONE consumer: the wide scoring tiles (windows > WG_MEDIUM_WMAX sites: deep mode, the densest islands), which
     // k_window_scan has counted on this stream before this kernel starts.  A job without any (every default-parameter
     // genome) needs none: this launch leaves at once and k_validate (launched beside it) does the read-only pass.
     if (want_carry == 0 && __hip_atomic_load(&st->wide_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
@@ -223,6 +226,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int
         // wave-wide inclusive prefix of the lane totals (two 32-bit DPP scans)
         const uint32_t im = wg_wave_incl_scan_dpp_u32(tm);
         const uint32_t it = wg_wave_incl_scan_dpp_u32(tt);
+        // (one 8-byte store from every 8th lane.  Round 3: the same store with a non-temporal hint measured 0.432 against 0.434 ms for
+        // hg19 x 32 with islands — no difference, the hint is not used)
         if (((A6 + off) & (WG_CARRY_G - 1)) == 0 && rel0 > 0 && rel0 < len)
             carry[(A6 + off) >> WG_CARRY_SHIFT] = make_uint2(run_m + (im - tm), run_t + (it - tt));
         run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, c
 }
 
 #define WG_WSCAN_BLOCK 1024      // one workgroup per chunk: 16 wavefronts x 8 sites per thread = 8192 sites per step (a 60,000-site chunk: 8 steps)
-__global__ __launch_bounds__(WG_WSCAN_BLOCK) void k_window_scan(JobView J, JobStatus* st)
+__global__ __launch_bounds__(WG_WSCAN_BLOCK) void k_window_scan(JobView J, JobStatus* st, int wide_from)      // wide_from: widest window that is NOT scored in wide tiles
 {
     __shared__ uint32_t wsum[WG_WSCAN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(WG_WSCAN_BLOCK) void k_window_scan(JobView J, JobSt
         run += btot;
     }
     uint32_t nwide = 0;
-    for (int u = tid; u < (cd.len + 15) >> 4; u += WG_WSCAN_BLOCK) nwide += J.umax16[cd.unit_off + u] > (uint32_t)WG_NARROW_WMAX ? 1u : 0u;
+    for (int u = tid; u < (cd.len + 15) >> 4; u += WG_WSCAN_BLOCK) nwide += J.umax16[cd.unit_off + u] > (uint32_t)wide_from ? 1u : 0u;
     for (int o = 32; o > 0; o >>= 1) nwide += (uint32_t)__shfl_down((int)nwide, o);
     if (lane == 0 && nwide) atomicAdd(&st->wide_units, nwide);
     if (tid == 0) {
@@ -426,68 +431,75 @@ __global__ __launch_bounds__(WG_WSCAN_BLOCK) void k_window_scan(JobView J, JobSt
 // k_tile_count counts the tiles of each class per (stage, chunk); k_stage_plan turns the counts into per-stage
 // prefixes over the chunks; k_tile_emit writes the tile descriptors in site order.
 // ------------------------------------------------------------------------------------------------------------
-struct PlanArgs { const int32_t* sb; int32_t TI, WA, TK, n_stages; };     // sb: stage bounds, as in StageView
+struct PlanArgs { const int32_t* sb; int32_t TI, WA, TK, n_stages, WM; };     // sb: stage bounds, as in StageView; WM: widest window of a medium tile (0: no medium class)
 
 struct TileDesc { int32_t chunk, ka, nk, et_lo; };     // start sites [ka, ka+nk); wide tiles: end sites [et_lo, et_lo+TK)
 
+// Tiles of the aligned group of TI start sites at ka: ONE narrow tile when every 16-site unit of it has umax16 <= WA; otherwise
+// unit by unit a medium tile (umax16 <= WM: the unit's 16 starts with all their ends) or as many wide tiles as its widest block
+// needs end tiles of TK sites.
 __device__ __forceinline__ void wg_group_tiles(const JobView& J, const ChunkDesc& cd, const PlanArgs& P, int ka, int s1,
-                                               uint32_t& nA, uint32_t& nB)
+                                               uint32_t& nA, uint32_t& nB, uint32_t& nM)
 {
     const int kb = (ka + P.TI < s1) ? ka + P.TI : s1;
-    uint32_t m = 0, tb = 0;
+    uint32_t m = 0, tb = 0, tm = 0;
     for (int k0 = ka; k0 < kb; k0 += 16) {
         const uint32_t um = J.umax16[cd.unit_off + (k0 >> 4)];
         const int nk = (kb - k0 < 16) ? kb - k0 : 16;
         m = um > m ? um : m;
-        tb += ((uint32_t)(nk - 1) + um + (uint32_t)P.TK - 1u) / (uint32_t)P.TK;     // ends k0 .. k0+nk-1+um-1
+        if (um <= (uint32_t)P.WM) tm += 1u;
+        else tb += ((uint32_t)(nk - 1) + um + (uint32_t)P.TK - 1u) / (uint32_t)P.TK;     // ends k0 .. k0+nk-1+um-1
     }
     const bool narrow = m <= (uint32_t)P.WA;
     nA = narrow ? 1u : 0u;
     nB = narrow ? 0u : tb;
+    nM = narrow ? 0u : tm;
 }
 
-__global__ __launch_bounds__(WG_BLOCK) void k_tile_count(JobView J, PlanArgs P, uint32_t* __restrict__ cntA, uint32_t* __restrict__ cntB)
+__global__ __launch_bounds__(WG_BLOCK) void k_tile_count(JobView J, PlanArgs P, uint32_t* __restrict__ cntA, uint32_t* __restrict__ cntB,
+                                                         uint32_t* __restrict__ cntM)
 {
-    __shared__ uint32_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64];
+    __shared__ uint32_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64], wm[WG_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = blockIdx.x, stg = blockIdx.y;
     const ChunkDesc cd = J.chunks[c];
     const int s0 = P.sb[stg];
-    uint32_t a = 0, b = 0;
+    uint32_t a = 0, b = 0, m = 0;
     if (s0 < cd.len) {
         const int s1 = (P.sb[stg + 1] < cd.len) ? P.sb[stg + 1] : cd.len;
         const int nU = (s1 - s0 + P.TI - 1) / P.TI;
         for (int u = tid; u < nU; u += WG_BLOCK) {
-            uint32_t na, nb;
-            wg_group_tiles(J, cd, P, s0 + u * P.TI, s1, na, nb);
-            a += na; b += nb;
+            uint32_t na, nb, nm;
+            wg_group_tiles(J, cd, P, s0 + u * P.TI, s1, na, nb, nm);
+            a += na; b += nb; m += nm;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) { a += (uint32_t)__shfl_down((int)a, o); b += (uint32_t)__shfl_down((int)b, o); }
-    if (lane == 0) { wa[wv] = a; wb[wv] = b; }
+    for (int o = 32; o > 0; o >>= 1) { a += (uint32_t)__shfl_down((int)a, o); b += (uint32_t)__shfl_down((int)b, o); m += (uint32_t)__shfl_down((int)m, o); }
+    if (lane == 0) { wa[wv] = a; wb[wv] = b; wm[wv] = m; }
     __syncthreads();
     if (tid == 0) {
-        uint32_t ta = 0, tb = 0;
-        for (int q = 0; q < WG_BLOCK / 64; q++) { ta += wa[q]; tb += wb[q]; }
+        uint32_t ta = 0, tb = 0, tm = 0;
+        for (int q = 0; q < WG_BLOCK / 64; q++) { ta += wa[q]; tb += wb[q]; tm += wm[q]; }
         cntA[(int64_t)stg * J.n_chunks + c] = ta;
         cntB[(int64_t)stg * J.n_chunks + c] = tb;
+        cntM[(int64_t)stg * J.n_chunks + c] = tm;
     }
 }
 
 // one workgroup per stage; per chunk the number of scored blocks in the stage, and the exclusive prefixes over the
 // chunks of the blocks and of the tiles of both classes
 __global__ __launch_bounds__(WG_BLOCK) void k_stage_plan(JobView J, PlanArgs P, const uint32_t* __restrict__ cntA,
-                                                         const uint32_t* __restrict__ cntB, int64_t* cbase, uint32_t* cum0,
-                                                         int64_t* tbaseA, int64_t* tbaseB, int64_t* stage_pairs, int64_t* stage_tiles)
+                                                         const uint32_t* __restrict__ cntB, const uint32_t* __restrict__ cntM, int64_t* cbase, uint32_t* cum0,
+                                                         int64_t* tbaseA, int64_t* tbaseB, int64_t* tbaseM, int64_t* stage_pairs, int64_t* stage_tiles)
 {
-    __shared__ uint64_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64], wc[WG_BLOCK / 64];
+    __shared__ uint64_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64], wc[WG_BLOCK / 64], wd[WG_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int stg = blockIdx.x;
     const int nC = J.n_chunks;
-    uint64_t runA = 0, runB = 0, runC = 0;
+    uint64_t runA = 0, runB = 0, runC = 0, runD = 0;
     for (int base = 0; base < nC; base += WG_BLOCK) {
         const int c = base + tid;
-        uint64_t sz = 0, nt = 0, nu = 0;
+        uint64_t sz = 0, nt = 0, nu = 0, nm = 0;
         uint32_t c0 = 0;
         if (c < nC) {
             const ChunkDesc cd = J.chunks[c];
@@ -499,38 +511,46 @@ __global__ __launch_bounds__(WG_BLOCK) void k_stage_plan(JobView J, PlanArgs P, 
                 sz = cend - c0;
                 nt = cntA[(int64_t)stg * nC + c];
                 nu = cntB[(int64_t)stg * nC + c];
+                nm = cntM[(int64_t)stg * nC + c];
             }
         }
-        const uint64_t ia = wg_wave_incl_scan_u64(sz, lane), ib = wg_wave_incl_scan_u64(nt, lane), ic = wg_wave_incl_scan_u64(nu, lane);
-        if (lane == 63) { wa[wv] = ia; wb[wv] = ib; wc[wv] = ic; }
+        const uint64_t ia = wg_wave_incl_scan_u64(sz, lane), ib = wg_wave_incl_scan_u64(nt, lane), ic = wg_wave_incl_scan_u64(nu, lane),
+                       id = wg_wave_incl_scan_u64(nm, lane);
+        if (lane == 63) { wa[wv] = ia; wb[wv] = ib; wc[wv] = ic; wd[wv] = id; }
         __syncthreads();
-        uint64_t oa = 0, ob = 0, oc = 0, ta = 0, tb2 = 0, tc = 0;
+        uint64_t oa = 0, ob = 0, oc = 0, od = 0, ta = 0, tb2 = 0, tc = 0, td = 0;
 #pragma unroll
-        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) { oa += wa[q]; ob += wb[q]; oc += wc[q]; } ta += wa[q]; tb2 += wb[q]; tc += wc[q]; }
+        for (int q = 0; q < WG_BLOCK / 64; q++) {
+            if (q < wv) { oa += wa[q]; ob += wb[q]; oc += wc[q]; od += wd[q]; }
+            ta += wa[q]; tb2 += wb[q]; tc += wc[q]; td += wd[q];
+        }
         __syncthreads();
         if (c < nC) {
             cbase[(int64_t)stg * nC + c] = (int64_t)(runA + oa + ia - sz);
             cum0[(int64_t)stg * nC + c] = c0;
             tbaseA[(int64_t)stg * (nC + 1) + c] = (int64_t)(runB + ob + ib - nt);
             tbaseB[(int64_t)stg * (nC + 1) + c] = (int64_t)(runC + oc + ic - nu);
+            tbaseM[(int64_t)stg * (nC + 1) + c] = (int64_t)(runD + od + id - nm);
         }
-        runA += ta; runB += tb2; runC += tc;
+        runA += ta; runB += tb2; runC += tc; runD += td;
     }
     if (tid == 0) {
         tbaseA[(int64_t)stg * (nC + 1) + nC] = (int64_t)runB;
         tbaseB[(int64_t)stg * (nC + 1) + nC] = (int64_t)runC;
+        tbaseM[(int64_t)stg * (nC + 1) + nC] = (int64_t)runD;
         stage_pairs[stg] = (int64_t)runA;
-        stage_tiles[2 * stg] = (int64_t)runB;
-        stage_tiles[2 * stg + 1] = (int64_t)runC;
+        stage_tiles[3 * stg] = (int64_t)runB;
+        stage_tiles[3 * stg + 1] = (int64_t)runC;
+        stage_tiles[3 * stg + 2] = (int64_t)runD;
     }
 }
 
 // one workgroup per chunk (of one stage): the tile descriptors of both classes, in site order
 __global__ __launch_bounds__(WG_BLOCK) void k_tile_emit(JobView J, PlanArgs P, int stg, const int64_t* __restrict__ tbaseA,
-                                                        const int64_t* __restrict__ tbaseB, TileDesc* __restrict__ tilesA,
-                                                        TileDesc* __restrict__ tilesB)
+                                                        const int64_t* __restrict__ tbaseB, const int64_t* __restrict__ tbaseM,
+                                                        TileDesc* __restrict__ tilesA, TileDesc* __restrict__ tilesB, TileDesc* __restrict__ tilesM)
 {
-    __shared__ uint32_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64];
+    __shared__ uint32_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64], wm[WG_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = blockIdx.x;
     const int nC = J.n_chunks;
@@ -539,18 +559,18 @@ __global__ __launch_bounds__(WG_BLOCK) void k_tile_emit(JobView J, PlanArgs P, i
     if (s0 >= cd.len) return;
     const int s1 = (P.sb[stg + 1] < cd.len) ? P.sb[stg + 1] : cd.len;
     const int nU = (s1 - s0 + P.TI - 1) / P.TI;
-    int64_t runA = tbaseA[(int64_t)stg * (nC + 1) + c], runB = tbaseB[(int64_t)stg * (nC + 1) + c];
+    int64_t runA = tbaseA[(int64_t)stg * (nC + 1) + c], runB = tbaseB[(int64_t)stg * (nC + 1) + c], runM = tbaseM[(int64_t)stg * (nC + 1) + c];
     for (int base = 0; base < nU; base += WG_BLOCK) {
         const int u = base + tid;
         const int ka = s0 + u * P.TI;
-        uint32_t na = 0, nb = 0;
-        if (u < nU) wg_group_tiles(J, cd, P, ka, s1, na, nb);
-        const uint32_t ia = wg_wave_incl_scan_dpp_u32(na), ib = wg_wave_incl_scan_dpp_u32(nb);
-        if (lane == 63) { wa[wv] = ia; wb[wv] = ib; }
+        uint32_t na = 0, nb = 0, nm = 0;
+        if (u < nU) wg_group_tiles(J, cd, P, ka, s1, na, nb, nm);
+        const uint32_t ia = wg_wave_incl_scan_dpp_u32(na), ib = wg_wave_incl_scan_dpp_u32(nb), im = wg_wave_incl_scan_dpp_u32(nm);
+        if (lane == 63) { wa[wv] = ia; wb[wv] = ib; wm[wv] = im; }
         __syncthreads();
-        uint32_t oa = 0, ob = 0, ta = 0, tb = 0;
+        uint32_t oa = 0, ob = 0, om = 0, ta = 0, tb = 0, tm = 0;
 #pragma unroll
-        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) { oa += wa[q]; ob += wb[q]; } ta += wa[q]; tb += wb[q]; }
+        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) { oa += wa[q]; ob += wb[q]; om += wm[q]; } ta += wa[q]; tb += wb[q]; tm += wm[q]; }
         __syncthreads();
         if (u < nU) {
             const int kb = (ka + P.TI < s1) ? ka + P.TI : s1;
@@ -558,16 +578,17 @@ __global__ __launch_bounds__(WG_BLOCK) void k_tile_emit(JobView J, PlanArgs P, i
                 TileDesc d = {c, ka, kb - ka, 0};
                 tilesA[runA + oa + ia - na] = d;
             } else {
-                int64_t o = runB + ob + ib - nb;
+                int64_t o = runB + ob + ib - nb, om2 = runM + om + im - nm;
                 for (int k0 = ka; k0 < kb; k0 += 16) {
                     const uint32_t um = J.umax16[cd.unit_off + (k0 >> 4)];
                     const int nk = (kb - k0 < 16) ? kb - k0 : 16;
+                    if (um <= (uint32_t)P.WM) { TileDesc d = {c, k0, nk, 0}; tilesM[om2++] = d; continue; }
                     const int kt = (int)(((uint32_t)(nk - 1) + um + (uint32_t)P.TK - 1u) / (uint32_t)P.TK);
                     for (int e = 0; e < kt; e++) { TileDesc d = {c, k0, nk, k0 + e * P.TK}; tilesB[o++] = d; }
                 }
             }
         }
-        runA += ta; runB += tb;
+        runA += ta; runB += tb; runM += tm;
     }
 }
 
@@ -702,19 +723,86 @@ __device__ __forceinline__ void wg_stage_local_rows(uint32_t* __restrict__ Et, c
     }
 }
 
+// The same for the rows of a MEDIUM tile (16 starts, windows <= WG_MEDIUM_WMAX: up to 269 entries): one sample row per wavefront
+// pass, 8 sites (one aligned 16-byte vector) per lane.  The packed sums may now carry from the #meth field into the #cov field
+// (35 lanes x 8 x 255 > 2^16) and wrap at 2^32: harmless, because an entry is the plain integer  sum(meth) + 2^16 sum(cov)  mod 2^32,
+// so the difference of two entries is  d(meth) + 2^16 d(cov)  mod 2^32, and both differences of a block of <= 252 sites are below
+// 2^16: the two halves of the difference ARE the block's counts.
+template <int ROW>
+__device__ __forceinline__ void wg_stage_local_rows8(uint32_t* __restrict__ Et, const uint8_t* __restrict__ betas, int64_t pitch,
+                                                     int s_first, int ns, const ChunkDesc& cd, int64_t n_total, int ka, int cnt,
+                                                     int lane, int wv)
+{
+    // one sample row per wavefront, 256 sites (64 lanes x 4 sites, one 8-byte load each) per pass with the running total carried
+    // over: a row of 269 entries takes two passes (the second one a few lanes wide).  (A single pass of 8 sites per lane cost six
+    // more registers than the kernel's main loop needs: 101 VGPRs, one wavefront per SIMD fewer.)
+    const int64_t abs0 = cd.start0 + ka;
+    const int64_t al = abs0 & ~3LL;                    // 8-byte aligned
+    const int hs = (int)(abs0 - al);
+    const int nsite = cnt - 1;                         // sites ka .. ka+cnt-2 are summed
+    for (int rr = wv; rr < ns; rr += WG_BLOCK / 64) {
+        const uint8_t* row = betas + (int64_t)(s_first + rr) * pitch;
+        uint32_t* dst = Et + (size_t)rr * ROW;
+        uint32_t run = 0;
+        for (int p0 = 0; p0 < nsite + hs; p0 += 256) {
+            const int sidx = p0 + lane * 4;            // site offset of this lane from `al`
+            const int64_t a = al + sidx;
+            uint32_t w0 = 0, w1 = 0;
+            if (sidx < nsite + hs) {
+                if (a + 4 <= n_total) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(row + 2 * a);
+                    w0 = v.x; w1 = v.y;
+                } else {
+                    for (int j = 0; j < 4; j++) if (a + j < n_total) {
+                        const uint32_t h = (uint32_t)row[2 * (a + j)] | ((uint32_t)row[2 * (a + j) + 1] << 8);
+                        if (j < 2) w0 |= h << (16 * j); else w1 |= h << (16 * (j - 2));
+                    }
+                }
+            }
+            uint32_t mt[4];
+            uint32_t tot = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t h = ((j < 2) ? w0 : w1) >> (16 * (j & 1));
+                const int x = sidx + j - hs;           // site index relative to ka
+                const bool in = x >= 0 && x < nsite;
+                mt[j] = in ? ((h & 0xffu) | ((h & 0xff00u) << 8)) : 0u;
+                tot += mt[j];
+            }
+            const uint32_t incl = wg_wave_incl_scan_dpp_u32(tot);
+            uint32_t e = run + (incl - tot);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = sidx + j - hs;
+                if (x >= 0 && x < cnt) dst[x] = e;
+                e += mt[j];
+            }
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+        // the entry behind the last site when it falls exactly on a pass boundary (x == nsite, sidx + j - hs beyond the loop's reach)
+        if (lane == 0 && ((nsite + hs) & 255) == 0 && nsite < cnt) dst[nsite] = run;
+    }
+}
+
 #define WG_WIDE_TK      128         // end sites per wide tile
 #define WG_WIDE_TS      16          // start sites per wide tile
 
 // Scored blocks of one tile.  SPLIT 0: narrow tile, TI start sites whose windows are all <= WG_NARROW_WMAX, prefixes
 // tile-local and packed (wg_stage_local_rows).  SPLIT 1: wide tile, WG_WIDE_TS start sites x WG_WIDE_TK end sites,
-// prefixes of starts and ends staged separately from the carries of k_scan.  The LDS row strides are compile-time
-// constants: the sample loop is unrolled by four with the row offsets in the instructions' offset fields.
+// prefixes of starts and ends staged separately from the carries of k_scan.  SPLIT 2 (round 3): medium tile, the 16 start sites
+// of one unit whose windows are all <= WG_MEDIUM_WMAX with ALL their ends — CpG islands: windows of 60 .. 250 sites — scored like
+// a narrow tile (tile-local packed prefixes from the raw bytes, one subtraction per block and sample, the short division core)
+// where the wide tiles spent two carry-seeded scans per sample and end tile and ran at half the narrow tiles' rate.  The LDS row
+// strides are compile-time constants: the sample loop is unrolled by four with the row offsets in the instructions' offset fields.
 template <int TI, int FAST, int SPLIT>      // FAST = wg_term_mode(pseudo count)
 __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, CostArgs A, const TileDesc* __restrict__ tiles,
                                                    int64_t n_tiles, double* __restrict__ cost, int64_t n_tiles_padded)
 {
-    constexpr int KS = SPLIT ? WG_WIDE_TK + 1 : TI + WG_NARROW_WMAX + 1;   // entries per sample row of the E array
-    constexpr int IS = SPLIT ? WG_WIDE_TS + 1 : 0;                         // entries per sample row of the S array
+    constexpr bool WIDE = SPLIT == 1;
+    constexpr int WM = SPLIT == 2 ? WG_MEDIUM_WMAX : WG_NARROW_WMAX;       // widest window of a tile with tile-local prefixes
+    static_assert(SPLIT != 2 || TI == WG_MEDIUM_TS, "a medium tile is one 16-site unit");
+    constexpr int KS = WIDE ? WG_WIDE_TK + 1 : TI + WM + 1;                // entries per sample row of the E array
+    constexpr int IS = WIDE ? WG_WIDE_TS + 1 : 0;                          // entries per sample row of the S array
     // pseudo count >= 1: both logs on their k-scaled lookup tables, A.rows exponents each (sized by the host to the
     // longest block of the tile class)
     constexpr bool KY = (FAST >= 2);             // 2: k-scaled tables; 3: the same with the short division core (narrow tiles, verified per call)
@@ -730,7 +818,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     uint2* Et = reinterpret_cast<uint2*>(smem + TB);                             // wide: [NS][KS] P[i+1] of the ends
     uint2* St = Et + (size_t)A.NS * KS;                                          // wide: [NS][IS] P[k] of the starts
     uint32_t* Lt = reinterpret_cast<uint32_t*>(smem + TB);                       // narrow: [NS][KS] packed local prefixes
-    char* after = SPLIT ? reinterpret_cast<char*>(St + (size_t)A.NS * IS) : reinterpret_cast<char*>(Lt + (((size_t)A.NS * KS + 1) & ~(size_t)1));
+    char* after = WIDE ? reinterpret_cast<char*>(St + (size_t)A.NS * IS) : reinterpret_cast<char*>(Lt + (((size_t)A.NS * KS + 1) & ~(size_t)1));
     int64_t* radj = reinterpret_cast<int64_t*>(after);                           // [TI]
     int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
     int32_t* ist = offs + (TI + 1);                                              // [TI] first end of start kl in this unit
@@ -742,8 +830,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     // cohorts the coarse map frees a workgroup slot per CU (x 16: scoring 13.1 -> 12.0 ms).
     constexpr bool BMAP = false;
     uint8_t* bmap = reinterpret_cast<uint8_t*>(misc + 8);
-    uint8_t* cmap = bmap;                                                        // [TI * WG_NARROW_WMAX / 8 + 1]
-    constexpr bool CMAP = !SPLIT;
+    uint8_t* cmap = bmap;                                                        // [TI * WM / 8 + 1]
+    constexpr bool CMAP = !WIDE;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nC = J.n_chunks;
@@ -759,8 +847,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const ChunkDesc cd = J.chunks[c];
     const int ka = td.ka, nk = td.nk, kb = ka + nk;      // start sites [ka, kb)
     // end-site tile [et_lo, et_hi) of a wide tile; narrow tiles: no restriction
-    const int et_lo = SPLIT ? td.et_lo : 0;
-    const int et_hi = SPLIT ? et_lo + WG_WIDE_TK : (1 << 30);
+    const int et_lo = WIDE ? td.et_lo : 0;
+    const int et_hi = WIDE ? et_lo + WG_WIDE_TK : (1 << 30);
     const uint32_t cum0 = SV.cum0[(int64_t)SV.stage * nC + c];
 
     if (KY) wg_lookup_tables_to_lds(iyt, kyt, A.rows, A.tab, tid, WG_BLOCK);
@@ -810,7 +898,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int imax = PW > 1 ? (misc[1] > misc[3] ? misc[1] : misc[3]) : misc[1];
     // wide: E array = P[x] for x = eA .. imax+1 (ends use P[i+1]), S array = P[k] for k = ka .. kb-1.
     // narrow: one array L[x - ka], x = ka .. imax+1, serves both.
-    const int eA = SPLIT ? imin + 1 : ka;
+    const int eA = WIDE ? imin + 1 : ka;
     // carry position the scan of a wide row starts from.  eA == cd.len when the tile's first end is the chunk's last site (P[len]
     // alone is wanted): when start0 + len is a multiple of WG_CARRY_G that position is a group of its own, one past the cd.nG
     // carries k_scan wrote for the chunk — the scan starts from the last group INSIDE the chunk instead (up to WG_CARRY_G sites summed).
@@ -832,7 +920,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
         const int ns = (J.n_samples - g0 < A.NS) ? J.n_samples - g0 : A.NS;
         const bool firstg = ONEGROUP || g0 == 0, lastg = ONEGROUP || g0 + ns >= J.n_samples;
         __syncthreads();
-        if (SPLIT) {
+        if (WIDE) {
             for (int rr = wv; rr < ns; rr += WG_BLOCK / 64) {
                 const int s = g0 + rr;
                 const uint8_t* row = J.betas + (int64_t)s * J.pitch;
@@ -840,6 +928,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 wg_stage_prefix_row(Et + (size_t)rr * KS, row, carry, cd, J.n_total, eG, eA - eG, Ecnt, lane);
                 wg_stage_prefix_row(St + (size_t)rr * IS, row, carry, cd, J.n_total, sG, ka - sG, Scnt, lane);
             }
+        } else if (SPLIT == 2) {
+            wg_stage_local_rows8<KS>(Lt, J.betas, J.pitch, g0, ns, cd, J.n_total, ka, Ecnt, lane, wv);
         } else {
             wg_stage_local_rows<KS>(Lt, J.betas, J.pitch, g0, ns, cd, J.n_total, ka, Ecnt, lane, wv);
         }
@@ -858,7 +948,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 const float ll = FAST == 1 ? wg_sample_term(nm, nt, pc, pc2, tb, &g_wg_tables) : wg_sample_term_plain(nm, nt, pc, pc2, &g_wg_tables);
                 return (double)ll;                                               // segmentor.cpp:135 adds the float term to the double sum
             };
-            if (SPLIT) {
+            if (WIDE) {
                 const uint2* Ep = Et + (i + 1 - eA);       // P[i+1] of sample sl at Ep[sl * KS]
                 const uint2* Sp = St + lo;                 // P[k]   of sample sl at Sp[sl * IS]
                 auto one = [&](int sl) {

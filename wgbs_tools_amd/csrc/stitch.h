@@ -220,8 +220,13 @@ public:
         if (n <= 0) return;
         // one parallel section at a time: a second caller (another context on another thread) does its own work itself, and so
         // does a forked child, which has inherited the object but not the threads
+        // (and a section started from INSIDE a section — by the caller's own f(k) or by a worker's — runs on its thread: try_lock
+        // on a mutex the thread already holds is undefined, so nesting is told apart by a thread-local flag first)
+        static thread_local bool inside = false;
+        if (inside || workers_.empty() || n == 1 || getpid() != pid_) { for (int64_t k = 0; k < n; k++) f(k); return; }
         std::unique_lock<std::mutex> turn(run_m_, std::try_to_lock);
-        if (workers_.empty() || n == 1 || !turn.owns_lock() || getpid() != pid_) { for (int64_t k = 0; k < n; k++) f(k); return; }
+        if (!turn.owns_lock()) { for (int64_t k = 0; k < n; k++) f(k); return; }
+        struct Mark { bool& b; explicit Mark(bool& x) : b(x) { b = true; } ~Mark() { b = false; } } mark(inside);
         {
             std::lock_guard<std::mutex> g(m_);
             job_ = &f; n_ = n; next_.store(0); pending_.store((int)workers_.size());

@@ -117,7 +117,7 @@ struct wgbsseg_ctx {
     int64_t n_loci = 0;
     // scratch
     DevBuf chunks, wtile, carry, W16, cum32, back16, chunk_pairs, status;
-    DevBuf plan_cbase, plan_cum0, plan_tbase, plan_pairs, plan_tiles, plan_cnt, tilesA, tilesB, umax16;
+    DevBuf plan_cbase, plan_cum0, plan_tbase, plan_pairs, plan_tiles, plan_cnt, tilesA, tilesB, tilesM, umax16;
     std::vector<PinnedBuf> pinned;
     std::vector<PinnedBuf> up_stage;   // two page-locked staging pieces per upload thread (set_betas_host)
     DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders, dbg_a, dbg_b, dbg_c, lookup;
@@ -150,6 +150,8 @@ struct wgbsseg_ctx {
     // the short division core of the narrow scoring tiles: verified on the device per pseudo count (k_check_div)
     float divs_pc = -1.0f;     // pseudo count the verdict below is for
     bool divs_ok = false;
+    float divs_m_pc = -1.0f;   // the same for the operand pairs of a medium tile (ntotal <= 255 * WG_MEDIUM_WMAX)
+    bool divs_m_ok = false;
     bool divs_enabled = true;  // WGBSSEG_DIV_SHORT=0: always the 8-instruction core
     bool bs_general = false;   // WGBSSEG_BLOCK_SUMS_GENERAL=1: never the streaming block-sums kernel
     int64_t scan_piece_sites = 4096;    // WGBSSEG_SCAN_PIECE_SITES: sites per wave task of k_validate (multiple of 1024)
@@ -289,7 +291,7 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->wtile, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs,
-                     &c->status, &c->plan_cbase, &c->plan_cum0, &c->plan_tbase, &c->plan_pairs, &c->plan_tiles, &c->plan_cnt, &c->tilesA, &c->tilesB, &c->umax16,
+                     &c->status, &c->plan_cbase, &c->plan_cum0, &c->plan_tbase, &c->plan_pairs, &c->plan_tiles, &c->plan_cnt, &c->tilesA, &c->tilesB, &c->tilesM, &c->umax16,
                      &c->cost[0], &c->cost[1], &c->dpstate, &c->tmp_borders, &c->nb, &c->boff, &c->out_borders,
                      &c->dbg_a, &c->dbg_b, &c->dbg_c, &c->lookup, &c->scan_pieces, &c->divcheck, &c->plan_sb, &c->bs_desc};
     for (auto* b : all) b->release();
@@ -532,7 +534,8 @@ hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a,
 template <int FAST>
 hipError_t launch_cost_ti(int TI, bool wide, const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
-    if (wide) return launch_cost<WG_WIDE_TS, FAST == 3 ? 2 : FAST, 1>(v, sv, a, td, tiles, cost, lds, s);      // (the short division is a narrow-tile form)
+    if (TI < 0) return launch_cost<WG_MEDIUM_TS, FAST, 2>(v, sv, a, td, tiles, cost, lds, s);                     // medium tiles (TI = -1)
+    if (wide) return launch_cost<WG_WIDE_TS, FAST == 3 ? 2 : FAST, 1>(v, sv, a, td, tiles, cost, lds, s);      // (the short division is a form of the tiles with few operand pairs)
     if (TI == 128) return launch_cost<128, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
     if (TI == 64) return launch_cost<64, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
     if (TI == 32) return launch_cost<32, FAST, 0>(v, sv, a, td, tiles, cost, lds, s);
@@ -546,7 +549,8 @@ hipError_t set_cost_attrs()
 {
     const void* fns[] = {reinterpret_cast<const void*>(&k_cost<128, FAST, 0>),
                          reinterpret_cast<const void*>(&k_cost<64, FAST, 0>), reinterpret_cast<const void*>(&k_cost<32, FAST, 0>),
-                         reinterpret_cast<const void*>(&k_cost<16, FAST, 0>), reinterpret_cast<const void*>(&k_cost<WG_WIDE_TS, FAST == 3 ? 2 : FAST, 1>)};
+                         reinterpret_cast<const void*>(&k_cost<16, FAST, 0>), reinterpret_cast<const void*>(&k_cost<WG_WIDE_TS, FAST == 3 ? 2 : FAST, 1>),
+                         reinterpret_cast<const void*>(&k_cost<WG_MEDIUM_TS, FAST, 2>)};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
@@ -645,7 +649,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     hipLaunchKernelGGL(k_window, dim3((unsigned)job.wtile_off[(size_t)nC]), dim3(WG_BLOCK), (size_t)win_lds * 4, c->sA, v, c->status.as<JobStatus>(),
                        c->wtile.as<int64_t>(), reinterpret_cast<const int32_t*>(c->wtile.as<int64_t>() + nC + 1), P->max_cpg, P->max_bp, win_lds);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_window_scan, dim3((unsigned)nC), dim3(WG_WSCAN_BLOCK), 0, c->sA, v, c->status.as<JobStatus>());
+    // medium tiles (round 3): units of a non-narrow group whose windows stay <= WG_MEDIUM_WMAX = 252 sites (block counts < 2^16): CpG islands
+    const int wm_env = getenv("WGBSSEG_MEDIUM_WMAX") ? std::max(0, std::min(WG_MEDIUM_WMAX, atoi(getenv("WGBSSEG_MEDIUM_WMAX")))) : WG_MEDIUM_WMAX;   // 0: no medium class (A/B, tests; read per call)
+    const int WMED = wm_env > WG_NARROW_WMAX ? wm_env : 0;
+    hipLaunchKernelGGL(k_window_scan, dim3((unsigned)nC), dim3(WG_WSCAN_BLOCK), 0, c->sA, v, c->status.as<JobStatus>(), std::max(WMED, WG_NARROW_WMAX));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
     JobStatus* hst = reinterpret_cast<JobStatus*>(c->h_status.p);
@@ -714,16 +721,19 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const bool ks = term_modeA == 2, ksB = term_modeB == 2;
     const int rowsA = ks ? wg_lookup_rows(P->pseudo_count, 255.0 * WG_NARROW_WMAX) : 0;
     const int rowsB = ksB ? wg_lookup_rows(P->pseudo_count, 255.0 * std::max(Wmax, 1)) : 0;
-    if (rowsA > WG_KY_KMIN + 1 || rowsB > WG_KY_KMIN + 1) { set_err(err, errlen, "internal: %d / %d lookup rows", rowsA, rowsB); return WGBSSEG_E_ARG; }
-    auto lds_for = [&](int ti, bool split, int ns) -> size_t {
-        const size_t rows = split ? (size_t)ns * (WG_WIDE_TK + 1 + WG_WIDE_TS + 1) * 8                      // P of the ends + P of the starts, (meth, cov) as two dwords
-                                  : ((((size_t)ns * (ti + WG_NARROW_WMAX + 1) + 1) & ~(size_t)1) * 4);     // tile-local prefixes, packed in one dword
+    const int rowsM = ks ? wg_lookup_rows(P->pseudo_count, 255.0 * WG_MEDIUM_WMAX) : 0;
+    if (rowsA > WG_KY_KMIN + 1 || rowsB > WG_KY_KMIN + 1 || rowsM > WG_KY_KMIN + 1) { set_err(err, errlen, "internal: %d / %d / %d lookup rows", rowsA, rowsB, rowsM); return WGBSSEG_E_ARG; }
+    // tile class: 0 narrow (ti starts), 1 wide, 2 medium
+    auto lds_for = [&](int ti, int cls, int ns) -> size_t {
+        const int wm = cls == 2 ? WG_MEDIUM_WMAX : WG_NARROW_WMAX;
+        const size_t rows = cls == 1 ? (size_t)ns * (WG_WIDE_TK + 1 + WG_WIDE_TS + 1) * 8                  // P of the ends + P of the starts, (meth, cov) as two dwords
+                                     : ((((size_t)ns * (ti + wm + 1) + 1) & ~(size_t)1) * 4);             // tile-local prefixes, packed in one dword
         // guard-free kernels: just the two lookup tables, sized to the pseudo count and the tile class; otherwise the general fast tables
-        const size_t tabs = (split ? ksB : ks) ? (size_t)(split ? rowsB : rowsA) * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
+        const size_t tabs = (cls == 1 ? ksB : ks) ? (size_t)(cls == 1 ? rowsB : cls == 2 ? rowsM : rowsA) * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
         return tabs + rows + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 32 +
-               (split ? 0 : (size_t)ti * WG_NARROW_WMAX / 8 + 8);      // (+ the coarse block -> start map; an entry per 16 blocks for the 128-start tiles would let a seventh workgroup onto the CU at 8 samples: measured, no gain)      // (+ the block -> start map: a byte per block / per eight blocks)
+               (cls == 1 ? 0 : (size_t)ti * wm / 8 + 8);      // (+ the coarse block -> start map: a byte per eight blocks)
     };
-    int TI = 64, NSA = 1, NSB = 1;
+    int TI = 64, NSA = 1, NSB = 1, NSM = 1;
     static const int ti128_max_n = getenv("WGBSSEG_TI128_MAX_N") ? atoi(getenv("WGBSSEG_TI128_MAX_N")) : 16;
     {
         double best = -1;
@@ -736,7 +746,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
                 // and not by default above WGBSSEG_TI128_MAX_N samples, where their larger rows cost a workgroup per CU
                 if (ti == 128 && (ns != Nsmp || (c->force_ti != 128 && Nsmp > ti128_max_n))) continue;
                 if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
-                const size_t l = lds_for(ti, false, ns);
+                const size_t l = lds_for(ti, 0, ns);
                 if (l > 64 * 1024) continue;
                 const int wgs = (int)std::min<size_t>(ti == 128 ? 8 : 5, (160 * 1024) / (size_t)round_up((int64_t)l, 1280));   // registers allow 5 workgroups per CU; LDS is handed out in granules of 1280 bytes
                 const double q = ti * std::min<double>(Favg, WA), eff = q / (256.0 * std::ceil(q / 256.0));
@@ -751,12 +761,24 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         for (int ns : ns_opts) {
             if (ns > Nsmp) continue;
             if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
-            const size_t l = lds_for(WG_WIDE_TS, true, ns);
+            const size_t l = lds_for(WG_WIDE_TS, 1, ns);
             if (l > 64 * 1024) continue;
             const int wgs = (int)std::min<size_t>(4, (160 * 1024) / (size_t)round_up((int64_t)l, 1280));      // 103 VGPRs: 4 workgroups per CU at most
             const double groups = std::ceil((double)Nsmp / ns);
             const double score = wgs / (1.0 + 0.02 * (groups - 1));
             if (score > best) { best = score; NSB = ns; }
+        }
+        best = -1;
+        static const int force_nsm = getenv("WGBSSEG_NSM") ? atoi(getenv("WGBSSEG_NSM")) : 0;
+        for (int ns : ns_opts) {                                   // medium tiles: rows of 269 dwords per sample
+            if (ns > Nsmp) continue;
+            if (force_nsm > 0 && ns != std::min(force_nsm, Nsmp)) continue;
+            const size_t l = lds_for(WG_MEDIUM_TS, 2, ns);
+            if (l > 64 * 1024) continue;
+            const int wgs = (int)std::min<size_t>(5, (160 * 1024) / (size_t)round_up((int64_t)l, 1280));
+            const double groups = std::ceil((double)Nsmp / ns);
+            const double score = wgs / (1.0 + 0.02 * (groups - 1));
+            if (score > best) { best = score; NSM = ns; }
         }
     }
     CostArgs caA, caB;
@@ -767,24 +789,28 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     static const int use_cmap = !(getenv("WGBSSEG_NO_CMAP") && atoi(getenv("WGBSSEG_NO_CMAP")));
     caA.cmap = use_cmap ? 3 : 0;
     caB = caA;
+    CostArgs caM = caA;
     caA.NS = NSA; caA.rows = rowsA;
     caB.NS = NSB; caB.rows = rowsB;
-    if (ks) {   // the k-scaled tables of both tile classes, built here once per call (same IEEE operations as on the device)
+    caM.NS = NSM; caM.rows = rowsM;
+    if (ks) {   // the k-scaled tables of the tile classes, built here once per call (same IEEE operations as on the device)
         static const wg_log_tables host_tabs = WG_LOG_TABLES_INIT;
-        c->h_lookup.resize((size_t)(rowsA + rowsB) * 80);
-        wg_d2* ta = c->h_lookup.data();
-        wg_d2* tb2 = ta + (size_t)rowsA * 80;
-        for (int x = 0; x < rowsA * 16; x++) ta[x] = wg_ks_iy_entry(&host_tabs, rowsA, x);
-        for (int x = 0; x < rowsA * 64; x++) ta[rowsA * 16 + x] = wg_ks_ky_entry(&host_tabs, rowsA, x);
-        for (int x = 0; x < rowsB * 16; x++) tb2[x] = wg_ks_iy_entry(&host_tabs, rowsB, x);
-        for (int x = 0; x < rowsB * 64; x++) tb2[rowsB * 16 + x] = wg_ks_ky_entry(&host_tabs, rowsB, x);
+        c->h_lookup.resize((size_t)(rowsA + rowsB + rowsM) * 80);
+        wg_d2* dst = c->h_lookup.data();
+        for (int rows : {rowsA, rowsB, rowsM}) {
+            for (int x = 0; x < rows * 16; x++) dst[x] = wg_ks_iy_entry(&host_tabs, rows, x);
+            for (int x = 0; x < rows * 64; x++) dst[rows * 16 + x] = wg_ks_ky_entry(&host_tabs, rows, x);
+            dst += (size_t)rows * 80;
+        }
         HIP_TRY(c->lookup.ensure(c->h_lookup.size() * sizeof(wg_d2)));
         HIP_TRY(hipMemcpyAsync(c->lookup.p, c->h_lookup.data(), c->h_lookup.size() * sizeof(wg_d2), hipMemcpyHostToDevice, c->sA));   // h_lookup lives in the context
         caA.tab = c->lookup.as<wg_d2>();
         caB.tab = caA.tab + (size_t)rowsA * 80;
+        caM.tab = caB.tab + (size_t)rowsB * 80;
     }
-    const size_t ldsA = (size_t)round_up((int64_t)lds_for(TI, false, NSA), 16);
-    const size_t ldsB = (size_t)round_up((int64_t)lds_for(WG_WIDE_TS, true, NSB), 16);
+    const size_t ldsA = (size_t)round_up((int64_t)lds_for(TI, 0, NSA), 16);
+    const size_t ldsB = (size_t)round_up((int64_t)lds_for(WG_WIDE_TS, 1, NSB), 16);
+    const size_t ldsM = (size_t)round_up((int64_t)lds_for(WG_MEDIUM_TS, 2, NSM), 16);
     const int term_mode = term_modeA;
 
     // ---- stages: bound the scored-block buffer and overlap scoring (stream A) with the recurrence (stream B) --
@@ -833,36 +859,58 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipMemcpyAsync(c->plan_sb.p, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, c->sA));
     HIP_TRY(c->plan_cbase.ensure((size_t)n_stages * nC * 8));
     HIP_TRY(c->plan_cum0.ensure((size_t)n_stages * nC * 4));
-    HIP_TRY(c->plan_tbase.ensure((size_t)n_stages * (nC + 1) * 8 * 2));
-    HIP_TRY(c->plan_cnt.ensure((size_t)n_stages * nC * 4 * 2));
+    HIP_TRY(c->plan_tbase.ensure((size_t)n_stages * (nC + 1) * 8 * 3));
+    HIP_TRY(c->plan_cnt.ensure((size_t)n_stages * nC * 4 * 3));
     HIP_TRY(c->plan_pairs.ensure((size_t)n_stages * 8));
-    HIP_TRY(c->plan_tiles.ensure((size_t)n_stages * 8 * 2));
-    PlanArgs pa = {c->plan_sb.as<int32_t>(), TI, WA, TKB, n_stages};
+    HIP_TRY(c->plan_tiles.ensure((size_t)n_stages * 8 * 3));
+    PlanArgs pa = {c->plan_sb.as<int32_t>(), TI, WA, TKB, n_stages, WMED};
     uint32_t* cntA = c->plan_cnt.as<uint32_t>();
     uint32_t* cntB = cntA + (size_t)n_stages * nC;
+    uint32_t* cntM = cntB + (size_t)n_stages * nC;
     int64_t* tbaseA = c->plan_tbase.as<int64_t>();
     int64_t* tbaseB = tbaseA + (size_t)n_stages * (nC + 1);
-    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)nC, (unsigned)n_stages), dim3(WG_BLOCK), 0, c->sA, v, pa, cntA, cntB);
+    int64_t* tbaseM = tbaseB + (size_t)n_stages * (nC + 1);
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)nC, (unsigned)n_stages), dim3(WG_BLOCK), 0, c->sA, v, pa, cntA, cntB, cntM);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_stage_plan, dim3((unsigned)n_stages), dim3(WG_BLOCK), 0, c->sA, v, pa, cntA, cntB, c->plan_cbase.as<int64_t>(),
-                       c->plan_cum0.as<uint32_t>(), tbaseA, tbaseB, c->plan_pairs.as<int64_t>(), c->plan_tiles.as<int64_t>());
+    hipLaunchKernelGGL(k_stage_plan, dim3((unsigned)n_stages), dim3(WG_BLOCK), 0, c->sA, v, pa, cntA, cntB, cntM, c->plan_cbase.as<int64_t>(),
+                       c->plan_cum0.as<uint32_t>(), tbaseA, tbaseB, tbaseM, c->plan_pairs.as<int64_t>(), c->plan_tiles.as<int64_t>());
     HIP_TRY(hipGetLastError());
-    std::vector<int64_t> stage_pairs((size_t)n_stages), stage_tiles((size_t)n_stages * 2);
-    HIP_TRY(hipMemcpyAsync(stage_pairs.data(), c->plan_pairs.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
-    HIP_TRY(hipMemcpyAsync(stage_tiles.data(), c->plan_tiles.p, (size_t)n_stages * 16, hipMemcpyDeviceToHost, c->sA));
-    HIP_TRY(hipStreamSynchronize(c->sA));
-    if (!own_stream && hst[2].first_bad != ~0ULL) return report_bad_site(c, hst[2], err, errlen);     // (scan on this stream: its verdict is here already)
-    std::vector<int64_t> tileA0((size_t)n_stages + 1, 0), tileB0((size_t)n_stages + 1, 0);
-    for (int stg = 0; stg < n_stages; stg++) {
-        tileA0[(size_t)stg + 1] = tileA0[(size_t)stg] + stage_tiles[2 * (size_t)stg];
-        tileB0[(size_t)stg + 1] = tileB0[(size_t)stg] + stage_tiles[2 * (size_t)stg + 1];
+    // medium tiles and a pseudo count whose short division has not been tried on THEIR operand pairs yet (0 <= nmeth <= ntotal <=
+    // 255 * 252: 2.1e9 pairs, ~2 ms, once per context and pseudo count, and only for a job that has windows > 60 at all)
+    const bool check_div_m = c->divs_enabled && term_modeA == 2 && WMED > 0 && Wmax > WG_NARROW_WMAX && c->divs_m_pc != P->pseudo_count;
+    if (check_div_m) {
+        HIP_TRY(c->divcheck.ensure(4));
+        HIP_TRY(hipMemsetAsync(c->divcheck.p, 0, 4, c->sA));
+        const int max_total = 255 * WG_MEDIUM_WMAX;
+        hipLaunchKernelGGL(k_check_div, dim3((unsigned)max_total + 1), dim3(WG_BLOCK), 0, c->sA, P->pseudo_count, P->pseudo_count + P->pseudo_count,
+                           max_total, c->divcheck.as<unsigned int>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(reinterpret_cast<JobStatus*>(c->h_status.p) + 3, c->divcheck.p, 4, hipMemcpyDeviceToHost, c->sA));
     }
-    if (tileA0[(size_t)n_stages] > 0x7fffffffLL || tileB0[(size_t)n_stages] > 0x7fffffffLL) { set_err(err, errlen, "too many scoring tiles in one call"); return WGBSSEG_E_ARG; }
+    std::vector<int64_t> stage_pairs((size_t)n_stages), stage_tiles((size_t)n_stages * 3);
+    HIP_TRY(hipMemcpyAsync(stage_pairs.data(), c->plan_pairs.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipMemcpyAsync(stage_tiles.data(), c->plan_tiles.p, (size_t)n_stages * 24, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    if (check_div_m) {
+        c->divs_m_ok = *reinterpret_cast<const unsigned int*>(&hst[3]) == 0u;
+        c->divs_m_pc = P->pseudo_count;
+        if (profiling()) fprintf(stderr, "[wgbsseg] short division core for pseudo count %g on the operand pairs of a MEDIUM tile: %s\n", (double)P->pseudo_count, c->divs_m_ok ? "verified on every pair" : "NOT exact, the full core stays");
+    }
+    if (!own_stream && hst[2].first_bad != ~0ULL) return report_bad_site(c, hst[2], err, errlen);     // (scan on this stream: its verdict is here already)
+    std::vector<int64_t> tileA0((size_t)n_stages + 1, 0), tileB0((size_t)n_stages + 1, 0), tileM0((size_t)n_stages + 1, 0);
+    for (int stg = 0; stg < n_stages; stg++) {
+        tileA0[(size_t)stg + 1] = tileA0[(size_t)stg] + stage_tiles[3 * (size_t)stg];
+        tileB0[(size_t)stg + 1] = tileB0[(size_t)stg] + stage_tiles[3 * (size_t)stg + 1];
+        tileM0[(size_t)stg + 1] = tileM0[(size_t)stg] + stage_tiles[3 * (size_t)stg + 2];
+    }
+    if (tileA0[(size_t)n_stages] > 0x7fffffffLL || tileB0[(size_t)n_stages] > 0x7fffffffLL || tileM0[(size_t)n_stages] > 0x7fffffffLL) { set_err(err, errlen, "too many scoring tiles in one call"); return WGBSSEG_E_ARG; }
     HIP_TRY(c->tilesA.ensure((size_t)std::max<int64_t>(1, tileA0[(size_t)n_stages]) * sizeof(TileDesc)));
     HIP_TRY(c->tilesB.ensure((size_t)std::max<int64_t>(1, tileB0[(size_t)n_stages]) * sizeof(TileDesc)));
+    HIP_TRY(c->tilesM.ensure((size_t)std::max<int64_t>(1, tileM0[(size_t)n_stages]) * sizeof(TileDesc)));
     for (int stg = 0; stg < n_stages; stg++) {
-        hipLaunchKernelGGL(k_tile_emit, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, pa, stg, tbaseA, tbaseB,
-                           c->tilesA.as<TileDesc>() + tileA0[(size_t)stg], c->tilesB.as<TileDesc>() + tileB0[(size_t)stg]);
+        hipLaunchKernelGGL(k_tile_emit, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, pa, stg, tbaseA, tbaseB, tbaseM,
+                           c->tilesA.as<TileDesc>() + tileA0[(size_t)stg], c->tilesB.as<TileDesc>() + tileB0[(size_t)stg],
+                           c->tilesM.as<TileDesc>() + tileM0[(size_t)stg]);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[3], c->sA));
@@ -895,20 +943,32 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         double* cbuf = c->cost[stg % nbuf].as<double>();
         if (stg >= nbuf) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev_dp1[stg - nbuf], 0));   // buffer free again
         HIP_TRY(hipEventRecord(c->ev_cost0[stg], c->sA));
-        if (stage_tiles[2 * (size_t)stg] > 0) {
+        if (stage_tiles[3 * (size_t)stg] > 0) {
             const TileDesc* td = c->tilesA.as<TileDesc>() + tileA0[(size_t)stg];
+            const int64_t nt = stage_tiles[3 * (size_t)stg];
             const bool divs = c->divs_enabled && c->divs_ok && c->divs_pc == P->pseudo_count;
-            hipError_t e = term_mode == 2 ? (divs ? launch_cost_ti<3>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
-                                                  : launch_cost_ti<2>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA))
-                         : (term_mode == 1 ? launch_cost_ti<1>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA)
-                                           : launch_cost_ti<0>(TI, false, v, sv, caA, td, stage_tiles[2 * (size_t)stg], cbuf, ldsA, c->sA));
+            hipError_t e = term_mode == 2 ? (divs ? launch_cost_ti<3>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, c->sA)
+                                                  : launch_cost_ti<2>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, c->sA))
+                         : (term_mode == 1 ? launch_cost_ti<1>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, c->sA)
+                                           : launch_cost_ti<0>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, c->sA));
             HIP_TRY(e);
         }
-        if (stage_tiles[2 * (size_t)stg + 1] > 0) {
+        if (stage_tiles[3 * (size_t)stg + 2] > 0) {                  // medium tiles: the narrow tiles' arithmetic on rows of 269 entries
+            const TileDesc* td = c->tilesM.as<TileDesc>() + tileM0[(size_t)stg];
+            const int64_t nt = stage_tiles[3 * (size_t)stg + 2];
+            const bool divs = c->divs_enabled && c->divs_m_ok && c->divs_m_pc == P->pseudo_count;
+            hipError_t e = term_mode == 2 ? (divs ? launch_cost_ti<3>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, c->sA)
+                                                  : launch_cost_ti<2>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, c->sA))
+                         : (term_mode == 1 ? launch_cost_ti<1>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, c->sA)
+                                           : launch_cost_ti<0>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, c->sA));
+            HIP_TRY(e);
+        }
+        if (stage_tiles[3 * (size_t)stg + 1] > 0) {
             const TileDesc* td = c->tilesB.as<TileDesc>() + tileB0[(size_t)stg];
-            hipError_t e = term_modeB == 2 ? launch_cost_ti<2>(TI, true, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
-                         : (term_modeB == 1 ? launch_cost_ti<1>(TI, true, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA)
-                                           : launch_cost_ti<0>(TI, true, v, sv, caB, td, stage_tiles[2 * (size_t)stg + 1], cbuf, ldsB, c->sA));
+            const int64_t nt = stage_tiles[3 * (size_t)stg + 1];
+            hipError_t e = term_modeB == 2 ? launch_cost_ti<2>(TI, true, v, sv, caB, td, nt, cbuf, ldsB, c->sA)
+                         : (term_modeB == 1 ? launch_cost_ti<1>(TI, true, v, sv, caB, td, nt, cbuf, ldsB, c->sA)
+                                           : launch_cost_ti<0>(TI, true, v, sv, caB, td, nt, cbuf, ldsB, c->sA));
             HIP_TRY(e);
         }
         HIP_TRY(hipEventRecord(c->ev_cost1[stg], c->sA));
@@ -1449,14 +1509,24 @@ int wgbsseg_group_load_host_async(wgbsseg_group* g, const uint8_t* const* sample
     const int G = (int)g->shares.size();
     g->loaders.clear();
     g->loaders.resize((size_t)G);
-    // the device rows exist (and the contexts point at them) before any byte moves; the uploaders then fill them front to back
+    // the device rows exist (and the contexts point at them) before any byte moves; the uploaders then fill them front to back.
+    // A failure here leaves no share half-way: nothing counts as loaded, no loader runs, the group is not streaming.
+    auto fail = [&](hipError_t e, const char* what) {
+        for (int q = 0; q < G; q++) { g->loaded[(size_t)q] = 0; g->shares[(size_t)q]->last_valid = false; }
+        g->loaders.clear();
+        g->streaming = false;
+        set_err(err, errlen, "group_load_host_async: %s: %s", what, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? WGBSSEG_E_NOMEM : WGBSSEG_E_HIP;
+    };
     for (int d = 0; d < G; d++) {
         const int64_t lo = g->win_lo[(size_t)d], hi = g->win_hi[(size_t)d];
         if (hi <= lo) continue;
         wgbsseg_ctx* c = g->shares[(size_t)d];
-        HIP_TRY(hipSetDevice(c->device));
+        hipError_t e = hipSetDevice(c->device);
+        if (e != hipSuccess) return fail(e, "hipSetDevice");
         const int64_t n = hi - lo, pitch = round_up(2 * n, 256) + 256;
-        HIP_TRY(c->betas_own.ensure((size_t)pitch * (size_t)n_samples));
+        e = c->betas_own.ensure((size_t)pitch * (size_t)n_samples);
+        if (e != hipSuccess) return fail(e, "device rows of a share");
         c->betas = c->betas_own.as<uint8_t>();
         c->pitch = pitch; c->n_total = n; c->n_samples = (int32_t)n_samples; c->elem = 1;
         c->last_valid = false;
@@ -2010,6 +2080,8 @@ struct wgbsseg_patbeta {
 
 extern "C" {
 
+void wgbsseg_patbeta_destroy(wgbsseg_patbeta* p);
+
 int wgbsseg_patbeta_create(int device, int64_t start_cpg, int64_t end_cpg, wgbsseg_patbeta** out, char* err, size_t errlen)
 {
     if (!out) { set_err(err, errlen, "out is NULL"); return WGBSSEG_E_ARG; }
@@ -2019,7 +2091,10 @@ int wgbsseg_patbeta_create(int device, int64_t start_cpg, int64_t end_cpg, wgbss
     int rc = wgbsseg_create(device, &probe, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
     wgbsseg_destroy(probe);
-    std::unique_ptr<wgbsseg_patbeta> p(new (std::nothrow) wgbsseg_patbeta());
+    // (the struct's members are plain handles: whatever has been created when a HIP call fails is released by the destroy
+    // function, which is what the owner calls on every early return)
+    struct Free { void operator()(wgbsseg_patbeta* q) const { wgbsseg_patbeta_destroy(q); } };
+    std::unique_ptr<wgbsseg_patbeta, Free> p(new (std::nothrow) wgbsseg_patbeta());
     if (!p) { set_err(err, errlen, "out of host memory"); return WGBSSEG_E_NOMEM; }
     p->device = device; p->start = start_cpg; p->end = end_cpg;
     HIP_TRY(hipSetDevice(device));

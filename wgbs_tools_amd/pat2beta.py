@@ -76,8 +76,25 @@ def bgzf_pieces(path, read_bytes=8 << 20, threads=None):
                     blocks.append(buf[pos:pos + size])
                     pos += size
                 if not blocks:
+                    if len(buf) >= 18 and buf[0] == 0x1f and buf[1] == 0x8b and _bgzf_block_size(buf, 0) is None:
+                        # a member that is gzip but not BGZF (`cat a.pat.gz b.pat.gz` of different writers): the reference's
+                        # `gunzip -cd` reads such a file, so hand the rest to zlib's multi-member inflater, in bounded pieces
+                        import zlib
+                        d = zlib.decompressobj(wbits=31)
+                        while buf:
+                            out = d.decompress(buf)
+                            while d.eof:                          # next member
+                                rest = d.unused_data
+                                d = zlib.decompressobj(wbits=31)
+                                if not rest:
+                                    break
+                                out += d.decompress(rest)
+                            if out:
+                                yield out
+                            buf = f.read(read_bytes)
+                        return True
                     more = f.read(read_bytes)
-                    if not more:
+                    if not more or len(buf) > (1 << 20):          # a BGZF block is at most 64 KB: more than that without one is not BGZF
                         raise IllegalArgumentError(f'Invalid gzip data in {path}: truncated or not BGZF after the first block')
                     buf = buf[pos:] + more
                     continue
