@@ -198,6 +198,12 @@ int wgbsseg_plan_shares(const uint32_t* loci, int64_t n_sites, const int64_t* re
                         int64_t n_regions, int64_t chunk_size, const wgbsseg_params* params, int32_t n_shares, int64_t halo,
                         int64_t* own_lo, int64_t* own_hi, int64_t* win_lo, int64_t* win_hi, int64_t* share_chunks,
                         int64_t* share_work, char* err, size_t errlen);
+/* The same with unequal targets: share d takes weights[d] / sum(weights) of the work (NULL: equal shares).  The multi-process driver
+ * gives rank 0 — which also runs the stitching tree of every step — a smaller share than the other ranks. */
+int wgbsseg_plan_shares_weighted(const uint32_t* loci, int64_t n_sites, const int64_t* region_start, const int64_t* region_end,
+                                 int64_t n_regions, int64_t chunk_size, const wgbsseg_params* params, int32_t n_shares, const double* weights,
+                                 int64_t halo, int64_t* own_lo, int64_t* own_hi, int64_t* win_lo, int64_t* win_hi,
+                                 int64_t* share_chunks, int64_t* share_work, char* err, size_t errlen);
 int wgbsseg_group_create(const int32_t* devices, int32_t n_shares, wgbsseg_group** out, char* err, size_t errlen);
 void wgbsseg_group_destroy(wgbsseg_group* g);
 int32_t wgbsseg_group_size(const wgbsseg_group* g);

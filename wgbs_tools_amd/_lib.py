@@ -30,7 +30,7 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_patbeta_destroy', 'wgbsseg_group_load_host_async', 'wgbsseg_group_load_wait',
            'wgbsseg_marker_stats', 'wgbsseg_blocks_parse', 'wgbsseg_blocks_write_table', 'wgbsseg_blocks_write_bedgraph',
            'wgbsseg_format_fixed', 'wgbsseg_bed_parse', 'wgbsseg_bed_write_annotated', 'wgbsseg_debug_canonical_float',
-           'wgbsseg_first_batch_items']
+           'wgbsseg_first_batch_items', 'wgbsseg_plan_shares_weighted']
 
 
 class NativeLibraryError(RuntimeError):
@@ -162,6 +162,8 @@ def load():
     L.wgbsseg_first_batch_items.argtypes = [vp, vp, i64, i64, i32, vp, vp, i64, C.POINTER(i64), C.POINTER(i64), C.c_char_p, C.c_size_t]
     L.wgbsseg_plan_shares.restype = i32
     L.wgbsseg_plan_shares.argtypes = [vp, i64, vp, vp, i64, i64, C.POINTER(Params), i32, i64, vp, vp, vp, vp, vp, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_plan_shares_weighted.restype = i32
+    L.wgbsseg_plan_shares_weighted.argtypes = [vp, i64, vp, vp, i64, i64, C.POINTER(Params), i32, vp, i64, vp, vp, vp, vp, vp, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_group_create.restype = i32
     L.wgbsseg_group_create.argtypes = [vp, i32, C.POINTER(vp), C.c_char_p, C.c_size_t]
     L.wgbsseg_group_destroy.restype = None
@@ -581,9 +583,10 @@ def stitch_regions_csr(regions, chunk_size, batch_csr, speculate=True, copy=True
     return [out[off[r]:off[r + 1]].astype(np.int64) if copy else out[off[r]:off[r + 1]] for r in range(n)], _stats_dict(stats)
 
 
-def plan_shares(loci, regions, chunk_size, pcount, max_cpg, max_bp, n_shares, halo=-1):
-    """wgbsseg_plan_shares (host only): contiguous work-balanced runs of chunks.  -> dict of int64 arrays [n_shares]:
-    own_lo/own_hi (0-based sites [lo, hi) of the chunks of each share), win_lo/win_hi (+- halo), chunks, work."""
+def plan_shares(loci, regions, chunk_size, pcount, max_cpg, max_bp, n_shares, halo=-1, weights=None):
+    """wgbsseg_plan_shares[_weighted] (host only): contiguous work-balanced runs of chunks (weights: share d takes weights[d] /
+    sum(weights) of the work).  -> dict of int64 arrays [n_shares]: own_lo/own_hi (0-based sites [lo, hi) of the chunks of each
+    share), win_lo/win_hi (+- halo), chunks, work."""
     L = load()
     loci = np.ascontiguousarray(loci, dtype=np.uint32)
     rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
@@ -591,9 +594,12 @@ def plan_shares(loci, regions, chunk_size, pcount, max_cpg, max_bp, n_shares, ha
     out = {k: np.zeros(n_shares, dtype=np.int64) for k in ('own_lo', 'own_hi', 'win_lo', 'win_hi', 'chunks', 'work')}
     err = C.create_string_buffer(ERRLEN)
     p = Params(float(pcount), int(max_cpg), int(max_bp))
-    _check(L.wgbsseg_plan_shares(loci.ctypes.data, loci.size, rs.ctypes.data, re_.ctypes.data, rs.size, int(chunk_size), C.byref(p),
-                                 int(n_shares), int(halo), out['own_lo'].ctypes.data, out['own_hi'].ctypes.data, out['win_lo'].ctypes.data,
-                                 out['win_hi'].ctypes.data, out['chunks'].ctypes.data, out['work'].ctypes.data, err, ERRLEN), err)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    assert w is None or w.size == n_shares
+    _check(L.wgbsseg_plan_shares_weighted(loci.ctypes.data, loci.size, rs.ctypes.data, re_.ctypes.data, rs.size, int(chunk_size), C.byref(p),
+                                          int(n_shares), None if w is None else w.ctypes.data, int(halo), out['own_lo'].ctypes.data,
+                                          out['own_hi'].ctypes.data, out['win_lo'].ctypes.data, out['win_hi'].ctypes.data,
+                                          out['chunks'].ctypes.data, out['work'].ctypes.data, err, ERRLEN), err)
     return out
 
 

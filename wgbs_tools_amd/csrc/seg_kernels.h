@@ -1376,6 +1376,9 @@ __device__ __forceinline__ void wg_dp_group64_lean(double& best, int32_t& arg, u
 
 // state kept per chunk in global memory: [0] M[k] of the next step, [1..64] best, [65..128] arg, [129..192] bestB,
 // [193..256] argB (args as doubles' bits) — written only between stages — then the ring: ringN doubles, ringN int32
+// (Tried in round 3: the wavefront that shares the recurrence wavefront's SIMD — a workgroup's wavefronts go to the four SIMDs in
+// cyclic order, so wavefront 4 — leaving at once, six or five workers on the other three SIMDs: 1.63 -> 1.67 / 1.76 ms for the 483
+// chunks of hg19, 3.00 -> 3.05 / 3.04 for a 61-chunk share: the workers' issue slots on that SIMD are not what the step waits for.)
 template <int NW, int BL, bool LEAN = false>      // LEAN (BL == 64 only): every window of the job is <= WG_NARROW_WMAX sites
 __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, const double* __restrict__ cost, DpArgs A,
                                                       double* __restrict__ state, int64_t state_stride)

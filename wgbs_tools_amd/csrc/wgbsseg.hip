@@ -1386,6 +1386,14 @@ int wgbsseg_plan_shares(const uint32_t* loci, int64_t n_sites, const int64_t* re
                         int64_t chunk_size, const wgbsseg_params* P, int32_t n_shares, int64_t halo, int64_t* own_lo, int64_t* own_hi,
                         int64_t* win_lo, int64_t* win_hi, int64_t* share_chunks, int64_t* share_work, char* err, size_t errlen)
 {
+    return wgbsseg_plan_shares_weighted(loci, n_sites, region_start, region_end, n_regions, chunk_size, P, n_shares, nullptr, halo, own_lo, own_hi,
+                                        win_lo, win_hi, share_chunks, share_work, err, errlen);
+}
+
+int wgbsseg_plan_shares_weighted(const uint32_t* loci, int64_t n_sites, const int64_t* region_start, const int64_t* region_end, int64_t n_regions,
+                                 int64_t chunk_size, const wgbsseg_params* P, int32_t n_shares, const double* weights, int64_t halo, int64_t* own_lo,
+                                 int64_t* own_hi, int64_t* win_lo, int64_t* win_hi, int64_t* share_chunks, int64_t* share_work, char* err, size_t errlen)
+{
     if (!loci || n_sites < 1 || !region_start || !region_end || n_regions < 1 || chunk_size < 1 || !P || n_shares < 1 || !own_lo || !own_hi) {
         set_err(err, errlen, "bad arguments to plan_shares"); return WGBSSEG_E_ARG;
     }
@@ -1398,6 +1406,18 @@ int wgbsseg_plan_shares(const uint32_t* loci, int64_t n_sites, const int64_t* re
         if (a < 1 || b <= a || b - 1 > n_sites) { set_err(err, errlen, "region %lld = [%lld, %lld) is empty or outside the %lld sites", (long long)r, (long long)a, (long long)b, (long long)n_sites); return WGBSSEG_E_ARG; }
         if (r && a < region_end[r - 1]) { set_err(err, errlen, "plan_shares: regions must be ascending and disjoint"); return WGBSSEG_E_ARG; }
         for (int64_t s0 = a; s0 < b; s0 += chunk_size) cks.push_back({s0 - 1, std::min(s0 + chunk_size, b) - 1, 0});
+    }
+    // share d's target: weights[d] / sum(weights) of the work (NULL: equal shares)
+    std::vector<double> upto((size_t)G);
+    {
+        double sum = 0;
+        for (int d = 0; d < G; d++) {
+            const double w = weights ? weights[d] : 1.0;
+            if (!(w >= 0.0)) { set_err(err, errlen, "plan_shares: weights must be >= 0"); return WGBSSEG_E_ARG; }
+            sum += w; upto[(size_t)d] = sum;
+        }
+        if (!(sum > 0.0)) { set_err(err, errlen, "plan_shares: all weights are zero"); return WGBSSEG_E_ARG; }
+        for (auto& u : upto) u /= sum;
     }
     if (G == 1) {
         for (auto& c : cks) c.w = c.hi - c.lo;                  // nothing to balance: do not walk the loci
@@ -1416,7 +1436,7 @@ int wgbsseg_plan_shares(const uint32_t* loci, int64_t n_sites, const int64_t* re
         int d = 0;
         int64_t acc = 0;
         for (auto& c : cks) {
-            while (d < G - 1 && (double)acc >= (double)total * (d + 1) / G) d++;
+            while (d < G - 1 && (double)acc >= (double)total * (weights ? upto[(size_t)d] : (double)(d + 1) / G)) d++;
             if (!any[(size_t)d]) { own_lo[d] = c.lo; any[(size_t)d] = 1; }
             own_hi[d] = c.hi;
             nch[(size_t)d]++; wk[(size_t)d] += c.w;

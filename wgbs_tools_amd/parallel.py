@@ -34,6 +34,12 @@ def plan(regions, chunk, world, loci, params):
     return _lib.plan_shares(loci, regions, chunk, params['pcount'], params['max_cpg'], params['max_bp'], world)
 
 
+def plan_weighted(regions, chunk, world, loci, params, weights):
+    """wgbsseg_plan_shares_weighted: contiguous runs of chunks whose work is proportional to `weights` (equal weights: `plan`)."""
+    from . import _lib
+    return _lib.plan_shares(loci, regions, chunk, params['pcount'], params['max_cpg'], params['max_bp'], world, weights=list(weights))
+
+
 def chunks_of_rank(regions, chunk, world, rank, loci, params, shares=None):
     """The chunks (1-based half-open) rank `rank` of `world` segments: a contiguous run of the reference's chunk grid."""
     sh = shares or plan(regions, chunk, world, loci, params)
@@ -100,10 +106,14 @@ def item_owners(starts, n_chunks, shares):
 
 
 class NodeSlots:
-    """Hand-over of the ranks' border lists to rank 0.  On one node: every rank owns two slots (files under /dev/shm mapped by
-    rank 0 as well; steps alternate between them, so that a rank may fill the next step's slot while rank 0 still reads this
-    one's) and the only communication is the barrier that says "written".  Ranks on several hosts fall back to a gather of
-    Python objects.  Slot layout: int64 offsets [items + 1], then int32 borders [cap]."""
+    """Hand-over of the ranks' border lists to rank 0.  On one node: every rank owns two slots (files under /dev/shm that rank 0 maps
+    as well; steps alternate between them) and NO collective is needed per step: a rank stamps its slot with the step's number
+    when its lists are complete, rank 0 waits for the stamps, and stamps its own header with the number of steps it has consumed —
+    which is what a rank waits for before it reuses a slot (it may run one step ahead of rank 0's stitching, no further).
+    Ranks on several hosts fall back to a gather of Python objects.
+    Slot layout: int64 header [8] (0: step stamp; rank 0 only, 1: steps consumed), int64 offsets [items + 1], int32 borders [cap]."""
+    HDR = 64
+    TIMEOUT_S = 600.0
 
     def __init__(self, dist, rank, world, n_items, caps):
         import os
@@ -118,45 +128,80 @@ class NodeSlots:
         self.shared = len(set(hosts)) == 1 and os.path.isdir('/dev/shm') and not os.environ.get('WGBSSEG_NO_SHM')
         self.n_items, self.caps = [int(x) for x in n_items], [int(x) for x in caps]
         self.paths, self.maps, self.step_no = [], {}, 0
-        self._pickled = None
         if self.shared:
             def path(r, k):
                 return '/dev/shm/wgbsseg_%s_r%d_%d.bin' % (tag[0], r, k)
             for k in range(2):
                 pth = path(rank, k)
-                np.memmap(pth, dtype=np.uint8, mode='w+', shape=(self._bytes(rank),)).flush()
+                np.memmap(pth, dtype=np.uint8, mode='w+', shape=(self._bytes(rank),)).flush()      # zero-filled: stamp 0 = nothing yet
                 self.paths.append(pth)
             dist.barrier()
-            for r in (range(world) if rank == 0 else [rank]):
+            for r in range(world):
                 for k in range(2):
-                    self.maps[(r, k)] = np.memmap(path(r, k), dtype=np.uint8, mode='r+', shape=(self._bytes(r),))
+                    if rank == 0 or r == rank or (r == 0 and k == 0):                             # (everybody reads rank 0's header)
+                        self.maps[(r, k)] = np.memmap(path(r, k), dtype=np.uint8, mode='r+', shape=(self._bytes(r),))
+            dist.barrier()
 
     def _bytes(self, r):
-        return 8 * (self.n_items[r] + 1) + 4 * max(1, self.caps[r]) + 8
+        return self.HDR + 8 * (self.n_items[r] + 1) + 4 * max(1, self.caps[r]) + 8
+
+    def _hdr(self, r, k):
+        import numpy as np
+        return self.maps[(r, k)][:self.HDR].view(np.int64)
 
     def _views(self, r, k):
         import numpy as np
         m = self.maps[(r, k)]
         n = self.n_items[r]
-        return m[:8 * (n + 1)].view(np.int64), m[8 * (n + 1):8 * (n + 1) + 4 * max(1, self.caps[r])].view(np.int32)
+        o = self.HDR
+        return m[o:o + 8 * (n + 1)].view(np.int64), m[o + 8 * (n + 1):o + 8 * (n + 1) + 4 * max(1, self.caps[r])].view(np.int32)
+
+    def _wait(self, ready, what):
+        import time
+        t0 = time.monotonic()
+        spins = 0
+        while not ready():
+            spins += 1
+            if spins > 2000:
+                time.sleep(0.00002)
+                if time.monotonic() - t0 > self.TIMEOUT_S:
+                    raise RuntimeError('timed out waiting for %s (another rank has failed?)' % what)
 
     def mine(self):
-        """(off, borders) views of this rank's slot of the current step, to be filled in place (None, None without /dev/shm)."""
-        return self._views(self.rank, self.step_no & 1) if self.shared else (None, None)
+        """(off, borders) views of this rank's slot of the current step, to be filled in place (None, None without /dev/shm).
+        Waits until rank 0 has consumed what the slot held two steps ago."""
+        if not self.shared:
+            return None, None
+        if self.step_no >= 2 and self.rank != 0:
+            ack = self._hdr(0, 0)
+            self._wait(lambda: int(ack[1]) >= self.step_no - 1, 'rank 0 to consume step %d' % (self.step_no - 2))
+        return self._views(self.rank, self.step_no & 1)
 
     def publish(self, off, flat):
         """This rank's CSR of the current step is complete.  -> on rank 0: [(off, flat)] of every rank; else None."""
         k = self.step_no & 1
         self.step_no += 1
         if self.shared:
-            self.dist.barrier()
-            return [self._views(r, k) for r in range(self.world)] if self.rank == 0 else None
+            self._hdr(self.rank, k)[0] = self.step_no              # the stamp goes last (x86 keeps the stores in order)
+            if self.rank != 0:
+                return None
+            for r in range(1, self.world):
+                h = self._hdr(r, k)
+                self._wait(lambda: int(h[0]) >= self.step_no, 'rank %d to deliver step %d' % (r, self.step_no - 1))
+            return [self._views(r, k) for r in range(self.world)]
         out = [None] * self.world if self.rank == 0 else None
         self.dist.gather_object((off, flat), out, dst=0)
         return out
 
+    def consumed(self):
+        """rank 0: the lists of the step just published have been stitched; their slots may be reused."""
+        if self.shared and self.rank == 0:
+            self._hdr(0, 0)[1] = self.step_no
+
     def close(self):
         import os
+        if self.shared and self.rank == 0:
+            self._hdr(0, 0)[1] = 1 << 60                          # nobody waits for a rank 0 that has left
         self.maps = {}
         for pth in self.paths:
             try:
@@ -172,13 +217,18 @@ class ShardedRun:
     them and runs the one tree (wgbsseg_stitch_regions) over all chunks; only the few patches the rehearsal still misses are
     computed afterwards, by rank 0's `patch_csr`.  No collective on the data path; the borders do not depend on `world`."""
 
-    def __init__(self, dist, regions, chunk_size, loci, params, rank, world, speculate=True):
+    def __init__(self, dist, regions, chunk_size, loci, params, rank, world, speculate=True, rank0_weight=None):
+        import os
         import numpy as np
         from . import _lib
         self.dist, self.rank, self.world = dist, rank, world
         self.regions, self.chunk_size, self.speculate = list(regions), int(chunk_size), speculate
         self.starts, self.ends, self.n_chunks = _lib.first_batch_items(self.regions, chunk_size, speculate)
-        self.shares = plan(self.regions, chunk_size, world, loci, params)
+        # rank 0 also runs the tree (and the follow-up patches) of every step while the other ranks are already computing the
+        # next one: it takes a smaller share of the chunks (WGBSSEG_RANK0_WEIGHT; 1 = equal shares)
+        if rank0_weight is None:
+            rank0_weight = float(os.environ.get('WGBSSEG_RANK0_WEIGHT', '0.75' if world >= 4 else '0.9' if world > 1 else '1'))
+        self.shares = plan_weighted(self.regions, chunk_size, world, loci, params, [rank0_weight] + [1.0] * (world - 1))
         self.owner = item_owners(self.starts, self.n_chunks, self.shares)
         self.idx = [np.flatnonzero(self.owner == r) for r in range(world)]
         lens = self.ends - self.starts
@@ -227,6 +277,7 @@ class ShardedRun:
             o = np.asarray(o[:st.size + 1])
             return np.uint64(f.ctypes.data) + (4 * o[:-1]).astype(np.uint64), np.diff(o)
         merged, self.last_stats = _lib.stitch_regions_csr(self.regions, self.chunk_size, batch, speculate=self.speculate, copy=copy)
+        self.slots.consumed()
         return merged
 
     def close(self):
