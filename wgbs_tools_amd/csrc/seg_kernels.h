@@ -999,6 +999,11 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 //   Timeline, batch b = steps [base, base+32): sources of batch b are pushed during batch b+1 (targets >= base+128),
 //   the ring entries of batch b+2 are fetched (and reset) during batch b+1 — always disjoint from the pushes.
 // ------------------------------------------------------------------------------------------------------------
+#ifdef WGBSSEG_DP_TIMING
+#define WG_DP_T(...) __VA_ARGS__
+#else
+#define WG_DP_T(...)
+#endif
 struct DpArgs { int32_t ringN; int32_t pad[3]; };      // ringN: pending-step ring (pow2 >= max window + 128), 0 if BL == 64
 
 #define WG_DP_STATE_HDR 257   // doubles of per-chunk state ahead of the ring: M[k], bestA[64], argA[64], bestB[64], argB[64]
@@ -1396,6 +1401,9 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     const int lane = threadIdx.x & 63;
     // (Tried: rotating which wavefront of the workgroup runs the recurrence by dispatch round, so that two workgroups sharing
     // a CU do not both put theirs on wavefront 0's SIMD — 1.75 -> 2.35 ms for 483 chunks: worse; wavefront 0 it stays.)
+    // (Round 3, measured: the wavefront index in a SCALAR register (readfirstlane) turns a worker's row indices into scalar arithmetic and
+    // removes a v_readfirstlane + four wait states per row — and the recurrence gets SLOWER: 1.62 -> 1.71 ms for hg19, 4.29 -> 5.04 ms
+    // with CpG islands (profiles/r03_dp_experiments.txt).  The workers' idle slots are slots the recurrence wavefront gets.)
     const int wvl = (int)(threadIdx.x >> 6);          // 0 = recurrence
     const bool worker = wvl != 0;
     const int lw = wvl - 1;                           // worker index (0..NW-1)
@@ -1469,6 +1477,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     // — by then the updating wave has waited for loads it issued after that store (the row loads that end every batch), and vector
     // memory operations of a wave complete in order.  Waiting for store latency there, every 32 steps, would cost more than the steps.
 #define WG_DP_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    WG_DP_T(uint64_t dbg_wait = 0; uint64_t dbg_vm = 0; uint64_t dbg_commit = 0; uint64_t dbg_issue = 0; const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime();)
     if (worker) {
       for (int b = 0; b < nb; b++) {
         const int base = s0 + b * BL;
@@ -1498,21 +1507,27 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
             // eight: one workgroup per CU, 1.75 -> 2.9-3.0 ms); after the split it fits (84-114 VGPRs) and, with every load out of its
             // branch so that the waits leave the younger set in flight, measures 1.79 against 1.61 ms: the rows are not what the
             // recurrence waits for.)
+            WG_DP_T(const uint64_t tc0 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_vm += __builtin_amdgcn_s_memtime() - tc0;)
             if (b + 1 < nb)
                 wg_dp_rows_commit<NW, BL>(rows, slots + (size_t)((b + 1) & 1) * SLOT, slots + (size_t)((b + 1) & 1) * SLOT + BL * 64,
                                           kinds + ((b + 1) & 1), lane, lw);
+            WG_DP_T(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_commit += __builtin_amdgcn_s_memtime() - tc0;)
             if (fetch) {
                 pendLB[((b + 1) & 1) * 32 + lane] = fv;
                 pendLA[((b + 1) & 1) * 32 + lane] = fa;
             }
             uint32_t fm_n2 = 0;
+            WG_DP_T(const uint64_t ti0 = __builtin_amdgcn_s_memtime();)
             if (b + 2 < nb) {
                 wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, (b + 2) * BL, lane), base + 2 * BL, lane, lw);
                 fm_n2 = rows.fmax;
             }
+            WG_DP_T(dbg_issue += __builtin_amdgcn_s_memtime() - ti0;)
             fm_prev = fm_cur; fm_cur = fm_n1; fm_n1 = fm_n2;
         }
+        WG_DP_T(const uint64_t tb0 = __builtin_amdgcn_s_memtime();)
         WG_DP_BARRIER;
+        WG_DP_T(dbg_wait += __builtin_amdgcn_s_memtime() - tb0;)
       }
     } else {
       for (int b = 0; b < nb; b++) {
@@ -1574,10 +1589,19 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
             }
             if (fin && base + d < s1) J.back16[cd.site_off + base + d] = (uint16_t)tbk;
         }
+        WG_DP_T(const uint64_t tb0 = __builtin_amdgcn_s_memtime();)
         WG_DP_BARRIER;
+        WG_DP_T(dbg_wait += __builtin_amdgcn_s_memtime() - tb0;)
       }
     }
 #undef WG_DP_BARRIER
+    // timing diagnostics (-DWGBSSEG_DP_TIMING builds only; tools/dp_timing.py): [wavefront 0 | worker 0] x [loop cycles, of which at the
+    // barrier], then worker 0's wait for its rows, its arranging and its load-issue phase — left in the chunk's state slots
+    WG_DP_T(if (s1 >= cd.len && lane == 0 && wvl <= 1) {
+        gs[2 * wvl] = (double)(__builtin_amdgcn_s_memtime() - dbg_t0);
+        gs[2 * wvl + 1] = (double)dbg_wait;
+        if (wvl == 1) { gs[4] = (double)dbg_vm; gs[5] = (double)dbg_commit; gs[6] = (double)dbg_issue; }
+    })
     if (WIDEJOB && worker && fm_prev > 128u)
         wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, s0 + (nb - 1) * BL, s1, Mring, pendB, pendA, rmask, lane, lw);
     if (!worker && s1 < cd.len) {

@@ -150,6 +150,7 @@ struct wgbsseg_ctx {
     // the short division core of the narrow scoring tiles: verified on the device per pseudo count (k_check_div)
     float divs_pc = -1.0f;     // pseudo count the verdict below is for
     bool divs_ok = false;
+    int64_t last_dp_chunks = 0, last_dp_stride = 0;
     float divs_m_pc = -1.0f;   // the same for the operand pairs of a medium tile (ntotal <= 255 * WG_MEDIUM_WMAX)
     bool divs_m_ok = false;
     bool divs_enabled = true;  // WGBSSEG_DIV_SHORT=0: always the 8-instruction core
@@ -936,6 +937,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     sv.sb = c->plan_sb.as<int32_t>();
     // LDS of k_dp: two arranged batches (64 steps x 64 lanes, or 32 steps x 64 lanes x {A, B}) + M ring + fetched ring entries + flags + ring of windows / row offsets
     DpArgs da = {ringN, {0, 0, 0}};
+    c->last_dp_chunks = nC; c->last_dp_stride = state_stride;
     const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16 + 1024 * 6;
     if (own_stream && (!beside || st.wide_units)) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));      // scoring after the scan (always when it reads carries)
     for (int stg = 0; stg < n_stages; stg++) {
@@ -2205,6 +2207,7 @@ int64_t wgbsseg_debug_fetch(wgbsseg_ctx* c, const char* what, void* out, int64_t
     if (!strcmp(what, "window")) { src = c->W16.p; bytes = c->last_sites * 2; }
     else if (!strcmp(what, "cum")) { src = c->cum32.p; bytes = c->last_sites * 4; }
     else if (!strcmp(what, "back")) { src = c->back16.p; bytes = c->last_sites * 2; }
+    else if (!strcmp(what, "dpstate")) { src = c->dpstate.p; bytes = c->last_dp_chunks * c->last_dp_stride * 8; }
     else if (!strcmp(what, "cost")) { if (c->last_stages != 1) return WGBSSEG_E_STATE; src = c->cost[0].p; bytes = c->last_pairs * 8; }
     else return WGBSSEG_E_ARG;
     if (bytes > cap_bytes) return WGBSSEG_E_CAPACITY;
