@@ -710,3 +710,41 @@ def test_16_medium_tiles_match_oracle_and_wide_tiles(monkeypatch, n_samples, cov
                 for c, (a, b) in enumerate(zip(got, want)):
                     assert a.tolist() == b.tolist(), 'pcount %r max_cpg %d medium<=%s chunk [%d,+%d): %s' % (pcount, max_cpg, wm, starts[c], lens[c], _first_diff(a, b))
         monkeypatch.delenv('WGBSSEG_MEDIUM_WMAX')
+
+
+def test_17_lean_step_in_the_narrow_batches_of_a_wide_job(monkeypatch):
+    """Round 3: in a job with windows > 64 sites somewhere (32-step batches, a second pending register per lane, the ring), the batches
+    whose windows are all <= 60 run a hand-scheduled step in which a finished lane MOVES ON to its second register four steps late.
+    Worlds that alternate open sea (windows ~20), islands (windows 61 .. 250: the second register is live when narrow batches
+    follow) and very dense stretches (windows > 128: the ring), at chunk offsets that put the batch boundaries on both lane halves;
+    borders == oracle, and == the generic step (WGBSSEG_DP_WLEAN=0)."""
+    rng = np.random.default_rng(1717)
+    n = 20000
+    gap = np.full(n, 100)
+    for a in range(300, n - 700, 900):                       # an island every 900 sites, 80 .. 500 sites long, 4 .. 12 bp apart
+        ln = int(rng.integers(80, 500))
+        gap[a:a + ln] = rng.integers(4, 13)
+    gap[15000:15600] = 2                                     # and one stretch dense enough for windows of several hundred sites
+    loci = (np.cumsum(gap) + 1000).astype(np.uint32)
+    slices = []
+    for _ in range(3):
+        cov = rng.integers(0, 60, n)
+        lvl = np.repeat(rng.random(n // 40 + 1), 40)[:n]
+        meth = rng.binomial(cov, lvl)
+        slices.append(np.stack([meth, cov], axis=1).astype(np.uint8))
+    chunks = [(0, 9000), (37, 9003), (4096 + 32, 8000), (9000, 11000), (14000, 3000), (123, 700)]
+    starts, lens = [c[0] for c in chunks], [c[1] for c in chunks]
+    with _lib.Segmenter(0) as sg:
+        sg.set_betas(slices)
+        sg.set_loci(loci)
+        for pcount, max_cpg, max_bp in [(15.0, 1000, 2000), (15.0, 200, 2000), (1.0, 100, 1200), (0.5, 1000, 900), (15.0, 65, 2000)]:
+            want = oracle.segment_chunks(slices, loci, starts, lens, pcount, max_cpg, max_bp, threads=os.cpu_count() or 1)
+            assert max(int(w.size) for w in want) > 10
+            for wlean in ('1', '0'):
+                monkeypatch.setenv('WGBSSEG_DP_WLEAN', wlean)
+                got = sg.segment_chunks(starts, lens, pcount, max_cpg, max_bp)
+                if wlean == '1':
+                    assert sg.timings()['max_window'] > 64 or max_cpg <= 65, 'the case must be a wide job'
+                for c, (a, b) in enumerate(zip(got, want)):
+                    assert a.tolist() == b.tolist(), 'pcount %r max_cpg %d max_bp %d lean %s chunk [%d,+%d): %s' % (pcount, max_cpg, max_bp, wlean, starts[c], lens[c], _first_diff(a, b))
+        monkeypatch.delenv('WGBSSEG_DP_WLEAN')

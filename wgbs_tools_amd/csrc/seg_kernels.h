@@ -1105,7 +1105,7 @@ __device__ __forceinline__ void wg_dp_rows_commit(const DpRows<NW, BL>& R, doubl
                                                   uint32_t* __restrict__ kind, int lane, int lw)
 {
     constexpr bool WIDEJOB = BL < 64;
-    if (lw == 0 && lane == 0) *kind = R.wideb ? 1u : 0u;
+    if (lw == 0 && lane == 0) *kind = R.wideb ? 1u : (R.fmax > (uint32_t)WG_NARROW_WMAX ? 2u : 0u);      // 0: every window of the batch <= 60 sites, 2: <= 64, 1: wide (slot B in use)
 #pragma unroll
     for (int q = 0; q < DpRows<NW, BL>::PER; q++) {
         const int sidx = lw + q * NW;
@@ -1379,6 +1379,89 @@ __device__ __forceinline__ void wg_dp_group64_lean(double& best, int32_t& arg, u
     }
 }
 
+// Round 3: the same lean block for the NARROW batches (every window <= 60 sites) of a job that has wider windows elsewhere (CpG
+// islands: ~6 % of the 16-site units of an hg19-like genome) — 94 % of such a job's steps used to run the compiler-scheduled
+// 14-instruction step of wg_dp_step32.  What differs from the block above: `arg` holds the absolute source site (a pending maximum
+// may come from the second register or the ring: sources up to thousands of sites back), kept in v45; and a finished lane does not restart from -inf but MOVES ON to what earlier 65..128-site blocks left for its next step in
+// (bestB v[42:43], argB v44), which is then re-armed: per four steps one capture, three moves and two re-arms (v_cndmask under the lane
+// mask of the four finished lanes), and the source site advances by one v_add per step — 7 + 6/4 = 8.5 VALU per step (14 before).  The deferral is safe for the same reason as above:
+// rows of a narrow batch reach at most 59 steps ahead, so neither a finished lane's next step (64 ahead) nor any second register is
+// touched by the rows of the four steps in between.  32-step batches (the slot holds both planes for the wide ones), first lane G0.
+#define WG_DP32W_CORE(CV, P)                            \
+    "v_add_f64 v[6:7], s[20:21], " CV "\n"              \
+    "v_cmp_gt_f64 vcc, v[6:7], v[2:3]\n"                \
+    "v_max_f64 v[2:3], v[2:3], v[6:7]\n"                \
+    "v_cndmask_b32_e32 v4, v4, v45, vcc\n"              \
+    "v_readlane_b32 s20, v2, %[" P "]\n"                \
+    "v_readlane_b32 s21, v3, %[" P "]\n"                \
+    "v_add_u32_e32 v45, 1, v45\n"
+// (the source site k of the step lives in every lane of v45: a v_cndmask cannot take it from a scalar register beside vcc)
+#define WG_DP32W_MOVE  "v_cndmask_b32_e64 v2, v2, v42, s[24:25]\n" "v_cndmask_b32_e64 v3, v3, v43, s[24:25]\n" "v_cndmask_b32_e64 v4, v4, v44, s[24:25]\n"
+#define WG_DP32W_REARM "v_cndmask_b32_e64 v42, v42, 0, s[24:25]\n" "v_cndmask_b32_e64 v43, v43, v40, s[24:25]\n"
+#define WG_DP32W_CAPT  "v_cndmask_b32_e64 v5, v5, v4, s[24:25]\n"
+// After four steps g .. g+3 (mask = their lanes): the capture right behind step g+3, the three moves right behind step g+4 (a
+// finished lane's next candidate can arrive with step g+5), the re-arm of the second register behind step g+5; the mask of the
+// next four lanes is set a step ahead of its first use.  A block starts with the moves of the PREVIOUS block's last four lanes.
+#define WG_DP32W_BLOCK(R0, R1, R2, R3, R4, R5, R6, R7)                                                     \
+            WG_DP32W_CORE(R0, "p0") WG_DP32W_MOVE                                                          \
+            WG_DP32W_CORE(R1, "p1") WG_DP32W_REARM                                                         \
+            WG_DP32W_CORE(R2, "p2") WG_DP64L_MASK("ml0", "mh0")                                            \
+            WG_DP32W_CORE(R3, "p3") WG_DP32W_CAPT                                                          \
+            WG_DP32W_CORE(R4, "p4") WG_DP32W_MOVE                                                          \
+            WG_DP32W_CORE(R5, "p5") WG_DP32W_REARM                                                         \
+            WG_DP32W_CORE(R6, "p6") WG_DP64L_MASK("ml1", "mh1")                                            \
+            WG_DP32W_CORE(R7, "p7") WG_DP32W_CAPT
+#define WG_DP32W_OPERANDS(V0, V1, V2, V3, V4, V5, V6, V7)                                                  \
+            : "+{v[2:3]}"(best), "+{v4}"(arg), "+{v5}"(tbk), "+{s[20:21]}"(Mk), "+{s[24:25]}"(mask), "+{v45}"(kk), "+{v[42:43]}"(bestB), "+{v44}"(argB) \
+            : V0(cur[0]), V1(cur[1]), V2(cur[2]), V3(cur[3]), V4(cur[4]), V5(cur[5]), V6(cur[6]), V7(cur[7]), "{v40}"(ninf_splat), \
+              [p0] "n"(G + 0), [p1] "n"(G + 1), [p2] "n"(G + 2), [p3] "n"(G + 3), [p4] "n"(G + 4), [p5] "n"(G + 5), [p6] "n"(G + 6), [p7] "n"(G + 7), \
+              [ml0] "n"((int)(uint32_t)(0xfull << G)), [mh0] "n"((int)(uint32_t)((0xfull << G) >> 32)),   \
+              [ml1] "n"((int)(uint32_t)(0xfull << (G + 4))), [mh1] "n"((int)(uint32_t)((0xfull << (G + 4)) >> 32)) \
+            : "v6", "v7", "vcc"
+
+// Eight steps on lanes G .. G+7.  `mask` enters as the lane mask of the PREVIOUS four finished lanes (0: none — the first block of a
+// batch), whose moves this block begins with, and leaves as the mask of lanes G+4 .. G+7 (their capture done, their moves pending).
+template <int G, int SET>
+__device__ __forceinline__ void wg_dp_group32w(double& best, int32_t& arg, double& bestB, int32_t& argB, uint32_t& tbk, double& Mk, uint64_t& mask,
+                                               uint32_t& kk, const double (&cur)[8], const uint32_t ninf_splat)
+{
+    if (SET == 0) asm volatile(WG_DP32W_BLOCK("v[8:9]", "v[10:11]", "v[12:13]", "v[14:15]", "v[16:17]", "v[18:19]", "v[20:21]", "v[22:23]")
+                               WG_DP32W_OPERANDS("{v[8:9]}", "{v[10:11]}", "{v[12:13]}", "{v[14:15]}", "{v[16:17]}", "{v[18:19]}", "{v[20:21]}", "{v[22:23]}"));
+    else          asm volatile(WG_DP32W_BLOCK("v[24:25]", "v[26:27]", "v[28:29]", "v[30:31]", "v[32:33]", "v[34:35]", "v[36:37]", "v[38:39]")
+                               WG_DP32W_OPERANDS("{v[24:25]}", "{v[26:27]}", "{v[28:29]}", "{v[30:31]}", "{v[32:33]}", "{v[34:35]}", "{v[36:37]}", "{v[38:39]}"));
+}
+
+// 32 steps of a narrow batch (every window <= 60) of a wide job, first step on lane STP0 (0 or 32), first site `base`
+template <int STP0>
+__device__ __forceinline__ void wg_dp_batch32w(double& best, int32_t& arg, double& bestB, int32_t& argB, uint32_t& tbk, double& Mk,
+                                               const double* __restrict__ my, const int base, const int lane)
+{
+    const uint32_t ninf_hi = 0xfff00000u;
+    const double NEG_INF = -__builtin_inf();
+    double Ms = wg_readlane_f64(Mk, 0);
+    uint32_t kk = (uint32_t)base;                      // source site of the step, in every lane
+    uint64_t mask = 0;
+    double ra[8], rb[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) ra[u] = my[u * 64];
+#pragma unroll
+    for (int u = 0; u < 8; u++) rb[u] = my[(8 + u) * 64];
+    wg_dp_group32w<STP0 + 0, 0>(best, arg, bestB, argB, tbk, Ms, mask, kk, ra, ninf_hi);
+#pragma unroll
+    for (int u = 0; u < 8; u++) ra[u] = my[(16 + u) * 64];
+    wg_dp_group32w<STP0 + 8, 1>(best, arg, bestB, argB, tbk, Ms, mask, kk, rb, ninf_hi);
+#pragma unroll
+    for (int u = 0; u < 8; u++) rb[u] = my[(24 + u) * 64];
+    wg_dp_group32w<STP0 + 16, 0>(best, arg, bestB, argB, tbk, Ms, mask, kk, ra, ninf_hi);
+    wg_dp_group32w<STP0 + 24, 1>(best, arg, bestB, argB, tbk, Ms, mask, kk, rb, ninf_hi);
+    // the batch's last four finished lanes: their capture is done, their move to the second register is not
+    const bool last4 = lane >= STP0 + 28 && lane < STP0 + 32;
+    best = last4 ? bestB : best;
+    arg = last4 ? argB : arg;
+    bestB = last4 ? NEG_INF : bestB;
+    Mk = Ms;
+}
+
 // state kept per chunk in global memory: [0] M[k] of the next step, [1..64] best, [65..128] arg, [129..192] bestB,
 // [193..256] argB (args as doubles' bits) — written only between stages — then the ring: ringN doubles, ringN int32
 // (Tried in round 3: the wavefront that shares the recurrence wavefront's SIMD — a workgroup's wavefronts go to the four SIMDs in
@@ -1534,7 +1617,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
         const int base = s0 + b * BL;
         {
             const double* slot = slots + (size_t)(b & 1) * SLOT;
-            const bool wideb = WIDEJOB && kinds[b & 1] != 0u;
+            const bool wideb = WIDEJOB && kinds[b & 1] == 1u;
             const int stp0 = WIDEJOB ? (base & 63) : 0;          // lane of the batch's first step
             const int d = (lane - stp0) & 63;                    // this lane finishes step base + d (in this batch iff d < BL)
             const bool fin = d < BL;
@@ -1571,13 +1654,17 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
                     if (LEAN) best = lane >= 60 ? NEG_INF : best;     // the batch's last four finished lanes (the blocks re-arm the others)
                     Mk = Ms;
                     tbk = (((uint32_t)lane - tbk) & 63u) + 1u;        // source lane -> length of the best block ending here
+                } else if (kinds[b & 1] == 0u && A.pad[0] == 0) {     // every window of the batch <= 60: the hand-scheduled lean step (pad[0]: off, A/B)
+                    if (stp0 == 0) wg_dp_batch32w<0>(best, arg, bestB, argB, tbk, Mk, my, base, lane);
+                    else           wg_dp_batch32w<32>(best, arg, bestB, argB, tbk, Mk, my, base, lane);
                 } else if (stp0 == 0) {
                     wg_dp_batch32<0>(best, arg, tbk, Mk, my, base, lane, bestB, argB);
+                    bestB = fin ? NEG_INF : bestB;
                 } else {
                     wg_dp_batch32<32>(best, arg, tbk, Mk, my, base, lane, bestB, argB);
+                    bestB = fin ? NEG_INF : bestB;
                 }
                 if (WIDEJOB) tbk = (uint32_t)(base + d + 1) - tbk;    // start of the best block -> its length
-                if (WIDEJOB) bestB = fin ? NEG_INF : bestB;
             } else {
                 const double* myB = my + BL * 64;
                 double Mfin = 0.0;

@@ -936,7 +936,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbaseA = tbaseA; sv.tbaseB = tbaseB;
     sv.sb = c->plan_sb.as<int32_t>();
     // LDS of k_dp: two arranged batches (64 steps x 64 lanes, or 32 steps x 64 lanes x {A, B}) + M ring + fetched ring entries + flags + ring of windows / row offsets
-    DpArgs da = {ringN, {0, 0, 0}};
+    const int dp_wlean_off = (getenv("WGBSSEG_DP_WLEAN") && atoi(getenv("WGBSSEG_DP_WLEAN")) == 0) ? 1 : 0;      // 0: narrow batches of a wide job on the generic step (A/B, tests; read per call)
+    DpArgs da = {ringN, {dp_wlean_off, 0, 0}};
     c->last_dp_chunks = nC; c->last_dp_stride = state_stride;
     const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16 + 1024 * 6;
     if (own_stream && (!beside || st.wide_units)) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));      // scoring after the scan (always when it reads carries)
@@ -977,7 +978,9 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipStreamWaitEvent(c->sB, c->ev_cost1[stg], 0));
         HIP_TRY(hipEventRecord(c->ev_dp0[stg], c->sB));
         // worker waves per chunk, measured: 64-step batches (no window > 64): 7 (whole genome 3 -> 2.14 ms, 7 -> 1.77 ms,
-        // 5 / 11 / 15 -> 2.8-3.1 ms); 32-step batches (islands): 3 (4.8 ms; 7 -> 5.8 ms).  WGBSSEG_DP_NW overrides (tests, tuning).
+        // 5 / 11 / 15 -> 2.8-3.1 ms); 32-step batches (islands): round 1 measured 3 workers 4.8 ms, 7 -> 5.8 ms; round 3 (the batch loops written per role
+        // since round 2: 127 instead of 174 VGPRs) 3 -> 4.28 ms, 7 -> 3.52, with the lean step in the narrow batches 3.34 (11 workers: 5.0): 7 is the default now.  64-step batches again in round 3: 5 -> 1.83, 7 -> 1.66, 11 -> 1.65 ms.
+        // WGBSSEG_DP_NW overrides (tests, tuning).
         static const int dp_nw = getenv("WGBSSEG_DP_NW") ? atoi(getenv("WGBSSEG_DP_NW")) : 0;
         // 16-step batches at the footprint of one scoring workgroup when the recurrence of a stage runs beside the scoring of
         // the next one (WGBSSEG_DP16: 0 never, 1 always when windows allow; default: whenever the call is staged)
@@ -991,7 +994,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         else if (dp_mode == 0 && dp_lean && Wmax <= WG_NARROW_WMAX)
                                              hipLaunchKernelGGL((k_dp<7, 64, true>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else if (dp_mode == 0)               hipLaunchKernelGGL((k_dp<7, 64>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
-        else if (dp_mode == 1 && dp_nw == 7) hipLaunchKernelGGL((k_dp<7, 32>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
+        else if (dp_mode == 1 && dp_nw != 3) hipLaunchKernelGGL((k_dp<7, 32>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else if (dp_mode == 1)               hipLaunchKernelGGL((k_dp<3, 32>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else                   hipLaunchKernelGGL((k_dp<15, 32>), dim3((unsigned)nC), dim3(64 * 16), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         HIP_TRY(hipGetLastError());
