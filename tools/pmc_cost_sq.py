@@ -34,7 +34,9 @@ def main():
                 continue
             tot[row['Counter_Name']] = tot.get(row['Counter_Name'], 0.0) + float(row['Counter_Value'])
             n += 1
-    res = {'counters': tot, 'rows': n, 'command': ' '.join(cmd[cmd.index('--') + 1:])}
+    sys.path.insert(0, ROOT)
+    from wgbs_tools_amd import build
+    res = {'csrc_sha': build.source_hash(), 'counters': tot, 'rows': n, 'command': ' '.join(cmd[cmd.index('--') + 1:])}
     w = tot.get('SQ_WAVE_CYCLES', 0.0)
     if w:
         res['frac_of_wave_cycles'] = {k: v / w for k, v in tot.items() if k.startswith(('SQ_ACTIVE', 'SQ_WAIT'))}
