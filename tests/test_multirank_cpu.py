@@ -167,3 +167,46 @@ def test_sharded_driver_equals_single_rank(tmp_path):
     out = res.stdout.decode()
     assert res.returncode == 0, out[-3000:]
     assert 'SHARDED_CLI_OK' in out, out[-3000:]
+
+
+def test_first_batch_items_are_what_the_stitcher_asks_for_first_and_weighted_plans():
+    """wgbsseg_first_batch_items == the first request of wgbsseg_stitch_regions (chunks, then the up-front patches), with and without
+    speculation; item owners follow the planner's shares; wgbsseg_plan_shares_weighted gives rank 0 its smaller share."""
+    from wgbs_tools_amd import parallel, synth, _lib
+    sizes = [24900, 100000, 3700, 50000, 1]
+    loci = synth.synth_loci(5, sizes)
+    regions = parallel.regions_of_sizes(sizes)
+    params = dict(pcount=15.0, max_cpg=1000, max_bp=2000)
+    for chunk in (1000, 7000, 60000):
+        for spec in (True, False):
+            st, en, nch = _lib.first_batch_items(regions, chunk, spec)
+            grid = parallel.chunk_grid(regions, chunk)
+            assert nch == len(grid) and list(zip(st[:nch].tolist(), en[:nch].tolist())) == [(a, b) for _, a, b in grid]
+            assert len(set(zip(st.tolist(), en.tolist()))) == st.size and ((en - st)[nch:] <= 200).all()
+            seen = []
+
+            class Stop(Exception):
+                pass
+
+            def many(sites):
+                seen.append(list(sites))
+                raise Stop()
+            try:
+                _lib.stitch_regions(regions, chunk, many, speculate=spec)
+            except Stop:
+                pass
+            assert seen and seen[0] == list(zip(st.tolist(), en.tolist()))
+        st, en, nch = _lib.first_batch_items(regions, chunk, True)
+        for world in (1, 2, 8):
+            w = [0.6] + [1.0] * (world - 1)
+            sh = parallel.plan_weighted(regions, chunk, world, loci, params, w)
+            eq = parallel.plan(regions, chunk, world, loci, params)
+            assert sh['chunks'].sum() == eq['chunks'].sum() == nch
+            if world > 1 and nch >= 16 * world:
+                assert sh['work'][0] < eq['work'][0] and sh['work'][0] / sh['work'].sum() < 0.9 * eq['work'][0] / eq['work'].sum()
+            owner = parallel.item_owners(st, nch, sh)
+            for r in range(world):
+                mine = parallel.chunks_of_rank(regions, chunk, world, r, loci, params, shares=sh)
+                assert [(int(a), int(b)) for a, b in zip(st[:nch][owner[:nch] == r], en[:nch][owner[:nch] == r])] == mine
+            lo, hi = sh['win_lo'][owner], sh['win_hi'][owner]                 # every item lies inside its owner's resident window
+            assert (st - 1 >= lo).all() and (en - 1 <= hi).all()

@@ -94,6 +94,13 @@ def test_bgzf_pat_files_are_inflated_block_by_block(tmp_path, monkeypatch):
     plain.write_bytes(gzip.compress(text[:300000]) + gzip.compress(text[300000:]))      # two ordinary members
     assert list(P2B.bgzf_pieces(str(plain))) == []
     assert b''.join(P2B.pat_chunks(str(plain), chunk_bytes=50000)) == text
+    # BGZF blocks followed by ordinary gzip members (`cat` of files from different writers): the reference's `gunzip -cd` reads it
+    # (pat2beta.py:30), so the rest goes to zlib's multi-member inflater instead of an error
+    mixed = tmp_path / 'mixed.pat.gz'
+    mixed.write_bytes(_bgzf_bytes(text[:200000], block=30000) + gzip.compress(text[200000:450000]) + gzip.compress(text[450000:]))
+    for rb in (1 << 20, 70000):
+        assert b''.join(P2B.bgzf_pieces(str(mixed), read_bytes=rb, threads=2)) == text, rb
+    assert b''.join(P2B.pat_chunks(str(mixed), chunk_bytes=100000)) == text
     cut = tmp_path / 'cut.pat.gz'
     whole = _bgzf_bytes(text)
     cut.write_bytes(whole[:len(whole) // 2 + 7])
