@@ -23,9 +23,12 @@
 #include "exact_log2.h"
 #include "wave_prims.h"
 
-#define WG_CARRY_SHIFT  7
+#ifndef WG_CARRY_SHIFT
+#define WG_CARRY_SHIFT  7           // (-DWG_CARRY_SHIFT=8 .. 10: A/B builds, tools/build_carry_libs.sh)
+#endif
 #define WG_CARRY_G      (1 << WG_CARRY_SHIFT)   // a carry (chunk-relative exclusive prefix) is stored at every absolute site index
-                                    // that is a multiple of 128 inside the chunk, plus (group 0) at the chunk start itself
+                                    // that is a multiple of WG_CARRY_G inside the chunk, plus (group 0) at the chunk start itself
+static_assert(WG_CARRY_SHIFT >= 4 && WG_CARRY_SHIFT <= 10, "k_scan: a lane vector is 16 sites, an iteration 1024");
 #define WG_BLOCK        256
 #define WG_WIN_TILE     1024        // sites per k_window workgroup
 #define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)

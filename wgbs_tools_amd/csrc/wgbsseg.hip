@@ -105,6 +105,7 @@ struct PinnedBuf {          // grow-only page-locked host buffer (fast, truly as
 struct wgbsseg_ctx {
     int device = 0;
     hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;     // scoring (+ everything else) | recurrence, traceback | the scan pass
+    hipStream_t sA2 = nullptr;                                // second scoring stream: medium / wide tiles beside the narrow ones (stage loop)
     int scan_stream = 1;       // WGBSSEG_SCAN_STREAM: 0 the scan pass on the scoring stream, ahead of the scoring kernel; 1 on its own stream for small jobs; 2 always
     // inputs
     DevBuf betas_own, loci_own;
@@ -125,7 +126,7 @@ struct wgbsseg_ctx {
     // events
     hipEvent_t ev[9] = {};   // [8]: between the two launches of the scan pass (k_scan | k_validate)
     PinnedBuf h_status;      // page-locked landing area of the status words: D2H copies that really are asynchronous
-    std::vector<hipEvent_t> ev_cost0, ev_cost1, ev_dp0, ev_dp1;
+    std::vector<hipEvent_t> ev_cost0, ev_cost1, ev_dp0, ev_dp1, ev_fork, ev_join;     // per stage
     // last-call info
     wgbsseg_timings tim = {};
     int64_t last_sites = 0, last_pairs = 0;
@@ -260,6 +261,7 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
         HIP_TRY(hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, hi_p));
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->sC, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->sA2, hipStreamNonBlocking));
     { const char* e = getenv("WGBSSEG_SCAN_STREAM"); if (e) c->scan_stream = std::min(2, std::max(0, atoi(e))); }
     for (auto& v : c->ev) HIP_TRY(hipEventCreate(&v));
     const char* b = getenv("WGBSSEG_COST_BUDGET_MB");
@@ -300,10 +302,11 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     for (auto& pb : c->up_stage) pb.release();
     c->h_status.release();
     for (auto& v : c->ev) if (v) (void)hipEventDestroy(v);
-    for (auto* vec : {&c->ev_cost0, &c->ev_cost1, &c->ev_dp0, &c->ev_dp1}) for (auto v : *vec) (void)hipEventDestroy(v);
+    for (auto* vec : {&c->ev_cost0, &c->ev_cost1, &c->ev_dp0, &c->ev_dp1, &c->ev_fork, &c->ev_join}) for (auto v : *vec) (void)hipEventDestroy(v);
     if (c->sA) (void)hipStreamDestroy(c->sA);
     if (c->sB) (void)hipStreamDestroy(c->sB);
     if (c->sC) (void)hipStreamDestroy(c->sC);
+    if (c->sA2) (void)hipStreamDestroy(c->sA2);
     delete c;
     if (profiling()) fprintf(stderr, "[wgbsseg] destroy: %.1f ms\n", (wall_s() - t0) * 1e3);
 }
@@ -932,6 +935,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(c->out_borders.ensure((size_t)(J + nC) * 4));
     grow_events(c->ev_cost0, n_stages); grow_events(c->ev_cost1, n_stages);
     grow_events(c->ev_dp0, n_stages); grow_events(c->ev_dp1, n_stages);
+    grow_events(c->ev_fork, n_stages); grow_events(c->ev_join, n_stages);
     StageView sv;
     sv.cbase = c->plan_cbase.as<int64_t>(); sv.cum0 = c->plan_cum0.as<uint32_t>(); sv.tbaseA = tbaseA; sv.tbaseB = tbaseB;
     sv.sb = c->plan_sb.as<int32_t>();
@@ -941,40 +945,53 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     c->last_dp_chunks = nC; c->last_dp_stride = state_stride;
     const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16 + 1024 * 6;
     if (own_stream && (!beside || st.wide_units)) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));      // scoring after the scan (always when it reads carries)
+    // Two scoring streams.  A scoring launch ends in a tail of partly filled workgroup slots (1280 on the chip), and a stage
+    // with more than one tile class pays one per class: there the medium and wide tiles go to a second stream, beside the
+    // narrow ones (they write disjoint rows of the cost buffer), forked off the first stream when the stage may begin
+    // and joined before the stage's end is recorded (ev_fork / ev_join).  Measured, islands x32: scoring 29.49 -> 28.70 ms, x8 9.35 -> 9.14 ms.
+    // Alternating the STAGES of a staged job between the streams was measured too and is not done: the one-eighth share
+    // (8 stages) scored in 3.40 instead of 3.49 ms but its recurrences, which run beside the next stage's scoring, fell behind
+    // (step 4.56 -> 4.79 ms); x200 / x512 gained 0.1-0.5 %.  WGBSSEG_COST_STREAMS=1: everything on the first stream (A/B, read per call).
+    const bool two_cost_streams = !(getenv("WGBSSEG_COST_STREAMS") && atoi(getenv("WGBSSEG_COST_STREAMS")) == 1);
+    hipStream_t const sP = c->sA;
     for (int stg = 0; stg < n_stages; stg++) {
         sv.stage = stg;
         double* cbuf = c->cost[stg % nbuf].as<double>();
-        if (stg >= nbuf) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev_dp1[stg - nbuf], 0));   // buffer free again
-        HIP_TRY(hipEventRecord(c->ev_cost0[stg], c->sA));
+        const bool side = two_cost_streams && stage_tiles[3 * (size_t)stg] > 0 && (stage_tiles[3 * (size_t)stg + 1] > 0 || stage_tiles[3 * (size_t)stg + 2] > 0);
+        hipStream_t const sSide = side ? c->sA2 : sP;
+        if (stg >= nbuf) HIP_TRY(hipStreamWaitEvent(sP, c->ev_dp1[stg - nbuf], 0));   // buffer free again
+        HIP_TRY(hipEventRecord(c->ev_cost0[stg], sP));
+        if (side) { HIP_TRY(hipEventRecord(c->ev_fork[stg], sP)); HIP_TRY(hipStreamWaitEvent(sSide, c->ev_fork[stg], 0)); }
         if (stage_tiles[3 * (size_t)stg] > 0) {
             const TileDesc* td = c->tilesA.as<TileDesc>() + tileA0[(size_t)stg];
             const int64_t nt = stage_tiles[3 * (size_t)stg];
             const bool divs = c->divs_enabled && c->divs_ok && c->divs_pc == P->pseudo_count;
-            hipError_t e = term_mode == 2 ? (divs ? launch_cost_ti<3>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, c->sA)
-                                                  : launch_cost_ti<2>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, c->sA))
-                         : (term_mode == 1 ? launch_cost_ti<1>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, c->sA)
-                                           : launch_cost_ti<0>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, c->sA));
+            hipError_t e = term_mode == 2 ? (divs ? launch_cost_ti<3>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, sP)
+                                                  : launch_cost_ti<2>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, sP))
+                         : (term_mode == 1 ? launch_cost_ti<1>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, sP)
+                                           : launch_cost_ti<0>(TI, false, v, sv, caA, td, nt, cbuf, ldsA, sP));
             HIP_TRY(e);
         }
         if (stage_tiles[3 * (size_t)stg + 2] > 0) {                  // medium tiles: the narrow tiles' arithmetic on rows of 269 entries
             const TileDesc* td = c->tilesM.as<TileDesc>() + tileM0[(size_t)stg];
             const int64_t nt = stage_tiles[3 * (size_t)stg + 2];
             const bool divs = c->divs_enabled && c->divs_m_ok && c->divs_m_pc == P->pseudo_count;
-            hipError_t e = term_mode == 2 ? (divs ? launch_cost_ti<3>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, c->sA)
-                                                  : launch_cost_ti<2>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, c->sA))
-                         : (term_mode == 1 ? launch_cost_ti<1>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, c->sA)
-                                           : launch_cost_ti<0>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, c->sA));
+            hipError_t e = term_mode == 2 ? (divs ? launch_cost_ti<3>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, sSide)
+                                                  : launch_cost_ti<2>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, sSide))
+                         : (term_mode == 1 ? launch_cost_ti<1>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, sSide)
+                                           : launch_cost_ti<0>(-1, false, v, sv, caM, td, nt, cbuf, ldsM, sSide));
             HIP_TRY(e);
         }
         if (stage_tiles[3 * (size_t)stg + 1] > 0) {
             const TileDesc* td = c->tilesB.as<TileDesc>() + tileB0[(size_t)stg];
             const int64_t nt = stage_tiles[3 * (size_t)stg + 1];
-            hipError_t e = term_modeB == 2 ? launch_cost_ti<2>(TI, true, v, sv, caB, td, nt, cbuf, ldsB, c->sA)
-                         : (term_modeB == 1 ? launch_cost_ti<1>(TI, true, v, sv, caB, td, nt, cbuf, ldsB, c->sA)
-                                           : launch_cost_ti<0>(TI, true, v, sv, caB, td, nt, cbuf, ldsB, c->sA));
+            hipError_t e = term_modeB == 2 ? launch_cost_ti<2>(TI, true, v, sv, caB, td, nt, cbuf, ldsB, sSide)
+                         : (term_modeB == 1 ? launch_cost_ti<1>(TI, true, v, sv, caB, td, nt, cbuf, ldsB, sSide)
+                                           : launch_cost_ti<0>(TI, true, v, sv, caB, td, nt, cbuf, ldsB, sSide));
             HIP_TRY(e);
         }
-        HIP_TRY(hipEventRecord(c->ev_cost1[stg], c->sA));
+        if (side) { HIP_TRY(hipEventRecord(c->ev_join[stg], sSide)); HIP_TRY(hipStreamWaitEvent(sP, c->ev_join[stg], 0)); }
+        HIP_TRY(hipEventRecord(c->ev_cost1[stg], sP));
         HIP_TRY(hipStreamWaitEvent(c->sB, c->ev_cost1[stg], 0));
         HIP_TRY(hipEventRecord(c->ev_dp0[stg], c->sB));
         // worker waves per chunk, measured: 64-step batches (no window > 64): 7 (whole genome 3 -> 2.14 ms, 7 -> 1.77 ms,
@@ -1051,8 +1068,12 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const int64_t scan_bytes = 2 * (st.wide_units ? J : job.val_sites) * c->n_samples;
     if (scan_bytes > T.scan_main_bytes) { T.scan_main_bytes = scan_bytes; T.scan_main_ms = ms; }
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); T.window_ms += ms;
+    float cost_end = 0;      // scoring time = the union of the stages' intervals (neighbouring stages overlap on the two scoring streams)
     for (int stg = 0; stg < n_stages; stg++) {
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev_cost0[stg], c->ev_cost1[stg])); T.cost_ms += ms;
+        float t0 = 0, t1 = 0;
+        HIP_TRY(hipEventElapsedTime(&t0, c->ev[0], c->ev_cost0[stg])); HIP_TRY(hipEventElapsedTime(&t1, c->ev[0], c->ev_cost1[stg]));
+        if (t1 > std::max(t0, cost_end)) T.cost_ms += t1 - std::max(t0, cost_end);
+        cost_end = std::max(cost_end, t1);
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_dp0[stg], c->ev_dp1[stg])); T.dp_ms += ms;
     }
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[4], c->ev[5])); T.trace_ms += ms;
