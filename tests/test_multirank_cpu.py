@@ -59,10 +59,18 @@ WORKER = textwrap.dedent('''
         dist.barrier()
         # the product's form (parallel.ShardedRun: every rank computes the items of the stitcher's first batch that it owns,
         # slots in /dev/shm or - second pass - a gather of objects), three steps each so that the two slots alternate
-        for no_shm in ('', '1'):
-            os.environ['WGBSSEG_NO_SHM'] = no_shm
+        # third pass: /dev/shm too small on ONE rank (its reservation fails): every rank must fall back to the gather of objects
+        for no_shm in ('', '1', 'full'):
+            os.environ['WGBSSEG_NO_SHM'] = no_shm if no_shm != 'full' else ''
+            reserve = parallel.NodeSlots._reserve
+            if no_shm == 'full' and rank == 1:
+                def refuse(fd, size):
+                    raise OSError(28, 'No space left on device')
+                parallel.NodeSlots._reserve = staticmethod(refuse)
             run = parallel.ShardedRun(dist, regions, chunk, loci, params, rank, world)
+            parallel.NodeSlots._reserve = staticmethod(reserve)
             assert run.slots.shared == (no_shm == '')
+            assert no_shm != 'full' or run.slots.paths == []           # (the slot files of the failed attempt are gone)
             late = []
             def patches(st, en, _e=parallel.csr_engine(eng, pr)):
                 late.extend((en - st).tolist())
@@ -71,7 +79,7 @@ WORKER = textwrap.dedent('''
                 merged = run.step(parallel.csr_engine(eng, pr), patches)
                 if rank == 0:
                     ok = all(np.array_equal(m, w) for m, w in zip(merged, want))
-                    verdicts.append((name + ' sharded' + (' objects' if no_shm else ' shm') + ' step %%d' %% step, ok, any(x > 100 for x in late)))
+                    verdicts.append((name + ' sharded' + (' objects' if no_shm == '1' else ' no room in shm' if no_shm else ' shm') + ' step %%d' %% step, ok, any(x > 100 for x in late)))
                 else:
                     assert merged is None
             assert sum(i.size for i in run.idx) == run.starts.size and all(i.size for i in run.idx)

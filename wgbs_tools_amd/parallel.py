@@ -2,11 +2,12 @@
 the data path.
 
 Chunks are independent DP problems and chromosomes never interact (segment.py:84-86,129-134).  The chunk grid is cut into
-`world` contiguous runs of chunks by the planner of the share groups (wgbsseg_plan_shares, include/wgbsseg.h: balanced by the
-scored blocks the chunks hold, always on the reference's grid so every chunk is the very chunk a one-GPU run would segment).
-Each rank runs its chunk DPs on its own GPU; the per-chunk border lists are gathered as Python objects on the host of rank
-0, which walks the reference's pairwise tree (segment.py:157-165,199-252) over ALL chunks with the native stitcher
-(wgbsseg_stitch_regions): the answer does not depend on the number of ranks.
+`world` contiguous runs of chunks by the planner of the share groups (wgbsseg_plan_shares[_weighted], include/wgbsseg.h:
+balanced by the scored blocks the chunks hold, always on the reference's grid so every chunk is the very chunk a one-GPU run
+would segment).  Each rank runs, on its own GPU, the chunk DPs of its run and the junction patches the stitcher is known to
+ask for first (ShardedRun); the border lists reach rank 0 through slots in /dev/shm (NodeSlots; a gather of Python objects
+between hosts), and rank 0 walks the reference's pairwise tree (segment.py:157-165,199-252) over ALL chunks with the native
+stitcher (wgbsseg_stitch_regions): the answer does not depend on the number of ranks.
 """
 
 
@@ -131,16 +132,46 @@ class NodeSlots:
         if self.shared:
             def path(r, k):
                 return '/dev/shm/wgbsseg_%s_r%d_%d.bin' % (tag[0], r, k)
-            for k in range(2):
-                pth = path(rank, k)
-                np.memmap(pth, dtype=np.uint8, mode='w+', shape=(self._bytes(rank),)).flush()      # zero-filled: stamp 0 = nothing yet
-                self.paths.append(pth)
-            dist.barrier()
+            # the slots are sized for the worst case (every site a border) and RESERVED, not just mapped: a /dev/shm too small for
+            # them (containers often get 64 MB) must show now, as an error every rank can agree on, not later as a SIGBUS in the
+            # middle of a step.  One rank that cannot reserve sends all of them to the gather of objects.
+            ok = True
+            try:
+                for k in range(2):
+                    pth = path(rank, k)
+                    self.paths.append(pth)
+                    fd = os.open(pth, os.O_CREAT | os.O_RDWR | os.O_TRUNC, 0o600)
+                    try:
+                        self._reserve(fd, self._bytes(rank))                    # zero-filled: stamp 0 = nothing yet
+                    finally:
+                        os.close(fd)
+            except OSError:
+                ok = False
+            oks = [None] * world
+            dist.all_gather_object(oks, ok)
+            if not all(oks):
+                self._unlink()
+                self.shared = False
+        if self.shared:
             for r in range(world):
                 for k in range(2):
                     if rank == 0 or r == rank or (r == 0 and k == 0):                             # (everybody reads rank 0's header)
                         self.maps[(r, k)] = np.memmap(path(r, k), dtype=np.uint8, mode='r+', shape=(self._bytes(r),))
             dist.barrier()
+
+    @staticmethod
+    def _reserve(fd, size):
+        import os
+        os.posix_fallocate(fd, 0, size)
+
+    def _unlink(self):
+        import os
+        for pth in self.paths:
+            try:
+                os.unlink(pth)
+            except OSError:
+                pass
+        self.paths = []
 
     def _bytes(self, r):
         return self.HDR + 8 * (self.n_items[r] + 1) + 4 * max(1, self.caps[r]) + 8
@@ -199,16 +230,10 @@ class NodeSlots:
             self._hdr(0, 0)[1] = self.step_no
 
     def close(self):
-        import os
         if self.shared and self.rank == 0:
             self._hdr(0, 0)[1] = 1 << 60                          # nobody waits for a rank 0 that has left
         self.maps = {}
-        for pth in self.paths:
-            try:
-                os.unlink(pth)
-            except OSError:
-                pass
-        self.paths = []
+        self._unlink()
 
 
 class ShardedRun:
