@@ -277,13 +277,16 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     ndev = torch.cuda.device_count()
-    group_mode = world == 1 and args.gpus > 1    # ONE process drives --gpus GPUs (the product's `wgbstools segment --gpus N`)
+    # the multi-process path: under a launcher with more than one rank — or, to exercise its plumbing (RCCL group, host group,
+    # /dev/shm slots) on a 1-GPU box, with ONE rank when WGBSSEG_BENCH_DIST=1 (torch.distributed.run --nproc-per-node 1)
+    multi = world > 1 or (os.environ.get('WGBSSEG_BENCH_DIST') == '1' and 'RANK' in os.environ)
+    group_mode = not multi and args.gpus > 1    # ONE process drives --gpus GPUs (the product's `wgbstools segment --gpus N`)
     oversub = world > 1 and ndev < world            # test mode: more ranks than GPUs (e.g. 2 ranks on a 1-GPU box)
     local = local % max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     host_group = None
-    if world > 1:
+    if multi:
         if oversub:
             dist.init_process_group('gloo')          # RCCL refuses two ranks on one device; the barrier is all we need
             host_group = dist
@@ -329,7 +332,7 @@ def main():
 
         def timings():
             return grp.timings(0)
-    elif world > 1:
+    elif multi:
         # one process per GPU: the product's multi-process path (wgbs_tools_amd/parallel.py ShardedRun).  A rank generates and
         # holds only its own window; rank 0, which also serves the follow-up patches of the tree, holds the genome.
         if host_group is None:
@@ -401,7 +404,7 @@ def main():
         for d in range(ndev if group_mode else 0):
             torch.cuda.synchronize(d)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier() if oversub else dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
@@ -416,7 +419,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device='cpu' if oversub else dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
@@ -452,7 +455,7 @@ def main():
         scan_kernel = 'k_scan' if stats_wide else 'k_validate'
         # HBM traffic of the scan launch from the PMC counters (separate rocprofv3 passes, tools/pmc_scan_traffic.py): only a file
         # made from THIS source state, for this kernel and these algorithmic bytes, is reported
-        tr = keyed_profile('*scan_traffic*.json', sha, kernel=scan_kernel) if (world == 1 and not group_mode) else None
+        tr = keyed_profile('*scan_traffic*.json', sha, kernel=scan_kernel) if (not multi and not group_mode) else None
         traffic, traffic_note = None, 'traffic: no PMC pass of this source state (csrc_sha %s) for %s on this workload under profiles/' % (sha, scan_kernel)
         if tr and abs(tr['algorithmic_bytes'] - acc['scan_main_bytes']) <= 0.001 * acc['scan_main_bytes']:
             traffic = tr['traffic_bytes']
@@ -487,7 +490,7 @@ def main():
         mode = ('one process, %d GPUs: a share group (work-balanced contiguous chunk runs, one host thread per GPU, one host-side tree)' % args.gpus
                 if group_mode else
                 'one process per GPU (parallel.ShardedRun): work-balanced contiguous chunk runs per rank, border lists handed to rank 0 through /dev/shm, '
-                'ONE stitching tree on rank 0 inside the timed step; no collective' if world > 1 else 'one GPU')
+                'ONE stitching tree on rank 0 inside the timed step; no collective' if multi else 'one GPU')
         cost_ms = acc['cost_ms'] / args.steps
         out = {
             'metric': 'CpG-sites/sec segmented',
@@ -526,7 +529,7 @@ def main():
             'block_sums': block_sums,
             'device_ms_per_step': {k: acc[k] / args.steps for k in ('scan_ms', 'window_ms', 'cost_ms', 'dp_ms', 'trace_ms', 'total_ms')},
         }
-        single = world == 1 and not group_mode
+        single = not multi and not group_mode
         if single and args.e2e:
             try:
                 out['end_to_end'] = end_to_end(args, buf, sizes, names, loci)
@@ -582,7 +585,7 @@ def main():
         seg.close()
     if grp is not None:
         grp.close()
-    if world > 1:
+    if multi:
         dist.barrier() if oversub else dist.barrier(device_ids=[local])
         if run is not None:
             run.close()
