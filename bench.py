@@ -441,6 +441,13 @@ def main():
             block_sums = {'kernel': 'k_block_sums_prep + k_block_sums_run + k_block_sums_direct (per block, per sample sums of meth/cov -> .bin rows; HIP events around the launches)',
                           'blocks': int(bs.size), 'ms_bin_rows': t_bin, 'ms_bin_rows_all': times[:5], 'ms_means': min(times[5:7]), 'ms_raw_sums': min(times[7:9]),
                           'algorithmic_bytes': alg, 'GB_per_s': alg / (t_bin * 1e-3) / 1e9, 'frac_of_hbm_peak': alg / (t_bin * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          # not credited above, reported beside it: the table the kernel has to write (2 B per block and sample as .bin rows, 8 B as
+                          # means or raw sums) — with it the three output forms move 4.7-5.0 TB/s alike, which is why the raw sums (a third fewer
+                          # instructions, four times the output) are not the fastest form
+                          'written_bytes': {'bin_rows': 2 * int(bs.size) * args.samples, 'means': 8 * int(bs.size) * args.samples, 'raw_sums': 8 * int(bs.size) * args.samples},
+                          'GB_per_s_reads_and_writes': {'bin_rows': (alg + 2 * int(bs.size) * args.samples) / (t_bin * 1e-3) / 1e9,
+                                                        'means': (alg + 8 * int(bs.size) * args.samples) / (min(times[5:7]) * 1e-3) / 1e9,
+                                                        'raw_sums': (alg + 8 * int(bs.size) * args.samples) / (min(times[7:9]) * 1e-3) / 1e9},
                           'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
 
         ms_step = dt / args.steps * 1e3
