@@ -2,6 +2,7 @@
 
   libwgbsseg.so    the product: HIP kernels + C ABI (include/wgbsseg.h)            <- csrc/wgbsseg.hip
   libwgbssynth.so  synthetic-input generator on the device (bench / tests only)     <- csrc/synth.hip
+  segmentor        the reference's per-chunk executable (same argv / stdin / stdout) over libwgbsseg.so   <- csrc/segmentor_main.cpp
 
 The built .so files are git-ignored but travel with gpurun snapshots.
 """
@@ -42,6 +43,12 @@ def hipcc():
     raise RuntimeError('hipcc not found: cannot build the gfx950 libraries')
 
 
+# host executables linked against the library next to them (rpath $ORIGIN): name -> (sources, headers)
+PROGRAMS = {
+    'segmentor': (['segmentor_main.cpp'], ['../../include/wgbsseg.h']),
+}
+
+
 def _stale(out, deps):
     if not op.isfile(out):
         return True
@@ -63,6 +70,16 @@ def build(force=False, verbose=False):
                 print(' '.join(cmd), file=sys.stderr)
             subprocess.check_call(cmd, cwd=CSRC)
             built.append(lib)
+    for exe, (srcs, hdrs) in PROGRAMS.items():
+        out = op.join(CSRC, exe)
+        srcp = [op.join(CSRC, s) for s in srcs]
+        deps = srcp + [op.normpath(op.join(CSRC, h)) for h in hdrs] + [op.join(CSRC, 'libwgbsseg.so')]
+        if force or _stale(out, deps):
+            cmd = [hipcc(), '-O2', '-std=c++17'] + srcp + ['-L' + CSRC, '-lwgbsseg', '-Wl,-rpath,$ORIGIN', '-o', out]
+            if verbose:
+                print(' '.join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd, cwd=CSRC)
+            built.append(exe)
     return built
 
 
