@@ -340,3 +340,29 @@ def test_random_block_tables_fast_path_never_disagrees(tmp_path, monkeypatch):
                     monkeypatch.delenv('WGBSSEG_PY_TABLES')
             assert res[0] == res[1], (it, anno, text)
     assert taken > 1000, taken
+
+
+def test_comments_inside_a_line_and_pandas_missing_values(tmp_path):
+    """The reference reads a blocks table with pd.read_csv(sep='\\t', comment='#') (beta_to_blocks.py:50-91): a '#' ANYWHERE ends the
+    parsed part of its line, and the CpG columns know pandas' whole vocabulary of missing values.  Checked against pandas itself."""
+    pd = pytest.importorskip('pandas')
+    from wgbs_tools_amd.genome import IllegalArgumentError
+    text = ('chr1\t100\t200\t5\t9\tanno # trailing words\there\n'
+            '# a whole line\n'
+            'chr1\t300\t400\t9\t12# glued to the number\n'
+            'chr1\t500\t600\t-nan\t14\n'
+            'chr1\t700\t800\t14\t-NaN# a comment glued to a missing value\n'
+            'chr2\t10\t20\t20\t25\n')
+    p = tmp_path / 'c.bed'
+    p.write_text(text)
+    t = B2B.load_blocks_file(str(p))
+    df = pd.read_csv(str(p), sep='\t', header=None, comment='#', usecols=range(5), names=['chr', 'start', 'end', 'startCpG', 'endCpG'])
+    assert len(t) == len(df) == 5
+    na = df['startCpG'].isna() | df['endCpG'].isna()
+    assert t.na.tolist() == na.tolist() == [False, False, True, True, False]
+    assert t.startCpG[~t.na].tolist() == df['startCpG'][~na].astype(int).tolist() == [5, 9, 20]
+    assert t.endCpG[~t.na].tolist() == df['endCpG'][~na].astype(int).tolist() == [9, 12, 25]
+    q = tmp_path / 'd.bed'
+    q.write_text('chr1\t100\t200\tfive\t9\n')
+    with pytest.raises(IllegalArgumentError):
+        B2B.load_blocks_file(str(q))

@@ -18,15 +18,16 @@ one numpy pass per file in a process pool; input files may be uint8 `.beta` / `.
 """
 import argparse
 import os
+import re
 import os.path as op
 import sys
 
 import numpy as np
 
 from .genome import IllegalArgumentError, eprint
+from .cliutil import NA_TOKENS
 
 COORDS_COLS5 = ['chr', 'start', 'end', 'startCpG', 'endCpG']
-NA_TOKENS = ('', 'NA', 'NaN', 'nan', 'N/A', 'NULL', 'null', '<NA>', 'n/a', '#N/A', 'None')
 
 
 def b2b_log(*args, **kwargs):
@@ -156,6 +157,9 @@ def _opener(path):
     return open(path, 'r')
 
 
+_MIDLINE_COMMENT = re.compile(rb'[^\n]#')
+
+
 def _load_blocks_native(blocks_path, nrows, anno=False):
     """The library's one-pass parser (include/wgbsseg.h: wgbsseg_blocks_parse) on the file's bytes -> BlocksTable, or None when
     the library is not built or the file is not a plain table (the line-by-line parser below then handles it and owns the
@@ -174,6 +178,8 @@ def _load_blocks_native(blocks_path, nrows, anno=False):
     else:
         with open(blocks_path, 'rb') as f:
             data = f.read()
+    if _MIDLINE_COMMENT.search(data):          # pandas comment='#' cuts a line at a '#' anywhere: the line-by-line parser does that
+        return None
     p = _lib.blocks_parse(data, nrows)
     if p is None:
         return None
@@ -198,7 +204,8 @@ def load_blocks_file(blocks_path, anno=False, nrows=None):
     first = True
     with _opener(blocks_path) as f:
         for line in f:
-            if line.startswith('#') or not line.strip():
+            line = line.split('#', 1)[0]                         # pd.read_csv(comment='#'): the rest of the line is not parsed
+            if not line.strip():
                 continue
             tok = line.rstrip('\n').rstrip('\r').split('\t')
             if first:
@@ -217,8 +224,11 @@ def load_blocks_file(blocks_path, anno=False, nrows=None):
             chrom.append(tok[0]); start.append(tok[1]); end.append(tok[2])
             miss = tok[3] in NA_TOKENS or tok[4] in NA_TOKENS
             na.append(miss)
-            scpg.append(0 if miss else int(float(tok[3])))
-            ecpg.append(0 if miss else int(float(tok[4])))
+            try:
+                scpg.append(0 if miss else int(float(tok[3])))
+                ecpg.append(0 if miss else int(float(tok[4])))
+            except (ValueError, OverflowError):
+                raise IllegalArgumentError(f'Invalid CpG columns in blocks file {blocks_path}: {tok[3]!r}, {tok[4]!r}')
             if extra is not None:
                 extra['anno'].append(tok[5] if len(tok) > 5 else '')
                 extra['gene'].append(tok[6] if len(tok) > 6 else '')

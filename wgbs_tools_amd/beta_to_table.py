@@ -48,7 +48,7 @@ class Groups:
 def load_gfile_helper(groups_file):
     """Parse a groups file (format above) -> Groups without paths."""
     with open(groups_file, newline='') as f:
-        rows = [r for r in csv.reader(line for line in f if not line.startswith('#')) if r]
+        rows = [r for r in csv.reader(line.split('#', 1)[0] for line in f) if r]      # (pandas comment='#': a '#' anywhere ends the parsed part of a line)
     if not rows:
         raise IllegalArgumentError('gropus file must have a column named "group"')
     header, body = [h.strip() for h in rows[0]], rows[1:]

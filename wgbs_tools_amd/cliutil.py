@@ -73,3 +73,9 @@ def add_threads_option(parser):
     """-@ (kept for command-line compatibility: the GPU path does not fork workers; host-side thread pools read it where they exist)."""
     parser.add_argument('-@', '--threads', type=int, default=default_threads(),
                         help='Number of threads to use (default: all available CPUs)')
+
+
+# what pandas.read_csv treats as missing by default (the reference reads every table with it; with comment='#' the entries that
+# hold a '#' can never reach a field)
+NA_TOKENS = frozenset(['', '#N/A', '#N/A N/A', '#NA', '-1.#IND', '-1.#QNAN', '-NaN', '-nan', '1.#IND', '1.#QNAN', '<NA>',
+                       'N/A', 'NA', 'NULL', 'NaN', 'None', 'n/a', 'nan', 'null'])

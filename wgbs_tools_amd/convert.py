@@ -26,11 +26,8 @@ import sys
 import numpy as np
 
 from .genome import GenomeRefPaths, GenomicRegion, IllegalArgumentError, eprint, write_bed
-from .cliutil import add_threads_option, add_where_options
+from .cliutil import NA_TOKENS, add_threads_option, add_where_options
 
-# what pandas.read_csv treats as missing by default (the reference reads every table with it)
-NA_TOKENS = frozenset(['', '#N/A', '#N/A N/A', '#NA', '-1.#IND', '-1.#QNAN', '-NaN', '-nan', '1.#IND', '1.#QNAN', '<NA>',
-                       'N/A', 'NA', 'NULL', 'NaN', 'None', 'n/a', 'nan', 'null'])
 _INT = re.compile(r'^[+-]?\d+$')
 
 
