@@ -26,6 +26,7 @@
 #ifndef WG_CARRY_SHIFT
 #define WG_CARRY_SHIFT  7           // (-DWG_CARRY_SHIFT=8 .. 10: A/B builds, tools/build_carry_libs.sh)
 #endif
+#define WG_SCAN_STAGED  512         // carry groups of a chunk that k_scan keeps in LDS until the row is done
 #define WG_CARRY_G      (1 << WG_CARRY_SHIFT)   // a carry (chunk-relative exclusive prefix) is stored at every absolute site index
                                     // that is a multiple of WG_CARRY_G inside the chunk, plus (group 0) at the chunk start itself
 static_assert(WG_CARRY_SHIFT >= 4 && WG_CARRY_SHIFT <= 10, "k_scan: a lane vector is 16 sites, an iteration 1024");
@@ -152,7 +153,7 @@ __device__ __forceinline__ void wg_sum8(const uint4 v, uint32_t& tm, uint32_t& t
 
 // One wavefront streams one (chunk, sample) row, 64 lanes x 32 B = 1024 sites per iteration, the next iteration in
 // flight.  Lane vectors are 32-byte aligned in the sample row, so every 8th lane starts on an absolute site index that
-// is a multiple of 128: that lane stores the carry of its group, no intra-vector partial sums needed; the two wave scans
+// is a multiple of 128: that lane holds the carry of its group, no intra-vector partial sums needed; the two wave scans
 // are amortised over 2 KB.  Register-lean on purpose (32-bit chunk-relative indices, the rare paths out of line):
 // 8 wavefronts per SIMD, so that the 15,456 equally long rows of an hg19 x 32 job run in two rounds, not three.
 __device__ __noinline__ uint4 wg_blank_outside(uint4 v, int rel0, int len)
@@ -207,6 +208,14 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int
     int bad_rel = 0x7fffffff;
     if (lane == 0) carry[0] = make_uint2(0u, 0u);     // group 0: the chunk start
     const int nit = (span + 1023) >> 10;              // 1024-site iterations of the row
+    // The row's carries stay in LDS (up to WG_SCAN_STAGED groups = 4 KB per wavefront, 16 KB per workgroup: eight workgroups per CU
+    // still fit) and leave as full-wavefront stores when the row is done: a store in every iteration of the read stream is what
+    // held this pass at 0.54-0.58 of the HBM peak (round 3, hg19 x 32 with islands: 0.375-0.408 -> 0.357-0.359 ms = 0.65; the
+    // volume of the stores, the instruction count and the loads in flight measured irrelevant: DESIGN.md 8.5).  A chunk of more
+    // groups than that (> 65,000 sites) stores directly.
+    __shared__ uint2 cstage[WG_BLOCK / 64][WG_SCAN_STAGED];
+    uint2* cs = cstage[threadIdx.x >> 6];
+    const bool staged = cd.nG <= WG_SCAN_STAGED;
 
     int vi = 2 * lane;                                // this lane's first vector of the current iteration
     uint4 c0 = rv[vi < vlast ? vi : vlast], c1 = rv[vi + 1 < vlast ? vi + 1 : vlast];
@@ -231,11 +240,21 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int
         const uint32_t it = wg_wave_incl_scan_dpp_u32(tt);
         // (one 8-byte store from every 8th lane.  Round 3: the same store with a non-temporal hint measured 0.432 against 0.434 ms for
         // hg19 x 32 with islands — no difference, the hint is not used)
-        if (((A6 + off) & (WG_CARRY_G - 1)) == 0 && rel0 > 0 && rel0 < len)
-            carry[(A6 + off) >> WG_CARRY_SHIFT] = make_uint2(run_m + (im - tm), run_t + (it - tt));
+        if (((A6 + off) & (WG_CARRY_G - 1)) == 0 && rel0 > 0 && rel0 < len) {
+            const uint2 cv = make_uint2(run_m + (im - tm), run_t + (it - tt));
+            if (staged) cs[(A6 + off) >> WG_CARRY_SHIFT] = cv; else carry[(A6 + off) >> WG_CARRY_SHIFT] = cv;
+        }
         run_m += (uint32_t)__builtin_amdgcn_readlane((int)im, 63);
         run_t += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
         c0 = m0; c1 = m1; vi = vn;
+    }
+    if (staged) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int g = 1 + lane; g < cd.nG; g += 64) {
+            const int rel0 = (g << WG_CARRY_SHIFT) - A6 - head;          // chunk-relative first site of group g: stored above iff inside the chunk
+            if (rel0 > 0 && rel0 < len) carry[g] = cs[g];
+        }
     }
     if (bad_rel != 0x7fffffff)
         atomicMin(&st->first_bad, ((unsigned long long)s << 40) | (unsigned long long)(cd.start0 + bad_rel));
