@@ -52,6 +52,11 @@ def emu_scan_carries(row, start0, ln):
             if ((A6 + off) & (CARRY_G - 1)) == 0 and 0 < rel0 < ln:
                 carry[(A6 + off) >> CARRY_SHIFT] = run + incl[lane] - tot[lane]
         run += incl[63]
+    # round 3: the carries are staged in LDS and written after the loop by lanes that decide from the group number alone which entries
+    # the loop has stored (k_scan's flush): that rule must select exactly the entries written above
+    for g in range(1, nG):
+        rel0 = (g << CARRY_SHIFT) - A6 - head
+        assert (0 < rel0 < ln) == (carry[g, 0] >= 0), (start0, ln, g, rel0, carry[g])
     return carry
 
 def emu_stage_row(row, carry, start0, ln, A, cnt, x0=0):
