@@ -748,3 +748,31 @@ def test_17_lean_step_in_the_narrow_batches_of_a_wide_job(monkeypatch):
                 for c, (a, b) in enumerate(zip(got, want)):
                     assert a.tolist() == b.tolist(), 'pcount %r max_cpg %d max_bp %d lean %s chunk [%d,+%d): %s' % (pcount, max_cpg, max_bp, wlean, starts[c], lens[c], _first_diff(a, b))
         monkeypatch.delenv('WGBSSEG_DP_WLEAN')
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 18. carries of k_scan: staged in LDS for a chunk of up to 512 carry groups, stored directly beyond (round 3)
+# ---------------------------------------------------------------------------------------------------------
+def test_18_carries_staged_in_lds_and_stored_directly_in_one_batch():
+    """k_scan keeps the carries of a row in LDS (512 groups of 128 sites) and writes them when the row is done; a chunk of more groups
+    — more than 65,000 sites — stores them from inside its loop.  One batch holds both kinds, at offsets off the vector grid, with
+    windows of 300 sites (wide scoring tiles: the consumers of the carries); borders == oracle."""
+    rng = np.random.default_rng(1800)
+    n = 70400
+    loci = (np.cumsum(rng.integers(1, 4, n)) + 5000).astype(np.uint32)
+    slices = []
+    for _ in range(2):
+        cov = rng.integers(0, 256, n)
+        cov[rng.random(n) < 0.1] = 0
+        meth = np.minimum(cov, rng.integers(0, 256, n))
+        slices.append(np.stack([meth, cov], axis=1).astype(np.uint8))
+    chunks = [(7, 70001), (100, 60000), (0, 65536), (129, 65409), (3, 300)]          # 548, 470, 512, 512 and 3 carry groups
+    starts, lens = [c[0] for c in chunks], [c[1] for c in chunks]
+    want = oracle.segment_chunks(slices, loci, starts, lens, 15.0, 300, 10**6, threads=os.cpu_count() or 1)
+    with _lib.Segmenter(0) as sg:
+        sg.set_betas(slices)
+        sg.set_loci(loci)
+        got = sg.segment_chunks(starts, lens, 15.0, 300, 10**6)
+        assert sg.timings()['max_window'] == 300
+    for c, (a, b) in enumerate(zip(got, want)):
+        assert a.tolist() == b.tolist(), 'chunk [%d,+%d): %s' % (starts[c], lens[c], _first_diff(a, b))
