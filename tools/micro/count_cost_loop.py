@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """VALU / SALU / LDS instruction counts of the loops of k_cost<TI, FAST, SPLIT> in the gfx950 ISA (no GPU needed):
-    python tools/micro/count_cost_loop.py [TI] [FAST] [SPLIT] [--show] [--all] [--json PATH]
+    python tools/micro/count_cost_loop.py [TI] [FAST] [SPLIT] [ONEG] [--show] [--all] [--json PATH]
 compiles csrc/wgbsseg.hip to assembly (device only) and lists every loop of the kernel; the sample loop is the one with the
 most fp64 instructions (four evaluations per trip, the rare exact path inside it behind s_cbranch_execz).
 
@@ -19,7 +19,7 @@ with the issue cycles per wavefront instruction of each class, written with the 
 import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-args = [a for a in sys.argv[1:] if not a.startswith('--')]
+args = [a for a in sys.argv[1:] if not a.startswith('-')]
 jpath = sys.argv[sys.argv.index('--json') + 1] if '--json' in sys.argv else None
 if jpath in args: args.remove(jpath)
 ti = args[0] if len(args) > 0 else '64'
@@ -27,11 +27,12 @@ fast = args[1] if len(args) > 1 else '2'
 split = args[2] if len(args) > 2 else '0'
 out = os.path.join(ROOT, 'tools', 'micro', '_build', 'w.s')
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-S',
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-S'] + [a for a in sys.argv[1:] if a.startswith('-D')] + [
                        '--cuda-device-only', os.path.join(ROOT, 'wgbs_tools_amd', 'csrc', 'wgbsseg.hip'), '-o', out],
                       stderr=subprocess.DEVNULL)
 lines = open(out).read().split('\n')
-name = '_Z6k_costILi%sELi%sELi%sEE' % (ti, fast, split)
+oneg = args[3] if len(args) > 3 else '1'          # one sample group (k_cost<.., true>: the x32 bench's form)
+name = '_Z6k_costILi%sELi%sELi%sELb%sEE' % (ti, fast, split, oneg)
 s = [i for i, l in enumerate(lines) if l.startswith(name) and ':' in l][0]
 e = [i for i in range(s, len(lines)) if lines[i].strip().startswith('.Lfunc_end')][0]
 body = lines[s:e]

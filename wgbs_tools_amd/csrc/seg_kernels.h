@@ -31,6 +31,9 @@
                                     // that is a multiple of WG_CARRY_G inside the chunk, plus (group 0) at the chunk start itself
 static_assert(WG_CARRY_SHIFT >= 4 && WG_CARRY_SHIFT <= 10, "k_scan: a lane vector is 16 sites, an iteration 1024");
 #define WG_BLOCK        256
+#ifndef WG_COST_ILP
+#define WG_COST_ILP     1           // evaluations of the narrow / medium scoring tiles that share one guard-band branch (1, 2 or 4; A/B builds: tools/build_variants.sh)
+#endif
 #define WG_WIN_TILE     1024        // sites per k_window workgroup
 #define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)
 #define WG_TRACE_WIN    32768       // back-pointers staged in LDS by k_trace (64 KiB)
@@ -816,7 +819,7 @@ __device__ __forceinline__ void wg_stage_local_rows8(uint32_t* __restrict__ Et, 
 // a narrow tile (tile-local packed prefixes from the raw bytes, one subtraction per block and sample, the short division core)
 // where the wide tiles spent two carry-seeded scans per sample and end tile and ran at half the narrow tiles' rate.  The LDS row
 // strides are compile-time constants: the sample loop is unrolled by four with the row offsets in the instructions' offset fields.
-template <int TI, int FAST, int SPLIT>      // FAST = wg_term_mode(pseudo count)
+template <int TI, int FAST, int SPLIT, bool ONEG>      // FAST = wg_term_mode(pseudo count); ONEG: every sample of the job in LDS at once (one sample group)
 __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, CostArgs A, const TileDesc* __restrict__ tiles,
                                                    int64_t n_tiles, double* __restrict__ cost, int64_t n_tiles_padded)
 {
@@ -935,8 +938,10 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     // order of segmentor.cpp:120-136.
     const float pc = A.pc, pc2 = A.pc2;
     double* cb = cost + SV.cbase[(int64_t)SV.stage * nC + c];
-    // TI = 128 tiles (up to 7680 blocks) are only planned when all samples fit LDS at once: one group, no partial sums
-    constexpr bool ONEGROUP = TI > 64;
+    // One sample group (ONEG: the host launches this form when NS >= the job's samples; TI = 128 tiles — up to 7680 blocks — are only
+    // planned then): no partial sums across groups, and the 32 registers of their array are free (x 32: 95 -> 63 VGPRs)
+    static_assert(TI <= 64 || ONEG, "128-start tiles hold every sample at once");
+    constexpr bool ONEGROUP = ONEG;
     double accR[ONEGROUP ? 1 : WG_PAIR_CAP / WG_BLOCK];  // partial sums of this thread's blocks across sample groups
     for (int g0 = 0; g0 < J.n_samples; g0 += A.NS) {
         const int ns = (J.n_samples - g0 < A.NS) ? J.n_samples - g0 : A.NS;
@@ -991,6 +996,37 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                     else acc += term((float)(d & 0xffffu), (float)(d >> 16));
                 };
                 int sl = 0;
+#if WG_COST_ILP > 1
+                // WG_COST_ILP evaluations as straight-line code — the LDS reads of the group first, the common paths side by side — and
+                // ONE branch for their guard bands (each evaluation's own branch kept its dependent chain, LDS round trips and wait
+                // states apart from the next one's); the terms are still added in file order
+                if (KY) {
+                    auto group = [&](int s0) {
+                        uint32_t d[WG_COST_ILP];
+                        double sm[WG_COST_ILP];
+                        float r[WG_COST_ILP];
+#pragma unroll
+                        for (int e = 0; e < WG_COST_ILP; e++) d[e] = Ep[(s0 + e) * KS] - Sp[(s0 + e) * KS];
+#pragma unroll
+                        for (int e = 0; e < WG_COST_ILP; e++) sm[e] = wg_term_sum_ks<DIVS>((float)(d[e] & 0xffffu), (float)(d[e] >> 16), pc, pc2, iy0, ky0);
+                        bool any = false;
+#pragma unroll
+                        for (int e = 0; e < WG_COST_ILP; e++) { r[e] = (float)sm[e]; any |= wg_in_guard_band(sm[e], WG_GUARD_ULPS_KS); }
+                        if (any) {
+#pragma unroll
+                            for (int e = 0; e < WG_COST_ILP; e++)
+                                if (wg_in_guard_band(sm[e], WG_GUARD_ULPS_KS)) {
+                                    uint32_t dd = d[e];
+                                    asm volatile("" : "+v"(dd));                 // (nothing of the common path is reused: it need not stay in registers)
+                                    r[e] = wg_sample_term_pcpos_ks<DIVS>((float)(dd & 0xffffu), (float)(dd >> 16), pc, pc2, iy0, ky0, &g_wg_tables);
+                                }
+                        }
+#pragma unroll
+                        for (int e = 0; e < WG_COST_ILP; e++) acc += (double)r[e];
+                    };
+                    for (; sl + 4 <= ns; sl += 4) { for (int e0 = 0; e0 < 4; e0 += WG_COST_ILP) group(sl + e0); }
+                } else
+#endif
                 for (; sl + 4 <= ns; sl += 4) { one(sl); one(sl + 1); one(sl + 2); one(sl + 3); }
                 for (; sl < ns; sl++) one(sl);
             }

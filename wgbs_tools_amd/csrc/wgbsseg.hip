@@ -530,7 +530,10 @@ template <int TI, int FAST, int SPLIT>
 hipError_t launch_cost(const JobView& v, const StageView& sv, const CostArgs& a, const TileDesc* td, int64_t tiles, double* cost, size_t lds, hipStream_t s)
 {
     const int64_t padded = round_up(tiles, 8 * (int64_t)a.xcd_group);      // whole groups for every XCD; workgroups behind the last tile leave at once
-    hipLaunchKernelGGL((k_cost<TI, FAST, SPLIT>), dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, td, tiles, cost, padded);
+    if (TI > 64 || a.NS >= v.n_samples)      // every sample in LDS at once: the form without partial sums across sample groups
+        hipLaunchKernelGGL((k_cost<TI, FAST, SPLIT, true>), dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, td, tiles, cost, padded);
+    else
+        hipLaunchKernelGGL((k_cost<(TI > 64 ? 64 : TI), FAST, SPLIT, false>), dim3((unsigned)padded), dim3(WG_BLOCK), lds, s, v, sv, a, td, tiles, cost, padded);
     return hipGetLastError();
 }
 
@@ -551,10 +554,13 @@ hipError_t launch_cost_ti(int TI, bool wide, const JobView& v, const StageView& 
 template <int FAST>
 hipError_t set_cost_attrs()
 {
-    const void* fns[] = {reinterpret_cast<const void*>(&k_cost<128, FAST, 0>),
-                         reinterpret_cast<const void*>(&k_cost<64, FAST, 0>), reinterpret_cast<const void*>(&k_cost<32, FAST, 0>),
-                         reinterpret_cast<const void*>(&k_cost<16, FAST, 0>), reinterpret_cast<const void*>(&k_cost<WG_WIDE_TS, FAST == 3 ? 2 : FAST, 1>),
-                         reinterpret_cast<const void*>(&k_cost<WG_MEDIUM_TS, FAST, 2>)};
+    const void* fns[] = {reinterpret_cast<const void*>(&k_cost<128, FAST, 0, true>),
+                         reinterpret_cast<const void*>(&k_cost<64, FAST, 0, true>), reinterpret_cast<const void*>(&k_cost<32, FAST, 0, true>),
+                         reinterpret_cast<const void*>(&k_cost<16, FAST, 0, true>), reinterpret_cast<const void*>(&k_cost<WG_WIDE_TS, FAST == 3 ? 2 : FAST, 1, true>),
+                         reinterpret_cast<const void*>(&k_cost<WG_MEDIUM_TS, FAST, 2, true>),
+                         reinterpret_cast<const void*>(&k_cost<64, FAST, 0, false>), reinterpret_cast<const void*>(&k_cost<32, FAST, 0, false>),
+                         reinterpret_cast<const void*>(&k_cost<16, FAST, 0, false>), reinterpret_cast<const void*>(&k_cost<WG_WIDE_TS, FAST == 3 ? 2 : FAST, 1, false>),
+                         reinterpret_cast<const void*>(&k_cost<WG_MEDIUM_TS, FAST, 2, false>)};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
