@@ -69,6 +69,7 @@ def parse():
     ap.add_argument('--pcount', type=float, default=15.0)
     ap.add_argument('--islands', action='store_true', help='add CpG islands to the synthetic loci (windows of several hundred sites; not the BASELINE workload)')
     ap.add_argument('--block-sums', type=int, default=1, help='also time the block reduction over the blocks just found (0: skip)')
+    ap.add_argument('--scan-carries', type=int, default=1, help='also time the prefix-sum pass with carries (k_scan) on the chunk grid (0: skip)')
     ap.add_argument('--matrix', type=int, default=1, help='also run a few steps at x8, x200 and x512 (1 GPU only; 0: skip)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='wall-time budget of the CPU baseline runs (0: skip)')
     ap.add_argument('--e2e', type=int, default=1, help='also time the CLI end to end on page-cached files (1 GPU only; 0: skip)')
@@ -253,7 +254,7 @@ def keyed_profile(pattern, sha, **match):
             rec = json.load(open(f))
         except Exception:
             continue
-        if rec.get('csrc_sha') == sha and all(rec.get(k) == v for k, v in match.items()):
+        if rec.get('csrc_sha') == sha and all(rec.get(k, False if v is False else None) == v for k, v in match.items()):
             rec['_file'] = op.basename(f)
             return rec
     return None
@@ -450,6 +451,31 @@ def main():
                                                         'raw_sums': (alg + 8 * int(bs.size) * args.samples) / (min(times[7:9]) * 1e-3) / 1e9},
                           'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'}
 
+        # the prefix-sum pass PROPER (k_scan: per-sample prefix sums of (meth, cov), a carry per 128 sites, the validation) on this
+        # workload's chunk grid.  A default-parameter job never runs it (its windows stay <= 252 sites: no wide tile reads carries, the
+        # read-only k_validate is its scan pass, `roofline_scan` below); jobs with CpG islands / deep windows do.  north_star names
+        # this pass, so it is timed here on the BASELINE workload with carries forced (wgbsseg_scan_only, want_carry = 1).
+        scan_carries = None
+        if args.scan_carries and seg is not None and not multi:
+            grid = parallel.chunk_grid(regions, args.chunk)
+            g_st = np.array([s0 - 1 for _, s0, _ in grid], dtype=np.int64)
+            g_ln = np.array([e0 - s0 for _, s0, e0 in grid], dtype=np.int32)
+            sc_ms, sc_bytes, sc_carry = seg.scan_only(g_st, g_ln, repeat=20, want_carry=True)
+            trc = keyed_profile('*scan_traffic*.json', sha, kernel='k_scan', forced_carries=True)
+            sc_traffic, sc_note = None, 'traffic: no PMC pass of this source state (csrc_sha %s) for k_scan with forced carries under profiles/' % sha
+            if trc and abs(trc['algorithmic_bytes'] - sc_bytes) <= 0.001 * sc_bytes:
+                sc_traffic = trc['traffic_bytes']
+                sc_note = 'traffic (bytes per launch) = 2 x FETCH_SIZE + WRITE_SIZE from profiles/%s (gfx950 FETCH_SIZE x2 correction)' % trc['_file']
+            scan_carries = {'kernel': 'k_scan with carries (coalesced 32 B per lane loads, per-sample prefix sums of (meth, cov) by SWAR + DPP wave scans, one carry per 128 sites '
+                                      'staged in LDS and written as full-wavefront stores, meth<=cov validation): segmentor.cpp:164-190 + the scan of SURVEY (a-spec)',
+                            'bound': 'hbm', 'achieved': sc_bytes / (sc_ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                            'frac': sc_bytes / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'traffic': sc_traffic,
+                            'algorithmic_bytes_per_launch': int(sc_bytes), 'carry_bytes_written_per_launch': int(sc_carry),
+                            'traffic_over_algorithmic': None if sc_traffic is None else sc_traffic / sc_bytes,
+                            'avg_launch_ms': sc_ms, 'launches_timed': 20, 'chunks': len(grid),
+                            'note': 'HIP events around 20 back-to-back launches on the kernel\'s stream, after one warm-up launch; carries forced on the whole chunk grid of this '
+                                    'workload (the step above does not need them); ' + sc_note}
+
         ms_step = dt / args.steps * 1e3
         value = args.sites / (dt / args.steps)
         # the scan pass: the launch of the batch that holds the chunks (one per step); the follow-up batches (a few hundred
@@ -462,7 +488,7 @@ def main():
         scan_kernel = 'k_scan' if stats_wide else 'k_validate'
         # HBM traffic of the scan launch from the PMC counters (separate rocprofv3 passes, tools/pmc_scan_traffic.py): only a file
         # made from THIS source state, for this kernel and these algorithmic bytes, is reported
-        tr = keyed_profile('*scan_traffic*.json', sha, kernel=scan_kernel) if (not multi and not group_mode) else None
+        tr = keyed_profile('*scan_traffic*.json', sha, kernel=scan_kernel, forced_carries=False) if (not multi and not group_mode) else None
         traffic, traffic_note = None, 'traffic: no PMC pass of this source state (csrc_sha %s) for %s on this workload under profiles/' % (sha, scan_kernel)
         if tr and abs(tr['algorithmic_bytes'] - acc['scan_main_bytes']) <= 0.001 * acc['scan_main_bytes']:
             traffic = tr['traffic_bytes']
@@ -533,6 +559,7 @@ def main():
                               'all_launches': {'count': acc['scan_launches'], 'bytes': acc['scan_bytes'], 'ms': acc['scan_ms'],
                                                'GB/s': scan_all_gbs},
                               'note': 'rank 0 / share 0, HIP events on the kernel stream inside the timed steps; ' + traffic_note},
+            'roofline_scan_carries': scan_carries,
             'block_sums': block_sums,
             'device_ms_per_step': {k: acc[k] / args.steps for k in ('scan_ms', 'window_ms', 'cost_ms', 'dp_ms', 'trace_ms', 'total_ms')},
         }
@@ -585,6 +612,36 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as e:
                     rows.append({'samples': ns, 'failed': repr(e)})
+            # the genome WITH CpG islands (windows up to ~250 sites and a few beyond: narrow + medium + wide tiles, k_scan with carries, the
+            # 32-step recurrence), x32: the shape of a real genome, one row
+            try:
+                loci_i = synth.synth_loci(SEED, sizes, islands=True)
+                b2, pitch2 = device_rows(0, args.sites, local, samples=32)
+                s2 = _lib.Segmenter(local)
+                s2.set_betas_device(b2.data_ptr(), 32, pitch2, args.sites, keepalive=b2)
+                s2.set_loci(loci_i)
+                k = 5
+                s2.segment_regions(st, en, args.chunk, args.pcount, max_cpg, args.max_bp, copy=False)
+                torch.cuda.synchronize()
+                a2, t1 = None, time.perf_counter()
+                for _ in range(k):
+                    r2, _st = s2.segment_regions(st, en, args.chunk, args.pcount, max_cpg, args.max_bp, copy=False)
+                    a2 = accumulate(a2, s2.timings())
+                torch.cuda.synchronize()
+                d2 = (time.perf_counter() - t1) / k
+                ev2 = a2['evals'] / (a2['cost_ms'] * 1e-3)
+                rows.append({'samples': 32, 'islands': True, 'steps': k, 'ms_per_step': d2 * 1e3, 'value': args.sites / d2, 'unit': 'CpG-sites/s',
+                             'blocks': int(sum(len(r) - 1 for r in r2)), 'max_window': a2['max_window'],
+                             'cost_ms': a2['cost_ms'] / k, 'dp_ms': a2['dp_ms'] / k, 'scan_ms': a2['scan_main_ms'] / k,
+                             'scan_kernel': 'k_scan (carries)' if a2['max_window'] > 252 else 'k_validate',
+                             'evals_per_s': ev2, 'roofline_frac': ev2 * FLOP_PER_EVAL / FP64_VALU_PEAK,
+                             'scan_GB_per_s': a2['scan_main_bytes'] / (a2['scan_main_ms'] / k * 1e-3) / 1e9,
+                             'scan_frac_of_hbm_peak': a2['scan_main_bytes'] / (a2['scan_main_ms'] / k * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                s2.close()
+                del b2, s2
+                torch.cuda.empty_cache()
+            except Exception as e:
+                rows.append({'samples': 32, 'islands': True, 'failed': repr(e)})
             out['matrix'] = {'what': 'the same whole-genome step at the other sample counts of the metric (inputs resident, 1 warm-up, timed with '
                                      'synchronize + perf_counter around the steps like the main run)', 'rows': rows}
         print(json.dumps(out), flush=True)

@@ -246,9 +246,14 @@ int wgbsseg_segment_chunks_host(const uint8_t* betas, int64_t n_samples, int64_t
 int wgbsseg_prefix_sums(wgbsseg_ctx* ctx, int64_t start0, int64_t len, uint32_t* out, char* err, size_t errlen);
 
 /* The scan/validation pass alone over the given chunks (bandwidth benchmark): runs it `repeat` times and
- * returns the mean HIP-event time per launch in *ms_per_launch and the algorithmic bytes per launch. */
+ * returns the mean HIP-event time per launch in *ms_per_launch and the algorithmic bytes per launch (2 bytes per
+ * sample and site read).  want_carry 0: the read-only pass of a job without wide scoring tiles (k_validate: what is left
+ * of segmentor.cpp:164-190 there is the read and its `meth > cov` abort); 1: the prefix-sum pass proper (k_scan: per-sample
+ * prefix sums of (meth, cov), one carry per 128 sites written, the same validation) as jobs with windows beyond 252 sites
+ * run it; *carry_bytes_per_launch = the carries it writes (implementation traffic, not credited as algorithmic). */
 int wgbsseg_scan_only(wgbsseg_ctx* ctx, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
-                      int repeat, double* ms_per_launch, int64_t* bytes_per_launch, char* err, size_t errlen);
+                      int repeat, int want_carry, double* ms_per_launch, int64_t* bytes_per_launch,
+                      int64_t* carry_bytes_per_launch, char* err, size_t errlen);
 
 /*
  * Block sums: (#meth, #cov) of every block in every resident sample — the reduction of the reference's

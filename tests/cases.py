@@ -98,6 +98,52 @@ CHUNK_CASES = {
     'n200_pcount0':   dict(n=1000, a=170000, samples=list(range(200)), pcount=0.0, max_cpg=1000, max_bp=2000),
 }
 
+# Loci that are NOT ascending inside a chunk (hand-made genomes, a chunk laid across two chromosomes): the reference bars an extension
+# whose locus lies behind the start's or more than max_bp ahead of it and leaves that site out of the start's running sums
+# (segmentor.cpp:114-117).  `disorder` names what is done to the ascending loci of the base spec (disorder_loci below).
+DISORDER_CASES = {
+    'one_step_back':   dict(n=600, a=1000, samples=[0, 1, 2], pcount=15.0, max_cpg=50, max_bp=700, disorder=('step_back', 200, 1)),
+    'back_run':        dict(n=700, a=3000, samples=[0, 1], pcount=15.0, max_cpg=1000, max_bp=2000, disorder=('descending_run', 300, 40)),
+    'two_chromosomes': dict(n=900, a=5000, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=2000, disorder=('restart', 450, 5)),
+    'restart_pcount0': dict(n=500, a=7000, samples=[0, 1], pcount=0.0, max_cpg=60, max_bp=2000, disorder=('restart', 123, 5)),
+    'swapped_pairs':   dict(n=800, a=9000, samples=[0], pcount=0.5, max_cpg=1000, max_bp=2000, disorder=('swap_pairs', 64, 16)),
+    'shuffled_dense':  dict(n=400, a=0, samples=[0, 1, 2], pcount=15.0, max_cpg=300, max_bp=500, loci='dense', disorder=('shuffle_window', 100, 200)),
+    'equal_then_back': dict(n=600, a=0, samples=[0, 1], pcount=15.0, max_cpg=1000, max_bp=2000, loci='equal_runs', disorder=('step_back', 301, 3)),
+    'back_at_the_end': dict(n=300, a=11000, samples=[0, 1, 2, 3], pcount=15.0, max_cpg=1000, max_bp=2000, disorder=('step_back', 299, 1)),
+    'near_int_max':    dict(n=300, a=12000, samples=[0, 1], pcount=15.0, max_cpg=1000, max_bp=2000, disorder=('huge_then_small', 150, 0)),
+    'n33_restart':     dict(n=500, a=13000, samples=list(range(33)), pcount=15.0, max_cpg=1000, max_bp=2000, disorder=('restart', 250, 5)),
+}
+
+
+def disorder_loci(loci, how):
+    """The loci of a DISORDER_CASES spec: ascending `loci` with one stretch put out of order."""
+    kind, at, arg = how
+    out = loci.astype(np.int64).copy()
+    if kind == 'step_back':              # `arg` sites from `at` on lie 1000 bp (or as far as the values allow) behind their place
+        out[at:at + arg] -= min(1000, int(out[at]) - 1)
+    elif kind == 'descending_run':       # a run of `arg` sites in descending order
+        out[at:at + arg] = out[at:at + arg][::-1]
+    elif kind == 'restart':              # the positions start again at `arg` (a second chromosome inside the chunk)
+        out[at:] -= out[at] - arg
+    elif kind == 'swap_pairs':           # every `arg`-th pair from `at` on swapped
+        for x in range(at, len(out) - 1, arg):
+            out[x], out[x + 1] = out[x + 1], out[x]
+    elif kind == 'shuffle_window':       # `arg` sites from `at` on in a seeded random order
+        perm = np.random.default_rng(at * 1000 + arg).permutation(arg)
+        out[at:at + arg] = out[at:at + arg][perm]
+    elif kind == 'huge_then_small':      # positions up to INT_MAX (what load_dists' std::stoi takes, segmentor.cpp:44) in the first half, small ones after: the unsigned difference wraps (:114)
+        out[:at] += 2147483000 - int(out[at - 1])
+    else:
+        raise ValueError(kind)
+    assert out.min() >= 0 and out.max() < 2 ** 32
+    return out.astype(np.uint32)
+
+
+def build_disorder_case(spec):
+    slices, loci = build_case({k: v for k, v in spec.items() if k != 'disorder'})
+    return slices, disorder_loci(loci, spec['disorder'])
+
+
 # Chunks INSIDE a larger resident world (the way the driver calls the library: `-s start0 -n len` on whole-genome files), placed on the
 # kernels' boundaries: carries of the scan pass sit at every 128th ABSOLUTE site, scoring tiles and units begin at chunk-relative
 # multiples of 16 / 64 / 128.  `ends` are absolute end sites, `lens` chunk lengths: every (end - len, len) with len <= end is a chunk.

@@ -479,14 +479,14 @@ def test_11_argument_errors(seg):
         seg.segment_chunks([spec['n'] - 10], [11], 15.0, 50, 700)           # runs past the file
     with pytest.raises(_lib.SegmentorError):
         seg.segment_chunks([0], [0], 15.0, 50, 700)                          # empty chunk (segment.py:44 asserts)
-    # loci going backwards inside a chunk (a chunk crossing chromosomes)
+    # loci going backwards inside a chunk (a chunk crossing chromosomes) are no error: the reference bars the extension and carries on
+    # (segmentor.cpp:114-117), and so does the plain path (test_19)
     slices, loci = cases.build_case(spec)
     loci2 = loci.copy()
     loci2[200:] -= loci2[200] - 5
     seg.set_loci(loci2)
-    with pytest.raises(_lib.SegmentorError) as e:
-        seg.segment_chunks([0], [spec['n']], 15.0, 50, 700)
-    assert e.value.code == _lib.E_LOCI_ORDER
+    got = seg.segment_chunks([0], [spec['n']], 15.0, 50, 700)[0]
+    assert got.tolist() == oracle.segment_chunk(slices, loci2, 15.0, 50, 700).tolist()
 
 
 def test_12_device_generator_equals_numpy_generator():
@@ -776,3 +776,61 @@ def test_18_carries_staged_in_lds_and_stored_directly_in_one_batch():
         assert sg.timings()['max_window'] == 300
     for c, (a, b) in enumerate(zip(got, want)):
         assert a.tolist() == b.tolist(), 'chunk [%d,+%d): %s' % (starts[c], lens[c], _first_diff(a, b))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# loci that are not ascending inside a chunk (round 4): segmentor.cpp:114-117 bars the extension and leaves the site out of
+# the start's running sums; csrc/plain_dp.h follows the reference's loops as written for such chunks
+# ------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def golden_disorder():
+    import json
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'disorder_cases.json')) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('name', sorted(cases.DISORDER_CASES))
+def test_19_non_ascending_loci_match_the_reference(seg, name, golden_disorder):
+    g = golden_disorder[name]
+    spec = cases.DISORDER_CASES[name]
+    slices, loci = cases.build_disorder_case(spec)
+    assert cases.case_checksum(slices, loci) == g['input_crc32']
+    seg.set_betas(slices)
+    seg.set_loci(loci)
+    got = seg.segment_chunks([0], [spec['n']], spec['pcount'], spec['max_cpg'], spec['max_bp'])[0]
+    assert got.tolist() == g['borders'], _first_diff(got, g['borders'])                # the reference binary's own output
+    assert got.tolist() == oracle.segment_chunk(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp']).tolist()
+    if oracle.have_ref():
+        assert got.tolist() == oracle.ref_segment_arrays(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp']).tolist()
+
+
+def test_19b_ordered_and_disordered_chunks_in_one_batch(seg):
+    """A batch of chunks inside a resident world, some of them across a place where the positions start again: every chunk as the
+    reference computes it, in the caller's order; the ring of the plain path forced to wrap (a deep window on a long chunk)."""
+    spec = dict(n=9000, a=20000, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=2000)
+    slices, loci = cases.build_case(spec)
+    loci = loci.astype(np.int64)
+    loci[3000:] -= loci[3000] - 7            # a second chromosome from site 3000
+    loci[6100:6110] = loci[6100:6110][::-1]  # and a descending run
+    loci = loci.astype(np.uint32)
+    seg.set_betas(slices)
+    seg.set_loci(loci)
+    starts = [0, 2500, 3000, 2999, 5000, 6000, 8000, 6105]
+    lens = [2500, 1000, 2000, 2, 1000, 300, 1000, 1]
+    for pcount, max_cpg, max_bp in [(15.0, 1000, 2000), (0.0, 40, 700), (0.5, 3000, 100000)]:
+        got = seg.segment_chunks(starts, lens, pcount, max_cpg, max_bp)
+        want = oracle.segment_chunks(slices, loci, starts, lens, pcount, max_cpg, max_bp, threads=4)
+        for c, (a, b) in enumerate(zip(got, want)):
+            assert a.tolist() == b.tolist(), (pcount, max_cpg, max_bp, starts[c], lens[c], _first_diff(a, b))
+
+
+def test_19c_invalid_counts_in_a_disordered_chunk(seg):
+    spec = cases.DISORDER_CASES['two_chromosomes']
+    slices, loci = cases.build_disorder_case(spec)
+    slices = [s.copy() for s in slices]
+    slices[1][700] = (9, 3)
+    seg.set_betas(slices)
+    seg.set_loci(loci)
+    with pytest.raises(_lib.SegmentorError) as e:
+        seg.segment_chunks([0], [spec['n']], spec['pcount'], spec['max_cpg'], spec['max_bp'])
+    assert e.value.code == _lib.E_METH_GT_COV

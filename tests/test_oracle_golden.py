@@ -140,3 +140,22 @@ def test_debug_outputs_consistent():
         ks = np.arange(max(0, i + 1 - spec['max_cpg']), i + 1)
         v = M[ks] + band[ks, i - ks]
         assert M[i + 1] == v.max() and T[i + 1] == ks[np.argmax(v)]
+
+
+def test_restatement_on_non_ascending_loci_matches_reference_golden():
+    """Loci that go backwards inside the chunk: the reference bars the extension and leaves the site out of the start's running sums
+    (segmentor.cpp:114-117); goldens printed by the reference binary (tests/golden/make_golden_disorder.py)."""
+    import json
+    import os.path as op
+    with open(op.join(op.dirname(__file__), 'golden', 'disorder_cases.json')) as f:
+        golden = json.load(f)
+    assert sorted(golden) == sorted(cases.DISORDER_CASES)
+    for name, g in golden.items():
+        spec = cases.DISORDER_CASES[name]
+        slices, loci = cases.build_disorder_case(spec)
+        assert cases.case_checksum(slices, loci) == g['input_crc32'], name
+        assert np.any(np.diff(loci.astype(np.int64)) < 0), name
+        b = oracle.segment_chunk(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp'])
+        assert b.tolist() == g['borders'], name
+        if oracle.have_ref():
+            assert oracle.ref_segment_arrays(slices, loci, spec['pcount'], spec['max_cpg'], spec['max_bp']).tolist() == g['borders'], name

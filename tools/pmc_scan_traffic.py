@@ -15,7 +15,8 @@ import sys
 
 ROOT = op.dirname(op.dirname(op.abspath(__file__)))
 OUT = op.join(ROOT, 'gpurun_out')
-EXTRA = sys.argv[1:]            # further bench.py arguments (e.g. --islands: then the pass is k_scan with its carries)
+FORCED = '--forced-carries' in sys.argv[1:]     # the prefix-sum pass with carries forced on the workload's chunk grid (bench.py: roofline_scan_carries)
+EXTRA = [a for a in sys.argv[1:] if a != '--forced-carries'] + ['--scan-carries', '1' if FORCED else '0']            # further bench.py arguments (e.g. --islands: then the step's own pass is k_scan with its carries)
 
 
 def one_pass(counter):
@@ -29,7 +30,7 @@ def one_pass(counter):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row.get('Kernel_Name', '')
-                if row.get('Counter_Name') != counter or not (name.startswith('k_scan') or name.startswith('k_validate')):
+                if row.get('Counter_Name') != counter or not (name.startswith('k_scan') or (name.startswith('k_validate') and not FORCED)):
                     continue
                 grid = int(row['Grid_Size'])
                 val = float(row['Counter_Value'])
@@ -52,7 +53,7 @@ def main():
                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=240)
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     bl = json.loads(line)
-    alg = int(bl['roofline_scan']['algorithmic_bytes_per_launch'])
+    alg = int(bl['roofline_scan_carries' if FORCED else 'roofline_scan']['algorithmic_bytes_per_launch'])
     sys.path.insert(0, ROOT)
     from wgbs_tools_amd import build
     rec = {'kernel': kname, 'csrc_sha': build.source_hash(), 'workload': bl['config']['workload'] + ': main batch (chunks + upfront patches; the patches lie inside the chunks and are not read again)',
@@ -60,8 +61,11 @@ def main():
            'grid_size': gf, 'FETCH_SIZE_KB': fetch, 'WRITE_SIZE_KB': write,
            'correction': 'MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane) -> doubled; WRITE_SIZE taken as is; units KB = 1024 B',
            'read_bytes': 2 * fetch * 1024, 'write_bytes': write * 1024, 'traffic_bytes': 2 * fetch * 1024 + write * 1024,
-           'algorithmic_bytes': alg, 'traffic_over_algorithmic': (2 * fetch * 1024 + write * 1024) / alg}
-    json.dump(rec, open(op.join(OUT, 'scan_traffic%s.json' % ('_islands' if '--islands' in EXTRA else '')), 'w'), indent=1)
+           'algorithmic_bytes': alg, 'traffic_over_algorithmic': (2 * fetch * 1024 + write * 1024) / alg, 'forced_carries': FORCED}
+    if FORCED:
+        rec['workload'] = bl['config']['workload'] + ': the chunk grid, carries forced (wgbsseg_scan_only want_carry = 1; the dispatch with the most bytes of 22)'
+        rec['carry_bytes_written'] = bl['roofline_scan_carries']['carry_bytes_written_per_launch']
+    json.dump(rec, open(op.join(OUT, 'scan_traffic%s.json' % ('_carries' if FORCED else '_islands' if '--islands' in EXTRA else '')), 'w'), indent=1)
     print(json.dumps(rec))
 
 

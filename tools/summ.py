@@ -17,9 +17,12 @@ for f in sys.argv[1:]:
             f.split('/')[-1], d['ms_per_step'], dm['scan_ms'], rs['frac'], dm['window_ms'], dm['cost_ms'],
             rc['evals_per_s'], dm['dp_ms'], dm['trace_ms'], dm['total_ms'], rc['stages'],
             '' if not bs else ' | block_sums %.3f ms %.2f of peak' % (bs['ms_bin_rows'], bs['frac_of_hbm_peak'])))
+        sc = d.get('roofline_scan_carries')
+        if sc:
+            print('    k_scan with carries: %.3f ms, %.2f of peak, traffic %s' % (sc['avg_launch_ms'], sc['frac'], sc['traffic_over_algorithmic']))
         for r in (d.get('matrix') or {}).get('rows', []):
             if 'failed' in r:
                 print('    x%-4d failed: %s' % (r['samples'], r['failed']))
             else:
-                print('    x%-4d %8.3f ms/step  %.3g sites/s | cost %.3f (%.3g ev/s) dp %.3f scan %.3f (%.2f of peak)' % (
-                    r['samples'], r['ms_per_step'], r['value'], r['cost_ms'], r['evals_per_s'], r['dp_ms'], r['scan_ms'], r['scan_frac_of_hbm_peak']))
+                print('    x%-4d%s %8.3f ms/step  %.3g sites/s | cost %.3f (%.3g ev/s) dp %.3f scan %.3f (%.2f of peak)' % (
+                    r['samples'], ' islands' if r.get('islands') else '', r['ms_per_step'], r['value'], r['cost_ms'], r['evals_per_s'], r['dp_ms'], r['scan_ms'], r['scan_frac_of_hbm_peak']))

@@ -135,7 +135,7 @@ def load():
     L.wgbsseg_prefix_sums.restype = i32
     L.wgbsseg_prefix_sums.argtypes = [vp, i64, i64, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_scan_only.restype = i32
-    L.wgbsseg_scan_only.argtypes = [vp, vp, vp, i64, i32, C.POINTER(C.c_double), C.POINTER(i64), C.c_char_p, C.c_size_t]
+    L.wgbsseg_scan_only.argtypes = [vp, vp, vp, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64), C.c_char_p, C.c_size_t]
     L.wgbsseg_get_timings.restype = i32
     L.wgbsseg_get_timings.argtypes = [vp, C.POINTER(Timings)]
     L.wgbsseg_debug_fetch.restype = i64
@@ -353,13 +353,14 @@ class Segmenter:
         _check(self._L.wgbsseg_prefix_sums(self._h, int(start0), int(length), out.ctypes.data, self._err, ERRLEN), self._err)
         return out
 
-    def scan_only(self, start0, lens, repeat=10):
+    def scan_only(self, start0, lens, repeat=10, want_carry=False):
+        """The scan pass alone: (ms per launch, algorithmic bytes per launch[, carry bytes written per launch when want_carry])."""
         start0 = np.ascontiguousarray(start0, dtype=np.int64)
         lens = np.ascontiguousarray(lens, dtype=np.int32)
-        ms, nbytes = C.c_double(0), C.c_int64(0)
-        _check(self._L.wgbsseg_scan_only(self._h, start0.ctypes.data, lens.ctypes.data, start0.size, int(repeat),
-                                         C.byref(ms), C.byref(nbytes), self._err, ERRLEN), self._err)
-        return ms.value, nbytes.value
+        ms, nbytes, cbytes = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        _check(self._L.wgbsseg_scan_only(self._h, start0.ctypes.data, lens.ctypes.data, start0.size, int(repeat), int(bool(want_carry)),
+                                         C.byref(ms), C.byref(nbytes), C.byref(cbytes), self._err, ERRLEN), self._err)
+        return (ms.value, nbytes.value, cbytes.value) if want_carry else (ms.value, nbytes.value)
 
     def block_sums(self, start0, end0, mode=0, min_cov=1):
         """wgbsseg_block_sums over the resident samples: 0-based half-open site ranges -> array [n_samples][n_blocks]

@@ -19,7 +19,7 @@ ARCH = 'gfx950'
 HIPFLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-pthread']
 
 TARGETS = {
-    'libwgbsseg.so': (['wgbsseg.hip'], ['seg_kernels.h', 'wave_prims.h', 'exact_log2.h', 'stitch.h', 'add_loci.h', 'table_io.h', '../../include/wgbsseg.h']),
+    'libwgbsseg.so': (['wgbsseg.hip'], ['seg_kernels.h', 'plain_dp.h', 'wave_prims.h', 'exact_log2.h', 'stitch.h', 'add_loci.h', 'table_io.h', '../../include/wgbsseg.h']),
     'libwgbssynth.so': (['synth.hip'], []),
 }
 

@@ -516,22 +516,6 @@ WG_HD float wg_sample_term_pcpos_ks(float nmeth, float ntotal, float pc, float p
         res = (float)((double)ll + (double)df * wg_log2(1.0 - (double)wg_opaque_f32(p), xt->d_tab, xt->d_tab2));
     return res;
 }
-// The same evaluation in two pieces, for scoring loops that run a GROUP of evaluations as straight-line code and test all their
-// guard bands with ONE branch (k_cost, WG_COST_ILP > 1): wg_term_sum_ks is the common path up to the double sum s (no branch: the
-// optimiser may interleave the dependent chains of the group's evaluations); the caller rounds s to float unless
-// wg_in_guard_band(s, WG_GUARD_ULPS_KS), and then wg_sample_term_pcpos_ks — the whole evaluation again, from the counts: nothing of
-// the common path is kept alive for it — decides.  Bit for bit the results of wg_sample_term_pcpos_ks (same operations, same order).
-template <bool DIVS = false>
-WG_HD double wg_term_sum_ks(float nmeth, float ntotal, float pc, float pc2, const wg_d2* __restrict__ iys0, const wg_d2* __restrict__ kys0)
-{
-    const float p = DIVS ? wg_div_f32_short(nmeth + pc, ntotal + pc2) : wg_div_f32(nmeth + pc, ntotal + pc2);          // :127
-    const double pd = (double)p;
-    const float ll = nmeth * wg_log2f_ks(p, pd, iys0);             // :129-131
-    const float df = wg_opaque_f32(ntotal) - nmeth;
-    const double x = 1.0 - pd;                                     // :132-134
-    return WG_FMA((double)df, wg_fast_log2_ks<false>(x, kys0), (double)ll);
-}
-
 // Rows (exponents k = -(rows-1) .. 0) the two lookup tables need when every block has ntotal <= max_total < 2^21 and the
 // pseudo count is pc >= 1.  In exact arithmetic p and 1 - p are both >= v = pc / (max_total + 2 pc) >= 2^-21.01.  The
 // computed p = fl(fl(nmeth+pc) / fl(ntotal+2pc)) carries three float roundings, a relative error below 3 * 2^-24: the

@@ -31,9 +31,6 @@
                                     // that is a multiple of WG_CARRY_G inside the chunk, plus (group 0) at the chunk start itself
 static_assert(WG_CARRY_SHIFT >= 4 && WG_CARRY_SHIFT <= 10, "k_scan: a lane vector is 16 sites, an iteration 1024");
 #define WG_BLOCK        256
-#ifndef WG_COST_ILP
-#define WG_COST_ILP     1           // evaluations of the narrow / medium scoring tiles that share one guard-band branch (1, 2 or 4; A/B builds: tools/build_variants.sh)
-#endif
 #define WG_WIN_TILE     1024        // sites per k_window workgroup
 #define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)
 #define WG_TRACE_WIN    32768       // back-pointers staged in LDS by k_trace (64 KiB)
@@ -996,37 +993,6 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                     else acc += term((float)(d & 0xffffu), (float)(d >> 16));
                 };
                 int sl = 0;
-#if WG_COST_ILP > 1
-                // WG_COST_ILP evaluations as straight-line code — the LDS reads of the group first, the common paths side by side — and
-                // ONE branch for their guard bands (each evaluation's own branch kept its dependent chain, LDS round trips and wait
-                // states apart from the next one's); the terms are still added in file order
-                if (KY) {
-                    auto group = [&](int s0) {
-                        uint32_t d[WG_COST_ILP];
-                        double sm[WG_COST_ILP];
-                        float r[WG_COST_ILP];
-#pragma unroll
-                        for (int e = 0; e < WG_COST_ILP; e++) d[e] = Ep[(s0 + e) * KS] - Sp[(s0 + e) * KS];
-#pragma unroll
-                        for (int e = 0; e < WG_COST_ILP; e++) sm[e] = wg_term_sum_ks<DIVS>((float)(d[e] & 0xffffu), (float)(d[e] >> 16), pc, pc2, iy0, ky0);
-                        bool any = false;
-#pragma unroll
-                        for (int e = 0; e < WG_COST_ILP; e++) { r[e] = (float)sm[e]; any |= wg_in_guard_band(sm[e], WG_GUARD_ULPS_KS); }
-                        if (any) {
-#pragma unroll
-                            for (int e = 0; e < WG_COST_ILP; e++)
-                                if (wg_in_guard_band(sm[e], WG_GUARD_ULPS_KS)) {
-                                    uint32_t dd = d[e];
-                                    asm volatile("" : "+v"(dd));                 // (nothing of the common path is reused: it need not stay in registers)
-                                    r[e] = wg_sample_term_pcpos_ks<DIVS>((float)(dd & 0xffffu), (float)(dd >> 16), pc, pc2, iy0, ky0, &g_wg_tables);
-                                }
-                        }
-#pragma unroll
-                        for (int e = 0; e < WG_COST_ILP; e++) acc += (double)r[e];
-                    };
-                    for (; sl + 4 <= ns; sl += 4) { for (int e0 = 0; e0 < 4; e0 += WG_COST_ILP) group(sl + e0); }
-                } else
-#endif
                 for (; sl + 4 <= ns; sl += 4) { one(sl); one(sl + 1); one(sl + 2); one(sl + 3); }
                 for (; sl < ns; sl++) one(sl);
             }

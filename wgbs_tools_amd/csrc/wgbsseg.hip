@@ -22,6 +22,7 @@
 
 #include "../../include/wgbsseg.h"
 #include "seg_kernels.h"
+#include "plain_dp.h"
 #include "stitch.h"
 #include "add_loci.h"
 #include "table_io.h"
@@ -596,7 +597,107 @@ namespace {
 typedef std::function<int32_t*(int64_t)> BorderAlloc;       // total border count -> destination (NULL: too small)
 
 int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
-                        const wgbsseg_params* P, const BorderAlloc& alloc, int64_t* borders_off, char* err, size_t errlen)
+                        const wgbsseg_params* P, const BorderAlloc& alloc, int64_t* borders_off, char* err, size_t errlen, bool allow_plain = true);
+
+// One chunk whose loci are not ascending, the reference's loops as written (csrc/plain_dp.h): ascending borders incl. 0 and len.
+int plain_segment_chunk(wgbsseg_ctx* c, int64_t start0, int32_t n, const wgbsseg_params* P, std::vector<int32_t>& borders, char* err, size_t errlen)
+{
+    const int32_t W = (int32_t)std::min<int64_t>(P->max_cpg, n);
+    // rows of the band in flight + the W - 1 rows before it that its steps still read; <= ~1 GB of ring
+    const int64_t budget_rows = std::max<int64_t>((int64_t)W + 255, (1LL << 30) / ((int64_t)W * 8));
+    const int32_t R = (int32_t)std::min<int64_t>(n, budget_rows);
+    const int32_t band = R >= n ? n : R - (W - 1);
+    DevBuf buf, M, T, bad;
+    struct Free { DevBuf& a; DevBuf& b; DevBuf& c; DevBuf& d; ~Free() { a.release(); b.release(); c.release(); d.release(); } } fr{buf, M, T, bad};
+    if (buf.ensure((size_t)W * (size_t)R * 8) != hipSuccess || M.ensure((size_t)(n + 1) * 8) != hipSuccess || T.ensure((size_t)(n + 1) * 4) != hipSuccess ||
+        bad.ensure(8) != hipSuccess) {
+        (void)hipGetLastError();
+        set_err(err, errlen, "out of device memory for the plain recurrence of a chunk with non-ascending loci (%d sites, max_cpg %d)", (int)n, (int)W);
+        return WGBSSEG_E_NOMEM;
+    }
+    JobStatus st = {};
+    st.first_bad = ~0ULL;
+    HIP_TRY(hipMemcpyAsync(bad.p, &st.first_bad, 8, hipMemcpyHostToDevice, c->sA));
+    PlainArgs A = {c->betas, c->pitch, c->n_total, c->n_samples, c->loci, start0, n, W, P->max_bp, P->pseudo_count, P->pseudo_count + P->pseudo_count,
+                   R, buf.as<double>(), M.as<double>(), T.as<int32_t>(), bad.as<unsigned long long>()};
+    for (int32_t b0 = 0; b0 < n; b0 += band) {
+        const int32_t b1 = (int32_t)std::min<int64_t>(n, (int64_t)b0 + band);
+        hipLaunchKernelGGL(k_plain_rows, dim3((unsigned)((b1 - b0 + WG_BLOCK - 1) / WG_BLOCK)), dim3(WG_BLOCK), 0, c->sA, A, b0, b1);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_plain_dp, dim3(1), dim3(WG_BLOCK), 0, c->sA, A, b0, b1);
+        HIP_TRY(hipGetLastError());
+    }
+    std::vector<int32_t> hT((size_t)n + 1);
+    HIP_TRY(hipMemcpyAsync(hT.data(), T.p, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipMemcpyAsync(&st.first_bad, bad.p, 8, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    if (st.first_bad != ~0ULL) return report_bad_site(c, st, err, errlen);
+    borders.clear();                                          // segmentor.cpp:50-58: i = n; push; while i > 0: i = max(0, T[i]); push — printed in reverse
+    int32_t i = n;
+    borders.push_back(i);
+    while (i > 0) {
+        const int32_t t = hT[(size_t)i];
+        const int32_t nx = t > 0 ? t : 0;
+        if (nx >= i) { set_err(err, errlen, "internal: back-pointer %d at step %d of a plain recurrence", (int)t, (int)i); return WGBSSEG_E_STATE; }
+        i = nx;
+        borders.push_back(i);
+    }
+    std::reverse(borders.begin(), borders.end());
+    return WGBSSEG_OK;
+}
+
+// A batch in which k_window found chunks with non-ascending loci: those chunks take the plain path, the others the batch path (again,
+// without them), and the border lists are put back in the caller's order.
+int segment_chunks_with_disorder(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks, const wgbsseg_params* P,
+                                 const wgbsseg_params* Peff, const Job& job, const BorderAlloc& alloc, int64_t* borders_off, char* err, size_t errlen)
+{
+    DevBuf flags;
+    struct Free { DevBuf& a; ~Free() { a.release(); } } fr{flags};
+    HIP_TRY(flags.ensure((size_t)n_chunks * 4));
+    HIP_TRY(hipMemsetAsync(flags.p, 0, (size_t)n_chunks * 4, c->sA));
+    hipLaunchKernelGGL(k_find_disorder, dim3((unsigned)n_chunks), dim3(WG_BLOCK), 0, c->sA, job.v, flags.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> hf((size_t)n_chunks);
+    HIP_TRY(hipMemcpyAsync(hf.data(), flags.p, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, c->sA));
+    HIP_TRY(hipStreamSynchronize(c->sA));
+    std::vector<int64_t> os, ooff;
+    std::vector<int32_t> ol, ob;
+    std::vector<int64_t> oidx;
+    for (int64_t i = 0; i < n_chunks; i++) if (!hf[(size_t)i]) { os.push_back(chunk_start0[i]); ol.push_back(chunk_len[i]); oidx.push_back(i); }
+    if (!os.empty()) {
+        ooff.resize(os.size() + 1);
+        const int rc = segment_chunks_impl(c, os.data(), ol.data(), (int64_t)os.size(), P,
+                                           [&](int64_t total) { ob.resize((size_t)std::max<int64_t>(1, total)); return ob.data(); }, ooff.data(), err, errlen, false);
+        if (rc != WGBSSEG_OK) return rc;
+    }
+    std::vector<std::vector<int32_t>> plain((size_t)n_chunks);
+    for (int64_t i = 0; i < n_chunks; i++)
+        if (hf[(size_t)i]) {
+            wgbsseg_params Pc = *Peff;                         // (max_cpg is already cut to the longest chunk of the call; the kernels cut it to this chunk)
+            const int rc = plain_segment_chunk(c, chunk_start0[i], chunk_len[i], &Pc, plain[(size_t)i], err, errlen);
+            if (rc != WGBSSEG_OK) return rc;
+        }
+    int64_t total = 0;
+    size_t oi = 0;
+    for (int64_t i = 0; i < n_chunks; i++) {
+        borders_off[i] = total;
+        if (hf[(size_t)i]) total += (int64_t)plain[(size_t)i].size();
+        else { total += ooff[oi + 1] - ooff[oi]; oi++; }
+    }
+    borders_off[n_chunks] = total;
+    int32_t* out = alloc(total);
+    if (!out) { set_err(err, errlen, "borders_out too small: need %lld ints", (long long)total); return WGBSSEG_E_CAPACITY; }
+    oi = 0;
+    for (int64_t i = 0; i < n_chunks; i++) {
+        if (hf[(size_t)i]) memcpy(out + borders_off[i], plain[(size_t)i].data(), plain[(size_t)i].size() * 4);
+        else { memcpy(out + borders_off[i], ob.data() + ooff[oi], (size_t)(ooff[oi + 1] - ooff[oi]) * 4); oi++; }
+    }
+    c->last_valid = false;
+    return WGBSSEG_OK;
+}
+
+int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
+                        const wgbsseg_params* P, const BorderAlloc& alloc, int64_t* borders_off, char* err, size_t errlen, bool allow_plain)
 {
     if (!P || !borders_off) { set_err(err, errlen, "NULL params/borders pointer"); return WGBSSEG_E_ARG; }
     if (P->max_bp == 0) { set_err(err, errlen, "max_bp must be >= 1 (the reference reads uninitialised loci when it is 0: segmentor.cpp:38,114)"); return WGBSSEG_E_ARG; }
@@ -614,6 +715,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
                 "in the float sums of the reference itself (segmentor.cpp:122-123), and windows are stored in 16 bits", P->max_cpg, (int)longest, WGBSSEG_MAX_CPG);
         return WGBSSEG_E_ARG;
     }
+    const wgbsseg_params* const P0 = P;
     P = &Peff;
     if (!(P->pseudo_count >= 0.0f)) { set_err(err, errlen, "pseudo_count must be >= 0"); return WGBSSEG_E_ARG; }
     if (c && c->sC) HIP_TRY(hipStreamSynchronize(c->sC));      // (a call that failed half way may have left its scan pass running)
@@ -698,9 +800,11 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipStreamSynchronize(c->sA));
         if (st2.first_bad != ~0ULL) return report_bad_site(c, st2, err, errlen);
         if (st.loci_disorder) {
-            set_err(err, errlen, "loci are not ascending inside chunk %u (0-based sites [%lld, +%d)): the reference's segmentor bars such an extension and leaves the site out of "
-                    "its running sums (segmentor.cpp:114-117), which this implementation does not reproduce — it refuses instead.  A chunk must not cross chromosomes; "
-                    "check the genome's CpG.bed.gz (positions ascending within a chromosome) or the regions of -L / -s",
+            // loci not ascending inside a chunk: the reference bars such an extension and leaves the site out of its running sums
+            // (segmentor.cpp:114-117).  The batch path rests on ascending loci (windows, prefix sums); the chunks concerned take
+            // the plain path (csrc/plain_dp.h: the reference's loops as written), the rest of the batch runs again without them.
+            if (allow_plain) return segment_chunks_with_disorder(c, chunk_start0, chunk_len, n_chunks, P0, &Peff, job, alloc, borders_off, err, errlen);
+            set_err(err, errlen, "internal: loci not ascending inside chunk %u (0-based sites [%lld, +%d)) of a batch that was filtered for such chunks",
                     st.loci_disorder - 1, (long long)(job.h[st.loci_disorder - 1].start0 + c->site_base), (int)job.h[st.loci_disorder - 1].len);
             return WGBSSEG_E_LOCI_ORDER;
         }
@@ -1739,8 +1843,8 @@ int wgbsseg_group_get_timings(const wgbsseg_group* g, int32_t share, wgbsseg_tim
     return wgbsseg_get_timings(g->shares[(size_t)share], out);
 }
 
-int wgbsseg_scan_only(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks, int repeat,
-                      double* ms_per_launch, int64_t* bytes_per_launch, char* err, size_t errlen)
+int wgbsseg_scan_only(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks, int repeat, int want_carry,
+                      double* ms_per_launch, int64_t* bytes_per_launch, int64_t* carry_bytes_per_launch, char* err, size_t errlen)
 {
     Job job;
     int rc = build_job(c, chunk_start0, chunk_len, n_chunks, job, false, err, errlen);
@@ -1749,16 +1853,20 @@ int wgbsseg_scan_only(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t
     if (rc != WGBSSEG_OK) return rc;
     c->validated.clear();
     if (repeat < 1) repeat = 1;
-    rc = launch_scan(c, job, 0, c->sA, err, errlen);           // warm-up (a fresh status block: no wide units, so the read-only pass)
+    want_carry = want_carry ? 1 : 0;
+    // want_carry 0: a fresh status block counts no wide units, so k_scan leaves at once and k_validate does the read-only pass;
+    // 1: k_scan itself — per-sample prefix sums of (meth, cov), a carry per 128 sites, the validation — as a job with wide tiles runs it
+    rc = launch_scan(c, job, want_carry, c->sA, err, errlen);           // warm-up
     if (rc != WGBSSEG_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
-    for (int r = 0; r < repeat; r++) { rc = launch_scan(c, job, 0, c->sA, err, errlen); if (rc != WGBSSEG_OK) return rc; }
+    for (int r = 0; r < repeat; r++) { rc = launch_scan(c, job, want_carry, c->sA, err, errlen); if (rc != WGBSSEG_OK) return rc; }
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
     if (ms_per_launch) *ms_per_launch = (double)ms / repeat;
-    if (bytes_per_launch) *bytes_per_launch = 2 * job.val_sites * c->n_samples;
+    if (bytes_per_launch) *bytes_per_launch = 2 * (want_carry ? job.sites : job.val_sites) * c->n_samples;
+    if (carry_bytes_per_launch) *carry_bytes_per_launch = want_carry ? (int64_t)sizeof(uint2) * job.carry_entries : 0;
     JobStatus st;
     HIP_TRY(hipMemcpyAsync(&st, c->status.p, sizeof(st), hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
