@@ -625,7 +625,7 @@ struct CostArgs {
     int32_t rows;      // guard-free kernels: exponents held by the two lookup tables (wg_lookup_rows for the longest block of the tile class)
     const wg_d2* tab;  // those tables, built by the host: rows * 16 log2f entries, then rows * 64 fast-log2 entries
     int32_t xcd_group; // consecutive tiles that go to one XCD before the next XCD's group begins (see k_cost)
-    int32_t cmap;      // log2 of the blocks per entry of the coarse block -> start map (3 or 4); 0: binary search instead (WGBSSEG_NO_CMAP=1: A/B measurements)
+    int32_t cmap;      // log2 of the blocks per entry of the block -> start map of the narrow / medium tiles: 0 = a byte per block (small cohorts: LDS to spare), 3 = a byte per eight blocks + forward steps
 };
 
 // Stage the exclusive prefixes P[A+x], x = x0 .. x0+cnt-1, of sample row `row` into dst[0..cnt) (one wavefront).
@@ -830,6 +830,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     constexpr bool KY = (FAST >= 2);             // 2: k-scaled tables; 3: the same with the short division core (narrow tiles, verified per call)
     constexpr bool DIVS = (FAST == 3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(sizeof(wg_fast_tables) % 16 == 0 && sizeof(wg_d2) == 16, "the arrays behind the tables are 16-byte aligned");
     // KY: only the two lookup tables, A.rows exponents each; otherwise the general fast tables
     const size_t TB = KY ? (size_t)A.rows * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
     wg_fast_tables* tb = reinterpret_cast<wg_fast_tables*>(smem);
@@ -840,19 +841,21 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     uint2* Et = reinterpret_cast<uint2*>(smem + TB);                             // wide: [NS][KS] P[i+1] of the ends
     uint2* St = Et + (size_t)A.NS * KS;                                          // wide: [NS][IS] P[k] of the starts
     uint32_t* Lt = reinterpret_cast<uint32_t*>(smem + TB);                       // narrow: [NS][KS] packed local prefixes
-    char* after = WIDE ? reinterpret_cast<char*>(St + (size_t)A.NS * IS) : reinterpret_cast<char*>(Lt + (((size_t)A.NS * KS + 1) & ~(size_t)1));
-    int64_t* radj = reinterpret_cast<int64_t*>(after);                           // [TI]
-    int32_t* offs = reinterpret_cast<int32_t*>(radj + TI);                       // [TI+1]
-    int32_t* ist = offs + (TI + 1);                                              // [TI] first end of start kl in this unit
-    int32_t* misc = ist + TI;                                                    // [2 (+1 pad)]
-    // The start site of a block: a byte per EIGHT blocks — the start of block 8 g — and a step forward from there when needed (a
-    // start has ~20 blocks), instead of a 6-7-step binary search in offs[] per block.  Why not a byte per block (tried for the
-    // 128-start tiles: 7.7 KB) or per four: LDS is handed out in granules of 1280 bytes and a 64-start tile at 32 samples sits at
-    // 31.6 KB = 25 granules = five workgroups per CU; one granule more and it is four (-5 %).  For the 128-start tiles of small
-    // cohorts the coarse map frees a workgroup slot per CU (x 16: scoring 13.1 -> 12.0 ms).
-    constexpr bool BMAP = false;
-    uint8_t* bmap = reinterpret_cast<uint8_t*>(misc + 8);
-    uint8_t* cmap = bmap;                                                        // [TI * WM / 8 + 1]
+    char* after = WIDE ? reinterpret_cast<char*>(St + (((size_t)A.NS * (KS + IS) + 1) & ~(size_t)1) - (size_t)A.NS * KS)
+                       : reinterpret_cast<char*>(Lt + (((size_t)A.NS * KS + 3) & ~(size_t)3));              // 16-byte aligned
+    // One 16-byte record per start site kl of the tile (round 4; rounds 1-3 kept offs[], ist[] and radj[] apart: three LDS round trips and
+    // ~45 VALU instructions per block outside the sample loop, which a small cohort amortises over few evaluations):
+    //   offs  first flattened block of the start (rec[nk].offs = Q closes the table)
+    //   ea    block q of the start reads the prefix entry  q + ea  (= i + 1 - first staged site: i = ist + (q - offs))
+    //   sb    ... and is stored at cost element  q + sb        (= row offset of the start - k + i)
+    struct Rec { int32_t offs, ea; int64_t sb; };
+    Rec* rec = reinterpret_cast<Rec*>(after);                                    // [TI + 1]
+    int32_t* misc = reinterpret_cast<int32_t*>(rec + (TI + 1));                  // [8]
+    // The start site of a block (narrow / medium tiles): a byte per block where LDS is to spare (A.cmap = 0: the 128-start tiles of small
+    // cohorts), else a byte per EIGHT blocks — the start of block 8 g — and a step forward from there when needed (a start has ~20
+    // blocks).  Why not a byte per block everywhere: LDS is handed out in granules of 1280 bytes and a 64-start tile at 32 samples sits
+    // at 31.6 KB = 25 granules = five workgroups per CU; one granule more and it is four (-5 %).
+    uint8_t* cmap = reinterpret_cast<uint8_t*>(misc + 8);                        // [(TI * WM >> A.cmap) + 1]
     constexpr bool CMAP = !WIDE;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -887,40 +890,46 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             ie = (k + f < et_hi ? k + f : et_hi) - 1;
             cnt = ie - is + 1;
             if (cnt < 0) cnt = 0;
-            if (kl < TI) {
-                radj[kl] = (int64_t)(J.cum32[cd.site_off + k] - cum0) - k;      // row offset of k, minus k: + i addresses (k, i)
-                ist[kl] = is;
-            }
         }
         const uint32_t incl = wg_wave_incl_scan_dpp_u32((uint32_t)cnt);
-        if (kl < TI) offs[kl + 1] = (int32_t)incl;       // (second wavefront: still without the first one's total)
-        if (kl == 0) offs[0] = 0;
+        // the record of the start, relative to the FIRST staged entry being that of site ka (narrow / medium) — the wide tiles' first entry
+        // (site imin + 1) is known only after the barrier and is subtracted there; second wavefront: still without the first one's total
+        if (kl < TI) {
+            const int32_t o = (int32_t)(incl - (uint32_t)cnt);
+            Rec r;
+            r.offs = o;
+            r.ea = is - o + 1 - (WIDE ? 0 : ka);
+            r.sb = (valid ? (int64_t)(J.cum32[cd.site_off + k] - cum0) - k : 0) + (is - o);      // row offset of k, minus k: + i addresses (k, i)
+            rec[kl] = r;
+        }
         const uint32_t imin = wg_wave_min_u32(cnt > 0 ? (uint32_t)is : 0x7fffffffu);
         const uint32_t imax = wg_wave_max_u32(cnt > 0 ? (uint32_t)ie : 0u);
         if (lane == 0) { misc[2 * wv] = (int32_t)imin; misc[2 * wv + 1] = (int32_t)imax; }
-        if (PW > 1 && lane == 63) misc[4 + wv] = (int32_t)incl;
+        if (lane == 63) misc[4 + wv] = (int32_t)incl;
     }
     __syncthreads();
-    if (PW > 1) {
-        if (wv == 1 && 64 + lane < TI) offs[64 + lane + 1] += misc[4];
-        __syncthreads();
-    }
-    const int Q = offs[nk];
-    if (Q == 0) return;
-    if (BMAP && tid < nk) {
-        const int o0 = offs[tid], o1 = offs[tid + 1];
-        for (int o = o0; o < o1; o++) bmap[o] = (uint8_t)tid;                    // (read after the barrier that opens the sample group)
-    }
-    if (CMAP && tid < nk) {
-        const int o0 = offs[tid], o1 = offs[tid + 1];
-        const int sh = A.cmap ? A.cmap : 3;
-        for (int g = (o0 + (1 << sh) - 1) >> sh; (g << sh) < o1; g++) cmap[g] = (uint8_t)tid;
-    }
     const int imin = PW > 1 ? (misc[0] < misc[2] ? misc[0] : misc[2]) : misc[0];
     const int imax = PW > 1 ? (misc[1] > misc[3] ? misc[1] : misc[3]) : misc[1];
+    const int Q = PW > 1 ? misc[4] + misc[5] : misc[4];
+    if (Q == 0) return;
     // wide: E array = P[x] for x = eA .. imax+1 (ends use P[i+1]), S array = P[k] for k = ka .. kb-1.
     // narrow: one array L[x - ka], x = ka .. imax+1, serves both.
     const int eA = WIDE ? imin + 1 : ka;
+    if (PW > 1 || WIDE) {
+        if (wv < PW && wv * 64 + lane < TI) {
+            const int t0 = wv == 1 ? misc[4] : 0;
+            Rec& r = rec[wv * 64 + lane];
+            if (PW > 1 && wv == 1) { r.offs += t0; r.sb -= t0; }
+            if (WIDE || (PW > 1 && wv == 1)) r.ea -= t0 + (WIDE ? eA : 0);
+        }
+    }
+    if (PW > 1 || WIDE) __syncthreads();
+    if (tid == 0) rec[nk].offs = Q;                                              // closes the table: no start beyond nk - 1 is ever stepped to (read after the next barrier)
+    if (CMAP && tid < nk) {                                                      // (read after the barrier that opens the sample group)
+        const int o0 = rec[tid].offs, o1 = tid + 1 < nk ? rec[tid + 1].offs : Q;
+        const int sh = A.cmap;
+        for (int g = (o0 + (1 << sh) - 1) >> sh; (g << sh) < o1; g++) cmap[g] = (uint8_t)tid;
+    }
     // carry position the scan of a wide row starts from.  eA == cd.len when the tile's first end is the chunk's last site (P[len]
     // alone is wanted): when start0 + len is a multiple of WG_CARRY_G that position is a group of its own, one past the cd.nG
     // carries k_scan wrote for the chunk — the scan starts from the last group INSIDE the chunk instead (up to WG_CARRY_G sites summed).
@@ -960,11 +969,10 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
         __syncthreads();
         int qi = 0;
         for (int q = tid; q < Q; q += WG_BLOCK, qi++) {
-            int lo = 0, hi = nk;                           // largest kl with offs[kl] <= q
-            if (BMAP) lo = (int)bmap[q];
-            else if (CMAP && A.cmap) { lo = (int)cmap[q >> A.cmap]; while (lo + 1 < nk && offs[lo + 1] <= q) lo++; }
-            else while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
-            const int i = ist[lo] + (q - offs[lo]);
+            int lo = 0, hi = nk;                           // largest kl with rec[kl].offs <= q
+            if (CMAP) { lo = (int)cmap[q >> A.cmap]; if (A.cmap) while (rec[lo + 1].offs <= q) lo++; }
+            else while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rec[mid].offs <= q) lo = mid; else hi = mid; }
+            const Rec r = rec[lo];
             double acc = firstg ? 0.0 : accR[qi];
             // sample loop, unrolled by four by hand (the optimiser leaves a loop with the rare exact path inside alone):
             // one address update per four evaluations, the row offsets sit in the instructions' offset fields
@@ -973,7 +981,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 return (double)ll;                                               // segmentor.cpp:135 adds the float term to the double sum
             };
             if (WIDE) {
-                const uint2* Ep = Et + (i + 1 - eA);       // P[i+1] of sample sl at Ep[sl * KS]
+                const uint2* Ep = Et + (q + r.ea);         // P[i+1] of sample sl at Ep[sl * KS]
                 const uint2* Sp = St + lo;                 // P[k]   of sample sl at Sp[sl * IS]
                 auto one = [&](int sl) {
                     const uint2 pi = Ep[sl * KS];
@@ -985,7 +993,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 for (; sl + 4 <= ns; sl += 4) { one(sl); one(sl + 1); one(sl + 2); one(sl + 3); }
                 for (; sl < ns; sl++) one(sl);
             } else {
-                const uint32_t* Ep = Lt + (i + 1 - ka);    // L[i+1-ka] of sample sl at Ep[sl * KS]
+                const uint32_t* Ep = Lt + (q + r.ea);      // L[i+1-ka] of sample sl at Ep[sl * KS]
                 const uint32_t* Sp = Lt + lo;              // L[k-ka]
                 auto one = [&](int sl) {
                     const uint32_t d = Ep[sl * KS] - Sp[sl * KS];                // both fields at once: no borrow, L is monotone per field
@@ -996,7 +1004,9 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 for (; sl + 4 <= ns; sl += 4) { one(sl); one(sl + 1); one(sl + 2); one(sl + 3); }
                 for (; sl < ns; sl++) one(sl);
             }
-            if (lastg) cb[radj[lo] + i] = (acc != 0.0) ? acc : 0.0;              // segmentor.cpp:106,137
+            // segmentor.cpp:106,137 `if (ll_sum) row[j] = ll_sum` over the 0.0 fill: a sum that began at +0.0 is never -0.0 (IEEE: +0 + -0 = +0,
+            // an exact cancellation of non-zero terms gives +0), so the sum itself is what the reference stores
+            if (lastg) cb[r.sb + q] = acc;
             else accR[qi] = acc;
         }
     }

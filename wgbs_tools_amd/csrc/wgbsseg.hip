@@ -838,14 +838,18 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const int rowsM = ks ? wg_lookup_rows(P->pseudo_count, 255.0 * WG_MEDIUM_WMAX) : 0;
     if (rowsA > WG_KY_KMIN + 1 || rowsB > WG_KY_KMIN + 1 || rowsM > WG_KY_KMIN + 1) { set_err(err, errlen, "internal: %d / %d / %d lookup rows", rowsA, rowsB, rowsM); return WGBSSEG_E_ARG; }
     // tile class: 0 narrow (ti starts), 1 wide, 2 medium
+    // block -> start map of the narrow / medium tiles: a byte per eight blocks + forward steps.  (A byte per block — no steps — was measured for
+    // the 128-start tiles of small cohorts, whose LDS has room: x8 scoring 6.73 ms against 6.59 with the coarse map, x16 12.50 / 12.07: the
+    // workgroup per CU it costs outweighs the steps it saves; profiles/r04_cost_rec_ab.txt.)
+    auto cmap_shift = [&](int, int) { return 3; };
     auto lds_for = [&](int ti, int cls, int ns) -> size_t {
         const int wm = cls == 2 ? WG_MEDIUM_WMAX : WG_NARROW_WMAX;
-        const size_t rows = cls == 1 ? (size_t)ns * (WG_WIDE_TK + 1 + WG_WIDE_TS + 1) * 8                  // P of the ends + P of the starts, (meth, cov) as two dwords
-                                     : ((((size_t)ns * (ti + wm + 1) + 1) & ~(size_t)1) * 4);             // tile-local prefixes, packed in one dword
+        const size_t rows = cls == 1 ? ((((size_t)ns * (WG_WIDE_TK + 1 + WG_WIDE_TS + 1) + 1) & ~(size_t)1) * 8)    // P of the ends + P of the starts, (meth, cov) as two dwords
+                                     : ((((size_t)ns * (ti + wm + 1) + 3) & ~(size_t)3) * 4);             // tile-local prefixes, packed in one dword
         // guard-free kernels: just the two lookup tables, sized to the pseudo count and the tile class; otherwise the general fast tables
         const size_t tabs = (cls == 1 ? ksB : ks) ? (size_t)(cls == 1 ? rowsB : cls == 2 ? rowsM : rowsA) * (16 + 64) * sizeof(wg_d2) : sizeof(wg_fast_tables);
-        return tabs + rows + (size_t)ti * 8 + (size_t)(ti + 1) * 4 + (size_t)ti * 4 + 32 +
-               (cls == 1 ? 0 : (size_t)ti * wm / 8 + 8);      // (+ the coarse block -> start map: a byte per eight blocks)
+        return tabs + rows + (size_t)(ti + 1) * 16 + 32 +      // one 16-byte record per start (+ the closing one), 8 ints
+               (cls == 1 ? 0 : ((size_t)ti * wm >> cmap_shift(ti, cls)) + 8);      // (+ the block -> start map)
     };
     int TI = 64, NSA = 1, NSB = 1, NSM = 1;
     static const int ti128_max_n = getenv("WGBSSEG_TI128_MAX_N") ? atoi(getenv("WGBSSEG_TI128_MAX_N")) : 16;
@@ -862,7 +866,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
                 if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
                 const size_t l = lds_for(ti, 0, ns);
                 if (l > 64 * 1024) continue;
-                const int wgs = (int)std::min<size_t>(ti == 128 ? 8 : 5, (160 * 1024) / (size_t)round_up((int64_t)l, 1280));   // registers allow 5 workgroups per CU; LDS is handed out in granules of 1280 bytes
+                // workgroups per CU the score counts on: LDS is handed out in granules of 1280 bytes; 5 for the 64-start tiles and below (the form
+                // with partial sums across sample groups has 95 VGPRs = 5 per CU; the one-group form has 63, but letting it count 7 makes small
+                // cohorts pick 64-start tiles, measured slower than 128-start ones: x8 scoring 6.92 vs 6.59 ms, profiles/r04_cost_rec_ab.txt)
+                const int wgs = (int)std::min<size_t>(ti == 128 ? 8 : 5, (160 * 1024) / (size_t)round_up((int64_t)l, 1280));
                 const double q = ti * std::min<double>(Favg, WA), eff = q / (256.0 * std::ceil(q / 256.0));
                 const double groups = std::ceil((double)Nsmp / ns);
                 const double score = wgs * eff / (1.0 + 0.02 * (groups - 1)) * (1.0 + 0.04 * (ti / 16));   // bias to big tiles (less staging)
@@ -900,10 +907,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     caA.pc = P->pseudo_count; caA.pc2 = P->pseudo_count + P->pseudo_count;
     static const int xcd_group = getenv("WGBSSEG_XCD_GROUP") ? std::max(1, atoi(getenv("WGBSSEG_XCD_GROUP"))) : 64;
     caA.xcd_group = xcd_group;
-    static const int use_cmap = !(getenv("WGBSSEG_NO_CMAP") && atoi(getenv("WGBSSEG_NO_CMAP")));
-    caA.cmap = use_cmap ? 3 : 0;
+    caA.cmap = 3;
     caB = caA;
     CostArgs caM = caA;
+    caA.cmap = cmap_shift(TI, 0);
     caA.NS = NSA; caA.rows = rowsA;
     caB.NS = NSB; caB.rows = rowsB;
     caM.NS = NSM; caM.rows = rowsM;
