@@ -424,6 +424,59 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
+    # N > 1: the same sharded step at x200 (BASELINE.json configs[3], the 8-GPU configuration: scoring-bound, so the shares' fixed costs weigh
+    # least there), a few steps, timed like the main run (barrier, max over ranks)
+    multi_rows = None
+    if args.matrix and (multi or group_mode):
+        multi_rows = []
+        for ns in ([200] if args.samples != 200 else []):
+            try:
+                k2 = 3
+                if multi:
+                    b2, pitch2 = device_rows(lo, max(hi, lo + 1), local, samples=ns)
+                    s2 = _lib.Segmenter(local)
+                    s2.set_betas_device(b2.data_ptr(), ns, pitch2, max(hi - lo, 1), keepalive=b2)
+                    s2.set_loci(loci[lo:max(hi, lo + 1)])
+                    s2.set_site_base(lo)
+
+                    def compute2(starts, ends, off=None, out=None):
+                        flat, off = s2.segment_chunks_csr(starts - 1 - lo, (ends - starts).astype(np.int32), args.pcount, max_cpg, args.max_bp, out=out, off=off)
+                        return off, flat
+
+                    def patches2(starts, ends):
+                        flat, off = s2.segment_chunks_csr(starts - 1 - lo, (ends - starts).astype(np.int32), args.pcount, max_cpg, args.max_bp)
+                        return off, flat
+                    step2 = lambda: run.step(compute2, patches2, copy=False)
+                    closer = s2.close
+                else:
+                    g2 = _lib.SegmenterGroup(devices)
+                    sh2 = g2.plan(loci, regions, args.chunk, args.pcount, max_cpg, args.max_bp)
+                    keep2 = []
+                    for d in range(args.gpus):
+                        l2, h2 = int(sh2['win_lo'][d]), int(sh2['win_hi'][d])
+                        if h2 > l2:
+                            b2, pitch2 = device_rows(l2, h2, devices[d], samples=ns)
+                            g2.share_set_device(d, b2.data_ptr(), ns, pitch2, keepalive=b2)
+                    torch.cuda.set_device(local)
+                    step2 = lambda: g2.segment_regions(copy=False)
+                    closer = g2.close
+                step2()
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(k2):
+                    r2 = step2()
+                barrier()
+                d2 = (time.perf_counter() - t1) / k2
+                t2 = torch.tensor([d2], dtype=torch.float64, device='cpu' if oversub else dev)
+                if multi:
+                    dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                d2 = float(t2.item())
+                multi_rows.append({'samples': ns, 'steps': k2, 'ms_per_step': d2 * 1e3, 'value': args.sites / d2, 'unit': 'CpG-sites/s', 'n_gpus': args.gpus if group_mode else world})
+                closer()
+                torch.cuda.empty_cache()
+            except Exception as e:
+                multi_rows.append({'samples': ns, 'failed': repr(e)})
+
     if rank == 0:
         n_blocks = int(sum(len(r) - 1 for r in res))
         block_sums = None
@@ -537,6 +590,9 @@ def main():
                        'chunks': n_chunks_total, 'chromosomes': len(sizes), 'sharding': mode,
                        'share_chunks': None if shares is None else [int(x) for x in shares['chunks']],
                        'share_work': None if shares is None else [int(x) for x in shares['work']],
+                       # how even the shares are: the largest share's work over the mean (1.0 = perfectly even; rank 0 is given less on purpose in the
+                       # multi-process form: it also runs the one stitching tree)
+                       'share_work_max_over_mean': None if shares is None else float(max(shares['work'])) / (float(sum(shares['work'])) / len(shares['work'])),
                        'rank0_sites': my_sites, 'rank0_stats': stats, 'rank0_blocks': n_blocks, 'csrc_sha': sha},
             # the kernel that IS the step.  Not HBM- and not MFMA-bound (integer scan + scalar cost on the vector ALUs): priced in
             # algorithmic flops against the vector-fp64 peak, with the instruction-issue bound of its real mix beside it.
@@ -564,6 +620,8 @@ def main():
             'device_ms_per_step': {k: acc[k] / args.steps for k in ('scan_ms', 'window_ms', 'cost_ms', 'dp_ms', 'trace_ms', 'total_ms')},
         }
         single = not multi and not group_mode
+        if multi_rows is not None:
+            out['matrix'] = {'what': 'the same sharded whole-genome step at x200 (BASELINE.json configs[3]), timed like the main run (barrier, max over ranks)', 'rows': multi_rows}
         if single and args.e2e:
             try:
                 out['end_to_end'] = end_to_end(args, buf, sizes, names, loci)

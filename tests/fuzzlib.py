@@ -4,7 +4,19 @@ The ALIGNED draw puts chunk starts, ends and lengths on and next to the multiple
 tiles, carry groups and batches begin, with window limits next to the tile-class boundary (60 / 64 / 128 sites): the cases a uniform
 draw meets once in thousands of chunks (round 2: seed 5751 of the uniform fuzz, the carry defect of a wide tile that wants P[len]
 alone)."""
+import glob
+import os.path as op
+import re
+
 import numpy as np
+
+
+def round_number():
+    """The build round, read off the newest profiles/rNN_* file (tracked, so the GPU box sees the same number): the fuzzers derive
+    their first seed from it, so every round's suite covers ground no earlier round has."""
+    here = op.dirname(op.dirname(op.abspath(__file__)))
+    r = [int(m.group(1)) for f in glob.glob(op.join(here, 'profiles', 'r[0-9][0-9]_*')) for m in [re.match(r'r(\d\d)_', op.basename(f))] if m]
+    return max(r) if r else 0
 
 
 def fuzz_world(rng, n, n_samples):
@@ -103,3 +115,24 @@ def run_aligned(seg, oracle, first, count, budget_s, threads, log=None, draws=4)
                     if log:
                         log(msg)
     return done, chunks, bad
+
+
+def deep_draw(seed):
+    """One deep-mode case (windows of thousands of sites: wide scoring tiles, the 32-step recurrence with its ring, stages of the
+    scored-block buffer): -> (slices, loci, pcount, max_cpg, max_bp, starts, lens).  8-12 k sites, 1 / 3 / 40 samples."""
+    rng = np.random.default_rng(700000 + seed)
+    n = int(rng.integers(8000, 12001))
+    n_samples = int(rng.choice([1, 3, 40]))
+    slices, loci = fuzz_world(rng, n, n_samples)
+    shape = rng.integers(0, 3)
+    if shape == 0:                                                # dense: every window is what max_cpg says
+        loci = (np.cumsum(rng.integers(0, 4, n)) + 1000).astype(np.uint32)
+    elif shape == 1:                                              # dense stretches between sparse ones
+        gap = np.where((np.arange(n) // int(rng.integers(500, 3000))) % 2 == 0, rng.integers(0, 4, n), rng.integers(50, 4000, n))
+        loci = (np.cumsum(gap) + 1000).astype(np.uint32)
+    pcount = float(rng.choice([0.0, 0.5, 1.0, 15.0, 15.0, float(np.float32(np.exp2(rng.uniform(-6, 8))))]))
+    max_cpg = int(rng.integers(2000, 5001))
+    max_bp = int(rng.choice([4000, 20000, 1000000, 100000000]))
+    ln = int(rng.integers(max(1, n // 2), n + 1))
+    st = int(rng.integers(0, n - ln + 1))
+    return slices, loci, pcount, max_cpg, max_bp, [0, st], [n, ln]

@@ -282,8 +282,8 @@ def test_x512_deep_full_genome(hg19):
     """BASELINE.json configs[4] at FULL size on one GPU: 28,217,448 CpGs x 512 betas (28.9 GB resident), max_cpg 5000, max_bp 1e6,
     chunk_size 50000 — 576 chunks, every window 5000 sites wide: 1.4e11 scored blocks x 512 samples = 7.2e13 evaluations through
     the staged scored-block buffer (WGBSSEG_COST_BUDGET_MB), the wide scoring tiles, the <15,32> recurrence and its L2 ring.
-    Checked: the genome-wide properties; full 50,000-site chunks spread over the genome (WGBSSEG_DEEP_ORACLE_CHUNKS, default 1 —
-    1.3e11 evaluations and two minutes on all host threads each; 8 of them in profiles/r03_deep_full_genome.log) against the oracle's many-thread restatement; the stitched trees of chr21 and chr22
+    Checked: the genome-wide properties; three 6,000-site ranges spread over the genome (or WGBSSEG_DEEP_ORACLE_CHUNKS full 50,000-site
+    chunks: 1.3e11 evaluations and two minutes on all host threads each; 8 of them in profiles/r03_deep_full_genome.log) against the oracle's many-thread restatement; the stitched trees of chr21 and chr22
     against the reference's pairwise tree walked over the same DPs.  The run's timing goes to gpurun_out/deep_full_timing.json."""
     import json
     import time
@@ -316,14 +316,18 @@ def test_x512_deep_full_genome(hg19):
         with open(op.join('gpurun_out', 'deep_full_timing.json'), 'w') as f:
             json.dump(rec, f, indent=1)
         print('deep full genome: %.1f s, %s' % (wall, json.dumps(rec['device_ms'])))
-        # full chunks spread over the genome against the oracle restatement
-        k = int(os.environ.get('WGBSSEG_DEEP_ORACLE_CHUNKS', '1'))
-        pick = _spread_chunks(sizes, chunk, k)
-        got = seg.segment_chunks(pick, [chunk] * len(pick), pc, mc, max_bp)
-        for st, g in zip(pick, got):
-            host = buf[:, 2 * st:2 * (st + chunk)].cpu().numpy()
-            want = oracle.segment_chunk_mt([host[s].reshape(-1, 2) for s in range(N)], loci[st:st + chunk], pc, mc, max_bp)
-            assert np.array_equal(g.astype(np.int64), want.astype(np.int64)), 'full deep chunk at site %d differs from the oracle restatement' % st
+        # ranges of the resident genome against the oracle restatement.  In the suite: WGBSSEG_DEEP_ORACLE_SITES (default 6,000) sites at
+        # three places of the genome (3 x 9e9 evaluations on the host: the suite has to fit the driver's window, and
+        # test_x512_deep_share compares a FULL 50,000-site chunk of the same configuration); WGBSSEG_DEEP_ORACLE_CHUNKS = k: k full
+        # chunks spread over the genome instead (two minutes of all host threads each: profiles/r03_deep_full_genome.log has 8)
+        k = int(os.environ.get('WGBSSEG_DEEP_ORACLE_CHUNKS', '0'))
+        part = int(os.environ.get('WGBSSEG_DEEP_ORACLE_SITES', '6000'))
+        pick = [(st, chunk) for st in _spread_chunks(sizes, chunk, k)] if k > 0 else [(st + 777, part) for st in _spread_chunks(sizes, chunk, 3)]
+        got = seg.segment_chunks([st for st, _ in pick], [ln for _, ln in pick], pc, mc, max_bp)
+        for (st, ln), g in zip(pick, got):
+            host = buf[:, 2 * st:2 * (st + ln)].cpu().numpy()
+            want = oracle.segment_chunk_mt([host[s].reshape(-1, 2) for s in range(N)], loci[st:st + ln], pc, mc, max_bp)
+            assert np.array_equal(g.astype(np.int64), want.astype(np.int64)), 'deep range [%d, +%d) differs from the oracle restatement' % (st, ln)
             del host
         # the stitched trees of chr21 and chr22 (9 and 10 chunks) against the reference's pairwise tree over the same DPs
         _stitched_vs_tree(seg, res, regions, [20, 21], chunk, pc, mc, max_bp)

@@ -106,3 +106,25 @@ def test_bgzf_pat_files_are_inflated_block_by_block(tmp_path, monkeypatch):
     cut.write_bytes(whole[:len(whole) // 2 + 7])
     with pytest.raises(Exception):
         b''.join(P2B.pat_chunks(str(cut)))
+
+
+def test_truncated_or_corrupt_plain_gzip_member_behind_bgzf_blocks_is_an_error(tmp_path):
+    """the multi-member inflater that takes over behind the BGZF blocks used to return a partial stream when its last
+    member stopped in the middle, and let zlib.error escape on trailing junk; both are IllegalArgumentError now, like the pure-BGZF
+    path's 'truncated or not BGZF'."""
+    from wgbs_tools_amd.genome import IllegalArgumentError
+    text = b''.join(b'chr1\t%d\tCCTT\t1\n' % i for i in range(60000))
+    head = _bgzf_bytes(text[:200000], block=30000)
+    member = gzip.compress(text[200000:])
+    cut = tmp_path / 'cut_member.pat.gz'
+    cut.write_bytes(head + member[:len(member) // 2])
+    for rb in (1 << 20, 70000):
+        with pytest.raises(IllegalArgumentError, match='truncated'):
+            b''.join(P2B.bgzf_pieces(str(cut), read_bytes=rb, threads=2))
+    junk = tmp_path / 'junk.pat.gz'
+    junk.write_bytes(head + member + b'\x1f\x8b\x08\x00 this is not a deflate stream at all')
+    with pytest.raises(IllegalArgumentError, match='Invalid gzip data'):
+        b''.join(P2B.bgzf_pieces(str(junk), threads=2))
+    whole = tmp_path / 'whole.pat.gz'                              # the stream may END between two members: no error
+    whole.write_bytes(head + member)
+    assert b''.join(P2B.bgzf_pieces(str(whole), threads=2)) == text

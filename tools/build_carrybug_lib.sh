@@ -2,7 +2,7 @@
 # Test infrastructure: builds tools/micro/_build/libwgbsseg_carrybug.so = the CURRENT library sources with round 1's carry defect
 # (fixed in 8c1419e: a wide scoring tile that wants P[len] alone read one carry past the chunk's) put back, to show that the fuzz
 # inside the GPU suite (tests/test_gpu_fuzz.py, test_13b) fails on it:
-#     tools/build_carrybug_lib.sh && WGBSSEG_LIB=$PWD/tools/micro/_build/libwgbsseg_carrybug.so python -m pytest tests/test_gpu_fuzz.py -m gpu -q
+#     tools/build_carrybug_lib.sh && WGBSSEG_ALLOW_LIB_OVERRIDE=1 WGBSSEG_LIB=$PWD/tools/micro/_build/libwgbsseg_carrybug.so python -m pytest tests/test_gpu_fuzz.py -m gpu -q
 set -e
 cd "$(dirname "$0")/.."
 B=tools/micro/_build/carrybug

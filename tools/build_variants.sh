@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B builds of libwgbsseg.so into tools/micro/_build/ (they travel with gpurun; WGBSSEG_LIB selects one):
+# A/B builds of libwgbsseg.so into tools/micro/_build/ (they travel with gpurun; WGBSSEG_ALLOW_LIB_OVERRIDE=1 WGBSSEG_LIB=... selects one):
 #   tools/build_variants.sh name1 "-DFLAG=1 ..." name2 "..." ...
 set -e
 cd "$(dirname "$0")/../wgbs_tools_amd/csrc"

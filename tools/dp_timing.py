@@ -11,6 +11,7 @@ if not os.path.isfile(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(os.pa
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared', '-pthread',
                            '-DWGBSSEG_DP_TIMING', SRC, '-o', LIB])
 os.environ['WGBSSEG_LIB'] = LIB
+os.environ['WGBSSEG_ALLOW_LIB_OVERRIDE'] = '1'
 sys.path.insert(0, ROOT)
 import numpy as np
 from wgbs_tools_amd import _lib, synth

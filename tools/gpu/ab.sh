@@ -10,7 +10,7 @@ B="--matrix 0 --cpu-seconds 0 --e2e 0 --block-sums 0 --scan-carries 0 --steps 10
 IFS=';' read -ra SETS <<< "$3"
 for spec in $2; do
   v=${spec%%@*}; envs=""; [ "$spec" != "$v" ] && envs=${spec#*@}
-  if [ "$v" = "main" ]; then LIBENV=""; else LIBENV="WGBSSEG_LIB=$REPO/tools/micro/_build/libwgbsseg_$v.so"; fi
+  if [ "$v" = "main" ]; then LIBENV=""; else LIBENV="WGBSSEG_ALLOW_LIB_OVERRIDE=1 WGBSSEG_LIB=$REPO/tools/micro/_build/libwgbsseg_$v.so"; fi
   i=0
   for a in "${SETS[@]}"; do
     tag=$(echo "${spec}_$i" | tr '@=,/' '____')

@@ -10,9 +10,14 @@ import os.path as op
 import numpy as np
 
 HERE = op.dirname(op.abspath(__file__))
-# WGBSSEG_LIB: another build of the same ABI (tests only: e.g. tools/build_carrybug_lib.sh, the library with a fixed defect put back,
-# to show that the suite's fuzz catches it)
-LIB_PATH = os.environ.get('WGBSSEG_LIB') or op.join(HERE, 'csrc', 'libwgbsseg.so')
+LIB_PATH = op.join(HERE, 'csrc', 'libwgbsseg.so')
+# Another build of the same ABI (tests and A/B measurements only: tools/build_carrybug_lib.sh — the library with a fixed defect put back, to
+# show that the suite's fuzz catches it — and tools/build_variants.sh): honoured only together with WGBSSEG_ALLOW_LIB_OVERRIDE=1, and said on
+# stderr, so that a stray variable cannot make a CLI run load some other shared object silently.
+if os.environ.get('WGBSSEG_LIB') and os.environ.get('WGBSSEG_ALLOW_LIB_OVERRIDE') == '1':
+    LIB_PATH = os.environ['WGBSSEG_LIB']
+    import sys as _sys
+    print('[wgbsseg] WGBSSEG_LIB: loading %s instead of the in-tree library' % LIB_PATH, file=_sys.stderr)
 SYNTH_LIB_PATH = op.join(HERE, 'csrc', 'libwgbssynth.so')
 
 OK, E_ARG, E_METH_GT_COV, E_NOMEM, E_HIP, E_LOCI_ORDER, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7

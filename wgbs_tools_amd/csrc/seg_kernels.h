@@ -745,13 +745,13 @@ __device__ __forceinline__ void wg_stage_local_rows(uint32_t* __restrict__ Et, c
     }
 }
 
-// The same for the rows of a MEDIUM tile (16 starts, windows <= WG_MEDIUM_WMAX: up to 269 entries): one sample row per wavefront
-// pass, 8 sites (one aligned 16-byte vector) per lane.  The packed sums may now carry from the #meth field into the #cov field
+// The same for the rows of a MEDIUM tile (16 starts, windows <= WG_MEDIUM_WMAX: up to 269 entries): one sample row per wavefront,
+// 4 sites (one 8-byte load) per lane and pass, the running total carried from pass to pass (two passes per row).  The packed sums may now carry from the #meth field into the #cov field
 // (35 lanes x 8 x 255 > 2^16) and wrap at 2^32: harmless, because an entry is the plain integer  sum(meth) + 2^16 sum(cov)  mod 2^32,
 // so the difference of two entries is  d(meth) + 2^16 d(cov)  mod 2^32, and both differences of a block of <= 252 sites are below
 // 2^16: the two halves of the difference ARE the block's counts.
 template <int ROW>
-__device__ __forceinline__ void wg_stage_local_rows8(uint32_t* __restrict__ Et, const uint8_t* __restrict__ betas, int64_t pitch,
+__device__ __forceinline__ void wg_stage_local_rows_long(uint32_t* __restrict__ Et, const uint8_t* __restrict__ betas, int64_t pitch,
                                                      int s_first, int ns, const ChunkDesc& cd, int64_t n_total, int ka, int cnt,
                                                      int lane, int wv)
 {
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
                 wg_stage_prefix_row(St + (size_t)rr * IS, row, carry, cd, J.n_total, sG, ka - sG, Scnt, lane);
             }
         } else if (SPLIT == 2) {
-            wg_stage_local_rows8<KS>(Lt, J.betas, J.pitch, g0, ns, cd, J.n_total, ka, Ecnt, lane, wv);
+            wg_stage_local_rows_long<KS>(Lt, J.betas, J.pitch, g0, ns, cd, J.n_total, ka, Ecnt, lane, wv);
         } else {
             wg_stage_local_rows<KS>(Lt, J.betas, J.pitch, g0, ns, cd, J.n_total, ka, Ecnt, lane, wv);
         }

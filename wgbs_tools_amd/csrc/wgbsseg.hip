@@ -107,7 +107,6 @@ struct wgbsseg_ctx {
     int device = 0;
     hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;     // scoring (+ everything else) | recurrence, traceback | the scan pass
     hipStream_t sA2 = nullptr;                                // second scoring stream: medium / wide tiles beside the narrow ones (stage loop)
-    int scan_stream = 1;       // WGBSSEG_SCAN_STREAM: 0 the scan pass on the scoring stream, ahead of the scoring kernel; 1 on its own stream for small jobs; 2 always
     // inputs
     DevBuf betas_own, loci_own;
     const uint8_t* betas = nullptr;
@@ -138,7 +137,6 @@ struct wgbsseg_ctx {
     int force_dp_mode = 0;   // WGBSSEG_DP_MODE: 1 = 32-step batches (wide-window path), 2 = the same with 15 worker waves
     int force_ns = 0;
     int force_ti = 0;
-    int min_stages = 0;      // WGBSSEG_MIN_STAGES; 0: decided per call from the number of chunks
     double last_block_sums_ms = 0.0;
     int64_t table_blocks = 0;  // > 0: dbg_b still holds the [n_samples][table_blocks] ratio table of the last mode-3 block reduction
     bool accumulate = false;   // add to `tim` instead of resetting it (region-level calls span several batches)
@@ -148,7 +146,6 @@ struct wgbsseg_ctx {
     std::vector<std::pair<int64_t, int64_t>> validated;
     DevBuf scan_pieces, divcheck, plan_sb, bs_desc;
     std::vector<int32_t> h_stage_bounds;
-    double tail_frac = 0.0;   // WGBSSEG_TAIL_FRAC: share of every chunk scored in the second of two uneven stages (many-chunk jobs); 0: one stage; < 0: from the call's size
     // the short division core of the narrow scoring tiles: verified on the device per pseudo count (k_check_div)
     float divs_pc = -1.0f;     // pseudo count the verdict below is for
     bool divs_ok = false;
@@ -263,7 +260,6 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     }
     HIP_TRY(hipStreamCreateWithFlags(&c->sC, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->sA2, hipStreamNonBlocking));
-    { const char* e = getenv("WGBSSEG_SCAN_STREAM"); if (e) c->scan_stream = std::min(2, std::max(0, atoi(e))); }
     for (auto& v : c->ev) HIP_TRY(hipEventCreate(&v));
     const char* b = getenv("WGBSSEG_COST_BUDGET_MB");
     c->cost_budget_bytes = (b && atoll(b) > 0 ? atoll(b) : 6144LL) << 20;
@@ -274,10 +270,6 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     c->force_ns = fn ? atoi(fn) : 0;
     const char* ft = getenv("WGBSSEG_TI");
     c->force_ti = ft ? atoi(ft) : 0;
-    const char* ms = getenv("WGBSSEG_MIN_STAGES");
-    if (ms && atoi(ms) > 0) c->min_stages = atoi(ms);
-    const char* tf = getenv("WGBSSEG_TAIL_FRAC");
-    if (tf) c->tail_frac = std::min(0.9, atof(tf));
     const char* bg = getenv("WGBSSEG_BLOCK_SUMS_GENERAL");
     if (bg) c->bs_general = atoi(bg) != 0;
     const char* dv = getenv("WGBSSEG_DIV_SHORT");
@@ -574,8 +566,8 @@ hipError_t set_kernel_attributes()
     if (e == hipSuccess) e = set_cost_attrs<1>();
     if (e == hipSuccess) e = set_cost_attrs<2>();
     if (e == hipSuccess) e = set_cost_attrs<3>();
-    const void* dps[] = {reinterpret_cast<const void*>(&k_dp<3, 64>), reinterpret_cast<const void*>(&k_dp<7, 64>), reinterpret_cast<const void*>(&k_dp<7, 64, true>),
-                         reinterpret_cast<const void*>(&k_dp<7, 32>), reinterpret_cast<const void*>(&k_dp<3, 32>),
+    const void* dps[] = {reinterpret_cast<const void*>(&k_dp<7, 64>), reinterpret_cast<const void*>(&k_dp<7, 64, true>),
+                         reinterpret_cast<const void*>(&k_dp<7, 32>),
                          reinterpret_cast<const void*>(&k_dp<15, 32>)};
     for (const void* f : dps)
         if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -718,7 +710,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const wgbsseg_params* const P0 = P;
     P = &Peff;
     if (!(P->pseudo_count >= 0.0f)) { set_err(err, errlen, "pseudo_count must be >= 0"); return WGBSSEG_E_ARG; }
-    if (c && c->sC) HIP_TRY(hipStreamSynchronize(c->sC));      // (a call that failed half way may have left its scan pass running)
+    if (c && c->sC) HIP_TRY(hipStreamSynchronize(c->sC));      // (a call that failed half way may have left its scan pass running ...
+    if (c && c->sA2) HIP_TRY(hipStreamSynchronize(c->sA2));    //  ... or the medium / wide tiles of a stage on the second scoring stream)
     Job job;
     int rc = build_job(c, chunk_start0, chunk_len, n_chunks, job, true, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
@@ -773,12 +766,12 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // The scan pass on its own stream.  It needs the windows' verdict (wide units or not: device-side flag), nothing else; the
     // narrow scoring tiles need nothing from it, so for a job without wide units the HBM-bound scan and its host round trips run
     // beside the tile plan and the VALU-bound scoring kernel; wide tiles (carries) make the scoring stream wait for it.
-    // Measured (WGBSSEG_SCAN_STREAM=1 / 0, ms per step): hg19 x 8 10.24 / 10.61, one eighth x 32 4.42 / 4.52, x 32 26.90 / 26.88,
+    // Measured (scan beside / ahead of the scoring kernel, ms per step): hg19 x 8 10.24 / 10.61, one eighth x 32 4.42 / 4.52, x 32 26.90 / 26.88,
     // x 200 141.3 / 142.1: it pays where the scan and the round trips are a visible share of the step; a large job keeps the scan
-    // alone on the chip (WGBSSEG_SCAN_STREAM=2: always beside).
+    // alone on the chip.
     // (The tile plan beside the scan of a large job, scoring behind both: measured neutral in time, and the plan kernels cost the
     // scan 3 % of its rate; not done.)
-    const bool beside = c->scan_stream == 2 || (c->scan_stream == 1 && (double)J * c->n_samples < 5e8);
+    const bool beside = (double)J * c->n_samples < 5e8;
     const bool own_stream = beside;
     hipStream_t sS = own_stream ? c->sC : c->sA;
     if (own_stream) HIP_TRY(hipStreamWaitEvent(c->sC, c->ev[1], 0));
@@ -852,7 +845,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
                (cls == 1 ? 0 : ((size_t)ti * wm >> cmap_shift(ti, cls)) + 8);      // (+ the block -> start map)
     };
     int TI = 64, NSA = 1, NSB = 1, NSM = 1;
-    static const int ti128_max_n = getenv("WGBSSEG_TI128_MAX_N") ? atoi(getenv("WGBSSEG_TI128_MAX_N")) : 16;
+    const int ti128_max_n = 16;
     {
         double best = -1;
         for (int ti = 128; ti >= 16; ti >>= 1) {
@@ -861,7 +854,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
             for (int ns : ns_opts) {
                 if (ns > Nsmp) continue;
                 // 128-start tiles: half the per-tile overhead for small cohorts; only with every sample in LDS at once (one group),
-                // and not by default above WGBSSEG_TI128_MAX_N samples, where their larger rows cost a workgroup per CU
+                // and not by default above 16 samples, where their larger rows cost a workgroup per CU
                 if (ti == 128 && (ns != Nsmp || (c->force_ti != 128 && Nsmp > ti128_max_n))) continue;
                 if (c->force_ns > 0 && ns != std::min(c->force_ns, Nsmp)) continue;
                 const size_t l = lds_for(ti, 0, ns);
@@ -890,10 +883,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
             if (score > best) { best = score; NSB = ns; }
         }
         best = -1;
-        static const int force_nsm = getenv("WGBSSEG_NSM") ? atoi(getenv("WGBSSEG_NSM")) : 0;
         for (int ns : ns_opts) {                                   // medium tiles: rows of 269 dwords per sample
             if (ns > Nsmp) continue;
-            if (force_nsm > 0 && ns != std::min(force_nsm, Nsmp)) continue;
             const size_t l = lds_for(WG_MEDIUM_TS, 2, ns);
             if (l > 64 * 1024) continue;
             const int wgs = (int)std::min<size_t>(5, (160 * 1024) / (size_t)round_up((int64_t)l, 1280));
@@ -905,8 +896,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     CostArgs caA, caB;
     memset(&caA, 0, sizeof(caA));
     caA.pc = P->pseudo_count; caA.pc2 = P->pseudo_count + P->pseudo_count;
-    static const int xcd_group = getenv("WGBSSEG_XCD_GROUP") ? std::max(1, atoi(getenv("WGBSSEG_XCD_GROUP"))) : 64;
-    caA.xcd_group = xcd_group;
+    caA.xcd_group = 64;
     caA.cmap = 3;
     caB = caA;
     CostArgs caM = caA;
@@ -936,7 +926,6 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
 
     // ---- stages: bound the scored-block buffer and overlap scoring (stream A) with the recurrence (stream B) --
     int n_stages = 1;
-    bool tail_split = false;          // two uneven stages: the recurrence of the long first one hides behind the scoring of the short last one
     {
         const long long bytes = total_pairs * 8;
         n_stages = (int)std::max<long long>(1, (bytes + c->cost_budget_bytes - 1) / c->cost_budget_bytes);
@@ -946,31 +935,15 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         // (the junction patches that ride along in the batch are a few hundred sites each: they do not count)
         int n_long = 0;
         for (const ChunkDesc& d : job.h) n_long += d.len >= 8192;
-        if (job.max_len >= 8192) n_stages = std::max(n_stages, c->min_stages > 0 ? c->min_stages : (n_long <= 160 ? 8 : 1));
-        // Many chunks, all windows <= 64: one stage scores and k_dp<7,64> follows alone (1.8 ms exposed).  The alternative
-        // (WGBSSEG_TAIL_FRAC=f, off by default): score the first (1 - f) of every chunk, then score the rest while k_dp16 runs
-        // the recurrence of the first part beside it; only the last part's recurrence is exposed.  Measured (hg19 x 32, f =
-        // 1/16 .. 3/8): 27.1-27.3 ms against 27.0 — whatever f, the scoring kernel loses the 1.4 ms the recurrence no longer
-        // shows: a recurrence wave issues ~40 of every ~57 cycles on its SIMD at raised priority, and the scoring kernel is
-        // VALU-issue bound, so the chain's instructions are paid either way (x 8: 11.2 -> 11.0).
-        if (n_stages == 1 && c->force_stages <= 0 && c->min_stages <= 0 && job.max_len >= 8192 && Wmax <= 64 && c->tail_frac != 0.0) { n_stages = 2; tail_split = true; }
+        if (job.max_len >= 8192) n_stages = std::max(n_stages, n_long <= 160 ? 8 : 1);
+        // Many chunks, all windows <= 64: one stage scores and k_dp<7,64> follows alone (1.7 ms exposed).  (Two uneven stages — the
+        // recurrence of the first part of every chunk beside the scoring of the rest — were measured in round 2: 27.1-27.3 ms against 27.0
+        // whatever the split, profiles/r02_tail_split_sweep.txt: the scoring kernel loses what the recurrence no longer shows.)
         if (c->force_stages > 0) n_stages = c->force_stages;
         n_stages = std::min<int>(n_stages, std::max(1, (job.max_len + 63) / 64));
     }
     std::vector<int32_t>& sb = c->h_stage_bounds;              // (lives in the context: source of an async upload)
-    if (tail_split) {
-        // the second stage must score for as long as k_dp16 needs for the first: ~3.5 ms per 60,000 steps beside the scoring
-        // kernel (measured), against evaluations at ~7.5e11 / s
-        double f = c->tail_frac;
-        if (f < 0.0) {
-            const double t_dp = 3.5e-3 * (double)job.max_len / 60000.0, t_cost = (double)total_pairs * Nsmp / 7.5e11;
-            f = std::min(0.5, 1.25 * t_dp / (t_cost + t_dp));
-        }
-        const int cut = (int)std::max<int64_t>(64, round_up((int64_t)((1.0 - f) * job.max_len), 64));
-        tail_split = cut < job.max_len;
-        sb.assign({0, std::min<int32_t>(cut, job.max_len)});
-        if (tail_split) sb.push_back(job.max_len); else n_stages = 1;
-    } else {
+    {
         const int S = (int)round_up((job.max_len + n_stages - 1) / n_stages, 64);
         n_stages = (job.max_len + S - 1) / S;
         sb.resize((size_t)n_stages + 1);
@@ -1068,8 +1041,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // and joined before the stage's end is recorded (ev_fork / ev_join).  Measured, islands x32: scoring 29.49 -> 28.70 ms, x8 9.35 -> 9.14 ms.
     // Alternating the STAGES of a staged job between the streams was measured too and is not done: the one-eighth share
     // (8 stages) scored in 3.40 instead of 3.49 ms but its recurrences, which run beside the next stage's scoring, fell behind
-    // (step 4.56 -> 4.79 ms); x200 / x512 gained 0.1-0.5 %.  WGBSSEG_COST_STREAMS=1: everything on the first stream (A/B, read per call).
-    const bool two_cost_streams = !(getenv("WGBSSEG_COST_STREAMS") && atoi(getenv("WGBSSEG_COST_STREAMS")) == 1);
+    // (step 4.56 -> 4.79 ms); x200 / x512 gained 0.1-0.5 %.
+    const bool two_cost_streams = true;
     hipStream_t const sP = c->sA;
     for (int stg = 0; stg < n_stages; stg++) {
         sv.stage = stg;
@@ -1114,22 +1087,16 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         // worker waves per chunk, measured: 64-step batches (no window > 64): 7 (whole genome 3 -> 2.14 ms, 7 -> 1.77 ms,
         // 5 / 11 / 15 -> 2.8-3.1 ms); 32-step batches (islands): round 1 measured 3 workers 4.8 ms, 7 -> 5.8 ms; round 3 (the batch loops written per role
         // since round 2: 127 instead of 174 VGPRs) 3 -> 4.28 ms, 7 -> 3.52, with the lean step in the narrow batches 3.34 (11 workers: 5.0): 7 is the default now.  64-step batches again in round 3: 5 -> 1.83, 7 -> 1.66, 11 -> 1.65 ms.
-        // WGBSSEG_DP_NW overrides (tests, tuning).
-        static const int dp_nw = getenv("WGBSSEG_DP_NW") ? atoi(getenv("WGBSSEG_DP_NW")) : 0;
         // 16-step batches at the footprint of one scoring workgroup when the recurrence of a stage runs beside the scoring of
-        // the next one (WGBSSEG_DP16: 0 never, 1 always when windows allow; default: whenever the call is staged)
-        static const int dp16_env = getenv("WGBSSEG_DP16") ? atoi(getenv("WGBSSEG_DP16")) : -1;
-        // windows <= 60 (no wide tile in the job): the step with the batched bookkeeping, 6.75 instead of 10 VALU instructions (WGBSSEG_DP_LEAN=0: never)
-        static const bool dp_lean = !(getenv("WGBSSEG_DP_LEAN") && atoi(getenv("WGBSSEG_DP_LEAN")) == 0);
+        // the next one: whenever the call is staged.  Windows <= 60 (no wide tile in the job): the step with the batched bookkeeping, 6.75 instead
+        // of 10 VALU instructions.
         // the LAST stage's recurrence has the chip to itself: the 64-step-batch kernel is twice as fast there
-        const bool dp16 = dp_mode == 0 && (dp16_env < 0 ? (n_stages > 1 && stg + 1 < n_stages) : dp16_env != 0);
+        const bool dp16 = dp_mode == 0 && n_stages > 1 && stg + 1 < n_stages;
         if (dp16)                            hipLaunchKernelGGL((k_dp16<3>), dim3((unsigned)nC), dim3(64 * 4), (size_t)(2 * 16 * 64 * 8 + WG_DP_META_RING * 6), c->sB, v, sv, cbuf, c->dpstate.as<double>(), state_stride);
-        else if (dp_mode == 0 && dp_nw == 3) hipLaunchKernelGGL((k_dp<3, 64>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
-        else if (dp_mode == 0 && dp_lean && Wmax <= WG_NARROW_WMAX)
+        else if (dp_mode == 0 && Wmax <= WG_NARROW_WMAX)
                                              hipLaunchKernelGGL((k_dp<7, 64, true>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else if (dp_mode == 0)               hipLaunchKernelGGL((k_dp<7, 64>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
-        else if (dp_mode == 1 && dp_nw != 3) hipLaunchKernelGGL((k_dp<7, 32>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
-        else if (dp_mode == 1)               hipLaunchKernelGGL((k_dp<3, 32>), dim3((unsigned)nC), dim3(64 * 4), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
+        else if (dp_mode == 1) hipLaunchKernelGGL((k_dp<7, 32>), dim3((unsigned)nC), dim3(64 * 8), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         else                   hipLaunchKernelGGL((k_dp<15, 32>), dim3((unsigned)nC), dim3(64 * 16), lds_dp, c->sB, v, sv, cbuf, da, c->dpstate.as<double>(), state_stride);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev_dp1[stg], c->sB));

@@ -112,9 +112,15 @@ class NodeSlots:
     when its lists are complete, rank 0 waits for the stamps, and stamps its own header with the number of steps it has consumed —
     which is what a rank waits for before it reuses a slot (it may run one step ahead of rank 0's stitching, no further).
     Ranks on several hosts fall back to a gather of Python objects.
+    The slot FILES are unlinked as soon as every rank has mapped them (the mappings stay valid): a run that crashes or is killed
+    leaks nothing under /dev/shm.  A waiting rank checks every tenth of a second that the ranks it waits for are still alive (their
+    process ids are exchanged once) and gives up at once when one is gone, after TIMEOUT_S otherwise.
+    Memory ordering: a slot's stamp is a plain 8-byte store issued after the stores of the lists it covers, and the reader loads the
+    stamp before the lists; both rest on x86-64's total store order / ordered loads (the hosts of MI355X nodes) — on a weakly
+    ordered host the stamp would need a release store and an acquire load.
     Slot layout: int64 header [8] (0: step stamp; rank 0 only, 1: steps consumed), int64 offsets [items + 1], int32 borders [cap]."""
     HDR = 64
-    TIMEOUT_S = 600.0
+    TIMEOUT_S = 120.0
 
     def __init__(self, dist, rank, world, n_items, caps):
         import os
@@ -123,7 +129,9 @@ class NodeSlots:
         import numpy as np
         self.dist, self.rank, self.world = dist, rank, world
         hosts = [None] * world
-        dist.all_gather_object(hosts, socket.gethostname())
+        dist.all_gather_object(hosts, (socket.gethostname(), os.getpid()))
+        self.pids = [p for _, p in hosts]
+        hosts = [h for h, _ in hosts]
         tag = [uuid.uuid4().hex[:12] if rank == 0 else None]
         dist.broadcast_object_list(tag, src=0)
         self.shared = len(set(hosts)) == 1 and os.path.isdir('/dev/shm') and not os.environ.get('WGBSSEG_NO_SHM')
@@ -158,6 +166,7 @@ class NodeSlots:
                     if rank == 0 or r == rank or (r == 0 and k == 0):                             # (everybody reads rank 0's header)
                         self.maps[(r, k)] = np.memmap(path(r, k), dtype=np.uint8, mode='r+', shape=(self._bytes(r),))
             dist.barrier()
+            self._unlink()                                       # every rank holds its mappings: the names can go (nothing to leak on a crash)
 
     @staticmethod
     def _reserve(fd, size):
@@ -187,16 +196,26 @@ class NodeSlots:
         o = self.HDR
         return m[o:o + 8 * (n + 1)].view(np.int64), m[o + 8 * (n + 1):o + 8 * (n + 1) + 4 * max(1, self.caps[r])].view(np.int32)
 
-    def _wait(self, ready, what):
+    def _wait(self, ready, what, peer):
+        import os
         import time
         t0 = time.monotonic()
-        spins = 0
+        spins, checked = 0, t0
         while not ready():
             spins += 1
             if spins > 2000:
                 time.sleep(0.00002)
-                if time.monotonic() - t0 > self.TIMEOUT_S:
-                    raise RuntimeError('timed out waiting for %s (another rank has failed?)' % what)
+                now = time.monotonic()
+                if now - checked > 0.1:
+                    checked = now
+                    try:
+                        os.kill(self.pids[peer], 0)               # signal 0: does the process still exist?
+                    except ProcessLookupError:
+                        raise RuntimeError('rank %d (pid %d) is gone while this rank waits for %s' % (peer, self.pids[peer], what))
+                    except PermissionError:
+                        pass
+                    if now - t0 > self.TIMEOUT_S:
+                        raise RuntimeError('timed out after %.0f s waiting for %s' % (self.TIMEOUT_S, what))
 
     def mine(self):
         """(off, borders) views of this rank's slot of the current step, to be filled in place (None, None without /dev/shm).
@@ -205,7 +224,7 @@ class NodeSlots:
             return None, None
         if self.step_no >= 2 and self.rank != 0:
             ack = self._hdr(0, 0)
-            self._wait(lambda: int(ack[1]) >= self.step_no - 1, 'rank 0 to consume step %d' % (self.step_no - 2))
+            self._wait(lambda: int(ack[1]) >= self.step_no - 1, 'rank 0 to consume step %d' % (self.step_no - 2), 0)
         return self._views(self.rank, self.step_no & 1)
 
     def publish(self, off, flat):
@@ -218,7 +237,7 @@ class NodeSlots:
                 return None
             for r in range(1, self.world):
                 h = self._hdr(r, k)
-                self._wait(lambda: int(h[0]) >= self.step_no, 'rank %d to deliver step %d' % (r, self.step_no - 1))
+                self._wait(lambda: int(h[0]) >= self.step_no, 'rank %d to deliver step %d' % (r, self.step_no - 1), r)
             return [self._views(r, k) for r in range(self.world)]
         out = [None] * self.world if self.rank == 0 else None
         self.dist.gather_object((off, flat), out, dst=0)

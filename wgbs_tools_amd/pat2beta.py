@@ -81,17 +81,26 @@ def bgzf_pieces(path, read_bytes=8 << 20, threads=None):
                         # `gunzip -cd` reads such a file, so hand the rest to zlib's multi-member inflater, in bounded pieces
                         import zlib
                         d = zlib.decompressobj(wbits=31)
-                        while buf:
-                            out = d.decompress(buf)
-                            while d.eof:                          # next member
-                                rest = d.unused_data
-                                d = zlib.decompressobj(wbits=31)
-                                if not rest:
-                                    break
-                                out += d.decompress(rest)
-                            if out:
-                                yield out
-                            buf = f.read(read_bytes)
+                        fresh = True                              # `d` has not seen a byte yet (the stream may end between two members)
+                        try:
+                            while buf:
+                                out = d.decompress(buf)
+                                fresh = False
+                                while d.eof:                      # next member
+                                    rest = d.unused_data
+                                    d = zlib.decompressobj(wbits=31)
+                                    fresh = True
+                                    if not rest:
+                                        break
+                                    out += d.decompress(rest)
+                                    fresh = False
+                                if out:
+                                    yield out
+                                buf = f.read(read_bytes)
+                        except zlib.error as e:                   # trailing junk, a corrupt member: what the BGZF path and gzip.open refuse as well
+                            raise IllegalArgumentError(f'Invalid gzip data in {path}: {e}')
+                        if not fresh and not d.eof:               # the last member stops in the middle (gzip.open: EOFError; the BGZF path: "truncated")
+                            raise IllegalArgumentError(f'Invalid gzip data in {path}: truncated (the last gzip member is incomplete)')
                         return True
                     more = f.read(read_bytes)
                     if not more or len(buf) > (1 << 20):          # a BGZF block is at most 64 KB: more than that without one is not BGZF
