@@ -72,9 +72,10 @@ def main():
         with contextlib.redirect_stderr(err):
             rc = wgbs_tools.main(['wgbstools', 'segment', '--betas'] + paths + ['--genome', ref, '-o', out])
         dt = time.perf_counter() - t0
-        lines = [l for l in err.getvalue().splitlines() if 'phases' in l or 'found' in l]
+        lines = [l for l in err.getvalue().splitlines() if 'phases' in l or 'found' in l or 'betas to the device' in l]
         print('run %d: rc %s, %.3f s wall, %.3g CpG-sites/s end to end; %s' % (rep, rc, dt, args.sites / dt, ' | '.join(lines)), flush=True)
-    print('BED: %d rows, %.1f MB' % (sum(1 for _ in open(out)), op.getsize(out) / 1e6))
+    import hashlib
+    print('BED: %d rows, %.1f MB, md5 %s' % (sum(1 for _ in open(out)), op.getsize(out) / 1e6, hashlib.md5(open(out, 'rb').read()).hexdigest()))
     if not args.keep:
         for p in paths:
             os.remove(p)
