@@ -37,7 +37,7 @@ extern "C" {
 #define WGBSSEG_E_METH_GT_COV  -2      /* a requested site has #meth > #cov: segmentor.cpp:181-188 "invalid data" */
 #define WGBSSEG_E_NOMEM        -3
 #define WGBSSEG_E_HIP          -4      /* HIP runtime error / no usable device */
-#define WGBSSEG_E_LOCI_ORDER   -5      /* loci not ascending inside a chunk (chunks never cross chromosomes: segment.py:84-86) */
+#define WGBSSEG_E_LOCI_ORDER   -5      /* (internal since round 4: chunks whose loci do not ascend take the plain path — the reference's loops as written, segmentor.cpp:114-117 — and are no error) */
 #define WGBSSEG_E_CAPACITY     -6      /* borders_out too small */
 #define WGBSSEG_E_STATE        -7      /* betas / loci not set */
 
