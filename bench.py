@@ -573,11 +573,36 @@ def main():
                                                           'v_fma_f32 and v_fma_f64 runs at 0.95 of the pure fp64 time per instruction); v_rcp_f32 at its own measured time'}
             except Exception:
                 pass
+            # round 4: the same question asked with a stream shaped like the evaluation itself (10 cheap, 1 v_rcp_f32, 29 fp64-class instructions in the
+            # kernel's order, dependent chain, 5 unsynchronised wavefronts per SIMD): tools/micro/gen_valu_cluster.py, profiles/r04_valu_cluster.json —
+            # clustering the cheap instructions (runs of 1 .. 16) does not change the rate, so this IS the issue bound of the mix
+            try:
+                vc = json.load(open(op.join(ROOT, 'profiles', 'r04_valu_cluster.json')))['rows']
+                row = [r for r in vc if r['pattern'].startswith('evaluation-shaped:') and r['waves_per_simd'] == 5 and r['desync'] == 1][0]
+                n_instr = 40.0                                                        # instructions of that stream per evaluation
+                t_eval = row['ns_per_wave_instr'] * 1e-9 * n_instr * (main_mix['valu_per_eval'] / n_instr)
+                issue['measured_evaluation_shaped_stream'] = {'ns_per_wave_instr': row['ns_per_wave_instr'], 'peak_evals_per_s': N_SIMD * 64 / t_eval,
+                                                              'frac': evals_s / (N_SIMD * 64 / t_eval), 'file': 'r04_valu_cluster.json',
+                                                              'note': 'a bare instruction stream of the evaluation\'s mix (no LDS, no branches, no per-block work) on another box of the pool; '
+                                                                      'runs of 1 / 2 / 4 / 8 / 16 cheap instructions in a 1:3 mix all issue at 1.77-1.80 ns per instruction: clustering buys nothing'}
+            except Exception:
+                pass
         mode = ('one process, %d GPUs: a share group (work-balanced contiguous chunk runs, one host thread per GPU, one host-side tree)' % args.gpus
                 if group_mode else
                 'one process per GPU (parallel.ShardedRun): work-balanced contiguous chunk runs per rank, border lists handed to rank 0 through /dev/shm, '
                 'ONE stitching tree on rank 0 inside the timed step; no collective' if multi else 'one GPU')
         cost_ms = acc['cost_ms'] / args.steps
+        # HBM-side traffic of the scoring kernel's main launch from the PMC counters (tools/pmc_cost_traffic.py: FETCH_SIZE / WRITE_SIZE in separate
+        # rocprofv3 passes, calibrated in the same passes on known byte counts): only a file of THIS source state and this workload is reported
+        ct = keyed_profile('*cost_traffic*.json', sha) if (not multi and not group_mode) else None
+        cost_traffic, cost_traffic_note = None, 'traffic: no PMC pass of this source state (csrc_sha %s) for k_cost on this workload under profiles/' % sha
+        alg_cost_bytes = 2.0 * args.samples * args.sites + 8.0 * acc['pairs'] / args.steps
+        if ct and abs(ct['algorithmic_bytes']['sum'] - alg_cost_bytes) <= 0.02 * alg_cost_bytes:
+            cost_traffic = ct['traffic_bytes']
+            cost_traffic_note = ('traffic (HBM-side bytes of the main launch) = %.3f x the algorithmic bytes (every beta byte once + one double per scored block): %.2f GB read '
+                                 '(%.2f x the beta bytes: the halo re-reads of neighbouring tiles stay in L2) + %.2f GB written; FETCH_SIZE / WRITE_SIZE of profiles/%s, '
+                                 'calibrated there on 1 GiB read / written once at the kernel\'s access widths'
+                                 % (ct['traffic_over_algorithmic'], ct['read_bytes'] / 1e9, ct['read_over_beta_bytes'], ct['write_bytes'] / 1e9, ct['_file']))
         out = {
             'metric': 'CpG-sites/sec segmented',
             'value': value, 'unit': 'CpG-sites/s', 'n_gpus': args.gpus if group_mode else world, 'steps': args.steps, 'warmup': args.warmup,
@@ -598,14 +623,15 @@ def main():
             # algorithmic flops against the vector-fp64 peak, with the instruction-issue bound of its real mix beside it.
             'roofline': {'kernel': 'k_cost (block log-likelihoods: %.0f %% of the step)' % (100 * cost_ms / ms_step), 'bound': 'valu (vector fp64 peak; no MFMA: not a contraction)',
                          'achieved': evals_s * FLOP_PER_EVAL / 1e12, 'peak': FP64_VALU_PEAK / 1e12, 'unit': 'TFLOP/s',
-                         'frac': evals_s * FLOP_PER_EVAL / FP64_VALU_PEAK, 'traffic': None,
+                         'frac': evals_s * FLOP_PER_EVAL / FP64_VALU_PEAK, 'traffic': cost_traffic,
                          'algorithmic_flop_per_eval': FLOP_PER_EVAL, 'evals_per_launch': acc['evals'] / args.steps, 'avg_launch_ms': cost_ms,
                          'launches_timed': args.steps, 'evals_per_s': evals_s,
                          'fp64_flop_executed_per_eval': FP64_FLOP_EXECUTED, 'fp64_executed_frac_of_peak': evals_s * FP64_FLOP_EXECUTED / FP64_VALU_PEAK,
                          'issue': issue, 'division_core': '4 instructions, verified on the device for this pseudo count' if acc.get('div_short') else '8 instructions',
                          'pairs_per_step': acc['pairs'] / args.steps, 'max_window': acc['max_window'], 'stages': acc['n_stages'],
-                         'note': 'rank 0 / share 0; HIP events on the scoring stream inside the timed steps; traffic: the kernel reads the beta bytes of its '
-                                 'tiles through L2 (HBM-side traffic is that of the scan pass, not a bound here)'},
+                         'algorithmic_bytes_per_launch': alg_cost_bytes,
+                         'note': 'rank 0 / share 0; HIP events on the scoring stream inside the timed steps; ' + cost_traffic_note + ' — the kernel moves ~0.3 TB/s: '
+                                 'not a memory kernel, its bound is VALU issue'},
             'roofline_scan': {'kernel': ('k_scan (per-sample prefix scan -> 128-site carries + meth<=cov validation: the job has wide tiles)' if stats_wide else
                                          'k_validate (the scan pass of a job without wide tiles: every beta byte read once, meth<=cov checked; no carries needed)'), 'bound': 'hbm',
                               'achieved': scan_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': scan_gbs / HBM_PEAK_GBS,
