@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 4, call 6: end to end through the CLI — the upload from mapped rows (rounds 2-3) against pread into page-locked staging, 4 / 8 / 16 threads
+# end to end through the CLI — the upload from mapped rows (rounds 2-3) against pread into page-locked staging, 4 / 8 / 16 threads
 set -u
-O=gpurun_out/r04c6; mkdir -p $O
+O=gpurun_out/e2e_loader_ab; mkdir -p $O
 timeout 600 python tools/e2e_bench.py --keep > $O/e2e_pread8.log 2>&1; echo "pread 8 (default): rc $?"; grep "^run\|BED" $O/e2e_pread8.log | cut -c1-400
 for spec in "mapped:WGBSSEG_UPLOAD_MAPPED=1" "pread4:WGBSSEG_UPLOAD_THREADS=4" "pread16:WGBSSEG_UPLOAD_THREADS=16" "pread8_2MB:WGBSSEG_UPLOAD_PIECE_KB=2048" "pread12_512KB:WGBSSEG_UPLOAD_THREADS=12 WGBSSEG_UPLOAD_PIECE_KB=512"; do
   n=${spec%%:*}; e=${spec#*:}

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 4, call 1: does clustering cheap VALU instructions pay (micro), the baseline of this box, HBM traffic of k_cost by PMC
+# does clustering cheap VALU instructions pay (micro), the baseline of this box, HBM traffic of k_cost by PMC
 set -u
 REPO=$PWD
-O=$REPO/gpurun_out/r04c1
+O=$REPO/gpurun_out/micro
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 timeout 120 $REPO/tools/micro/_build/valu_cluster > $O/valu_cluster.json 2> $O/valu_cluster.err; echo "valu_cluster rc $?"
