@@ -834,3 +834,29 @@ def test_19c_invalid_counts_in_a_disordered_chunk(seg):
     with pytest.raises(_lib.SegmentorError) as e:
         seg.segment_chunks([0], [spec['n']], spec['pcount'], spec['max_cpg'], spec['max_bp'])
     assert e.value.code == _lib.E_METH_GT_COV
+
+
+def test_19d_whole_region_call_over_a_genome_with_disordered_loci(seg):
+    """wgbsseg_segment_regions (chunk grid + junction patches + the tree, one native call) over ONE region whose loci start again in
+    the middle and hold a descending run: chunks and patches that touch those places take the plain path inside the same batches as the
+    others; the merged borders equal the reference's pairwise tree (tests/reftree.py) walked over the ORACLE's chunk DPs."""
+    import reftree
+    spec = dict(n=9000, a=30000, samples=[0, 1, 2], pcount=15.0, max_cpg=1000, max_bp=2000)
+    slices, loci = cases.build_case(spec)
+    loci = loci.astype(np.int64)
+    loci[3000:] -= loci[3000] - 7            # exactly on a chunk boundary of the 1500-site grid: the junction patch straddles it
+    loci[4400:4440] = loci[4400:4440][::-1]  # inside a chunk
+    loci[7499:7502] = loci[7499:7502][::-1]  # across a chunk boundary
+    loci = loci.astype(np.uint32)
+    seg.set_betas(slices)
+    seg.set_loci(loci)
+    n = spec['n']
+    for chunk in (1500, 4000):
+        got, stats = seg.segment_regions(np.array([1]), np.array([n + 1]), chunk, spec['pcount'], spec['max_cpg'], spec['max_bp'])
+
+        def many(sites):                     # 1-based half-open site ranges -> absolute border lists, as segment_process returns them
+            return [oracle.segment_chunk([s[a - 1:b - 1] for s in slices], loci[a - 1:b - 1], spec['pcount'], spec['max_cpg'], spec['max_bp']).astype(np.int64) + a
+                    for a, b in sites]
+        grid = [(s, min(s + chunk, n + 1)) for s in range(1, n + 1, chunk)]
+        want = reftree.tree(many(grid), many)
+        assert np.array_equal(np.asarray(got[0], dtype=np.int64), want), (chunk, _first_diff(got[0], want))
