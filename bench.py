@@ -216,9 +216,11 @@ def end_to_end(args, buf, sizes, names, loci):
             pth = op.join(d, 's%03d.beta' % s)
             buf[s, :2 * args.sites].cpu().numpy().tofile(pth)
             paths.append(pth)
-        out = op.join(d, 'blocks.bed')
         best, rows, phases = None, 0, []
-        for _ in range(3):
+        for rep in range(3):
+            # a NEW output file per run, as a user's run writes one: overwriting the previous 115 MB of BED makes the kernel drop its page-cache
+            # pages first (O_TRUNC: ~25 ms on this host, more than the writing itself) — that is not part of the pipeline
+            out = op.join(d, 'blocks_%d.bed' % rep)
             err = io.StringIO()
             t0 = time.perf_counter()
             with contextlib.redirect_stderr(err):

@@ -311,6 +311,17 @@ int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom
                      int32_t n_chroms, const int64_t* start_cpg, const int64_t* end_cpg, int64_t n_blocks,
                      const char* path, int32_t append, int32_t threads, char* err, size_t errlen);
 
+/* The same rows straight from the merged border lists of a segmentation (round 4) — what wgbsseg_segment_regions /
+ * wgbsseg_group_segment_regions leave: region r's ascending 1-based borders are borders[borders_off[r] .. borders_off[r+1]) — without
+ * building (start, end) arrays first: a row is a pair of consecutive borders of a region (segment.py:154), written when
+ * endCpG - startCpG >= min_cpg (the filter of segment.py:172-175 dump_result); *n_written / *n_dropped count both kinds (the numbers of
+ * dump_result's stderr summary).  The regions must be given in ascending order (the rows come out sorted by startCpG as segment.py:169
+ * sorts them; refused otherwise).  Same validations, messages, path / append / threads as wgbsseg_add_loci. */
+int wgbsseg_add_loci_borders(const uint32_t* loci, int64_t n_sites, const int64_t* chrom_cum, const char* const* chrom_names,
+                             int32_t n_chroms, const int32_t* borders, const int64_t* borders_off, int64_t n_regions,
+                             int64_t min_cpg, const char* path, int32_t append, int32_t threads,
+                             int64_t* n_written, int64_t* n_dropped, char* err, size_t errlen);
+
 /*
  * The text either side of the block reduction (`wgbstools beta_to_table`: beta_to_table.py:59-127, `beta_to_blocks --bedGraph`:
  * beta_to_blocks.py:112-126; the reference reads the blocks table with pandas.read_csv and prints with DataFrame.to_csv).  Host

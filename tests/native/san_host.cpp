@@ -99,6 +99,26 @@ int main(int argc, char** argv)
     const int rc = wgadd::add_loci(g, bs.data(), be.data(), (int64_t)bs.size(), fp, atoi(argv[1]), err);
     fclose(fp);
     printf("add_loci: %zu rows, rc %d %s\n", bs.size(), rc, err.c_str());
+    {   // the same genome's rows straight from border lists (three regions = the chromosomes, one of them without a block), min_cpg 1 and 3
+        std::vector<int32_t> flat;
+        std::vector<int64_t> off{0};
+        const int64_t lo[3] = {1, 701, 1501}, hi[3] = {701, 1501, 2001};
+        for (int r = 0; r < 3; r++) {
+            if (r != 1) for (int64_t b = lo[r]; b < hi[r]; b += 1 + (int64_t)(mix((uint64_t)b) % 9)) flat.push_back((int32_t)b);
+            if (r != 1) flat.push_back((int32_t)hi[r]);
+            off.push_back((int64_t)flat.size());
+        }
+        for (int64_t mc : {(int64_t)1, (int64_t)3}) {
+            wgadd::BorderRows rows{flat.data(), off.data(), 3, mc, {}};
+            rows.index();
+            FILE* nul = fopen("/dev/null", "wb");
+            std::string m;
+            int64_t written = 0;
+            const int r3 = wgadd::add_loci_rows(g, rows, rows.total(), nul, atoi(argv[1]), m, &written);
+            fclose(nul);
+            printf("add_loci from borders, min_cpg %lld: %lld of %lld blocks written, rc %d %s\n", (long long)mc, (long long)written, (long long)rows.total(), r3, m.c_str());
+        }
+    }
     // and its refusals
     const int64_t bad_s[3] = {5, 0, 1999}, bad_e[3] = {3, 4, 2003};
     for (int i = 0; i < 3; i++) {

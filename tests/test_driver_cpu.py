@@ -539,3 +539,52 @@ def test_blocks_file_loader_of_dash_L_both_parsers(tmp_path, monkeypatch):
         assert res[0] == res[1], name
         if name == 'plain':
             assert res[0] == ('ok', [[1, 3], [3, 7]])
+
+
+def test_bed_rows_straight_from_border_lists(tmp_path, capfd):
+    """wgbsseg_add_loci_borders (round 4): the BED of a segmentation from its merged border lists (one CSR) == wgbsseg_add_loci over the
+    (start, end) pairs numpy makes of the same lists, for every min_cpg, several formatting shards, regions without a block, file /
+    append / standard output; the counts it returns are dump_result's; regions out of order and a failing row are refused / reported
+    like the array form."""
+    from wgbs_tools_amd import _lib
+    rng = np.random.default_rng(11)
+    sizes = np.array([190000, 1, 90000, 120000])
+    names = ['chr1', 'chrTiny', 'chr2', 'chrM']
+    cum = np.cumsum(sizes)
+    n = int(cum[-1])
+    loci = np.concatenate([np.cumsum(rng.integers(2, 300, sz)) + 10000 for sz in sizes]).astype(np.uint32)
+    lists, lo = [], 1
+    for hi in cum:                                         # one region per chromosome: borders from lo to hi + 1, blocks of 1 .. ~8 sites
+        b = np.unique(np.concatenate([[lo, hi + 1], rng.integers(lo, hi + 2, int((hi - lo + 1) // 3) + 1)]))
+        lists.append(b.astype(np.int32))
+        lo = hi + 1
+    lists.insert(2, np.array([int(cum[1]) + 1], dtype=np.int32))      # a region with ONE border: no block
+    lists.insert(0, np.zeros(0, dtype=np.int32))                       # and an empty one
+    flat = np.concatenate(lists)
+    off = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+    s = np.concatenate([x[:-1] for x in lists if len(x) > 1]).astype(np.int64)
+    e = np.concatenate([x[1:] for x in lists if len(x) > 1]).astype(np.int64)
+    assert s.size > 3 * 32768                              # several formatting shards
+    for min_cpg in (1, 2, 3, 7):
+        keep = (e - s) > min_cpg - 1                       # segment.py:172
+        a, b = str(tmp_path / 'a.bed'), str(tmp_path / 'b.bed')
+        _lib.add_loci(loci, names, cum, s[keep], e[keep], a, threads=5)
+        written, dropped = _lib.add_loci_borders(loci, names, cum, flat, off, min_cpg, b, threads=5)
+        assert (written, dropped) == (int(keep.sum()), int((~keep).sum()))
+        assert open(a, 'rb').read() == open(b, 'rb').read(), min_cpg
+    whole = open(b, 'rb').read()
+    w2, d2 = _lib.add_loci_borders(loci, names, cum, flat, off, 7, b, append=True, threads=1)
+    assert open(b, 'rb').read() == whole + whole and (w2, d2) == (written, dropped)
+    capfd.readouterr()
+    _lib.add_loci_borders(loci, names, cum, flat[:off[2]], off[:3], 1, None, threads=2)     # standard output
+    assert capfd.readouterr().out.encode() == open(a, 'rb').read()[:0] + ''.join(
+        '%s\t%d\t%d\t%d\t%d\n' % (names[0], loci[x - 1], loci[y - 2] + 1, x, y) for x, y in zip(lists[1][:-1].tolist(), lists[1][1:].tolist())).encode()
+    # regions out of order: refused (the rows would not come out sorted by startCpG, segment.py:169)
+    with pytest.raises(_lib.SegmentorError, match='begins before'):
+        _lib.add_loci_borders(loci, names, cum, np.concatenate([lists[3], lists[1]]), np.array([0, len(lists[3]), len(lists[3]) + len(lists[1])]), 1, b)
+    # a failing row: the reference's message with the row's position among the WRITTEN rows, rows before it written
+    bad = np.array([1, 5, 9, int(cum[0]) - 3, int(cum[0]) + 5], dtype=np.int32)            # the last block crosses chr1 -> chrTiny/chr2
+    with pytest.raises(_lib.SegmentorError) as ei:
+        _lib.add_loci_borders(loci, names, cum, bad, np.array([0, 5]), 5, b)              # min_cpg 5 drops the first two blocks: the bad row is line 1
+    assert ei.value.msg == '[wt add_loci] line 1: Cross chromosomes'
+    assert open(b).read().count('\n') == 1

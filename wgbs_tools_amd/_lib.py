@@ -27,7 +27,7 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_set_betas_host', 'wgbsseg_set_betas_device', 'wgbsseg_set_loci_host', 'wgbsseg_set_loci_device',
            'wgbsseg_segment_chunks', 'wgbsseg_segment_regions', 'wgbsseg_segment_chunks_host', 'wgbsseg_prefix_sums', 'wgbsseg_scan_only',
            'wgbsseg_get_timings', 'wgbsseg_debug_fetch', 'wgbsseg_debug_sample_terms', 'wgbsseg_debug_log2',
-           'wgbsseg_debug_div', 'wgbsseg_debug_check_div', 'wgbsseg_debug_div_short', 'wgbsseg_add_loci', 'wgbsseg_block_sums', 'wgbsseg_last_block_sums_ms',
+           'wgbsseg_debug_div', 'wgbsseg_debug_check_div', 'wgbsseg_debug_div_short', 'wgbsseg_add_loci', 'wgbsseg_add_loci_borders', 'wgbsseg_block_sums', 'wgbsseg_last_block_sums_ms',
            'wgbsseg_set_site_base', 'wgbsseg_stitch_regions', 'wgbsseg_group_create', 'wgbsseg_group_destroy', 'wgbsseg_group_size',
            'wgbsseg_group_plan', 'wgbsseg_group_load_host', 'wgbsseg_group_share_set_device', 'wgbsseg_group_segment_regions',
            'wgbsseg_group_get_timings', 'wgbsseg_plan_shares', 'wgbsseg_set_lbetas_host',
@@ -203,6 +203,9 @@ def load():
     L.wgbsseg_marker_stats.argtypes = [vp, vp, i32, vp, i32, i64, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_add_loci.restype = i32
     L.wgbsseg_add_loci.argtypes = [vp, i64, vp, C.POINTER(C.c_char_p), i32, vp, vp, i64, C.c_char_p, i32, i32, C.c_char_p, C.c_size_t]
+    L.wgbsseg_add_loci_borders.restype = i32
+    L.wgbsseg_add_loci_borders.argtypes = [vp, i64, vp, C.POINTER(C.c_char_p), i32, vp, vp, i64, i64, C.c_char_p, i32, i32,
+                                           C.POINTER(i64), C.POINTER(i64), C.c_char_p, C.c_size_t]
     L.wgbsseg_blocks_parse.restype = i32
     L.wgbsseg_blocks_parse.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, vp, C.POINTER(i64), vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.wgbsseg_blocks_write_table.restype = i32
@@ -698,6 +701,7 @@ class SegmenterGroup:
             if getattr(self, '_streaming', None) is not None:
                 self._L.wgbsseg_group_load_wait(self._h, None, 0)      # (already collected on success; a failed call may have left uploaders running)
                 self._streaming = None
+        self.last_csr = (out, off)                # the same lists as one CSR (views into the buffer the next call overwrites)
         res = [out[off[r]:off[r + 1]].astype(np.int64) if copy else out[off[r]:off[r + 1]] for r in range(n)]
         return res, _stats_dict(stats)
 
@@ -739,6 +743,24 @@ def add_loci(loci, chrom_names, chrom_cum, start_cpg, end_cpg, path=None, append
     rc = L.wgbsseg_add_loci(loci.ctypes.data, loci.size, cum.ctypes.data, names, len(chrom_names), s.ctypes.data, e.ctypes.data,
                             s.size, None if path is None else os.fsencode(path), 1 if append else 0, int(threads), err, ERRLEN)
     _check(rc, err)
+
+
+def add_loci_borders(loci, chrom_names, chrom_cum, flat, off, min_cpg=1, path=None, append=False, threads=0):
+    """wgbsseg_add_loci_borders: the BED rows of a segmentation straight from its merged border lists (CSR: region r's ascending 1-based
+    borders are flat[off[r]:off[r+1]], int32) -> (rows written, blocks dropped as shorter than min_cpg)."""
+    L = load()
+    loci = np.ascontiguousarray(loci, dtype=np.uint32)
+    cum = np.ascontiguousarray(chrom_cum, dtype=np.int64)
+    flat = np.ascontiguousarray(flat, dtype=np.int32)
+    off = np.ascontiguousarray(off, dtype=np.int64)
+    names = (C.c_char_p * len(chrom_names))(*[str(n).encode() for n in chrom_names])
+    err = C.create_string_buffer(ERRLEN)
+    nw, nd = C.c_int64(0), C.c_int64(0)
+    rc = L.wgbsseg_add_loci_borders(loci.ctypes.data, loci.size, cum.ctypes.data, names, len(chrom_names), flat.ctypes.data, off.ctypes.data,
+                                    off.size - 1, int(min_cpg), None if path is None else os.fsencode(path), 1 if append else 0, int(threads),
+                                    C.byref(nw), C.byref(nd), err, ERRLEN)
+    _check(rc, err)
+    return nw.value, nd.value
 
 
 # ------------------------------------------------------------------------------------------------------------

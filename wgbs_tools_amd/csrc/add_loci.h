@@ -82,7 +82,8 @@ inline int check_row(const Genome& g, int64_t s, int64_t e, int& c1, std::string
 // Text of one shard of rows.  Raw storage (not std::string): resize() would zero-fill ~100 bytes per row first.
 struct Shard {
     char* buf = nullptr; size_t len = 0;
-    int64_t bad_line = -1; int bad_kind = 0; std::string msg;
+    int64_t rows = 0;                                             // rows formatted (a BorderRows shard drops the blocks shorter than min_cpg)
+    int64_t bad_line = -1; int bad_kind = 0; std::string msg;    // bad_line: position of the failing row among the shard's rows
     Shard() {}
     Shard(const Shard&) = delete;
     Shard& operator=(const Shard&) = delete;
@@ -90,28 +91,64 @@ struct Shard {
     void release() { free(buf); buf = nullptr; len = 0; }
 };
 
-inline void format_range(const Genome& g, const int64_t* s, const int64_t* e, int64_t lo, int64_t hi, size_t max_name, Shard& out)
+// Where the rows come from.  ArrayRows: two arrays (startCpG, endCpG), every row is written.  BorderRows (round 4): the merged border lists
+// of the regions as the segmentation leaves them (CSR: region r's ascending 1-based borders are flat[off[r] .. off[r+1])); row = a pair of
+// consecutive borders (segment.py:154), kept when endCpG - startCpG >= min_cpg (segment.py:172-175 dump_result) — no (start, end) arrays
+// are ever built (for hg19: 2 x 22 MB of numpy concatenations and a filter pass, ~25 ms of one Python thread around 15 ms of writing).
+struct ArrayRows {
+    const int64_t* s; const int64_t* e;
+    struct Cursor { int64_t r; };
+    Cursor at(int64_t r) const { return Cursor{r}; }
+    bool get(Cursor& c, int64_t& a, int64_t& b) const { a = s[c.r]; b = e[c.r]; c.r++; return true; }
+};
+struct BorderRows {
+    const int32_t* flat; const int64_t* off; int64_t n_regions; int64_t min_cpg;
+    std::vector<int64_t> bcum;                                   // blocks before region r (unfiltered): [n_regions + 1]
+    void index() { bcum.assign((size_t)n_regions + 1, 0); for (int64_t r = 0; r < n_regions; r++) bcum[(size_t)r + 1] = bcum[(size_t)r] + std::max<int64_t>(0, off[r + 1] - off[r] - 1); }
+    int64_t total() const { return bcum.back(); }
+    struct Cursor { int64_t reg, j; };
+    Cursor at(int64_t r) const
+    {
+        const int64_t reg = (int64_t)(std::upper_bound(bcum.begin(), bcum.end(), r) - bcum.begin()) - 1;
+        return Cursor{reg, r - bcum[(size_t)reg]};
+    }
+    bool get(Cursor& c, int64_t& a, int64_t& b) const
+    {
+        while (c.j >= off[c.reg + 1] - off[c.reg] - 1) { c.reg++; c.j = 0; }             // (regions without a block)
+        const int32_t* p = flat + off[c.reg] + c.j;
+        a = p[0]; b = p[1];
+        c.j++;
+        return b - a >= min_cpg;
+    }
+};
+
+template <class Rows>
+inline void format_range(const Genome& g, const Rows& rows, int64_t lo, int64_t hi, size_t max_name, Shard& out)
 {
     const size_t row_cap = max_name + 4 * 20 + 5;              // name, four numbers of <= 20 digits, 4 tabs + newline
     out.buf = static_cast<char*>(malloc((size_t)(hi - lo) * row_cap + 1));
     if (!out.buf) { out.bad_line = lo; out.bad_kind = 3; out.msg = "out of memory"; return; }
     char* p = out.buf;
     int hint = -1;
+    typename Rows::Cursor cur = rows.at(lo);
     for (int64_t r = lo; r < hi; r++) {
+        int64_t sr, er;
+        if (!rows.get(cur, sr, er)) continue;                   // (a block shorter than min_cpg: not a row)
         int c1 = 0;
-        const int kind = check_row(g, s[r], e[r], c1, out.msg, hint);
+        const int kind = check_row(g, sr, er, c1, out.msg, hint);
         hint = c1;
-        if (kind) { out.bad_line = r; out.bad_kind = kind; break; }
+        if (kind) { out.bad_line = out.rows; out.bad_kind = kind; break; }      // (position among the shard's rows; the callers add the rows before it)
         const char* nm = g.names[c1];
         const size_t nl = strlen(nm);
-        const uint64_t start = g.loci[s[r] - 1];
-        const uint64_t end = (e[r] == s[r]) ? start + 2 : (uint64_t)g.loci[e[r] - 2] + 1;
+        const uint64_t start = g.loci[sr - 1];
+        const uint64_t end = (er == sr) ? start + 2 : (uint64_t)g.loci[er - 2] + 1;
         memcpy(p, nm, nl); p += nl;
         *p++ = '\t'; p = put_u64(p, start);
         *p++ = '\t'; p = put_u64(p, end);
-        *p++ = '\t'; p = put_u64(p, (uint64_t)s[r]);
-        *p++ = '\t'; p = put_u64(p, (uint64_t)e[r]);
+        *p++ = '\t'; p = put_u64(p, (uint64_t)sr);
+        *p++ = '\t'; p = put_u64(p, (uint64_t)er);
         *p++ = '\n';
+        out.rows++;
     }
     out.len = (size_t)(p - out.buf);
 }
@@ -121,8 +158,10 @@ inline void format_range(const Genome& g, const int64_t* s, const int64_t* e, in
 // Shards of WG_ADD_SHARD rows are formatted by a pool of threads (next shard from a shared counter) while the calling
 // thread writes finished shards in order: the wall time is max(formatting, writing), not their sum.
 #define WG_ADD_SHARD 32768
-inline int add_loci(const Genome& g, const int64_t* s, const int64_t* e, int64_t n, FILE* fp, int threads, std::string& err)
+template <class Rows>
+inline int add_loci_rows(const Genome& g, const Rows& rows, int64_t n, FILE* fp, int threads, std::string& err, int64_t* n_written = nullptr)
 {
+    if (n_written) *n_written = 0;
     if (n <= 0) return 0;
     int T = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     const int64_t n_shards = (n + WG_ADD_SHARD - 1) / WG_ADD_SHARD;
@@ -140,7 +179,7 @@ inline int add_loci(const Genome& g, const int64_t* s, const int64_t* e, int64_t
         for (;;) {
             const int64_t k = next.fetch_add(1);
             if (k >= n_shards || k > stop_at.load()) break;
-            format_range(g, s, e, k * WG_ADD_SHARD, std::min<int64_t>(n, (k + 1) * WG_ADD_SHARD), max_name, sh[(size_t)k]);
+            format_range(g, rows, k * WG_ADD_SHARD, std::min<int64_t>(n, (k + 1) * WG_ADD_SHARD), max_name, sh[(size_t)k]);
             if (sh[(size_t)k].bad_line >= 0) {
                 int64_t cur = stop_at.load();
                 while (k < cur && !stop_at.compare_exchange_weak(cur, k)) {}
@@ -152,9 +191,10 @@ inline int add_loci(const Genome& g, const int64_t* s, const int64_t* e, int64_t
     std::vector<std::thread> th;
     if (T > 1) for (int t = 0; t < T; t++) th.emplace_back(worker);
     int rc = 0;
+    int64_t written = 0;
     for (int64_t k = 0; k < n_shards && rc == 0; k++) {
         if (T == 1) {
-            format_range(g, s, e, k * WG_ADD_SHARD, std::min<int64_t>(n, (k + 1) * WG_ADD_SHARD), max_name, sh[(size_t)k]);
+            format_range(g, rows, k * WG_ADD_SHARD, std::min<int64_t>(n, (k + 1) * WG_ADD_SHARD), max_name, sh[(size_t)k]);
         } else {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return done[(size_t)k].load(std::memory_order_acquire) != 0; });
@@ -163,24 +203,32 @@ inline int add_loci(const Genome& g, const int64_t* s, const int64_t* e, int64_t
         if (x.bad_kind == 3) { err = x.msg; rc = 3; break; }
         if (x.len && fwrite(x.buf, 1, x.len, fp) != x.len) { err = "write failed"; rc = 3; break; }
         if (x.bad_line >= 0) {
-            if (x.bad_kind == 1) err = "[wt add_loci] line " + std::to_string(x.bad_line) + ": " + x.msg;
+            if (x.bad_kind == 1) err = "[wt add_loci] line " + std::to_string(written + x.bad_line) + ": " + x.msg;
             else err = x.msg;
             rc = x.bad_kind;
         }
+        written += x.rows;
         x.release();
     }
+    if (n_written) *n_written = written;
     if (rc != 0) { int64_t cur = stop_at.load(); while (cur > -1 && !stop_at.compare_exchange_weak(cur, -1)) {} }   // let the pool drain
     for (auto& t : th) t.join();
     if (fflush(fp) != 0 && rc == 0) { err = "write failed"; rc = 3; }
     return rc;
+}
+inline int add_loci(const Genome& g, const int64_t* s, const int64_t* e, int64_t n, FILE* fp, int threads, std::string& err)
+{
+    return add_loci_rows(g, ArrayRows{s, e}, n, fp, threads, err);
 }
 
 // The same rows into a regular FILE at byte offset `base` (descriptor `fd`): every shard is formatted by the pool first, the
 // shard lengths give every shard its place in the file, and the pool then writes the shards side by side with pwrite — a
 // single writer into the page cache tops out near 2 GB/s, a few of them do not.  Same return codes and messages as add_loci();
 // rows before a failing row are written.
-inline int add_loci_fd(const Genome& g, const int64_t* s, const int64_t* e, int64_t n, int fd, int64_t base, int threads, std::string& err)
+template <class Rows>
+inline int add_loci_fd_rows(const Genome& g, const Rows& rows, int64_t n, int fd, int64_t base, int threads, std::string& err, int64_t* n_written = nullptr)
 {
+    if (n_written) *n_written = 0;
     if (n <= 0) return 0;
     int T = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     const int64_t n_shards = (n + WG_ADD_SHARD - 1) / WG_ADD_SHARD;
@@ -199,7 +247,7 @@ inline int add_loci_fd(const Genome& g, const int64_t* s, const int64_t* e, int6
     };
     pool([&](int64_t k) {
         if (k > stop_at.load()) return;
-        format_range(g, s, e, k * WG_ADD_SHARD, std::min<int64_t>(n, (k + 1) * WG_ADD_SHARD), max_name, sh[(size_t)k]);
+        format_range(g, rows, k * WG_ADD_SHARD, std::min<int64_t>(n, (k + 1) * WG_ADD_SHARD), max_name, sh[(size_t)k]);
         if (sh[(size_t)k].bad_line >= 0) {
             int64_t cur = stop_at.load();
             while (k < cur && !stop_at.compare_exchange_weak(cur, k)) {}
@@ -208,10 +256,14 @@ inline int add_loci_fd(const Genome& g, const int64_t* s, const int64_t* e, int6
     const int64_t last = std::min<int64_t>(stop_at.load(), n_shards - 1);       // shards 0 .. last hold rows to write
     int rc = 0;
     std::vector<int64_t> off((size_t)last + 2, base);
+    int64_t written = 0, before_last = 0;
     for (int64_t k = 0; k <= last; k++) {
         if (sh[(size_t)k].bad_kind == 3) { err = sh[(size_t)k].msg; return 3; }
         off[(size_t)k + 1] = off[(size_t)k] + (int64_t)sh[(size_t)k].len;
+        before_last = written;
+        written += sh[(size_t)k].rows;
     }
+    if (n_written) *n_written = written;
     if (ftruncate(fd, off[(size_t)last + 1]) != 0) { err = "write failed"; return 3; }
     std::atomic<int> io_bad(0);
     pool([&](int64_t k) {
@@ -227,11 +279,15 @@ inline int add_loci_fd(const Genome& g, const int64_t* s, const int64_t* e, int6
     if (io_bad.load()) { err = "write failed"; return 3; }
     const Shard& b = sh[(size_t)last];
     if (b.bad_line >= 0) {
-        if (b.bad_kind == 1) err = "[wt add_loci] line " + std::to_string(b.bad_line) + ": " + b.msg;
+        if (b.bad_kind == 1) err = "[wt add_loci] line " + std::to_string(before_last + b.bad_line) + ": " + b.msg;
         else err = b.msg;
         rc = b.bad_kind;
     }
     return rc;
+}
+inline int add_loci_fd(const Genome& g, const int64_t* s, const int64_t* e, int64_t n, int fd, int64_t base, int threads, std::string& err)
+{
+    return add_loci_fd_rows(g, ArrayRows{s, e}, n, fd, base, threads, err);
 }
 
 }  // namespace wgadd

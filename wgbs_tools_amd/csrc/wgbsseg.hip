@@ -2048,6 +2048,46 @@ int wgbsseg_add_loci(const uint32_t* loci, int64_t n_sites, const int64_t* chrom
     return WGBSSEG_OK;
 }
 
+int wgbsseg_add_loci_borders(const uint32_t* loci, int64_t n_sites, const int64_t* chrom_cum, const char* const* chrom_names, int32_t n_chroms,
+                             const int32_t* borders, const int64_t* borders_off, int64_t n_regions, int64_t min_cpg,
+                             const char* path, int32_t append, int32_t threads, int64_t* n_written, int64_t* n_dropped, char* err, size_t errlen)
+{
+    if (n_written) *n_written = 0;
+    if (n_dropped) *n_dropped = 0;
+    if (!loci || !chrom_cum || !chrom_names || n_chroms < 1 || n_sites < 1 || n_regions < 0 || (n_regions && (!borders || !borders_off))) {
+        set_err(err, errlen, "add_loci_borders: bad argument"); return WGBSSEG_E_ARG;
+    }
+    if (chrom_cum[n_chroms - 1] != n_sites) { set_err(err, errlen, "add_loci: chromosome sizes sum to %lld, loci has %lld sites", (long long)chrom_cum[n_chroms - 1], (long long)n_sites); return WGBSSEG_E_ARG; }
+    // the rows must come out sorted by startCpG (segment.py:169 sorts them): region lists in ascending order, each ascending
+    for (int64_t r = 0; r < n_regions; r++) {
+        if (borders_off[r + 1] < borders_off[r]) { set_err(err, errlen, "add_loci_borders: offsets not ascending"); return WGBSSEG_E_ARG; }
+        if (r > 0 && borders_off[r + 1] > borders_off[r] && borders_off[r] > borders_off[r - 1] && borders[borders_off[r]] < borders[borders_off[r] - 1]) {
+            set_err(err, errlen, "add_loci_borders: region %lld begins before region %lld ends (sort the blocks first)", (long long)r, (long long)(r - 1)); return WGBSSEG_E_ARG;
+        }
+    }
+    wgadd::Genome g = {loci, n_sites, chrom_cum, chrom_names, n_chroms};
+    wgadd::BorderRows rows{borders, borders_off, n_regions, min_cpg, {}};
+    rows.index();
+    const int64_t total = rows.total();
+    std::string msg;
+    int rc = 0;
+    int64_t written = 0;
+    if (path) {
+        const int fd = open(path, O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0666);
+        if (fd < 0) { set_err(err, errlen, "add_loci: cannot open %s", path); return WGBSSEG_E_ARG; }
+        const off_t base = append ? lseek(fd, 0, SEEK_END) : 0;
+        rc = base < 0 ? 3 : wgadd::add_loci_fd_rows(g, rows, total, fd, (int64_t)base, threads, msg, &written);
+        if (close(fd) != 0 && rc == 0) { set_err(err, errlen, "add_loci: write to %s failed", path); return WGBSSEG_E_ARG; }
+        if (rc == 3 && msg.empty()) msg = "write failed";
+    } else {
+        rc = wgadd::add_loci_rows(g, rows, total, stdout, threads, msg, &written);
+    }
+    if (n_written) *n_written = written;
+    if (n_dropped) *n_dropped = rc ? 0 : total - written;
+    if (rc) { set_err(err, errlen, "%s", msg.c_str()); return WGBSSEG_E_ARG; }
+    return WGBSSEG_OK;
+}
+
 int wgbsseg_blocks_parse(const char* text, int64_t len, int64_t max_rows, int64_t cap, int64_t* line_off, int32_t* len3,
                          int64_t* start_cpg, int64_t* end_cpg, uint8_t* na, int64_t* n_rows,
                          int64_t* bp_start, int64_t* bp_end, int32_t* bp_ok, int32_t* first_fields)

@@ -36,6 +36,18 @@ class GroupEngine:
         res, self.last_stats = self.group.segment_regions()
         return res
 
+    def segment_regions_csr(self, regions, chunk_size, params):
+        """The same call, the result left as ONE CSR: (flat int32 absolute 1-based borders, off int64 [regions + 1]) — views into the
+        group's result buffer, valid until its next call; what wgbsseg_add_loci_borders prints the BED from without any (start, end)
+        arrays in between."""
+        loci = self.genome.loci()
+        self.windows = self.group.plan(loci, regions, chunk_size, params['pcount'], params['max_cpg'], params['max_bp'])
+        if self._maps is None:
+            self._maps = [np.memmap(b, dtype=np.uint8, mode='r') for b in self.betas]
+        self.group.load_host(self._maps, wait=False)
+        _, self.last_stats = self.group.segment_regions(copy=False)
+        return self.group.last_csr
+
     def timings(self):
         return [self.group.timings(d) for d in range(self.group.n_shares)]
 

@@ -234,6 +234,7 @@ class SegmentByChunks:
         from . import parallel
         rank, world, local = parallel.env_rank_world()
         own_engine = self.param_dict['engine'] is None
+        csr = None
         if world > 1:
             return self.run_sharded(rank, world, local)
         want_stats = bool(getattr(self.args, 'stats', None))
@@ -251,8 +252,11 @@ class SegmentByChunks:
             if hasattr(eng, 'segment_regions'):
                 # native chunk grid + batched patches + stitching around the GPU batches (csrc/stitch.h)
                 regs = self.regions()
+                # an engine that can leave its result as one CSR of absolute borders (the share groups: every whole-genome / -r / -s run and
+                # sorted -L files) hands it to the BED writer as it is (wgbsseg_add_loci_borders): no per-region copies, no (start, end) arrays
+                as_csr = lambda e: getattr(e, 'segment_regions_csr', None) if all(regs[i][0] >= regs[i - 1][1] for i in range(1, len(regs))) else None
                 try:
-                    res = eng.segment_regions(regs, self.args.chunk_size, self.param_dict)
+                    res = (as_csr(eng) or eng.segment_regions)(regs, self.args.chunk_size, self.param_dict)
                 except Exception as e:
                     if not (own_engine and getattr(e, 'code', 0) == -7 and 'not resident on any single share' in str(e)):
                         raise _as_reference_error(e)
@@ -260,8 +264,11 @@ class SegmentByChunks:
                     eprint('[wt segment] a junction patch outgrew the share halo; rerunning on one GPU')
                     eng.close()
                     eng = self.param_dict['engine'] = self.make_engine(starts, ends, gpus=1)
-                    res = eng.segment_regions(regs, self.args.chunk_size, self.param_dict)
-                merged = dict(zip([f'{a}-{b}' for a, b in regs], res))
+                    res = (as_csr(eng) or eng.segment_regions)(regs, self.args.chunk_size, self.param_dict)
+                if as_csr(eng):
+                    csr, merged = res, None
+                else:
+                    merged = dict(zip([f'{a}-{b}' for a, b in regs], res))
                 if want_stats:                                   # (before the engine goes away)
                     self.report['engine'] = type(eng).__name__
                     self.report['stitching'] = getattr(eng, 'last_stats', None)
@@ -288,9 +295,12 @@ class SegmentByChunks:
                 self.param_dict['engine'] = None
         try:
             if prof: prof.append(('segmentation (device + stitching)', time.perf_counter()))
-            s = np.concatenate([m[:-1] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
-            e = np.concatenate([m[1:] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
-            self.dump_result(s, e)
+            if csr is not None:
+                self.dump_result_csr(*csr)
+            else:
+                s = np.concatenate([m[:-1] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
+                e = np.concatenate([m[1:] for m in merged.values()]) if merged else np.zeros(0, dtype=np.int64)
+                self.dump_result(s, e)
         finally:
             if closer is not None:
                 closer.join()
@@ -385,6 +395,30 @@ class SegmentByChunks:
             self.param_dict['engine'] = None
             dist.barrier()
             run.close()
+
+    def dump_result_csr(self, flat, off):
+        """dump_result (segment.py:167-190) straight from the merged border lists (CSR of absolute 1-based borders, regions ascending): the
+        blocks are the pairs of consecutive borders (segment.py:154), the `min_cpg` filter and the BED rows happen in the library
+        (wgbsseg_add_loci_borders) — same rows, same stderr summary."""
+        from . import _lib
+        nr_blocks = int(np.maximum(np.diff(off) - 1, 0).sum())
+        if nr_blocks == 0:
+            eprint('Empty blocks array')
+            return
+        names, sizes = self.genome.get_chrom_cpg_sizes()
+        out_path = self.args.out_path
+        to_stdout = out_path is None or out_path is sys.stdout
+        if to_stdout:
+            sys.stdout.flush()
+        try:
+            written, dropped = _lib.add_loci_borders(self.genome.loci(), names, np.cumsum(sizes), flat, off, self.args.min_cpg,
+                                                     None if to_stdout else out_path)
+        except _lib.SegmentorError as e:
+            raise RuntimeError(e.msg)
+        eprint(f'[wt segment] found {written:,} blocks\n'
+               f'             (dropped {dropped:,} short blocks)')
+        if hasattr(self, 'report'):
+            self.report.update(blocks_found=int(written), blocks_dropped=int(dropped))
 
     def dump_result(self, start_cpg, end_cpg):
         """segment.py:167-190"""
