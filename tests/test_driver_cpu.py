@@ -582,6 +582,8 @@ def test_bed_rows_straight_from_border_lists(tmp_path, capfd):
     # regions out of order: refused (the rows would not come out sorted by startCpG, segment.py:169)
     with pytest.raises(_lib.SegmentorError, match='begins before'):
         _lib.add_loci_borders(loci, names, cum, np.concatenate([lists[3], lists[1]]), np.array([0, len(lists[3]), len(lists[3]) + len(lists[1])]), 1, b)
+    with pytest.raises(_lib.SegmentorError, match='region 2 begins before region 0 ends'):       # ... also across a region without borders
+        _lib.add_loci_borders(loci, names, cum, np.concatenate([lists[3], lists[1]]), np.array([0, len(lists[3]), len(lists[3]), len(lists[3]) + len(lists[1])]), 1, b)
     # a failing row: the reference's message with the row's position among the WRITTEN rows, rows before it written
     bad = np.array([1, 5, 9, int(cum[0]) - 3, int(cum[0]) + 5], dtype=np.int32)            # the last block crosses chr1 -> chrTiny/chr2
     with pytest.raises(_lib.SegmentorError) as ei:

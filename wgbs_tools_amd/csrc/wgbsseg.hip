@@ -2059,10 +2059,16 @@ int wgbsseg_add_loci_borders(const uint32_t* loci, int64_t n_sites, const int64_
     }
     if (chrom_cum[n_chroms - 1] != n_sites) { set_err(err, errlen, "add_loci: chromosome sizes sum to %lld, loci has %lld sites", (long long)chrom_cum[n_chroms - 1], (long long)n_sites); return WGBSSEG_E_ARG; }
     // the rows must come out sorted by startCpG (segment.py:169 sorts them): region lists in ascending order, each ascending
-    for (int64_t r = 0; r < n_regions; r++) {
-        if (borders_off[r + 1] < borders_off[r]) { set_err(err, errlen, "add_loci_borders: offsets not ascending"); return WGBSSEG_E_ARG; }
-        if (r > 0 && borders_off[r + 1] > borders_off[r] && borders_off[r] > borders_off[r - 1] && borders[borders_off[r]] < borders[borders_off[r] - 1]) {
-            set_err(err, errlen, "add_loci_borders: region %lld begins before region %lld ends (sort the blocks first)", (long long)r, (long long)(r - 1)); return WGBSSEG_E_ARG;
+    {
+        int64_t last_r = -1;                                      // the last region that held a border, and that border
+        int32_t last_b = 0;
+        for (int64_t r = 0; r < n_regions; r++) {
+            if (borders_off[r + 1] < borders_off[r] || (r == 0 && borders_off[0] < 0)) { set_err(err, errlen, "add_loci_borders: offsets not ascending"); return WGBSSEG_E_ARG; }
+            if (borders_off[r + 1] == borders_off[r]) continue;
+            if (last_r >= 0 && borders[borders_off[r]] < last_b) {
+                set_err(err, errlen, "add_loci_borders: region %lld begins before region %lld ends (sort the blocks first)", (long long)r, (long long)last_r); return WGBSSEG_E_ARG;
+            }
+            last_r = r; last_b = borders[borders_off[r + 1] - 1];
         }
     }
     wgadd::Genome g = {loci, n_sites, chrom_cum, chrom_names, n_chroms};
