@@ -18,7 +18,7 @@ import sys
 ROOT = op.dirname(op.dirname(op.abspath(__file__)))
 OUT = op.join(ROOT, 'gpurun_out')
 EXTRA = sys.argv[1:]
-BENCH = [sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--matrix', '0', '--block-sums', '0'] + EXTRA
+BENCH = [sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--matrix', '0', '--block-sums', '0', '--scan-carries', '0'] + EXTRA
 CALIB = [op.join(ROOT, 'tools', 'micro', '_build', 'fetch_calib')]
 
 
