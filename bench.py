@@ -480,6 +480,7 @@ def main():
                 multi_rows.append({'samples': ns, 'failed': repr(e)})
 
     if rank == 0:
+        res = [np.array(r) for r in res]          # (the lists are views into a buffer later calls reuse)
         n_blocks = int(sum(len(r) - 1 for r in res))
         block_sums = None
         if args.block_sums and seg is not None:
@@ -665,6 +666,30 @@ def main():
         if single and args.matrix:
             # the other sample counts of the metric, same genome and parameters, a few steps each (timed like the main run)
             rows = []
+            # what ONE GPU of eight would run: the same genome as a share group of 8 with all shares on this device (each share's launches are those of a
+            # GPU's share; they run one after the other here), per share = step / 8.  Borders must equal the one-context result.
+            try:
+                g8 = _lib.SegmenterGroup([local] * 8)
+                w8 = g8.plan(loci, regions, args.chunk, args.pcount, max_cpg, args.max_bp)
+                for d in range(8):
+                    g8.share_set_device(d, int(buf.data_ptr()) + 2 * int(w8['win_lo'][d]), args.samples, pitch, keepalive=buf)
+                r8, _s8 = g8.segment_regions(copy=False)
+                same = len(r8) == len(res) and all(np.array_equal(a, b) for a, b in zip(r8, res))
+                torch.cuda.synchronize()
+                k8, t1 = 5, time.perf_counter()
+                for _ in range(k8):
+                    g8.segment_regions(copy=False)
+                torch.cuda.synchronize()
+                d8 = (time.perf_counter() - t1) / k8
+                rows.append({'samples': args.samples, 'shares_on_this_gpu': 8, 'steps': k8, 'ms_per_step': d8 * 1e3, 'ms_per_share': d8 * 1e3 / 8,
+                             'value': args.sites / d8, 'unit': 'CpG-sites/s', 'borders_equal_one_context': bool(same),
+                             'share_work_max_over_mean': float(max(w8['work'])) / (float(sum(w8['work'])) / 8),
+                             'what': 'a share group of 8 with every share on this GPU: ms_per_share is what one GPU of eight would spend on its share (its own '
+                                     'launches, stages and recurrence tail), before the one host-side tree'})
+                g8.close()
+                del g8
+            except Exception as e:
+                rows.append({'samples': args.samples, 'shares_on_this_gpu': 8, 'failed': repr(e)})
             seg.close()
             seg, buf = None, None
             torch.cuda.empty_cache()

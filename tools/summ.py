@@ -21,6 +21,9 @@ for f in sys.argv[1:]:
         if sc:
             print('    k_scan with carries: %.3f ms, %.2f of peak, traffic %s' % (sc['avg_launch_ms'], sc['frac'], sc['traffic_over_algorithmic']))
         for r in (d.get('matrix') or {}).get('rows', []):
+            if 'shares_on_this_gpu' in r and 'failed' not in r:
+                print('    x%-4d as %d shares on this GPU: %8.3f ms/step = %.3f ms per share, borders equal: %s' % (r['samples'], r['shares_on_this_gpu'], r['ms_per_step'], r['ms_per_share'], r['borders_equal_one_context']))
+                continue
             if 'failed' in r:
                 print('    x%-4d failed: %s' % (r['samples'], r['failed']))
             else:
