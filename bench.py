@@ -666,8 +666,8 @@ def main():
         if single and args.matrix:
             # the other sample counts of the metric, same genome and parameters, a few steps each (timed like the main run)
             rows = []
-            # what ONE GPU of eight would run: the same genome as a share group of 8 with all shares on this device (each share's launches are those of a
-            # GPU's share; they run one after the other here), per share = step / 8.  Borders must equal the one-context result.
+            # the 8-GPU form of the product on this one GPU: the same genome as a share group of 8 with all shares on this device (each share's launches
+            # are those of a GPU's share; the shares' host threads run them concurrently here).  Borders must equal the one-context result.
             try:
                 g8 = _lib.SegmenterGroup([local] * 8)
                 w8 = g8.plan(loci, regions, args.chunk, args.pcount, max_cpg, args.max_bp)
@@ -684,8 +684,10 @@ def main():
                 rows.append({'samples': args.samples, 'shares_on_this_gpu': 8, 'steps': k8, 'ms_per_step': d8 * 1e3, 'ms_per_share': d8 * 1e3 / 8,
                              'value': args.sites / d8, 'unit': 'CpG-sites/s', 'borders_equal_one_context': bool(same),
                              'share_work_max_over_mean': float(max(w8['work'])) / (float(sum(w8['work'])) / 8),
-                             'what': 'a share group of 8 with every share on this GPU: ms_per_share is what one GPU of eight would spend on its share (its own '
-                                     'launches, stages and recurrence tail), before the one host-side tree'})
+                             'what': 'the product\'s 8-GPU form (a share group of 8: work-balanced chunk runs, one host thread per share, ONE host-side tree) with every '
+                                     'share on this one GPU: checks that it gives the one-context borders, and times it.  The shares\' launches run concurrently here, '
+                                     'so ms_per_share = step / 8 is a THROUGHPUT figure; a share alone on its own GPU also pays its front, stage drains and recurrence '
+                                     'tail unhidden (bench.py --sites 3527181: ~4.4 ms, profiles/r04_bench_one_eighth.json)'})
                 g8.close()
                 del g8
             except Exception as e:
