@@ -625,6 +625,7 @@ class SegmenterGroup:
         self.devices = [int(d) for d in dv]
         self._keep = []
         self._rbuf = None
+        self.last_csr = None          # (flat int32 borders, int64 offsets) of the last segment_regions call
         self._cap = 0
         self.n_regions = 0
 

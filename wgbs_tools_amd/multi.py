@@ -25,27 +25,25 @@ class GroupEngine:
         self.last_stats = None
         self.windows = None
 
-    def segment_regions(self, regions, chunk_size, params):
-        """regions: [(startCpG, endCpG)] 1-based half-open, ascending and disjoint (whole chromosomes, a -s/-r range or the
-        rows of a sorted -L file).  -> merged absolute border list of each region."""
+    def _run(self, regions, chunk_size, params, copy):
         loci = self.genome.loci()
         self.windows = self.group.plan(loci, regions, chunk_size, params['pcount'], params['max_cpg'], params['max_bp'])
         if self._maps is None:
             self._maps = [np.memmap(b, dtype=np.uint8, mode='r') for b in self.betas]
         self.group.load_host(self._maps, wait=False)        # the shares segment what has arrived while the rest is uploading
-        res, self.last_stats = self.group.segment_regions()
+        res, self.last_stats = self.group.segment_regions(copy=copy)
         return res
+
+    def segment_regions(self, regions, chunk_size, params):
+        """regions: [(startCpG, endCpG)] 1-based half-open, ascending and disjoint (whole chromosomes, a -s/-r range or the
+        rows of a sorted -L file).  -> merged absolute border list of each region."""
+        return self._run(regions, chunk_size, params, True)
 
     def segment_regions_csr(self, regions, chunk_size, params):
         """The same call, the result left as ONE CSR: (flat int32 absolute 1-based borders, off int64 [regions + 1]) — views into the
         group's result buffer, valid until its next call; what wgbsseg_add_loci_borders prints the BED from without any (start, end)
         arrays in between."""
-        loci = self.genome.loci()
-        self.windows = self.group.plan(loci, regions, chunk_size, params['pcount'], params['max_cpg'], params['max_bp'])
-        if self._maps is None:
-            self._maps = [np.memmap(b, dtype=np.uint8, mode='r') for b in self.betas]
-        self.group.load_host(self._maps, wait=False)
-        _, self.last_stats = self.group.segment_regions(copy=False)
+        self._run(regions, chunk_size, params, False)
         return self.group.last_csr
 
     def timings(self):
