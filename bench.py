@@ -262,6 +262,25 @@ def keyed_profile(pattern, sha, **match):
     return None
 
 
+def device_report(form, asked, placements):
+    """What actually ran, for the N > 1 lines: `placements` = one (host, device index) per share (share group) or per rank (one process per
+    GPU).  `n_gpus` is the number of DISTINCT physical devices among them — never the number asked for: eight shares wrapped onto one GPU
+    (a 1-GPU box running `--gpus 8`) or two ranks sharing a device are reported as what they are.  Pure function (tests/test_bench_report_cpu.py)."""
+    placements = [(str(h), int(d)) for h, d in placements]
+    distinct = len(set(placements))
+    units = len(placements)
+    what = {'one': 'one GPU',
+            'group': 'one process, %d share%s on %d distinct GPU%s: a share group (work-balanced contiguous chunk runs, one host thread per share, one host-side tree)'
+                     % (units, '' if units == 1 else 's', distinct, '' if distinct == 1 else 's'),
+            'ranks': 'one process per share (parallel.ShardedRun), %d rank%s on %d distinct GPU%s: work-balanced contiguous chunk runs per rank, border lists handed to '
+                     'rank 0 through /dev/shm, ONE stitching tree on rank 0 inside the timed step; no collective'
+                     % (units, '' if units == 1 else 's', distinct, '' if distinct == 1 else 's')}[form]
+    if form != 'one' and distinct < units:
+        what += ' — OVERSUBSCRIBED: %d shares share %d device%s, so this line is NOT a %d-GPU measurement' % (units, distinct, '' if distinct == 1 else 's', units)
+    return {'n_gpus': distinct, 'gpus_requested': int(asked), 'shares': units, 'distinct_devices': distinct,
+            'oversubscribed': distinct < units, 'sharding': what}
+
+
 def accumulate(acc, t):
     if acc is None:
         return dict(t)
@@ -426,6 +445,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
 
+    # what ran where: one (host, device) per share / rank, so that the line can only state the devices it really used
+    import socket
+    host = socket.gethostname()
+    if group_mode:
+        placements, form = [(host, d) for d in devices], 'group'
+    elif multi:
+        gathered = [None] * world
+        _G.all_gather_object(gathered, (host, local))
+        placements, form = gathered, 'ranks'
+    else:
+        placements, form = [(host, local)], 'one'
+    devrep = device_report(form, args.gpus, placements)
+    devrep['devices_visible'] = ndev
+
     # N > 1: the same sharded step at x200 (BASELINE.json configs[3], the 8-GPU configuration: scoring-bound, so the shares' fixed costs weigh
     # least there), a few steps, timed like the main run (barrier, max over ranks)
     multi_rows = None
@@ -473,7 +506,7 @@ def main():
                 if multi:
                     dist.all_reduce(t2, op=dist.ReduceOp.MAX)
                 d2 = float(t2.item())
-                multi_rows.append({'samples': ns, 'steps': k2, 'ms_per_step': d2 * 1e3, 'value': args.sites / d2, 'unit': 'CpG-sites/s', 'n_gpus': args.gpus if group_mode else world})
+                multi_rows.append({'samples': ns, 'steps': k2, 'ms_per_step': d2 * 1e3, 'value': args.sites / d2, 'unit': 'CpG-sites/s', 'n_gpus': devrep['n_gpus'], 'shares': devrep['shares']})
                 closer()
                 torch.cuda.empty_cache()
             except Exception as e:
@@ -590,10 +623,7 @@ def main():
                                                                       'runs of 1 / 2 / 4 / 8 / 16 cheap instructions in a 1:3 mix all issue at 1.77-1.80 ns per instruction: clustering buys nothing'}
             except Exception:
                 pass
-        mode = ('one process, %d GPUs: a share group (work-balanced contiguous chunk runs, one host thread per GPU, one host-side tree)' % args.gpus
-                if group_mode else
-                'one process per GPU (parallel.ShardedRun): work-balanced contiguous chunk runs per rank, border lists handed to rank 0 through /dev/shm, '
-                'ONE stitching tree on rank 0 inside the timed step; no collective' if multi else 'one GPU')
+        mode = devrep['sharding']
         cost_ms = acc['cost_ms'] / args.steps
         # HBM-side traffic of the scoring kernel's main launch from the PMC counters (tools/pmc_cost_traffic.py: FETCH_SIZE / WRITE_SIZE in separate
         # rocprofv3 passes, calibrated in the same passes on known byte counts): only a file of THIS source state and this workload is reported
@@ -608,7 +638,7 @@ def main():
                                  % (ct['traffic_over_algorithmic'], ct['read_bytes'] / 1e9, ct['read_over_beta_bytes'], ct['write_bytes'] / 1e9, ct['_file']))
         out = {
             'metric': 'CpG-sites/sec segmented',
-            'value': value, 'unit': 'CpG-sites/s', 'n_gpus': args.gpus if group_mode else world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': value, 'unit': 'CpG-sites/s', 'n_gpus': devrep['n_gpus'], 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_step, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'u8 counts -> u32 prefix sums -> f32/f64 log-likelihood (bit-exact with the reference)',
             'data': 'synthetic (seeded hg19-shaped genome and betas, generated on the device)',
@@ -616,6 +646,8 @@ def main():
                                    % (args.sites, args.samples, args.chunk, args.max_cpg, args.max_bp, args.pcount) + (' + CpG islands in the loci' if args.islands else ''),
                        'baseline_config': 'BASELINE.json configs[2]' if (args.sites, args.samples, args.islands) == (28217448, 32, False) else 'custom',
                        'chunks': n_chunks_total, 'chromosomes': len(sizes), 'sharding': mode,
+                       'gpus_requested': devrep['gpus_requested'], 'shares': devrep['shares'], 'distinct_devices': devrep['distinct_devices'],
+                       'devices_visible': devrep['devices_visible'], 'oversubscribed': devrep['oversubscribed'],
                        'share_chunks': None if shares is None else [int(x) for x in shares['chunks']],
                        'share_work': None if shares is None else [int(x) for x in shares['work']],
                        # how even the shares are: the largest share's work over the mean (1.0 = perfectly even; rank 0 is given less on purpose in the

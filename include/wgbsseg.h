@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WGBSSEG_VERSION 200            /* 0.2.0 */
+#define WGBSSEG_VERSION 210            /* 0.2.1: round 4 changed wgbsseg_scan_only's argument list and added wgbsseg_add_loci_borders without a bump; a binding compares wgbsseg_version() with the header it was written against */
 #define WGBSSEG_MAX_CPG 65535          /* longest block, in sites (min(max_cpg, longest chunk)): see wgbsseg_segment_chunks */
 
 #define WGBSSEG_OK              0

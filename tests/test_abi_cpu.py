@@ -27,7 +27,16 @@ def test_header_and_library_agree(lib):
     raw = C.CDLL(_lib.LIB_PATH)
     for sym in declared:
         assert hasattr(raw, sym), 'libwgbsseg.so does not export %s' % sym
-    assert lib.wgbsseg_version() == int(re.search(r'#define WGBSSEG_VERSION (\d+)', hdr).group(1))
+    assert lib.wgbsseg_version() == int(re.search(r'#define WGBSSEG_VERSION (\d+)', hdr).group(1)) == _lib.ABI_VERSION
+
+
+def test_binding_refuses_a_library_of_another_abi_version(lib, monkeypatch):
+    """Argument lists differ between ABI versions (wgbsseg_scan_only, 200 -> 210): load() compares wgbsseg_version() with the version its
+    prototypes describe and refuses anything else."""
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'ABI_VERSION', _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.NativeLibraryError, match='ABI version'):
+        _lib.load()
 
 
 def test_error_codes_match_header():

@@ -584,9 +584,35 @@ def test_bed_rows_straight_from_border_lists(tmp_path, capfd):
         _lib.add_loci_borders(loci, names, cum, np.concatenate([lists[3], lists[1]]), np.array([0, len(lists[3]), len(lists[3]) + len(lists[1])]), 1, b)
     with pytest.raises(_lib.SegmentorError, match='region 2 begins before region 0 ends'):       # ... also across a region without borders
         _lib.add_loci_borders(loci, names, cum, np.concatenate([lists[3], lists[1]]), np.array([0, len(lists[3]), len(lists[3]), len(lists[3]) + len(lists[1])]), 1, b)
+    # a descending pair INSIDE a region: refused like the array form's "endCpG < startCpG", not counted as a dropped short block
+    desc = lists[1].copy()
+    desc[[40, 41]] = desc[[41, 40]]
+    with pytest.raises(_lib.SegmentorError, match=r'region 0: border 41 \(%d\) follows %d' % (desc[41], desc[40])):
+        _lib.add_loci_borders(loci, names, cum, desc, np.array([0, len(desc)]), 1, b)
     # a failing row: the reference's message with the row's position among the WRITTEN rows, rows before it written
     bad = np.array([1, 5, 9, int(cum[0]) - 3, int(cum[0]) + 5], dtype=np.int32)            # the last block crosses chr1 -> chrTiny/chr2
     with pytest.raises(_lib.SegmentorError) as ei:
         _lib.add_loci_borders(loci, names, cum, bad, np.array([0, 5]), 5, b)              # min_cpg 5 drops the first two blocks: the bad row is line 1
     assert ei.value.msg == '[wt add_loci] line 1: Cross chromosomes'
     assert open(b).read().count('\n') == 1
+
+
+def test_dump_result_csr_reports_before_a_failing_writer(synth_world, tmp_path):
+    """dump_result_csr on a list the writer refuses (a block across two chromosomes): the summary line and the --stats counts are still
+    produced — the reference prints them before it writes (segment.py:180) — and the error is the writer's."""
+    out_path = str(tmp_path / 'out.bed')
+    args = make_args(synth_world, out_path, min_cpg=3)
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        sbc = S.SegmentByChunks(args, synth_world['paths'], engine=object())
+        sbc.report = {}
+        c0 = int(synth_world['sizes'][0])
+        # two regions + an empty one between them; blocks of 4, 2 (short), 5 sites | 1 (short), 9, then one that crosses chromosome 1's end
+        flat = np.array([1, 5, 7, 12, 20, 21, 30, c0 - 2, c0 + 6], dtype=np.int32)
+        off = np.array([0, 4, 4, 9], dtype=np.int64)
+        with pytest.raises(RuntimeError, match='Cross chromosomes'):
+            sbc.dump_result_csr(flat, off)
+    text = err.getvalue()
+    assert '[wt segment] found 5 blocks\n             (dropped 2 short blocks)' in text
+    assert sbc.report == {'blocks_found': 5, 'blocks_dropped': 2}
+    assert sum(1 for _ in open(out_path)) == 4          # the rows before the failing one are written, as the reference's streaming loop would have

@@ -824,6 +824,29 @@ def test_19b_ordered_and_disordered_chunks_in_one_batch(seg):
             assert a.tolist() == b.tolist(), (pcount, max_cpg, max_bp, starts[c], lens[c], _first_diff(a, b))
 
 
+@pytest.mark.parametrize('ring_rows', [1, 130, 257, 1000])
+def test_19e_plain_path_banded_ring(seg, ring_rows, monkeypatch):
+    """The plain path's ring of rows with FEWER rows than the chunk has sites (R < n: bands of R - (W - 1) steps, slot k % R reused across the
+    k_plain_rows / k_plain_dp launches) — at the default ~1 GB budget a suite-sized chunk never gets there, so the rows are capped
+    through WGBSSEG_PLAIN_RING_ROWS (floored at W by the library: bands of ONE step at ring_rows = 1)."""
+    spec = dict(n=2400, a=52000, samples=[0, 1, 2, 3], pcount=15.0, max_cpg=1000, max_bp=2000)
+    slices, loci = cases.build_case(spec)
+    loci = loci.astype(np.int64)
+    loci[1000:] -= loci[1000] - 3            # a second chromosome
+    loci[1700:1720] = loci[1700:1720][::-1]  # a descending run
+    loci[300] = loci[299]                    # equal positions
+    loci = loci.astype(np.uint32)
+    seg.set_betas(slices)
+    seg.set_loci(loci)
+    monkeypatch.setenv('WGBSSEG_PLAIN_RING_ROWS', str(ring_rows))
+    for pcount, max_cpg, max_bp in [(15.0, 120, 2000), (0.0, 37, 900), (1.0, 256, 100000)]:
+        assert max(ring_rows, max_cpg) < spec['n']            # the ring does wrap
+        got = seg.segment_chunks([0, 900], [spec['n'], 1300], pcount, max_cpg, max_bp)
+        want = oracle.segment_chunks(slices, loci, [0, 900], [spec['n'], 1300], pcount, max_cpg, max_bp, threads=2)
+        for a, b in zip(got, want):
+            assert a.tolist() == b.tolist(), (ring_rows, pcount, max_cpg, max_bp, _first_diff(a, b))
+
+
 def test_19c_invalid_counts_in_a_disordered_chunk(seg):
     spec = cases.DISORDER_CASES['two_chromosomes']
     slices, loci = cases.build_disorder_case(spec)

@@ -23,6 +23,7 @@ SYNTH_LIB_PATH = op.join(HERE, 'csrc', 'libwgbssynth.so')
 OK, E_ARG, E_METH_GT_COV, E_NOMEM, E_HIP, E_LOCI_ORDER, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/wgbsseg.h declares (tests check the built library exports exactly these)
+ABI_VERSION = 210          # include/wgbsseg.h WGBSSEG_VERSION this binding's prototypes describe
 EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg_destroy',
            'wgbsseg_set_betas_host', 'wgbsseg_set_betas_device', 'wgbsseg_set_loci_host', 'wgbsseg_set_loci_device',
            'wgbsseg_segment_chunks', 'wgbsseg_segment_regions', 'wgbsseg_segment_chunks_host', 'wgbsseg_prefix_sums', 'wgbsseg_scan_only',
@@ -115,6 +116,11 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
     L.wgbsseg_version.restype = i32
+    got = L.wgbsseg_version()
+    if got != ABI_VERSION:
+        # argument lists differ between versions (e.g. wgbsseg_scan_only, 200 -> 210): never call through prototypes of another one
+        raise NativeLibraryError('%s reports ABI version %d, this binding was written against %d (include/wgbsseg.h WGBSSEG_VERSION): '
+                                 'rebuild it with `python -m wgbs_tools_amd.build -f`' % (LIB_PATH, got, ABI_VERSION))
     L.wgbsseg_device_count.restype = i32
     L.wgbsseg_create.restype = i32
     L.wgbsseg_create.argtypes = [i32, C.POINTER(vp), C.c_char_p, C.c_size_t]

@@ -595,8 +595,15 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
 int plain_segment_chunk(wgbsseg_ctx* c, int64_t start0, int32_t n, const wgbsseg_params* P, std::vector<int32_t>& borders, char* err, size_t errlen)
 {
     const int32_t W = (int32_t)std::min<int64_t>(P->max_cpg, n);
-    // rows of the band in flight + the W - 1 rows before it that its steps still read; <= ~1 GB of ring
-    const int64_t budget_rows = std::max<int64_t>((int64_t)W + 255, (1LL << 30) / ((int64_t)W * 8));
+    // Ring of R rows of W doubles: the rows of the band in flight + the W - 1 rows before it that its steps still read.  ~1 GB of
+    // ring while that holds at least W + 255 rows (W <= ~11,400); deeper windows take the floor W + 255 rows, i.e. up to W * n * 8
+    // bytes (28.8 GB for max_cpg >= chunk = 60,000 — within an MI355X's 288 GB; E_NOMEM below when the device cannot give it).
+    // WGBSSEG_PLAIN_RING_ROWS caps the rows (tests: the banded ring with R < n on chunks small enough for the suite).
+    int64_t budget_rows = std::max<int64_t>((int64_t)W + 255, (1LL << 30) / ((int64_t)W * 8));
+    if (const char* e = getenv("WGBSSEG_PLAIN_RING_ROWS")) {
+        const long long v = atoll(e);
+        if (v > 0) budget_rows = std::max<int64_t>((int64_t)W, (int64_t)v);     // R >= W keeps the band >= 1 row
+    }
     const int32_t R = (int32_t)std::min<int64_t>(n, budget_rows);
     const int32_t band = R >= n ? n : R - (W - 1);
     DevBuf buf, M, T, bad;
@@ -2067,6 +2074,19 @@ int wgbsseg_add_loci_borders(const uint32_t* loci, int64_t n_sites, const int64_
             if (borders_off[r + 1] == borders_off[r]) continue;
             if (last_r >= 0 && borders[borders_off[r]] < last_b) {
                 set_err(err, errlen, "add_loci_borders: region %lld begins before region %lld ends (sort the blocks first)", (long long)r, (long long)last_r); return WGBSSEG_E_ARG;
+            }
+            // ... and ascending INSIDE the region: a descending pair would be counted as a dropped short block (b - a < min_cpg) where the
+            // array form's check_row refuses "endCpG < startCpG" — refused here too, so that n_dropped counts short blocks only
+            const int32_t* p = borders + borders_off[r];
+            const int64_t nb = borders_off[r + 1] - borders_off[r];
+            int32_t desc = 0;
+            for (int64_t j = 0; j + 1 < nb; j++) desc |= (int32_t)(p[j + 1] < p[j]);
+            if (desc) {
+                int64_t j = 0;
+                while (p[j + 1] >= p[j]) j++;
+                set_err(err, errlen, "add_loci_borders: region %lld: border %lld (%d) follows %d (endCpG < startCpG; each region's borders must ascend)",
+                        (long long)r, (long long)(j + 1), (int)p[j + 1], (int)p[j]);
+                return WGBSSEG_E_ARG;
             }
             last_r = r; last_b = borders[borders_off[r + 1] - 1];
         }

@@ -114,13 +114,23 @@ class NodeSlots:
     Ranks on several hosts fall back to a gather of Python objects.
     The slot FILES are unlinked as soon as every rank has mapped them (the mappings stay valid): a run that crashes or is killed
     leaks nothing under /dev/shm.  A waiting rank checks every tenth of a second that the ranks it waits for are still alive (their
-    process ids are exchanged once) and gives up at once when one is gone, after TIMEOUT_S otherwise.
+    process ids are exchanged once; only when all ranks share one pid namespace) and gives up at once when one is gone, after
+    TIMEOUT_S otherwise (TIMEOUT_NO_PROBE_S when the probe cannot be used; WGBSSEG_SLOT_TIMEOUT_S sets it).
     Memory ordering: a slot's stamp is a plain 8-byte store issued after the stores of the lists it covers, and the reader loads the
     stamp before the lists; both rest on x86-64's total store order / ordered loads (the hosts of MI355X nodes) — on a weakly
     ordered host the stamp would need a release store and an acquire load.
     Slot layout: int64 header [8] (0: step stamp; rank 0 only, 1: steps consumed), int64 offsets [items + 1], int32 borders [cap]."""
     HDR = 64
-    TIMEOUT_S = 120.0
+    TIMEOUT_S = 120.0                 # with the liveness probe (a dead peer is noticed within 0.1 s; this only catches a hung one)
+    TIMEOUT_NO_PROBE_S = 600.0        # without it; WGBSSEG_SLOT_TIMEOUT_S overrides both
+
+    @staticmethod
+    def _pid_namespace():
+        import os
+        try:
+            return os.readlink('/proc/self/ns/pid')
+        except OSError:
+            return None
 
     def __init__(self, dist, rank, world, n_items, caps):
         import os
@@ -129,9 +139,16 @@ class NodeSlots:
         import numpy as np
         self.dist, self.rank, self.world = dist, rank, world
         hosts = [None] * world
-        dist.all_gather_object(hosts, (socket.gethostname(), os.getpid()))
-        self.pids = [p for _, p in hosts]
-        hosts = [h for h, _ in hosts]
+        dist.all_gather_object(hosts, (socket.gethostname(), os.getpid(), self._pid_namespace()))
+        self.pids = [p for _, p, _ in hosts]
+        # the liveness probe (signal 0 to a peer's pid) means something only when every rank lives in ONE pid namespace: ranks in separate
+        # containers that share a hostname and /dev/shm would see a stranger's pid, or none, and report a live peer as gone
+        spaces = set(ns for _, _, ns in hosts)
+        self.liveness = len(spaces) == 1 and None not in spaces
+        # without the probe a dead peer shows only as a timeout, and a slow step (a large cohort, the plain path of disordered chunks) must
+        # not: the short timeout is kept for runs that can tell the two apart
+        self.timeout_s = float(os.environ.get('WGBSSEG_SLOT_TIMEOUT_S', self.TIMEOUT_S if self.liveness else self.TIMEOUT_NO_PROBE_S))
+        hosts = [h for h, _, _ in hosts]
         tag = [uuid.uuid4().hex[:12] if rank == 0 else None]
         dist.broadcast_object_list(tag, src=0)
         self.shared = len(set(hosts)) == 1 and os.path.isdir('/dev/shm') and not os.environ.get('WGBSSEG_NO_SHM')
@@ -208,14 +225,15 @@ class NodeSlots:
                 now = time.monotonic()
                 if now - checked > 0.1:
                     checked = now
-                    try:
-                        os.kill(self.pids[peer], 0)               # signal 0: does the process still exist?
-                    except ProcessLookupError:
-                        raise RuntimeError('rank %d (pid %d) is gone while this rank waits for %s' % (peer, self.pids[peer], what))
-                    except PermissionError:
-                        pass
-                    if now - t0 > self.TIMEOUT_S:
-                        raise RuntimeError('timed out after %.0f s waiting for %s' % (self.TIMEOUT_S, what))
+                    if self.liveness:
+                        try:
+                            os.kill(self.pids[peer], 0)           # signal 0: does the process still exist?
+                        except ProcessLookupError:
+                            raise RuntimeError('rank %d (pid %d) is gone while this rank waits for %s' % (peer, self.pids[peer], what))
+                        except PermissionError:
+                            pass
+                    if now - t0 > self.timeout_s:
+                        raise RuntimeError('timed out after %.0f s waiting for %s' % (self.timeout_s, what))
 
     def mine(self):
         """(off, borders) views of this rank's slot of the current step, to be filled in place (None, None without /dev/shm).

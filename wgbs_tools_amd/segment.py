@@ -399,7 +399,9 @@ class SegmentByChunks:
     def dump_result_csr(self, flat, off):
         """dump_result (segment.py:167-190) straight from the merged border lists (CSR of absolute 1-based borders, regions ascending): the
         blocks are the pairs of consecutive borders (segment.py:154), the `min_cpg` filter and the BED rows happen in the library
-        (wgbsseg_add_loci_borders) — same rows, same stderr summary."""
+        (wgbsseg_add_loci_borders) — same rows, same stderr summary (also when the writer fails on a row).  `flat` / `off` may be the engine's
+        `last_csr` views: they are numpy-owned buffers of the binding (not device or library memory) and stay valid after the engine is closed,
+        until its next segment_regions_csr call."""
         from . import _lib
         nr_blocks = int(np.maximum(np.diff(off) - 1, 0).sum())
         if nr_blocks == 0:
@@ -410,15 +412,26 @@ class SegmentByChunks:
         to_stdout = out_path is None or out_path is sys.stdout
         if to_stdout:
             sys.stdout.flush()
+        def summary(found, short):
+            eprint(f'[wt segment] found {found:,} blocks\n'
+                   f'             (dropped {short:,} short blocks)')
+            if hasattr(self, 'report'):
+                self.report.update(blocks_found=int(found), blocks_dropped=int(short))
         try:
             written, dropped = _lib.add_loci_borders(self.genome.loci(), names, np.cumsum(sizes), flat, off, self.args.min_cpg,
                                                      None if to_stdout else out_path)
         except _lib.SegmentorError as e:
+            # the reference reports the counts BEFORE it writes (segment.py:180), so a run whose writer fails has still said them: on this
+            # path the counts come from one numpy pass over the lists (the library's counts exist only for a completed file)
+            flat_, off_ = np.asarray(flat, dtype=np.int64), np.asarray(off, dtype=np.int64)
+            d = np.diff(flat_)
+            inner = np.ones(d.size, dtype=bool)
+            cut = off_[1:-1] - 1                                  # the pair that straddles two regions is not a block
+            inner[cut[(cut >= 0) & (cut < d.size)]] = False
+            short = int((d[inner] < self.args.min_cpg).sum())
+            summary(nr_blocks - short, short)
             raise RuntimeError(e.msg)
-        eprint(f'[wt segment] found {written:,} blocks\n'
-               f'             (dropped {dropped:,} short blocks)')
-        if hasattr(self, 'report'):
-            self.report.update(blocks_found=int(written), blocks_dropped=int(dropped))
+        summary(written, dropped)
 
     def dump_result(self, start_cpg, end_cpg):
         """segment.py:167-190"""
