@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""The whole synthetic hg19 genome x N betas against the REFERENCE BINARY (oracle/_ref/segmentor), on the library that is in the tree.
+
+north_star: "bit-exact block boundaries at 28M CpGs x 200 betas".  The suite samples (64 of 483 chunks, 3 of 25 chromosomes: it has to fit
+the driver's window); this tool runs everything once:
+
+  1. wgbsseg_segment_regions over the 25 chromosomes (the product call);
+  2. per chromosome: every chunk of the reference's grid through wgbsseg_segment_chunks, then the reference's pairwise stitching tree
+     (tests/reftree.py, pinned by vectors of the reference's own driver) over those chunk DPs, with every patch it asks for computed by the
+     HIP path — the stitched list must equal (1);
+  3. EVERY range the 25 trees touched (all chunks + all junction patches) through the reference binary, one single-threaded process per range
+     on all host cores, compared border by border with what the HIP path returned for that range.
+
+Prints one summary line per stage and a final JSON line; exit code 1 on any difference.  Test infrastructure: the oracle is the checker here.
+
+    python tools/full_vs_reference.py [--samples 200] [--procs N] [--chromosomes 0-24]
+"""
+import argparse
+import json
+import os
+import os.path as op
+import sys
+import time
+
+import numpy as np
+
+ROOT = op.dirname(op.dirname(op.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, op.join(ROOT, 'tests'))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--samples', type=int, default=200)
+    ap.add_argument('--sites', type=int, default=0, help='0: hg19 (28,217,448)')
+    ap.add_argument('--chunk', type=int, default=60000)
+    ap.add_argument('--pcount', type=float, default=15.0)
+    ap.add_argument('--max-cpg', type=int, default=1000)
+    ap.add_argument('--max-bp', type=int, default=2000)
+    ap.add_argument('--procs', type=int, default=0, help='reference processes at a time (0: all logical CPUs)')
+    ap.add_argument('--chromosomes', default='', help='e.g. 0-24 or 20,21 (default: all)')
+    args = ap.parse_args()
+
+    import test_gpu_fullsize as F                      # the suite's helpers: device genome, recorder, reference runner, tree
+    from oracle import oracle
+    from wgbs_tools_amd import _lib, synth, build as nbuild
+    import torch
+
+    sites = args.sites or synth.HG19_NR_SITES
+    N, chunk, pc, mb = args.samples, args.chunk, args.pcount, args.max_bp
+    mc = min(args.max_cpg, mb // 2)                    # segment.py:65
+    names, sizes = synth.genome_shape(sites, 25 if sites >= 2500000 else max(1, min(25, sites // 100000)))
+    sizes = [int(s) for s in sizes]
+    loci = synth.synth_loci(F.SEED, sizes)
+    regions, pos = [], 1
+    for s in sizes:
+        regions.append((pos, pos + s))
+        pos += s
+    which = list(range(len(regions)))
+    if args.chromosomes:
+        which = []
+        for part in args.chromosomes.split(','):
+            a, _, b = part.partition('-')
+            which += list(range(int(a), int(b or a) + 1))
+    sha = nbuild.source_hash()
+    print('library csrc_sha %s, ABI %d; %d CpGs x %d betas, chunk %d, max_cpg %d, max_bp %d, pcount %g; reference binary: %s'
+          % (sha, _lib.load().wgbsseg_version(), sites, N, chunk, mc, mb, pc, oracle.REF_BIN), flush=True)
+    assert oracle.have_ref(), 'oracle/_ref/segmentor is missing'
+    t0 = time.time()
+    buf, pitch = F._device_genome(sites, N)
+    bad = 0
+    with _lib.Segmenter(0) as seg:
+        seg.set_betas_device(buf.data_ptr(), N, pitch, sites, keepalive=buf)
+        seg.set_loci(loci)
+        res, stats = F._run_whole(seg, regions, chunk, pc, mc, mb)
+        F._check_properties(res, regions, loci, mc, mb)
+        n_blocks = int(sum(len(r) - 1 for r in res))
+        print('[1] whole-genome call: %d chunks, %d blocks, stitch stats %s (%.1f s since start)'
+              % (stats['chunks'], n_blocks, {k: int(v) for k, v in stats.items()}, time.time() - t0), flush=True)
+        # 2. the reference's tree over the HIP path's chunk / patch DPs, chromosome by chromosome
+        asked, n_chunks, n_patches, chrom_ok = {}, 0, 0, 0
+        for ri in which:
+            a, e = regions[ri]
+            eng = F._Recorder(seg, pc, mc, mb)
+            grid = F._grid(a, e, chunk)
+            chunks = eng.segment_many(grid, {})
+            want = F._tree(chunks, eng)
+            same = np.array_equal(np.asarray(res[ri], dtype=np.int64), want)
+            chrom_ok += bool(same)
+            if not same:
+                bad += 1
+                print('    DIFFERENT: stitched borders of %s differ from the reference tree' % names[ri], flush=True)
+            gs = set(grid)
+            n_chunks += len(grid)
+            n_patches += sum(1 for k in eng.asked if k not in gs)
+            asked.update(eng.asked)
+        print('[2] stitched chromosomes identical to the reference tree: %d/%d (%d chunks, %d distinct junction patches asked for; %.1f s since start)'
+              % (chrom_ok, len(which), n_chunks, n_patches, time.time() - t0), flush=True)
+        # 3. every one of those ranges through the reference binary (longest first: the chunks fill the cores, the patches the gaps)
+        ranges = sorted(((a - 1, b - a) for (a, b) in asked), key=lambda r: -r[1])
+        procs = args.procs or (os.cpu_count() or 8)
+        # a group of `procs` ranges sits in /dev/shm as .beta files while it runs: keep it under half of what is free there
+        import shutil
+        shm = '/dev/shm' if op.isdir('/dev/shm') else '/tmp'
+        free = shutil.disk_usage(shm).free
+        procs = int(max(1, min(procs, (free // 2) // max(1, 2 * N * chunk))))
+        print('    %s has %.1f GB free: %d reference processes at a time' % (shm, free / 1e9, procs), flush=True)
+        t1 = time.time()
+        ref = {}
+        step = max(procs, 1)
+        for g0 in range(0, len(ranges), step):
+            ref.update(F._ref_on_ranges(buf, loci, ranges[g0:g0 + step], pc, mc, mb, procs=procs))
+            done = min(len(ranges), g0 + step)
+            if done == len(ranges) or (g0 // step) % 4 == 0:
+                print('    reference binary: %d/%d ranges (%.0f s)' % (done, len(ranges), time.time() - t1), flush=True)
+        ch_ok = ch_n = pa_ok = pa_n = 0
+        for (a, b), r in asked.items():
+            same = np.array_equal(r - a, ref[(a - 1, b - a)])
+            if not same:
+                bad += 1
+                print('    DIFFERENT: range [%d, %d) differs from the reference binary' % (a, b), flush=True)
+            asked[(a, b)] = same
+        grid_all = set()
+        for ri in which:
+            grid_all.update(F._grid(*regions[ri], chunk))
+        for k, same in asked.items():
+            if k in grid_all:
+                ch_n += 1
+                ch_ok += bool(same)
+            else:
+                pa_n += 1
+                pa_ok += bool(same)
+        ref_s = time.time() - t1
+        print('[3] against the reference binary: %d/%d chunks identical, %d/%d patches identical (%d processes at a time, %.0f s)'
+              % (ch_ok, ch_n, pa_ok, pa_n, procs, ref_s), flush=True)
+    out = {'csrc_sha': sha, 'sites': sites, 'samples': N, 'chunk': chunk, 'max_cpg': mc, 'max_bp': mb, 'pcount': pc,
+           'chromosomes_identical': chrom_ok, 'chromosomes': len(which), 'chunks_identical': ch_ok, 'chunks': ch_n,
+           'patches_identical': pa_ok, 'patches': pa_n, 'blocks': n_blocks, 'differences': bad,
+           'reference_seconds': ref_s, 'reference_procs': procs, 'host_cpus': os.cpu_count(), 'wall_s': time.time() - t0,
+           'device': torch.cuda.get_device_name(0)}
+    print(json.dumps(out), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1038,6 +1038,9 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 #else
 #define WG_DP_T(...)
 #endif
+#ifdef WGBSSEG_DP_RECSEL
+__device__ uint32_t g_dp_cu_ctr[4096];
+#endif
 struct DpArgs { int32_t ringN; int32_t pad[3]; };      // ringN: pending-step ring (pow2 >= max window + 128), 0 if BL == 64
 
 #define WG_DP_STATE_HDR 257   // doubles of per-chunk state ahead of the ring: M[k], bestA[64], argA[64], bestB[64], argB[64]
@@ -1521,7 +1524,22 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     // (Round 3, measured: the wavefront index in a SCALAR register (readfirstlane) turns a worker's row indices into scalar arithmetic and
     // removes a v_readfirstlane + four wait states per row — and the recurrence gets SLOWER: 1.62 -> 1.71 ms for hg19, 4.29 -> 5.04 ms
     // with CpG islands (profiles/r03_dp_experiments.txt).  The workers' idle slots are slots the recurrence wavefront gets.)
+#ifdef WGBSSEG_DP_RECSEL
+    // (experiment, round 5) two workgroups share a CU and both put their recurrence on wavefront 0 = the same SIMD: let every other
+    // workgroup that arrives on a CU run its recurrence on wavefront 2 instead (a counter per CU in global memory gives the parity)
+    __shared__ int s_recw;
+    if (threadIdx.x == 0) {
+        const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        const uint32_t key = ((xc & 15u) << 8) | ((hw >> 8) & 0xffu);
+        s_recw = (atomicAdd(&g_dp_cu_ctr[key], 1u) & 1u) ? 2 : 0;
+    }
+    __syncthreads();
+    const int recw = s_recw;
+    const int wv_phys = (int)(threadIdx.x >> 6);
+    const int wvl = wv_phys == recw ? 0 : (wv_phys < recw ? wv_phys + 1 : wv_phys);      // role: 0 = recurrence, 1..NW = workers
+#else
     const int wvl = (int)(threadIdx.x >> 6);          // 0 = recurrence
+#endif
     const bool worker = wvl != 0;
     const int lw = wvl - 1;                           // worker index (0..NW-1)
     const int c = blockIdx.x;
@@ -1722,6 +1740,11 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
         gs[2 * wvl] = (double)(__builtin_amdgcn_s_memtime() - dbg_t0);
         gs[2 * wvl + 1] = (double)dbg_wait;
         if (wvl == 1) { gs[4] = (double)dbg_vm; gs[5] = (double)dbg_commit; gs[6] = (double)dbg_issue; }
+    })
+    // ... and where the workgroup ran: HW_ID of every wavefront by ROLE (slot 8 = the recurrence), XCC_ID, and when (s_memtime)
+    WG_DP_T(if (s1 >= cd.len && lane == 0) {
+        gs[8 + wvl] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        if (wvl == 0) { gs[16] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20); gs[17] = (double)dbg_t0; gs[18] = (double)__builtin_amdgcn_s_memtime(); }
     })
     if (WIDEJOB && worker && fm_prev > 128u)
         wg_dp_far<NW, BL>(cb, Wp, Cp, cum0, s0 + (nb - 1) * BL, s1, Mring, pendB, pendA, rmask, lane, lw);
