@@ -395,6 +395,8 @@ int wgbsseg_patbeta_create(int device, int64_t start_cpg, int64_t end_cpg, wgbss
 int wgbsseg_patbeta_feed(wgbsseg_patbeta* pb, const char* text, int64_t n_bytes, char* err, size_t errlen);
 int wgbsseg_patbeta_finish(wgbsseg_patbeta* pb, int32_t lbeta, void* out, char* err, size_t errlen);
 void wgbsseg_patbeta_destroy(wgbsseg_patbeta* pb);
+/* device time (ms, HIP events) of the counting-kernel launches of all chunks fed so far; waits for them.  < 0: error */
+double wgbsseg_patbeta_kernel_ms(wgbsseg_patbeta* pb);
 
 int wgbsseg_get_timings(const wgbsseg_ctx* ctx, wgbsseg_timings* out);
 

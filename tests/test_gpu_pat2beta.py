@@ -61,3 +61,46 @@ def test_ranges_chunks_and_malformed_lines():
     want = np.zeros((99, 2), dtype=np.uint8)
     want[2] = (2, 2); want[3] = (5, 5); want[5] = (0, 3)
     assert np.array_equal(got, want)
+
+
+def test_lines_against_the_tiles_of_the_counting_kernel():
+    """Round 5's k_pat_count stages 4096-byte tiles (+ 1024 bytes behind them) into LDS and parses one line per thread: lines longer than
+    the staged bytes (reads of thousands of CpGs), lines across tile boundaries at every phase, runs of empty lines, two-byte-dense lines
+    (a line start at every 8th byte), a chunk that ends inside a tile's last 16 bytes — against the reference binary / the oracle."""
+    rng = np.random.default_rng(5)
+    n_sites = 20000
+    alphabet = np.frombuffer(b'CCCTTTH.', dtype=np.uint8)
+    lines = []
+    pos = 1
+    for k in range(6000):
+        kind = k % 7
+        if kind == 0:
+            ln = int(rng.integers(1100, 5200))               # longer than the tile's overhang, some longer than a tile
+        elif kind in (1, 2):
+            ln = 1
+        else:
+            ln = int(rng.integers(1, 40))
+        pat = alphabet[rng.integers(0, 8, ln)].tobytes().decode()
+        lines.append('c\t%d\t%s\t%d' % (pos, pat, int(rng.integers(1, 30))))
+        if kind == 3:
+            lines += [''] * int(rng.integers(1, 40))         # empty lines: skipped (stdin2beta.cpp:100)
+        pos = int(min(n_sites - 5, pos + rng.integers(0, 9)))
+    text = ('\n'.join(lines) + '\n').encode()
+    assert len(text) > 40 * 4096
+    want_counts = OP.ref_counts(text, 1, n_sites + 1) if OP.have_ref() else OP.counts([l for l in lines if l], 1, n_sites + 1)
+    want = OP.trim(want_counts, True).astype(np.int64)
+    for pieces in (1, 7):                                    # one chunk, and chunks cut at line ends (every chunk begins a new tile grid)
+        with _lib.PatBeta(1, n_sites + 1) as pb:
+            cuts = [0] + [text.find(b'\n', len(text) * q // pieces) + 1 for q in range(1, pieces)] + [len(text)]
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                pb.feed(text[a:b])
+            assert pb.kernel_ms() > 0
+            got = pb.finish(lbeta=True)
+        assert np.array_equal(got.astype(np.int64), want), pieces
+    # a malformed line deep inside a later tile is reported with its byte offset in the whole input
+    bad_at = text.find(b'\n', 9 * 4096 + 100) + 1
+    broken = text[:bad_at] + b'c\t77\tCT\n' + text[bad_at:]
+    with _lib.PatBeta(1, n_sites + 1) as pb:
+        pb.feed(broken)
+        with pytest.raises(_lib.SegmentorError, match='invalid line at byte offset %d ' % bad_at):
+            pb.finish()

@@ -5,7 +5,7 @@ k_dp leave, per chunk, the cycles its recurrence wavefront and its first worker 
 wavefront sat on, and whether another workgroup's recurrence shared that SIMD.  This script runs the chunk DPs of a stretch of the bench
 genome (one batch: chunks only, no stitching) and prints the averages.
 
-    python tools/dp_timing.py [n_chunks] [samples] [--flags "-DWGBSSEG_DP_RECSEL"] [--tag recsel]"""
+    python tools/dp_timing.py [n_chunks] [samples] [--flags "-D..."] [--tag name]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 argv = sys.argv[1:]

@@ -8,8 +8,6 @@ O=$REPO/gpurun_out/r05c1; mkdir -p $O
 timeout 120 tools/micro/_build/dp_simd_share > $O/dp_simd_share.txt 2>&1; echo "micro: rc $?"
 timeout 300 python tools/dp_timing.py 480 8 > $O/dp_timing_480.txt 2>&1; echo "dp_timing 480: rc $?"
 timeout 300 python tools/dp_timing.py 240 8 > $O/dp_timing_240.txt 2>&1
-timeout 300 python tools/dp_timing.py 480 8 --flags "-DWGBSSEG_DP_RECSEL" --tag recsel > $O/dp_timing_recsel_480.txt 2>&1; echo "dp_timing recsel: rc $?"
-timeout 300 python tools/dp_timing.py 483 32 --flags "-DWGBSSEG_DP_RECSEL" --tag recsel > $O/dp_timing_recsel_483x32.txt 2>&1
 timeout 300 python tools/dp_timing.py 483 32 > $O/dp_timing_483x32.txt 2>&1
 tail -12 $O/dp_timing_480.txt $O/dp_timing_recsel_480.txt
 timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "test_19 or test_11 or test_06" > $O/tests_new.log 2>&1; echo "new tests: rc $? ($(tail -1 $O/tests_new.log))"

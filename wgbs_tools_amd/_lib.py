@@ -33,7 +33,7 @@ EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg
            'wgbsseg_group_plan', 'wgbsseg_group_load_host', 'wgbsseg_group_share_set_device', 'wgbsseg_group_segment_regions',
            'wgbsseg_group_get_timings', 'wgbsseg_plan_shares', 'wgbsseg_set_lbetas_host',
            'wgbsseg_convert_regions', 'wgbsseg_patbeta_create', 'wgbsseg_patbeta_feed', 'wgbsseg_patbeta_finish',
-           'wgbsseg_patbeta_destroy', 'wgbsseg_group_load_host_async', 'wgbsseg_group_load_wait',
+           'wgbsseg_patbeta_destroy', 'wgbsseg_patbeta_kernel_ms', 'wgbsseg_group_load_host_async', 'wgbsseg_group_load_wait',
            'wgbsseg_marker_stats', 'wgbsseg_blocks_parse', 'wgbsseg_blocks_write_table', 'wgbsseg_blocks_write_bedgraph',
            'wgbsseg_format_fixed', 'wgbsseg_bed_parse', 'wgbsseg_bed_write_annotated', 'wgbsseg_debug_canonical_float',
            'wgbsseg_first_batch_items', 'wgbsseg_plan_shares_weighted']
@@ -205,6 +205,8 @@ def load():
     L.wgbsseg_patbeta_finish.argtypes = [vp, i32, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_patbeta_destroy.restype = None
     L.wgbsseg_patbeta_destroy.argtypes = [vp]
+    L.wgbsseg_patbeta_kernel_ms.restype = C.c_double
+    L.wgbsseg_patbeta_kernel_ms.argtypes = [vp]
     L.wgbsseg_marker_stats.restype = i32
     L.wgbsseg_marker_stats.argtypes = [vp, vp, i32, vp, i32, i64, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_add_loci.restype = i32
@@ -488,6 +490,10 @@ class PatBeta:
     def feed(self, text):
         """text: bytes made of whole lines (must end with a newline)"""
         _check(self._L.wgbsseg_patbeta_feed(self._h, text, len(text), self._err, ERRLEN), self._err)
+
+    def kernel_ms(self):
+        """device time of the counting kernel over every chunk fed so far (waits for them)"""
+        return float(self._L.wgbsseg_patbeta_kernel_ms(self._h))
 
     def finish(self, lbeta=False):
         out = np.empty((self.n, 2), dtype=np.uint16 if lbeta else np.uint8)

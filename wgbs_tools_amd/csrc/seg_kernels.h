@@ -1038,9 +1038,6 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
 #else
 #define WG_DP_T(...)
 #endif
-#ifdef WGBSSEG_DP_RECSEL
-__device__ uint32_t g_dp_cu_ctr[4096];
-#endif
 struct DpArgs { int32_t ringN; int32_t pad[3]; };      // ringN: pending-step ring (pow2 >= max window + 128), 0 if BL == 64
 
 #define WG_DP_STATE_HDR 257   // doubles of per-chunk state ahead of the ring: M[k], bestA[64], argA[64], bestB[64], argB[64]
@@ -1524,22 +1521,9 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     // (Round 3, measured: the wavefront index in a SCALAR register (readfirstlane) turns a worker's row indices into scalar arithmetic and
     // removes a v_readfirstlane + four wait states per row — and the recurrence gets SLOWER: 1.62 -> 1.71 ms for hg19, 4.29 -> 5.04 ms
     // with CpG islands (profiles/r03_dp_experiments.txt).  The workers' idle slots are slots the recurrence wavefront gets.)
-#ifdef WGBSSEG_DP_RECSEL
-    // (experiment, round 5) two workgroups share a CU and both put their recurrence on wavefront 0 = the same SIMD: let every other
-    // workgroup that arrives on a CU run its recurrence on wavefront 2 instead (a counter per CU in global memory gives the parity)
-    __shared__ int s_recw;
-    if (threadIdx.x == 0) {
-        const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        const uint32_t key = ((xc & 15u) << 8) | ((hw >> 8) & 0xffu);
-        s_recw = (atomicAdd(&g_dp_cu_ctr[key], 1u) & 1u) ? 2 : 0;
-    }
-    __syncthreads();
-    const int recw = s_recw;
-    const int wv_phys = (int)(threadIdx.x >> 6);
-    const int wvl = wv_phys == recw ? 0 : (wv_phys < recw ? wv_phys + 1 : wv_phys);      // role: 0 = recurrence, 1..NW = workers
-#else
+    // (Round 5, measured with the HW_ID probe of the timing build: the two workgroups of a CU already have their recurrence wavefronts on
+    // DIFFERENT SIMDs — the dispatcher rotates the SIMD of a workgroup's first wavefront — so there is nothing to select: profiles/r05_dp_placement.txt.)
     const int wvl = (int)(threadIdx.x >> 6);          // 0 = recurrence
-#endif
     const bool worker = wvl != 0;
     const int lw = wvl - 1;                           // worker index (0..NW-1)
     const int c = blockIdx.x;
@@ -1613,6 +1597,8 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
     // memory operations of a wave complete in order.  Waiting for store latency there, every 32 steps, would cost more than the steps.
 #define WG_DP_BARRIER asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     WG_DP_T(uint64_t dbg_wait = 0; uint64_t dbg_vm = 0; uint64_t dbg_commit = 0; uint64_t dbg_issue = 0; const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime();)
+    WG_DP_T(const int dbg_mode = A.pad[1];      /* timing builds only (WGBSSEG_DP_DEBUG): 1 workers leave, 2 no commits, 4 no row loads — WRONG results, timing only */
+            if (worker && (dbg_mode & 1)) return;)
     if (worker) {
       for (int b = 0; b < nb; b++) {
         const int base = s0 + b * BL;
@@ -1643,7 +1629,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
             // branch so that the waits leave the younger set in flight, measures 1.79 against 1.61 ms: the rows are not what the
             // recurrence waits for.)
             WG_DP_T(const uint64_t tc0 = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_vm += __builtin_amdgcn_s_memtime() - tc0;)
-            if (b + 1 < nb)
+            if (b + 1 < nb WG_DP_T(&& !(dbg_mode & 2)))
                 wg_dp_rows_commit<NW, BL>(rows, slots + (size_t)((b + 1) & 1) * SLOT, slots + (size_t)((b + 1) & 1) * SLOT + BL * 64,
                                           kinds + ((b + 1) & 1), lane, lw);
             WG_DP_T(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg_commit += __builtin_amdgcn_s_memtime() - tc0;)
@@ -1653,7 +1639,7 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp(JobView J, StageView SV, c
             }
             uint32_t fm_n2 = 0;
             WG_DP_T(const uint64_t ti0 = __builtin_amdgcn_s_memtime();)
-            if (b + 2 < nb) {
+            if (b + 2 < nb WG_DP_T(&& !(dbg_mode & 4))) {
                 wg_dp_rows_issue<NW, BL>(rows, cb, wg_dp_meta_lds<BL>(metaW, metaC, (b + 2) * BL, lane), base + 2 * BL, lane, lw);
                 fm_n2 = rows.fmax;
             }
@@ -2546,21 +2532,33 @@ __global__ __launch_bounds__(WG_BLOCK) void k_convert(const uint32_t* __restrict
 // k_pat_count / k_pat_trim: a pat file -> (#meth, #cov) per CpG, the producer of the path's input (src/pat2beta/
 // stdin2beta.cpp:59-93 proc_line, :95-123 parse; utils_wgbs.py:277-290 trim_to_uint8).  A pat line is
 //     chr \t first CpG index \t pattern over {C, T, H, .} \t number of reads with that pattern [\t ...]
-// One thread per byte of a chunk of text (whole lines); the threads that sit on the first byte of a line parse it and
-// add `count` to the coverage of every site under a C / T / H and to the methylated count under C / H
+// Every line adds `count` to the coverage of every site under a C / T / H and to the methylated count under C / H
 // (atomics on int32: reads overlap).  Reads that end before `start` or begin at or after `end` are skipped, sites outside
 // are ignored, empty lines are skipped (stdin2beta.cpp:75-78,:100).  A line with fewer than four fields or a non-numeric
 // site / count makes the reference give up ("failed calculating beta"): its offset is reported through `bad`.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool wg_parse_int(const char* __restrict__ t, int64_t& i, int64_t n, int64_t& val)
+// Round 5: the text is parsed out of LDS, one LINE per thread.  (Rounds 3-4: one thread per BYTE, the thread on a line's first byte parsing
+// it alone with byte loads from global memory — 1 lane in ~25 at work, each a chain of dependent loads.)  A workgroup takes WG_PAT_TILE
+// bytes of the chunk + WG_PAT_OVER bytes behind them (a line that begins in the tile may end there) into LDS with 16-byte loads, finds
+// the line starts of its tile (16 bytes per thread, a workgroup-wide prefix count), and thread l then parses line l: ~160 lines of ~25
+// bytes per tile.  A line that runs past the staged bytes (a read of hundreds of CpGs) reads the rest from global memory.
+#define WG_PAT_TILE 4096
+#define WG_PAT_OVER 1024
+struct PatText {
+    const char* lds; const char* __restrict__ g; int64_t base, n;          // staged bytes [base, base + WG_PAT_TILE + WG_PAT_OVER) of g[0, n)
+    __device__ __forceinline__ char at(int64_t i) const { const int64_t r = i - base; return r < WG_PAT_TILE + WG_PAT_OVER ? lds[r] : g[i]; }
+};
+
+__device__ __forceinline__ bool wg_parse_int(const PatText& t, int64_t& i, int64_t n, int64_t& val)
 {
     // std::stoi: leading white space, an optional sign, at least one digit; anything after the digits is ignored
-    while (i < n && (t[i] == ' ' || (t[i] >= 9 && t[i] <= 13 && t[i] != '\n' && t[i] != '\t'))) i++;
+    char ch;
+    while (i < n && ((ch = t.at(i)) == ' ' || (ch >= 9 && ch <= 13 && ch != '\n' && ch != '\t'))) i++;
     bool neg = false;
-    if (i < n && (t[i] == '-' || t[i] == '+')) { neg = t[i] == '-'; i++; }
-    if (!(i < n && t[i] >= '0' && t[i] <= '9')) return false;
+    if (i < n && ((ch = t.at(i)) == '-' || ch == '+')) { neg = ch == '-'; i++; }
+    if (!(i < n && (ch = t.at(i)) >= '0' && ch <= '9')) return false;
     int64_t v = 0;
-    while (i < n && t[i] >= '0' && t[i] <= '9') { v = v * 10 + (t[i] - '0'); if (v > 0x7fffffffLL) return false; i++; }
+    while (i < n && (ch = t.at(i)) >= '0' && ch <= '9') { v = v * 10 + (ch - '0'); if (v > 0x7fffffffLL) return false; i++; }
     val = neg ? -v : v;
     return true;
 }
@@ -2569,36 +2567,95 @@ __global__ __launch_bounds__(WG_BLOCK) void k_pat_count(const char* __restrict__
                                                         int32_t* __restrict__ meth, int32_t* __restrict__ cov, unsigned long long* bad,
                                                         unsigned long long chunk_off)
 {
-    const int64_t p = (int64_t)blockIdx.x * WG_BLOCK + threadIdx.x;
-    if (p >= n) return;
-    if (!(p == 0 || text[p - 1] == '\n')) return;              // not the first byte of a line
-    if (text[p] == '\n') return;                                // empty line
-    int64_t i = p;
-    auto fail = [&]() { atomicMin(bad, chunk_off + (unsigned long long)p); };
-    while (i < n && text[i] != '\t' && text[i] != '\n') i++;   // field 1: chromosome
-    if (i >= n || text[i] == '\n') return fail();
-    i++;
-    int64_t site = 0, count = 0;
-    if (!wg_parse_int(text, i, n, site)) return fail();        // field 2: index of the read's first CpG
-    while (i < n && text[i] != '\t' && text[i] != '\n') i++;
-    if (i >= n || text[i] == '\n') return fail();
-    i++;
-    const int64_t ps = i;                                       // field 3: the pattern
-    while (i < n && text[i] != '\t' && text[i] != '\n') i++;
-    if (i >= n || text[i] == '\n') return fail();
-    const int64_t plen = i - ps;
-    i++;
-    if (i >= n || text[i] == '\n' || text[i] == '\t') { if (i >= n || text[i] == '\n') return fail(); }   // an empty fourth field with more behind it: stoi throws
-    if (!wg_parse_int(text, i, n, count)) return fail();       // field 4: how many reads
-    if (site + plen - 1 < start || site >= end) return;        // stdin2beta.cpp:75-78
+    static_assert(WG_PAT_TILE == 16 * WG_BLOCK && WG_PAT_OVER % 16 == 0 && WG_PAT_OVER / 16 <= WG_BLOCK, "16 bytes per thread");
+    __shared__ __attribute__((aligned(16))) char tx[16 + WG_PAT_TILE + WG_PAT_OVER];     // tx[15] = the byte before the tile; the tile from tx[16]
+    __shared__ uint16_t lstart[WG_PAT_TILE / 2 + 1];         // tile-relative first bytes of the lines that begin in the tile (at most every other byte)
+    __shared__ uint32_t wtot[WG_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * WG_PAT_TILE;
+    // ---- stage: 16 bytes per thread (the chunk's buffer is 16-byte aligned and so is base), bytes at or past n as '\n'
+    auto stage16 = [&](int64_t off) {                        // off: tile-relative, multiple of 16
+        const int64_t a = base + off;
+        uint4 v;
+        if (a + 16 <= n) v = *reinterpret_cast<const uint4*>(text + a);
+        else {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 16; j++) w[j >> 2] |= (uint32_t)(unsigned char)(a + j < n ? text[a + j] : '\n') << (8 * (j & 3));
+            v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        }
+        *reinterpret_cast<uint4*>(tx + 16 + off) = v;
+    };
+    stage16((int64_t)tid * 16);
+    if (tid < WG_PAT_OVER / 16) stage16(WG_PAT_TILE + (int64_t)tid * 16);
+    if (tid == 0) tx[15] = base > 0 ? text[base - 1] : '\n';
+    __syncthreads();
+    // ---- line starts of the tile: byte x begins a line when the byte before it is a newline and it is not one itself (empty lines: skipped,
+    // stdin2beta.cpp:100)
+    uint32_t mask = 0;
+    {
+        const char* q = tx + 16 + tid * 16;
+        char prev = q[-1];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const char c = q[j];
+            if (prev == '\n' && c != '\n' && base + tid * 16 + j < n) mask |= 1u << j;
+            prev = c;
+        }
+    }
+    const uint32_t cnt = (uint32_t)__popc(mask);
+    const uint32_t incl = wg_wave_incl_scan_dpp_u32(cnt);
+    if (lane == 63) wtot[wv] = incl;
+    __syncthreads();
+    uint32_t before = incl - cnt, total = 0;
+#pragma unroll
+    for (int w = 0; w < WG_BLOCK / 64; w++) { if (w < wv) before += wtot[w]; total += wtot[w]; }
+    while (mask) {
+        const int j = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        lstart[before++] = (uint16_t)(tid * 16 + j);
+    }
+    __syncthreads();
+    // ---- one line per thread
+    const PatText T = {tx + 16, text, base, n};
     const int64_t nr = end - start;
-    for (int64_t k = 0; k < plen; k++) {
-        const int64_t x = site - start + k;
-        if (x < 0 || x >= nr) continue;
-        const char ch = text[ps + k];
-        if (!(ch == 'T' || ch == 'C' || ch == 'H')) continue;
-        atomicAdd(&cov[x], (int32_t)count);
-        if (ch != 'T') atomicAdd(&meth[x], (int32_t)count);
+    for (uint32_t l = (uint32_t)tid; l < total; l += WG_BLOCK) {
+        const int64_t p = base + lstart[l];
+        int64_t i = p;
+        char ch = 0;
+        bool ok = true;
+        while (i < n && (ch = T.at(i)) != '\t' && ch != '\n') i++;   // field 1: chromosome
+        ok = i < n && ch == '\t';
+        int64_t site = 0, count = 0, ps = 0, plen = 0;
+        if (ok) {
+            i++;
+            ok = wg_parse_int(T, i, n, site);                           // field 2: index of the read's first CpG
+        }
+        if (ok) {
+            while (i < n && (ch = T.at(i)) != '\t' && ch != '\n') i++;
+            ok = i < n && ch == '\t';
+        }
+        if (ok) {
+            i++;
+            ps = i;                                                     // field 3: the pattern
+            while (i < n && (ch = T.at(i)) != '\t' && ch != '\n') i++;
+            ok = i < n && ch == '\t';
+            plen = i - ps;
+        }
+        if (ok) {
+            i++;
+            ok = i < n && T.at(i) != '\n' && wg_parse_int(T, i, n, count);   // field 4: how many reads (an empty one: stoi throws)
+        }
+        if (!ok) { atomicMin(bad, chunk_off + (unsigned long long)p); continue; }
+        if (site + plen - 1 < start || site >= end) continue;           // stdin2beta.cpp:75-78
+        for (int64_t k = 0; k < plen; k++) {
+            const int64_t x = site - start + k;
+            if (x < 0 || x >= nr) continue;
+            const char c = T.at(ps + k);
+            if (!(c == 'T' || c == 'C' || c == 'H')) continue;
+            atomicAdd(&cov[x], (int32_t)count);
+            if (c != 'T') atomicAdd(&meth[x], (int32_t)count);
+        }
     }
 }
 

@@ -1039,6 +1039,9 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // LDS of k_dp: two arranged batches (64 steps x 64 lanes, or 32 steps x 64 lanes x {A, B}) + M ring + fetched ring entries + flags + ring of windows / row offsets
     const int dp_wlean_off = (getenv("WGBSSEG_DP_WLEAN") && atoi(getenv("WGBSSEG_DP_WLEAN")) == 0) ? 1 : 0;      // 0: narrow batches of a wide job on the generic step (A/B, tests; read per call)
     DpArgs da = {ringN, {dp_wlean_off, 0, 0}};
+#ifdef WGBSSEG_DP_TIMING
+    if (const char* e = getenv("WGBSSEG_DP_DEBUG")) da.pad[1] = atoi(e);      // timing builds only: see k_dp (results are WRONG in these modes)
+#endif
     c->last_dp_chunks = nC; c->last_dp_stride = state_stride;
     const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16 + 1024 * 6;
     if (own_stream && (!beside || st.wide_units)) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));      // scoring after the scan (always when it reads carries)
@@ -2274,8 +2277,16 @@ struct wgbsseg_patbeta {
     bool busy[2] = {false, false};
     int k = 0;
     unsigned long long fed = 0;
-    double kernel_ms = 0.0;
+    double kernel_ms = 0.0;                                       // k_pat_count launches whose events have been read
+    hipEvent_t k0[2] = {nullptr, nullptr}, k1[2] = {nullptr, nullptr};   // around the counting kernel of the chunk in slot k
+    bool timed[2] = {false, false};                               // slot k holds a pair not yet added to kernel_ms
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    void collect(int k)                                           // (after the slot's work is known to be complete)
+    {
+        float ms = 0.f;
+        if (timed[k] && hipEventElapsedTime(&ms, k0[k], k1[k]) == hipSuccess) kernel_ms += (double)ms;
+        timed[k] = false;
+    }
 };
 
 extern "C" {
@@ -2301,6 +2312,7 @@ int wgbsseg_patbeta_create(int device, int64_t start_cpg, int64_t end_cpg, wgbss
     HIP_TRY(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
     for (auto& e : p->ev) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&p->t0)); HIP_TRY(hipEventCreate(&p->t1));
+    for (int k = 0; k < 2; k++) { HIP_TRY(hipEventCreate(&p->k0[k])); HIP_TRY(hipEventCreate(&p->k1[k])); }
     const size_t nb = (size_t)(end_cpg - start_cpg) * 4;
     HIP_TRY(p->meth.ensure(nb)); HIP_TRY(p->cov.ensure(nb)); HIP_TRY(p->bad.ensure(8));
     HIP_TRY(hipMemsetAsync(p->meth.p, 0, nb, p->st));            // (the reference leaves its arrays uninitialised: stdin2beta.cpp:48-49)
@@ -2320,6 +2332,7 @@ void wgbsseg_patbeta_destroy(wgbsseg_patbeta* p)
     for (auto& e : p->ev) if (e) (void)hipEventDestroy(e);
     if (p->t0) (void)hipEventDestroy(p->t0);
     if (p->t1) (void)hipEventDestroy(p->t1);
+    for (int k = 0; k < 2; k++) { if (p->k0[k]) (void)hipEventDestroy(p->k0[k]); if (p->k1[k]) (void)hipEventDestroy(p->k1[k]); }
     if (p->st) (void)hipStreamDestroy(p->st);
     delete p;
 }
@@ -2331,16 +2344,19 @@ int wgbsseg_patbeta_feed(wgbsseg_patbeta* p, const char* text, int64_t n_bytes, 
     if (text[n_bytes - 1] != '\n') { set_err(err, errlen, "patbeta_feed: a chunk must end with a complete line"); return WGBSSEG_E_ARG; }
     HIP_TRY(hipSetDevice(p->device));
     const int k = p->k;
-    if (p->busy[k]) HIP_TRY(hipEventSynchronize(p->ev[k]));      // its previous chunk has been consumed
+    if (p->busy[k]) { HIP_TRY(hipEventSynchronize(p->ev[k])); p->collect(k); }      // its previous chunk has been consumed
     if (!p->stage[k].ensure((size_t)n_bytes)) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
     HIP_TRY(p->text[k].ensure((size_t)n_bytes));
     memcpy(p->stage[k].p, text, (size_t)n_bytes);
     HIP_TRY(hipMemcpyAsync(p->text[k].p, p->stage[k].p, (size_t)n_bytes, hipMemcpyHostToDevice, p->st));
-    const int64_t gx = (n_bytes + WG_BLOCK - 1) / WG_BLOCK;
+    const int64_t gx = (n_bytes + WG_PAT_TILE - 1) / WG_PAT_TILE;     // one workgroup per tile of text
     if (gx > 0x7fffffff) { set_err(err, errlen, "patbeta_feed: chunk too large"); return WGBSSEG_E_ARG; }
+    HIP_TRY(hipEventRecord(p->k0[k], p->st));
     hipLaunchKernelGGL(k_pat_count, dim3((unsigned)gx), dim3(WG_BLOCK), 0, p->st, p->text[k].as<char>(), n_bytes, p->start, p->end,
                        p->meth.as<int32_t>(), p->cov.as<int32_t>(), p->bad.as<unsigned long long>(), p->fed);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(p->k1[k], p->st));
+    p->timed[k] = true;
     HIP_TRY(hipEventRecord(p->ev[k], p->st));
     p->busy[k] = true;
     p->k ^= 1;
@@ -2368,6 +2384,14 @@ int wgbsseg_patbeta_finish(wgbsseg_patbeta* p, int32_t lbeta, void* out, char* e
     HIP_TRY(hipMemcpyAsync(out, p->outb.p, ob, hipMemcpyDeviceToHost, p->st));
     HIP_TRY(hipStreamSynchronize(p->st));
     return WGBSSEG_OK;
+}
+
+double wgbsseg_patbeta_kernel_ms(wgbsseg_patbeta* p)
+{
+    if (!p) return -1.0;
+    if (hipSetDevice(p->device) != hipSuccess || hipStreamSynchronize(p->st) != hipSuccess) return -1.0;
+    p->collect(0); p->collect(1);
+    return p->kernel_ms;
 }
 
 int wgbsseg_get_timings(const wgbsseg_ctx* c, wgbsseg_timings* out)
