@@ -72,6 +72,7 @@ def parse():
     ap.add_argument('--scan-carries', type=int, default=1, help='also time the prefix-sum pass with carries (k_scan) on the chunk grid (0: skip)')
     ap.add_argument('--matrix', type=int, default=1, help='also run a few steps at x8, x200 and x512 (1 GPU only; 0: skip)')
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='wall-time budget of the CPU baseline runs (0: skip)')
+    ap.add_argument('--extras', type=int, default=1, help='also time convert, pat2beta and the find_markers statistics (1 GPU only; 0: skip)')
     ap.add_argument('--e2e', type=int, default=1, help='also time the CLI end to end on page-cached files (1 GPU only; 0: skip)')
     return ap.parse_args()
 
@@ -187,7 +188,7 @@ def cpu_baseline(args, buf, sizes, loci, seg, params):
 # ------------------------------------------------------------------------------------------------------------
 # end to end through the CLI
 # ------------------------------------------------------------------------------------------------------------
-def end_to_end(args, buf, sizes, names, loci):
+def end_to_end(args, buf, sizes, names, loci, samples=None, reps=3):
     """`wgbstools segment` as a user runs it: .beta files (just written: in the page cache) -> BED, through the CLI entry point in
     this process.  SURVEY.md 8(d)(ii); PCIe- and file-I/O-inclusive, never `value`."""
     import contextlib
@@ -196,28 +197,15 @@ def end_to_end(args, buf, sizes, names, loci):
     from wgbs_tools_amd import wgbs_tools
     d = tempfile.mkdtemp(prefix='wgbs_e2e_')      # just written = in the page cache (tmpfs, measured, is the slower place: its page faults and writes cost 2x)
     try:
-        ref = op.join(d, 'references', 'synth')
-        os.makedirs(ref)
-        with open(op.join(ref, 'CpG.chrome.size'), 'w') as f:
-            for c, sz in zip(names, sizes):
-                f.write('%s\t%d\n' % (c, sz))
-        with open(op.join(ref, 'chrome.size'), 'w') as f:
-            pos = 0
-            for c, sz in zip(names, sizes):
-                f.write('%s\t%d\n' % (c, int(loci[pos + sz - 1]) + 10000))
-                pos += sz
-        import gzip
-        with gzip.open(op.join(ref, 'CpG.bed.gz'), 'wb') as f:       # only ever read to build loci.u32, which is written below
-            f.write(b'')
-        os.symlink('CpG.bed.gz', op.join(ref, 'rev.CpG.bed.gz'))
-        loci.tofile(op.join(ref, 'loci.u32'))
+        ref = write_reference_dir(d, names, sizes, loci)
         paths = []
-        for s in range(args.samples):
+        samples = samples or args.samples
+        for s in range(samples):
             pth = op.join(d, 's%03d.beta' % s)
             buf[s, :2 * args.sites].cpu().numpy().tofile(pth)
             paths.append(pth)
         best, rows, phases = None, 0, []
-        for rep in range(3):
+        for rep in range(reps):
             # a NEW output file per run, as a user's run writes one: overwriting the previous 115 MB of BED makes the kernel drop its page-cache
             # pages first (O_TRUNC: ~25 ms on this host, more than the writing itself) — that is not part of the pipeline
             out = op.join(d, 'blocks_%d.bed' % rep)
@@ -238,10 +226,203 @@ def end_to_end(args, buf, sizes, names, loci):
         rows = sum(1 for _ in open(out))
         return {'wall_s': best, 'value': args.sites / best, 'unit': 'CpG-sites/s', 'bed_rows': rows, 'bed_MB': op.getsize(out) / 1e6,
                 'phases_of_best_run': phases[0] if phases else None,
-                'what': '`wgbstools segment --betas <%d page-cached files> -o blocks.bed`, best of 3 in-process runs: files -> HBM -> borders -> BED '
-                        '(PCIe and file I/O included; not `value`)' % args.samples}
+                'what': '`wgbstools segment --betas <%d page-cached files> -o blocks.bed`, best of %d in-process runs: files -> HBM -> borders -> BED '
+                        '(PCIe and file I/O included; not `value`)' % (samples, reps), 'samples': samples,
+                'beta_GB': 2e-9 * args.sites * samples}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the rows of SURVEY.md 8(f) beside the path: convert, pat2beta, find_markers' statistics
+# ------------------------------------------------------------------------------------------------------------
+def synth_pat_text(seed, n_sites, n_reads):
+    """A pat file's text (bytes) over CpGs 1..n_sites, built with numpy: `chr1 \t first CpG \t pattern over {C,T,H,.} \t count \n`, reads of
+    1-12 CpGs, counts 1-40, sorted by start as real pat files are (the same distribution as synth.synth_pat_lines, millions of lines per second)."""
+    from wgbs_tools_amd.synth import hash_at
+    idx = np.arange(n_reads, dtype=np.int64)
+    start = np.sort((hash_at(seed, 91, idx) % np.uint64(n_sites)).astype(np.int64) + 1)
+    h1 = hash_at(seed, 92, idx)
+    ln = 1 + ((h1 & np.uint64(15)).astype(np.int64) % 12)
+    cnt = 1 + ((h1 >> np.uint64(8)) % np.uint64(40)).astype(np.int64)
+    hp = hash_at(seed, 93, idx)
+    ds = np.floor(np.log10(start)).astype(np.int64) + 1                   # digits of the start
+    dc = 1 + (cnt >= 10)
+    size = 5 + ds + 1 + ln + 1 + dc + 1
+    off = np.concatenate([[0], np.cumsum(size)])
+    buf = np.empty(int(off[-1]), dtype=np.uint8)
+    o = off[:-1]
+    for k, ch in enumerate(b'chr1\t'):
+        buf[o + k] = ch
+    for k in range(int(ds.max())):
+        m = ds > k
+        buf[o[m] + 5 + ds[m] - 1 - k] = 48 + (start[m] // 10 ** k) % 10
+    buf[o + 5 + ds] = 9
+    alphabet = np.frombuffer(b'CCCTTTH.', dtype=np.uint8)
+    po = o + 6 + ds
+    for k in range(12):
+        m = ln > k
+        buf[po[m] + k] = alphabet[((hp[m] >> np.uint64(3 * k)) & np.uint64(7)).astype(np.int64)]
+    buf[po + ln] = 9
+    co = po + ln + 1
+    two = dc == 2
+    buf[co[two]] = 48 + cnt[two] // 10
+    buf[co + dc - 1] = 48 + cnt % 10
+    buf[co + dc] = 10
+    return buf.tobytes(), int(ln.sum())
+
+
+def write_bgzf(path, data, level=6):
+    """`data` as a BGZF file (what bgzip writes and wgbstools' .pat.gz are: gzip members of <= 64 KB with their size in a 'BC' extra field)."""
+    import struct
+    import zlib
+    with open(path, 'wb') as f:
+        for p in list(range(0, len(data), 65280)) + [None]:
+            blk = b'' if p is None else data[p:p + 65280]
+            c = zlib.compressobj(level, zlib.DEFLATED, -15)
+            body = c.compress(blk) + c.flush()
+            f.write(b'\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00' + struct.pack('<H', len(body) + 25) + body +
+                    struct.pack('<II', zlib.crc32(blk), len(blk)))
+
+
+def write_reference_dir(d, names, sizes, loci):
+    """a genome directory the CLI entry points accept (the loci cached as loci.u32: CpG.bed.gz is never parsed)"""
+    import gzip
+    ref = op.join(d, 'references', 'synth')
+    os.makedirs(ref)
+    with open(op.join(ref, 'CpG.chrome.size'), 'w') as f:
+        for c, sz in zip(names, sizes):
+            f.write('%s\t%d\n' % (c, sz))
+    with open(op.join(ref, 'chrome.size'), 'w') as f:
+        pos = 0
+        for c, sz in zip(names, sizes):
+            f.write('%s\t%d\n' % (c, int(loci[pos + sz - 1]) + 10000))
+            pos += sz
+    with gzip.open(op.join(ref, 'CpG.bed.gz'), 'wb') as f:       # only ever read to build loci.u32, which is written below
+        f.write(b'')
+    os.symlink('CpG.bed.gz', op.join(ref, 'rev.CpG.bed.gz'))
+    loci.tofile(op.join(ref, 'loci.u32'))
+    return ref
+
+
+def extras(args, seg, loci, sizes, names, res):
+    """Throughput of the SURVEY.md 8(f) rows that had none in the line: `convert` (k_convert), `pat2beta` (k_pat_count + k_pat_trim; kernel only,
+    from host memory, through the CLI on a BGZF file, and the reference's stdin2beta on this host beside it), find_markers' per-block
+    statistics (k_marker_stats).  Each with the bound it runs against.  A few seconds in total."""
+    import shutil
+    from oracle import pat2beta_oracle as OP
+    from wgbs_tools_amd import _lib, wgbs_tools
+    out = {}
+    cum = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    L64 = loci.astype(np.int64)
+    n_sites = int(cum[-1])
+    # ---- convert: 2 M BED regions -> CpG ranges (two lower bounds in the chromosome's slice of the loci per region)
+    try:
+        rng = np.random.default_rng(7)
+        n = 2000000
+        ci = rng.integers(0, len(sizes), n)
+        clo, chi = cum[ci], cum[ci + 1]
+        anchor = L64[rng.integers(clo, chi)]
+        start = anchor + rng.integers(-300, 300, n)
+        end = start + rng.integers(1, 4000, n)
+        cbp = L64[chi - 1] + 10000
+        slow = (rng.random(n) < 0.1).astype(np.uint8)
+        seg.convert_regions(clo, chi, cbp, start, end, slow)
+        t0 = time.perf_counter()
+        s_, e_ = seg.convert_regions(clo, chi, cbp, start, end, slow)
+        wall = time.perf_counter() - t0
+        ms = seg.last_block_sums_ms()
+        steps = 2 * int(np.ceil(np.log2(max(sizes))))
+        out['convert'] = {'kernel': 'k_convert (one thread per BED region: two lower bounds in its chromosome\'s slice of the resident loci, both rule sets of convert.py:133-185)',
+                          'regions': n, 'kernel_ms': ms, 'regions_per_s': n / (ms * 1e-3), 'call_wall_ms': wall * 1e3, 'regions_per_s_call': n / wall,
+                          'mapped': int((s_ != 0).sum()),
+                          'bound': 'memory latency: ~%d dependent 4-byte loads per region into a %.0f MB array (L2 / MALL resident); the call itself is the '
+                                   'PCIe copy of 5 x 16 MB in and 2 x 16 MB out' % (steps, loci.nbytes / 1e6),
+                          'dependent_loads_per_s': n * steps / (ms * 1e-3)}
+    except Exception as e:
+        out['convert'] = {'failed': repr(e)}
+    # ---- find_markers: per-block statistics of a target and a background set over the ratio table of the blocks just found
+    try:
+        bs = np.concatenate([np.asarray(r[:-1], dtype=np.int64) for r in res]) - 1
+        be = np.concatenate([np.asarray(r[1:], dtype=np.int64) for r in res]) - 1
+        seg.block_sums(bs, be, mode=3, min_cov=4)
+        t_table = seg.last_block_sums_ms()
+        tg = list(range(0, args.samples, 4))
+        bg = [s for s in range(args.samples) if s % 4]
+        seg.marker_stats(tg, bg, bs.size)
+        seg.marker_stats(tg, bg, bs.size)
+        ms = seg.last_block_sums_ms()
+        rd = 8.0 * bs.size * (len(tg) + len(bg))
+        out['find_markers'] = {'kernel': 'k_marker_stats (per block: count, sequential sum, min, max of the target and of the background samples\' ratios; find_markers.py:318-335) '
+                                         'over the device-resident ratio table of block-reduction mode 3',
+                               'blocks': int(bs.size), 'samples': len(tg) + len(bg), 'kernel_ms': ms, 'block_samples_per_s': bs.size * (len(tg) + len(bg)) / (ms * 1e-3),
+                               'ratio_table_ms': t_table, 'algorithmic_bytes': rd + 64.0 * bs.size, 'GB_per_s': (rd + 64.0 * bs.size) / (ms * 1e-3) / 1e9,
+                               'frac_of_hbm_peak': (rd + 64.0 * bs.size) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'bound': 'hbm (every ratio of the table read once, 64 B written per block)'}
+    except Exception as e:
+        out['find_markers'] = {'failed': repr(e)}
+    # ---- pat2beta
+    d = tempfile.mkdtemp(prefix='wgbs_pat_')
+    try:
+        n_reads = 4000000
+        text, n_chars = synth_pat_text(SEED, n_sites, n_reads)
+        mb = len(text) / 1e6
+        cuts = [0]
+        while cuts[-1] < len(text):
+            cuts.append(len(text) if len(text) - cuts[-1] <= (64 << 20) else text.rfind(b'\n', cuts[-1], cuts[-1] + (64 << 20)) + 1)
+        rows0 = None
+        best_wall, best_k = None, None
+        for rep in range(3):
+            with _lib.PatBeta(1, n_sites + 1) as pb:
+                t0 = time.perf_counter()
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    pb.feed(text[a:b])
+                k_ms = pb.kernel_ms()
+                rows = pb.finish()
+                wall = time.perf_counter() - t0
+            rows0 = rows
+            if rep and (best_wall is None or wall < best_wall):
+                best_wall = wall
+            if rep and (best_k is None or k_ms < best_k):
+                best_k = k_ms
+        # the CLI on a BGZF file (inflate on the host's threads + the feed above + the .beta file)
+        ref = write_reference_dir(d, names, sizes, loci)
+        gz = op.join(d, 'smp.pat.gz')
+        write_bgzf(gz, text, level=1)
+        cli = None
+        for rep in range(2):
+            t0 = time.perf_counter()
+            rc = wgbs_tools.main(['wgbstools', 'pat2beta', gz, '-o', d, '--genome', ref, '-f'])
+            w = time.perf_counter() - t0
+            assert not rc
+            cli = w if cli is None else min(cli, w)
+        same_file = bool(np.array_equal(np.fromfile(op.join(d, 'smp.beta'), dtype=np.uint8).reshape(-1, 2), rows0))
+        # the reference's binary on this host (1 core): the text from memory, and its own pipeline `gunzip -c | stdin2beta` (pat2beta.py:30)
+        refrec = None
+        if OP.have_ref():
+            sample = text[:cuts[1]]
+            t0 = time.perf_counter()
+            r = subprocess.run([OP.REF_BIN, '1', str(n_sites + 1)], input=sample, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            t_ref = time.perf_counter() - t0
+            # (its stdout is the whole genome's counts as text: 2 x 28 M numbers — part of what the reference's pipeline pays per file)
+            t0 = time.perf_counter()
+            r2 = subprocess.run('gunzip -c %s | %s 1 %d > %s' % (gz, OP.REF_BIN, n_sites + 1, op.join(d, 'ref_counts.txt')), shell=True)
+            t_pipe = time.perf_counter() - t0
+            refrec = {'binary': 'oracle/_ref/stdin2beta (the reference\'s own source, g++ -O2)', 'cores': 1, 'sample_MB': len(sample) / 1e6, 'wall_s': t_ref,
+                      'text_MB_per_s': len(sample) / 1e6 / t_ref, 'pipeline': '`gunzip -c smp.pat.gz | stdin2beta 1 N+1 > counts.txt` over the whole file (pat2beta.py:30; the reference '
+                      'then parses that text again with numpy and trims it)', 'pipeline_wall_s': t_pipe, 'pipeline_text_MB_per_s': mb / t_pipe, 'pipeline_rc': r2.returncode, 'rc': r.returncode}
+        out['pat2beta'] = {'kernel': 'k_pat_count (4 KB tiles of text through LDS, one line per thread, int32 atomics per covered site) + k_pat_trim; stdin2beta.cpp:59-123',
+                           'text_MB': mb, 'reads': n_reads, 'covered_sites_chars': n_chars, 'chunks': len(cuts) - 1,
+                           'kernel_ms': best_k, 'kernel_text_GB_per_s': mb / 1e3 / (best_k * 1e-3), 'kernel_reads_per_s': n_reads / (best_k * 1e-3),
+                           'from_host_memory_wall_s': best_wall, 'from_host_memory_text_MB_per_s': mb / best_wall, 'from_host_memory_reads_per_s': n_reads / best_wall,
+                           'cli_bgzf_wall_s': cli, 'cli_bgzf_text_MB_per_s': mb / cli, 'cli_bgzf_reads_per_s': n_reads / cli, 'cli_file_equals_device_rows': same_file,
+                           'bgzf_MB': op.getsize(gz) / 1e6, 'reference_cpu': refrec,
+                           'bound': 'the kernel is not the bound: from host memory the call is the copy of the text into page-locked memory and over PCIe (1 byte of text moved per byte '
+                                    'counted) + 2 x 4 B x %d sites of counts trimmed and copied back; through the CLI it is the host\'s inflate of the BGZF blocks' % n_sites}
+    except Exception as e:
+        out['pat2beta'] = {'failed': repr(e)}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -683,6 +864,11 @@ def main():
         single = not multi and not group_mode
         if multi_rows is not None:
             out['matrix'] = {'what': 'the same sharded whole-genome step at x200 (BASELINE.json configs[3]), timed like the main run (barrier, max over ranks)', 'rows': multi_rows}
+        if single and args.extras:
+            try:
+                out['extras'] = extras(args, seg, loci, sizes, names, res)
+            except Exception as e:
+                out['extras'] = {'failed': repr(e)}
         if single and args.e2e:
             try:
                 out['end_to_end'] = end_to_end(args, buf, sizes, names, loci)
@@ -753,7 +939,14 @@ def main():
                                  'scan_frac_of_hbm_peak': a2['scan_main_bytes'] / (a2['scan_main_ms'] / k * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                  'beta_GB_resident': ns * pitch2 / 1e9})
                     s2.close()
-                    del b2, s2
+                    del s2
+                    if ns == 200 and args.e2e:
+                        # the atlas-scale cohort end to end: 11.3 GB of page-cached files -> HBM -> BED; the upload is longer than the compute
+                        try:
+                            rows[-1]['end_to_end'] = end_to_end(args, b2, sizes, names, loci, samples=ns, reps=2)
+                        except Exception as e:
+                            rows[-1]['end_to_end'] = {'value': None, 'what': 'failed: %r' % (e,)}
+                    del b2
                     torch.cuda.empty_cache()
                 except Exception as e:
                     rows.append({'samples': ns, 'failed': repr(e)})

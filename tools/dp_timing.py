@@ -82,5 +82,16 @@ with _lib.Segmenter(0) as sg:
             for k, v in cls.items():
                 if v:
                     print('   %-48s %4d chunks: %.1f ticks per step in the loop, %.1f without the barrier waits' % (k, len(v), rec_ticks[v].mean(), rec_busy[v].mean()))
+            nw = int((hw[0] != 0).sum())
+            waits = full[:, 20:20 + nw] / full[:, 0:1]                     # fraction of the loop each role spends at the barrier
+            issue = full[:, 40:40 + nw] / chunk * 64                       # ticks per batch each worker spends issuing its row loads
+            same = np.array([[simd[c, r] == simd[c, 0] for r in range(nw)] for c in range(nch)])
+            print('   barrier wait by role (0 = recurrence, then the workers), mean over chunks: %s' % ' '.join('%.2f' % x for x in waits.mean(0)))
+            print('   load-issue ticks per batch by role: %s' % ' '.join('%.0f' % x for x in issue.mean(0)))
+            for r in range(1, nw):
+                a, b = waits[same[:, r], r], waits[~same[:, r], r]
+                if a.size and b.size:
+                    print('   worker %d: on the recurrence wavefront\'s SIMD in %d chunks: wait %.2f, issue %.0f | elsewhere in %d: wait %.2f, issue %.0f'
+                          % (r - 1, a.size, a.mean(), issue[same[:, r], r].mean(), b.size, b.mean(), issue[~same[:, r], r].mean()))
             life = (t_end - t_begin)
             print('   loop lifetime (ticks): min %.3g mean %.3g max %.3g; first begin .. last end %.3g' % (life.min(), life.mean(), life.max(), t_end.max() - t_begin.min()))

@@ -6,7 +6,7 @@
 set -u
 REPO=$PWD
 O=$REPO/gpurun_out/$1; mkdir -p $O
-B="--matrix 0 --cpu-seconds 0 --e2e 0 --block-sums 0 --scan-carries 0 --steps 10 --warmup 3"
+B="--matrix 0 --cpu-seconds 0 --e2e 0 --extras 0 --block-sums 0 --scan-carries 0 --steps 10 --warmup 3"
 IFS=';' read -ra SETS <<< "$3"
 for spec in $2; do
   v=${spec%%@*}; envs=""; [ "$spec" != "$v" ] && envs=${spec#*@}

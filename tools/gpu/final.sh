@@ -6,9 +6,9 @@ REPO=$PWD
 O=$REPO/gpurun_out/final
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o stats -- python $REPO/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --e2e 0 --matrix 0 > $O/rocprof_bench.log 2>&1; echo "rocprofv3 stats: rc $?"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o stats -- python $REPO/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --e2e 0 --extras 0 --matrix 0 > $O/rocprof_bench.log 2>&1; echo "rocprofv3 stats: rc $?"
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/rocprofv3_kernel_stats_28M_x32.csv
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_isl -o stats -- python $REPO/bench.py --islands --steps 5 --warmup 2 --cpu-seconds 0 --e2e 0 --matrix 0 > $O/rocprof_bench_islands.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_isl -o stats -- python $REPO/bench.py --islands --steps 5 --warmup 2 --cpu-seconds 0 --e2e 0 --extras 0 --matrix 0 > $O/rocprof_bench_islands.log 2>&1
 find $O/prof_isl -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/rocprofv3_kernel_stats_28M_x32_islands.csv
 timeout 900 python $REPO/tools/pmc_cost_traffic.py > $O/pmc_cost_traffic.log 2>&1; echo "pmc cost traffic: rc $?"
 timeout 600 python $REPO/tools/pmc_scan_traffic.py > $O/pmc_scan.log 2>&1; echo "pmc scan traffic: rc $?"
@@ -20,7 +20,7 @@ rm -rf $O/prof $O/prof_isl $REPO/gpurun_out/pmc_*
 cd $REPO
 # (the PMC files above are now under profiles/ of THIS box's copy: the bench line below reports them; they come home under gpurun_out/final/)
 timeout 900 python bench.py --steps 20 --warmup 5 2> $O/bench.err | tail -1 > $O/bench.json; echo "bench: $(cut -c1-160 $O/bench.json)"; python tools/summ.py $O/bench.json
-B="--matrix 0 --cpu-seconds 0 --e2e 0 --scan-carries 0 --steps 10 --warmup 2"
+B="--matrix 0 --cpu-seconds 0 --e2e 0 --extras 0 --scan-carries 0 --steps 10 --warmup 2"
 timeout 300 python bench.py --islands $B 2> /dev/null | tail -1 > $O/bench_islands.json
 timeout 300 python bench.py --islands --samples 8 $B 2> /dev/null | tail -1 > $O/bench_islands_x8.json
 timeout 300 python bench.py --sites 3527181 $B 2> /dev/null | tail -1 > $O/bench_one_eighth.json

@@ -21,7 +21,7 @@ COUNTERS = ['SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_VALU', 'SQ_ACTIV
 def main():
     d = op.join(OUT, 'pmc_cost_sq')
     cmd = ['rocprofv3', '--kernel-trace', '--pmc'] + COUNTERS + ['--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
-           sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--matrix', '0', '--block-sums', '0', '--scan-carries', '0'] + sys.argv[1:]
+           sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--extras', '0', '--matrix', '0', '--block-sums', '0', '--scan-carries', '0'] + sys.argv[1:]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     files = glob.glob(op.join(d, '**', '*counter_collection.csv'), recursive=True)
     if not files:

@@ -18,7 +18,7 @@ import sys
 ROOT = op.dirname(op.dirname(op.abspath(__file__)))
 OUT = op.join(ROOT, 'gpurun_out')
 EXTRA = sys.argv[1:]
-BENCH = [sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--matrix', '0', '--block-sums', '0', '--scan-carries', '0'] + EXTRA
+BENCH = [sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--extras', '0', '--matrix', '0', '--block-sums', '0', '--scan-carries', '0'] + EXTRA
 CALIB = [op.join(ROOT, 'tools', 'micro', '_build', 'fetch_calib')]
 
 
@@ -78,7 +78,7 @@ def main():
     from wgbs_tools_amd import build
     rec = {'kernel': main_k, 'csrc_sha': build.source_hash(), 'workload': bl['config']['workload'],
            'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), gfx950, ROCm 7.2, over `python bench.py --steps 1 --warmup 0 --cpu-seconds 0 '
-                     '--e2e 0 --matrix 0 --block-sums 0` + the arguments after --; the k_cost dispatch with the most bytes (the main batch: every chunk of the genome)',
+                     '--e2e 0 --extras 0 --matrix 0 --block-sums 0` + the arguments after --; the k_cost dispatch with the most bytes (the main batch: every chunk of the genome)',
            'calibration': {'what': 'tools/micro/fetch_calib under the same two passes: 1 GiB read / written once per kernel; bytes per reported KB (1024 would be exact)',
                            'FETCH_SIZE_KB': calib.get('FETCH_SIZE'), 'WRITE_SIZE_KB': calib.get('WRITE_SIZE'),
                            'read_factor_4_8_16B_per_lane': fkb, 'write_factor': wkb, 'read_factor_used': ff, 'write_factor_used': wf,

@@ -30,7 +30,7 @@ def main():
     a = ap.parse_args(argv)
     d = op.join(OUT, 'pmc_' + a.kernel)
     cmd = ['rocprofv3', '--kernel-trace', '--pmc'] + a.counters + ['--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
-           sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--matrix', '0', '--block-sums', '0', '--scan-carries', '0'] + extra
+           sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--extras', '0', '--matrix', '0', '--block-sums', '0', '--scan-carries', '0'] + extra
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
     files = glob.glob(op.join(d, '**', '*counter_collection.csv'), recursive=True)
     if not files:

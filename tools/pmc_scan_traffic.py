@@ -22,7 +22,7 @@ EXTRA = [a for a in sys.argv[1:] if a != '--forced-carries'] + ['--scan-carries'
 def one_pass(counter):
     d = op.join(OUT, 'pmc_' + counter)
     cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
-           sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--matrix', '0', '--block-sums', '0'] + EXTRA
+           sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--extras', '0', '--matrix', '0', '--block-sums', '0'] + EXTRA
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'),
                    timeout=240)
     best = None
@@ -49,7 +49,7 @@ def main():
     except AssertionError:
         gw, write = gf, 0.0
     # the exact algorithmic bytes of that launch (2 bytes x samples x sites of the main batch: chunks + upfront patches): bench.py reports it
-    r = subprocess.run([sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--matrix', '0', '--block-sums', '0'] + EXTRA,
+    r = subprocess.run([sys.executable, op.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--cpu-seconds', '0', '--e2e', '0', '--extras', '0', '--matrix', '0', '--block-sums', '0'] + EXTRA,
                        stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=240)
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     bl = json.loads(line)
@@ -57,7 +57,7 @@ def main():
     sys.path.insert(0, ROOT)
     from wgbs_tools_amd import build
     rec = {'kernel': kname, 'csrc_sha': build.source_hash(), 'workload': bl['config']['workload'] + ': main batch (chunks + upfront patches; the patches lie inside the chunks and are not read again)',
-           'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), gfx950, ROCm 7.2; the scan-pass dispatch with the most bytes of `python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --e2e 0 --matrix 0 --block-sums 0` + the arguments after --',
+           'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), gfx950, ROCm 7.2; the scan-pass dispatch with the most bytes of `python bench.py --steps 1 --warmup 0 --cpu-seconds 0 --e2e 0 --extras 0 --matrix 0 --block-sums 0` + the arguments after --',
            'grid_size': gf, 'FETCH_SIZE_KB': fetch, 'WRITE_SIZE_KB': write,
            'correction': 'MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B/lane) -> doubled; WRITE_SIZE taken as is; units KB = 1024 B',
            'read_bytes': 2 * fetch * 1024, 'write_bytes': write * 1024, 'traffic_bytes': 2 * fetch * 1024 + write * 1024,
