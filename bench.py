@@ -396,6 +396,15 @@ def extras(args, seg, loci, sizes, names, res):
             assert not rc
             cli = w if cli is None else min(cli, w)
         same_file = bool(np.array_equal(np.fromfile(op.join(d, 'smp.beta'), dtype=np.uint8).reshape(-1, 2), rows0))
+        # the host side of that run alone: the file's text through pat_chunks (BGZF blocks inflated on the host's threads), nothing fed to the device
+        from wgbs_tools_amd import pat2beta as P2B
+        inflate = None
+        for rep in range(2):
+            t0 = time.perf_counter()
+            got = sum(len(c) for c in P2B.pat_chunks(gz))
+            w = time.perf_counter() - t0
+            assert got == len(text)
+            inflate = w if inflate is None else min(inflate, w)
         # the reference's binary on this host (1 core): the text from memory, and its own pipeline `gunzip -c | stdin2beta` (pat2beta.py:30)
         refrec = None
         if OP.have_ref():
@@ -415,9 +424,10 @@ def extras(args, seg, loci, sizes, names, res):
                            'kernel_ms': best_k, 'kernel_text_GB_per_s': mb / 1e3 / (best_k * 1e-3), 'kernel_reads_per_s': n_reads / (best_k * 1e-3),
                            'from_host_memory_wall_s': best_wall, 'from_host_memory_text_MB_per_s': mb / best_wall, 'from_host_memory_reads_per_s': n_reads / best_wall,
                            'cli_bgzf_wall_s': cli, 'cli_bgzf_text_MB_per_s': mb / cli, 'cli_bgzf_reads_per_s': n_reads / cli, 'cli_file_equals_device_rows': same_file,
-                           'bgzf_MB': op.getsize(gz) / 1e6, 'reference_cpu': refrec,
+                           'bgzf_MB': op.getsize(gz) / 1e6, 'host_inflate_only_wall_s': inflate, 'host_inflate_only_text_MB_per_s': mb / inflate, 'reference_cpu': refrec,
                            'bound': 'the kernel is not the bound: from host memory the call is the copy of the text into page-locked memory and over PCIe (1 byte of text moved per byte '
-                                    'counted) + 2 x 4 B x %d sites of counts trimmed and copied back; through the CLI it is the host\'s inflate of the BGZF blocks' % n_sites}
+                                    'counted) + 2 x 4 B x %d sites of counts trimmed and copied back; through the CLI it is the host (host_inflate_only_wall_s: the BGZF blocks inflated on the host\'s threads and cut at line ends, in Python; the rest is the 56 MB .beta file, '
+                                    'the genome tables and the accumulator\'s 2 x 4 B x %d counters)' % (n_sites, n_sites)}
     except Exception as e:
         out['pat2beta'] = {'failed': repr(e)}
     finally:

@@ -1053,11 +1053,7 @@ __device__ __forceinline__ int32_t wg_ld_l2_i32(const int32_t* p) { return __hip
 // the end of batch b and stored to the free LDS slot at the end of batch b+1 — a full batch to land.
 template <int NW, int BL>
 struct DpRows {                                          // one worker's share of a batch, in registers
-#ifdef WGBSSEG_DP_UNEVEN
-    static constexpr int PER = (NW == 7 && BL == 64) ? (64 - WGBSSEG_DP_UNEVEN + 5) / 6 : (BL + NW - 1) / NW;
-#else
     static constexpr int PER = (BL + NW - 1) / NW;
-#endif
     double va[PER], vb[PER];
     uint32_t fmax;                                       // widest window of the batch
     bool wideb;
@@ -1115,24 +1111,6 @@ __device__ __forceinline__ DpMeta wg_dp_meta_lds(const uint16_t* __restrict__ me
     return m;
 }
 
-// Row q of worker lw.  Default: rows lw, lw + NW, ...  -DWGBSSEG_DP_UNEVEN (experiment, 1 + 7 wavefronts, 64-step batches): the worker that shares the
-// recurrence wavefront's SIMD (wavefront 4 = worker 3: the dispatcher deals a workgroup's wavefronts to the SIMDs in cyclic order) takes only the last
-// WGBSSEG_DP_UNEVEN rows, the other six share the rest.
-template <int NW, int BL>
-__device__ __forceinline__ int wg_dp_row_of(int lw, int q)
-{
-#ifdef WGBSSEG_DP_UNEVEN
-    if (NW == 7 && BL == 64) {
-        constexpr int SLOW = WGBSSEG_DP_UNEVEN, REST = 64 - SLOW;          // rows 0 .. REST-1 dealt to six workers, REST .. 63 to worker 3
-        if (lw == 3) return q < SLOW ? REST + q : 64;
-        const int l6 = lw < 3 ? lw : lw - 1;
-        const int sidx = l6 + 6 * q;
-        return sidx < REST ? sidx : 64;
-    }
-#endif
-    return lw + q * NW;
-}
-
 template <int NW, int BL>
 __device__ __forceinline__ void wg_dp_rows_issue(DpRows<NW, BL>& R, const double* __restrict__ cb, const DpMeta M, int base, int lane, int lw)
 {
@@ -1144,7 +1122,7 @@ __device__ __forceinline__ void wg_dp_rows_issue(DpRows<NW, BL>& R, const double
     const int stp0 = base & 63;
 #pragma unroll
     for (int q = 0; q < DpRows<NW, BL>::PER; q++) {
-        const int sidx = wg_dp_row_of<NW, BL>(lw, q);
+        const int sidx = lw + q * NW;
         R.va[q] = NEG_INF; R.vb[q] = NEG_INF;
         if (sidx < BL) {
             const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)w, sidx);
@@ -1164,7 +1142,7 @@ __device__ __forceinline__ void wg_dp_rows_commit(const DpRows<NW, BL>& R, doubl
     if (lw == 0 && lane == 0) *kind = R.wideb ? 1u : (R.fmax > (uint32_t)WG_NARROW_WMAX ? 2u : 0u);      // 0: every window of the batch <= 60 sites, 2: <= 64, 1: wide (slot B in use)
 #pragma unroll
     for (int q = 0; q < DpRows<NW, BL>::PER; q++) {
-        const int sidx = wg_dp_row_of<NW, BL>(lw, q);
+        const int sidx = lw + q * NW;
         if (sidx < BL) {
             slotA[sidx * 64 + lane] = R.va[q];
             if (WIDEJOB && R.wideb) slotB[sidx * 64 + lane] = R.vb[q];

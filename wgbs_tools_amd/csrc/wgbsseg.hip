@@ -19,6 +19,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <pthread.h>
+#include <sched.h>
 
 #include "../../include/wgbsseg.h"
 #include "seg_kernels.h"
@@ -159,6 +161,8 @@ struct wgbsseg_ctx {
 
 namespace {
 
+bool device_local_cpus(int device, cpu_set_t* out);      // (below, with the streaming upload)
+
 // Pageable host rows (typically memory-mapped .beta files) -> HBM: dst + r * dst_pitch <- rows[r][0 .. row_bytes).
 // One thread drives ~33 GB/s of that (page faults + the copy into page-locked staging); a few threads, each with its
 // own stream and two 4 MB staging pieces, fill the link (measured 46 GB/s with 4; more threads only contend).
@@ -182,7 +186,10 @@ int upload_rows(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const uint8_t* 
             if (!c->up_stage[(size_t)i].ensure_exact((size_t)piece)) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
         std::atomic<int64_t> next(0);
         std::vector<hipError_t> terr((size_t)T, hipSuccess);
+        cpu_set_t near_cpus;
+        const bool pin = device_local_cpus(c->device, &near_cpus);
         auto worker = [&](int t) {
+            if (pin) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
             hipError_t e = hipSetDevice(c->device);
             hipStream_t st = nullptr;
             hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1400,6 +1407,42 @@ void parallel_for(int64_t n, int max_threads, F f)
 
 namespace {
 
+// The CPUs next to a device: /sys/bus/pci/devices/<bus id>/local_cpulist (e.g. "0-63,128-191"), cut to the CPUs this process may use.
+// An upload thread that runs on the OTHER socket of a two-socket host fills page-locked pieces over there and the DMA then crosses the
+// socket link: measured on an MI355X box (round 5, x200 = 11.3 GB): the same upload at 9 .. 35 GB/s from run to run with free-running
+// threads.  false: unknown (no sysfs, every CPU listed, WGBSSEG_UPLOAD_PIN=0) — the threads then run where the scheduler puts them.
+bool device_local_cpus(int device, cpu_set_t* out)
+{
+    { const char* e = getenv("WGBSSEG_UPLOAD_PIN"); if (e && atoi(e) == 0) return false; }
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    for (char* q = bus; *q; q++) if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a');       // sysfs names are lower case
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char line[4096] = {0};
+    const bool got = fgets(line, (int)sizeof line, f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t allowed, local;
+    CPU_ZERO(&allowed); CPU_ZERO(&local);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    int n_local = 0;
+    for (const char* q = line; *q;) {
+        while (*q == ',' || *q == ' ' || *q == '\n') q++;
+        if (*q < '0' || *q > '9') break;
+        char* end = nullptr;
+        long a = strtol(q, &end, 10), b = a;
+        if (*end == '-') b = strtol(end + 1, &end, 10);
+        for (long x = a; x <= b && x < CPU_SETSIZE; x++) if (CPU_ISSET((int)x, &allowed)) { CPU_SET((int)x, &local); n_local++; }
+        q = end;
+    }
+    if (n_local == 0 || n_local == CPU_COUNT(&allowed)) return false;      // nothing to choose from
+    *out = local;
+    return true;
+}
+
 // Site-major upload of `n_rows` pageable rows: pieces of `piece` bytes go out in the order (piece 0 of every row, piece 1 of
 // every row, ...) on T host threads, each with its own stream and two page-locked staging buffers; `ready_sites` follows
 // the longest prefix of every row that is known to be resident, in sites of 2 bytes (a piece counts once its DMA has completed).
@@ -1407,10 +1450,14 @@ int upload_rows_streaming(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const
                           std::atomic<int64_t>& ready_sites, std::string& msg)
 {
     const double t0 = wall_s();
-    int64_t piece = 1 << 20;      // (measured: 4 threads x 1 MB 33.5 GB/s, x 2 MB 26-29, 8-16 threads 17-30: profiles/r02_upload_sweep.txt)
+    // (measured, free-running threads: 4 threads x 1 MB 33.5 GB/s, x 2 MB 26-29, 8-16 threads 17-30: profiles/r02_upload_sweep.txt.  Round 5, threads on the
+    // device's CPUs: 8 threads x 4 MB 37-42 GB/s on 11.3 GB (x200: 0.35-0.38 s end to end against 0.43-0.50 with 4 x 1 MB); x32's 1.8 GB the same either
+    // way: profiles/r05_upload_pinned_ab.txt.  Large cohorts take the wide form.)
+    const bool big = row_bytes * n_rows >= (4LL << 30);
+    int64_t piece = big ? (4 << 20) : (1 << 20);
     { const char* e = getenv("WGBSSEG_UPLOAD_PIECE_KB"); if (e && atoi(e) >= 64) piece = (int64_t)atoi(e) << 10; }
     const int64_t ppr = (row_bytes + piece - 1) / piece, n_tasks = ppr * n_rows;
-    int T = 4;
+    int T = big ? 8 : 4;
     { const char* e = getenv("WGBSSEG_UPLOAD_THREADS"); if (e && atoi(e) > 0) T = atoi(e); }
     T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(T, 64), n_tasks));
     std::vector<std::atomic<int>> rows_done((size_t)ppr);
@@ -1418,6 +1465,8 @@ int upload_rows_streaming(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const
     std::atomic<int64_t> next(0), pieces_done(0);
     std::mutex mu;
     std::vector<hipError_t> terr((size_t)T, hipSuccess);
+    cpu_set_t near_cpus;
+    const bool pin = device_local_cpus(c->device, &near_cpus);      // upload threads (and the pieces they allocate and fill) on the device's socket
     auto complete = [&](int64_t task) {                          // task = p * n_rows + r: row r's piece p is on the device
         const int64_t p = task / n_rows;
         if (rows_done[(size_t)p].fetch_add(1) + 1 == (int)n_rows) {
@@ -1429,6 +1478,7 @@ int upload_rows_streaming(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const
         }
     };
     auto worker = [&](int t) {
+        if (pin) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
         hipError_t e = hipSetDevice(c->device);
         hipStream_t st = nullptr;
         hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1462,8 +1512,8 @@ int upload_rows_streaming(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const
     for (int t = 0; t < T; t++)
         if (terr[(size_t)t] != hipSuccess) { msg = std::string("HIP error during the upload: ") + hipGetErrorString(terr[(size_t)t]); return WGBSSEG_E_HIP; }
     ready_sites.store(row_bytes / 2);
-    if (profiling()) fprintf(stderr, "[wgbsseg] betas to the device (streaming): %.1f ms, %.1f GB/s (%d upload threads)\n", (wall_s() - t0) * 1e3,
-                             (double)row_bytes * n_rows / (wall_s() - t0) * 1e-9, T);
+    if (profiling()) fprintf(stderr, "[wgbsseg] betas to the device (streaming): %.1f ms, %.1f GB/s (%d upload threads%s)\n", (wall_s() - t0) * 1e3,
+                             (double)row_bytes * n_rows / (wall_s() - t0) * 1e-9, T, pin ? ", on the device's CPUs" : "");
     return WGBSSEG_OK;
 }
 
