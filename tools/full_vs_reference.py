@@ -39,6 +39,10 @@ def main():
     ap.add_argument('--max-bp', type=int, default=2000)
     ap.add_argument('--procs', type=int, default=0, help='reference processes at a time (0: all logical CPUs)')
     ap.add_argument('--chromosomes', default='', help='e.g. 0-24 or 20,21 (default: all)')
+    ap.add_argument('--adversarial', action='store_true',
+                    help='another world at full size: loci with CpG islands (windows of hundreds of sites: medium and wide tiles, the 32-step recurrence, carries), a few '
+                         'runs of EQUAL positions and backward steps (the plain path on whole chunks), and in every sample thousands of stretches of zero coverage, '
+                         'saturated counts (255, 255), (0, 255), (127, 255) and single reads (1, 1) — the shapes the small fuzz worlds hold, at the size of the genome')
     args = ap.parse_args()
 
     import test_gpu_fullsize as F                      # the suite's helpers: device genome, recorder, reference runner, tree
@@ -62,12 +66,45 @@ def main():
         for part in args.chromosomes.split(','):
             a, _, b = part.partition('-')
             which += list(range(int(a), int(b or a) + 1))
+    if args.adversarial:
+        loci = synth.synth_loci(F.SEED, sizes, islands=True)
+        rng = np.random.default_rng(20260927)
+        L = loci.astype(np.int64)
+        edges = np.concatenate([[0], np.cumsum(sizes)])
+        n_disorder = 0
+        for c in rng.choice(len(sizes) - 1, 8, replace=False):          # eight places, each inside one chromosome
+            p0 = int(rng.integers(edges[c] + 1000, edges[c + 1] - 1000))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                k = int(rng.integers(1, 6)); L[p0 + 1:p0 + 1 + k] = L[p0]            # a run of equal positions
+            elif kind == 1:
+                L[p0 + 1] = L[p0] - int(rng.integers(1, 50))                          # one step backwards
+            else:
+                k = int(rng.integers(3, 30)); L[p0:p0 + k] = L[p0:p0 + k][::-1].copy()   # a descending run
+            n_disorder += 1
+        loci = L.astype(np.uint32)
     sha = nbuild.source_hash()
     print('library csrc_sha %s, ABI %d; %d CpGs x %d betas, chunk %d, max_cpg %d, max_bp %d, pcount %g; reference binary: %s'
           % (sha, _lib.load().wgbsseg_version(), sites, N, chunk, mc, mb, pc, oracle.REF_BIN), flush=True)
     assert oracle.have_ref(), 'oracle/_ref/segmentor is missing'
     t0 = time.time()
     buf, pitch = F._device_genome(sites, N)
+    if args.adversarial:
+        kinds = torch.tensor([[0, 0], [255, 255], [0, 255], [127, 255], [1, 1], [255, 255]], dtype=torch.uint8, device=buf.device)
+        n_st = 0
+        for smp in range(N):
+            r = np.random.default_rng(1000 + smp)
+            K = 1500
+            a = r.integers(0, sites - 1, K)
+            ln = np.minimum(np.where(r.random(K) < 0.8, r.integers(1, 60, K), r.integers(60, 4000, K)), sites - a)
+            kd = r.integers(0, len(kinds), K)
+            row = buf[smp, :2 * sites].view(sites, 2)
+            for x, l, k in zip(a.tolist(), ln.tolist(), kd.tolist()):
+                row[x:x + l] = kinds[k]
+            n_st += K
+        torch.cuda.synchronize()
+        print('adversarial world: loci with CpG islands, %d places with equal / backward positions, %d stretches of zero / saturated / single-read counts over the %d samples'
+              % (n_disorder, n_st, N), flush=True)
     bad = 0
     with _lib.Segmenter(0) as seg:
         seg.set_betas_device(buf.data_ptr(), N, pitch, sites, keepalive=buf)
@@ -137,7 +174,7 @@ def main():
            'chromosomes_identical': chrom_ok, 'chromosomes': len(which), 'chunks_identical': ch_ok, 'chunks': ch_n,
            'patches_identical': pa_ok, 'patches': pa_n, 'blocks': n_blocks, 'differences': bad,
            'reference_seconds': ref_s, 'reference_procs': procs, 'host_cpus': os.cpu_count(), 'wall_s': time.time() - t0,
-           'device': torch.cuda.get_device_name(0)}
+           'device': torch.cuda.get_device_name(0), 'adversarial': bool(args.adversarial)}
     print(json.dumps(out), flush=True)
     return 1 if bad else 0
 
