@@ -366,3 +366,37 @@ def test_comments_inside_a_line_and_pandas_missing_values(tmp_path):
     q.write_text('chr1\t100\t200\tfive\t9\n')
     with pytest.raises(IllegalArgumentError):
         B2B.load_blocks_file(str(q))
+
+
+def test_trim_rescale_is_an_integer_division():
+    """utils_wgbs.py:277-290 trim_to_uint8 rescales a saturated pair with three float64 operations, trunc(fl(fl(m / c) * 255)).  Round 5's block reduction
+    computes floor(255 m / c) in integers instead (csrc/seg_kernels.h wg_rescale_255: a float32 estimate pushed down by 1e-4, one exact correction).
+    (1) the two are the same number: every exact quotient K / 255 (and K / 65535) survives the two roundings, and random / structured pairs agree;
+    (2) the device's arithmetic, restated in numpy float32 with the reciprocal off by one ulp EITHER way (v_rcp_f32's accuracy), returns that floor."""
+    # (1a) exact quotients: m / c = K / M as a real number => fl(m / c) = fl(K / M): 256 (65536) cases cover every such pair
+    for M in (255, 65535):
+        K = np.arange(M + 1, dtype=np.float64)
+        assert np.array_equal(np.trunc(K / np.float64(M) * np.float64(M)), K)
+    rng = np.random.default_rng(17)
+    # (1b) + (2): random pairs over the whole range the block reduction can meet (c <= 65535 sites x 255), and the structured ones
+    c = np.concatenate([rng.integers(256, 65535 * 255 + 1, 3000000), rng.integers(256, 300000, 3000000), rng.integers(256, 2000, 500000)]).astype(np.int64)
+    m = (rng.random(c.size) * (c + 1)).astype(np.int64).clip(0, c)
+    g = rng.integers(2, 65535, 400000).astype(np.int64)
+    kq = rng.integers(0, 256, g.size).astype(np.int64)
+    c = np.concatenate([c, 255 * g, 255 * g, g[g > 255], g[g > 255], 255 * g])            # exact quotients, m = 0, m = c, one off an exact quotient
+    m = np.concatenate([m, kq * g, kq * g + (kq < 255), np.zeros((g > 255).sum(), dtype=np.int64), g[g > 255], np.maximum(kq * g - 1, 0)])
+    want = np.trunc(m.astype(np.float64) / c.astype(np.float64) * np.float64(255.0)).astype(np.int64)
+    assert np.array_equal(want, 255 * m // c)
+    N = (255 * m).astype(np.uint32)
+    Nf = N.astype(np.float32)
+    cf = c.astype(np.float32)
+    assert np.array_equal(cf.astype(np.int64), c)                                       # c < 2^24: exact in float
+    rc0 = np.float32(1.0) / cf
+    for rcv in (rc0, np.nextafter(rc0, np.float32(0)), np.nextafter(rc0, np.float32(1))):
+        est = (Nf.astype(np.float64) * rcv.astype(np.float64) + np.float64(np.float32(-1.0e-4))).astype(np.float32)   # the fused multiply-add: one rounding
+        q = np.where(est > 0, np.floor(est), 0).astype(np.int64)
+        assert ((q == want) | (q == want - 1)).all()                                    # the biased estimate never overshoots
+        r = N.astype(np.int64) - q * c
+        assert (r >= 0).all()
+        got = q + (r >= c)
+        assert np.array_equal(got, want)

@@ -198,3 +198,35 @@ def test_block_sums_full_size_tiling_property():
         print('k_block_sums: %.3f ms for %d blocks x %d samples' % (sg.last_block_sums_ms(), b.size - 1, N))
     finally:
         sg.close()
+
+
+@pytest.mark.parametrize('general', [0, 1])
+def test_bin_rows_of_exact_quotients(general, monkeypatch):
+    """.bin rows whose rescale 255 m / c is an EXACT integer — every site of a sample (K, 255), so a block of j sites has m = K j, c = 255 j — plus m = 0, m = c
+    and counts one off such quotients: round 5's integer rescale in the streaming kernel (and the float64 one of the general kernel) against numpy's float64
+    trim_to_uint8 restatement, blocks of 2 .. 1000 sites."""
+    monkeypatch.setenv('WGBSSEG_BLOCK_SUMS_GENERAL', str(general))
+    n = 400000
+    ks = [0, 1, 51, 85, 127, 128, 254, 255]
+    data = []
+    for K in ks:
+        d = np.empty((n, 2), dtype=np.uint8)
+        d[:, 0] = K; d[:, 1] = 255
+        data.append(d)
+    rng = np.random.default_rng(23)
+    off = data[3].copy(); off[rng.integers(0, n, 40000), 0] = 86          # one count off the exact quotient here and there
+    few = data[1].copy(); few[rng.integers(0, n, 40000), 0] = 0
+    data += [off, few, synth.synth_betas(5, 0, 0, n)]
+    ln = np.where(rng.random(60000) < 0.7, rng.integers(2, 30, 60000), rng.integers(30, 1000, 60000))
+    edges = np.concatenate([[0], np.cumsum(ln)])
+    edges = edges[edges <= n]
+    s0, e0 = edges[:-1], edges[1:]
+    with _lib.Segmenter(0) as sg:
+        sg.set_betas(data)
+        b8 = sg.block_sums(s0, e0, mode=1)
+        for s in range(len(data)):
+            want = OB.trim(OB.block_sums(data[s], s0, e0), False)
+            assert (b8[s] == want).all(), (general, s, int(np.flatnonzero((b8[s] != want).any(1))[0]))
+        for i, K in enumerate(ks):                                      # the exact quotients themselves: (K, 255) for every saturated block
+            sat = (e0 - s0) * 255 > 255
+            assert (b8[i][sat, 0] == K).all() and (b8[i][sat, 1] == 255).all()

@@ -2271,15 +2271,22 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums(const uint8_t* __restri
 #define WG_BSR_RUN 8
 #define WG_BSR_PK (WG_BSR_TILE + 16)          // packed in-lane prefixes of a tile (+ the entry behind its last site)
 
-// trunc(fl(fl(m / c) * 255)) — utils_wgbs.py:277-290 — with the reference's own float64 operations (division, product,
-// truncation; no contraction): 15 fp64 instructions, straight-line.  (Until the end of round 2 the common case — 255 m / c not an
-// integer, where the two roundings cannot carry the product across one — was taken in integers from a float estimate, 12
-// instructions, and only integer quotients went through float64.  But m = 0 and m = c ARE integer quotients, and with a few per
-// cent of such blocks per lane nearly every wavefront took both paths: 40 instructions per block and sample, a quarter of the
-// kernel's static instruction count — tools/micro/count_block_sums.py: 315 -> 231 VALU per tile and wavefront in mode 1.)
+// trunc(fl(fl(m / c) * 255)) — utils_wgbs.py:277-290 trim_to_uint8, float64 division, product, truncation — for integers 0 <= m <= c, 255 < c <= 65535 * 255.
+// Round 5: it IS floor(255 m / c), always, so it is computed in integers (10 VALU instructions, none of them fp64; rounds 2-4: the reference's own three
+// float64 operations, 16 instructions with v_rcp_f64 and the v_div_* family, which nearly every wavefront of the block reduction executes).  Why:
+//   * 255 m / c not an integer: it lies at least 1 / c >= 6e-8 from the nearest integer, the two roundings move the product by less than 255 * 2^-52 = 6e-14;
+//   * 255 m / c = K an integer: then m / c = K / 255 as a real number, so fl(m / c) = fl(K / 255) whatever m and c are, and trunc(fl(fl(K / 255) * 255)) = K for
+//     every K in 0 .. 255 (256 cases: tests/test_blocks_cpu.py::test_trim_rescale_is_an_integer_division walks them, and 65535 likewise).
+// The division: q = floor of a float estimate of N / c, N = 255 m < 2^32, pushed DOWN by 1e-4 — Nf and the product carry 2^-24 each, v_rcp_f32 one ulp
+// (2^-23): the estimate is within 6.1e-5 of N / c <= 255, so the biased one lies in (N / c - 1.7e-4, N / c) and its floor is K or K - 1 (0 when negative:
+// v_cvt_u32_f32 clamps) — then one exact correction from the remainder.  c < 2^24 is exact in float; q * c <= N needs no wider type.
 __device__ __forceinline__ uint32_t wg_rescale_255(uint32_t m, uint32_t c)
 {
-    return (uint32_t)((double)m / (double)c * 255.0);
+    const uint32_t N = __umul24(m, 255u);            // m < 2^24: the low 32 bits of the 48-bit product are the product
+    const float est = __builtin_fmaf((float)N, __builtin_amdgcn_rcpf((float)c), -1.0e-4f);
+    uint32_t q = (uint32_t)est;                                           // (negative -> 0)
+    const uint32_t r = N - __umul24(q, c);
+    return q + (r >= c ? 1u : 0u);
 }
 
 // k_block_sums_direct: the blocks the streaming kernel leaves out — those that begin before their run or more than a tile
@@ -2319,9 +2326,13 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_direct(const uint8_t* _
     }
 }
 
+#ifndef WG_BSR_PRE
 #define WG_BSR_PRE 3                           // rounds of 64 block descriptors fetched a tile ahead (a tile of a segmentation ends ~100 blocks)
+#endif
 #define WG_BSR_RING (2 * WG_BSR_TILE)
+#ifndef WG_BSR_AHEAD
 #define WG_BSR_AHEAD 4                         // tiles of sample bytes in flight per wavefront (2 KB each)
+#endif
 
 // LDS layout of the prefix ring: ring position q = (half, site x of the tile); the four sites 4 g .. 4 g + 3 of lane L (x = 16 L +
 // 4 g + k) sit at dwords (g * 64 + L) * 4 + k of their half: consecutive lanes write consecutive 16-byte slots (no bank
