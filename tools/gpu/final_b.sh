@@ -5,6 +5,7 @@ set -u
 REPO=$PWD
 O=$REPO/gpurun_out/final
 mkdir -p $O
+timeout 300 python -m pytest tests/test_gpu_integration_stub.py -q > $O/tests_stub.log 2>&1; echo "integration stub (as printed in INTEGRATION.md): rc $? ($(tail -1 $O/tests_stub.log))"
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29579 bench.py --gpus 2 --steps 5 --warmup 1 > $O/torchrun2.log 2>&1; echo "torchrun x2: rc $?"
 WGBSSEG_BENCH_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29580 bench.py --gpus 1 --steps 5 --warmup 1 --matrix 0 > $O/torchrun1_rccl.log 2>&1; echo "torchrun x1 (RCCL group): rc $?"
 timeout 600 python bench.py --gpus 8 --steps 5 --warmup 1 > $O/group8_on_one_gpu.log 2>&1; echo "group of 8 shares on one GPU: rc $? $(tail -1 $O/group8_on_one_gpu.log | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('n_gpus', d['n_gpus'], 'shares', d['config']['shares'], d['ms_per_step'], d['config']['share_work_max_over_mean'], (d.get('matrix') or {}).get('rows'))")"
