@@ -29,7 +29,11 @@ The JSON line carries
   matrix          the same step at the other sample counts of the metric (x8, x200, x512), a few steps each.
   cpu_baseline    the reference's own `segmentor` (oracle/_ref) on this host: 1 core, one process per physical core, one per
                   logical CPU; bounded sample of the same workload.
-  end_to_end      the CLI on page-cached files (PCIe and file I/O included; never `value`).
+  end_to_end      the CLI on page-cached files (PCIe and file I/O included; never `value`); the x200 row of `matrix` carries one too.
+  extras          (round 5) the SURVEY 8(f) rows that had no figure: `convert` (k_convert), `pat2beta` (kernel alone, from host memory, through the CLI on
+                  a BGZF file, the host's inflate alone, and the reference's stdin2beta on this host), find_markers' statistics (k_marker_stats).
+N > 1 lines say what ran: `n_gpus` = DISTINCT physical devices among the shares / ranks (device_report), with `gpus_requested`, `shares`,
+`distinct_devices`, `devices_visible`, `oversubscribed` in `config` — eight shares wrapped onto one GPU are `n_gpus: 1, shares: 8`.
 """
 import argparse
 import ctypes as C
