@@ -39,3 +39,25 @@ def test_ranks_sharing_devices_are_counted_once():
 def test_one_gpu_line():
     r = bench.device_report('one', 1, [('box', 0)])
     assert r == {'n_gpus': 1, 'gpus_requested': 1, 'shares': 1, 'distinct_devices': 1, 'oversubscribed': False, 'sharding': 'one GPU'}
+
+
+def test_synthetic_pat_text_and_bgzf_writer(tmp_path):
+    """bench.py's `extras` feed pat2beta a text built with numpy and a BGZF file written by hand: every line must be a pat line the reference's parser accepts
+    (checked against the oracle's restatement of stdin2beta.cpp:59-93), and the file must read back through gzip AND through the block-parallel BGZF reader."""
+    import gzip
+    from oracle import pat2beta_oracle as OP
+    from wgbs_tools_amd import pat2beta
+    n_sites = 50000
+    text, n_chars = bench.synth_pat_text(7, n_sites, 30000)
+    lines = text.decode().split('\n')
+    assert lines[-1] == '' and len(lines) == 30001
+    tok = [l.split('\t') for l in lines[:-1]]
+    assert all(len(t) == 4 and t[0] == 'chr1' and 1 <= int(t[1]) <= n_sites and 1 <= len(t[2]) <= 12 and set(t[2]) <= set('CTH.') and 1 <= int(t[3]) <= 40 for t in tok)
+    assert [int(t[1]) for t in tok] == sorted(int(t[1]) for t in tok) and sum(len(t[2]) for t in tok) == n_chars
+    counts = OP.counts(lines[:-1], 1, n_sites + 1)
+    assert counts is not None and counts[:, 1].sum() > 0 and (counts[:, 0] <= counts[:, 1]).all()
+    gz = str(tmp_path / 'x.pat.gz')
+    bench.write_bgzf(gz, text, level=1)
+    assert gzip.open(gz, 'rb').read() == text
+    assert b''.join(pat2beta.bgzf_pieces(gz)) == text
+    assert b''.join(pat2beta.pat_chunks(gz)) == text
