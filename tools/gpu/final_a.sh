@@ -6,7 +6,11 @@ R=${R:-r05}
 REPO=$PWD
 O=$REPO/gpurun_out/final
 mkdir -p $O
+if [ "${SUITE:-1}" = "1" ]; then
 timeout 1500 python -m pytest tests -q -x -m gpu --durations=12 > $O/gpu_tests_all.log 2>&1; echo "gpu tests: rc $? ($(tail -1 $O/gpu_tests_all.log))"
+else      # (SUITE=0: after a HOST-side change — the device code of the suite's run stands: the tests that go through the changed host code only)
+timeout 600 python -m pytest tests/test_gpu_driver.py tests/test_gpu_fullsize.py tests/test_gpu_parity.py -q -x -m gpu -k "driver or x32 or x200 or test_09 or test_19d or test_08" > $O/gpu_tests_host_subset.log 2>&1; echo "gpu tests (host-side subset): rc $? ($(tail -1 $O/gpu_tests_host_subset.log))"
+fi
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o stats -- python $REPO/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --e2e 0 --extras 0 --matrix 0 > $O/rocprof_bench.log 2>&1; echo "rocprofv3 stats: rc $?"
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/rocprofv3_kernel_stats_28M_x32.csv

@@ -8,22 +8,27 @@ int main()
     std::vector<int64_t> rs, re; int64_t pos = 1;
     for (int i = 0; i < 25; i++) { rs.push_back(pos); pos += sizes[i]; re.push_back(pos); }
     std::vector<int32_t> out(30000000); std::vector<int64_t> off(26); int64_t stats[8]; std::string err;
-    BatchFn fn = [](const std::vector<Sites>& items, BatchResult& res, std::string&) -> int {
+    // a stand-in chunk engine: a border every 16 sites (aligned to absolute multiples of 16, so neighbouring results agree and every junction stitches at once)
+    std::vector<std::vector<int32_t>> flats; std::vector<std::vector<int64_t>> offs;
+    BatchFn fn = [&](const std::vector<Sites>& items, BatchResult& res, std::string&) -> int {
         size_t total = 0;
         for (auto& it : items) total += (size_t)((it.second - it.first) / 16 + 3);
-        res.owned.reset(new int32_t[total]); res.flat = res.owned.get(); res.off.assign(items.size() + 1, 0);
+        flats.emplace_back(total); offs.emplace_back(items.size() + 1);
+        std::vector<int32_t>& flat = flats.back(); std::vector<int64_t>& off = offs.back();
         int64_t w = 0;
         for (size_t i = 0; i < items.size(); i++) {
-            res.off[i] = w;
+            off[i] = w;
             const int64_t s = items[i].first, e = items[i].second;
-            res.flat[w++] = 0;
-            for (int64_t x = (s / 16 + 1) * 16; x < e; x += 16) res.flat[w++] = (int32_t)(x - s);
-            res.flat[w++] = (int32_t)(e - s);
+            flat[w++] = 0;
+            for (int64_t x = (s / 16 + 1) * 16; x < e; x += 16) flat[w++] = (int32_t)(x - s);
+            flat[w++] = (int32_t)(e - s);
         }
-        res.off[items.size()] = w;
+        off[items.size()] = w;
+        res.set_csr(flat.data(), off.data(), items.size());
         return 0;
     };
     for (int rep = 0; rep < 5; rep++) {
+        flats.clear(); offs.clear();
         auto t0 = std::chrono::steady_clock::now();
         int rc = segment_regions(rs.data(), re.data(), 25, 60000, fn, out.data(), (int64_t)out.size(), off.data(), stats, err);
         auto t1 = std::chrono::steady_clock::now();

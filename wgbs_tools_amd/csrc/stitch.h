@@ -312,6 +312,55 @@ struct BatchResult {
 typedef std::function<int(const std::vector<Sites>&, BatchResult&, std::string&)> BatchFn;
 enum { E_ARG = -1, E_CAPACITY = -6 };
 
+// Sites -> V, open addressing (round 5: two std::map<Sites, .> of ~2,000 patches each cost 0.2 ms of every whole-genome call in node allocations, on the host,
+// before the first kernel could start).  Grows by doubling; nothing is ever erased; find() results are invalidated by an insertion, so readers that run beside each
+// other (the rehearsal's pool threads) only ever find().
+template <class V>
+class SiteTable {
+    struct Slot { Sites k; V v; };
+    std::vector<Slot> t_;
+    size_t n_ = 0;
+    static constexpr int64_t EMPTY = INT64_MIN;
+    static size_t hash(const Sites& s)
+    {
+        uint64_t x = (uint64_t)s.first * 0x9E3779B97F4A7C15ull ^ ((uint64_t)s.second + 0x632BE59BD9B4E019ull) * 0xC2B2AE3D27D4EB4Full;
+        return (size_t)(x ^ (x >> 31));
+    }
+    size_t probe(const Sites& k) const
+    {
+        const size_t m = t_.size() - 1;
+        size_t i = hash(k) & m;
+        while (t_[i].k.first != EMPTY && t_[i].k != k) i = (i + 1) & m;
+        return i;
+    }
+    void grow()
+    {
+        std::vector<Slot> old;
+        old.swap(t_);
+        t_.assign(old.size() * 2, Slot{Sites(EMPTY, 0), V()});
+        for (Slot& s : old) if (s.k.first != EMPTY) t_[probe(s.k)] = s;
+    }
+public:
+    explicit SiteTable(size_t expect = 8)
+    {
+        size_t c = 16;
+        while (c < 2 * expect) c <<= 1;
+        t_.assign(c, Slot{Sites(EMPTY, 0), V()});
+    }
+    const V* find(const Sites& k) const { const Slot& s = t_[probe(k)]; return s.k.first == EMPTY ? nullptr : &s.v; }
+    bool count(const Sites& k) const { return find(k) != nullptr; }
+    V& operator[](const Sites& k)                               // (inserts a default value when the key is new)
+    {
+        size_t i = probe(k);
+        if (t_[i].k.first == EMPTY) {
+            if (2 * (n_ + 1) > t_.size()) { grow(); i = probe(k); }
+            t_[i].k = k;
+            n_++;
+        }
+        return t_[i].v;
+    }
+};
+
 // The items of the FIRST batch of segment_regions — every chunk of the grid (segment.py:124-135), then every junction's
 // first-attempt patch and (speculate) its three possible second attempts, without repeats — a pure function of the regions and
 // the chunk size: a multi-process run lets every rank work out the same list and compute the items it holds.
@@ -337,7 +386,7 @@ inline int first_batch(const int64_t* region_start, const int64_t* region_end, i
     }
     fb.region_first_chunk[(size_t)n_regions] = (int64_t)fb.items.size();
     fb.n_chunks = (int64_t)fb.items.size();
-    std::map<Sites, char> seen;
+    SiteTable<char> seen(fb.patches.size());
     for (auto& p : fb.patches) if (!seen.count(p)) { seen[p] = 1; fb.items.push_back(p); }
     return 0;
 }
@@ -371,7 +420,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     std::vector<Junction>& junctions = fb.junctions;
     const int64_t n_chunks = fb.n_chunks;
     struct Patch { const int32_t* p; int64_t n; };             // into a BatchResult kept alive in `keep`
-    std::map<Sites, Patch> cache;
+    SiteTable<Patch> cache(2 * (items.size() - (size_t)n_chunks) + 64);
     for (size_t i = (size_t)n_chunks; i < items.size(); i++) cache[items[i]] = Patch{nullptr, 0};
     int64_t n_batches = 0, n_patch_dp = 0;
     std::vector<std::unique_ptr<BatchResult>> keep;
@@ -416,8 +465,8 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                 while (!t.done) {
                     Sites w;
                     if (!t.want(w, e2) || t.p1 > llen || t.p2 > rlen) break;       // the tree will deal with it
-                    auto it = cache.find(w);
-                    if (it == cache.end() || it->second.p == nullptr) {
+                    const Patch* it = cache.find(w);
+                    if (it == nullptr || it->p == nullptr) {
                         out.want.push_back(w);
                         const int64_t j = t.b1.back();
                         const int64_t q1 = increase_patch(t.p1, t.n1), q2 = increase_patch(t.p2, t.n2);
@@ -427,7 +476,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                         out.still = true;
                         break;
                     }
-                    t.feed(it->second.p, it->second.n, w.first);
+                    t.feed(it->p, it->n, w.first);
                 }
             });
             mark("  rehearsal: junctions against the cache");
@@ -477,9 +526,9 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
                 while (!st1.done) {
                     Sites w;
                     if (!st1.want(w, e2)) { ok = false; break; }
-                    auto it = cache.find(w);
-                    if (it == cache.end() || it->second.p == nullptr) { ok = false; break; }
-                    st1.feed(it->second.p, it->second.n, w.first);
+                    const Patch* it = cache.find(w);
+                    if (it == nullptr || it->p == nullptr) { ok = false; break; }
+                    st1.feed(it->p, it->n, w.first);
                 }
                 if (ok) nxt.push_back(std::move(st1.result));
             }
