@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
+#include <thread>
 #include <vector>
 #include <fcntl.h>
 #include <unistd.h>
@@ -83,6 +85,27 @@ int main(int argc, char** argv)
         run_world(5, 30000, 3000, 40, false, s1, e1);                        // the same without speculation
         run_world(1, 9000, 700, 200, true, s1, e1);                          // one region, patches that grow past a chunk
         run_world(3, 500, 60000, 0, true, s, e);                             // single-chunk regions (s, e: the blocks written below)
+    }
+    {   // the stitcher's open-addressing table (round 5) against std::map: inserts that force it to grow, updates, hits and misses, then concurrent readers
+        wgstitch::SiteTable<int64_t> tab(4);
+        std::map<wgstitch::Sites, int64_t> ref;
+        uint64_t x = 12345;
+        long bad = 0;
+        for (int i = 0; i < 60000; i++) {
+            x = mix(x + (uint64_t)i);
+            const wgstitch::Sites k((int64_t)(x % 5000) + 1, (int64_t)(x % 5000) + 1 + (int64_t)((x >> 20) % 300));
+            if ((x >> 40) % 3 == 0) { tab[k] = (int64_t)i; ref[k] = (int64_t)i; }
+            else {
+                const int64_t* f = tab.find(k);
+                auto it = ref.find(k);
+                bad += (f == nullptr) != (it == ref.end()) || (f && *f != it->second) || tab.count(k) != (ref.count(k) != 0);
+            }
+        }
+        std::vector<std::thread> th;
+        std::vector<long> miss((size_t)4, 0);
+        for (int t = 0; t < 4; t++) th.emplace_back([&, t] { for (auto& kv : ref) { const int64_t* f = tab.find(kv.first); miss[(size_t)t] += !f || *f != kv.second; } });
+        for (auto& t : th) t.join();
+        printf("sitetable: %zu keys, mismatches %ld, concurrent misses %ld\n", ref.size(), bad, miss[0] + miss[1] + miss[2] + miss[3]);
     }
     // BED rows of the last world's blocks on a toy genome of 3 chromosomes
     const int64_t n_sites = 2000;

@@ -38,6 +38,7 @@ def test_stitching_and_bed_rows_under_sanitizers(tmp_path):
             outs[(name, threads)] = (text, open(bed, 'rb').read())
     ref = outs[('plain', '1')]
     assert 'checksum' in ref[0] and ref[0].count('world') == 15 and 'rc 0' in ref[0] and len(ref[1]) > 5000
+    assert 'sitetable: ' in ref[0] and 'mismatches 0, concurrent misses 0' in ref[0]
     assert 'parse_blocks: rc 0 rows 40000 na 413' in ref[0] and 'parse_blocks on a float field: rc 1' in ref[0]
     assert ref[0].count('write_table pass') == 2 and 'DIFFERS' not in ref[0] and 'write_bedgraph: rc 0' in ref[0]
     assert 'parse_bed: rc 0 rows 50000 width 6 unknown 237' in ref[0] and 'parse_bed on a float column: rc 1' in ref[0] and 'write_annotated_bed: rc 0' in ref[0]
