@@ -5,8 +5,9 @@
         and the STITCHED border lists of four chromosomes against the reference's pairwise tree (segment.py:157-165,
         199-252; restated in tests/reftree.py and pinned there by vectors captured from the reference's
         driver) walked over the same chunk / patch DPs.
-  x200  the same genome x 200 betas (7 LDS sample groups in the scoring kernel): 64 sampled chunks against the
-        reference binary, the stitched result of three chromosomes against the tree, genome-wide properties.
+  x200  the same genome x 200 betas (7 LDS sample groups in the scoring kernel), north_star's named target, IN FULL: all 483
+        chunks and every junction patch against the reference binary, all 25 stitched chromosomes against the tree
+        (tests/fullref.py; hosts with fewer than 64 CPUs: 64 chunks, one chromosome's patches, three trees).
   x512  one piece of configs[4] (max_cpg 5000, max_bp 1e6, chunk 50000, 512 betas): eight 50,000-site chunks on the
         GPU; one FULL chunk against the many-thread oracle restatement (1.3e11 evaluations), four reduced chunks
         against the reference binary, stitched result against the tree.
@@ -14,17 +15,15 @@
 Bit-exact everywhere.  The genome-wide properties: borders strictly ascending, first/last = the chromosome's ends,
 every block <= max_cpg sites and <= max_bp base pairs (segmentor.cpp:111-117).
 """
+import json
 import os
 import os.path as op
-import shutil
-import subprocess
-import tempfile
-import threading
 
 import ctypes as C
 import numpy as np
 import pytest
 
+import fullref
 from oracle import oracle
 from wgbs_tools_amd import _lib, synth, segment as S
 
@@ -44,68 +43,10 @@ def _device_genome(n_sites, n_samples):
     return buf, pitch
 
 
-def _ref_on_ranges(buf, loci, ranges, pcount, max_cpg, max_bp, procs=None):
-    """The reference binary on 0-based site ranges [(start0, n), ...] of the device-resident betas: every range's
-    bytes are written as per-sample .beta files (what `segmentor` reads, segmentor.cpp:164-177) and one single-threaded
-    process per range runs with the loci on stdin (segment.py:48-55 minus tabix).  -> {(start0, n): int64 borders}"""
-    assert oracle.have_ref(), 'oracle/_ref/segmentor did not travel with the snapshot'
-    procs = procs or (os.cpu_count() or 8)
-    out = {}
-    td = tempfile.mkdtemp(dir='/dev/shm' if op.isdir('/dev/shm') else None)
-    try:
-        for g0 in range(0, len(ranges), procs):
-            jobs = []
-            for st, n in ranges[g0:g0 + procs]:
-                host = buf[:, 2 * st:2 * (st + n)].cpu().numpy()
-                d = op.join(td, 'r%d_%d' % (st, n))
-                os.mkdir(d)
-                paths = []
-                for s in range(host.shape[0]):
-                    p = op.join(d, 's%04d.beta' % s)
-                    host[s].tofile(p)
-                    paths.append(p)
-                cmd = [oracle.REF_BIN] + paths + ['-s', '0', '-n', str(n), '-max_cpg', str(max_cpg), '-ps', repr(float(pcount)),
-                                                 '-max_bp', str(max_bp)]
-                stdin = ('\n'.join(map(str, loci[st:st + n].tolist())) + '\n').encode()
-                jobs.append(((st, n), cmd, stdin, d))
-
-            def run(key, cmd, stdin, d):
-                r = subprocess.run(cmd, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-                assert r.returncode == 0, r.stderr.decode()[-500:]
-                out[key] = np.array(r.stdout.split(), dtype=np.int64)
-                shutil.rmtree(d, ignore_errors=True)
-            th = [threading.Thread(target=run, args=j) for j in jobs]
-            [t.start() for t in th]
-            [t.join() for t in th]
-    finally:
-        shutil.rmtree(td, ignore_errors=True)
-    return out
-
-
-class _Recorder:
-    """chunk engine over the HIP path that remembers every range it was asked for (1-based half-open)."""
-
-    def __init__(self, seg, pcount, max_cpg, max_bp):
-        self.seg, self.p = seg, (pcount, max_cpg, max_bp)
-        self.asked = {}
-
-    def segment_many(self, sites_list, params):
-        st0 = [a - 1 for a, _ in sites_list]
-        ln = [b - a for a, b in sites_list]
-        res = self.seg.segment_chunks(st0, ln, *self.p)
-        outs = []
-        for (a, b), r in zip(sites_list, res):
-            r = r.astype(np.int64) + a
-            self.asked[(a, b)] = r
-            outs.append(r)
-        return outs
-
-
-def _tree(chunks, eng):
-    """segment.py:157-165 over stitch_2_dfs (segment.py:199-232), junction by junction (tests/reftree.py: the suite's restatement,
-    pinned by vectors from the reference's own Python)."""
-    import reftree
-    return reftree.tree(chunks, lambda sites: eng.segment_many(sites, {}))
+# the reference runner, the recording chunk engine, the reference's grid and tree: tests/fullref.py
+_ref_on_ranges = fullref.ref_on_ranges
+_Recorder = fullref.Recorder
+_tree = fullref.tree
 
 
 def _check_properties(res, regions, loci, max_cpg, max_bp):
@@ -120,9 +61,7 @@ def _check_properties(res, regions, loci, max_cpg, max_bp):
         assert bp.max() <= max_bp, 'a block spans more than max_bp'
 
 
-def _grid(a, e, chunk):
-    bords = list(range(a, e, chunk)) + [e]
-    return list(zip(bords[:-1], bords[1:]))
+_grid = fullref.grid
 
 
 def _run_whole(seg, regions, chunk, pcount, max_cpg, max_bp):
@@ -203,8 +142,21 @@ def test_hg19_x32_whole_genome(hg19):
     del buf
 
 
+def _x200_mode():
+    """'full': every chunk, every junction patch, every chromosome against the reference binary (north_star's named target; two
+    minutes on the GPU box's 256 CPUs); 'sample': 64 chunks, the patches of one chromosome, three trees — what a host with few
+    cores can afford.  WGBSSEG_X200_CHECK = full | sample overrides the choice by core count."""
+    mode = os.environ.get('WGBSSEG_X200_CHECK', '')
+    if mode not in ('full', 'sample'):
+        mode = 'full' if (os.cpu_count() or 1) >= 64 else 'sample'
+    return mode
+
+
 def test_hg19_x200_atlas_scale(hg19):
-    """BASELINE.json configs[3] (one GPU's view: the whole genome fits a single MI355X)."""
+    """BASELINE.json configs[3] (one GPU's view: the whole genome fits a single MI355X) = north_star's "bit-exact block boundaries
+    at 28M CpGs x 200 betas": ALL 483 chunks of the reference's grid and EVERY junction patch its 25 pairwise trees ask for through
+    the reference binary (segmentor.cpp:60-159), ALL 25 stitched chromosomes against the reference's tree (segment.py:157-165,
+    199-252) over those DPs.  The counts go to gpurun_out/x200_full_vs_reference.json."""
     import torch
     N, chunk, pc, mc, mb = 200, 60000, 15.0, 1000, 2000
     torch.cuda.empty_cache()
@@ -216,19 +168,32 @@ def test_hg19_x200_atlas_scale(hg19):
         res, stats = _run_whole(seg, regions, chunk, pc, mc, mb)
         assert stats['chunks'] == 483
         _check_properties(res, regions, loci, mc, mb)
-        pick = _spread_chunks(sizes, chunk, 64)
-        ref = _ref_on_ranges(buf, loci, [(st, chunk) for st in pick], pc, mc, mb)
-        got = seg.segment_chunks(pick, [chunk] * len(pick), pc, mc, mb)
-        for st, g in zip(pick, got):
-            assert np.array_equal(g.astype(np.int64), ref[(st, chunk)]), 'chunk at site %d differs from the reference binary' % st
-        recs = _stitched_vs_tree(seg, res, regions, [1, 21, 24], chunk, pc, mc, mb)
-        # the patches of chr22 against the reference binary
-        eng, _ = recs[1]
-        grid = set(_grid(*regions[21], chunk))
-        patches = [(a, b) for (a, b) in eng.asked if (a, b) not in grid]
-        refp = _ref_on_ranges(buf, loci, [(a - 1, b - a) for a, b in patches], pc, mc, mb)
-        for a, b in patches:
-            assert np.array_equal(eng.asked[(a, b)] - a, refp[(a - 1, b - a)])
+        mode = _x200_mode()
+        if mode == 'full':
+            out = fullref.whole_genome_vs_reference(seg, buf, loci, regions, chunk, pc, mc, mb, res, log=print)
+            out.update(mode=mode, sites=SITES, samples=N, blocks=int(sum(len(r) - 1 for r in res)))
+            os.makedirs('gpurun_out', exist_ok=True)
+            with open(op.join('gpurun_out', 'x200_full_vs_reference.json'), 'w') as f:
+                json.dump(out, f, indent=1)
+            print('x200 whole genome vs the reference binary: %s' % json.dumps(out))
+            assert out['differences'] == 0, out['different']
+            assert (out['chunks_identical'], out['chunks']) == (483, 483)
+            assert (out['chromosomes_identical'], out['chromosomes']) == (25, 25)
+            assert out['patches_identical'] == out['patches'] >= 483 - 25          # one junction between neighbouring chunks, at least
+        else:
+            pick = _spread_chunks(sizes, chunk, 64)
+            ref = _ref_on_ranges(buf, loci, [(st, chunk) for st in pick], pc, mc, mb)
+            got = seg.segment_chunks(pick, [chunk] * len(pick), pc, mc, mb)
+            for st, g in zip(pick, got):
+                assert np.array_equal(g.astype(np.int64), ref[(st, chunk)]), 'chunk at site %d differs from the reference binary' % st
+            recs = _stitched_vs_tree(seg, res, regions, [1, 21, 24], chunk, pc, mc, mb)
+            # the patches of chr22 against the reference binary
+            eng, _ = recs[1]
+            grid = set(_grid(*regions[21], chunk))
+            patches = [(a, b) for (a, b) in eng.asked if (a, b) not in grid]
+            refp = _ref_on_ranges(buf, loci, [(a - 1, b - a) for a, b in patches], pc, mc, mb)
+            for a, b in patches:
+                assert np.array_equal(eng.asked[(a, b)] - a, refp[(a - 1, b - a)])
         # sharded == unsharded: the 8-piece split of the chunk grid (one piece per GPU of a node), every piece on its own
         # context holding only its share of the beta bytes, stitched on the host
         from wgbs_tools_amd import multi

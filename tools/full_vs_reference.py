@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The whole synthetic hg19 genome x N betas against the REFERENCE BINARY (oracle/_ref/segmentor), on the library that is in the tree.
 
-north_star: "bit-exact block boundaries at 28M CpGs x 200 betas".  The suite samples (64 of 483 chunks, 3 of 25 chromosomes: it has to fit
-the driver's window); this tool runs everything once:
+north_star: "bit-exact block boundaries at 28M CpGs x 200 betas".  Round 6: the suite's own x200 test runs this check in full
+(tests/fullref.py::whole_genome_vs_reference, shared with this tool); the tool is for other cohorts, chromosomes and the adversarial world:
 
   1. wgbsseg_segment_regions over the 25 chromosomes (the product call);
   2. per chromosome: every chunk of the reference's grid through wgbsseg_segment_chunks, then the reference's pairwise stitching tree
@@ -45,7 +45,8 @@ def main():
                          'saturated counts (255, 255), (0, 255), (127, 255) and single reads (1, 1) — the shapes the small fuzz worlds hold, at the size of the genome')
     args = ap.parse_args()
 
-    import test_gpu_fullsize as F                      # the suite's helpers: device genome, recorder, reference runner, tree
+    import fullref                                     # the check itself: the same function the suite's x200 test runs
+    import test_gpu_fullsize as F                      # the suite's helpers: device genome, whole-genome call, properties
     from oracle import oracle
     from wgbs_tools_amd import _lib, synth, build as nbuild
     import torch
@@ -114,67 +115,15 @@ def main():
         n_blocks = int(sum(len(r) - 1 for r in res))
         print('[1] whole-genome call: %d chunks, %d blocks, stitch stats %s (%.1f s since start)'
               % (stats['chunks'], n_blocks, {k: int(v) for k, v in stats.items()}, time.time() - t0), flush=True)
-        # 2. the reference's tree over the HIP path's chunk / patch DPs, chromosome by chromosome
-        asked, n_chunks, n_patches, chrom_ok = {}, 0, 0, 0
-        for ri in which:
-            a, e = regions[ri]
-            eng = F._Recorder(seg, pc, mc, mb)
-            grid = F._grid(a, e, chunk)
-            chunks = eng.segment_many(grid, {})
-            want = F._tree(chunks, eng)
-            same = np.array_equal(np.asarray(res[ri], dtype=np.int64), want)
-            chrom_ok += bool(same)
-            if not same:
-                bad += 1
-                print('    DIFFERENT: stitched borders of %s differ from the reference tree' % names[ri], flush=True)
-            gs = set(grid)
-            n_chunks += len(grid)
-            n_patches += sum(1 for k in eng.asked if k not in gs)
-            asked.update(eng.asked)
-        print('[2] stitched chromosomes identical to the reference tree: %d/%d (%d chunks, %d distinct junction patches asked for; %.1f s since start)'
-              % (chrom_ok, len(which), n_chunks, n_patches, time.time() - t0), flush=True)
-        # 3. every one of those ranges through the reference binary (longest first: the chunks fill the cores, the patches the gaps)
-        ranges = sorted(((a - 1, b - a) for (a, b) in asked), key=lambda r: -r[1])
-        procs = args.procs or (os.cpu_count() or 8)
-        # a group of `procs` ranges sits in /dev/shm as .beta files while it runs: keep it under half of what is free there
-        import shutil
-        shm = '/dev/shm' if op.isdir('/dev/shm') else '/tmp'
-        free = shutil.disk_usage(shm).free
-        procs = int(max(1, min(procs, (free // 2) // max(1, 2 * N * chunk))))
-        print('    %s has %.1f GB free: %d reference processes at a time' % (shm, free / 1e9, procs), flush=True)
-        t1 = time.time()
-        ref = {}
-        step = max(procs, 1)
-        for g0 in range(0, len(ranges), step):
-            ref.update(F._ref_on_ranges(buf, loci, ranges[g0:g0 + step], pc, mc, mb, procs=procs))
-            done = min(len(ranges), g0 + step)
-            if done == len(ranges) or (g0 // step) % 4 == 0:
-                print('    reference binary: %d/%d ranges (%.0f s)' % (done, len(ranges), time.time() - t1), flush=True)
-        ch_ok = ch_n = pa_ok = pa_n = 0
-        for (a, b), r in asked.items():
-            same = np.array_equal(r - a, ref[(a - 1, b - a)])
-            if not same:
-                bad += 1
-                print('    DIFFERENT: range [%d, %d) differs from the reference binary' % (a, b), flush=True)
-            asked[(a, b)] = same
-        grid_all = set()
-        for ri in which:
-            grid_all.update(F._grid(*regions[ri], chunk))
-        for k, same in asked.items():
-            if k in grid_all:
-                ch_n += 1
-                ch_ok += bool(same)
-            else:
-                pa_n += 1
-                pa_ok += bool(same)
-        ref_s = time.time() - t1
-        print('[3] against the reference binary: %d/%d chunks identical, %d/%d patches identical (%d processes at a time, %.0f s)'
-              % (ch_ok, ch_n, pa_ok, pa_n, procs, ref_s), flush=True)
-    out = {'csrc_sha': sha, 'sites': sites, 'samples': N, 'chunk': chunk, 'max_cpg': mc, 'max_bp': mb, 'pcount': pc,
-           'chromosomes_identical': chrom_ok, 'chromosomes': len(which), 'chunks_identical': ch_ok, 'chunks': ch_n,
-           'patches_identical': pa_ok, 'patches': pa_n, 'blocks': n_blocks, 'differences': bad,
-           'reference_seconds': ref_s, 'reference_procs': procs, 'host_cpus': os.cpu_count(), 'wall_s': time.time() - t0,
-           'device': torch.cuda.get_device_name(0), 'adversarial': bool(args.adversarial)}
+        # 2. + 3.: the reference's tree over the HIP path's chunk / patch DPs, every range through the reference binary (tests/fullref.py)
+        chk = fullref.whole_genome_vs_reference(seg, buf, loci, regions, chunk, pc, mc, mb, res, which=which, names=names,
+                                                procs=args.procs, log=lambda *a: print(*a, flush=True))
+        for line in chk['different']:
+            print('    DIFFERENT: ' + line, flush=True)
+        bad = chk['differences']
+    out = {'csrc_sha': sha, 'sites': sites, 'samples': N, 'chunk': chunk, 'max_cpg': mc, 'max_bp': mb, 'pcount': pc, 'blocks': n_blocks,
+           'wall_s': time.time() - t0, 'device': torch.cuda.get_device_name(0), 'adversarial': bool(args.adversarial)}
+    out.update(chk)
     print(json.dumps(out), flush=True)
     return 1 if bad else 0
 

@@ -4,8 +4,8 @@
 //   k_scan    per-sample prefix scan of (#meth,#cov) with 128-site carries + the #meth<=#cov validation of
 //             read_beta_file (segmentor.cpp:179-188).  HBM-bound: reads every beta byte once, writes 1/16 of that.
 //   k_window  forward window F_k of every site from the loci (the bp/CpG limits of segmentor.cpp:111-117: the
-//             extensions of a block starting at k that are admissible) and the CSR row offsets of the scored-block
-//             matrix, which is START-major like the reference's own rows (segmentor.cpp:103-138).
+//             extensions of a block starting at k that are admissible); k_window_scan + k_window_cum: the CSR row offsets
+//             of the scored-block matrix, which is START-major like the reference's own rows (segmentor.cpp:103-138).
 //   k_cost    block log-likelihoods (segmentor.cpp:119-137) for every (start k, end i) inside the window, scored
 //             from LDS-staged prefix tiles; samples are visited in file order inside each lane (the double
 //             accumulation order is part of the bit-exactness contract).  fp64-VALU bound.
@@ -34,7 +34,6 @@ static_assert(WG_CARRY_SHIFT >= 4 && WG_CARRY_SHIFT <= 10, "k_scan: a lane vecto
 #define WG_WIN_TILE     1024        // sites per k_window workgroup
 #define WG_PAIR_CAP     4096        // candidate blocks per k_cost tile (bounds the LDS partial-sum array)
 #define WG_TRACE_WIN    32768       // back-pointers staged in LDS by k_trace (64 KiB)
-#define WG_TRACE_SEG    128         // speculative walks per window
 #define WG_NARROW_WMAX  60          // widest window of a narrow scoring tile: TI + 60 + 1 <= 125 entries, + 3 of alignment <= 128 = 32 lanes x 4 sites
 #define WG_MEDIUM_WMAX  252         // widest window of a medium scoring tile (16 starts, every end): block counts <= 255 * 252 < 2^16 still fit the packed
                                     // tile-local prefixes of the narrow tiles (a block's counts are ONE difference of two dwords), no carries of k_scan
@@ -178,13 +177,12 @@ __device__ __noinline__ int wg_first_bad_site(uint4 v0, uint4 v1)      // index 
     return bad;
 }
 
-__global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int want_carry)
+__global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st)
 {
     const int lane = threadIdx.x & 63;
-    // The carries have ONE consumer: the wide scoring tiles (windows > WG_MEDIUM_WMAX sites: deep mode, the densest islands), which
-    // k_window_scan has counted on this stream before this kernel starts.  A job without any (every default-parameter
-    // genome) needs none: this launch leaves at once and k_validate (launched beside it) does the read-only pass.
-    if (want_carry == 0 && __hip_atomic_load(&st->wide_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+    // The carries have ONE consumer: the wide scoring tiles (windows > WG_MEDIUM_WMAX sites: deep mode, the densest islands).  The host
+    // launches this kernel only for a job that has any (it knows from the windows' statistics), or for a caller that asks for the carries;
+    // every other job's scan pass is the read-only k_validate, which starts with the batch.
     const int64_t rowid = (int64_t)blockIdx.x * (WG_BLOCK / 64) + (threadIdx.x >> 6);      // a wave task = one (chunk, sample) row
     const int64_t nrows = (int64_t)J.n_chunks * J.n_samples;
     if (rowid >= nrows) return;                       // whole wave leaves together
@@ -265,7 +263,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_scan(JobView J, JobStatus* st, int
 // genome tile their regions; junction patches lie inside chunks the same call has already checked and add nothing), one
 // wave task = one (piece, sample): 64 lanes x 32 B per iteration, the next iteration in flight, loads clamped to the
 // piece so that no byte outside it is fetched; a packed compare per dword, no sums, no scans, no stores.
-// Leaves at once when the job has wide units (k_scan, launched beside it, then validates while it builds the carries).
+// Round 6: it needs nothing from the windows pass, so a batch launches it first of all, on the scan stream beside k_window (a job that
+// turns out to have wide tiles runs k_scan afterwards, which checks the same bytes again while it builds the carries).
 struct ScanPiece {
     int64_t lo;          // first site (0-based, resident-relative)
     int32_t n;           // sites
@@ -287,7 +286,6 @@ __device__ __forceinline__ uint32_t wg_ok8(const uint4 v, uint32_t ok)
 
 __global__ __launch_bounds__(WG_BLOCK) void k_validate(JobView J, JobStatus* st, const ScanPiece* __restrict__ pieces, int64_t n_pieces)
 {
-    if (__hip_atomic_load(&st->wide_units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const int lane = threadIdx.x & 63;
     const int64_t task = (int64_t)blockIdx.x * (WG_BLOCK / 64) + (threadIdx.x >> 6);
     const int64_t pi = task / J.n_samples;
@@ -324,123 +322,233 @@ __global__ __launch_bounds__(WG_BLOCK) void k_validate(JobView J, JobStatus* st,
 // ------------------------------------------------------------------------------------------------------------
 // k_window: F_k = number of admissible ends of a block starting at site k:
 //   i admissible  <=>  k <= i < len,  i-k < max_cpg  and  loci[i]-loci[k] <= max_bp   (segmentor.cpp:111-117, loci ascending)
-// Four sites per thread (grid: 1024-site tiles, `wtile_off` = exclusive prefix of tiles per chunk); k_window_scan then
-// turns F into the CSR row offsets, one workgroup per chunk.
+// Grid: 1024-site tiles (`wtile_off` = exclusive prefix of tiles per chunk), four sites per thread.  Round 6: the windows pass is
+// three launches — k_window (F, per-unit maxima, the tile's total), k_window_scan (per chunk: exclusive prefix of its tiles'
+// totals: 59 numbers for a 60,000-site chunk) and k_window_cum (per tile: F -> CSR row offsets) — where rounds 1-5 had one
+// workgroup per chunk walk its 60,000 sites in eight dependent steps (0.10 ms of latency in front of every batch).
+//
+// The search.  F_k - 1 = the largest d <= hi - k with loci[k + d] - loci[k] <= max_bp, found bit by bit from the top (d |= step
+// when the probe at d + step is admissible): a fixed number of probes, no data-dependent loop, uint32 differences (ascending
+// loci: a chunk whose loci are not is flagged and takes the plain path, whatever this kernel made of it).  A wavefront none of
+// whose sites reaches 64 sites ahead — every wavefront of a default-parameter genome outside CpG islands — starts at step 32:
+// 1 + 6 probes instead of the 10 a binary search over [k, k + max_cpg) takes.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, const int64_t* __restrict__ wtile_off,
-                                                     const int32_t* __restrict__ wtile_hint, uint32_t max_cpg, uint32_t max_bp, int lds_cap)
+// Staged form: the tile's loci sit in LDS from the site before the tile's first one (the order check of that site) to the last one a
+// search can touch; the LDS area is as long as the farthest PROBE (tile + 2 * top_step entries), so a probe beyond a site's reach needs
+// no branch: it reads whatever is there and the reach test discards it.
+template <bool STAGED>
+__device__ __forceinline__ void wg_window_body(const JobView& J, JobStatus* st, const ChunkDesc& cd, int c, int k0, const uint32_t* __restrict__ sloc, int kb,
+                                               uint32_t max_cpg, uint32_t max_bp, int top_step, int wide_from, uint32_t& tile_total)
 {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int nC = J.n_chunks;
+    const uint32_t* __restrict__ loc = J.loci + cd.start0;
+    int reach[4], d[4];
+    uint32_t lk[4];
+    const uint32_t* at[4];                                       // locus of site k[j] + x: at[j][x]
+    bool disorder = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int k = k0 + j * WG_BLOCK + tid;
+        at[j] = STAGED ? sloc + (k - kb) : loc + k;
+        reach[j] = -1; lk[j] = 0u; d[j] = 0;
+        if (k < cd.len) {
+            lk[j] = at[j][0];
+            if (k > 0 && at[j][-1] > lk[j]) disorder = true;
+            const int64_t far_end = (int64_t)k + max_cpg - 1 < cd.len - 1 ? (int64_t)k + max_cpg - 1 : cd.len - 1;
+            reach[j] = (int)(far_end - k);                       // 0 .. max_cpg - 1
+        }
+    }
+    // does any site of the wavefront reach 64 sites ahead?
+    bool far = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (STAGED) { const uint32_t l64 = at[j][64]; far = far | ((reach[j] >= 64) & (l64 - lk[j] <= max_bp)); }      // (bitwise: the read is unconditional, four of them in flight)
+        else if (reach[j] >= 64) far = far || (at[j][64] - lk[j] <= max_bp);
+    }
+    int step = __any(far) ? top_step : (top_step < 32 ? top_step : 32);
+    for (; step > 0; step >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int cand = d[j] + step;
+            if (STAGED) {
+                const uint32_t lm = at[j][cand];
+                d[j] = ((cand <= reach[j]) & (lm - lk[j] <= max_bp)) ? cand : d[j];      // (bitwise: no branch around the read)
+            } else if (cand <= reach[j]) {
+                if (at[j][cand] - lk[j] <= max_bp) d[j] = cand;
+            }
+        }
+    }
+    uint32_t wmax_t = 0, wsum_t = 0, nwide = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int k = k0 + j * WG_BLOCK + tid;
+        const bool valid = k < cd.len;
+        const uint32_t w = valid ? (uint32_t)(d[j] + 1) : 0u;
+        if (valid) J.W16[cd.site_off + k] = (uint16_t)w;
+        // largest window of each 16-site unit = of each row of 16 lanes (DPP butterflies inside the row)
+        uint32_t um = w;
+        um = max(um, wg_dpp_u32<WG_DPP_QUAD_1032>(um)); um = max(um, wg_dpp_u32<WG_DPP_QUAD_2301>(um));
+        um = max(um, wg_dpp_u32<WG_DPP_ROW_HMIRROR>(um)); um = max(um, wg_dpp_u32<WG_DPP_ROW_MIRROR>(um));
+        const bool unit_head = (lane & 15) == 0 && valid;
+        if (unit_head) J.umax16[cd.unit_off + (k >> 4)] = (uint16_t)um;
+        nwide += (uint32_t)__popcll(__ballot(unit_head && um > (uint32_t)wide_from));      // (wave-uniform)
+        wmax_t = max(wmax_t, w);
+        wsum_t += w;
+    }
+    const uint32_t wmax = wg_wave_max_u32(wmax_t);
+    const uint32_t wsum = wg_wave_incl_scan_dpp_u32(wsum_t);     // lane 63: the wavefront's total
+    const bool any_dis = __any(disorder);
+    if (lane == 0) {
+        // tens of thousands of wavefronts: touch the shared words only when they would change
+        if (wmax > __hip_atomic_load(&st->max_window, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_window, wmax);
+        if (any_dis) atomicMax(&st->loci_disorder, (unsigned int)(c + 1));
+        if (nwide) atomicAdd(&st->wide_units, nwide);
+    }
+    tile_total = wsum;
+}
+
+__global__ __launch_bounds__(WG_BLOCK) void k_window(JobView J, JobStatus* st, const int64_t* __restrict__ wtile_off,
+                                                     const int32_t* __restrict__ wtile_hint, uint32_t max_cpg, uint32_t max_bp, int lds_cap,
+                                                     int top_step, int wide_from, uint32_t* __restrict__ tile_tot, int4* __restrict__ tile_info)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
     const int64_t t = blockIdx.x;
     // chunk of this tile = the last c with wtile_off[c] <= t.  The host hands over the answer for every 256th tile
     // (wtile_hint), so the search runs over the chunks 256 tiles can span: one or two for 60,000-site chunks — a
-    // full binary search would put nine DEPENDENT L2 loads in front of every one of the 110 k tiles of hg19
+    // full binary search would put nine DEPENDENT L2 loads in front of every one of the 27 k tiles of hg19
     int clo = wtile_hint[t >> 8], chi = wtile_hint[(t >> 8) + 1] + 1;
     while (chi - clo > 1) { const int mid = (clo + chi) >> 1; if (wtile_off[mid] <= t) clo = mid; else chi = mid; }
     const int c = clo;
     const ChunkDesc cd = J.chunks[c];
-    const uint32_t* loc = J.loci + cd.start0;
     const int k0 = (int)(t - wtile_off[c]) * WG_WIN_TILE;
-    // the loci the tile's searches can touch, [k0, k0 + tile + max_cpg - 1), staged in LDS when they fit (lds_cap
-    // entries): the dependent probes of a search then cost LDS latency instead of L2 latency; every thread runs the
-    // searches of WG_WIN_TILE / 256 sites side by side, so the tile's fixed latencies are paid once per 1024 sites
-    extern __shared__ uint32_t sloc[];
-    const int64_t want = (int64_t)WG_WIN_TILE + max_cpg - 1;
-    const int span = (int)((int64_t)cd.len - k0 < want ? (int64_t)cd.len - k0 : want);
-    const bool staged = span <= lds_cap;
+    // the loci the tile's searches can touch, [kb, k0 + tile + max_cpg - 1) with kb = the site before the tile, staged in LDS when the
+    // probes fit (lds_cap entries; the host sizes the area to 1 + tile + 2 * top_step + 8): the dependent probes of a search then cost
+    // LDS latency instead of L2 latency.  16-byte loads from the aligned address below the first locus (`shift` entries earlier);
+    // a vector that crosses an end of the loci array is read entry by entry.
+    extern __shared__ __attribute__((aligned(16))) uint32_t sloc[];
+    __shared__ uint32_t wtot[WG_BLOCK / 64];
+    const int kb = k0 > 0 ? k0 - 1 : 0;
+    const int64_t want = (int64_t)(k0 - kb) + WG_WIN_TILE + max_cpg - 1;
+    const int span = (int)((int64_t)cd.len - kb < want ? (int64_t)cd.len - kb : want);
+    const bool staged = lds_cap > 0;
+    uint32_t total = 0;
     if (staged) {
-        for (int x = tid; x < span; x += WG_BLOCK) sloc[x] = loc[k0 + x];
-        __syncthreads();
-    }
-    constexpr int NPT = WG_WIN_TILE / WG_BLOCK;
-    int lo[NPT], hi[NPT];
-    int64_t limit[NPT];
-    bool disorder = false;
-#pragma unroll
-    for (int j = 0; j < NPT; j++) {
-        const int k = k0 + j * WG_BLOCK + tid;
-        lo[j] = k; hi[j] = k - 1; limit[j] = 0;
-        if (k < cd.len) {
-            const int64_t lk = staged ? sloc[k - k0] : loc[k];
-            const int64_t lprev = k > 0 ? ((staged && k > k0) ? sloc[k - 1 - k0] : loc[k - 1]) : lk;
-            if (lprev > lk) disorder = true;
-            limit[j] = lk + (int64_t)max_bp;
-            hi[j] = (int)((int64_t)k + max_cpg - 1 < cd.len - 1 ? (int64_t)k + max_cpg - 1 : cd.len - 1);
-        }
-    }
-    bool more = true;
-    while (more) {                                        // last i in [k, hi] with loc[i] <= limit (loc[k] <= limit always)
-        more = false;
-#pragma unroll
-        for (int j = 0; j < NPT; j++) {
-            if (lo[j] < hi[j]) {
-                const int mid = (lo[j] + hi[j] + 1) >> 1;
-                const int64_t lm = staged ? sloc[mid - k0] : loc[mid];
-                if (lm <= limit[j]) lo[j] = mid; else hi[j] = mid - 1;
-                more = more || lo[j] < hi[j];
+        const int64_t g0 = cd.start0 + kb;                      // absolute index of the first staged locus
+        const int shift = (int)((reinterpret_cast<uintptr_t>(J.loci + g0) >> 2) & 3);      // entries between the 16-byte boundary below it and the locus
+        const int64_t a0 = g0 - shift;
+        const int nv = (shift + span + 3) >> 2;
+        for (int x = tid; x < nv; x += WG_BLOCK) {
+            const int64_t a = a0 + 4 * (int64_t)x;
+            uint4 v;
+            if (a >= 0 && a + 4 <= J.n_total) v = *reinterpret_cast<const uint4*>(J.loci + a);
+            else {
+                v.x = a >= 0 ? J.loci[a] : 0u;
+                v.y = (a + 1 >= 0 && a + 1 < J.n_total) ? J.loci[a + 1] : 0u;
+                v.z = (a + 2 >= 0 && a + 2 < J.n_total) ? J.loci[a + 2] : 0u;
+                v.w = (a + 3 >= 0 && a + 3 < J.n_total) ? J.loci[a + 3] : 0u;
             }
+            *reinterpret_cast<uint4*>(sloc + 4 * x) = v;
         }
+        __syncthreads();
+        wg_window_body<true>(J, st, cd, c, k0, sloc + shift, kb, max_cpg, max_bp, top_step, wide_from, total);
+    } else {
+        wg_window_body<false>(J, st, cd, c, k0, nullptr, kb, max_cpg, max_bp, top_step, wide_from, total);
     }
-    uint32_t wmax_t = 0;
+    if (lane == 63) wtot[tid >> 6] = total;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
 #pragma unroll
-    for (int j = 0; j < NPT; j++) {
-        const int k = k0 + j * WG_BLOCK + tid;
-        uint32_t w = 0;
-        if (k < cd.len) {
-            w = (uint32_t)(lo[j] - k + 1);
-            J.W16[cd.site_off + k] = (uint16_t)w;
-        }
-        uint32_t um = w;                                  // largest window of each 16-site unit (16 consecutive lanes)
-        um = max(um, (uint32_t)__shfl_xor((int)um, 1)); um = max(um, (uint32_t)__shfl_xor((int)um, 2));
-        um = max(um, (uint32_t)__shfl_xor((int)um, 4)); um = max(um, (uint32_t)__shfl_xor((int)um, 8));
-        if ((lane & 15) == 0 && k < cd.len) J.umax16[cd.unit_off + (k >> 4)] = (uint16_t)um;
-        wmax_t = max(wmax_t, w);
-    }
-    const uint32_t wmax = wg_wave_max_u32(wmax_t);
-    const bool any_dis = __any(disorder);
-    if (lane == 0) {
-        // hundreds of thousands of wavefronts: touch the shared word only when it would change
-        if (wmax > __hip_atomic_load(&st->max_window, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&st->max_window, wmax);
-        if (any_dis) atomicMax(&st->loci_disorder, (unsigned int)(c + 1));
+        for (int q = 0; q < WG_BLOCK / 64; q++) tot += wtot[q];
+        tile_tot[t] = tot;                                       // <= 1024 * 65,535
+        // what k_window_cum needs of this tile, in one 16-byte record: where its sites sit in the job-site arrays, how many there are
+        const int64_t at = cd.site_off + k0;
+        const int nv = cd.len - k0 < WG_WIN_TILE ? cd.len - k0 : WG_WIN_TILE;
+        tile_info[t] = make_int4((int)(uint32_t)at, (int)(at >> 32), nv, c);
     }
 }
 
-#define WG_WSCAN_BLOCK 1024      // one workgroup per chunk: 16 wavefronts x 8 sites per thread = 8192 sites per step (a 60,000-site chunk: 8 steps)
-__global__ __launch_bounds__(WG_WSCAN_BLOCK) void k_window_scan(JobView J, JobStatus* st, int wide_from)      // wide_from: widest window that is NOT scored in wide tiles
+// k_window_scan: one workgroup per chunk turns its tiles' totals into their exclusive prefix (chunk-relative, the row offset of
+// the tile's first site), and the chunk's total into chunk_pairs / the job's statistics.
+__global__ __launch_bounds__(WG_BLOCK) void k_window_scan(JobView J, JobStatus* st, const int64_t* __restrict__ wtile_off,
+                                                          const uint32_t* __restrict__ tile_tot, uint32_t* __restrict__ tile_base)
 {
-    __shared__ uint32_t wsum[WG_WSCAN_BLOCK / 64];
+    __shared__ uint64_t ws[WG_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = blockIdx.x;
-    const ChunkDesc cd = J.chunks[c];
-    const uint16_t* W = J.W16 + cd.site_off;
-    uint32_t* C = J.cum32 + cd.site_off;
+    const int64_t t0 = wtile_off[c], t1 = wtile_off[c + 1];
     uint64_t run = 0;
-    for (int base = 0; base < cd.len; base += WG_WSCAN_BLOCK * 8) {   // 8 consecutive sites per thread
-        const int k0 = base + tid * 8;
-        uint32_t w[8], tot = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { w[j] = (k0 + j < cd.len) ? (uint32_t)W[k0 + j] : 0u; tot += w[j]; }
-        const uint32_t incl = wg_wave_incl_scan_dpp_u32(tot);
-        if (lane == 63) wsum[wv] = incl;
+    for (int64_t base = t0; base < t1; base += WG_BLOCK) {
+        const int64_t t = base + tid;
+        const uint64_t v = t < t1 ? (uint64_t)tile_tot[t] : 0;
+        const uint64_t incl = wg_wave_incl_scan_u64(v, lane);
+        if (lane == 63) ws[wv] = incl;
         __syncthreads();
-        uint32_t woff = 0, btot = 0;
+        uint64_t o = 0, tot = 0;
 #pragma unroll
-        for (int q = 0; q < WG_WSCAN_BLOCK / 64; q++) { if (q < wv) woff += wsum[q]; btot += wsum[q]; }
+        for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) o += ws[q]; tot += ws[q]; }
         __syncthreads();
-        uint32_t e = (uint32_t)(run + woff + (incl - tot));
-#pragma unroll
-        for (int j = 0; j < 8; j++) { if (k0 + j < cd.len) C[k0 + j] = e; e += w[j]; }
-        run += btot;
+        if (t < t1) tile_base[t] = (uint32_t)(run + o + incl - v);
+        run += tot;
     }
-    uint32_t nwide = 0;
-    for (int u = tid; u < (cd.len + 15) >> 4; u += WG_WSCAN_BLOCK) nwide += J.umax16[cd.unit_off + u] > (uint32_t)wide_from ? 1u : 0u;
-    for (int o = 32; o > 0; o >>= 1) nwide += (uint32_t)__shfl_down((int)nwide, o);
-    if (lane == 0 && nwide) atomicAdd(&st->wide_units, nwide);
     if (tid == 0) {
         J.chunk_pairs[c] = (int64_t)run;
         atomicAdd(&st->total_pairs, (unsigned long long)run);
         if (run >> 32) atomicMax(&st->overflow, 1u);
+    }
+}
+
+// k_window_cum: cum32[k] = the tile's base + the exclusive prefix of F inside the tile.  One workgroup takes WG_CUM_TILES consecutive
+// 1024-site tiles, four consecutive sites per thread and tile; site_off and the tile starts are multiples of 8, so F arrives as one
+// 8-byte load and the offsets leave as one 16-byte store per thread.  The pass is a chain of dependent loads (the tile's record, then
+// its F) in front of a trivial scan: every tile's record comes from k_window in one 16-byte entry, and the loads of a workgroup's
+// tiles are all in flight before the first scan (one tile per workgroup and four dependent header loads: 0.10 ms for hg19, latency).
+#define WG_CUM_TILES 4
+__global__ __launch_bounds__(WG_BLOCK) void k_window_cum(const uint16_t* __restrict__ W16, uint32_t* __restrict__ cum32, const int4* __restrict__ tile_info,
+                                                         const uint32_t* __restrict__ tile_base, int64_t n_tiles)
+{
+    __shared__ uint32_t ws[WG_CUM_TILES][WG_BLOCK / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * WG_CUM_TILES;
+    int4 info[WG_CUM_TILES];
+    uint32_t base[WG_CUM_TILES];
+#pragma unroll
+    for (int q = 0; q < WG_CUM_TILES; q++) {
+        const int64_t t = t0 + q < n_tiles ? t0 + q : n_tiles - 1;
+        info[q] = tile_info[t];
+        base[q] = tile_base[t];
+        if (t0 + q >= n_tiles) info[q].z = 0;
+    }
+    uint2 v[WG_CUM_TILES];
+#pragma unroll
+    for (int q = 0; q < WG_CUM_TILES; q++) {
+        const int64_t at = (int64_t)(((uint64_t)(uint32_t)info[q].y << 32) | (uint32_t)info[q].x) + 4 * tid;
+        v[q] = make_uint2(0u, 0u);
+        if (4 * tid < info[q].z) v[q] = *reinterpret_cast<const uint2*>(W16 + at);       // (entries beyond the chunk's end: inside the padded array, masked below)
+    }
+    uint32_t w[WG_CUM_TILES][4], tot[WG_CUM_TILES], incl[WG_CUM_TILES];
+#pragma unroll
+    for (int q = 0; q < WG_CUM_TILES; q++) {
+        const int k = 4 * tid, n = info[q].z;
+        w[q][0] = k < n ? v[q].x & 0xffffu : 0u; w[q][1] = k + 1 < n ? v[q].x >> 16 : 0u;
+        w[q][2] = k + 2 < n ? v[q].y & 0xffffu : 0u; w[q][3] = k + 3 < n ? v[q].y >> 16 : 0u;
+        tot[q] = w[q][0] + w[q][1] + w[q][2] + w[q][3];
+        incl[q] = wg_wave_incl_scan_dpp_u32(tot[q]);
+        if (lane == 63) ws[q][wv] = incl[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < WG_CUM_TILES; q++) {
+        const int k = 4 * tid, n = info[q].z;
+        if (k >= n) continue;
+        uint32_t e = base[q] + (incl[q] - tot[q]);
+#pragma unroll
+        for (int x = 0; x < WG_BLOCK / 64; x++) if (x < wv) e += ws[q][x];
+        const int64_t at = (int64_t)(((uint64_t)(uint32_t)info[q].y << 32) | (uint32_t)info[q].x) + k;
+        uint32_t* C = cum32 + at;
+        const uint4 o = make_uint4(e, e + w[q][0], e + w[q][0] + w[q][1], e + w[q][0] + w[q][1] + w[q][2]);
+        if (k + 4 <= n) *reinterpret_cast<uint4*>(C) = o;
+        else { C[0] = o.x; if (k + 1 < n) C[1] = o.y; if (k + 2 < n) C[2] = o.z; }
     }
 }
 
@@ -510,16 +618,18 @@ __global__ __launch_bounds__(WG_BLOCK) void k_tile_count(JobView J, PlanArgs P, 
 
 // one workgroup per stage; per chunk the number of scored blocks in the stage, and the exclusive prefixes over the
 // chunks of the blocks and of the tiles of both classes
-__global__ __launch_bounds__(WG_BLOCK) void k_stage_plan(JobView J, PlanArgs P, const uint32_t* __restrict__ cntA,
+#define WG_PLAN_BLOCK 256       // (round 6: 1024 threads — three rounds over the 2,315 items of a whole-genome batch instead of ten — took 0.24 ms instead of 0.03:
+                                // a workgroup of sixteen wavefronts waits for a whole CU while k_validate holds the wavefront slots)
+__global__ __launch_bounds__(WG_PLAN_BLOCK) void k_stage_plan(JobView J, PlanArgs P, const uint32_t* __restrict__ cntA,
                                                          const uint32_t* __restrict__ cntB, const uint32_t* __restrict__ cntM, int64_t* cbase, uint32_t* cum0,
                                                          int64_t* tbaseA, int64_t* tbaseB, int64_t* tbaseM, int64_t* stage_pairs, int64_t* stage_tiles)
 {
-    __shared__ uint64_t wa[WG_BLOCK / 64], wb[WG_BLOCK / 64], wc[WG_BLOCK / 64], wd[WG_BLOCK / 64];
+    __shared__ uint64_t wa[WG_PLAN_BLOCK / 64], wb[WG_PLAN_BLOCK / 64], wc[WG_PLAN_BLOCK / 64], wd[WG_PLAN_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int stg = blockIdx.x;
     const int nC = J.n_chunks;
     uint64_t runA = 0, runB = 0, runC = 0, runD = 0;
-    for (int base = 0; base < nC; base += WG_BLOCK) {
+    for (int base = 0; base < nC; base += WG_PLAN_BLOCK) {
         const int c = base + tid;
         uint64_t sz = 0, nt = 0, nu = 0, nm = 0;
         uint32_t c0 = 0;
@@ -531,9 +641,10 @@ __global__ __launch_bounds__(WG_BLOCK) void k_stage_plan(JobView J, PlanArgs P, 
                 c0 = J.cum32[cd.site_off + s0];
                 const uint64_t cend = (s1 < cd.len) ? (uint64_t)J.cum32[cd.site_off + s1] : (uint64_t)J.chunk_pairs[c];
                 sz = cend - c0;
-                nt = cntA[(int64_t)stg * nC + c];
-                nu = cntB[(int64_t)stg * nC + c];
-                nm = cntM[(int64_t)stg * nC + c];
+                // (cntA == NULL: a job without a window beyond the narrow tiles' — every aligned group of TI starts is one narrow tile)
+                nt = cntA ? (uint64_t)cntA[(int64_t)stg * nC + c] : (uint64_t)((s1 - s0 + P.TI - 1) / P.TI);
+                nu = cntA ? (uint64_t)cntB[(int64_t)stg * nC + c] : 0;
+                nm = cntA ? (uint64_t)cntM[(int64_t)stg * nC + c] : 0;
             }
         }
         const uint64_t ia = wg_wave_incl_scan_u64(sz, lane), ib = wg_wave_incl_scan_u64(nt, lane), ic = wg_wave_incl_scan_u64(nu, lane),
@@ -542,7 +653,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_stage_plan(JobView J, PlanArgs P, 
         __syncthreads();
         uint64_t oa = 0, ob = 0, oc = 0, od = 0, ta = 0, tb2 = 0, tc = 0, td = 0;
 #pragma unroll
-        for (int q = 0; q < WG_BLOCK / 64; q++) {
+        for (int q = 0; q < WG_PLAN_BLOCK / 64; q++) {
             if (q < wv) { oa += wa[q]; ob += wb[q]; oc += wc[q]; od += wd[q]; }
             ta += wa[q]; tb2 += wb[q]; tc += wc[q]; td += wd[q];
         }
@@ -1896,14 +2007,20 @@ __global__ __launch_bounds__(64 * (1 + NW)) void k_dp16(JobView J, StageView SV,
 // k_trace / k_border_offsets / k_gather_borders
 // ------------------------------------------------------------------------------------------------------------
 // k_trace: one workgroup per chunk walks T[] back from the chunk's end (segmentor.cpp:50-58) and leaves the borders in
-// DESCENDING order in tmp.  The walk is a dependent chain of LDS reads, so it is cut into WG_TRACE_SEG segments per
-// LDS window of back-pointers:
-//   1. thread j walks, speculatively, from the top node of segment j down to the segment's end, marking the nodes it
-//      visits inside its own segment and remembering where it left;
-//   2. one thread follows the true path: inside a segment it steps only until it lands on a marked node — from there
-//      on the two walks are the same walk (each step depends only on the node), so it jumps to the segment's exit;
-//   3. thread j marks the part of its walk below the join as path; the marked nodes are emitted by a bit scan.
-// Paths of a changepoint recurrence join within a block or two, so step 2 costs a few reads per segment.
+// DESCENDING order in tmp.  The walk is a dependent chain of LDS reads, so every LDS window of back-pointers is cut into
+// one segment per thread (segment j = the nodes (lim_j, p_j], p_j = hi - j L):
+//   1. thread j walks, speculatively, from the top node of its segment down to the segment's end, marking the nodes it
+//      visits and remembering where it left (e_j);
+//   2. where does the TRUE path enter segment j?  At the node where it leaves segment j - 1 — and a walk that starts anywhere
+//      in a segment joins the speculative walk of that segment within a block or two (each step depends only on the node:
+//      from a common node on, two walks are one), after which it leaves at e_j.  So every thread assumes the entry
+//      a_j = e_(j-1), follows it until it meets a marked node (exit e_j) or the segment's end (exit = where it left), and
+//      the assumptions are checked against the exits of the neighbours above: a thread whose assumption was wrong takes the
+//      right entry and walks again.  a_0 = hi is exact, so the first wrong assumption is corrected in every round: the
+//      fixed point — one or two rounds, each a few steps long — is the true path.  (Rounds 1-5 had one thread follow the
+//      true path through all 128 segments, a chain of ~6 dependent LDS reads per segment: 0.08 of the kernel's 0.18 ms.)
+//   3. thread j marks the walk from its true entry as path; the marked nodes are emitted by a bit scan.
+// The window arrives as aligned 16-byte loads (the chunks' slices of back16 begin at multiples of 8 entries).
 __device__ __forceinline__ int wg_trace_step(const uint16_t* win, int i, int wlo)
 {
     int stepb = (int)win[i - 1 - wlo];                       // i = T[i] (segmentor.cpp:55)
@@ -1913,63 +2030,75 @@ __device__ __forceinline__ int wg_trace_step(const uint16_t* win, int i, int wlo
 
 __global__ __launch_bounds__(WG_BLOCK) void k_trace(JobView J, int32_t* __restrict__ tmp, int32_t* __restrict__ nb)
 {
-    __shared__ uint16_t win[WG_TRACE_WIN];                   // back-pointer of node i (wlo < i <= hi) at win[i-1-wlo]
+    __shared__ __attribute__((aligned(16))) uint16_t win_raw[WG_TRACE_WIN + 8];      // back-pointer of node i (wlo < i <= hi) at win[i-1-wlo], win = win_raw + (wlo mod 8)
     __shared__ uint32_t vis[WG_TRACE_WIN / 32 + 1];          // bit i-wlo: node visited by the speculative walk of its own segment
     __shared__ uint32_t tp[WG_TRACE_WIN / 32 + 1];           // bit i-wlo: node is on the path
-    __shared__ int seg_exit[WG_TRACE_SEG], seg_join[WG_TRACE_SEG];
+    __shared__ int seg_exit[WG_BLOCK], seg_r[WG_BLOCK];
     __shared__ uint32_t wsum[WG_BLOCK / 64];
-    __shared__ int sh_cur;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c = blockIdx.x;
     const ChunkDesc cd = J.chunks[c];
     int32_t* out = tmp + cd.site_off + c;                    // len+1 slots
-    const uint16_t* bk = J.back16 + cd.site_off;
+    const uint16_t* bk = J.back16 + cd.site_off;             // (16-byte aligned: site_off is a multiple of 8)
     int hi = cd.len, cnt = 0;
     while (hi > 0) {
         const int wlo = (hi > WG_TRACE_WIN) ? hi - WG_TRACE_WIN : 0;
         const int nw = (hi - wlo) / 32 + 1;                   // bitmap words in use
-        const int L = (hi - wlo + WG_TRACE_SEG - 1) / WG_TRACE_SEG;
-        for (int x = tid; x < hi - wlo; x += WG_BLOCK) win[x] = bk[wlo + x];
+        // nodes per segment: a thread each for a full window (128 nodes), never fewer than 64 nodes — a block longer than a segment makes the
+        // path jump over segments, and every jumped segment costs the fixed point a round (a 400-site junction patch cut into 2-node
+        // segments took 200 rounds)
+        const int L0 = (hi - wlo + WG_BLOCK - 1) / WG_BLOCK;
+        const int L = L0 < 64 ? 64 : L0;
+        const int S = (hi - wlo + L - 1) / L;                 // segments in use (<= WG_BLOCK)
+        const int shift = wlo & 7;
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(bk + (wlo - shift));
+            const int nv = (shift + hi - wlo + 7) >> 3;       // (the last vector may reach into the padding behind the chunk's slice)
+            for (int x = tid; x < nv; x += WG_BLOCK) reinterpret_cast<uint4*>(win_raw)[x] = src[x];
+        }
+        const uint16_t* win = win_raw + shift;
         for (int x = tid; x < nw; x += WG_BLOCK) { vis[x] = 0u; tp[x] = 0u; }
         __syncthreads();
         const int p = hi - tid * L;                           // top node of this thread's segment
         const int lim = (p - L > wlo) ? p - L : wlo;
-        if (tid < WG_TRACE_SEG) {
+        const bool mine = tid < S;
+        if (mine) {
             int i = p;
             while (i > lim) { atomicOr(&vis[(i - wlo) >> 5], 1u << ((i - wlo) & 31)); i = wg_trace_step(win, i, wlo); }
             seg_exit[tid] = i;
-            seg_join[tid] = -1;
         }
         __syncthreads();
-        if (tid == 0) {
-            int i = hi;
-            while (i > wlo) {
-                if ((vis[(i - wlo) >> 5] >> ((i - wlo) & 31)) & 1u) {
-                    const int j = (hi - i) / L;
-                    seg_join[j] = i;
-                    i = seg_exit[j];
-                } else {
-                    tp[(i - wlo) >> 5] |= 1u << ((i - wlo) & 31);
+        // the fixed point of (entry of segment j) = (exit of segment j - 1 for ITS entry)
+        int a = mine ? (tid == 0 ? hi : seg_exit[tid - 1]) : 0;
+        bool need = mine;
+        for (;;) {
+            if (need) {
+                int i = a;
+                while (i > lim) {
+                    if ((vis[(i - wlo) >> 5] >> ((i - wlo) & 31)) & 1u) { i = seg_exit[tid]; break; }
                     i = wg_trace_step(win, i, wlo);
                 }
+                seg_r[tid] = i;
             }
-            sh_cur = i;
+            __syncthreads();
+            need = false;
+            if (mine && tid > 0) { const int ra = seg_r[tid - 1]; if (ra != a) { a = ra; need = true; } }
+            if (!__syncthreads_or(need ? 1 : 0)) break;
         }
-        __syncthreads();
-        if (tid < WG_TRACE_SEG && seg_join[tid] >= 0) {
-            const int join = seg_join[tid];
-            int i = p;
-            while (i > lim) { if (i <= join) atomicOr(&tp[(i - wlo) >> 5], 1u << ((i - wlo) & 31)); i = wg_trace_step(win, i, wlo); }
+        if (mine) {
+            int i = a;
+            while (i > lim) { atomicOr(&tp[(i - wlo) >> 5], 1u << ((i - wlo) & 31)); i = wg_trace_step(win, i, wlo); }
         }
+        const int next_hi = seg_r[S - 1];                     // where the path leaves the window
         __syncthreads();
         // emit the window's path nodes, largest first: thread t owns the words nw-1-t*wpt .. (descending)
         const int wpt = (nw + WG_BLOCK - 1) / WG_BLOCK;
-        uint32_t mine = 0;
-        for (int q = 0; q < wpt; q++) { const int w = nw - 1 - (tid * wpt + q); if (w >= 0) mine += (uint32_t)__popc(tp[w]); }
-        const uint32_t incl = wg_wave_incl_scan_dpp_u32(mine);
+        uint32_t mine_n = 0;
+        for (int q = 0; q < wpt; q++) { const int w = nw - 1 - (tid * wpt + q); if (w >= 0) mine_n += (uint32_t)__popc(tp[w]); }
+        const uint32_t incl = wg_wave_incl_scan_dpp_u32(mine_n);
         if (lane == 63) wsum[wv] = incl;
         __syncthreads();
-        uint32_t off = incl - mine, tot = 0;
+        uint32_t off = incl - mine_n, tot = 0;
 #pragma unroll
         for (int q = 0; q < WG_BLOCK / 64; q++) { if (q < wv) off += wsum[q]; tot += wsum[q]; }
         int pos = cnt + (int)off;
@@ -1980,7 +2109,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_trace(JobView J, int32_t* __restri
             while (bits) { const int b = 31 - __clz((int)bits); out[pos++] = wlo + w * 32 + b; bits &= ~(1u << b); }
         }
         cnt += (int)tot;
-        hi = sh_cur;
+        hi = next_hi;
         __syncthreads();
     }
     if (tid == 0) { out[cnt] = 0; nb[c] = cnt + 1; }          // the walk ends at border 0 (segmentor.cpp:54-57)

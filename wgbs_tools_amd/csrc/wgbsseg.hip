@@ -119,15 +119,20 @@ struct wgbsseg_ctx {
     const uint32_t* loci = nullptr;
     int64_t n_loci = 0;
     // scratch
-    DevBuf chunks, wtile, carry, W16, cum32, back16, chunk_pairs, status;
+    DevBuf chunks, wtile, carry, W16, cum32, back16, chunk_pairs, status, tile_tot, tile_base, tile_chunk;
     DevBuf plan_cbase, plan_cum0, plan_tbase, plan_pairs, plan_tiles, plan_cnt, tilesA, tilesB, tilesM, umax16;
     std::vector<PinnedBuf> pinned;
     std::vector<PinnedBuf> up_stage;   // two page-locked staging pieces per upload thread (set_betas_host)
     DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders, dbg_a, dbg_b, dbg_c, lookup;
     std::vector<wg_d2> h_lookup;   // host copy of the k-scaled log tables of the call in flight (source of an async upload)
+    float lookup_pc = -1.0f;       // what the device copy `lookup` was built for: pseudo count and exponent rows of the narrow / wide / medium class
+    int lookup_rows[3] = {-1, -1, -1};
     // events
-    hipEvent_t ev[9] = {};   // [8]: between the two launches of the scan pass (k_scan | k_validate)
+    hipEvent_t ev[13] = {};  // [0] batch begins, [1] windows done, [7] statistics copied, [3] plan done, [4]-[6] traceback / borders; the scan pass (stream C): [12] inputs uploaded,
+                             // [8]..[9] k_validate, [10]..[11] k_scan (jobs with wide tiles only), [2] its verdict may be copied
     PinnedBuf h_status;      // page-locked landing area of the status words: D2H copies that really are asynchronous
+    PinnedBuf h_job, h_pieces, h_sb;   // ... the staging areas of a job's tables on their way up (chunk table, window tiles, cleared status | k_validate's pieces)
+    PinnedBuf h_out;         // ... and of a batch's CSR offsets (a small batch: of its border lists too)
     std::vector<hipEvent_t> ev_cost0, ev_cost1, ev_dp0, ev_dp1, ev_fork, ev_join;     // per stage
     // last-call info
     wgbsseg_timings tim = {};
@@ -264,8 +269,13 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
         int lo_p = 0, hi_p = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
         HIP_TRY(hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, hi_p));
+        // ... and the scan stream ranks below it: k_validate starts with the batch, beside the windows pass, and must not take the wavefront
+        // slots of the kernels that are on the way to the first scoring tile (measured, hg19 x 32: scoring begins 0.36 ms into the batch
+        // instead of 0.46, profiles/r06_front_ab.txt)
+        const char* sp = getenv("WGBSSEG_SCAN_PRIO");          // (A/B) 0: the scan stream at the scoring stream's priority
+        if (!(sp && atoi(sp) == 0)) HIP_TRY(hipStreamCreateWithPriority(&c->sC, hipStreamNonBlocking, lo_p));
     }
-    HIP_TRY(hipStreamCreateWithFlags(&c->sC, hipStreamNonBlocking));
+    if (!c->sC) HIP_TRY(hipStreamCreateWithFlags(&c->sC, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->sA2, hipStreamNonBlocking));
     for (auto& v : c->ev) HIP_TRY(hipEventCreate(&v));
     const char* b = getenv("WGBSSEG_COST_BUDGET_MB");
@@ -293,7 +303,7 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     const double t0 = wall_s();
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->wtile, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs,
+    DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->wtile, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs, &c->tile_tot, &c->tile_base, &c->tile_chunk,
                      &c->status, &c->plan_cbase, &c->plan_cum0, &c->plan_tbase, &c->plan_pairs, &c->plan_tiles, &c->plan_cnt, &c->tilesA, &c->tilesB, &c->tilesM, &c->umax16,
                      &c->cost[0], &c->cost[1], &c->dpstate, &c->tmp_borders, &c->nb, &c->boff, &c->out_borders,
                      &c->dbg_a, &c->dbg_b, &c->dbg_c, &c->lookup, &c->scan_pieces, &c->divcheck, &c->plan_sb, &c->bs_desc};
@@ -301,6 +311,10 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     for (auto& pb : c->pinned) pb.release();
     for (auto& pb : c->up_stage) pb.release();
     c->h_status.release();
+    c->h_out.release();
+    c->h_job.release();
+    c->h_pieces.release();
+    c->h_sb.release();
     for (auto& v : c->ev) if (v) (void)hipEventDestroy(v);
     for (auto* vec : {&c->ev_cost0, &c->ev_cost1, &c->ev_dp0, &c->ev_dp1, &c->ev_fork, &c->ev_join}) for (auto v : *vec) (void)hipEventDestroy(v);
     if (c->sA) (void)hipStreamDestroy(c->sA);
@@ -384,6 +398,7 @@ struct Job {
     int64_t val_sites = 0;
     std::vector<int64_t> wtile_off;     // exclusive prefix of 256-site tiles per chunk (+ total), then (as int32 pairs) the chunk of every 256th tile
     int64_t sites = 0, carry_entries = 0, units = 0, n_hint = 0;
+    int64_t sites_padded = 0;           // the job-site arrays (W16, cum32, back16) hold every chunk from a multiple of 8 entries on: 16-byte vectors of them are aligned
     int32_t max_len = 0;
     JobStatus st0;          // source of an async H2D copy: must outlive the call's stream work
     JobView v = {};
@@ -399,7 +414,7 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
     if (!start0 || !len || n_chunks < 1 || n_chunks > 0x7fffffff) { set_err(err, errlen, "bad chunk list"); return WGBSSEG_E_ARG; }
     job.h.resize((size_t)n_chunks);
     job.wtile_off.resize((size_t)n_chunks + 1);
-    int64_t so = 0, co = 0, wt = 0, uo = 0;
+    int64_t so = 0, co = 0, wt = 0, uo = 0, total = 0;
     for (int64_t i = 0; i < n_chunks; i++) {
         if (len[i] < 1 || len[i] > (1 << 30) || start0[i] < 0 || start0[i] + len[i] > c->n_total) {
             set_err(err, errlen, "chunk %lld = [%lld, +%d) is empty or outside the %lld sites of the beta files",
@@ -410,7 +425,8 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
         d.start0 = start0[i]; d.len = len[i]; d.site_off = so; d.carry_off = co; d.unit_off = uo; d.nG = (int32_t)(((start0[i] + len[i] - 1) >> WG_CARRY_SHIFT) - (start0[i] >> WG_CARRY_SHIFT) + 1);
         job.wtile_off[(size_t)i] = wt;
         wt += (len[i] + WG_WIN_TILE - 1) / WG_WIN_TILE;
-        so += len[i];
+        so += round_up((int64_t)len[i], 8);
+        total += len[i];
         uo += (len[i] + 15) / 16;
         co += (int64_t)d.nG * c->n_samples;
         job.max_len = std::max(job.max_len, len[i]);
@@ -428,17 +444,31 @@ int build_job(wgbsseg_ctx* c, const int64_t* start0, const int32_t* len, int64_t
             hint[h] = (int32_t)cix;
         }
     }
-    job.sites = so; job.carry_entries = co; job.units = uo;
+    job.sites = total; job.sites_padded = so; job.carry_entries = co; job.units = uo;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(c->chunks.ensure(sizeof(ChunkDesc) * (size_t)n_chunks));
     HIP_TRY(c->carry.ensure(sizeof(uint2) * (size_t)co));
     HIP_TRY(c->status.ensure(sizeof(JobStatus)));
-    HIP_TRY(hipMemcpyAsync(c->chunks.p, job.h.data(), sizeof(ChunkDesc) * (size_t)n_chunks, hipMemcpyHostToDevice, c->sA));
     HIP_TRY(c->wtile.ensure(8 * job.wtile_off.size()));
-    HIP_TRY(hipMemcpyAsync(c->wtile.p, job.wtile_off.data(), 8 * job.wtile_off.size(), hipMemcpyHostToDevice, c->sA));
     memset(&job.st0, 0, sizeof(job.st0));
     job.st0.first_bad = ~0ULL;
-    HIP_TRY(hipMemcpyAsync(c->status.p, &job.st0, sizeof(job.st0), hipMemcpyHostToDevice, c->sA));
+    // the job's tables go up through ONE page-locked staging area (round 6): a copy out of pageable memory is staged by the runtime and
+    // blocks the caller for ~15 us — four of them in front of every batch, the follow-up batches of junction patches included
+    const size_t b_chunks = sizeof(ChunkDesc) * (size_t)n_chunks, b_wtile = 8 * job.wtile_off.size();
+    const size_t o_wtile = (size_t)round_up((int64_t)b_chunks, 64), o_status = o_wtile + (size_t)round_up((int64_t)b_wtile, 64), o_end = o_status + 64;
+    if (c->h_job.ensure(o_end)) {
+        char* h = reinterpret_cast<char*>(c->h_job.p);
+        memcpy(h, job.h.data(), b_chunks);
+        memcpy(h + o_wtile, job.wtile_off.data(), b_wtile);
+        memcpy(h + o_status, &job.st0, sizeof(job.st0));
+        HIP_TRY(hipMemcpyAsync(c->chunks.p, h, b_chunks, hipMemcpyHostToDevice, c->sA));
+        HIP_TRY(hipMemcpyAsync(c->wtile.p, h + o_wtile, b_wtile, hipMemcpyHostToDevice, c->sA));
+        HIP_TRY(hipMemcpyAsync(c->status.p, h + o_status, sizeof(job.st0), hipMemcpyHostToDevice, c->sA));
+    } else {
+        HIP_TRY(hipMemcpyAsync(c->chunks.p, job.h.data(), b_chunks, hipMemcpyHostToDevice, c->sA));
+        HIP_TRY(hipMemcpyAsync(c->wtile.p, job.wtile_off.data(), b_wtile, hipMemcpyHostToDevice, c->sA));
+        HIP_TRY(hipMemcpyAsync(c->status.p, &job.st0, sizeof(job.st0), hipMemcpyHostToDevice, c->sA));
+    }
     JobView& v = job.v;
     v.betas = c->betas; v.pitch = c->pitch; v.n_total = c->n_total; v.loci = c->loci;
     v.chunks = c->chunks.as<ChunkDesc>(); v.carry = c->carry.as<uint2>();
@@ -489,30 +519,37 @@ int plan_validation(wgbsseg_ctx* c, Job& job, bool fresh_call, char* err, size_t
         }
         V.resize(w + 1);
         HIP_TRY(c->scan_pieces.ensure(sizeof(ScanPiece) * job.pieces.size()));
-        HIP_TRY(hipMemcpyAsync(c->scan_pieces.p, job.pieces.data(), sizeof(ScanPiece) * job.pieces.size(), hipMemcpyHostToDevice, c->sA));
+        const size_t b_pieces = sizeof(ScanPiece) * job.pieces.size();
+        const void* src = job.pieces.data();
+        if (c->h_pieces.ensure(b_pieces)) { memcpy(c->h_pieces.p, src, b_pieces); src = c->h_pieces.p; }      // (page-locked: the copy does not block, see build_job)
+        HIP_TRY(hipMemcpyAsync(c->scan_pieces.p, src, b_pieces, hipMemcpyHostToDevice, c->sA));
     }
     return WGBSSEG_OK;
 }
 
-// The scan pass: k_scan (per chunk, with carries; does its work only when the job has wide units or the caller wants the
-// carries) and k_validate (per piece, read-only; only when it has none).  The device-side flag decides, so both can be
-// queued before the host has seen the window statistics.
-int launch_scan(wgbsseg_ctx* c, const Job& job, int want_carry, hipStream_t s, char* err, size_t errlen)
+// The scan pass.  k_validate (per piece, read-only): the `meth <= cov` check of read_beta_file (segmentor.cpp:179-188) over the sites of the
+// batch this API call has not checked yet; it needs nothing but the beta bytes, so a batch launches it first of all, beside the windows pass
+// (round 6).  k_scan (per chunk, with carries + the same check): only for a job with wide scoring tiles — the one consumer of the carries —
+// or a caller that wants them.
+int launch_validate(wgbsseg_ctx* c, const Job& job, hipStream_t s, char* err, size_t errlen)
+{
+    if (job.pieces.empty()) return WGBSSEG_OK;
+    const int64_t tasks = (int64_t)job.pieces.size() * job.v.n_samples;
+    const int64_t vb = (tasks + (WG_BLOCK / 64) - 1) / (WG_BLOCK / 64);
+    if (vb > 0x7fffffff) { set_err(err, errlen, "too many (piece, sample) rows"); return WGBSSEG_E_ARG; }
+    hipLaunchKernelGGL(k_validate, dim3((unsigned)vb), dim3(WG_BLOCK), 0, s, job.v, c->status.as<JobStatus>(),
+                       c->scan_pieces.as<ScanPiece>(), (int64_t)job.pieces.size());
+    HIP_TRY(hipGetLastError());
+    return WGBSSEG_OK;
+}
+
+int launch_scan(wgbsseg_ctx* c, const Job& job, hipStream_t s, char* err, size_t errlen)
 {
     const int64_t rows = (int64_t)job.v.n_chunks * job.v.n_samples;      // wave tasks
     const int64_t blocks = (rows + (WG_BLOCK / 64) - 1) / (WG_BLOCK / 64);
     if (blocks > 0x7fffffff) { set_err(err, errlen, "too many (chunk, sample) rows"); return WGBSSEG_E_ARG; }
-    hipLaunchKernelGGL(k_scan, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, s, job.v, c->status.as<JobStatus>(), want_carry);
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)blocks), dim3(WG_BLOCK), 0, s, job.v, c->status.as<JobStatus>());
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev[8], s));
-    if (!want_carry && !job.pieces.empty()) {
-        const int64_t tasks = (int64_t)job.pieces.size() * job.v.n_samples;
-        const int64_t vb = (tasks + (WG_BLOCK / 64) - 1) / (WG_BLOCK / 64);
-        if (vb > 0x7fffffff) { set_err(err, errlen, "too many (piece, sample) rows"); return WGBSSEG_E_ARG; }
-        hipLaunchKernelGGL(k_validate, dim3((unsigned)vb), dim3(WG_BLOCK), 0, s, job.v, c->status.as<JobStatus>(),
-                           c->scan_pieces.as<ScanPiece>(), (int64_t)job.pieces.size());
-        HIP_TRY(hipGetLastError());
-    }
     return WGBSSEG_OK;
 }
 
@@ -724,7 +761,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const wgbsseg_params* const P0 = P;
     P = &Peff;
     if (!(P->pseudo_count >= 0.0f)) { set_err(err, errlen, "pseudo_count must be >= 0"); return WGBSSEG_E_ARG; }
-    if (c && c->sC) HIP_TRY(hipStreamSynchronize(c->sC));      // (a call that failed half way may have left its scan pass running ...
+    if (c && c->sA) HIP_TRY(hipStreamSynchronize(c->sA));      // (a call that failed half way may have left work behind that reads the staging areas ...
+    if (c && c->sC) HIP_TRY(hipStreamSynchronize(c->sC));      //  ... its scan pass ...
     if (c && c->sA2) HIP_TRY(hipStreamSynchronize(c->sA2));    //  ... or the medium / wide tiles of a stage on the second scoring stream)
     Job job;
     int rc = build_job(c, chunk_start0, chunk_len, n_chunks, job, true, err, errlen);
@@ -736,20 +774,39 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const int64_t J = job.sites;
     JobView& v = job.v;
 
-    HIP_TRY(c->W16.ensure((size_t)J * 2));
-    HIP_TRY(c->cum32.ensure((size_t)J * 4));
-    HIP_TRY(c->back16.ensure((size_t)J * 2));
+    const int64_t Jp = job.sites_padded;                         // every chunk's slice of the job-site arrays begins at a multiple of 8 entries
+    const int64_t nT = job.wtile_off[(size_t)nC];                // 1024-site tiles of the windows pass
+    if (nT > 0x7fffffff) { set_err(err, errlen, "too many sites in one call"); return WGBSSEG_E_ARG; }
+    HIP_TRY(c->W16.ensure((size_t)Jp * 2 + 16));
+    HIP_TRY(c->cum32.ensure((size_t)Jp * 4 + 16));
+    HIP_TRY(c->back16.ensure((size_t)Jp * 2 + 16));
     HIP_TRY(c->chunk_pairs.ensure((size_t)nC * 8));
     HIP_TRY(c->umax16.ensure((size_t)job.units * 2));
+    HIP_TRY(c->tile_tot.ensure((size_t)nT * 4));
+    HIP_TRY(c->tile_base.ensure((size_t)nT * 4));
+    HIP_TRY(c->tile_chunk.ensure((size_t)nT * 16));          // (one int4 record per tile)
     v.W16 = c->W16.as<uint16_t>(); v.cum32 = c->cum32.as<uint32_t>(); v.back16 = c->back16.as<uint16_t>();
     v.chunk_pairs = c->chunk_pairs.as<int64_t>(); v.umax16 = c->umax16.as<uint16_t>();
-
-    // ---- window extents, then scan + validate ----------------------------------------------------------------
-    // The host needs the window statistics to plan the scoring tiles; the windows go first so that this round trip
-    // hides behind the scan pass (whose own verdict, meth > cov, is read with the plan totals further down).
-    HIP_TRY(hipEventRecord(c->ev[0], c->sA));
-    if (job.wtile_off[(size_t)nC] > 0x7fffffff) { set_err(err, errlen, "too many sites in one call"); return WGBSSEG_E_ARG; }
     if (!c->h_status.ensure(4 * sizeof(JobStatus))) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
+
+    // ---- the scan pass starts with the batch, on its own stream (round 6) ---------------------------------------
+    // k_validate needs the beta bytes and the list of pieces, nothing from the windows: it runs beside k_window (HBM-bound beside
+    // instruction-bound) instead of behind it, and the scoring kernel of a job without wide tiles — which needs nothing from the scan
+    // but its verdict, read at the end of the batch — no longer queues behind either.  (Rounds 1-5: windows 0.28 ms, then the scan
+    // 0.32 ms, then the tile plan: scoring began 0.71 ms into the hg19 x 32 batch.)
+    HIP_TRY(hipEventRecord(c->ev[0], c->sA));
+    HIP_TRY(hipEventRecord(c->ev[12], c->sA));                   // chunk table, pieces and the cleared status block are on the device
+    hipStream_t const sS = c->sC;
+    static const int scan_after = getenv("WGBSSEG_SCAN_AFTER") ? atoi(getenv("WGBSSEG_SCAN_AFTER")) : 0;      // (A/B) 1: k_validate behind the windows pass (beside the tile plan and the scoring)
+    HIP_TRY(hipStreamWaitEvent(sS, c->ev[12], 0));
+    if (!scan_after) {
+        HIP_TRY(hipEventRecord(c->ev[8], sS));
+        rc = launch_validate(c, job, sS, err, errlen);
+        if (rc != WGBSSEG_OK) return rc;
+        HIP_TRY(hipEventRecord(c->ev[9], sS));
+    }
+
+    // ---- window extents ------------------------------------------------------------------------------------------
     // a pseudo count this context has not scored with yet: may the narrow tiles use the short division core?  Every operand
     // pair they can form is tried on the device (0.1 ms, once); the verdict arrives with the window statistics.
     const bool check_div = c->divs_enabled && wg_term_mode(P->pseudo_count) == 2 && c->divs_pc != P->pseudo_count;
@@ -762,47 +819,58 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(reinterpret_cast<JobStatus*>(c->h_status.p) + 1, c->divcheck.p, 4, hipMemcpyDeviceToHost, c->sA));
     }
-    // loci of a 1024-site tile and of everything its windows can reach, in LDS (<= 48 KB; deeper windows search in L2)
-    const int win_cap = (int)std::min<int64_t>((int64_t)WG_WIN_TILE + P->max_cpg - 1, 12288);
-    const int win_lds = ((int64_t)WG_WIN_TILE + P->max_cpg - 1 <= 12288) ? win_cap : 0;
-    hipLaunchKernelGGL(k_window, dim3((unsigned)job.wtile_off[(size_t)nC]), dim3(WG_BLOCK), (size_t)win_lds * 4, c->sA, v, c->status.as<JobStatus>(),
-                       c->wtile.as<int64_t>(), reinterpret_cast<const int32_t*>(c->wtile.as<int64_t>() + nC + 1), P->max_cpg, P->max_bp, win_lds);
-    HIP_TRY(hipGetLastError());
+    // the search's first step when a wavefront has windows of 64 sites and more: 2^floor(log2(max_cpg - 1))
+    int top_step = 1;
+    while (2 * (int64_t)top_step <= (int64_t)P->max_cpg - 1) top_step *= 2;
+    // loci of a 1024-site tile, of the site before it and of everything a PROBE of its searches can touch, in LDS (<= 48 KB; deeper windows search in L2)
+    const int64_t win_want = 1 + (int64_t)WG_WIN_TILE + 2 * (int64_t)std::max(top_step, 32) + 8;
+    const int win_lds = win_want <= 12288 ? (int)win_want : 0;
     // medium tiles (round 3): units of a non-narrow group whose windows stay <= WG_MEDIUM_WMAX = 252 sites (block counts < 2^16): CpG islands
     const int wm_env = getenv("WGBSSEG_MEDIUM_WMAX") ? std::max(0, std::min(WG_MEDIUM_WMAX, atoi(getenv("WGBSSEG_MEDIUM_WMAX")))) : WG_MEDIUM_WMAX;   // 0: no medium class (A/B, tests; read per call)
     const int WMED = wm_env > WG_NARROW_WMAX ? wm_env : 0;
-    hipLaunchKernelGGL(k_window_scan, dim3((unsigned)nC), dim3(WG_WSCAN_BLOCK), 0, c->sA, v, c->status.as<JobStatus>(), std::max(WMED, WG_NARROW_WMAX));
+    const int64_t* const d_wtile = c->wtile.as<int64_t>();
+    hipLaunchKernelGGL(k_window, dim3((unsigned)nT), dim3(WG_BLOCK), (size_t)win_lds * 4, c->sA, v, c->status.as<JobStatus>(),
+                       d_wtile, reinterpret_cast<const int32_t*>(d_wtile + nC + 1), P->max_cpg, P->max_bp, win_lds, top_step, std::max(WMED, WG_NARROW_WMAX),
+                       c->tile_tot.as<uint32_t>(), c->tile_chunk.as<int4>());
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_window_scan, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, c->status.as<JobStatus>(), d_wtile, c->tile_tot.as<uint32_t>(), c->tile_base.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
+    if (scan_after) {
+        HIP_TRY(hipStreamWaitEvent(sS, c->ev[1], 0));
+        HIP_TRY(hipEventRecord(c->ev[8], sS));
+        rc = launch_validate(c, job, sS, err, errlen);
+        if (rc != WGBSSEG_OK) return rc;
+        HIP_TRY(hipEventRecord(c->ev[9], sS));
+    }
     JobStatus* hst = reinterpret_cast<JobStatus*>(c->h_status.p);
     HIP_TRY(hipMemcpyAsync(&hst[0], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, c->sA));
     HIP_TRY(hipEventRecord(c->ev[7], c->sA));
-    // The scan pass on its own stream.  It needs the windows' verdict (wide units or not: device-side flag), nothing else; the
-    // narrow scoring tiles need nothing from it, so for a job without wide units the HBM-bound scan and its host round trips run
-    // beside the tile plan and the VALU-bound scoring kernel; wide tiles (carries) make the scoring stream wait for it.
-    // Measured (scan beside / ahead of the scoring kernel, ms per step): hg19 x 8 10.24 / 10.61, one eighth x 32 4.42 / 4.52, x 32 26.90 / 26.88,
-    // x 200 141.3 / 142.1: it pays where the scan and the round trips are a visible share of the step; a large job keeps the scan
-    // alone on the chip.
-    // (The tile plan beside the scan of a large job, scoring behind both: measured neutral in time, and the plan kernels cost the
-    // scan 3 % of its rate; not done.)
-    const bool beside = (double)J * c->n_samples < 5e8;
-    const bool own_stream = beside;
-    hipStream_t sS = own_stream ? c->sC : c->sA;
-    if (own_stream) HIP_TRY(hipStreamWaitEvent(c->sC, c->ev[1], 0));
-    rc = launch_scan(c, job, 0, sS, err, errlen);
-    if (rc != WGBSSEG_OK) return rc;
-    HIP_TRY(hipEventRecord(c->ev[2], sS));
-    HIP_TRY(hipMemcpyAsync(&hst[2], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, sS));      // the scan's verdict, read at the end of the batch
-    HIP_TRY(hipEventSynchronize(c->ev[7]));                    // window statistics are here; the scan is still running
+    // (the row offsets are not in the statistics: this pass runs while the host reads them and plans the tiles)
+    hipLaunchKernelGGL(k_window_cum, dim3((unsigned)((nT + WG_CUM_TILES - 1) / WG_CUM_TILES)), dim3(WG_BLOCK), 0, c->sA, (const uint16_t*)v.W16, v.cum32, (const int4*)c->tile_chunk.as<int4>(),
+                       (const uint32_t*)c->tile_base.as<uint32_t>(), nT);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(c->ev[7]));                    // window statistics are here; the scan pass is still running
     const JobStatus st = hst[0];
     if (check_div) {
         c->divs_ok = *reinterpret_cast<const unsigned int*>(&hst[1]) == 0u;
         c->divs_pc = P->pseudo_count;
         if (profiling()) fprintf(stderr, "[wgbsseg] short division core for pseudo count %g: %s\n", (double)P->pseudo_count, c->divs_ok ? "verified on every operand pair of a narrow tile" : "NOT exact, the full core stays");
     }
+    // wide tiles read the carries of k_scan: behind k_validate on the scan stream, as soon as the windows are known
+    if (st.wide_units && !st.loci_disorder && !st.overflow) {
+        HIP_TRY(hipStreamWaitEvent(sS, c->ev[1], 0));
+        HIP_TRY(hipEventRecord(c->ev[10], sS));
+        rc = launch_scan(c, job, sS, err, errlen);
+        if (rc != WGBSSEG_OK) return rc;
+        HIP_TRY(hipEventRecord(c->ev[11], sS));
+    }
+    HIP_TRY(hipEventRecord(c->ev[2], sS));
+    HIP_TRY(hipMemcpyAsync(&hst[2], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, sS));      // the scan's verdict, read at the end of the batch
     if (st.loci_disorder || st.overflow) {
         JobStatus st2;                                        // the scan's verdict takes precedence, as it always has
         HIP_TRY(hipStreamSynchronize(sS));
+        HIP_TRY(hipStreamSynchronize(c->sA));
         HIP_TRY(hipMemcpyAsync(&st2, c->status.p, sizeof(st2), hipMemcpyDeviceToHost, c->sA));
         HIP_TRY(hipStreamSynchronize(c->sA));
         if (st2.first_bad != ~0ULL) return report_bad_site(c, st2, err, errlen);
@@ -918,17 +986,22 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     caA.NS = NSA; caA.rows = rowsA;
     caB.NS = NSB; caB.rows = rowsB;
     caM.NS = NSM; caM.rows = rowsM;
-    if (ks) {   // the k-scaled tables of the tile classes, built here once per call (same IEEE operations as on the device)
-        static const wg_log_tables host_tabs = WG_LOG_TABLES_INIT;
-        c->h_lookup.resize((size_t)(rowsA + rowsB + rowsM) * 80);
-        wg_d2* dst = c->h_lookup.data();
-        for (int rows : {rowsA, rowsB, rowsM}) {
-            for (int x = 0; x < rows * 16; x++) dst[x] = wg_ks_iy_entry(&host_tabs, rows, x);
-            for (int x = 0; x < rows * 64; x++) dst[rows * 16 + x] = wg_ks_ky_entry(&host_tabs, rows, x);
-            dst += (size_t)rows * 80;
+    if (ks) {   // the k-scaled tables of the tile classes (same IEEE operations as on the device): built and uploaded when the pseudo count or a
+                // class's exponent rows differ from what the context holds — a follow-up batch of the same call, the next call of a bench, reuse them
+        const bool same = c->lookup_pc == P->pseudo_count && c->lookup_rows[0] == rowsA && c->lookup_rows[1] == rowsB && c->lookup_rows[2] == rowsM && c->lookup.p;
+        if (!same) {
+            static const wg_log_tables host_tabs = WG_LOG_TABLES_INIT;
+            c->h_lookup.resize((size_t)(rowsA + rowsB + rowsM) * 80);
+            wg_d2* dst = c->h_lookup.data();
+            for (int rows : {rowsA, rowsB, rowsM}) {
+                for (int x = 0; x < rows * 16; x++) dst[x] = wg_ks_iy_entry(&host_tabs, rows, x);
+                for (int x = 0; x < rows * 64; x++) dst[rows * 16 + x] = wg_ks_ky_entry(&host_tabs, rows, x);
+                dst += (size_t)rows * 80;
+            }
+            HIP_TRY(c->lookup.ensure(c->h_lookup.size() * sizeof(wg_d2)));
+            HIP_TRY(hipMemcpyAsync(c->lookup.p, c->h_lookup.data(), c->h_lookup.size() * sizeof(wg_d2), hipMemcpyHostToDevice, c->sA));   // h_lookup lives in the context
+            c->lookup_pc = P->pseudo_count; c->lookup_rows[0] = rowsA; c->lookup_rows[1] = rowsB; c->lookup_rows[2] = rowsM;
         }
-        HIP_TRY(c->lookup.ensure(c->h_lookup.size() * sizeof(wg_d2)));
-        HIP_TRY(hipMemcpyAsync(c->lookup.p, c->h_lookup.data(), c->h_lookup.size() * sizeof(wg_d2), hipMemcpyHostToDevice, c->sA));   // h_lookup lives in the context
         caA.tab = c->lookup.as<wg_d2>();
         caB.tab = caA.tab + (size_t)rowsA * 80;
         caM.tab = caB.tab + (size_t)rowsB * 80;
@@ -964,7 +1037,11 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         for (int q = 0; q <= n_stages; q++) sb[(size_t)q] = (int32_t)std::min<int64_t>((int64_t)q * S, job.max_len);
     }
     HIP_TRY(c->plan_sb.ensure(sb.size() * 4));
-    HIP_TRY(hipMemcpyAsync(c->plan_sb.p, sb.data(), sb.size() * 4, hipMemcpyHostToDevice, c->sA));
+    {
+        const void* src = sb.data();
+        if (c->h_sb.ensure(sb.size() * 4)) { memcpy(c->h_sb.p, src, sb.size() * 4); src = c->h_sb.p; }      // (page-locked: the copy does not block)
+        HIP_TRY(hipMemcpyAsync(c->plan_sb.p, src, sb.size() * 4, hipMemcpyHostToDevice, c->sA));
+    }
     HIP_TRY(c->plan_cbase.ensure((size_t)n_stages * nC * 8));
     HIP_TRY(c->plan_cum0.ensure((size_t)n_stages * nC * 4));
     HIP_TRY(c->plan_tbase.ensure((size_t)n_stages * (nC + 1) * 8 * 3));
@@ -978,33 +1055,53 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     int64_t* tbaseA = c->plan_tbase.as<int64_t>();
     int64_t* tbaseB = tbaseA + (size_t)n_stages * (nC + 1);
     int64_t* tbaseM = tbaseB + (size_t)n_stages * (nC + 1);
-    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)nC, (unsigned)n_stages), dim3(WG_BLOCK), 0, c->sA, v, pa, cntA, cntB, cntM);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_stage_plan, dim3((unsigned)n_stages), dim3(WG_BLOCK), 0, c->sA, v, pa, cntA, cntB, cntM, c->plan_cbase.as<int64_t>(),
-                       c->plan_cum0.as<uint32_t>(), tbaseA, tbaseB, tbaseM, c->plan_pairs.as<int64_t>(), c->plan_tiles.as<int64_t>());
-    HIP_TRY(hipGetLastError());
-    // medium tiles and a pseudo count whose short division has not been tried on THEIR operand pairs yet (0 <= nmeth <= ntotal <=
-    // 255 * 252: 2.1e9 pairs, ~2 ms, once per context and pseudo count, and only for a job that has windows > 60 at all)
-    const bool check_div_m = c->divs_enabled && term_modeA == 2 && WMED > 0 && Wmax > WG_NARROW_WMAX && c->divs_m_pc != P->pseudo_count;
-    if (check_div_m) {
-        HIP_TRY(c->divcheck.ensure(4));
-        HIP_TRY(hipMemsetAsync(c->divcheck.p, 0, 4, c->sA));
-        const int max_total = 255 * WG_MEDIUM_WMAX;
-        hipLaunchKernelGGL(k_check_div, dim3((unsigned)max_total + 1), dim3(WG_BLOCK), 0, c->sA, P->pseudo_count, P->pseudo_count + P->pseudo_count,
-                           max_total, c->divcheck.as<unsigned int>());
+    std::vector<int64_t> stage_pairs((size_t)n_stages), stage_tiles((size_t)n_stages * 3, 0);
+    // No window beyond the narrow tiles' (every default-parameter genome outside CpG islands): every aligned group of TI starts is ONE narrow
+    // tile, so the host knows the tile counts without asking the device (round 6: one host round trip less in front of the scoring of every
+    // batch); the scored blocks per stage — what sizes the cost buffer — from the windows' statistics: all of them in one stage, at most
+    // (sites of the stage) x (widest window) otherwise.
+    const bool all_narrow = Wmax <= WG_NARROW_WMAX;
+    bool check_div_m = false;
+    if (all_narrow) {
+        for (int stg = 0; stg < n_stages; stg++) {
+            int64_t nt = 0, sites_in = 0;
+            for (const ChunkDesc& d : job.h) {
+                const int64_t s0 = sb[(size_t)stg], s1 = std::min<int64_t>(sb[(size_t)stg + 1], d.len);
+                if (s1 > s0) { nt += (s1 - s0 + TI - 1) / TI; sites_in += s1 - s0; }
+            }
+            stage_tiles[3 * (size_t)stg] = nt;
+            stage_pairs[(size_t)stg] = n_stages == 1 ? total_pairs : std::min<int64_t>(total_pairs, sites_in * std::max(Wmax, 1));
+        }
+        hipLaunchKernelGGL(k_stage_plan, dim3((unsigned)n_stages), dim3(WG_PLAN_BLOCK), 0, c->sA, v, pa, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                           c->plan_cbase.as<int64_t>(), c->plan_cum0.as<uint32_t>(), tbaseA, tbaseB, tbaseM, c->plan_pairs.as<int64_t>(), c->plan_tiles.as<int64_t>());
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(reinterpret_cast<JobStatus*>(c->h_status.p) + 3, c->divcheck.p, 4, hipMemcpyDeviceToHost, c->sA));
+    } else {
+        hipLaunchKernelGGL(k_tile_count, dim3((unsigned)nC, (unsigned)n_stages), dim3(WG_BLOCK), 0, c->sA, v, pa, cntA, cntB, cntM);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_stage_plan, dim3((unsigned)n_stages), dim3(WG_PLAN_BLOCK), 0, c->sA, v, pa, (const uint32_t*)cntA, (const uint32_t*)cntB, (const uint32_t*)cntM,
+                           c->plan_cbase.as<int64_t>(), c->plan_cum0.as<uint32_t>(), tbaseA, tbaseB, tbaseM, c->plan_pairs.as<int64_t>(), c->plan_tiles.as<int64_t>());
+        HIP_TRY(hipGetLastError());
+        // medium tiles and a pseudo count whose short division has not been tried on THEIR operand pairs yet (0 <= nmeth <= ntotal <=
+        // 255 * 252: 2.1e9 pairs, ~2 ms, once per context and pseudo count, and only for a job that has windows > 60 at all)
+        check_div_m = c->divs_enabled && term_modeA == 2 && WMED > 0 && c->divs_m_pc != P->pseudo_count;
+        if (check_div_m) {
+            HIP_TRY(c->divcheck.ensure(4));
+            HIP_TRY(hipMemsetAsync(c->divcheck.p, 0, 4, c->sA));
+            const int max_total = 255 * WG_MEDIUM_WMAX;
+            hipLaunchKernelGGL(k_check_div, dim3((unsigned)max_total + 1), dim3(WG_BLOCK), 0, c->sA, P->pseudo_count, P->pseudo_count + P->pseudo_count,
+                               max_total, c->divcheck.as<unsigned int>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(reinterpret_cast<JobStatus*>(c->h_status.p) + 3, c->divcheck.p, 4, hipMemcpyDeviceToHost, c->sA));
+        }
+        HIP_TRY(hipMemcpyAsync(stage_pairs.data(), c->plan_pairs.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
+        HIP_TRY(hipMemcpyAsync(stage_tiles.data(), c->plan_tiles.p, (size_t)n_stages * 24, hipMemcpyDeviceToHost, c->sA));
+        HIP_TRY(hipStreamSynchronize(c->sA));
+        if (check_div_m) {
+            c->divs_m_ok = *reinterpret_cast<const unsigned int*>(&hst[3]) == 0u;
+            c->divs_m_pc = P->pseudo_count;
+            if (profiling()) fprintf(stderr, "[wgbsseg] short division core for pseudo count %g on the operand pairs of a MEDIUM tile: %s\n", (double)P->pseudo_count, c->divs_m_ok ? "verified on every pair" : "NOT exact, the full core stays");
+        }
     }
-    std::vector<int64_t> stage_pairs((size_t)n_stages), stage_tiles((size_t)n_stages * 3);
-    HIP_TRY(hipMemcpyAsync(stage_pairs.data(), c->plan_pairs.p, (size_t)n_stages * 8, hipMemcpyDeviceToHost, c->sA));
-    HIP_TRY(hipMemcpyAsync(stage_tiles.data(), c->plan_tiles.p, (size_t)n_stages * 24, hipMemcpyDeviceToHost, c->sA));
-    HIP_TRY(hipStreamSynchronize(c->sA));
-    if (check_div_m) {
-        c->divs_m_ok = *reinterpret_cast<const unsigned int*>(&hst[3]) == 0u;
-        c->divs_m_pc = P->pseudo_count;
-        if (profiling()) fprintf(stderr, "[wgbsseg] short division core for pseudo count %g on the operand pairs of a MEDIUM tile: %s\n", (double)P->pseudo_count, c->divs_m_ok ? "verified on every pair" : "NOT exact, the full core stays");
-    }
-    if (!own_stream && hst[2].first_bad != ~0ULL) return report_bad_site(c, hst[2], err, errlen);     // (scan on this stream: its verdict is here already)
     std::vector<int64_t> tileA0((size_t)n_stages + 1, 0), tileB0((size_t)n_stages + 1, 0), tileM0((size_t)n_stages + 1, 0);
     for (int stg = 0; stg < n_stages; stg++) {
         tileA0[(size_t)stg + 1] = tileA0[(size_t)stg] + stage_tiles[3 * (size_t)stg];
@@ -1033,10 +1130,14 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     const int ringN = dp_mode ? ceil_pow2(Wmax + 128) : 0;
     const int64_t state_stride = round_up(WG_DP_STATE_HDR + (int64_t)ringN + (ringN + 1) / 2, 2);   // doubles per chunk
     HIP_TRY(c->dpstate.ensure((size_t)nC * (size_t)state_stride * 8));
-    HIP_TRY(c->tmp_borders.ensure((size_t)(J + nC) * 4));
+    HIP_TRY(c->tmp_borders.ensure((size_t)(Jp + nC) * 4));
     HIP_TRY(c->nb.ensure((size_t)nC * 4));
-    HIP_TRY(c->boff.ensure((size_t)(nC + 1) * 8));
-    HIP_TRY(c->out_borders.ensure((size_t)(J + nC) * 4));
+    // the batch's result on the device: the CSR offsets of the chunks' border lists, then the lists — one buffer, so that a small batch
+    // (a follow-up batch of junction patches) comes home in ONE copy
+    const size_t out_head = (size_t)round_up((int64_t)(nC + 1) * 8, 16);
+    HIP_TRY(c->out_borders.ensure(out_head + (size_t)(J + nC) * 4));
+    int64_t* const d_boff = c->out_borders.as<int64_t>();
+    int32_t* const d_bord = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(c->out_borders.p) + out_head);
     grow_events(c->ev_cost0, n_stages); grow_events(c->ev_cost1, n_stages);
     grow_events(c->ev_dp0, n_stages); grow_events(c->ev_dp1, n_stages);
     grow_events(c->ev_fork, n_stages); grow_events(c->ev_join, n_stages);
@@ -1051,7 +1152,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
 #endif
     c->last_dp_chunks = nC; c->last_dp_stride = state_stride;
     const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16 + 1024 * 6;
-    if (own_stream && (!beside || st.wide_units)) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));      // scoring after the scan (always when it reads carries)
+    if (st.wide_units) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));      // wide tiles read the carries: scoring after the scan
     // Two scoring streams.  A scoring launch ends in a tail of partly filled workgroup slots (1280 on the chip), and a stage
     // with more than one tile class pays one per class: there the medium and wide tiles go to a second stream, beside the
     // narrow ones (they write disjoint rows of the cost buffer), forked off the first stream when the stage may begin
@@ -1122,26 +1223,36 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipEventRecord(c->ev[4], c->sB));
     hipLaunchKernelGGL(k_trace, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sB, v, c->tmp_borders.as<int32_t>(), c->nb.as<int32_t>());
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_border_offsets, dim3(1), dim3(WG_BLOCK), 0, c->sB, c->nb.as<int32_t>(), nC, c->boff.as<int64_t>());
+    hipLaunchKernelGGL(k_border_offsets, dim3(1), dim3(WG_BLOCK), 0, c->sB, c->nb.as<int32_t>(), nC, d_boff);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_gather_borders, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sB, v, c->tmp_borders.as<int32_t>(), c->nb.as<int32_t>(),
-                       c->boff.as<int64_t>(), c->out_borders.as<int32_t>());
+                       (const int64_t*)d_boff, d_bord);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[5], c->sB));
-    HIP_TRY(hipMemcpyAsync(borders_off, c->boff.p, (size_t)(nC + 1) * 8, hipMemcpyDeviceToHost, c->sB));
+    // A chunk has at most len + 1 borders: a batch whose upper bound is small comes home in one copy (offsets + lists, through a page-locked
+    // landing area); a large one sends the offsets first and then exactly the lists.
+    const size_t small_bytes = out_head + (size_t)(J + nC) * 4;
+    const bool small = small_bytes <= (512u << 10);
+    if (!c->h_out.ensure(small ? small_bytes : out_head)) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
+    HIP_TRY(hipMemcpyAsync(c->h_out.p, c->out_borders.p, small ? small_bytes : (size_t)(nC + 1) * 8, hipMemcpyDeviceToHost, c->sB));
+    if (small) HIP_TRY(hipEventRecord(c->ev[6], c->sB));
     if (J >= (1 << 20)) {
-        // a large batch: when its recurrence is done, ~0.4 ms of traceback and copies remain — just the time the host threads
+        // a large batch: when its recurrence is done, ~0.2 ms of traceback and copies remain — just the time the host threads
         // of the junction stitching need to wake up (stitch.h)
         HIP_TRY(hipEventSynchronize(c->ev_dp1[n_stages - 1]));
         wgstitch::Pool::get().heat();
     }
     HIP_TRY(hipStreamSynchronize(c->sB));
+    memcpy(borders_off, c->h_out.p, (size_t)(nC + 1) * 8);
     const int64_t total_b = borders_off[nC];
     int32_t* borders_out = alloc(total_b);
     if (!borders_out) { set_err(err, errlen, "borders_out too small: need %lld ints", (long long)total_b); return WGBSSEG_E_CAPACITY; }
-    HIP_TRY(hipMemcpyAsync(borders_out, c->out_borders.p, (size_t)total_b * 4, hipMemcpyDeviceToHost, c->sB));
-    HIP_TRY(hipEventRecord(c->ev[6], c->sB));
-    HIP_TRY(hipStreamSynchronize(c->sB));
+    if (small) memcpy(borders_out, reinterpret_cast<const char*>(c->h_out.p) + out_head, (size_t)total_b * 4);
+    else {
+        HIP_TRY(hipMemcpyAsync(borders_out, d_bord, (size_t)total_b * 4, hipMemcpyDeviceToHost, c->sB));
+        HIP_TRY(hipEventRecord(c->ev[6], c->sB));
+        HIP_TRY(hipStreamSynchronize(c->sB));
+    }
     HIP_TRY(hipStreamSynchronize(c->sA));
     HIP_TRY(hipStreamSynchronize(sS));
     // the scan's verdict (segmentor.cpp:186-189).  With the scan beside the scoring kernel an invalid file is found out at the end
@@ -1153,16 +1264,16 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     static const bool timeline = getenv("WGBSSEG_PROFILE") && atoi(getenv("WGBSSEG_PROFILE")) >= 2;
     if (timeline) {       // device time line of the batch, ms after its first event (scoring / recurrence: first and last stage)
         auto at = [&](hipEvent_t e) { float x = 0; (void)hipEventElapsedTime(&x, c->ev[0], e); return (double)x; };
-        fprintf(stderr, "[wgbsseg] batch of %d chunks, %lld sites: windows done %.3f | stats copied %.3f | scan done %.3f | plan + tiles done %.3f | "
+        fprintf(stderr, "[wgbsseg] batch of %d chunks, %lld sites: windows done %.3f | stats copied %.3f | scan pass (its own stream) %.3f .. %.3f | plan + tiles done %.3f | "
                 "scoring %.3f .. %.3f | recurrence %.3f .. %.3f | trace %.3f .. %.3f | borders on the host %.3f\n", nC, (long long)J,
-                at(c->ev[1]), at(c->ev[7]), at(c->ev[2]), at(c->ev[3]), at(c->ev_cost0[0]), at(c->ev_cost1[n_stages - 1]),
+                at(c->ev[1]), at(c->ev[7]), at(c->ev[8]), at(c->ev[2]), at(c->ev[3]), at(c->ev_cost0[0]), at(c->ev_cost1[n_stages - 1]),
                 at(c->ev_dp0[0]), at(c->ev_dp1[n_stages - 1]), at(c->ev[4]), at(c->ev[5]), at(c->ev[6]));
     }
     wgbsseg_timings& T = c->tim;
     if (!c->accumulate) memset(&T, 0, sizeof(T));
     float ms = 0;
-    // the scan pass = the one of its two launches that did the work (the other left at once): k_scan before ev[8], k_validate after
-    if (st.wide_units) HIP_TRY(hipEventElapsedTime(&ms, c->ev[7], c->ev[8])); else HIP_TRY(hipEventElapsedTime(&ms, c->ev[8], c->ev[2]));
+    // the scan pass = k_scan for a job with wide tiles (it reads every chunk row of the batch, after k_validate has read the same bytes), k_validate otherwise
+    if (st.wide_units) HIP_TRY(hipEventElapsedTime(&ms, c->ev[10], c->ev[11])); else HIP_TRY(hipEventElapsedTime(&ms, c->ev[8], c->ev[9]));
     T.scan_ms += ms;
     // algorithmic bytes of the pass: with wide units k_scan reads every chunk row of the batch; without, k_validate reads the
     // batch's not-yet-validated sites once
@@ -1888,12 +1999,13 @@ int wgbsseg_scan_only(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t
     c->validated.clear();
     if (repeat < 1) repeat = 1;
     want_carry = want_carry ? 1 : 0;
-    // want_carry 0: a fresh status block counts no wide units, so k_scan leaves at once and k_validate does the read-only pass;
-    // 1: k_scan itself — per-sample prefix sums of (meth, cov), a carry per 128 sites, the validation — as a job with wide tiles runs it
-    rc = launch_scan(c, job, want_carry, c->sA, err, errlen);           // warm-up
+    // want_carry 0: k_validate, the read-only pass of a job without wide tiles;
+    // 1: k_scan — per-sample prefix sums of (meth, cov), a carry per 128 sites, the validation — as a job with wide tiles runs it
+    auto one = [&]() { return want_carry ? launch_scan(c, job, c->sA, err, errlen) : launch_validate(c, job, c->sA, err, errlen); };
+    rc = one();           // warm-up
     if (rc != WGBSSEG_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
-    for (int r = 0; r < repeat; r++) { rc = launch_scan(c, job, want_carry, c->sA, err, errlen); if (rc != WGBSSEG_OK) return rc; }
+    for (int r = 0; r < repeat; r++) { rc = one(); if (rc != WGBSSEG_OK) return rc; }
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
     HIP_TRY(hipStreamSynchronize(c->sA));
     float ms = 0;
@@ -1915,7 +2027,7 @@ int wgbsseg_prefix_sums(wgbsseg_ctx* c, int64_t start0, int64_t len, uint32_t* o
     Job job;
     int rc = build_job(c, &start0, &l32, 1, job, false, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
-    rc = launch_scan(c, job, 1, c->sA, err, errlen);           // the carries are what k_prefix_materialise builds on
+    rc = launch_scan(c, job, c->sA, err, errlen);           // the carries are what k_prefix_materialise builds on
     if (rc != WGBSSEG_OK) return rc;
     const size_t bytes = (size_t)c->n_samples * (size_t)(len + 1) * 8;
     HIP_TRY(c->dbg_a.ensure(bytes));
