@@ -398,7 +398,7 @@ def native_segment_regions(stitch_lib, engine, params, regions, chunk_size, spec
     return [out[off[r]:off[r + 1]].astype(np.int64) for r in range(len(regions))], stats
 
 
-@pytest.mark.parametrize('speculate', [0, 1])
+@pytest.mark.parametrize('speculate', [0, 1, 1 | (128 << 8), 1 | (4 << 8)])      # (bits 8..: early delivery of the first batch with edges of that many borders)
 @pytest.mark.parametrize('name', CASES)
 def test_native_stitching_matches_reference_driver(name, speculate, driver_golden, synth_world, stitch_lib):
     g = driver_golden['cases'][name]
@@ -489,7 +489,9 @@ def test_native_stitching_on_random_worlds_with_a_fickle_engine(seed, stitch_lib
             want.append(_tree_merge(chunks, {'engine': eng}))
     except G.IllegalArgumentError as e:                    # the reference gives up (patch grew past an operand)
         failed = str(e)
-    for speculate in (0, 1):
+    # speculate: 0 / 1, and 1 with EARLY DELIVERY of the first batch (round 6: the stitcher's first rehearsal plays on the edges of the
+    # chunks' lists — 2, 16 or 128 borders each — while the shim keeps the lists themselves poisoned until finish() is called)
+    for speculate in (0, 1, 1 | (2 << 8), 1 | (16 << 8), 1 | (128 << 8)):
         eng = FickleEngine(seed, density, agree_from)
         if failed is not None:
             with pytest.raises(AssertionError, match='Patch stitching Failed'):

@@ -2147,6 +2147,41 @@ __global__ __launch_bounds__(WG_BLOCK) void k_gather_borders(JobView J, const in
     for (int x = threadIdx.x; x < n; x += WG_BLOCK) dst[x] = src[n - 1 - x];     // ascending (segmentor.cpp:30-34)
 }
 
+// k_gather_edges / k_copy_out (round 6): a whole-genome batch brings 11 MB of borders home (0.24 ms of PCIe) while what the host
+// needs FIRST — to find out which junctions still lack a patch — lies within a few dozen borders of every chunk's two ends.
+// k_gather_edges leaves the first and the last WG_EDGE borders of the leading `n_lead` items (the chunks) in a compact array
+// [item][front | back][WG_EDGE], the back right-aligned; it goes home ahead of the lists themselves, which k_copy_out then writes
+// straight into the page-locked result buffer (stores over the link, no copy engine: the small copies of the follow-up batch that
+// runs meanwhile do not queue behind it).
+#define WG_EDGE 128
+__global__ __launch_bounds__(WG_BLOCK) void k_gather_edges(const int64_t* __restrict__ boff, const int32_t* __restrict__ bord, int n_lead, int32_t* __restrict__ edges,
+                                                           int32_t* __restrict__ rest)      // rest: the lists of the items from n_lead on, back to back (they ride home with the edges)
+{
+    const int c = blockIdx.x;
+    const int64_t b0 = boff[c];
+    const int n = (int)(boff[c + 1] - b0);
+    if (c >= n_lead) {
+        int32_t* dst = rest + (b0 - boff[n_lead]);
+        for (int x = threadIdx.x; x < n; x += WG_BLOCK) dst[x] = bord[b0 + x];
+        return;
+    }
+    const int m = n < WG_EDGE ? n : WG_EDGE;
+    const int x = threadIdx.x;                                  // 0 .. 255: front | back
+    const int side = x >> 7, q = x & (WG_EDGE - 1);
+    int32_t* dst = edges + ((int64_t)c * 2 + side) * WG_EDGE;
+    if (side == 0) { if (q < m) dst[q] = bord[b0 + q]; }
+    else if (q >= WG_EDGE - m) dst[q] = bord[b0 + n - WG_EDGE + q];
+}
+
+__global__ __launch_bounds__(WG_BLOCK) void k_copy_out(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int64_t n)      // both 16-byte aligned
+{
+    const int64_t nv = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * WG_BLOCK;
+    for (int64_t x = (int64_t)blockIdx.x * WG_BLOCK + threadIdx.x; x < nv; x += stride)
+        reinterpret_cast<int4*>(dst)[x] = reinterpret_cast<const int4*>(src)[x];
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) dst[4 * nv + threadIdx.x] = src[4 * nv + threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // k_block_sums: (#meth, #cov) of every block of a blocks table in every sample — the reduction of
 // beta_to_blocks.py:101-126 (np.add.reduceat over the sample's (meth, cov) rows / the per-row slice sums of its

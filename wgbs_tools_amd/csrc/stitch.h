@@ -32,6 +32,10 @@ struct Run { const int32_t* p; int64_t n; int64_t add; };   // n >= 1, values st
 
 struct Rope {
     std::vector<Run> runs;
+    // A rope over the EDGE of a list that has not arrived in full (BatchResult::edges): the walks below may run off the part that is there —
+    // then the answer is unknown, `undecided` says so and the caller sets the junction aside.
+    bool partial = false;
+    mutable bool undecided = false;
     int64_t front() const { return runs.front().p[0] + runs.front().add; }
     int64_t back() const { return runs.back().p[runs.back().n - 1] + runs.back().add; }
     int64_t span() const { return back() - front(); }
@@ -63,6 +67,7 @@ struct Rope {
                 if ((int64_t)r.p[q] < xr) return false;
             }
         }
+        if (partial) { undecided = true; return false; }
         return budget > 0 ? false : contains(x, run_idx, pos);
     }
     bool contains_near_front(int64_t x, size_t* run_idx = nullptr, int64_t* pos = nullptr) const
@@ -76,6 +81,7 @@ struct Rope {
                 if ((int64_t)r.p[q] > xr) return false;
             }
         }
+        if (partial) { undecided = true; return false; }
         return budget > 0 ? false : contains(x, run_idx, pos);
     }
     // keep everything up to and including value x (x must be present; it lies near the end)
@@ -302,6 +308,14 @@ struct BatchResult {
     std::vector<const int32_t*> ptr;         // [items]
     std::vector<int64_t> cnt;                // [items]
     std::vector<std::unique_ptr<int32_t[]>> owned;   // optional owners of what `ptr` points into
+    // Early delivery (optional).  The caller sets n_lead = the number of leading items (the chunks of the grid) whose lists it can do without
+    // for a while; a batch function that can deliver early then returns with cnt[] of every item, ptr[] of the others (the junction patches)
+    // and `edges` valid — [n_lead][front | back][edge_n] borders: the first and the last min(edge_n, cnt) entries of every leading list, the
+    // back right-aligned — while the leading lists themselves are still in flight: ptr[i < n_lead] may be read after finish() has returned 0.
+    int64_t n_lead = 0;
+    const int32_t* edges = nullptr;
+    int32_t edge_n = 0;
+    std::function<int(std::string&)> finish;
     // CSR form: item i = flat[off[i] .. off[i+1])
     void set_csr(const int32_t* flat, const int64_t* off, size_t n)
     {
@@ -428,6 +442,7 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     mark("grid + patch list");
     keep.emplace_back(new BatchResult());
     BatchResult& first = *keep.back();
+    first.n_lead = speculate ? n_chunks : 0;                   // (early delivery, if the batch function offers it: see BatchResult)
     int rc = timed_batch(items, first);
     mark("first batch");
     const int64_t us_first = us_batches;
@@ -442,61 +457,102 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     // every junction now against those two chunks, collect ALL missing patches, and fetch them in one batch (repeat while
     // something is missing).  Only the cache is filled here; the tree then does the real work and, where the rehearsal
     // could not foresee a request (a patch outgrowing its chunk), still asks for it.
+    // Round 6: with early delivery the first pass plays against the EDGES of the chunks' lists while the lists themselves
+    // (11 MB for a genome) are still on their way, and the follow-up batch runs beside their transfer; a junction whose
+    // walk runs off an edge is set aside for the passes on the full lists.
     Pool& pool = Pool::get();
-    if (speculate) {
-        std::vector<Junction> pend = junctions;
-        struct Sim { std::vector<Sites> want; bool still = false; };
-        for (int pass = 0; pass < 4 && !pend.empty(); pass++) {
-            // every junction against the cache as it stands (read-only: the junctions run on the pool's threads) ...
-            std::vector<Sim> sims(pend.size());
-            pool.run((int64_t)pend.size(), [&](int64_t k) {
-                const Junction& jn = pend[(size_t)k];
-                Sim& out = sims[(size_t)k];
-                const size_t li = (size_t)jn.left_item, ri = (size_t)jn.right_item;
-                const int64_t llen = items[li].second - items[li].first, rlen = items[ri].second - items[ri].first;
-                Stitch t;
-                Rope a, b;
+    struct Sim { std::vector<Sites> want; bool still = false, unknown = false; };
+    auto play = [&](const std::vector<Junction>& pend, bool on_edges, std::vector<Sim>& sims) {
+        sims.assign(pend.size(), Sim());
+        const int64_t E = first.edge_n;
+        pool.run((int64_t)pend.size(), [&](int64_t k) {
+            const Junction& jn = pend[(size_t)k];
+            Sim& out = sims[(size_t)k];
+            const size_t li = (size_t)jn.left_item, ri = (size_t)jn.right_item;
+            const int64_t llen = items[li].second - items[li].first, rlen = items[ri].second - items[ri].first;
+            Stitch t;
+            Rope a, b;
+            if (on_edges) {
+                const int64_t ml = std::min<int64_t>(E, first.cnt[li]), mr = std::min<int64_t>(E, first.cnt[ri]);
+                a.runs.push_back(Run{first.edges + ((int64_t)li * 2 + 1) * E + (E - ml), ml, items[li].first});      // the last ml borders of the left chunk
+                b.runs.push_back(Run{first.edges + ((int64_t)ri * 2) * E, mr, items[ri].first});                      // the first mr of the right one
+                a.partial = ml < first.cnt[li]; b.partial = mr < first.cnt[ri];
+            } else {
                 a.runs.push_back(Run{first.ptr[li], first.cnt[li], items[li].first});
                 b.runs.push_back(Run{first.ptr[ri], first.cnt[ri], items[ri].first});
-                std::string e2;
-                if (!t.init(std::move(a), std::move(b), e2)) return;
-                t.n1 = jn.n1; t.n2 = jn.n2;
-                t.p1 = std::min<int64_t>(50, t.n1); t.p2 = std::min<int64_t>(50, t.n2);
-                while (!t.done) {
-                    Sites w;
-                    if (!t.want(w, e2) || t.p1 > llen || t.p2 > rlen) break;       // the tree will deal with it
-                    const Patch* it = cache.find(w);
-                    if (it == nullptr || it->p == nullptr) {
-                        out.want.push_back(w);
-                        const int64_t j = t.b1.back();
-                        const int64_t q1 = increase_patch(t.p1, t.n1), q2 = increase_patch(t.p2, t.n2);
-                        const Sites alt[3] = {{j - q1, j + t.p2}, {j - t.p1, j + q2}, {j - q1, j + q2}};
-                        const bool ok[3] = {q1 <= t.n1, q2 <= t.n2, q1 <= t.n1 && q2 <= t.n2};
-                        for (int q = 0; q < 3; q++) if (ok[q]) out.want.push_back(alt[q]);
-                        out.still = true;
-                        break;
-                    }
-                    t.feed(it->p, it->n, w.first);
+            }
+            std::string e2;
+            if (!t.init(std::move(a), std::move(b), e2)) return;
+            t.n1 = jn.n1; t.n2 = jn.n2;
+            t.p1 = std::min<int64_t>(50, t.n1); t.p2 = std::min<int64_t>(50, t.n2);
+            while (!t.done) {
+                Sites w;
+                if (!t.want(w, e2) || t.p1 > llen || t.p2 > rlen) break;       // the tree will deal with it
+                const Patch* it = cache.find(w);
+                if (it == nullptr || it->p == nullptr) {
+                    out.want.push_back(w);
+                    const int64_t j = t.b1.back();
+                    const int64_t q1 = increase_patch(t.p1, t.n1), q2 = increase_patch(t.p2, t.n2);
+                    const Sites alt[3] = {{j - q1, j + t.p2}, {j - t.p1, j + q2}, {j - q1, j + q2}};
+                    const bool ok[3] = {q1 <= t.n1, q2 <= t.n2, q1 <= t.n1 && q2 <= t.n2};
+                    for (int q = 0; q < 3; q++) if (ok[q]) out.want.push_back(alt[q]);
+                    out.still = true;
+                    break;
                 }
-            });
+                t.feed(it->p, it->n, w.first);
+                if (t.b1.undecided || t.b2.undecided || t.result.undecided) { out.unknown = true; out.want.clear(); out.still = false; break; }
+            }
+        });
+    };
+    // what the junctions `pend` still miss (in junction order), fetched in one batch; -> the junctions to play again
+    auto fetch = [&](const std::vector<Junction>& pend, const std::vector<Sim>& sims, std::vector<Junction>& again, bool& fetched) -> int {
+        std::vector<Sites> need;
+        for (size_t k = 0; k < pend.size(); k++) {
+            for (const Sites& w : sims[k].want) if (!cache.count(w)) { cache[w] = Patch{nullptr, 0}; need.push_back(w); }
+            if (sims[k].still || sims[k].unknown) again.push_back(pend[k]);
+        }
+        mark("  rehearsal: list of missing patches");
+        fetched = !need.empty();
+        if (need.empty()) return 0;
+        keep.emplace_back(new BatchResult());
+        BatchResult& res = *keep.back();
+        const int r = timed_batch(need, res);
+        if (r != 0) return r;
+        n_batches++;
+        for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = Patch{res.ptr[i], res.cnt[i]}; n_patch_dp++; }
+        mark("  rehearsal: follow-up batch");
+        return 0;
+    };
+    std::vector<Junction> pend;
+    if (speculate) pend = junctions;
+    if (first.finish) {
+        if (speculate && first.edges && first.edge_n > 0) {
+            std::vector<Sim> sims;
+            play(pend, true, sims);
+            mark("  rehearsal on the edges: junctions against the cache");
+            std::vector<Junction> again;
+            bool fetched = false;
+            rc = fetch(pend, sims, again, fetched);
+            if (rc != 0) { std::string e2; (void)first.finish(e2); return rc; }
+            pend.swap(again);
+        }
+        rc = first.finish(err);
+        mark("  the chunks' lists are home");
+        if (rc != 0) return rc;
+    }
+    if (speculate) {
+        for (int pass = 0; pass < 4 && !pend.empty(); pass++) {
+            // every junction against the cache as it stands (read-only: the junctions run on the pool's threads) ...
+            std::vector<Sim> sims;
+            play(pend, false, sims);
             mark("  rehearsal: junctions against the cache");
             // ... then, in junction order, what is missing
-            std::vector<Sites> need;
-            std::vector<Junction> still;
-            for (size_t k = 0; k < pend.size(); k++) {
-                for (const Sites& w : sims[k].want) if (!cache.count(w)) { cache[w] = Patch{nullptr, 0}; need.push_back(w); }
-                if (sims[k].still) still.push_back(pend[k]);
-            }
-            mark("  rehearsal: list of missing patches");
-            if (need.empty()) break;
-            keep.emplace_back(new BatchResult());
-            BatchResult& res = *keep.back();
-            rc = timed_batch(need, res);
+            std::vector<Junction> again;
+            bool fetched = false;
+            rc = fetch(pend, sims, again, fetched);
             if (rc != 0) return rc;
-            n_batches++;
-            for (size_t i = 0; i < need.size(); i++) { cache[need[i]] = Patch{res.ptr[i], res.cnt[i]}; n_patch_dp++; }
-            pend.swap(still);
-            mark("  rehearsal: follow-up batch");
+            if (!fetched) break;
+            pend.swap(again);
         }
     }
     mark("rehearsal (incl. its batches)");
@@ -603,7 +659,26 @@ inline int segment_regions(const int64_t* region_start, const int64_t* region_en
     for (int64_t r = 0; r < n_regions; r++) { borders_off[r] = total; total += lists[(size_t)r][0].size(); }
     borders_off[n_regions] = total;
     if (total > borders_cap) { err = "borders_out too small: need " + std::to_string(total); return E_CAPACITY; }
-    pool.run(n_regions, [&](int64_t r) { lists[(size_t)r][0].flatten(borders_out + borders_off[r]); });
+    {   // pieces of ~64 k borders (whole runs) rather than whole regions: chr1 holds 9 % of a genome's borders, and the threads that got the small
+        // chromosomes would wait for the one that got it
+        struct Piece { const Run* r0; const Run* r1; int32_t* out; };
+        std::vector<Piece> pieces;
+        for (int64_t r = 0; r < n_regions; r++) {
+            const std::vector<Run>& rr = lists[(size_t)r][0].runs;
+            int32_t* out = borders_out + borders_off[r];
+            int64_t acc = 0;
+            size_t start = 0;
+            for (size_t i = 0; i < rr.size(); i++) {
+                acc += rr[i].n;
+                if (acc >= 65536 || i + 1 == rr.size()) { pieces.push_back(Piece{rr.data() + start, rr.data() + i + 1, out}); out += acc; acc = 0; start = i + 1; }
+            }
+        }
+        pool.run((int64_t)pieces.size(), [&](int64_t k) {
+            const Piece& pc = pieces[(size_t)k];
+            int32_t* out = pc.out;
+            for (const Run* q = pc.r0; q != pc.r1; q++) { const int32_t a = (int32_t)q->add; for (int64_t x = 0; x < q->n; x++) out[x] = q->p[x] + a; out += q->n; }
+        });
+    }
     mark("flatten");
     if (prof) {
         for (size_t i = 1; i < marks.size(); i++)

@@ -123,7 +123,11 @@ struct wgbsseg_ctx {
     DevBuf plan_cbase, plan_cum0, plan_tbase, plan_pairs, plan_tiles, plan_cnt, tilesA, tilesB, tilesM, umax16;
     std::vector<PinnedBuf> pinned;
     std::vector<PinnedBuf> up_stage;   // two page-locked staging pieces per upload thread (set_betas_host)
-    DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders, dbg_a, dbg_b, dbg_c, lookup;
+    DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders[2], edges, dbg_a, dbg_b, dbg_c, lookup;
+    int out_par = 0;              // which of the two result buffers the batch in flight writes: the lists of the previous batch may still be on their way home (below)
+    hipStream_t sD = nullptr;     // early delivery (segment_regions' first batch): k_copy_out writes the chunks' border lists into the page-locked result ...
+    hipEvent_t evD = nullptr;     // ... while the host already rehearses the junctions on the lists' edges and runs the follow-up batch; evD: the lists are home
+    bool out_pending = false;
     std::vector<wg_d2> h_lookup;   // host copy of the k-scaled log tables of the call in flight (source of an async upload)
     float lookup_pc = -1.0f;       // what the device copy `lookup` was built for: pseudo count and exponent rows of the narrow / wide / medium class
     int lookup_rows[3] = {-1, -1, -1};
@@ -277,6 +281,8 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     }
     if (!c->sC) HIP_TRY(hipStreamCreateWithFlags(&c->sC, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->sA2, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->sD, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->evD, hipEventDisableTiming));
     for (auto& v : c->ev) HIP_TRY(hipEventCreate(&v));
     const char* b = getenv("WGBSSEG_COST_BUDGET_MB");
     c->cost_budget_bytes = (b && atoll(b) > 0 ? atoll(b) : 6144LL) << 20;
@@ -305,7 +311,7 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->wtile, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs, &c->tile_tot, &c->tile_base, &c->tile_chunk,
                      &c->status, &c->plan_cbase, &c->plan_cum0, &c->plan_tbase, &c->plan_pairs, &c->plan_tiles, &c->plan_cnt, &c->tilesA, &c->tilesB, &c->tilesM, &c->umax16,
-                     &c->cost[0], &c->cost[1], &c->dpstate, &c->tmp_borders, &c->nb, &c->boff, &c->out_borders,
+                     &c->cost[0], &c->cost[1], &c->dpstate, &c->tmp_borders, &c->nb, &c->boff, &c->out_borders[0], &c->out_borders[1], &c->edges,
                      &c->dbg_a, &c->dbg_b, &c->dbg_c, &c->lookup, &c->scan_pieces, &c->divcheck, &c->plan_sb, &c->bs_desc};
     for (auto* b : all) b->release();
     for (auto& pb : c->pinned) pb.release();
@@ -321,6 +327,8 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     if (c->sB) (void)hipStreamDestroy(c->sB);
     if (c->sC) (void)hipStreamDestroy(c->sC);
     if (c->sA2) (void)hipStreamDestroy(c->sA2);
+    if (c->sD) (void)hipStreamDestroy(c->sD);
+    if (c->evD) (void)hipEventDestroy(c->evD);
     delete c;
     if (profiling()) fprintf(stderr, "[wgbsseg] destroy: %.1f ms\n", (wall_s() - t0) * 1e3);
 }
@@ -632,8 +640,27 @@ extern "C" {
 namespace {
 typedef std::function<int32_t*(int64_t)> BorderAlloc;       // total border count -> destination (NULL: too small)
 
+// Early delivery of a batch's result (the first batch of a region-level call; the destination must be page-locked, i.e. device-visible):
+// the call returns when the CSR offsets, the lists of the items from `n_lead` on (junction patches) and the EDGES of the leading items'
+// lists (the chunks: first / last WG_EDGE borders each) are on the host; the leading items' lists are still being written by k_copy_out
+// and are complete after wait_pending_output().
+struct EarlyOut {
+    int64_t n_lead = 0;              // in: leading items whose lists may come late (0: no early delivery)
+    bool dest_device_visible = false;   // in (set by the caller's BorderAlloc): the destination it handed out is page-locked memory the device can write
+    const int32_t* edges = nullptr;  // out: [n_lead][front | back][WG_EDGE], the back right-aligned (valid until the context's next batch)
+    bool pending = false;            // out: the leading lists are still on their way
+};
+int wait_pending_output(wgbsseg_ctx* c, char* err, size_t errlen)
+{
+    if (!c->out_pending) return WGBSSEG_OK;
+    c->out_pending = false;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->evD));
+    return WGBSSEG_OK;
+}
+
 int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
-                        const wgbsseg_params* P, const BorderAlloc& alloc, int64_t* borders_off, char* err, size_t errlen, bool allow_plain = true);
+                        const wgbsseg_params* P, const BorderAlloc& alloc, int64_t* borders_off, char* err, size_t errlen, bool allow_plain = true, EarlyOut* early = nullptr);
 
 // One chunk whose loci are not ascending, the reference's loops as written (csrc/plain_dp.h): ascending borders incl. 0 and len.
 int plain_segment_chunk(wgbsseg_ctx* c, int64_t start0, int32_t n, const wgbsseg_params* P, std::vector<int32_t>& borders, char* err, size_t errlen)
@@ -740,7 +767,7 @@ int segment_chunks_with_disorder(wgbsseg_ctx* c, const int64_t* chunk_start0, co
 }
 
 int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32_t* chunk_len, int64_t n_chunks,
-                        const wgbsseg_params* P, const BorderAlloc& alloc, int64_t* borders_off, char* err, size_t errlen, bool allow_plain)
+                        const wgbsseg_params* P, const BorderAlloc& alloc, int64_t* borders_off, char* err, size_t errlen, bool allow_plain, EarlyOut* early)
 {
     if (!P || !borders_off) { set_err(err, errlen, "NULL params/borders pointer"); return WGBSSEG_E_ARG; }
     if (P->max_bp == 0) { set_err(err, errlen, "max_bp must be >= 1 (the reference reads uninitialised loci when it is 0: segmentor.cpp:38,114)"); return WGBSSEG_E_ARG; }
@@ -1135,9 +1162,11 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // the batch's result on the device: the CSR offsets of the chunks' border lists, then the lists — one buffer, so that a small batch
     // (a follow-up batch of junction patches) comes home in ONE copy
     const size_t out_head = (size_t)round_up((int64_t)(nC + 1) * 8, 16);
-    HIP_TRY(c->out_borders.ensure(out_head + (size_t)(J + nC) * 4));
-    int64_t* const d_boff = c->out_borders.as<int64_t>();
-    int32_t* const d_bord = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(c->out_borders.p) + out_head);
+    c->out_par ^= 1;                                             // (the other buffer may still be feeding k_copy_out of the previous batch)
+    DevBuf& outb = c->out_borders[c->out_par];
+    HIP_TRY(outb.ensure(out_head + (size_t)(J + nC) * 4));
+    int64_t* const d_boff = outb.as<int64_t>();
+    int32_t* const d_bord = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(outb.p) + out_head);
     grow_events(c->ev_cost0, n_stages); grow_events(c->ev_cost1, n_stages);
     grow_events(c->ev_dp0, n_stages); grow_events(c->ev_dp1, n_stages);
     grow_events(c->ev_fork, n_stages); grow_events(c->ev_join, n_stages);
@@ -1230,12 +1259,27 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[5], c->sB));
     // A chunk has at most len + 1 borders: a batch whose upper bound is small comes home in one copy (offsets + lists, through a page-locked
-    // landing area); a large one sends the offsets first and then exactly the lists.
+    // landing area); a large one sends the offsets first and then exactly the lists — or, when the caller can use them (EarlyOut), the offsets
+    // with the edges of the leading items' lists, then the other items' lists, and the leading lists by k_copy_out behind the caller's back.
     const size_t small_bytes = out_head + (size_t)(J + nC) * 4;
     const bool small = small_bytes <= (512u << 10);
-    if (!c->h_out.ensure(small ? small_bytes : out_head)) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
-    HIP_TRY(hipMemcpyAsync(c->h_out.p, c->out_borders.p, small ? small_bytes : (size_t)(nC + 1) * 8, hipMemcpyDeviceToHost, c->sB));
-    if (small) HIP_TRY(hipEventRecord(c->ev[6], c->sB));
+    const int64_t n_lead = (early && !small && early->n_lead > 0 && early->n_lead <= nC) ? early->n_lead : 0;
+    // early delivery: the edges of the leading lists and, behind them, the lists of the other items (their size bounded by len + 1 each) ride
+    // home with the offsets in one copy
+    size_t rest_cap = 0;
+    if (n_lead) for (int64_t i = n_lead; i < nC; i++) rest_cap += (size_t)job.h[(size_t)i].len + 1;
+    const size_t edge_bytes = (size_t)n_lead * 2 * WG_EDGE * 4, rest_bytes = rest_cap * 4;
+    if (n_lead) {
+        HIP_TRY(c->edges.ensure(edge_bytes + rest_bytes + 16));
+        hipLaunchKernelGGL(k_gather_edges, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sB, (const int64_t*)d_boff, (const int32_t*)d_bord, (int)n_lead, c->edges.as<int32_t>(),
+                           c->edges.as<int32_t>() + edge_bytes / 4);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[5], c->sB));
+    }
+    if (!c->h_out.ensure((small ? small_bytes : out_head) + edge_bytes + rest_bytes)) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
+    HIP_TRY(hipMemcpyAsync(c->h_out.p, outb.p, small ? small_bytes : (size_t)(nC + 1) * 8, hipMemcpyDeviceToHost, c->sB));
+    if (n_lead) HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(c->h_out.p) + out_head, c->edges.p, edge_bytes + rest_bytes, hipMemcpyDeviceToHost, c->sB));
+    if (small || n_lead) HIP_TRY(hipEventRecord(c->ev[6], c->sB));
     if (J >= (1 << 20)) {
         // a large batch: when its recurrence is done, ~0.2 ms of traceback and copies remain — just the time the host threads
         // of the junction stitching need to wake up (stitch.h)
@@ -1248,7 +1292,17 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     int32_t* borders_out = alloc(total_b);
     if (!borders_out) { set_err(err, errlen, "borders_out too small: need %lld ints", (long long)total_b); return WGBSSEG_E_CAPACITY; }
     if (small) memcpy(borders_out, reinterpret_cast<const char*>(c->h_out.p) + out_head, (size_t)total_b * 4);
-    else {
+    else if (n_lead && early->dest_device_visible && (reinterpret_cast<uintptr_t>(borders_out) & 15) == 0) {
+        const int64_t lead_b = borders_off[n_lead];              // the leading items' borders: [0, lead_b) of the lists
+        HIP_TRY(hipStreamWaitEvent(c->sD, c->ev[5], 0));
+        hipLaunchKernelGGL(k_copy_out, dim3(512), dim3(WG_BLOCK), 0, c->sD, (const int32_t*)d_bord, borders_out, lead_b);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->evD, c->sD));
+        c->out_pending = true;
+        memcpy(borders_out + lead_b, reinterpret_cast<const char*>(c->h_out.p) + out_head + edge_bytes, (size_t)(total_b - lead_b) * 4);
+        early->edges = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(c->h_out.p) + out_head);
+        early->pending = true;
+    } else {
         HIP_TRY(hipMemcpyAsync(borders_out, d_bord, (size_t)total_b * 4, hipMemcpyDeviceToHost, c->sB));
         HIP_TRY(hipEventRecord(c->ev[6], c->sB));
         HIP_TRY(hipStreamSynchronize(c->sB));
@@ -1334,7 +1388,7 @@ namespace {
 // One GPU batch on one context: 0-based resident-relative site ranges -> CSR of relative borders in page-locked memory
 // that stays alive in the context (buffer `slot` of c->pinned) while ropes point into it.
 int run_ctx_batch(wgbsseg_ctx* c, const std::vector<int64_t>& st0, const std::vector<int32_t>& ln, const wgbsseg_params* P, int64_t slot,
-                  bool accumulate, const int32_t*& flat, std::vector<int64_t>& off, std::unique_ptr<int32_t[]>& owned, std::string& msg)
+                  bool accumulate, const int32_t*& flat, std::vector<int64_t>& off, std::unique_ptr<int32_t[]>& owned, std::string& msg, EarlyOut* early = nullptr)
 {
     off.resize(st0.size() + 1);
     int32_t* dst = nullptr;
@@ -1342,13 +1396,14 @@ int run_ctx_batch(wgbsseg_ctx* c, const std::vector<int64_t>& st0, const std::ve
         if (c->pinned.size() <= (size_t)slot) c->pinned.resize((size_t)slot + 1);
         PinnedBuf& pb = c->pinned[(size_t)slot];
         dst = pb.ensure((size_t)std::max<int64_t>(total, 1) * 4) ? reinterpret_cast<int32_t*>(pb.p) : nullptr;
+        if (early) early->dest_device_visible = dst != nullptr;
         if (!dst) { owned.reset(new int32_t[(size_t)std::max<int64_t>(total, 1)]); dst = owned.get(); }   // pageable fallback
         return dst;
     };
     char ebuf[512] = {0};
     const bool acc_before = c->accumulate;
     c->accumulate = accumulate;
-    const int rc = segment_chunks_impl(c, st0.data(), ln.data(), (int64_t)st0.size(), P, alloc, off.data(), ebuf, sizeof(ebuf));
+    const int rc = segment_chunks_impl(c, st0.data(), ln.data(), (int64_t)st0.size(), P, alloc, off.data(), ebuf, sizeof(ebuf), true, early);
     c->accumulate = acc_before;
     if (rc != WGBSSEG_OK) { msg = ebuf; return rc; }
     flat = dst;
@@ -1386,16 +1441,34 @@ int wgbsseg_segment_regions(wgbsseg_ctx* c, const int64_t* region_start, const i
         }
         const int32_t* flat = nullptr;
         std::unique_ptr<int32_t[]> owned;
-        const int rc = run_ctx_batch(c, st0, ln, P, n_batches, n_batches > 0, flat, off, owned, msg);
+        // the stitcher can start on the edges of the chunks' lists (res.n_lead = its number of chunks): ask for early delivery
+        static const bool early_on = !(getenv("WGBSSEG_NO_EARLY") && atoi(getenv("WGBSSEG_NO_EARLY")));
+        EarlyOut eo;
+        eo.n_lead = early_on ? res.n_lead : 0;
+        const int rc = run_ctx_batch(c, st0, ln, P, n_batches, n_batches > 0, flat, off, owned, msg, eo.n_lead > 0 ? &eo : nullptr);
         if (rc != WGBSSEG_OK) return rc;
         if (owned) res.owned.push_back(std::move(owned));
         res.set_csr(flat, off.data(), todo.size());
+        if (eo.pending) {
+            res.edges = eo.edges; res.edge_n = WG_EDGE;
+            res.finish = [c](std::string& m) -> int {
+                char e[256] = {0};
+                const int r = wait_pending_output(c, e, sizeof e);
+                if (r != WGBSSEG_OK) m = e;
+                return r;
+            };
+        }
         n_batches++;
         return WGBSSEG_OK;
     };
     std::string msg;
-    const int rc = wgstitch::segment_regions(region_start, region_end, n_regions, chunk_size, run_batch, borders_out, borders_cap,
-                                             borders_off, stats, msg, speculation_on());
+    int rc = wgstitch::segment_regions(region_start, region_end, n_regions, chunk_size, run_batch, borders_out, borders_cap,
+                                       borders_off, stats, msg, speculation_on());
+    {   // (an error path of the stitcher may have left the first batch's lists on their way: nothing may write into the context's buffers after this call)
+        char e[256] = {0};
+        const int r2 = wait_pending_output(c, e, sizeof e);
+        if (rc == 0 && r2 != WGBSSEG_OK) { rc = r2; msg = e; }
+    }
     if (profiling()) {
         fprintf(stderr, "[wgbsseg] segment_regions: %lld batches; allocations since the last report: %lld calls, %.1f MB, %.1f ms; "
                 "device ms: scan %.2f window %.2f cost %.2f dp %.2f trace %.2f, time line %.2f\n",
