@@ -78,6 +78,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='wall-time budget of the CPU baseline runs (0: skip)')
     ap.add_argument('--extras', type=int, default=1, help='also time convert, pat2beta and the find_markers statistics (1 GPU only; 0: skip)')
     ap.add_argument('--e2e', type=int, default=1, help='also time the CLI end to end on page-cached files (1 GPU only; 0: skip)')
+    ap.add_argument('--oversubscribe', action='store_true',
+                    help='dry runs of the N > 1 forms on fewer GPUs than shares / ranks (several shares per device): without this flag such a launch is refused')
     return ap.parse_args()
 
 
@@ -476,6 +478,17 @@ def device_report(form, asked, placements):
             'oversubscribed': distinct < units, 'sharding': what}
 
 
+def refuse_oversubscription(form, asked, units, devices_visible, allowed):
+    """None when every share (share group) / rank (one process per GPU) of an N > 1 launch gets a GPU of its own, or when the launch opted in with
+    --oversubscribe; otherwise the message bench.py dies with: a `--gpus 8` run on a box with one GPU must not end as a quiet line that says
+    n_gpus 1.  Pure function (tests/test_bench_report_cpu.py)."""
+    if form == 'one' or allowed or devices_visible >= units:
+        return None
+    return ('bench.py: --gpus %d asks for %d %s but this host shows %d GPU%s: the shares would double up and the line would not be a %d-GPU measurement. '
+            'Run it on a node with %d GPUs, or pass --oversubscribe for a dry run of the N > 1 plumbing (the line then says n_gpus = the distinct devices and OVERSUBSCRIBED).'
+            % (asked, units, 'shares of one process' if form == 'group' else 'ranks', devices_visible, '' if devices_visible == 1 else 's', units, units))
+
+
 def accumulate(acc, t):
     if acc is None:
         return dict(t)
@@ -498,7 +511,12 @@ def main():
     # /dev/shm slots) on a 1-GPU box, with ONE rank when WGBSSEG_BENCH_DIST=1 (torch.distributed.run --nproc-per-node 1)
     multi = world > 1 or (os.environ.get('WGBSSEG_BENCH_DIST') == '1' and 'RANK' in os.environ)
     group_mode = not multi and args.gpus > 1    # ONE process drives --gpus GPUs (the product's `wgbstools segment --gpus N`)
-    oversub = world > 1 and ndev < world            # test mode: more ranks than GPUs (e.g. 2 ranks on a 1-GPU box)
+    oversub = world > 1 and ndev < world            # dry-run mode: more ranks than GPUs (e.g. 2 ranks on a 1-GPU box)
+    refusal = refuse_oversubscription('ranks' if multi else 'group' if group_mode else 'one', args.gpus, world if multi else args.gpus, ndev, args.oversubscribe)
+    if refusal:
+        if rank == 0:
+            print(refusal, file=sys.stderr, flush=True)
+        sys.exit(2)
     local = local % max(1, ndev)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)

@@ -108,7 +108,14 @@ int wgbsseg_set_loci_device(wgbsseg_ctx* ctx, const void* loci, int64_t n_sites,
  * integers the reference prints (segmentor.cpp:30-34) — are borders_out[borders_off[c] .. borders_off[c+1]).
  * borders_off has n_chunks+1 entries; borders_cap >= sum(chunk_len) + n_chunks always suffices.
  * Errors the reference also raises: #meth > #cov inside a requested chunk (message names sample and site).
- * Rejected up front: max_bp == 0 (reference UB), max_cpg < 1, chunk out of range, and blocks of more than WGBSSEG_MAX_CPG =
+ * Rejected up front (WGBSSEG_E_ARG), every one of them:
+ *   - max_bp == 0: the reference then reads loci it never loaded (segmentor.cpp:38,114: undefined behaviour); unreachable from its CLI (segment.py:65-66);
+ *   - max_cpg < 1;
+ *   - pseudo_count < 0 or NaN: the reference computes SOMETHING there (p = (nmeth + pc) / (ntotal + 2 pc) may leave [0, 1]: log2 of a negative number is
+ *     NaN, the double sum goes NaN and its comparisons decide the borders), but nothing a user can mean — `-ps` is a pseudo COUNT, segment.py:276 defaults
+ *     it to 15 — and the exactness proofs of csrc/exact_log2.h cover pseudo counts >= 0 only.  A deliberate divergence: an error here, garbage there;
+ *   - a chunk that is empty, longer than 2^30 sites or outside the resident sites; NULL pointers; n_chunks < 1;
+ *   - blocks of more than WGBSSEG_MAX_CPG =
  * 65535 sites — i.e. min(max_cpg, longest chunk of the call) > 65535 (a window never exceeds its chunk, segmentor.cpp:110).
  * The reference sizes its ring to any max_cpg (segmentor.cpp:92-95); but with 255 * block sites >= 2^24 (65,794 sites) its own
  * float sums of the counts (segmentor.cpp:122-123) stop being exact, so nothing above that is reproducible from prefix sums

@@ -10,6 +10,8 @@ produce on a seeded synthetic genome.  What is replaced, and only that:
                                       reference's own shell pipelines in genomic_region.py (tabix | awk ...)
 Everything else — load_bed, add_cpgs_to_bed, chr_thread (merge_asof joins, end rules, drops), slow_conversion,
 GenomicRegion's parsing, range rules and __str__ — is the reference's own code.  Writes tests/golden/convert_cases.json.
+Round 6: the fixture says which vectors went through the `tabix` stand-in (`via_tabix_shim`), and holds a cross-check of the stand-in
+against the reference's own tabix-free path (`shim_cross_check`: 400 random regions through the pipeline AND through chr_thread's joins).
 """
 import contextlib
 import gzip
@@ -203,6 +205,38 @@ def main():
             fixture['sites'][s] = {'sites': list(g.sites), 'str': str(g), 'region_str': g.region_str}
         except rg.IllegalArgumentError as e:
             fixture['sites'][s] = {'error': str(e), 'stderr': err.getvalue()}
+    # Which vectors went through the `tabix` stand-in, and a cross-check of the stand-in that does not: the reference has TWO code paths from a region
+    # to its sites — GenomicRegion's `tabix | awk` pipeline (the stand-in answers the tabix half) and chr_thread's merge_asof joins (pure pandas over
+    # our loci array: no tabix anywhere).  For a region that holds a CpG they agree by the reference's own rules, except that a CpG exactly AT the
+    # region's end is left out by the pipeline (genomic_region.py:147-150) and kept by the joins (convert.py:169): on 400 random regions the two paths
+    # are compared here, and every vector is stored so that the suite can hold the product against both.
+    fixture['via_tabix_shim'] = {'bed': {'clean_shuffled': False, 'three_columns_sorted': False, 'with_header': False,
+                                         'overlaps_in_chr2': 'the rows of chr2 only (overlaps: slow_conversion -> GenomicRegion); its chr1 rows take chr_thread'},
+                                 'regions': True, 'sites': True, 'shim_free_cross_check': False}
+    rng2 = np.random.default_rng(SEED + 1)
+    cf = pd.DataFrame({'chr': names, 'size': np.cumsum(sizes)})
+    rows, agree, n_end_on = [], 0, 0
+    for k in range(400):
+        ci = int(rng2.integers(0, 3))
+        L = loci[cum[ci]:cum[ci + 1]].astype(np.int64)
+        i0 = int(rng2.integers(0, L.size - 40)); i1 = i0 + int(rng2.integers(1, 39))
+        a = int(L[i0]) - int(rng2.integers(0, 2)) * int(rng2.integers(0, max(1, min(50, int(L[i0]) - (int(L[i0 - 1]) if i0 else 0) - 1))))
+        end_on = bool(rng2.integers(0, 3) == 0)
+        b = int(L[i1]) if end_on else int(L[i1]) + 1 + int(rng2.integers(0, max(1, int(L[i1 + 1]) - int(L[i1]) - 1)))
+        if b <= a:
+            continue
+        g = rg.GenomicRegion(region='%s:%d-%d' % (names[ci], a, b), genome_name='synth')                    # the stand-in answers
+        one = pd.DataFrame({'chr': [names[ci]], 'start': [a], 'end': [b]})
+        t = rc.chr_thread(one.copy(), cf, 'synth')                                                           # no tabix
+        fast = (int(t['startCpG'].values[0]), int(t['endCpG'].values[0]))
+        slow = (int(g.sites[0]), int(g.sites[1]))
+        n_end_on += end_on
+        agree += slow == (fast[0], fast[1] - (1 if end_on else 0))
+        rows.append([names[ci], a, b, slow[0], slow[1], fast[0], fast[1], int(end_on)])
+    fixture['shim_cross_check'] = {'rows': rows, 'n': len(rows), 'agree': agree, 'end_on_a_cpg': n_end_on,
+                                   'columns': ['chr', 'start', 'end', 'pipeline_startCpG', 'pipeline_endCpG', 'joins_startCpG', 'joins_endCpG', 'end_on_a_cpg']}
+    print('tabix stand-in against the reference\'s own tabix-free joins: %d / %d regions agree (%d end on a CpG: pipeline = joins - 1 there)' % (agree, len(rows), n_end_on))
+    assert agree == len(rows)
     with open(op.join(HERE, 'convert_cases.json'), 'w') as f:
         json.dump(fixture, f, separators=(',', ':'))
     print('regions:', {k: v.get('sites', v.get('error')) for k, v in fixture['regions'].items()})

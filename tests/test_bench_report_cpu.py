@@ -36,6 +36,29 @@ def test_ranks_sharing_devices_are_counted_once():
     assert r['n_gpus'] == 2 and r['oversubscribed'] is False
 
 
+def test_a_launch_with_fewer_gpus_than_shares_is_refused_unless_it_opts_in():
+    # `bench.py --gpus 8` on a 1-GPU box, two ranks on one device: refused, loudly; --oversubscribe turns them into dry runs; real launches pass
+    msg = bench.refuse_oversubscription('group', 8, 8, 1, False)
+    assert msg and '--oversubscribe' in msg and 'not be a 8-GPU measurement' in msg and 'shows 1 GPU' in msg
+    assert bench.refuse_oversubscription('ranks', 2, 2, 1, False)
+    assert bench.refuse_oversubscription('group', 8, 8, 1, True) is None
+    assert bench.refuse_oversubscription('group', 8, 8, 8, False) is None
+    assert bench.refuse_oversubscription('ranks', 8, 8, 8, False) is None
+    assert bench.refuse_oversubscription('one', 1, 1, 1, False) is None
+    assert bench.refuse_oversubscription('ranks', 4, 4, 8, False) is None
+
+
+def test_bench_refuses_eight_shares_without_gpus(tmp_path):
+    """the refusal end to end: this container has no GPU at all, so `bench.py --gpus 8` must stop with exit code 2 and the message on stderr before any device work"""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, op.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 8:
+        return
+    assert res.returncode == 2 and b'--oversubscribe' in res.stderr and res.stdout.strip() == b'', (res.returncode, res.stderr[-500:])
+
+
 def test_one_gpu_line():
     r = bench.device_report('one', 1, [('box', 0)])
     assert r == {'n_gpus': 1, 'gpus_requested': 1, 'shares': 1, 'distinct_devices': 1, 'oversubscribed': False, 'sharding': 'one GPU'}

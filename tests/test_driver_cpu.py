@@ -618,3 +618,10 @@ def test_dump_result_csr_reports_before_a_failing_writer(synth_world, tmp_path):
     assert '[wt segment] found 5 blocks\n             (dropped 2 short blocks)' in text
     assert sbc.report == {'blocks_found': 5, 'blocks_dropped': 2}
     assert sum(1 for _ in open(out_path)) == 4          # the rows before the failing one are written, as the reference's streaming loop would have
+    # an ARGUMENT the library refuses (descending borders) is no list of blocks: the error, and no made-up summary
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        sbc.report = {}
+        with pytest.raises(RuntimeError):
+            sbc.dump_result_csr(np.array([1, 9, 5, 12], dtype=np.int32), np.array([0, 4], dtype=np.int64))
+    assert 'found' not in err.getvalue() and sbc.report == {}

@@ -230,3 +230,29 @@ def test_bin_rows_of_exact_quotients(general, monkeypatch):
         for i, K in enumerate(ks):                                      # the exact quotients themselves: (K, 255) for every saturated block
             sat = (e0 - s0) * 255 > 255
             assert (b8[i][sat, 0] == K).all() and (b8[i][sat, 1] == 255).all()
+
+
+def test_bin_rows_of_a_corrupt_file_do_not_depend_on_the_kernel(monkeypatch):
+    """the block reduction does not check meth <= cov (neither does beta_to_blocks.py:101-126).  Rows with meth > cov — a corrupt .beta —
+    leave the domain the streaming kernel's integer rescale is proved on; it falls back to the float64 form there, so that the streaming kernel,
+    the general kernel and numpy's float64 trim_to_uint8 restatement (utils_wgbs.py:277-290; wrap-around of the uint8 store included) agree."""
+    n = 200000
+    rng = np.random.default_rng(29)
+    bad = synth.synth_betas(6, 0, 0, n).copy()
+    where = rng.integers(0, n, 30000)
+    bad[where, 0] = 255; bad[where, 1] = rng.integers(1, 40, where.size)          # meth far above cov: block quotients of 255 m / c up to several thousand
+    worse = np.empty((n, 2), dtype=np.uint8); worse[:, 0] = 255; worse[:, 1] = 3    # every block: m = 85 c
+    ln = np.where(rng.random(40000) < 0.7, rng.integers(2, 30, 40000), rng.integers(30, 1000, 40000))
+    edges = np.concatenate([[0], np.cumsum(ln)]); edges = edges[edges <= n]
+    s0, e0 = edges[:-1], edges[1:]
+    res = []
+    for general in (0, 1):
+        monkeypatch.setenv('WGBSSEG_BLOCK_SUMS_GENERAL', str(general))
+        with _lib.Segmenter(0) as sg:
+            sg.set_betas([bad, worse])
+            res.append(sg.block_sums(s0, e0, mode=1).copy())
+    assert (res[0] == res[1]).all()
+    for s, d in enumerate((bad, worse)):
+        sums = OB.block_sums(d, s0, e0)
+        assert (sums[:, 0] > sums[:, 1]).any()
+        assert (res[0][s] == OB.trim(sums, False)).all()

@@ -99,3 +99,21 @@ def test_two_million_regions_against_oracle():
     assert np.array_equal(s, ws) and np.array_equal(e, we)
     assert (s[unknown] == 0).all() and (s != 0).sum() > n // 2
     print('k_convert: %.3f ms for %d regions against %d loci' % (ms, n, loci.size))
+
+
+def test_both_rule_sets_on_the_tabix_free_cross_check(cworld):
+    """The 400 regions the reference answered twice (tests/golden/make_golden_convert.py: its `tabix | awk` pipeline on the stand-in AND its
+    tabix-free pandas joins) through k_convert with either rule set: the device's answers are the reference's on both paths."""
+    g = cworld['g']
+    rows = g['shim_cross_check']['rows']
+    cum = np.concatenate([[0], np.cumsum(cworld['sizes'])]).astype(np.int64)
+    ci = np.array([cworld['names'].index(r[0]) for r in rows])
+    start = np.array([r[1] for r in rows], dtype=np.int64); end = np.array([r[2] for r in rows], dtype=np.int64)
+    from wgbs_tools_amd import genome as G
+    gen = G.GenomeRefPaths(cworld['ref'])
+    cbp = np.array([gen.get_chrom_size(r[0]) for r in rows], dtype=np.int64)
+    with _lib.Segmenter(0) as seg:
+        seg.set_loci(cworld['loci'])
+        for slow, cs, ce in ((0, 5, 6), (1, 3, 4)):
+            s, e = seg.convert_regions(cum[ci], cum[ci + 1], cbp, start, end, np.full(len(rows), slow, dtype=np.uint8))
+            assert s.tolist() == [r[cs] for r in rows] and e.tolist() == [r[ce] for r in rows], 'rule set %d' % slow

@@ -218,3 +218,68 @@ def test_first_batch_items_are_what_the_stitcher_asks_for_first_and_weighted_pla
                 assert [(int(a), int(b)) for a, b in zip(st[:nch][owner[:nch] == r], en[:nch][owner[:nch] == r])] == mine
             lo, hi = sh['win_lo'][owner], sh['win_hi'][owner]                 # every item lies inside its owner's resident window
             assert (st - 1 >= lo).all() and (en - 1 <= hi).all()
+
+
+WORKER8 = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+    import torch.distributed as dist
+    from wgbs_tools_amd import synth, parallel
+    from test_driver_cpu import FickleEngine, _tree_merge
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo')
+    assert world == 8
+    params = dict(pcount=15.0, max_cpg=1000, max_bp=2000)
+    verdicts = []
+    # (a) 40 chunks over 8 ranks, rank 0 at its default weight of 0.75 of an even share; (b) 5 chunks: ranks that own NOTHING publish empty slots;
+    # (c) one region of a single short chunk: seven ranks idle.  Three steps each: the two slots of every rank alternate and a rank may run one
+    # step ahead of rank 0's stitching, no further.
+    for tag, sizes, chunk in (('40 chunks', [90017, 60040, 30000, 17001, 7], 5000), ('5 chunks', [9000, 2001, 7], 4000), ('1 chunk', [900], 4000)):
+        loci = synth.synth_loci(79, sizes)
+        regions = parallel.regions_of_sizes(sizes)
+        eng = FickleEngine(3, 7, 170)
+        pr = dict(params, engine=eng)
+        want = None
+        if rank == 0:
+            want = []
+            for a, b in regions:
+                bords = list(range(a, b, chunk)) + [b]
+                want.append(_tree_merge(eng.segment_many(list(zip(bords[:-1], bords[1:])), pr), pr))
+        run = parallel.ShardedRun(dist, regions, chunk, loci, params, rank, world)
+        assert run.slots.shared, 'eight ranks of one host hand over through /dev/shm'
+        owns = [int(i.size) for i in run.idx]
+        assert sum(owns) == run.starts.size
+        if tag == '40 chunks':
+            w = run.shares['work'].astype(float)
+            assert all(o > 0 for o in owns) and w[0] < 0.9 * w[1:].mean(), (owns, w.tolist())      # rank 0 keeps room for the tree
+        else:
+            assert min(owns) == 0                                                                   # somebody owns nothing
+        for step in range(3):
+            merged = run.step(parallel.csr_engine(eng, pr), parallel.csr_engine(eng, pr))
+            if rank == 0:
+                verdicts.append((tag, step, all(np.array_equal(m, w) for m, w in zip(merged, want)), owns))
+            else:
+                assert merged is None
+        run.close()
+        dist.barrier()
+    if rank == 0:
+        print('WORLD8_OK' if all(ok for _, _, ok, _ in verdicts) and len(verdicts) == 9 else 'WORLD8_DIFF', verdicts, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_eight_gloo_ranks_equal_single_rank(tmp_path):
+    """VERDICT r05 item 7: everything an 8-GPU launch does besides the kernels — WGBSSEG_RANK0_WEIGHT's default of 0.75, eight pairs of
+    NodeSlots, the one-step-ahead protocol, ranks that own nothing — before the first real 8-GPU launch does."""
+    script = tmp_path / 'worker8.py'
+    script.write_text(WORKER8 % dict(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    env.pop('WGBSSEG_RANK0_WEIGHT', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=8', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', str(script)]
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = res.stdout.decode()
+    assert res.returncode == 0, out[-3000:]
+    assert 'WORLD8_OK' in out, out[-3000:]

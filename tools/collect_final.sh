@@ -1,5 +1,5 @@
 #!/bin/bash
-# gpurun_out/final/ (written by tools/gpu/final.sh on the GPU box) -> profiles/rNN_*   Usage: tools/collect_final.sh [r04]
+# gpurun_out/final/ (written by tools/gpu/final_a.sh on the GPU box) -> profiles/rNN_*   Usage: tools/collect_final.sh [r04]
 R=${1:-r04}
 cd "$(dirname "$0")/.."
 O=gpurun_out/final

@@ -2617,7 +2617,13 @@ __global__ __launch_bounds__(WG_BLOCK) void k_block_sums_run(const uint8_t* __re
         } else if (MODE == 3) {
             *reinterpret_cast<double*>(orow + o) = (c32 >= min_cov) ? (double)m32 / (double)c32 : __builtin_nan("");
         } else if (MODE == 1) {
-            if (c32 > 255u) { m32 = wg_rescale_255(m32, c32); c32 = 255u; }
+            if (c32 > 255u) {
+                // the integer form is proved for 0 <= m <= c (tests/test_blocks_cpu.py); a corrupt file with meth > cov — the block reduction, like
+                // the reference's (beta_to_blocks.py:101-126), does not check — takes the float64 form every other kernel of the reduction uses
+                // (wg_block_sum_store), so that a table's rows do not depend on which kernel produced them
+                m32 = m32 <= c32 ? wg_rescale_255(m32, c32) : (uint32_t)(uint64_t)((double)m32 / (double)c32 * 255.0);
+                c32 = 255u;
+            }
             *reinterpret_cast<uchar2*>(orow + o) = make_uchar2((unsigned char)m32, (unsigned char)c32);
         } else {
             if (c32 > 65535u) { m32 = (uint32_t)(uint64_t)((double)m32 / (double)c32 * 65535.0); c32 = 65535u; }     // (> 257 saturated sites: rare)

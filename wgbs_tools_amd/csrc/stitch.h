@@ -12,6 +12,7 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <cassert>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
@@ -365,6 +366,7 @@ public:
     bool count(const Sites& k) const { return find(k) != nullptr; }
     V& operator[](const Sites& k)                               // (inserts a default value when the key is new)
     {
+        assert(k.first != EMPTY && "SiteTable: INT64_MIN is the empty slot's mark, never a site");      // (sites are 1-based: region_start >= 1 is checked by first_batch)
         size_t i = probe(k);
         if (t_[i].k.first == EMPTY) {
             if (2 * (n_ + 1) > t_.size()) { grow(); i = probe(k); }

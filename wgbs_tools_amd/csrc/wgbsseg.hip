@@ -21,6 +21,10 @@
 #include <vector>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/mman.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <emmintrin.h>
+#endif
 
 #include "../../include/wgbsseg.h"
 #include "seg_kernels.h"
@@ -105,8 +109,12 @@ struct PinnedBuf {          // grow-only page-locked host buffer (fast, truly as
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+#define WG_MAX_CPUS 8192
+struct NearCpus { std::vector<unsigned long> bits; bool valid = false; };      // affinity mask of the CPUs next to a device
+
 struct wgbsseg_ctx {
     int device = 0;
+    NearCpus near_cpus;          // the upload threads run there (worked out once, at create)
     hipStream_t sA = nullptr, sB = nullptr, sC = nullptr;     // scoring (+ everything else) | recurrence, traceback | the scan pass
     hipStream_t sA2 = nullptr;                                // second scoring stream: medium / wide tiles beside the narrow ones (stage loop)
     // inputs
@@ -170,7 +178,8 @@ struct wgbsseg_ctx {
 
 namespace {
 
-bool device_local_cpus(int device, cpu_set_t* out);      // (below, with the streaming upload)
+bool device_local_cpus(int device, NearCpus* out);      // (below, with the streaming upload)
+inline void pin_to(const NearCpus& n);
 
 // Pageable host rows (typically memory-mapped .beta files) -> HBM: dst + r * dst_pitch <- rows[r][0 .. row_bytes).
 // One thread drives ~33 GB/s of that (page faults + the copy into page-locked staging); a few threads, each with its
@@ -191,15 +200,13 @@ int upload_rows(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const uint8_t* 
         HIP_TRY(hipStreamSynchronize(c->sA));
     } else {
         if (c->up_stage.size() < (size_t)(2 * T)) c->up_stage.resize((size_t)(2 * T));
-        for (int i = 0; i < 2 * T; i++)
-            if (!c->up_stage[(size_t)i].ensure_exact((size_t)piece)) { set_err(err, errlen, "out of page-locked host memory"); return WGBSSEG_E_NOMEM; }
         std::atomic<int64_t> next(0);
         std::vector<hipError_t> terr((size_t)T, hipSuccess);
-        cpu_set_t near_cpus;
-        const bool pin = device_local_cpus(c->device, &near_cpus);
         auto worker = [&](int t) {
-            if (pin) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
+            pin_to(c->near_cpus);
             hipError_t e = hipSetDevice(c->device);
+            // (its two staging pieces are allocated — first touched — by the worker itself, on the device's CPUs: they sit on that socket)
+            for (int k = 0; k < 2 && e == hipSuccess; k++) if (!c->up_stage[(size_t)(2 * t + k)].ensure_exact((size_t)piece)) e = hipErrorOutOfMemory;
             hipStream_t st = nullptr;
             hipEvent_t ev[2] = {nullptr, nullptr};
             if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
@@ -267,6 +274,7 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     wgbsseg_ctx* c = new (std::nothrow) wgbsseg_ctx();
     if (!c) { set_err(err, errlen, "out of host memory"); return WGBSSEG_E_NOMEM; }
     c->device = device;
+    (void)device_local_cpus(device, &c->near_cpus);
     HIP_TRY(hipStreamCreateWithFlags(&c->sA, hipStreamNonBlocking));
     {   // the recurrence stream outranks the scoring stream: its 483 latency-bound workgroups should never queue behind
         // the hundreds of thousands of throughput-bound scoring tiles
@@ -1595,8 +1603,11 @@ namespace {
 // An upload thread that runs on the OTHER socket of a two-socket host fills page-locked pieces over there and the DMA then crosses the
 // socket link: measured on an MI355X box (round 5, x200 = 11.3 GB): the same upload at 9 .. 35 GB/s from run to run with free-running
 // threads.  false: unknown (no sysfs, every CPU listed, WGBSSEG_UPLOAD_PIN=0) — the threads then run where the scheduler puts them.
-bool device_local_cpus(int device, cpu_set_t* out)
+// The CPUs next to a device (/sys/bus/pci/devices/<bus id>/local_cpulist) that this process may run on, as an affinity mask of up to WG_MAX_CPUS
+// CPUs (a fixed cpu_set_t stops at 1024 and sched_getaffinity then FAILS on a larger host: ADVICE r05).  Worked out once per context (create).
+bool device_local_cpus(int device, NearCpus* out)
 {
+    out->valid = false;
     { const char* e = getenv("WGBSSEG_UPLOAD_PIN"); if (e && atoi(e) == 0) return false; }
     char bus[64] = {0};
     if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -1605,13 +1616,16 @@ bool device_local_cpus(int device, cpu_set_t* out)
     snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
     FILE* f = fopen(path, "r");
     if (!f) return false;
-    char line[4096] = {0};
+    char line[8192] = {0};
     const bool got = fgets(line, (int)sizeof line, f) != nullptr;
     fclose(f);
     if (!got) return false;
-    cpu_set_t allowed, local;
-    CPU_ZERO(&allowed); CPU_ZERO(&local);
-    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    const size_t bytes = CPU_ALLOC_SIZE(WG_MAX_CPUS);
+    std::vector<unsigned long> allowed(bytes / sizeof(unsigned long), 0ul);
+    out->bits.assign(bytes / sizeof(unsigned long), 0ul);
+    cpu_set_t* A = reinterpret_cast<cpu_set_t*>(allowed.data());
+    cpu_set_t* L = reinterpret_cast<cpu_set_t*>(out->bits.data());
+    if (sched_getaffinity(0, bytes, A) != 0) return false;
     int n_local = 0;
     for (const char* q = line; *q;) {
         while (*q == ',' || *q == ' ' || *q == '\n') q++;
@@ -1619,17 +1633,54 @@ bool device_local_cpus(int device, cpu_set_t* out)
         char* end = nullptr;
         long a = strtol(q, &end, 10), b = a;
         if (*end == '-') b = strtol(end + 1, &end, 10);
-        for (long x = a; x <= b && x < CPU_SETSIZE; x++) if (CPU_ISSET((int)x, &allowed)) { CPU_SET((int)x, &local); n_local++; }
+        for (long x = a; x <= b && x < WG_MAX_CPUS; x++) if (CPU_ISSET_S((int)x, bytes, A)) { CPU_SET_S((int)x, bytes, L); n_local++; }
         q = end;
     }
-    if (n_local == 0 || n_local == CPU_COUNT(&allowed)) return false;      // nothing to choose from
-    *out = local;
+    if (n_local == 0 || n_local == CPU_COUNT_S(bytes, A)) return false;      // nothing to choose from
+    out->valid = true;
     return true;
 }
+inline void pin_to(const NearCpus& n)
+{
+    if (n.valid) (void)pthread_setaffinity_np(pthread_self(), n.bits.size() * sizeof(unsigned long), reinterpret_cast<const cpu_set_t*>(n.bits.data()));
+}
+// Page-cached file bytes -> a page-locked staging piece.  (A/B switches of round 6, profiles/r06_upload_ab.txt:
+//   WGBSSEG_UPLOAD_POPULATE=1  map the piece's pages in ONE call (madvise MADV_POPULATE_READ, Linux >= 5.14) instead of a minor fault per 4 KB page as the copy touches them;
+//   WGBSSEG_UPLOAD_NT=1        non-temporal stores: the staging piece is written once and read by the DMA engine — no read-for-ownership, no cache pollution.)
+struct FillMode { bool populate = false, nt = false; };
+inline FillMode fill_mode()
+{
+    FillMode m;
+    { const char* e = getenv("WGBSSEG_UPLOAD_POPULATE"); m.populate = e && atoi(e) != 0; }
+    { const char* e = getenv("WGBSSEG_UPLOAD_NT"); m.nt = e && atoi(e) != 0; }
+    return m;
+}
+inline void fill_piece(void* dst, const uint8_t* src, size_t n, const FillMode& m)
+{
+#ifdef MADV_POPULATE_READ
+    if (m.populate) {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(src) & ~(uintptr_t)4095, b = (reinterpret_cast<uintptr_t>(src) + n + 4095) & ~(uintptr_t)4095;
+        (void)madvise(reinterpret_cast<void*>(a), b - a, MADV_POPULATE_READ);      // (an error — an old kernel, not a mapping — just leaves the faults to the copy)
+    }
+#endif
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    if (m.nt && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        __m128i* d = reinterpret_cast<__m128i*>(dst);
+        const __m128i* s = reinterpret_cast<const __m128i*>(src);
+        size_t v = n >> 6;
+        for (; v > 0; v--, s += 4, d += 4) {
+            const __m128i x0 = _mm_loadu_si128(s), x1 = _mm_loadu_si128(s + 1), x2 = _mm_loadu_si128(s + 2), x3 = _mm_loadu_si128(s + 3);
+            _mm_stream_si128(d, x0); _mm_stream_si128(d + 1, x1); _mm_stream_si128(d + 2, x2); _mm_stream_si128(d + 3, x3);
+        }
+        _mm_sfence();
+        const size_t done = n & ~(size_t)63;
+        if (n > done) memcpy(static_cast<char*>(dst) + done, src + done, n - done);
+        return;
+    }
+#endif
+    memcpy(dst, src, n);
+}
 
-// Site-major upload of `n_rows` pageable rows: pieces of `piece` bytes go out in the order (piece 0 of every row, piece 1 of
-// every row, ...) on T host threads, each with its own stream and two page-locked staging buffers; `ready_sites` follows
-// the longest prefix of every row that is known to be resident, in sites of 2 bytes (a piece counts once its DMA has completed).
 int upload_rows_streaming(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const uint8_t* const* rows, int64_t n_rows, int64_t row_bytes,
                           std::atomic<int64_t>& ready_sites, std::string& msg)
 {
@@ -1649,8 +1700,7 @@ int upload_rows_streaming(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const
     std::atomic<int64_t> next(0), pieces_done(0);
     std::mutex mu;
     std::vector<hipError_t> terr((size_t)T, hipSuccess);
-    cpu_set_t near_cpus;
-    const bool pin = device_local_cpus(c->device, &near_cpus);      // upload threads (and the pieces they allocate and fill) on the device's socket
+    const bool pin = c->near_cpus.valid;                         // upload threads (and the pieces they allocate and fill) on the device's socket
     auto complete = [&](int64_t task) {                          // task = p * n_rows + r: row r's piece p is on the device
         const int64_t p = task / n_rows;
         if (rows_done[(size_t)p].fetch_add(1) + 1 == (int)n_rows) {
@@ -1661,29 +1711,33 @@ int upload_rows_streaming(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const
             ready_sites.store(std::min<int64_t>(d * piece, row_bytes) / 2);
         }
     };
+    const FillMode fm = fill_mode();
+    int depth = 2;                                               // staging pieces (copies in flight) per upload thread
+    { const char* e = getenv("WGBSSEG_UPLOAD_DEPTH"); if (e && atoi(e) >= 2 && atoi(e) <= 8) depth = atoi(e); }
     auto worker = [&](int t) {
-        if (pin) (void)pthread_setaffinity_np(pthread_self(), sizeof near_cpus, &near_cpus);
+        pin_to(c->near_cpus);
         hipError_t e = hipSetDevice(c->device);
         hipStream_t st = nullptr;
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        void* stg[2] = {nullptr, nullptr};
-        int64_t task_of[2] = {-1, -1};
+        hipEvent_t ev[8] = {};
+        void* stg[8] = {};
+        int64_t task_of[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
-        for (int k = 0; k < 2 && e == hipSuccess; k++) e = hipHostMalloc(&stg[k], (size_t)piece, hipHostMallocDefault);
+        for (int k = 0; k < depth && e == hipSuccess; k++) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+        // (allocated — and so first touched — by the thread that fills them, which runs on the device's CPUs: the pieces sit on that socket)
+        for (int k = 0; k < depth && e == hipSuccess; k++) e = hipHostMalloc(&stg[k], (size_t)piece, hipHostMallocDefault);
         int k = 0;
         while (e == hipSuccess) {
             const int64_t it = next.fetch_add(1);
             if (it >= n_tasks) break;
             const int64_t p = it / n_rows, r = it % n_rows, o = p * piece, b = std::min<int64_t>(piece, row_bytes - o);
             if (task_of[k] >= 0) { e = hipEventSynchronize(ev[k]); if (e != hipSuccess) break; complete(task_of[k]); task_of[k] = -1; }
-            memcpy(stg[k], rows[r] + o, (size_t)b);
+            fill_piece(stg[k], rows[r] + o, (size_t)b, fm);
             e = hipMemcpyAsync(dst + r * dst_pitch + o, stg[k], (size_t)b, hipMemcpyHostToDevice, st);
             if (e == hipSuccess) e = hipEventRecord(ev[k], st);
             task_of[k] = it;
-            k ^= 1;
+            k = (k + 1) % depth;
         }
-        for (int q = 0; q < 2 && e == hipSuccess; q++, k ^= 1)
+        for (int q = 0; q < depth && e == hipSuccess; q++, k = (k + 1) % depth)
             if (task_of[k] >= 0) { e = hipEventSynchronize(ev[k]); if (e == hipSuccess) complete(task_of[k]); task_of[k] = -1; }
         if (st) (void)hipStreamDestroy(st);
         for (auto& x : ev) if (x) (void)hipEventDestroy(x);
@@ -1696,8 +1750,9 @@ int upload_rows_streaming(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const
     for (int t = 0; t < T; t++)
         if (terr[(size_t)t] != hipSuccess) { msg = std::string("HIP error during the upload: ") + hipGetErrorString(terr[(size_t)t]); return WGBSSEG_E_HIP; }
     ready_sites.store(row_bytes / 2);
-    if (profiling()) fprintf(stderr, "[wgbsseg] betas to the device (streaming): %.1f ms, %.1f GB/s (%d upload threads%s)\n", (wall_s() - t0) * 1e3,
-                             (double)row_bytes * n_rows / (wall_s() - t0) * 1e-9, T, pin ? ", on the device's CPUs" : "");
+    if (profiling()) fprintf(stderr, "[wgbsseg] betas to the device (streaming): %.1f ms, %.1f GB/s (%d upload threads x %d pieces of %lld KB%s%s%s)\n", (wall_s() - t0) * 1e3,
+                             (double)row_bytes * n_rows / (wall_s() - t0) * 1e-9, T, depth, (long long)(piece >> 10), pin ? ", on the device's CPUs" : "",
+                             fm.populate ? ", pages mapped per piece" : "", fm.nt ? ", non-temporal fill" : "");
     return WGBSSEG_OK;
 }
 

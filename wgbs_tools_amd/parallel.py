@@ -126,11 +126,37 @@ class NodeSlots:
 
     @staticmethod
     def _pid_namespace():
+        """What tells two ranks that they share a machine AND a process table: the boot id of the kernel they run on (the initial pid namespace
+        has the same inode on every Linux host, and two machines may share a default hostname: ADVICE r05) + the pid namespace."""
         import os
         try:
-            return os.readlink('/proc/self/ns/pid')
+            with open('/proc/sys/kernel/random/boot_id') as f:
+                boot = f.read().strip()
+            return boot + ' ' + os.readlink('/proc/self/ns/pid')
         except OSError:
             return None
+
+    @staticmethod
+    def _boot_id():
+        try:
+            with open('/proc/sys/kernel/random/boot_id') as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    @classmethod
+    def _timeout_from_env(cls, default):
+        import os
+        v = os.environ.get('WGBSSEG_SLOT_TIMEOUT_S')
+        if v is None or v == '':
+            return default
+        try:
+            t = float(v)
+        except ValueError:
+            raise ValueError('WGBSSEG_SLOT_TIMEOUT_S must be a number of seconds, not %r' % v) from None
+        if not t > 0:
+            raise ValueError('WGBSSEG_SLOT_TIMEOUT_S must be positive, not %r' % v)
+        return t
 
     def __init__(self, dist, rank, world, n_items, caps):
         import os
@@ -139,7 +165,8 @@ class NodeSlots:
         import numpy as np
         self.dist, self.rank, self.world = dist, rank, world
         hosts = [None] * world
-        dist.all_gather_object(hosts, (socket.gethostname(), os.getpid(), self._pid_namespace()))
+        # (the timeout travels too: every rank waits as long as rank 0 says, whatever its own environment holds)
+        dist.all_gather_object(hosts, (socket.gethostname() + ' ' + str(self._boot_id()), os.getpid(), self._pid_namespace()))
         self.pids = [p for _, p, _ in hosts]
         # the liveness probe (signal 0 to a peer's pid) means something only when every rank lives in ONE pid namespace: ranks in separate
         # containers that share a hostname and /dev/shm would see a stranger's pid, or none, and report a live peer as gone
@@ -147,7 +174,9 @@ class NodeSlots:
         self.liveness = len(spaces) == 1 and None not in spaces
         # without the probe a dead peer shows only as a timeout, and a slow step (a large cohort, the plain path of disordered chunks) must
         # not: the short timeout is kept for runs that can tell the two apart
-        self.timeout_s = float(os.environ.get('WGBSSEG_SLOT_TIMEOUT_S', self.TIMEOUT_S if self.liveness else self.TIMEOUT_NO_PROBE_S))
+        tmo = [self._timeout_from_env(self.TIMEOUT_S if self.liveness else self.TIMEOUT_NO_PROBE_S) if rank == 0 else None]
+        dist.broadcast_object_list(tmo, src=0)
+        self.timeout_s = float(tmo[0])
         hosts = [h for h, _, _ in hosts]
         tag = [uuid.uuid4().hex[:12] if rank == 0 else None]
         dist.broadcast_object_list(tag, src=0)

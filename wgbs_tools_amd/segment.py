@@ -423,6 +423,10 @@ class SegmentByChunks:
         except _lib.SegmentorError as e:
             # the reference reports the counts BEFORE it writes (segment.py:180), so a run whose writer fails has still said them: on this
             # path the counts come from one numpy pass over the lists (the library's counts exist only for a completed file)
+            # — for a failing ROW only ('[wt add_loci] line N: ...', add_loci.cpp:42-49): an argument the library refused (descending borders, regions
+            # out of order, a NULL path) is no list of blocks at all, and counts made of it would mean nothing
+            if '[wt add_loci] line' not in (e.msg or ''):
+                raise RuntimeError(e.msg)
             flat_, off_ = np.asarray(flat, dtype=np.int64), np.asarray(off, dtype=np.int64)
             d = np.diff(flat_)
             inner = np.ones(d.size, dtype=bool)
