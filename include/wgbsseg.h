@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define WGBSSEG_VERSION 210            /* 0.2.1: round 4 changed wgbsseg_scan_only's argument list and added wgbsseg_add_loci_borders without a bump; a binding compares wgbsseg_version() with the header it was written against */
+#define WGBSSEG_VERSION 220            /* 0.2.1: round 4 changed wgbsseg_scan_only's argument list and added wgbsseg_add_loci_borders without a bump; a binding compares wgbsseg_version() with the header it was written against */
 #define WGBSSEG_MAX_CPG 65535          /* longest block, in sites (min(max_cpg, longest chunk)): see wgbsseg_segment_chunks */
 
 #define WGBSSEG_OK              0
@@ -231,6 +231,15 @@ int wgbsseg_group_share_set_device(wgbsseg_group* g, int32_t share, const void* 
                                    int64_t pitch_bytes, char* err, size_t errlen);
 int wgbsseg_group_segment_regions(wgbsseg_group* g, int32_t* borders_out, int64_t borders_cap, int64_t* borders_off,
                                   int64_t* stats, char* err, size_t errlen);
+
+/*
+ * The same over a SLICE of the planned regions, [first_region, end_region): regions never interact (segment.py:84-86,129-134), so a caller may
+ * take them in slices and do something with one slice's blocks — write their BED rows — while the next slice is segmented and the beta bytes of
+ * the later regions are still on their way up (wgbsseg_group_load_host_async streams site-major): `wgbstools segment` does (round 6).  borders_off has
+ * end_region - first_region + 1 entries.  The slices of one pass must be taken in ascending order; the uploaders are collected with the last one.
+ */
+int wgbsseg_group_segment_region_range(wgbsseg_group* g, int64_t first_region, int64_t end_region, int32_t* borders_out, int64_t borders_cap,
+                                       int64_t* borders_off, int64_t* stats, char* err, size_t errlen);
 int wgbsseg_group_get_timings(const wgbsseg_group* g, int32_t share, wgbsseg_timings* out);
 
 /*

@@ -98,6 +98,42 @@ def test_cli_over_a_share_group_matches_reference_driver(name, gpus, driver_gold
     assert hashlib.sha1(table.tobytes()).hexdigest() == g['table_sha1']
 
 
+@pytest.mark.parametrize('name,gpus,slices', [('wg_c20000', 1, 2), ('wg_c60000_min3', 1, 3), ('wg_pcount0', 2, 4), ('bed_regions', 3, 2), ('tiny_chunks', 1, 8)])
+def test_cli_in_region_slices_writes_the_same_file(name, gpus, slices, driver_golden, world, tmp_path, monkeypatch):
+    """Round 6: the regions in slices, slice k's BED rows written (append mode, a second thread) while slice k + 1 is segmented — the file, the
+    summary line and the --stats counts are those of the one-piece run and of the reference driver."""
+    g = driver_golden['cases'][name]
+    monkeypatch.setattr(S.SegmentByChunks, 'SLICE_MIN_SITES', 1)
+    argv0 = ['wgbstools', 'segment', '--betas'] + world['paths'] + ['--genome', world['refdir'], '--gpus', str(gpus)]
+    for k, v in g['args'].items():
+        flag = {'chunk_size': '-c', 'min_cpg': '--min_cpg', 'sites': '-s', 'pcount': '-p', 'max_cpg': '--max_cpg', 'max_bp': '--max_bp'}[k]
+        argv0 += [flag, str(v)]
+    if g['bed_rows'] is not None:
+        bed = str(tmp_path / 'regions.bed')
+        with open(bed, 'w') as f:
+            for s, e in g['bed_rows']:
+                f.write('chrN\t0\t1\t%d\t%d\n' % (s, e))
+        argv0 += ['-L', bed]
+    outs, errs = [], []
+    for n in (1, slices):
+        monkeypatch.setenv('WGBSSEG_BED_SLICES', str(n))
+        out = str(tmp_path / ('blocks_%d.bed' % n))
+        stats = str(tmp_path / ('stats_%d.json' % n))
+        err = io.StringIO()
+        with contextlib.redirect_stderr(err):
+            rc = wgbs_tools.main(argv0 + ['-o', out, '--stats', stats])
+        assert rc == 0, err.getvalue()
+        outs.append(open(out, 'rb').read()); errs.append(err.getvalue())
+        rep = json.load(open(stats))
+        assert rep['blocks_found'] == g['n_blocks']
+        if n > 1 and len(world['sizes']) >= 2 and g['bed_rows'] is None and 'sites' not in g['args']:
+            assert rep['stitching']['slices'] >= 2                  # (a whole-genome run of several chromosomes really went through the sliced form)
+    assert outs[0] == outs[1] and errs[0] == errs[1]
+    rows = [l.split('\t') for l in outs[1].decode().splitlines()]
+    table = np.array([[int(r[3]), int(r[4])] for r in rows], dtype=np.int64).reshape(-1, 2)
+    assert table.shape[0] == g['n_blocks'] and hashlib.sha1(table.tobytes()).hexdigest() == g['table_sha1']
+
+
 def test_share_group_plan_windows_and_errors(world):
     """The group API directly: windows cover the shares, a share reports #meth > #cov with the ABSOLUTE site, a share
     without data is refused, the group result equals the one-context result."""

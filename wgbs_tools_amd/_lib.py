@@ -23,14 +23,14 @@ SYNTH_LIB_PATH = op.join(HERE, 'csrc', 'libwgbssynth.so')
 OK, E_ARG, E_METH_GT_COV, E_NOMEM, E_HIP, E_LOCI_ORDER, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/wgbsseg.h declares (tests check the built library exports exactly these)
-ABI_VERSION = 210          # include/wgbsseg.h WGBSSEG_VERSION this binding's prototypes describe
+ABI_VERSION = 220          # include/wgbsseg.h WGBSSEG_VERSION this binding's prototypes describe
 EXPORTS = ['wgbsseg_version', 'wgbsseg_device_count', 'wgbsseg_create', 'wgbsseg_destroy',
            'wgbsseg_set_betas_host', 'wgbsseg_set_betas_device', 'wgbsseg_set_loci_host', 'wgbsseg_set_loci_device',
            'wgbsseg_segment_chunks', 'wgbsseg_segment_regions', 'wgbsseg_segment_chunks_host', 'wgbsseg_prefix_sums', 'wgbsseg_scan_only',
            'wgbsseg_get_timings', 'wgbsseg_debug_fetch', 'wgbsseg_debug_sample_terms', 'wgbsseg_debug_log2',
            'wgbsseg_debug_div', 'wgbsseg_debug_check_div', 'wgbsseg_debug_div_short', 'wgbsseg_add_loci', 'wgbsseg_add_loci_borders', 'wgbsseg_block_sums', 'wgbsseg_last_block_sums_ms',
            'wgbsseg_set_site_base', 'wgbsseg_stitch_regions', 'wgbsseg_group_create', 'wgbsseg_group_destroy', 'wgbsseg_group_size',
-           'wgbsseg_group_plan', 'wgbsseg_group_load_host', 'wgbsseg_group_share_set_device', 'wgbsseg_group_segment_regions',
+           'wgbsseg_group_plan', 'wgbsseg_group_load_host', 'wgbsseg_group_share_set_device', 'wgbsseg_group_segment_regions', 'wgbsseg_group_segment_region_range',
            'wgbsseg_group_get_timings', 'wgbsseg_plan_shares', 'wgbsseg_set_lbetas_host',
            'wgbsseg_convert_regions', 'wgbsseg_patbeta_create', 'wgbsseg_patbeta_feed', 'wgbsseg_patbeta_finish',
            'wgbsseg_patbeta_destroy', 'wgbsseg_patbeta_kernel_ms', 'wgbsseg_group_load_host_async', 'wgbsseg_group_load_wait',
@@ -193,6 +193,8 @@ def load():
     L.wgbsseg_group_share_set_device.argtypes = [vp, i32, vp, i64, i64, C.c_char_p, C.c_size_t]
     L.wgbsseg_group_segment_regions.restype = i32
     L.wgbsseg_group_segment_regions.argtypes = [vp, vp, i64, vp, vp, C.c_char_p, C.c_size_t]
+    L.wgbsseg_group_segment_region_range.restype = i32
+    L.wgbsseg_group_segment_region_range.argtypes = [vp, i64, i64, vp, i64, vp, vp, C.c_char_p, C.c_size_t]
     L.wgbsseg_group_get_timings.restype = i32
     L.wgbsseg_group_get_timings.argtypes = [vp, i32, C.POINTER(Timings)]
     L.wgbsseg_convert_regions.restype = i32
@@ -717,6 +719,27 @@ class SegmenterGroup:
         self.last_csr = (out, off)                # the same lists as one CSR (views into the buffer the next call overwrites)
         res = [out[off[r]:off[r + 1]].astype(np.int64) if copy else out[off[r]:off[r + 1]] for r in range(n)]
         return res, _stats_dict(stats)
+
+    def segment_region_range(self, first, end, cap):
+        """wgbsseg_group_segment_region_range: the planned regions [first, end) only -> (flat int32 absolute borders, off int64 [end - first + 1], stats).
+        The CSR lives in a buffer of its OWN (cap ints: the slice's sites + regions suffice): a caller writes one slice's BED rows while the next
+        slice is being segmented.  Slices in ascending order; the uploaders of a streaming load are collected with the last one."""
+        n = int(end) - int(first)
+        out = np.empty(int(cap), dtype=np.int32)
+        off = np.empty(n + 1, dtype=np.int64)
+        stats = np.zeros(8, dtype=np.int64)
+        try:
+            _check(self._L.wgbsseg_group_segment_region_range(self._h, int(first), int(end), out.ctypes.data, out.size, off.ctypes.data, stats.ctypes.data,
+                                                              self._err, ERRLEN), self._err)
+        except BaseException:
+            if getattr(self, '_streaming', None) is not None:
+                self._L.wgbsseg_group_load_wait(self._h, None, 0)
+                self._streaming = None
+            raise
+        if int(end) == self.n_regions and getattr(self, '_streaming', None) is not None:
+            self._L.wgbsseg_group_load_wait(self._h, None, 0)
+            self._streaming = None
+        return out, off, _stats_dict(stats)
 
     def timings(self, share):
         t = Timings()

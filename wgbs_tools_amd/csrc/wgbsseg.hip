@@ -1644,15 +1644,17 @@ inline void pin_to(const NearCpus& n)
 {
     if (n.valid) (void)pthread_setaffinity_np(pthread_self(), n.bits.size() * sizeof(unsigned long), reinterpret_cast<const cpu_set_t*>(n.bits.data()));
 }
-// Page-cached file bytes -> a page-locked staging piece.  (A/B switches of round 6, profiles/r06_upload_ab.txt:
-//   WGBSSEG_UPLOAD_POPULATE=1  map the piece's pages in ONE call (madvise MADV_POPULATE_READ, Linux >= 5.14) instead of a minor fault per 4 KB page as the copy touches them;
-//   WGBSSEG_UPLOAD_NT=1        non-temporal stores: the staging piece is written once and read by the DMA engine — no read-for-ownership, no cache pollution.)
-struct FillMode { bool populate = false, nt = false; };
+// Page-cached file bytes -> a page-locked staging piece (round 6, profiles/r06_upload_ab.txt):
+//   * the piece's pages are mapped in ONE call (madvise MADV_POPULATE_READ, Linux >= 5.14) instead of a minor fault per 4 KB page as the copy touches them;
+//   * non-temporal stores: the staging piece is written once and read by the DMA engine — no read-for-ownership, no cache pollution.
+// WGBSSEG_UPLOAD_POPULATE=0 / WGBSSEG_UPLOAD_NT=0 switch either off (A/B).  x200 (11.3 GB) end to end on one box: 0.38-0.45 s -> 0.32 s with both and
+// 8 x 2 MB pieces; x32 0.107-0.114 -> 0.098-0.110.  The rate of ONE setting still swings between 30 and 47 GB/s from run to run on the same box.
+struct FillMode { bool populate = true, nt = true; };
 inline FillMode fill_mode()
 {
     FillMode m;
-    { const char* e = getenv("WGBSSEG_UPLOAD_POPULATE"); m.populate = e && atoi(e) != 0; }
-    { const char* e = getenv("WGBSSEG_UPLOAD_NT"); m.nt = e && atoi(e) != 0; }
+    { const char* e = getenv("WGBSSEG_UPLOAD_POPULATE"); if (e) m.populate = atoi(e) != 0; }
+    { const char* e = getenv("WGBSSEG_UPLOAD_NT"); if (e) m.nt = atoi(e) != 0; }
     return m;
 }
 inline void fill_piece(void* dst, const uint8_t* src, size_t n, const FillMode& m)
@@ -1687,9 +1689,10 @@ int upload_rows_streaming(wgbsseg_ctx* c, uint8_t* dst, int64_t dst_pitch, const
     const double t0 = wall_s();
     // (measured, free-running threads: 4 threads x 1 MB 33.5 GB/s, x 2 MB 26-29, 8-16 threads 17-30: profiles/r02_upload_sweep.txt.  Round 5, threads on the
     // device's CPUs: 8 threads x 4 MB 37-42 GB/s on 11.3 GB (x200: 0.35-0.38 s end to end against 0.43-0.50 with 4 x 1 MB); x32's 1.8 GB the same either
-    // way: profiles/r05_upload_pinned_ab.txt.  Large cohorts take the wide form.)
+    // way: profiles/r05_upload_pinned_ab.txt.  Large cohorts take the wide form.  Round 6: 8 x 2 MB with the pieces' pages mapped per call and a non-temporal
+    // fill: x200 0.32 s end to end on both runs of the A/B against 0.33-0.45 for 8 x 4 MB, profiles/r06_upload_ab.txt.)
     const bool big = row_bytes * n_rows >= (4LL << 30);
-    int64_t piece = big ? (4 << 20) : (1 << 20);
+    int64_t piece = big ? (2 << 20) : (1 << 20);
     { const char* e = getenv("WGBSSEG_UPLOAD_PIECE_KB"); if (e && atoi(e) >= 64) piece = (int64_t)atoi(e) << 10; }
     const int64_t ppr = (row_bytes + piece - 1) / piece, n_tasks = ppr * n_rows;
     int T = big ? 8 : 4;
@@ -2005,11 +2008,19 @@ int wgbsseg_group_segment_regions(wgbsseg_group* g, int32_t* borders_out, int64_
                                   char* err, size_t errlen)
 {
     if (!g || !g->planned) { set_err(err, errlen, "group_segment_regions: call wgbsseg_group_plan first"); return WGBSSEG_E_STATE; }
+    return wgbsseg_group_segment_region_range(g, 0, (int64_t)g->rs.size(), borders_out, borders_cap, borders_off, stats, err, errlen);
+}
+
+int wgbsseg_group_segment_region_range(wgbsseg_group* g, int64_t first_region, int64_t end_region, int32_t* borders_out, int64_t borders_cap, int64_t* borders_off,
+                                       int64_t* stats, char* err, size_t errlen)
+{
+    if (!g || !g->planned) { set_err(err, errlen, "group_segment_regions: call wgbsseg_group_plan first"); return WGBSSEG_E_STATE; }
+    if (first_region < 0 || end_region <= first_region || end_region > (int64_t)g->rs.size()) { set_err(err, errlen, "group_segment_region_range: regions [%lld, %lld) of %lld planned", (long long)first_region, (long long)end_region, (long long)g->rs.size()); return WGBSSEG_E_ARG; }
     const int G = (int)g->shares.size();
     for (int d = 0; d < G; d++)
         if (g->win_hi[(size_t)d] > g->win_lo[(size_t)d] && !g->loaded[(size_t)d]) { set_err(err, errlen, "share %d has no beta data yet", d); return WGBSSEG_E_STATE; }
     int64_t n_batches = 0;
-    std::vector<char> ran((size_t)G, 0);                     // the share's timings of this call: reset on its first batch, summed after
+    std::vector<char> ran((size_t)G, first_region > 0 ? 1 : 0);     // the share's timings: reset on its first batch of the FIRST slice of the regions, summed after
     std::vector<int64_t> slot_next((size_t)G, 0);            // page-locked result buffers of a share used by this call so far
     wgstitch::BatchFn run_batch = [&](const std::vector<wgstitch::Sites>& todo, wgstitch::BatchResult& res, std::string& msg) -> int {
         // route: the share that owns the first site of the range; a junction patch reaches into the next share's first chunk,
@@ -2100,9 +2111,9 @@ int wgbsseg_group_segment_regions(wgbsseg_group* g, int32_t* borders_out, int64_
         return WGBSSEG_OK;
     };
     std::string msg;
-    const int rc = wgstitch::segment_regions(g->rs.data(), g->re.data(), (int64_t)g->rs.size(), g->chunk_size, run_batch, borders_out,
+    const int rc = wgstitch::segment_regions(g->rs.data() + first_region, g->re.data() + first_region, end_region - first_region, g->chunk_size, run_batch, borders_out,
                                              borders_cap, borders_off, stats, msg, speculation_on());
-    if (g->streaming) {                                        // every byte has been consumed by now; collect the uploaders
+    if (g->streaming && (end_region == (int64_t)g->rs.size() || rc != 0)) {      // every byte has been consumed by now; collect the uploaders
         char eb[512] = {0};
         const int lrc = wgbsseg_group_load_wait(g, eb, sizeof(eb));
         if (rc == 0 && lrc != WGBSSEG_OK) { set_err(err, errlen, "%s", eb); return lrc; }

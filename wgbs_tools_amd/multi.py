@@ -46,6 +46,29 @@ class GroupEngine:
         self._run(regions, chunk_size, params, False)
         return self.group.last_csr
 
+    def segment_region_slices(self, regions, chunk_size, params, n_slices=4):
+        """Generator over slices of the regions, cut where the cumulative sites pass k / n_slices of the total: yields (first, end, flat, off)
+        — regions [first, end) as one CSR of absolute borders in a buffer of its own — as soon as the slice is segmented, while the beta bytes
+        of the later slices are still uploading (the upload streams site-major) and before the next slice is computed: the caller's BED
+        writer works on slice k during slice k + 1 (round 6; regions never interact: segment.py:84-86,129-134)."""
+        loci = self.genome.loci()
+        self.windows = self.group.plan(loci, regions, chunk_size, params['pcount'], params['max_cpg'], params['max_bp'])
+        if self._maps is None:
+            self._maps = [np.memmap(b, dtype=np.uint8, mode='r') for b in self.betas]
+        self.group.load_host(self._maps, wait=False)
+        sizes = np.array([b - a for a, b in regions], dtype=np.int64)
+        cum = np.cumsum(sizes)
+        cuts = sorted(set([0, len(regions)] + [int(np.searchsorted(cum, cum[-1] * k / n_slices, side='left')) + 1 for k in range(1, n_slices)]))
+        cuts = [c for c in cuts if 0 <= c <= len(regions)]
+        stats = []
+        for first, end in zip(cuts[:-1], cuts[1:]):
+            flat, off, st = self.group.segment_region_range(first, end, int(sizes[first:end].sum()) + (end - first))
+            stats.append(st)
+            yield first, end, flat, off
+        self.last_stats = {k: (sum(s[k] for s in stats)) for k in stats[0]} if stats else None
+        if self.last_stats:
+            self.last_stats['slices'] = len(stats)
+
     def timings(self):
         return [self.group.timings(d) for d in range(self.group.n_shares)]
 

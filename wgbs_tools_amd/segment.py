@@ -256,6 +256,12 @@ class SegmentByChunks:
                 # sorted -L files) hands it to the BED writer as it is (wgbsseg_add_loci_borders): no per-region copies, no (start, end) arrays
                 as_csr = lambda e: getattr(e, 'segment_regions_csr', None) if all(regs[i][0] >= regs[i - 1][1] for i in range(1, len(regs))) else None
                 try:
+                    if own_engine and as_csr(eng) and self._slices_pay(eng, regs):
+                        # round 6: the regions in slices, the BED rows of one slice written while the next is segmented (and while the beta
+                        # bytes of the later ones are still uploading): the 20 ms of BED text leave the run's critical path
+                        sliced = self._run_sliced(eng, regs, prof, want_stats)
+                        if sliced:
+                            return
                     res = (as_csr(eng) or eng.segment_regions)(regs, self.args.chunk_size, self.param_dict)
                 except Exception as e:
                     if not (own_engine and getattr(e, 'code', 0) == -7 and 'not resident on any single share' in str(e)):
@@ -288,7 +294,7 @@ class SegmentByChunks:
                 merged = dict(zip([f'{a}-{b}' for a, b in regs], res))
         finally:
             closer = None
-            if own_engine:
+            if own_engine and self.param_dict['engine'] is not None:      # (None: the sliced form has closed it already)
                 # releasing ~10 GB of device buffers takes as long as writing the BED: do both at once
                 closer = threading.Thread(target=self.param_dict['engine'].close)
                 closer.start()
@@ -395,6 +401,101 @@ class SegmentByChunks:
             self.param_dict['engine'] = None
             dist.barrier()
             run.close()
+
+    # Regions in slices (round 6): measured and NOT the default.  hg19 x 32 end to end 0.100-0.115 s with 2 / 4 / 8 slices against 0.105-0.112 in one
+    # piece, x 200 0.325-0.373 against 0.314-0.403 with three runs of ~1.0 s among the sliced ones (profiles/r06_e2e_slices_ab.txt): what is exposed
+    # behind the last kernel is not the 20 ms of BED text but the engine's close (7-17 GB of device buffers: 17-40 ms), which the one-piece form
+    # already runs beside the BED writer.  WGBSSEG_BED_SLICES=n switches the sliced form on.
+    SLICES = 1
+    SLICE_MIN_SITES = 4000000   # below that a run is over before a second slice could help
+
+    def _slices_pay(self, eng, regs):
+        n = int(os.environ.get('WGBSSEG_BED_SLICES', self.SLICES))
+        return (n > 1 and hasattr(eng, 'segment_region_slices') and len(regs) >= 2 and sum(b - a for a, b in regs) >= self.SLICE_MIN_SITES)
+
+    def _run_sliced(self, eng, regs, prof, want_stats):
+        """run()'s segmentation + dump_result for an engine that can take the regions in slices (multi.GroupEngine): slice k's BED rows
+        (wgbsseg_add_loci_borders, append mode) are written by a second thread while slice k + 1 is segmented.  Same rows, same summary line,
+        same errors as the one-piece form; False (nothing written) when a junction patch outgrew a share's halo — the caller then reruns on
+        one GPU as before."""
+        import queue
+        import re
+        from . import _lib
+        names, sizes = self.genome.get_chrom_cpg_sizes()
+        cum = np.cumsum(sizes)
+        loci = self.genome.loci()
+        out_path = self.args.out_path
+        to_stdout = out_path is None or out_path is sys.stdout
+        if to_stdout:
+            sys.stdout.flush()
+        todo = queue.Queue()
+        state = dict(written=0, dropped=0, error=None, slices=0)
+
+        def writer():
+            while True:
+                item = todo.get()
+                if item is None:
+                    return
+                if state['error'] is not None:
+                    continue                                     # (drain: nothing is written behind a failed slice)
+                flat, off = item
+                try:
+                    w, d = _lib.add_loci_borders(loci, names, cum, flat, off, self.args.min_cpg, None if to_stdout else out_path, append=state['slices'] > 0)
+                    state['written'] += w; state['dropped'] += d; state['slices'] += 1
+                except _lib.SegmentorError as e:
+                    msg = e.msg or ''
+                    m = re.match(r'(\[wt add_loci\] line )(\d+)(: .*)', msg, re.S)
+                    if m:                                        # the row's number counts the rows of the earlier slices too
+                        msg = m.group(1) + str(int(m.group(2)) + state['written']) + m.group(3)
+                    state['error'] = msg
+        th = threading.Thread(target=writer)
+        th.start()
+        n_blocks = 0
+        try:
+            n = int(os.environ.get('WGBSSEG_BED_SLICES', self.SLICES))
+            for first, end, flat, off in eng.segment_region_slices(regs, self.args.chunk_size, self.param_dict, n):
+                n_blocks += int(np.maximum(np.diff(off) - 1, 0).sum())
+                todo.put((flat, off))
+                if state['error'] is not None:
+                    break
+        except Exception as e:
+            todo.put(None); th.join()
+            if getattr(e, 'code', 0) == -7 and 'not resident on any single share' in str(e):
+                if not to_stdout and state['slices'] > 0:
+                    os.remove(out_path)                          # (rows of the earlier slices: the rerun writes the file afresh)
+                if to_stdout and state['slices'] > 0:
+                    raise _as_reference_error(e)                 # (rows already on stdout cannot be taken back)
+                return False
+            raise _as_reference_error(e)
+        if want_stats:                                           # (before the engine goes away)
+            self.report['engine'] = type(eng).__name__
+            self.report['stitching'] = getattr(eng, 'last_stats', None)
+            tm = eng.timings() if hasattr(eng, 'timings') else None
+            self.report['device'] = tm if isinstance(tm, list) else ([tm] if tm else None)
+        # releasing ~10 GB of device buffers takes as long as writing the last slice: do both at once
+        closer = threading.Thread(target=eng.close)
+        closer.start()
+        self.param_dict['engine'] = None
+        if prof: prof.append(('segmentation (device + stitching; BED rows of the earlier slices beside it)', time.perf_counter()))
+        todo.put(None)
+        th.join()
+        closer.join()
+        if n_blocks == 0:
+            eprint('Empty blocks array')
+        elif state['error'] is not None:
+            if '[wt add_loci] line' in state['error']:
+                # the reference says the counts BEFORE it writes (segment.py:180): a run whose writer fails on a row has still said them
+                eprint(f"[wt segment] found {n_blocks - state['dropped']:,} blocks\n             (dropped {state['dropped']:,} short blocks)")
+            raise RuntimeError(state['error'])
+        else:
+            eprint(f"[wt segment] found {state['written']:,} blocks\n             (dropped {state['dropped']:,} short blocks)")
+            self.report.update(blocks_found=int(state['written']), blocks_dropped=int(state['dropped']))
+        if prof:
+            prof.append(('blocks to BED (last slice)', time.perf_counter()))
+            if os.environ.get('WGBSSEG_PROFILE'):
+                eprint('[wt segment] phases: ' + ', '.join('%s %.3f s' % (n, t - prof[i][1]) for i, (n, t) in enumerate(prof[1:])))
+        self.write_stats(prof)
+        return True
 
     def dump_result_csr(self, flat, off):
         """dump_result (segment.py:167-190) straight from the merged border lists (CSR of absolute 1-based borders, regions ascending): the
