@@ -796,6 +796,20 @@ def main():
             traffic = tr['traffic_bytes']
             traffic_note = ('traffic (bytes per launch) = 2 x FETCH_SIZE + WRITE_SIZE from profiles/%s (rocprofv3 PMC passes of this command on this '
                             'source state; gfx950 FETCH_SIZE x2 correction)' % tr['_file'])
+        # Round 6: inside the step the scan pass no longer has the chip to itself — it starts with the batch on the lowest-priority stream, beside the
+        # windows pass, the tile plan and the first scoring tiles — so its duration THERE says how well it hides, not how fast the kernel reads.  The
+        # kernel's own rate (the roofline figure) is timed like `roofline_scan_carries`: 20 back-to-back launches on this workload's chunk grid.
+        scan_in_step = {'avg_launch_ms': main_ms, 'GB/s': scan_gbs, 'frac_of_hbm_peak': scan_gbs / HBM_PEAK_GBS,
+                        'note': 'HIP events around the launch INSIDE the timed steps, where it runs on the lowest-priority stream beside the windows pass, the tile plan and the '
+                                'first scoring tiles (round 6: scoring begins 0.3 ms into the batch instead of 0.7)'}
+        scan_alone_note = 'rank 0 / share 0, HIP events on the kernel stream inside the timed steps; '
+        if seg is not None and not multi:
+            grid_s = parallel.chunk_grid(regions, args.chunk)
+            a_ms, a_bytes = seg.scan_only(np.array([s0 - 1 for _, s0, _ in grid_s], dtype=np.int64), np.array([e0 - s0 for _, s0, e0 in grid_s], dtype=np.int32),
+                                          repeat=20, want_carry=stats_wide)[:2]
+            if abs(a_bytes - acc['scan_main_bytes']) <= 0.001 * acc['scan_main_bytes']:
+                main_ms, scan_gbs = a_ms, a_bytes / (a_ms * 1e-3) / 1e9
+                scan_alone_note = 'rank 0; HIP events around 20 back-to-back launches on the kernel\'s stream over this workload\'s chunk grid, after one warm-up launch (the launch inside the step: `in_step`); '
         # instruction mix of the scoring kernel's evaluation (tools/micro/count_cost_loop.py --json), same keying
         mixes = {k: keyed_profile('*cost_isa_mix_%s.json' % k, sha) for k in ('narrow', 'narrow128', 'wide')}
         main_mix = mixes['narrow128' if args.samples <= 16 else 'narrow']
@@ -885,10 +899,10 @@ def main():
                               'achieved': scan_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': scan_gbs / HBM_PEAK_GBS,
                               'traffic': traffic,
                               'algorithmic_bytes_per_launch': acc['scan_main_bytes'], 'avg_launch_ms': main_ms,
-                              'launches_timed': args.steps,
+                              'launches_timed': args.steps, 'in_step': scan_in_step,
                               'all_launches': {'count': acc['scan_launches'], 'bytes': acc['scan_bytes'], 'ms': acc['scan_ms'],
                                                'GB/s': scan_all_gbs},
-                              'note': 'rank 0 / share 0, HIP events on the kernel stream inside the timed steps; ' + traffic_note},
+                              'note': scan_alone_note + traffic_note},
             'roofline_scan_carries': scan_carries,
             'block_sums': block_sums,
             'device_ms_per_step': {k: acc[k] / args.steps for k in ('scan_ms', 'window_ms', 'cost_ms', 'dp_ms', 'trace_ms', 'total_ms')},
@@ -969,6 +983,7 @@ def main():
                                  'evals_per_s': ev2, 'roofline_frac': ev2 * FLOP_PER_EVAL / FP64_VALU_PEAK,
                                  'scan_GB_per_s': a2['scan_main_bytes'] / (a2['scan_main_ms'] / k * 1e-3) / 1e9,
                                  'scan_frac_of_hbm_peak': a2['scan_main_bytes'] / (a2['scan_main_ms'] / k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 'scan_timed': 'inside the step: on the lowest-priority stream beside the windows pass, the tile plan and the first scoring tiles (not the kernel alone)',
                                  'beta_GB_resident': ns * pitch2 / 1e9})
                     s2.close()
                     del s2
@@ -1006,7 +1021,8 @@ def main():
                              'scan_kernel': 'k_scan (carries)' if a2['max_window'] > 252 else 'k_validate',
                              'evals_per_s': ev2, 'roofline_frac': ev2 * FLOP_PER_EVAL / FP64_VALU_PEAK,
                              'scan_GB_per_s': a2['scan_main_bytes'] / (a2['scan_main_ms'] / k * 1e-3) / 1e9,
-                             'scan_frac_of_hbm_peak': a2['scan_main_bytes'] / (a2['scan_main_ms'] / k * 1e-3) / 1e9 / HBM_PEAK_GBS})
+                             'scan_frac_of_hbm_peak': a2['scan_main_bytes'] / (a2['scan_main_ms'] / k * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 'scan_timed': 'inside the step: on the lowest-priority stream beside the windows pass, the tile plan and the first scoring tiles (not the kernel alone)'})
                 s2.close()
                 del b2, s2
                 torch.cuda.empty_cache()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # gpurun_out/final/ (written by tools/gpu/final_a.sh on the GPU box) -> profiles/rNN_*   Usage: tools/collect_final.sh [r04]
-R=${1:-r04}
+R=${1:-r06}
 cd "$(dirname "$0")/.."
 O=gpurun_out/final
 for f in cost_traffic scan_traffic scan_traffic_carries scan_traffic_islands pmc_cost_sq; do cp $O/$f.json profiles/${R}_$f.json; done

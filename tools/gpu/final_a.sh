@@ -1,8 +1,8 @@
 #!/bin/bash
-# Final measurements on the final sources, part A (round 5; R=rNN names the files): the whole GPU suite, the bench lines, rocprofv3 kernel statistics, the PMC passes
+# Final measurements on the final sources, part A (R=rNN names the files): the whole GPU suite, the bench lines, rocprofv3 kernel statistics, the PMC passes
 # (HBM traffic of k_cost / of the scan pass without and with forced carries and with islands; SQ counters of k_cost).  Everything lands in gpurun_out/final/.
 set -u
-R=${R:-r05}
+R=${R:-r06}
 REPO=$PWD
 O=$REPO/gpurun_out/final
 mkdir -p $O

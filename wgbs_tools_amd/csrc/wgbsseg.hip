@@ -2319,7 +2319,7 @@ int wgbsseg_marker_stats(wgbsseg_ctx* c, const int32_t* tg, int32_t n_tg, const 
     HIP_TRY(hipMemcpyAsync(dtg, tg, (size_t)n_tg * 4, hipMemcpyHostToDevice, c->sA));
     HIP_TRY(hipMemcpyAsync(dbg, bg, (size_t)n_bg * 4, hipMemcpyHostToDevice, c->sA));
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
-    hipLaunchKernelGGL(k_marker_stats, dim3((unsigned)((n_blocks + WG_BLOCK - 1) / WG_BLOCK)), dim3(WG_BLOCK), 0, c->sA, c->dbg_b.as<double>(), n_blocks,
+    hipLaunchKernelGGL(k_marker_stats, dim3((unsigned)(((n_blocks + 1) / 2 + WG_BLOCK - 1) / WG_BLOCK)), dim3(WG_BLOCK), 0, c->sA, c->dbg_b.as<double>(), n_blocks,      // (two blocks per thread)
                        dtg, (int)n_tg, dbg, (int)n_bg, dout);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
