@@ -133,9 +133,11 @@ struct wgbsseg_ctx {
     std::vector<PinnedBuf> up_stage;   // two page-locked staging pieces per upload thread (set_betas_host)
     DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders[2], edges, dbg_a, dbg_b, dbg_c, lookup;
     int out_par = 0;              // which of the two result buffers the batch in flight writes: the lists of the previous batch may still be on their way home (below)
-    hipStream_t sD = nullptr;     // early delivery (segment_regions' first batch): k_copy_out writes the chunks' border lists into the page-locked result ...
+    // early delivery (segment_regions' first batch): k_copy_out (on the scan stream) writes the chunks' border lists into the page-locked result ...
+    hipEvent_t evS = nullptr;     // the scan stream's last command of the batch in flight (the copy of its verdict)
     hipEvent_t evD = nullptr;     // ... while the host already rehearses the junctions on the lists' edges and runs the follow-up batch; evD: the lists are home
     bool out_pending = false;
+    bool batch_open = false;      // a batch is between its first launch and its clean end (an error return leaves it set: the next batch drains the device first)
     std::vector<wg_d2> h_lookup;   // host copy of the k-scaled log tables of the call in flight (source of an async upload)
     float lookup_pc = -1.0f;       // what the device copy `lookup` was built for: pseudo count and exponent rows of the narrow / wide / medium class
     int lookup_rows[3] = {-1, -1, -1};
@@ -289,8 +291,8 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     }
     if (!c->sC) HIP_TRY(hipStreamCreateWithFlags(&c->sC, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->sA2, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->sD, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->evD, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->evS, hipEventDisableTiming));
     for (auto& v : c->ev) HIP_TRY(hipEventCreate(&v));
     const char* b = getenv("WGBSSEG_COST_BUDGET_MB");
     c->cost_budget_bytes = (b && atoll(b) > 0 ? atoll(b) : 6144LL) << 20;
@@ -335,8 +337,8 @@ void wgbsseg_destroy(wgbsseg_ctx* c)
     if (c->sB) (void)hipStreamDestroy(c->sB);
     if (c->sC) (void)hipStreamDestroy(c->sC);
     if (c->sA2) (void)hipStreamDestroy(c->sA2);
-    if (c->sD) (void)hipStreamDestroy(c->sD);
     if (c->evD) (void)hipEventDestroy(c->evD);
+    if (c->evS) (void)hipEventDestroy(c->evS);
     delete c;
     if (profiling()) fprintf(stderr, "[wgbsseg] destroy: %.1f ms\n", (wall_s() - t0) * 1e3);
 }
@@ -795,10 +797,19 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     }
     const wgbsseg_params* const P0 = P;
     P = &Peff;
+    static const bool host_marks = getenv("WGBSSEG_PROFILE") && atoi(getenv("WGBSSEG_PROFILE")) >= 2;
+    double hm[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // (WGBSSEG_PROFILE=2) host clock: entry, tables up, windows queued, statistics here, scoring queued, everything queued, results here, return
+    if (host_marks) hm[0] = wall_s();
     if (!(P->pseudo_count >= 0.0f)) { set_err(err, errlen, "pseudo_count must be >= 0"); return WGBSSEG_E_ARG; }
-    if (c && c->sA) HIP_TRY(hipStreamSynchronize(c->sA));      // (a call that failed half way may have left work behind that reads the staging areas ...
-    if (c && c->sC) HIP_TRY(hipStreamSynchronize(c->sC));      //  ... its scan pass ...
-    if (c && c->sA2) HIP_TRY(hipStreamSynchronize(c->sA2));    //  ... or the medium / wide tiles of a stage on the second scoring stream)
+    // A batch that failed half way may have left work behind on the scoring / scan streams that reads the staging areas: such a context is drained before it is
+    // used again.  (A clean one is NOT synchronised stream by stream here: the follow-up batch of an early delivery starts while k_copy_out still writes the first
+    // batch's lists, and a stream synchronisation — a marker of its own in a hardware queue the streams share — waited ~0.13 ms behind that kernel.)
+    if (c && c->batch_open) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipDeviceSynchronize());
+        c->out_pending = false;
+    }
+    if (c) c->batch_open = true;
     Job job;
     int rc = build_job(c, chunk_start0, chunk_len, n_chunks, job, true, err, errlen);
     if (rc != WGBSSEG_OK) return rc;
@@ -829,12 +840,17 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // instruction-bound) instead of behind it, and the scoring kernel of a job without wide tiles — which needs nothing from the scan
     // but its verdict, read at the end of the batch — no longer queues behind either.  (Rounds 1-5: windows 0.28 ms, then the scan
     // 0.32 ms, then the tile plan: scoring began 0.71 ms into the hg19 x 32 batch.)
+    if (host_marks) hm[1] = wall_s();
     HIP_TRY(hipEventRecord(c->ev[0], c->sA));
     HIP_TRY(hipEventRecord(c->ev[12], c->sA));                   // chunk table, pieces and the cleared status block are on the device
     hipStream_t const sS = c->sC;
-    static const int scan_after = getenv("WGBSSEG_SCAN_AFTER") ? atoi(getenv("WGBSSEG_SCAN_AFTER")) : 0;      // (A/B) 1: k_validate behind the windows pass (beside the tile plan and the scoring)
+    // where k_validate starts (WGBSSEG_SCAN_AFTER, A/B): 0 with the batch, beside the windows pass; 1 behind the windows pass, beside the tile plan; 2 behind the
+    // tile plan, beside the first scoring tiles only (the latency-bound kernels of the front — row offsets, stage plan, tile descriptors — keep the memory system to themselves)
+    static const int scan_after = getenv("WGBSSEG_SCAN_AFTER") ? atoi(getenv("WGBSSEG_SCAN_AFTER")) : 0;
+    bool validate_queued = false;
     HIP_TRY(hipStreamWaitEvent(sS, c->ev[12], 0));
     if (!scan_after) {
+        validate_queued = true;
         HIP_TRY(hipEventRecord(c->ev[8], sS));
         rc = launch_validate(c, job, sS, err, errlen);
         if (rc != WGBSSEG_OK) return rc;
@@ -871,7 +887,8 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     hipLaunchKernelGGL(k_window_scan, dim3((unsigned)nC), dim3(WG_BLOCK), 0, c->sA, v, c->status.as<JobStatus>(), d_wtile, c->tile_tot.as<uint32_t>(), c->tile_base.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev[1], c->sA));
-    if (scan_after) {
+    if (scan_after == 1) {
+        validate_queued = true;
         HIP_TRY(hipStreamWaitEvent(sS, c->ev[1], 0));
         HIP_TRY(hipEventRecord(c->ev[8], sS));
         rc = launch_validate(c, job, sS, err, errlen);
@@ -885,7 +902,9 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     hipLaunchKernelGGL(k_window_cum, dim3((unsigned)((nT + WG_CUM_TILES - 1) / WG_CUM_TILES)), dim3(WG_BLOCK), 0, c->sA, (const uint16_t*)v.W16, v.cum32, (const int4*)c->tile_chunk.as<int4>(),
                        (const uint32_t*)c->tile_base.as<uint32_t>(), nT);
     HIP_TRY(hipGetLastError());
+    if (host_marks) hm[2] = wall_s();
     HIP_TRY(hipEventSynchronize(c->ev[7]));                    // window statistics are here; the scan pass is still running
+    if (host_marks) hm[3] = wall_s();
     const JobStatus st = hst[0];
     if (check_div) {
         c->divs_ok = *reinterpret_cast<const unsigned int*>(&hst[1]) == 0u;
@@ -900,10 +919,26 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         if (rc != WGBSSEG_OK) return rc;
         HIP_TRY(hipEventRecord(c->ev[11], sS));
     }
-    HIP_TRY(hipEventRecord(c->ev[2], sS));
-    HIP_TRY(hipMemcpyAsync(&hst[2], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, sS));      // the scan's verdict, read at the end of the batch
+    // (k_scan checks every byte k_validate would: a job with wide tiles that has not queued k_validate yet does without it)
+    const bool validate_late = !validate_queued && !(st.wide_units && !st.loci_disorder && !st.overflow);
+    auto close_scan_stream = [&]() -> hipError_t {             // the scan's verdict, read at the end of the batch
+        hipError_t e = hipEventRecord(c->ev[2], sS);
+        if (e == hipSuccess) e = hipMemcpyAsync(&hst[2], c->status.p, sizeof(JobStatus), hipMemcpyDeviceToHost, sS);
+        if (e == hipSuccess) e = hipEventRecord(c->evS, sS);
+        return e;
+    };
+    auto queue_validate_now = [&]() -> int {
+        HIP_TRY(hipEventRecord(c->ev[8], sS));
+        const int r = launch_validate(c, job, sS, err, errlen);
+        if (r != WGBSSEG_OK) return r;
+        HIP_TRY(hipEventRecord(c->ev[9], sS));
+        return WGBSSEG_OK;
+    };
+    if (!validate_queued && !validate_late) { HIP_TRY(hipEventRecord(c->ev[8], sS)); HIP_TRY(hipEventRecord(c->ev[9], sS)); }
+    if (!validate_late) HIP_TRY(close_scan_stream());
     if (st.loci_disorder || st.overflow) {
         JobStatus st2;                                        // the scan's verdict takes precedence, as it always has
+        if (validate_late) { rc = queue_validate_now(); if (rc != WGBSSEG_OK) return rc; HIP_TRY(close_scan_stream()); }
         HIP_TRY(hipStreamSynchronize(sS));
         HIP_TRY(hipStreamSynchronize(c->sA));
         HIP_TRY(hipMemcpyAsync(&st2, c->status.p, sizeof(st2), hipMemcpyDeviceToHost, c->sA));
@@ -1154,6 +1189,13 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[3], c->sA));
+    if (validate_late) {                                        // (WGBSSEG_SCAN_AFTER=2) k_validate behind the tile plan
+        HIP_TRY(hipStreamWaitEvent(sS, c->ev[3], 0));
+        rc = queue_validate_now();
+        if (rc != WGBSSEG_OK) return rc;
+        HIP_TRY(close_scan_stream());
+    }
+    if (host_marks) hm[4] = wall_s();
     int64_t max_stage_pairs = 1;
     for (auto x : stage_pairs) max_stage_pairs = std::max(max_stage_pairs, x);
     const int nbuf = n_stages > 1 ? 2 : 1;
@@ -1288,6 +1330,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     HIP_TRY(hipMemcpyAsync(c->h_out.p, outb.p, small ? small_bytes : (size_t)(nC + 1) * 8, hipMemcpyDeviceToHost, c->sB));
     if (n_lead) HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(c->h_out.p) + out_head, c->edges.p, edge_bytes + rest_bytes, hipMemcpyDeviceToHost, c->sB));
     if (small || n_lead) HIP_TRY(hipEventRecord(c->ev[6], c->sB));
+    if (host_marks) hm[5] = wall_s();
     if (J >= (1 << 20)) {
         // a large batch: when its recurrence is done, ~0.2 ms of traceback and copies remain — just the time the host threads
         // of the junction stitching need to wake up (stitch.h)
@@ -1302,10 +1345,12 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     if (small) memcpy(borders_out, reinterpret_cast<const char*>(c->h_out.p) + out_head, (size_t)total_b * 4);
     else if (n_lead && early->dest_device_visible && (reinterpret_cast<uintptr_t>(borders_out) & 15) == 0) {
         const int64_t lead_b = borders_off[n_lead];              // the leading items' borders: [0, lead_b) of the lists
-        HIP_TRY(hipStreamWaitEvent(c->sD, c->ev[5], 0));
-        hipLaunchKernelGGL(k_copy_out, dim3(512), dim3(WG_BLOCK), 0, c->sD, (const int32_t*)d_bord, borders_out, lead_b);
+        // on the scan stream: idle by now, the lowest priority (the follow-up batch's kernels go first) and — as the one stream of its priority — a hardware
+        // queue of its own (on a stream of the scoring streams' priority k_copy_out shared a queue with them: the follow-up batch's first kernel waited for it)
+        HIP_TRY(hipStreamWaitEvent(c->sC, c->ev[5], 0));
+        hipLaunchKernelGGL(k_copy_out, dim3(512), dim3(WG_BLOCK), 0, c->sC, (const int32_t*)d_bord, borders_out, lead_b);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->evD, c->sD));
+        HIP_TRY(hipEventRecord(c->evD, c->sC));
         c->out_pending = true;
         memcpy(borders_out + lead_b, reinterpret_cast<const char*>(c->h_out.p) + out_head + edge_bytes, (size_t)(total_b - lead_b) * 4);
         early->edges = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(c->h_out.p) + out_head);
@@ -1315,8 +1360,10 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         HIP_TRY(hipEventRecord(c->ev[6], c->sB));
         HIP_TRY(hipStreamSynchronize(c->sB));
     }
-    HIP_TRY(hipStreamSynchronize(c->sA));
-    HIP_TRY(hipStreamSynchronize(sS));
+    if (host_marks) hm[6] = wall_s();
+    // (events, not stream synchronisations: the scoring stream's work precedes the recurrence's by its events, and the scan stream ends in evS — a stream
+    // synchronisation queues a marker of its own, which waited ~0.2 ms behind k_copy_out when the two streams shared a hardware queue)
+    HIP_TRY(hipEventSynchronize(c->evS));
     // the scan's verdict (segmentor.cpp:186-189).  With the scan beside the scoring kernel an invalid file is found out at the end
     // of the batch; every kernel downstream of the counts is safe on such data (LDS indices out of a table's range read zeros,
     // the traceback bounds its steps) and what it produced is dropped here.
@@ -1357,6 +1404,12 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     T.n_stages = std::max<int32_t>(T.n_stages, n_stages); T.scan_launches += 1;
     if (term_mode == 2 && c->divs_enabled && c->divs_ok && c->divs_pc == P->pseudo_count) T.div_short = 1;
     c->last_sites = J; c->last_pairs = total_pairs; c->last_stages = n_stages; c->last_valid = true;
+    c->batch_open = false;
+    if (host_marks) {
+        hm[7] = wall_s();
+        fprintf(stderr, "[wgbsseg]   host clock of the batch, us after entry: tables up %.0f | windows queued %.0f | statistics here %.0f | scoring's tiles queued %.0f | everything queued %.0f | results here %.0f | return %.0f\n",
+                (hm[1] - hm[0]) * 1e6, (hm[2] - hm[0]) * 1e6, (hm[3] - hm[0]) * 1e6, (hm[4] - hm[0]) * 1e6, (hm[5] - hm[0]) * 1e6, (hm[6] - hm[0]) * 1e6, (hm[7] - hm[0]) * 1e6);
+    }
     return WGBSSEG_OK;
 }
 }  // namespace
