@@ -932,6 +932,10 @@ def main():
             rows = []
             # the 8-GPU form of the product on this one GPU: the same genome as a share group of 8 with all shares on this device (each share's launches
             # are those of a GPU's share; the shares' host threads run them concurrently here).  Borders must equal the one-context result.
+            # (the one-GPU context goes first: what `wgbstools segment --gpus 8` has in its process is the group alone — and a context's lowest-priority scan
+            # stream, even idle, changes how the runtime spreads the group's 32 streams over its hardware queues: 34 -> 38-40 ms per step for this row)
+            seg.close()
+            seg = None
             try:
                 g8 = _lib.SegmenterGroup([local] * 8)
                 w8 = g8.plan(loci, regions, args.chunk, args.pcount, max_cpg, args.max_bp)
@@ -956,8 +960,7 @@ def main():
                 del g8
             except Exception as e:
                 rows.append({'samples': args.samples, 'shares_on_this_gpu': 8, 'failed': repr(e)})
-            seg.close()
-            seg, buf = None, None
+            buf = None
             torch.cuda.empty_cache()
             for ns in MATRIX_SAMPLES:
                 if ns == args.samples:

@@ -254,7 +254,22 @@ int wgbsseg_device_count(void)
     return n;
 }
 
+}  // extern "C"
+namespace {
+int create_ctx(int device, bool scan_low_priority, wgbsseg_ctx** out, char* err, size_t errlen);
+}
+extern "C" {
+
 int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
+{
+    return create_ctx(device, true, out, err, errlen);
+}
+
+}  // extern "C"
+namespace {
+// scan_low_priority: the scan stream below the scoring streams (right where k_validate competes with the kernels of its OWN batch only; the shares of a group that
+// double up on a device get it at the scoring streams' priority: wgbsseg_group_create)
+int create_ctx(int device, bool scan_low_priority, wgbsseg_ctx** out, char* err, size_t errlen)
 {
     if (!out) { set_err(err, errlen, "out is NULL"); return WGBSSEG_E_ARG; }
     *out = nullptr;
@@ -287,7 +302,7 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
         // slots of the kernels that are on the way to the first scoring tile (measured, hg19 x 32: scoring begins 0.36 ms into the batch
         // instead of 0.46, profiles/r06_front_ab.txt)
         const char* sp = getenv("WGBSSEG_SCAN_PRIO");          // (A/B) 0: the scan stream at the scoring stream's priority
-        if (!(sp && atoi(sp) == 0)) HIP_TRY(hipStreamCreateWithPriority(&c->sC, hipStreamNonBlocking, lo_p));
+        if (scan_low_priority && !(sp && atoi(sp) == 0)) HIP_TRY(hipStreamCreateWithPriority(&c->sC, hipStreamNonBlocking, lo_p));
     }
     if (!c->sC) HIP_TRY(hipStreamCreateWithFlags(&c->sC, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->sA2, hipStreamNonBlocking));
@@ -312,6 +327,8 @@ int wgbsseg_create(int device, wgbsseg_ctx** out, char* err, size_t errlen)
     *out = c;
     return WGBSSEG_OK;
 }
+}  // namespace
+extern "C" {
 
 void wgbsseg_destroy(wgbsseg_ctx* c)
 {
@@ -1823,25 +1840,17 @@ int wgbsseg_group_create(const int32_t* devices, int32_t n_shares, wgbsseg_group
     if (!devices || n_shares < 1 || n_shares > 1024) { set_err(err, errlen, "group_create: need 1..1024 shares"); return WGBSSEG_E_ARG; }
     std::unique_ptr<wgbsseg_group> g(new (std::nothrow) wgbsseg_group());
     if (!g) { set_err(err, errlen, "out of host memory"); return WGBSSEG_E_NOMEM; }
+    // Shares that double up on a device (dry runs of the N > 1 form on fewer GPUs): their scan streams run at the scoring streams' priority.  The lowest priority
+    // is right where k_validate competes with the kernels of its OWN batch only; beside seven other shares' scoring kernels it would wait for the end of THEIR batches
+    // (measured: a group of eight on one MI355X 34.4 -> 38.7-40.6 ms per step).
+    bool doubled = false;
+    for (int32_t a = 0; a < n_shares && !doubled; a++) for (int32_t b = a + 1; b < n_shares; b++) if (devices[a] == devices[b]) { doubled = true; break; }
     for (int32_t d = 0; d < n_shares; d++) {
         wgbsseg_ctx* c = nullptr;
-        const int rc = wgbsseg_create(devices[d], &c, err, errlen);
+        const int rc = create_ctx(devices[d], !doubled, &c, err, errlen);
         if (rc != WGBSSEG_OK) { for (auto* x : g->shares) wgbsseg_destroy(x); return rc; }
         g->shares.push_back(c);
     }
-    // Shares that double up on a device (dry runs of the N > 1 form on fewer GPUs): their scan streams run at the scoring streams' priority.  The lowest priority
-    // is right where k_validate competes with the kernels of its OWN batch only; beside seven other shares' scoring kernels it would wait for the end of THEIR batches
-    // (measured: a group of eight on one MI355X 34.4 -> 38.7 ms per step).
-    bool doubled = false;
-    for (int32_t a = 0; a < n_shares && !doubled; a++) for (int32_t b = a + 1; b < n_shares; b++) if (devices[a] == devices[b]) { doubled = true; break; }
-    if (doubled)
-        for (wgbsseg_ctx* c : g->shares) {
-            HIP_TRY(hipSetDevice(c->device));
-            hipStream_t s = nullptr;
-            HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-            (void)hipStreamDestroy(c->sC);
-            c->sC = s;
-        }
     g->loaded.assign((size_t)n_shares, 0);
     *out = g.release();
     return WGBSSEG_OK;
