@@ -382,6 +382,41 @@ def test_07_staging_does_not_change_borders(stages, golden_chunks):
         sg.close()
 
 
+@pytest.mark.parametrize('stages,slack,last_pct', [(3, 1, 100), (7, 8, 40), (8, 4096, 300), (5, 64, 200)])
+def test_07c_gated_stages_and_a_short_last_stage(stages, slack, last_pct, golden_chunks):
+    """A staged all-narrow job with its stages alternating between the two scoring streams behind k_stage_gate (WGBSSEG_STAGE_GATE = tiles of
+    slack) and with a LAST stage shorter than the others (WGBSSEG_LAST_STAGE_PCT): only the timing may change.  Cases with wider windows take
+    the ungated path under the same switches."""
+    os.environ['WGBSSEG_FORCE_STAGES'] = str(stages)
+    os.environ['WGBSSEG_STAGE_GATE'] = str(slack)
+    os.environ['WGBSSEG_LAST_STAGE_PCT'] = str(last_pct)
+    os.environ['WGBSSEG_STAGE_GATE_SHARED'] = '1'              # (other tests' contexts are alive on the device: gate all the same)
+    try:
+        sg = _lib.Segmenter(0)
+    finally:
+        for k in ('WGBSSEG_FORCE_STAGES', 'WGBSSEG_STAGE_GATE', 'WGBSSEG_LAST_STAGE_PCT', 'WGBSSEG_STAGE_GATE_SHARED'):
+            del os.environ[k]
+    try:
+        for rep in range(2):                                   # (twice: the second run finds the first one's counters and buffers)
+            for name in ['default_chunk', 'dense_w_gt_64', 'deep']:
+                g = golden_chunks[name]
+                spec = g['spec']
+                _load_case(sg, spec)
+                got = sg.segment_chunks([0], [spec['n']], spec['pcount'], spec['max_cpg'], spec['max_bp'])[0]
+                assert got.tolist() == g['borders'], '%s with %d gated stages: %s' % (name, stages, _first_diff(got, np.array(g['borders'])))
+                assert sg.timings()['n_stages'] >= 2
+            g = golden_chunks['chr21']
+            spec = g['spec']
+            _load_case(sg, spec)
+            starts = np.array(g['starts'], dtype=np.int64)
+            lens = np.minimum(spec['chunk'], spec['n'] - starts).astype(np.int32)
+            res = sg.segment_chunks(starts, lens, spec['pcount'], spec['max_cpg'], spec['max_bp'])
+            for c, (got, want) in enumerate(zip(res, g['borders'])):
+                assert got.tolist() == want, 'chr21 chunk %d, %d gated stages: %s' % (c, stages, _first_diff(got, np.array(want)))
+    finally:
+        sg.close()
+
+
 @pytest.mark.parametrize('mode,stages', [(1, 0), (2, 0), (1, 3), (2, 2), (1, 64)])
 def test_07b_wide_window_recurrence_on_every_case(mode, stages, golden_chunks):
     """The recurrence has three builds (64-step batches; 32-step batches with a second pending register and worker

@@ -737,7 +737,23 @@ struct CostArgs {
     const wg_d2* tab;  // those tables, built by the host: rows * 16 log2f entries, then rows * 64 fast-log2 entries
     int32_t xcd_group; // consecutive tiles that go to one XCD before the next XCD's group begins (see k_cost)
     int32_t cmap;      // log2 of the blocks per entry of the block -> start map of the narrow / medium tiles: 0 = a byte per block (small cohorts: LDS to spare), 3 = a byte per eight blocks + forward steps
+    uint32_t* finished; // staged jobs (or NULL): counts the tiles of this launch that are DONE — what k_stage_gate watches (a scheduling hint, no data hangs on it)
 };
+
+// Gate between the scoring launches of two consecutive stages.  A kernel packet always waits for the kernel ahead of it in its hardware queue
+// to END (hipExtAnyOrderLaunch is not honoured on gfx9: tools/micro/any_order.hip), so a stage's last tiles leave the CUs partly idle for
+// most of a tile's duration (~40 of ~60 us) before the next stage's first tile.  The stages of a staged job therefore alternate between two
+// streams, and stage s + 1 is held back by this one-wavefront kernel until all but `slack` tiles of stage s are done — about as many as the chip
+// holds at a time, so the rest is in flight and every workgroup slot that falls free from now on would stay empty: it goes to stage s + 1, while
+// stage s still ends, and releases its recurrence, as early as before (two ungated streams were measured in round 3: the stages interleave, every
+// recurrence starts late).  Nothing but timing depends on the gate (the stages write disjoint buffers), so the wait is bounded: `max_ticks` of the
+// 100 MHz clock.
+__global__ __launch_bounds__(64) void k_stage_gate(const uint32_t* __restrict__ finished, uint32_t need, long long max_ticks)
+{
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(finished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(8);
+}
 
 // Stage the exclusive prefixes P[A+x], x = x0 .. x0+cnt-1, of sample row `row` into dst[0..cnt) (one wavefront).
 // A is chunk-relative; start0+A is either the chunk start or a multiple of WG_CARRY_G (wg_group_start), so a carry of
@@ -1022,7 +1038,7 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
     const int imin = PW > 1 ? (misc[0] < misc[2] ? misc[0] : misc[2]) : misc[0];
     const int imax = PW > 1 ? (misc[1] > misc[3] ? misc[1] : misc[3]) : misc[1];
     const int Q = PW > 1 ? misc[4] + misc[5] : misc[4];
-    if (Q == 0) return;
+    if (Q == 0) { if (A.finished != nullptr && tid == 0) __hip_atomic_fetch_add(A.finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     // wide: E array = P[x] for x = eA .. imax+1 (ends use P[i+1]), S array = P[k] for k = ka .. kb-1.
     // narrow: one array L[x - ka], x = ka .. imax+1, serves both.
     const int eA = WIDE ? imin + 1 : ka;
@@ -1121,6 +1137,8 @@ __global__ __launch_bounds__(WG_BLOCK) void k_cost(JobView J, StageView SV, Cost
             else accR[qi] = acc;
         }
     }
+    // (counted here, behind the loop: the same line at the tile's entry costs every form of the kernel two VGPRs — 95 -> 97 takes the forms with sample groups from five to four workgroups per CU)
+    if (A.finished != nullptr && tid == 0) __hip_atomic_fetch_add(A.finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -131,7 +131,7 @@ struct wgbsseg_ctx {
     DevBuf plan_cbase, plan_cum0, plan_tbase, plan_pairs, plan_tiles, plan_cnt, tilesA, tilesB, tilesM, umax16;
     std::vector<PinnedBuf> pinned;
     std::vector<PinnedBuf> up_stage;   // two page-locked staging pieces per upload thread (set_betas_host)
-    DevBuf cost[2], dpstate, tmp_borders, nb, boff, out_borders[2], edges, dbg_a, dbg_b, dbg_c, lookup;
+    DevBuf cost[3], stage_ctr, dpstate, tmp_borders, nb, boff, out_borders[2], edges, dbg_a, dbg_b, dbg_c, lookup;
     int out_par = 0;              // which of the two result buffers the batch in flight writes: the lists of the previous batch may still be on their way home (below)
     // early delivery (segment_regions' first batch): k_copy_out (on the scan stream) writes the chunks' border lists into the page-locked result ...
     hipEvent_t evS = nullptr;     // the scan stream's last command of the batch in flight (the copy of its verdict)
@@ -155,6 +155,11 @@ struct wgbsseg_ctx {
     bool last_valid = false;
     long long cost_budget_bytes = 0;
     int force_stages = 0;
+    bool counted_live = false;
+    bool stage_gate_shared = false;                           // (tests) gate even when other contexts live on the device
+    int stage_gate = 768;                                     // > 0: the stages of a staged all-narrow job alternate between the two scoring streams behind k_stage_gate; the value = tiles of slack
+    double stage_min_evals_per_step = 21000.0;                // staging for few chunks only from this many evaluations per step of the longest chunk
+    int last_stage_pct = -1;                                  // length of a staged job's LAST stage (whose recurrence nothing hides) in percent of the other stages'
     int force_dp_mode = 0;   // WGBSSEG_DP_MODE: 1 = 32-step batches (wide-window path), 2 = the same with 15 worker waves
     int force_ns = 0;
     int force_ti = 0;
@@ -257,6 +262,7 @@ int wgbsseg_device_count(void)
 }  // extern "C"
 namespace {
 int create_ctx(int device, bool scan_low_priority, wgbsseg_ctx** out, char* err, size_t errlen);
+std::atomic<int> g_live_ctx[64];      // contexts alive per device (gated stages want theirs alone on its device)
 }
 extern "C" {
 
@@ -313,6 +319,10 @@ int create_ctx(int device, bool scan_low_priority, wgbsseg_ctx** out, char* err,
     c->cost_budget_bytes = (b && atoll(b) > 0 ? atoll(b) : 6144LL) << 20;
     const char* fs = getenv("WGBSSEG_FORCE_STAGES");
     c->force_stages = fs ? atoi(fs) : 0;
+    { const char* e = getenv("WGBSSEG_STAGE_GATE"); if (e) c->stage_gate = std::max(0, atoi(e)); }
+    { const char* e = getenv("WGBSSEG_STAGE_GATE_SHARED"); c->stage_gate_shared = e && atoi(e) != 0; }
+    { const char* e = getenv("WGBSSEG_STAGE_MIN_EVALS"); if (e) c->stage_min_evals_per_step = atof(e); }
+    { const char* e = getenv("WGBSSEG_LAST_STAGE_PCT"); if (e) c->last_stage_pct = std::min(800, std::max(5, atoi(e))); }      // (A/B, tests; default: chosen per job)
     { const char* e = getenv("WGBSSEG_DP_MODE"); c->force_dp_mode = e ? std::min(2, std::max(0, atoi(e))) : 0; }
     const char* fn = getenv("WGBSSEG_NS");
     c->force_ns = fn ? atoi(fn) : 0;
@@ -324,6 +334,8 @@ int create_ctx(int device, bool scan_low_priority, wgbsseg_ctx** out, char* err,
     if (dv) c->divs_enabled = atoi(dv) != 0;
     const char* sp = getenv("WGBSSEG_SCAN_PIECE_SITES");
     if (sp && atoi(sp) >= 1024) c->scan_piece_sites = (int64_t)(atoi(sp) & ~1023);
+    g_live_ctx[device & 63].fetch_add(1, std::memory_order_relaxed);
+    c->counted_live = true;
     *out = c;
     return WGBSSEG_OK;
 }
@@ -333,12 +345,13 @@ extern "C" {
 void wgbsseg_destroy(wgbsseg_ctx* c)
 {
     if (!c) return;
+    if (c->counted_live) g_live_ctx[c->device & 63].fetch_sub(1, std::memory_order_relaxed);
     const double t0 = wall_s();
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->betas_own, &c->loci_own, &c->chunks, &c->wtile, &c->carry, &c->W16, &c->cum32, &c->back16, &c->chunk_pairs, &c->tile_tot, &c->tile_base, &c->tile_chunk,
                      &c->status, &c->plan_cbase, &c->plan_cum0, &c->plan_tbase, &c->plan_pairs, &c->plan_tiles, &c->plan_cnt, &c->tilesA, &c->tilesB, &c->tilesM, &c->umax16,
-                     &c->cost[0], &c->cost[1], &c->dpstate, &c->tmp_borders, &c->nb, &c->boff, &c->out_borders[0], &c->out_borders[1], &c->edges,
+                     &c->cost[0], &c->cost[1], &c->cost[2], &c->stage_ctr, &c->dpstate, &c->tmp_borders, &c->nb, &c->boff, &c->out_borders[0], &c->out_borders[1], &c->edges,
                      &c->dbg_a, &c->dbg_b, &c->dbg_c, &c->lookup, &c->scan_pieces, &c->divcheck, &c->plan_sb, &c->bs_desc};
     for (auto* b : all) b->release();
     for (auto& pb : c->pinned) pb.release();
@@ -1109,19 +1122,38 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         // (the junction patches that ride along in the batch are a few hundred sites each: they do not count)
         int n_long = 0;
         for (const ChunkDesc& d : job.h) n_long += d.len >= 8192;
-        if (job.max_len >= 8192) n_stages = std::max(n_stages, n_long <= 160 ? 8 : 1);
+        // ... unless the recurrence is the longer of the two anyway (a share of a SMALL cohort): beside the scoring kernel a step of the recurrence
+        // takes ~50 ns against ~21 alone, so staging pays only when the scoring lasts longer than the ~30 ns per step it costs: at 7e11
+        // evaluations/s, from ~21,000 evaluations per step of the longest chunk on (round 6, one GPU's share of 8, 71 chunks: x 8 3.69 ms in eight
+        // stages, 2.63 in one; x 32 4.09 against 5.08; profiles/r06_stage_gate_ab.txt)
+        const bool worth = (double)total_pairs * c->n_samples >= (double)job.max_len * c->stage_min_evals_per_step;
+        if (job.max_len >= 8192) n_stages = std::max(n_stages, n_long <= 160 && worth ? 8 : 1);
         // Many chunks, all windows <= 64: one stage scores and k_dp<7,64> follows alone (1.7 ms exposed).  (Two uneven stages — the
         // recurrence of the first part of every chunk beside the scoring of the rest — were measured in round 2: 27.1-27.3 ms against 27.0
         // whatever the split, profiles/r02_tail_split_sweep.txt: the scoring kernel loses what the recurrence no longer shows.)
         if (c->force_stages > 0) n_stages = c->force_stages;
         n_stages = std::min<int>(n_stages, std::max(1, (job.max_len + 63) / 64));
     }
+    // Gated stages (k_stage_gate): a staged job whose tiles are all narrow — every stage is ONE launch
+    const bool all_narrow = Wmax <= WG_NARROW_WMAX;
+    // (one context per device: the streams of several contexts share hardware queues, where a gate could sit ahead of the very launch another context's gate waits for —
+    // the waits are bounded, but nothing would be gained)
+    const bool gated = c->stage_gate > 0 && n_stages > 1 && all_narrow && (c->stage_gate_shared || g_live_ctx[c->device & 63].load(std::memory_order_relaxed) == 1);
     std::vector<int32_t>& sb = c->h_stage_bounds;              // (lives in the context: source of an async upload)
     {
-        const int S = (int)round_up((job.max_len + n_stages - 1) / n_stages, 64);
-        n_stages = (job.max_len + S - 1) / S;
+        // equal stages but the last (gated jobs only): its recurrence is the only one that runs with the chip to itself, at twice the pace of the others.
+        // Which length: the recurrences of the other stages take ~50 ns per step beside the scoring, so while the scoring of a stage lasts no longer than 1.5 x its
+        // recurrence (at 7e11 evaluations/s: up to ~52,000 evaluations per step of the longest chunk) the chain of recurrences is what the step waits for, and a last
+        // stage three times the others' shortens it (a share of 8, x 32: 4.08 -> 3.79 ms with the gate; equal stages + gate alone: 4.2); a scoring-bound job keeps equal
+        // stages (x 200: 20.4 -> 18.35 ms with the gate, 18.7 with a last stage twice the others').  profiles/r06_stage_gate_ab.txt
+        const double evals_per_step = (double)total_pairs * c->n_samples / std::max<double>(1.0, (double)job.max_len);
+        const int pct = !gated ? 100 : (c->last_stage_pct > 0 ? c->last_stage_pct : (evals_per_step <= 52500.0 ? 300 : 100));
+        const double parts = n_stages > 1 ? (double)(n_stages - 1) + pct / 100.0 : 1.0;
+        const int S = (int)round_up((int64_t)std::ceil((double)job.max_len / parts), 64);
+        n_stages = std::min<int>(n_stages, (job.max_len + S - 1) / S);
         sb.resize((size_t)n_stages + 1);
-        for (int q = 0; q <= n_stages; q++) sb[(size_t)q] = (int32_t)std::min<int64_t>((int64_t)q * S, job.max_len);
+        for (int q = 0; q < n_stages; q++) sb[(size_t)q] = (int32_t)std::min<int64_t>((int64_t)q * S, job.max_len);
+        sb[(size_t)n_stages] = (int32_t)job.max_len;
     }
     HIP_TRY(c->plan_sb.ensure(sb.size() * 4));
     {
@@ -1147,7 +1179,6 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // tile, so the host knows the tile counts without asking the device (round 6: one host round trip less in front of the scoring of every
     // batch); the scored blocks per stage — what sizes the cost buffer — from the windows' statistics: all of them in one stage, at most
     // (sites of the stage) x (widest window) otherwise.
-    const bool all_narrow = Wmax <= WG_NARROW_WMAX;
     bool check_div_m = false;
     if (all_narrow) {
         for (int stg = 0; stg < n_stages; stg++) {
@@ -1205,7 +1236,12 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
                            c->tilesM.as<TileDesc>() + tileM0[(size_t)stg]);
         HIP_TRY(hipGetLastError());
     }
+    if (gated) {
+        HIP_TRY(c->stage_ctr.ensure((size_t)n_stages * 4));
+        HIP_TRY(hipMemsetAsync(c->stage_ctr.p, 0, (size_t)n_stages * 4, c->sA));
+    }
     HIP_TRY(hipEventRecord(c->ev[3], c->sA));
+    if (gated) HIP_TRY(hipStreamWaitEvent(c->sA2, c->ev[3], 0));
     if (validate_late) {                                        // (WGBSSEG_SCAN_AFTER=2) k_validate behind the tile plan
         HIP_TRY(hipStreamWaitEvent(sS, c->ev[3], 0));
         rc = queue_validate_now();
@@ -1215,7 +1251,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     if (host_marks) hm[4] = wall_s();
     int64_t max_stage_pairs = 1;
     for (auto x : stage_pairs) max_stage_pairs = std::max(max_stage_pairs, x);
-    const int nbuf = n_stages > 1 ? 2 : 1;
+    const int nbuf = n_stages > 1 ? (gated && n_stages > 2 ? 3 : 2) : 1;      // (gated: a stage's scoring must not wait for the recurrence two stages back when its gate opens)
     for (int b = 0; b < nbuf; b++) HIP_TRY(c->cost[b].ensure((size_t)max_stage_pairs * 8));
     // k_dp: 64-step batches when no window of the job exceeds 64 sites; otherwise 32-step batches with a second pending
     // register per lane and, for blocks longer than 128 sites, a ring of pending maxima per chunk in global memory
@@ -1257,13 +1293,22 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     // (8 stages) scored in 3.40 instead of 3.49 ms but its recurrences, which run beside the next stage's scoring, fell behind
     // (step 4.56 -> 4.79 ms); x200 / x512 gained 0.1-0.5 %.
     const bool two_cost_streams = true;
-    hipStream_t const sP = c->sA;
     for (int stg = 0; stg < n_stages; stg++) {
+        hipStream_t const sP = gated && (stg & 1) ? c->sA2 : c->sA;
         sv.stage = stg;
         double* cbuf = c->cost[stg % nbuf].as<double>();
         const bool side = two_cost_streams && stage_tiles[3 * (size_t)stg] > 0 && (stage_tiles[3 * (size_t)stg + 1] > 0 || stage_tiles[3 * (size_t)stg + 2] > 0);
         hipStream_t const sSide = side ? c->sA2 : sP;
         if (stg >= nbuf) HIP_TRY(hipStreamWaitEvent(sP, c->ev_dp1[stg - nbuf], 0));   // buffer free again
+        if (gated) {
+            if (stg > 0 && stage_tiles[3 * (size_t)stg - 3] > 0) {
+                const int64_t before = stage_tiles[3 * (size_t)stg - 3];
+                hipLaunchKernelGGL(k_stage_gate, dim3(1), dim3(64), 0, sP, (const uint32_t*)(c->stage_ctr.as<uint32_t>() + (stg - 1)),
+                                   (uint32_t)std::max<int64_t>(1, before - c->stage_gate), 200000000LL);
+                HIP_TRY(hipGetLastError());
+            }
+            caA.finished = c->stage_ctr.as<uint32_t>() + stg;
+        }
         HIP_TRY(hipEventRecord(c->ev_cost0[stg], sP));
         if (side) { HIP_TRY(hipEventRecord(c->ev_fork[stg], sP)); HIP_TRY(hipStreamWaitEvent(sSide, c->ev_fork[stg], 0)); }
         if (stage_tiles[3 * (size_t)stg] > 0) {
@@ -1390,6 +1435,11 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     static const bool timeline = getenv("WGBSSEG_PROFILE") && atoi(getenv("WGBSSEG_PROFILE")) >= 2;
     if (timeline) {       // device time line of the batch, ms after its first event (scoring / recurrence: first and last stage)
         auto at = [&](hipEvent_t e) { float x = 0; (void)hipEventElapsedTime(&x, c->ev[0], e); return (double)x; };
+        if (n_stages > 1) {
+            fprintf(stderr, "[wgbsseg] %d stages%s, bounds", n_stages, gated ? " (gated: alternating scoring streams)" : "");
+            for (int q = 0; q <= n_stages; q++) fprintf(stderr, " %d", (int)sb[(size_t)q]);
+            fprintf(stderr, "\n");
+        }
         fprintf(stderr, "[wgbsseg] batch of %d chunks, %lld sites: windows done %.3f | stats copied %.3f | scan pass (its own stream) %.3f .. %.3f | plan + tiles done %.3f | "
                 "scoring %.3f .. %.3f | recurrence %.3f .. %.3f | trace %.3f .. %.3f | borders on the host %.3f\n", nC, (long long)J,
                 at(c->ev[1]), at(c->ev[7]), at(c->ev[8]), at(c->ev[2]), at(c->ev[3]), at(c->ev_cost0[0]), at(c->ev_cost1[n_stages - 1]),
