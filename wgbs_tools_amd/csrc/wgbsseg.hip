@@ -156,7 +156,8 @@ struct wgbsseg_ctx {
     long long cost_budget_bytes = 0;
     int force_stages = 0;
     bool counted_live = false;
-    bool stage_gate_shared = false;                           // (tests) gate even when other contexts live on the device
+    double stage_gate_wide_evals = 100000.0;                  // jobs with medium / wide tiles are gated from this many evaluations per step on
+    bool stage_gate_shared = false;                           // (tests) gate even when other contexts live on the device, and whatever the job's tiles
     int stage_gate = 768;                                     // > 0: the stages of a staged all-narrow job alternate between the two scoring streams behind k_stage_gate; the value = tiles of slack
     double stage_min_evals_per_step = 21000.0;                // staging for few chunks only from this many evaluations per step of the longest chunk
     int last_stage_pct = -1;                                  // length of a staged job's LAST stage (whose recurrence nothing hides) in percent of the other stages'
@@ -321,6 +322,7 @@ int create_ctx(int device, bool scan_low_priority, wgbsseg_ctx** out, char* err,
     c->force_stages = fs ? atoi(fs) : 0;
     { const char* e = getenv("WGBSSEG_STAGE_GATE"); if (e) c->stage_gate = std::max(0, atoi(e)); }
     { const char* e = getenv("WGBSSEG_STAGE_GATE_SHARED"); c->stage_gate_shared = e && atoi(e) != 0; }
+    { const char* e = getenv("WGBSSEG_STAGE_GATE_WIDE_EVALS"); if (e) c->stage_gate_wide_evals = atof(e); }
     { const char* e = getenv("WGBSSEG_STAGE_MIN_EVALS"); if (e) c->stage_min_evals_per_step = atof(e); }
     { const char* e = getenv("WGBSSEG_LAST_STAGE_PCT"); if (e) c->last_stage_pct = std::min(800, std::max(5, atoi(e))); }      // (A/B, tests; default: chosen per job)
     { const char* e = getenv("WGBSSEG_DP_MODE"); c->force_dp_mode = e ? std::min(2, std::max(0, atoi(e))) : 0; }
@@ -1134,11 +1136,17 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         if (c->force_stages > 0) n_stages = c->force_stages;
         n_stages = std::min<int>(n_stages, std::max(1, (job.max_len + 63) / 64));
     }
-    // Gated stages (k_stage_gate): a staged job whose tiles are all narrow — every stage is ONE launch
+    // Gated stages (k_stage_gate): the two scoring streams swap roles from stage to stage — the narrow tiles of an even stage on A with its medium / wide tiles
+    // beside them on A2, an odd stage the other way round (a second PAIR of streams was measured: six streams of one priority share hardware queues, every
+    // share lost 10-15 %)
     const bool all_narrow = Wmax <= WG_NARROW_WMAX;
     // (one context per device: the streams of several contexts share hardware queues, where a gate could sit ahead of the very launch another context's gate waits for —
     // the waits are bounded, but nothing would be gained)
-    const bool gated = c->stage_gate > 0 && n_stages > 1 && all_narrow && (c->stage_gate_shared || g_live_ctx[c->device & 63].load(std::memory_order_relaxed) == 1);
+    // A job with medium / wide tiles (its recurrences are the 32-step kernels with the full LDS footprint, which lived on the drains: a share of 8, x 32 with islands,
+    // 5.95 -> 6.4 ms under the gate) is gated only when it is clearly scoring-bound (x 100 with islands: 14.0 -> 13.3 ms): from 100,000 evaluations per step on.
+    const double evals_per_step = (double)total_pairs * c->n_samples / std::max<double>(1.0, (double)job.max_len);
+    const bool gated = c->stage_gate > 0 && n_stages > 1 && (all_narrow || evals_per_step >= c->stage_gate_wide_evals || c->stage_gate_shared) &&
+                       (c->stage_gate_shared || g_live_ctx[c->device & 63].load(std::memory_order_relaxed) == 1);
     std::vector<int32_t>& sb = c->h_stage_bounds;              // (lives in the context: source of an async upload)
     {
         // equal stages but the last (gated jobs only): its recurrence is the only one that runs with the chip to itself, at twice the pace of the others.
@@ -1146,7 +1154,6 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         // recurrence (at 7e11 evaluations/s: up to ~52,000 evaluations per step of the longest chunk) the chain of recurrences is what the step waits for, and a last
         // stage three times the others' shortens it (a share of 8, x 32: 4.08 -> 3.79 ms with the gate; equal stages + gate alone: 4.2); a scoring-bound job keeps equal
         // stages (x 200: 20.4 -> 18.35 ms with the gate, 18.7 with a last stage twice the others').  profiles/r06_stage_gate_ab.txt
-        const double evals_per_step = (double)total_pairs * c->n_samples / std::max<double>(1.0, (double)job.max_len);
         const int pct = !gated ? 100 : (c->last_stage_pct > 0 ? c->last_stage_pct : (evals_per_step <= 52500.0 ? 300 : 100));
         const double parts = n_stages > 1 ? (double)(n_stages - 1) + pct / 100.0 : 1.0;
         const int S = (int)round_up((int64_t)std::ceil((double)job.max_len / parts), 64);
@@ -1285,6 +1292,7 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
     c->last_dp_chunks = nC; c->last_dp_stride = state_stride;
     const size_t lds_dp = 2 * 4096 * 8 + 128 * 8 + 64 * 12 + 16 + 1024 * 6;
     if (st.wide_units) HIP_TRY(hipStreamWaitEvent(c->sA, c->ev[2], 0));      // wide tiles read the carries: scoring after the scan
+    if (st.wide_units && gated) HIP_TRY(hipStreamWaitEvent(c->sA2, c->ev[2], 0));
     // Two scoring streams.  A scoring launch ends in a tail of partly filled workgroup slots (1280 on the chip), and a stage
     // with more than one tile class pays one per class: there the medium and wide tiles go to a second stream, beside the
     // narrow ones (they write disjoint rows of the cost buffer), forked off the first stream when the stage may begin
@@ -1298,16 +1306,16 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         sv.stage = stg;
         double* cbuf = c->cost[stg % nbuf].as<double>();
         const bool side = two_cost_streams && stage_tiles[3 * (size_t)stg] > 0 && (stage_tiles[3 * (size_t)stg + 1] > 0 || stage_tiles[3 * (size_t)stg + 2] > 0);
-        hipStream_t const sSide = side ? c->sA2 : sP;
+        hipStream_t const sSide = side ? (gated && (stg & 1) ? c->sA : c->sA2) : sP;
         if (stg >= nbuf) HIP_TRY(hipStreamWaitEvent(sP, c->ev_dp1[stg - nbuf], 0));   // buffer free again
         if (gated) {
-            if (stg > 0 && stage_tiles[3 * (size_t)stg - 3] > 0) {
-                const int64_t before = stage_tiles[3 * (size_t)stg - 3];
+            const int64_t before = stg > 0 ? stage_tiles[3 * (size_t)stg - 3] + stage_tiles[3 * (size_t)stg - 2] + stage_tiles[3 * (size_t)stg - 1] : 0;      // tiles of every class
+            if (before > 0) {
                 hipLaunchKernelGGL(k_stage_gate, dim3(1), dim3(64), 0, sP, (const uint32_t*)(c->stage_ctr.as<uint32_t>() + (stg - 1)),
                                    (uint32_t)std::max<int64_t>(1, before - c->stage_gate), 200000000LL);
                 HIP_TRY(hipGetLastError());
             }
-            caA.finished = c->stage_ctr.as<uint32_t>() + stg;
+            caA.finished = caB.finished = caM.finished = c->stage_ctr.as<uint32_t>() + stg;
         }
         HIP_TRY(hipEventRecord(c->ev_cost0[stg], sP));
         if (side) { HIP_TRY(hipEventRecord(c->ev_fork[stg], sP)); HIP_TRY(hipStreamWaitEvent(sSide, c->ev_fork[stg], 0)); }
