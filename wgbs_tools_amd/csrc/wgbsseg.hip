@@ -1311,8 +1311,13 @@ int segment_chunks_impl(wgbsseg_ctx* c, const int64_t* chunk_start0, const int32
         if (gated) {
             const int64_t before = stg > 0 ? stage_tiles[3 * (size_t)stg - 3] + stage_tiles[3 * (size_t)stg - 2] + stage_tiles[3 * (size_t)stg - 1] : 0;      // tiles of every class
             if (before > 0) {
+                // the wait's bound: ten times what the stage before should take at 5e11 evaluations/s (its scored blocks are an upper bound for an all-narrow job), between
+                // 5 ms and 2 s — a gate that opens early lets two stages interleave (the recurrence of the first starts late); one that waits for a launch which some other
+                // context's work holds up (a context created on this device while the batch is in flight) gives up after a time in proportion to the job
+                const double est_s = 10.0 * (double)stage_pairs[(size_t)stg - 1] * c->n_samples / 5e11;
+                const long long max_ticks = (long long)(1e8 * std::min(2.0, std::max(0.005, est_s)));
                 hipLaunchKernelGGL(k_stage_gate, dim3(1), dim3(64), 0, sP, (const uint32_t*)(c->stage_ctr.as<uint32_t>() + (stg - 1)),
-                                   (uint32_t)std::max<int64_t>(1, before - c->stage_gate), 200000000LL);
+                                   (uint32_t)std::max<int64_t>(1, before - c->stage_gate), max_ticks);
                 HIP_TRY(hipGetLastError());
             }
             caA.finished = caB.finished = caM.finished = c->stage_ctr.as<uint32_t>() + stg;
